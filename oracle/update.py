@@ -1,0 +1,344 @@
+"""CPU oracle (PyTorch-CPU, fp32) for the SAC/TQC update.  TEST INFRASTRUCTURE ONLY.
+
+A functional restatement of the reference's trainer step written from its text; weights
+live in a flat ``dict`` keyed by the reference's ``state_dict`` names so golden vectors can
+be loaded directly.  Citations are path:line under /root/reference.
+
+    train_step            franQ/Agent/deepQlearning.py:105-127
+    losses                franQ/Agent/deepQlearning.py:198-258
+    encoder               franQ/Agent/components/encoder.py:52-67
+    skip_head_mlp         franQ/Agent/models/mlp.py:64-94          (quirk q8: always LeakyReLU(0.01))
+    gaussian_policy       franQ/Agent/models/gaussian_mlp.py:15-39 (quirk q9: eps 1e-4)
+    gumbel_policy         franQ/Agent/models/gumbel_mlp.py:7-54 + torch RelaxedOneHotCategorical
+    tqc target / loss     franQ/Agent/components/distributional_soft_actor_critic.py:40-103
+    sac target / loss     franQ/Agent/components/soft_actor_critic.py:63-134
+    actor / alpha loss    franQ/Agent/components/soft_actor_critic.py:136-154
+    polyak                franQ/Agent/utils/common.py:10-19
+    adam                  torch.optim.Adam defaults (deepQlearning.py:100-103), restated explicitly
+
+Backward uses torch autograd on this restated forward (it is the independent check of the
+hand-derived backward in the HIP kernels); Adam and polyak are written out.
+"""
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+@dataclass
+class Spec:
+    obs: int
+    act: int                      # action dim, or number of actions when discrete
+    goal: int = 0
+    discrete: bool = False
+    C: int = 2                    # num_critics            (conf.py:66)
+    Q: int = 10                   # num_q_predictions      (conf.py:67)
+    latent: int = 256             # latent_state_dim       (conf.py:68)
+    enc_features: int = 256       # EncoderConf.hidden_features (conf.py:81)
+    enc_hidden: Tuple[int, ...] = (256,)
+    joint_hidden: Tuple[int, ...] = (256,)
+    pi_hidden: Tuple[int, ...] = (256,)
+    critic_hidden: Tuple[int, ...] = (256, 256)
+    distributional: bool = True
+    lowerbound: bool = True       # use_nStep_lowerbounds
+    max_entropy: bool = True      # use_max_entropy_q
+    hard_updates: bool = False
+    gamma: float = 0.99
+    tau: float = 5e-2
+    lr: float = 3e-4
+    init_log_alpha: float = -2
+    drop: float = 0.2             # top_quantiles_to_drop
+    T: int = 50
+    B: int = 256
+
+    @property
+    def enc_in(self):             # encoder.py:26-32
+        return self.obs + 2 * self.goal
+
+    @property
+    def act_feat(self):           # width of the action block fed to the critic
+        return self.act
+
+    @property
+    def pi_out(self):             # gaussian_mlp.py:10 (2A) / gumbel_mlp.py:10 (n)
+        return self.act if self.discrete else 2 * self.act
+
+    @property
+    def Nq(self):
+        return self.C * self.Q
+
+    @property
+    def n_drop(self):
+        return int(self.drop * self.Nq)
+
+    @property
+    def target_entropy(self):     # soft_actor_critic.py:42
+        return -float(self.act)
+
+
+# ---------------------------------------------------------------------------------------
+# parameter naming (reference state_dict layout)
+# ---------------------------------------------------------------------------------------
+def mlp_shapes(prefix, din, hidden, dout):
+    """SkipHeadMLP parameter shapes: mlp.py:76-86."""
+    shapes = []
+    prev = din
+    for i, h in enumerate(hidden):
+        shapes.append((f"{prefix}.feature_extractor.{i}.0.weight", (h, prev)))
+        shapes.append((f"{prefix}.feature_extractor.{i}.0.bias", (h,)))
+        prev = h
+    shapes.append((f"{prefix}.head.weight", (dout, din + sum(hidden))))
+    shapes.append((f"{prefix}.head.bias", (dout,)))
+    return shapes
+
+
+def net_shapes(spec: Spec, which: str):
+    if which == "encoder.obs":
+        return mlp_shapes("encoder.visible_layer_encoders.obs_1d", spec.enc_in, spec.enc_hidden, spec.enc_features)
+    if which == "encoder.joiner":
+        return mlp_shapes("encoder.joiner", spec.enc_features, spec.joint_hidden, spec.latent)
+    if which in ("actor", "actor_target"):
+        return mlp_shapes(f"actor_critic.{which}", spec.latent, spec.pi_hidden, spec.pi_out)
+    if which in ("critic", "critic_target", "critic_frozen"):
+        out = []
+        for k in range(spec.C):
+            out += mlp_shapes(f"actor_critic.{which}.nets.{k}", spec.latent + spec.act_feat, spec.critic_hidden, spec.Q)
+        return out
+    raise KeyError(which)
+
+
+def trainable_names(spec: Spec) -> List[str]:
+    """fast_params: encoder + actor + critic + log_alpha (deepQlearning.py:47-62,
+    soft_actor_critic.py:44-52)."""
+    names = [n for n, _ in net_shapes(spec, "encoder.obs") + net_shapes(spec, "encoder.joiner")]
+    names += [n for n, _ in net_shapes(spec, "actor")]
+    names += [n for n, _ in net_shapes(spec, "critic")]
+    names.append("actor_critic.log_alpha")
+    return names
+
+
+def all_shapes(spec: Spec):
+    s = net_shapes(spec, "encoder.obs") + net_shapes(spec, "encoder.joiner")
+    s += [("actor_critic.log_alpha", ())]
+    for w in ("critic", "critic_target", "critic_frozen", "actor", "actor_target"):
+        s += net_shapes(spec, w)
+    return s
+
+
+def init_params(spec: Spec, seed=0) -> Dict[str, Tensor]:
+    """xavier_uniform(gain 1) weights, zero biases (mlp.py:5-8,86); targets = hard copies
+    (soft_actor_critic.py:34,38); critic_frozen has its own init (never copied until the
+    first actor_loss).  Not RNG-compatible with the reference (module construction order
+    differs); parity runs load the golden ``init`` instead."""
+    g = torch.Generator().manual_seed(seed)
+    p = {}
+    for name, shape in all_shapes(spec):
+        if name.endswith("weight"):
+            fan_out, fan_in = shape
+            a = math.sqrt(6.0 / (fan_in + fan_out))
+            p[name] = (torch.rand(shape, generator=g, dtype=torch.float32) * 2 - 1) * a
+        elif name.endswith("bias"):
+            p[name] = torch.zeros(shape, dtype=torch.float32)
+        else:
+            p[name] = torch.tensor(float(spec.init_log_alpha), dtype=torch.float32)
+    for src, dst in (("critic", "critic_target"), ("actor", "actor_target")):
+        for n, _ in net_shapes(spec, src):
+            p[n.replace(f".{src}.", f".{dst}.")] = p[n].clone()
+    return p
+
+
+# ---------------------------------------------------------------------------------------
+# networks
+# ---------------------------------------------------------------------------------------
+def skip_head_mlp(p, prefix, x, n_hidden):
+    """mlp.py:88-94: h_i = LeakyReLU_0.01(W_i h_{i-1} + b_i); out = W_head cat(x, h_1..h_n) + b."""
+    feats = [x]
+    h = x
+    for i in range(n_hidden):
+        h = F.leaky_relu(F.linear(h, p[f"{prefix}.feature_extractor.{i}.0.weight"],
+                                  p[f"{prefix}.feature_extractor.{i}.0.bias"]), 0.01)
+        feats.append(h)
+    return F.linear(torch.cat(feats, dim=-1), p[f"{prefix}.head.weight"], p[f"{prefix}.head.bias"])
+
+
+def encoder(p, spec: Spec, xp):
+    """encoder.py:52-67 (feed-forward joiner)."""
+    x = xp["obs_1d"]
+    if spec.goal:
+        x = torch.cat((x, xp["achieved_goal"], xp["desired_goal"]), dim=-1)
+    e = skip_head_mlp(p, "encoder.visible_layer_encoders.obs_1d", x, len(spec.enc_hidden))
+    return skip_head_mlp(p, "encoder.joiner", e, len(spec.joint_hidden))
+
+
+def ensemble(p, spec: Spec, which, x):
+    """mlp.py:105-108: concat of the C critics' outputs on the last dim."""
+    return torch.cat([skip_head_mlp(p, f"actor_critic.{which}.nets.{k}", x, len(spec.critic_hidden))
+                      for k in range(spec.C)], dim=-1)
+
+
+LOG_SQRT_2PI = math.log(math.sqrt(2 * math.pi))
+
+
+def gaussian_policy(p, spec: Spec, which, s, eps):
+    """gaussian_mlp.py:15-39 with the N(0,1) draw ``eps`` supplied by the caller."""
+    logits = skip_head_mlp(p, f"actor_critic.{which}", s, len(spec.pi_hidden))
+    mean, log_std = torch.chunk(logits, 2, dim=-1)
+    log_std = torch.clamp(log_std, min=-20.0, max=2.0)
+    std = log_std.exp()
+    x = mean + eps * std                                    # Normal.rsample
+    logp = -((x - mean) ** 2) / (2 * std ** 2) - std.log() - LOG_SQRT_2PI   # Normal.log_prob
+    a = torch.tanh(x)
+    logp = logp - torch.log((1 - a.pow(2)) + 1e-4)
+    return a, logp.sum(-1, keepdim=True)
+
+
+def gumbel_policy(p, spec: Spec, which, s, u):
+    """gumbel_mlp.py:13-21,40-54 on top of torch's ExpRelaxedCategorical.rsample at
+    temperature 1, with the U(0,1) draw ``u`` supplied by the caller."""
+    logits = skip_head_mlp(p, f"actor_critic.{which}", s, len(spec.pi_hidden))
+    norm = logits - logits.logsumexp(dim=-1, keepdim=True)      # Categorical normalisation
+    tiny = torch.finfo(torch.float32).eps
+    uc = u.clamp(min=tiny, max=1 - tiny)                        # clamp_probs
+    gumbels = -((-(uc.log())).log())
+    scores = (norm + gumbels) / 1.0
+    relaxed = (scores - scores.logsumexp(dim=-1, keepdim=True)).exp()
+    hard = F.one_hot(torch.argmax(relaxed, dim=-1), logits.shape[-1]).float()
+    st = (hard - relaxed).detach() + relaxed                    # straight-through
+    logp = -torch.sum(-st * F.log_softmax(norm, -1), -1, keepdim=True)
+    return st, logp
+
+
+def policy(p, spec, which, s, noise):
+    return gumbel_policy(p, spec, which, s, noise) if spec.discrete else gaussian_policy(p, spec, which, s, noise)
+
+
+# ---------------------------------------------------------------------------------------
+# losses
+# ---------------------------------------------------------------------------------------
+def quantile_huber(q, y):
+    """distributional_soft_actor_critic.py:90-103 (quirk q4: tau over the POOLED atoms)."""
+    delta = y[..., None, :] - q[..., None]
+    ad = delta.abs()
+    huber = torch.where(ad > 1, ad - 0.5, delta ** 2 * 0.5)
+    n = q.shape[-1]
+    tau = torch.arange(n, dtype=q.dtype) / n + 1 / 2 / n
+    tau = tau.view(*([1] * (q.dim() - 1)), n, 1)
+    return (torch.abs(tau - (delta < 0).float()) * huber).mean((-1, -2))
+
+
+def losses(p, spec: Spec, xp, noise_target, noise_actor, alpha):
+    """deepQlearning.py:198-249.  ``alpha`` is last step's exp(log_alpha) (quirk q5).
+    Returns the scalar loss and a dict of the intermediates the goldens hold."""
+    aux = {}
+    mask = (xp["task_done"] == 0)                                          # :201
+    contig = (xp["episode_step"][1:] == xp["episode_step"][:-1] + 1) & mask[:-1]   # :202-203
+    action = xp["action"]
+    if spec.discrete:                                                      # :206-210
+        action = torch.eye(spec.act)[action.view(action.shape[:-1]).long()]
+    state = encoder(p, spec, xp)                                           # :213
+    s_cur, s_nxt = state[:-1], state[1:]                                   # :251-258
+    with torch.no_grad():                                                  # q_loss target
+        a_n, logp_n = policy(p, spec, "actor_target", s_nxt, noise_target)
+        z = ensemble(p, spec, "critic_target", torch.cat((s_nxt, a_n), -1))
+        if spec.distributional:                                            # distributional…:50-58
+            zs, _ = torch.sort(z, dim=-1)
+            tq = zs[..., :-spec.n_drop]                                    # quirk q6: empty when n_drop == 0
+            if spec.max_entropy:
+                tq = tq + alpha * (-logp_n)
+        else:                                                              # soft_actor_critic.py:73-78
+            tq = z + alpha * (-logp_n) if spec.max_entropy else z
+            tq, _ = torch.min(tq, dim=-1, keepdim=True)
+        td = xp["reward"][1:] + mask[1:] * spec.gamma * tq
+    q = ensemble(p, spec, "critic", torch.cat((s_cur, action[:-1]), -1))
+    mc = xp["mc_return"][1:] if "mc_return" in xp else None
+    if spec.distributional:
+        q_loss = quantile_huber(q, td).unsqueeze(-1)                       # distributional…:70
+        if spec.lowerbound:
+            q_loss = q_loss + (mc - q).relu().mean(-1, keepdim=True)       # :76-79
+    else:
+        ql = F.smooth_l1_loss(q, td.expand_as(q), reduction="none")       # soft_actor_critic.py:88
+        if spec.lowerbound:                                                # :93-97
+            lb = (mc - q).relu()
+            ql = ql * (lb == 0) + lb
+        q_loss = ql.mean(-1, keepdim=True)                                 # :134
+    # actor / alpha, soft_actor_critic.py:136-154 (critic_frozen == critic, :142)
+    pi, logp = policy(p, spec, "actor", s_cur, noise_actor)
+    frozen = {k.replace(".critic.", ".critic_frozen."): v.detach() for k, v in p.items() if ".critic.nets." in k}
+    qpi = ensemble(frozen, spec, "critic_frozen", torch.cat((s_cur.detach(), pi), -1)).mean(-1, keepdim=True)
+    pi_loss = -(alpha * (-logp)) - qpi
+    alpha_loss = -(p["actor_critic.log_alpha"] * (spec.target_entropy - (-logp)).detach())
+    w = contig.float()
+    loss = ((q_loss + pi_loss + alpha_loss) * w).sum(0) / (w.sum(0) + 1e-4)   # :222-224
+    loss = loss.mean() / spec.T                                            # :225, :249
+    aux.update(state=state, next_action=a_n, next_log_pi=logp_n, next_z=z, td_target=td, q_pred=q,
+               q_loss=q_loss, pi=pi, log_pi=logp, q_frozen=None, pi_loss=pi_loss, alpha_loss=alpha_loss,
+               is_contiguous=w, qpi=qpi)
+    return loss, aux
+
+
+# ---------------------------------------------------------------------------------------
+# optimiser / targets
+# ---------------------------------------------------------------------------------------
+def adam_update(param, grad, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
+    """torch.optim.Adam (defaults; single-tensor path), restated: returns new (param, m, v)."""
+    m = m + (grad - m) * (1 - b1)                      # exp_avg.lerp_(grad, 1 - beta1)
+    v = v * b2 + (grad * grad) * (1 - b2)              # exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+    bc1 = 1 - b1 ** step
+    bc2 = 1 - b2 ** step
+    step_size = lr / bc1
+    denom = v.sqrt() / math.sqrt(bc2) + eps
+    return param - step_size * (m / denom), m, v
+
+
+@dataclass
+class TrainState:
+    params: Dict[str, Tensor]
+    adam_m: Dict[str, Tensor] = field(default_factory=dict)
+    adam_v: Dict[str, Tensor] = field(default_factory=dict)
+    step: int = 0
+    alpha: float = None           # curr_alpha carried between steps (soft_actor_critic.py:41,152)
+
+
+def new_state(spec: Spec, params) -> TrainState:
+    st = TrainState(params={k: v.clone() for k, v in params.items()})
+    for n in trainable_names(spec):
+        st.adam_m[n] = torch.zeros_like(st.params[n])
+        st.adam_v[n] = torch.zeros_like(st.params[n])
+    st.alpha = float(math.exp(float(st.params["actor_critic.log_alpha"])))   # soft_actor_critic.py:41 (float64 exp)
+    return st
+
+
+def train_step(st: TrainState, spec: Spec, xp, noise_target, noise_actor):
+    """deepQlearning.py:105-127 for one shard: loss -> backward -> Adam -> polyak."""
+    names = trainable_names(spec)
+    leaves = {}
+    for k, v in st.params.items():
+        leaves[k] = v.detach().clone().requires_grad_(k in names)
+    alpha = torch.tensor(st.alpha, dtype=torch.float32)
+    loss, aux = losses(leaves, spec, xp, noise_target, noise_actor, alpha)
+    grads = torch.autograd.grad(loss, [leaves[n] for n in names], allow_unused=True)
+    grads = {n: (g if g is not None else torch.zeros_like(leaves[n])) for n, g in zip(names, grads)}
+    # critic_frozen <- critic BEFORE the optimiser step (soft_actor_critic.py:142)
+    for k in list(st.params):
+        if ".critic.nets." in k:
+            st.params[k.replace(".critic.", ".critic_frozen.")] = st.params[k].clone()
+    # curr_alpha for the NEXT step uses log_alpha before this step's Adam (:152)
+    st.alpha = float(torch.exp(st.params["actor_critic.log_alpha"]))
+    st.step += 1
+    for n in names:
+        st.params[n], st.adam_m[n], st.adam_v[n] = adam_update(st.params[n], grads[n], st.adam_m[n], st.adam_v[n],
+                                                                st.step, spec.lr)
+    for src, dst in (("actor", "actor_target"), ("critic", "critic_target")):   # soft_actor_critic.py:54-60
+        for k in list(st.params):
+            if f".{src}." in k:
+                kt = k.replace(f".{src}.", f".{dst}.")
+                if spec.hard_updates:
+                    st.params[kt] = st.params[k].clone()
+                else:
+                    st.params[kt] = st.params[kt] * (1.0 - spec.tau) + st.params[k] * spec.tau
+    aux["grad"] = grads
+    return loss.detach(), aux

@@ -1,0 +1,160 @@
+"""Pin the CPU oracle against vectors produced by running the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from golden_io import load, spec_from_case, UPDATE_CASES
+from oracle import replay as orp
+from oracle import update as oup
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30)) if a.size else 0.0
+
+
+# --------------------------------------------------------------------------- ring
+@pytest.mark.parametrize("case", ["wrap8", "nowrap50", "wrap50"])
+def test_ring_matches_reference(case):
+    g = load("ring")[case]
+    r = orp.RingOracle(int(g["maxlen"]), int(g["B"]), int(g["T"]))
+    rows = g["rows"]
+    n = rows["reward"].shape[0]
+    for i in range(n):
+        r.add({"obs_1d": rows["obs_1d"][i], "action": rows["action"][i], "reward": float(rows["reward"][i]),
+               "task_done": bool(rows["task_done"][i]), "episode_done": bool(rows["episode_done"][i]),
+               "episode_step": int(rows["episode_step"][i]), "idx": int(rows["idx"][i])})
+    assert len(r) == int(g["len"]) and r.top == int(g["top"])
+    for k, v in g["memory"].items():
+        assert r.memory[k].dtype == v.dtype
+        np.testing.assert_array_equal(r.memory[k], v)
+    win = r.temporal_sample(starts=g["starts"])
+    for k, v in g["window"].items():
+        np.testing.assert_array_equal(win[k], v)
+    flat = r.sample(idx=g["flat_idx"])
+    for k, v in g["flat"].items():
+        np.testing.assert_array_equal(flat[k], v)
+
+
+def test_ring_len_quirk_q1():
+    r = orp.RingOracle(8, 2, 2)
+    for i in range(20):
+        r.add({"x": np.zeros(1, np.float32)})
+    assert len(r) == 7
+
+
+def test_ring_oversample_thresholds():
+    g = load("ring")["oversample"]
+    r = orp.RingOracle(100, int(g["B"]), int(g["T"]))
+    got = []
+    for i in range(len(g["ok_after_n_adds"])):
+        r.add({"x": np.zeros(1, np.float32)})
+        try:
+            r.temporal_sample()
+            got.append(1)
+        except orp.OversampleError:
+            got.append(0)
+    np.testing.assert_array_equal(got, g["ok_after_n_adds"])
+
+
+# --------------------------------------------------------------------------- n-step
+class Sink:
+    def __init__(self):
+        self.rows = []
+
+    def add(self, d):
+        self.rows.append(dict(d))
+
+    def stacked(self):
+        keys = sorted(self.rows[0].keys())
+        return {k: np.stack([np.asarray(r[k]).reshape(-1) for r in self.rows]) for k in keys}
+
+
+@pytest.mark.parametrize("case", ["sparse_1000", "dense_two_eps", "pop_quirk", "single_step"])
+def test_nstep_matches_reference(case):
+    g = load("nstep")[case]
+    sink = Sink()
+    w = orp.NStepOracle(sink, int(g["n_step"]), float(g["gamma"]))
+    inp = g["in"]
+    for i in range(inp["reward"].shape[0]):
+        w.add({"reward": float(inp["reward"][i, 0]), "episode_done": bool(inp["episode_done"][i, 0]),
+               "episode_step": int(inp["episode_step"][i, 0]), "obs_1d": inp["obs_1d"][i]})
+    out = sink.stacked()
+    assert out["reward"].shape == g["out"]["reward"].shape
+    for k, v in g["out"].items():
+        np.testing.assert_array_equal(np.asarray(out[k], v.dtype), v, err_msg=k)
+
+
+def test_nstep_reference_own_test():
+    """tests/test_replays.py:16-33 restated: mc_return == 0.99 ** (999 - step)."""
+    sink = Sink()
+    w = orp.NStepOracle(sink, 1000, 0.99)
+    for i in range(1000):
+        w.add({"reward": float(i == 999), "episode_done": i == 999, "step": i})
+    out = sink.stacked()
+    assert np.allclose(out["mc_return"], 0.99 ** (999 - out["step"]))
+
+
+# --------------------------------------------------------------------------- HER
+def l2_sparse_reward(ag, dg, thr=0.25):
+    d = np.linalg.norm(np.asarray(ag, np.float32) - np.asarray(dg, np.float32))
+    reward = np.float32(-1.0) if d > thr else np.float32(0.0)
+    return reward, bool(reward == 0)
+
+
+@pytest.mark.parametrize("case", ["final", "random", "final_nstep"])
+def test_her_matches_reference(case):
+    import random
+    g = load("her")[case]
+    sink = Sink()
+    inner = orp.NStepOracle(sink, 1000, float(g["gamma"])) if int(g["nstep"]) else sink
+    random.seed(3)
+    w = orp.HerOracle(inner, l2_sparse_reward, mode=str(g["mode"]))
+    inp = g["in"]
+    for i in range(inp["reward"].shape[0]):
+        w.add({"obs_1d": inp["obs_1d"][i], "achieved_goal": inp["achieved_goal"][i],
+               "desired_goal": inp["desired_goal"][i], "action": inp["action"][i],
+               "reward": float(inp["reward"][i, 0]), "task_done": bool(inp["task_done"][i, 0]),
+               "episode_done": bool(inp["episode_done"][i, 0]), "episode_step": int(inp["episode_step"][i, 0]),
+               "info": {}})
+    out = sink.stacked()
+    for k, v in g["out"].items():
+        assert out[k].shape == v.shape, k
+        np.testing.assert_allclose(np.asarray(out[k], np.float64), np.asarray(v, np.float64), rtol=0, atol=1e-6,
+                                   err_msg=k)
+
+
+# --------------------------------------------------------------------------- update
+TOL = 2e-5  # tensor-normalised max error; both sides are fp32 CPU with different op order
+
+
+@pytest.mark.parametrize("case", UPDATE_CASES)
+def test_update_matches_reference(case):
+    torch.set_num_threads(1)
+    g = load("update_" + case)
+    spec = spec_from_case(g["case"])
+    params = {k: torch.tensor(v) for k, v in g["init"].items()}
+    assert int(g["n_trainable"]) == sum(params[n].numel() for n in oup.trainable_names(spec))
+    st = oup.new_state(spec, params)
+    n_steps = len([k for k in g if k.startswith("step")])
+    for s in range(n_steps):
+        rec = g[f"step{s}"]
+        xp = {k: torch.tensor(v) for k, v in rec["batch"].items()}
+        assert abs(st.alpha - float(rec["alpha_in"])) <= 1e-6 * abs(st.alpha)
+        loss, aux = oup.train_step(st, spec, xp, torch.tensor(rec["noise_target"]), torch.tensor(rec["noise_actor"]))
+        assert rel_err(loss, rec["loss"]) < TOL, (s, float(loss), float(rec["loss"]))
+        for name in ["state", "next_action", "next_log_pi", "next_z", "q_pred", "pi", "log_pi", "q_loss",
+                     "pi_loss", "alpha_loss", "is_contiguous"]:
+            assert rel_err(aux[name].detach(), rec[name]) < TOL, (s, name)
+        if "grad" in rec:
+            for n, gr in rec["grad"].items():
+                assert rel_err(aux["grad"][n], gr) < 5e-5, (s, n, rel_err(aux["grad"][n], gr))
+        if "after" in rec:
+            for n, v in rec["after"].items():
+                assert rel_err(st.params[n], v) < TOL, (s, n, rel_err(st.params[n], v))
+        if "adam_m" in rec:
+            for n, v in rec["adam_m"].items():
+                assert rel_err(st.adam_m[n], v) < 5e-5, (s, n)
+            for n, v in rec["adam_v"].items():
+                assert rel_err(st.adam_v[n], v) < 5e-5, (s, n)
