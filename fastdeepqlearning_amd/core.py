@@ -1,0 +1,270 @@
+"""Thin object wrappers over the C ABI: device ring and device agent.
+
+torch supplies device memory, streams and (for N > 1) torch.distributed; every byte of
+compute on the hot path runs in libfdql_hip.so.  The franQ-shaped classes in
+fastdeepqlearning_amd.Replay / .Agent are built on these two.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+
+class NativeRing:
+    """SoA replay ring in HBM (include/fdql.h `fdql_ring_*`;
+    reference franQ/Replay/replay_memory.py:18-73)."""
+
+    def __init__(self, maxlen, dims, device="cuda:0"):
+        self.lib = N.load()
+        self.device = torch.device(device)
+        self.dims = [int(d) for d in dims]
+        self.maxlen = int(maxlen)
+        self.handle = C.c_void_p()
+        arr = (C.c_int32 * len(self.dims))(*self.dims)
+        with torch.cuda.device(self.device):
+            N.check(self.lib.fdql_ring_create(C.byref(self.handle), self.maxlen, len(self.dims), arr))
+        self.row_floats = sum(self.dims)
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            try:
+                self.lib.fdql_ring_destroy(h)
+            except Exception:
+                pass
+
+    def __len__(self):
+        return int(self.lib.fdql_ring_len(self.handle))
+
+    @property
+    def top(self):
+        return int(self.lib.fdql_ring_top(self.handle))
+
+    def add_rows(self, rows):
+        """rows: float32 numpy [n, row_floats] (host) or torch device tensor of that shape."""
+        if isinstance(rows, torch.Tensor) and rows.is_cuda:
+            rows = rows.contiguous()
+            assert rows.dtype == torch.float32 and rows.shape[-1] == self.row_floats
+            N.check(self.lib.fdql_ring_add_device(self.handle, C.c_void_p(rows.data_ptr()), rows.shape[0],
+                                                  N.current_stream(self.device)))
+            return
+        rows = np.ascontiguousarray(rows, dtype=np.float32).reshape(-1, self.row_floats)
+        N.check(self.lib.fdql_ring_add(self.handle, rows.ctypes.data_as(C.c_void_p), rows.shape[0],
+                                       N.current_stream(self.device)))
+
+    def flush(self):
+        N.check(self.lib.fdql_ring_flush(self.handle, N.current_stream(self.device)))
+
+    def _outs(self, lead):
+        outs = [torch.empty(tuple(lead) + (d,), dtype=torch.float32, device=self.device) for d in self.dims]
+        arr = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
+        return outs, arr
+
+    def sample_windows(self, T, B, starts=None, seed=0, counter=0, outs=None, return_starts=False):
+        """[T, B, dim_k] per key.  starts: optional int64 device tensor [B]."""
+        if outs is None:
+            outs, arr = self._outs((T, B))
+        else:
+            arr = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
+        sp = None
+        if starts is not None:
+            starts = torch.as_tensor(starts, dtype=torch.int64, device=self.device).contiguous()
+            sp = C.c_void_p(starts.data_ptr())
+        so = torch.empty(B, dtype=torch.int64, device=self.device) if return_starts else None
+        with torch.cuda.device(self.device):
+            N.check(self.lib.fdql_ring_sample_windows(self.handle, T, B, sp, seed, counter, arr,
+                                                      C.c_void_p(so.data_ptr()) if so is not None else None,
+                                                      N.current_stream(self.device)))
+        return (outs, so) if return_starts else outs
+
+    def sample_rows(self, B, idx=None, seed=0, counter=0):
+        outs, arr = self._outs((B,))
+        ip = None
+        if idx is not None:
+            idx = torch.as_tensor(idx, dtype=torch.int64, device=self.device).contiguous()
+            ip = C.c_void_p(idx.data_ptr())
+        with torch.cuda.device(self.device):
+            N.check(self.lib.fdql_ring_sample_rows(self.handle, B, ip, seed, counter, arr, None,
+                                                   N.current_stream(self.device)))
+        return outs
+
+
+def make_config(obs_dim, act_dim, T, B, goal_dim=0, discrete=False, n_critics=2, n_quantiles=10, latent=256,
+                enc_features=256, enc_hidden=(256,), joint_hidden=(256,), pi_hidden=(256,), critic_hidden=(256, 256),
+                distributional=True, use_lowerbound=True, use_max_entropy=True, hard_updates=False,
+                keep_frozen_copy=True, world_size=1, gamma=0.99, tau=5e-2, lr=3e-4, beta1=0.9, beta2=0.999,
+                adam_eps=1e-8, init_log_alpha=-2.0, drop_frac=0.2):
+    c = N.AgentConfig()
+    c.obs_dim, c.goal_dim, c.act_dim, c.discrete = obs_dim, goal_dim, act_dim, int(discrete)
+    c.n_critics, c.n_quantiles, c.latent, c.enc_features = n_critics, n_quantiles, latent, enc_features
+    for name, val in (("enc_hidden", enc_hidden), ("joint_hidden", joint_hidden), ("pi_hidden", pi_hidden),
+                      ("critic_hidden", critic_hidden)):
+        val = tuple(int(v) for v in val)
+        if len(val) > N.MAX_HIDDEN:
+            raise ValueError(f"{name}: at most {N.MAX_HIDDEN} hidden layers")
+        setattr(c, "n_" + name, len(val))
+        arr = getattr(c, name)
+        for i, v in enumerate(val):
+            arr[i] = v
+    c.distributional, c.use_lowerbound, c.use_max_entropy = int(distributional), int(use_lowerbound), int(use_max_entropy)
+    c.hard_updates, c.keep_frozen_copy = int(hard_updates), int(keep_frozen_copy)
+    c.T, c.B, c.world_size = T, B, world_size
+    c.gamma, c.tau, c.lr, c.beta1, c.beta2, c.adam_eps = gamma, tau, lr, beta1, beta2, adam_eps
+    c.init_log_alpha, c.drop_frac = init_log_alpha, drop_frac
+    return c
+
+
+BATCH_KEYS = ("obs_1d", "achieved_goal", "desired_goal", "action", "reward", "mc_return", "task_done", "episode_step")
+
+
+class NativeAgent:
+    """One SAC/TQC learner on one GPU (include/fdql.h `fdql_agent_*`;
+    reference franQ/Agent/deepQlearning.py:105-127,198-258).
+
+    Parameters, gradients, Adam moments and targets live in flat fp32 torch tensors
+    ("arenas"); ``tensors`` maps the reference's state_dict names to zero-copy views."""
+
+    def __init__(self, cfg, device="cuda:0"):
+        self.lib = N.load()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.handle = C.c_void_p()
+        N.check(self.lib.fdql_agent_create(C.byref(self.handle), C.byref(cfg)))
+        n0, n1, n2 = (int(self.lib.fdql_agent_arena_floats(self.handle, i)) for i in range(3))
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.params, self.grads = torch.zeros(n0, **f32), torch.zeros(n0, **f32)
+        self.adam_m, self.adam_v = torch.zeros(n0, **f32), torch.zeros(n0, **f32)
+        self.targets = torch.zeros(n1, **f32)
+        self.frozen = torch.zeros(n2, **f32)
+        self.workspace = torch.zeros(int(self.lib.fdql_agent_workspace_bytes(self.handle)) + 256, dtype=torch.uint8,
+                                     device=self.device)
+        self._ws_off = (-self.workspace.data_ptr()) % 256
+        with torch.cuda.device(self.device):
+            N.check(self.lib.fdql_agent_bind(self.handle, *[C.c_void_p(t.data_ptr()) for t in (
+                self.params, self.grads, self.adam_m, self.adam_v, self.targets, self.frozen)],
+                C.c_void_p(self.workspace.data_ptr() + self._ws_off), self.workspace.numel() - 256))
+        self.tensors, self.grad_views, self.m_views, self.v_views = OrderedDict(), OrderedDict(), OrderedDict(), OrderedDict()
+        arenas = {0: self.params, 1: self.targets, 2: self.frozen}
+        n = self.lib.fdql_agent_tensor_info(self.handle, -1, None, 0, None, None, None)
+        name = C.create_string_buffer(256)
+        arena, off, shape = C.c_int32(), C.c_int64(), (C.c_int32 * 2)()
+        for i in range(n):
+            N.check(self.lib.fdql_agent_tensor_info(self.handle, i, name, 256, C.byref(arena), C.byref(off), shape))
+            shp = (shape[0], shape[1]) if shape[1] else ((shape[0],) if shape[0] else ())
+            cnt = int(np.prod(shp)) if shp else 1
+            key = name.value.decode()
+            self.tensors[key] = arenas[arena.value][off.value: off.value + cnt].view(shp)
+            if arena.value == 0:
+                self.grad_views[key] = self.grads[off.value: off.value + cnt].view(shp)
+                self.m_views[key] = self.adam_m[off.value: off.value + cnt].view(shp)
+                self.v_views[key] = self.adam_v[off.value: off.value + cnt].view(shp)
+        self.trainable = list(self.grad_views.keys())
+        self._keep = None
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            try:
+                self.lib.fdql_agent_destroy(h)
+            except Exception:
+                pass
+
+    # ------------------------------------------------------------------ update
+    def _batch(self, xp):
+        b = N.Batch()
+        keep = []
+        for k in BATCH_KEYS:
+            t = xp.get(k)
+            if t is not None:
+                assert t.is_cuda and t.dtype == torch.float32, f"batch[{k}] must be a float32 device tensor"
+                t = t.contiguous()
+                keep.append(t)
+                setattr(b, k, t.data_ptr())
+        return b, keep
+
+    def update(self, xp, noise_target=None, noise_actor=None, seed=0, phase=N.PHASE_ALL):
+        """One train_step (deepQlearning.py:105-127) on the current torch stream; asynchronous."""
+        b, keep = self._batch(xp) if xp is not None else (N.Batch(), [])
+        for t in (noise_target, noise_actor):
+            if t is not None:
+                keep.append(t)
+        self._keep = keep  # keep the tensors alive until the next call
+        with torch.cuda.device(self.device):
+            N.check(self.lib.fdql_agent_update(self.handle, C.byref(b), N.ptr(noise_target), N.ptr(noise_actor), seed,
+                                               phase, N.current_stream(self.device)))
+
+    def profile_update(self, xp, noise_target=None, noise_actor=None, seed=0):
+        b, keep = self._batch(xp)
+        arr = (N.KernelTime * 256)()
+        with torch.cuda.device(self.device):
+            n = self.lib.fdql_agent_profile_update(self.handle, C.byref(b), N.ptr(noise_target), N.ptr(noise_actor), seed,
+                                                   arr, 256, N.current_stream(self.device))
+        if n < 0:
+            N.check(n)
+        return [(arr[i].name.decode(), float(arr[i].ms), float(arr[i].flops), float(arr[i].bytes)) for i in range(n)]
+
+    def scalars(self):
+        out = (C.c_float * 8)()
+        with torch.cuda.device(self.device):
+            N.check(self.lib.fdql_agent_scalars(self.handle, out, N.current_stream(self.device)))
+        keys = ("loss", "q_loss", "pi_loss", "alpha_loss", "q_pred_mu", "mc_constraint_violations", "alpha", "step")
+        return dict(zip(keys, [float(x) for x in out]))
+
+    def stats(self):
+        s = N.AgentStats()
+        N.check(self.lib.fdql_agent_stats(self.handle, C.byref(s)))
+        return {"gemm_flops": s.gemm_flops, "skinny_flops": s.skinny_flops, "n_launches": s.n_launches,
+                "n_gemm_launches": s.n_gemm_launches, "params": s.params}
+
+    def set_alpha(self, alpha):
+        N.check(self.lib.fdql_agent_set_alpha(self.handle, float(alpha), N.current_stream(self.device)))
+
+    def set_step(self, step):
+        N.check(self.lib.fdql_agent_set_step(self.handle, int(step), N.current_stream(self.device)))
+
+    def debug(self, name, shape=None):
+        """Copy of a named intermediate of the last update (parity tests)."""
+        p, cnt = C.c_void_p(), C.c_int64()
+        N.check(self.lib.fdql_agent_debug_ptr(self.handle, name.encode(), C.byref(p), C.byref(cnt)))
+        off = p.value - self.workspace.data_ptr()
+        t = self.workspace[off: off + 4 * cnt.value].view(torch.float32).clone()
+        return t.view(shape) if shape is not None else t
+
+    # ------------------------------------------------------------------ weights
+    def load_tensors(self, sd):
+        """Copy tensors (reference state_dict names) into the arenas."""
+        for k, v in sd.items():
+            if k in self.tensors:
+                self.tensors[k].copy_(torch.as_tensor(v, dtype=torch.float32).to(self.device))
+
+    def load_opt_state(self, adam_m=None, adam_v=None, step=None, alpha=None):
+        """Load Adam moments / step / lagged alpha (resume or test synchronisation)."""
+        for views, src in ((self.m_views, adam_m), (self.v_views, adam_v)):
+            if src is not None:
+                for k, v in src.items():
+                    views[k].copy_(torch.as_tensor(v, dtype=torch.float32).to(self.device))
+        if step is not None:
+            self.set_step(step)
+        if alpha is not None:
+            self.set_alpha(alpha)
+
+    def init_weights(self, seed=0):
+        """xavier_uniform(gain 1) weights, zero biases, targets = copies
+        (franQ/Agent/models/mlp.py:5-8,86; soft_actor_critic.py:34,38)."""
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        for k, v in self.tensors.items():
+            if k.endswith("weight"):
+                fan_out, fan_in = v.shape
+                a = (6.0 / (fan_in + fan_out)) ** 0.5
+                v.copy_(((torch.rand(v.shape, generator=g) * 2 - 1) * a).to(self.device))
+            elif k.endswith("bias"):
+                v.zero_()
+            elif k.endswith("log_alpha"):
+                v.fill_(float(self.cfg.init_log_alpha))
+        for k, v in self.tensors.items():
+            for src, dst in ((".actor.", ".actor_target."), (".critic.", ".critic_target.")):
+                if dst in k:
+                    v.copy_(self.tensors[k.replace(dst, src)])

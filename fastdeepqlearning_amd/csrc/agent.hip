@@ -1,0 +1,954 @@
+// Host-side plan builder and runner of one SAC/TQC gradient step.
+//
+// fdql_agent_create() lays out the parameter arenas with the reference's state_dict names;
+// the first fdql_agent_update() (or a change of batch pointers) builds a fixed list of
+// launch stages — grouped GEMM problem tables, skinny-head tables, fused loss/policy
+// kernels — uploads the tables once, and every later update just replays the launches.
+// All per-step varying scalars (Adam step, bias corrections, lagged alpha) live in device
+// memory (DevState), so the stage list is replayable without host-side changes.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "update_kernels.h"
+
+namespace fdql {
+
+static thread_local char g_err[1024] = "";
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+static inline int64_t pad4(int64_t n) { return (n + 3) / 4 * 4; }
+
+struct TensorInfo {
+  std::string name;
+  int arena;       // 0 trainable, 1 targets, 2 frozen
+  int64_t off;     // floats from the arena base
+  int rows, cols;  // weight [rows, cols]; bias [rows, 0]; scalar [0, 0]
+};
+
+struct MlpDesc {
+  int din = 0, dout = 0;
+  std::vector<int> hid;
+  std::vector<int64_t> w_off, b_off;  // offsets in the trainable arena
+  int64_t hw_off = 0, hb_off = 0;
+  int head_ld() const {
+    int s = din;
+    for (int h : hid) s += h;
+    return s;
+  }
+  int in_of(int i) const { return i == 0 ? din : hid[i - 1]; }
+};
+
+struct SegIn {
+  const float *ptr;
+  int ld, width;
+};
+
+// One MLP evaluated on one set of rows (e.g. critic 3 of critic_target on the "next" rows).
+struct MlpInst {
+  const MlpDesc *d = nullptr;
+  const float *wbase = nullptr;  // arena base the weights are read from (minus the arena's origin offset)
+  int64_t worigin = 0;           // offset to subtract from the MlpDesc offsets for this arena
+  std::vector<SegIn> in;
+  int rows = 0;
+  std::vector<float *> h;
+  float *out = nullptr;
+  int ldout = 0;
+  std::vector<float *> dpre;
+  const float *W(int i) const { return wbase + (d->w_off[i] - worigin); }
+  const float *Bv(int i) const { return wbase + (d->b_off[i] - worigin); }
+  const float *HW() const { return wbase + (d->hw_off - worigin); }
+  const float *HB() const { return wbase + (d->hb_off - worigin); }
+};
+
+enum StageKind { ST_GEMM, ST_SKINNY_FWD, ST_SKINNY_WGRAD, ST_FUNC };
+
+struct Stage {
+  StageKind kind;
+  std::string name;
+  std::vector<GemmProblem> gemm;
+  std::vector<SkinnyFwdProblem> sfwd;
+  std::vector<SkinnyWgradProblem> swg;
+  void *dev = nullptr;  // device copy of the table
+  int blocks = 0;
+  double flops = 0, bytes = 0;
+  int phase = FDQL_PHASE_GRAD;
+  std::function<hipError_t(hipStream_t)> fn;
+};
+
+}  // namespace fdql
+
+using namespace fdql;
+
+struct fdql_agent {
+  fdql_agent_config_t cfg;
+  MlpDesc enc_obs, joiner, actor;
+  std::vector<MlpDesc> critic;
+  int64_t log_alpha_off = 0;
+  int64_t n_train = 0, tgt_begin = 0, tgt_end = 0, crit_begin = 0, crit_end = 0;
+  std::vector<TensorInfo> tensors;
+
+  // bound memory
+  float *params = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr, *targets = nullptr, *frozen = nullptr;
+  char *ws = nullptr;
+  int64_t ws_bytes = 0, ws_need = 0;
+  bool bound = false;
+
+  // geometry
+  int T, B, N, M, A, L, Nq, Nt, nsplit;
+
+  // workspace carve (offsets in bytes); filled by carve()
+  int64_t carve_top = 0;
+  std::map<std::string, std::pair<int64_t, int64_t>> named;  // name -> (byte offset, float count)
+
+  // plan
+  fdql_batch_t batch = {};
+  bool plan_ready = false;
+  std::vector<Stage> stages;
+  void *tables_dev = nullptr;
+  const float *noise_t = nullptr, *noise_a = nullptr;  // per-call (read by the policy stage lambdas)
+  uint64_t seed = 0;
+
+  DevState *st() const { return reinterpret_cast<DevState *>(ws + named.at("dev_state").first); }
+  float *buf(const std::string &n) const { return reinterpret_cast<float *>(ws + named.at(n).first); }
+  float *alloc(const std::string &n, int64_t floats) {
+    const int64_t bytes = (floats * 4 + 255) / 256 * 256;
+    named[n] = {carve_top, floats};
+    carve_top += bytes;
+    return ws ? reinterpret_cast<float *>(ws + named[n].first) : nullptr;
+  }
+};
+
+namespace {
+
+void add_mlp(fdql_agent *a, MlpDesc &m, const std::string &prefix, int din, const int32_t *hid, int nh, int dout,
+             int64_t &top) {
+  m.din = din;
+  m.dout = dout;
+  m.hid.assign(hid, hid + nh);
+  for (int i = 0; i < nh; ++i) {
+    const int in = m.in_of(i);
+    m.w_off.push_back(top);
+    a->tensors.push_back({prefix + ".feature_extractor." + std::to_string(i) + ".0.weight", 0, top, m.hid[i], in});
+    top += pad4((int64_t)m.hid[i] * in);
+    m.b_off.push_back(top);
+    a->tensors.push_back({prefix + ".feature_extractor." + std::to_string(i) + ".0.bias", 0, top, m.hid[i], 0});
+    top += pad4(m.hid[i]);
+  }
+  m.hw_off = top;
+  a->tensors.push_back({prefix + ".head.weight", 0, top, dout, m.head_ld()});
+  top += pad4((int64_t)dout * m.head_ld());
+  m.hb_off = top;
+  a->tensors.push_back({prefix + ".head.bias", 0, top, dout, 0});
+  top += pad4(dout);
+}
+
+int layout(fdql_agent *a) {
+  const fdql_agent_config_t &c = a->cfg;
+  int64_t top = 0;
+  add_mlp(a, a->enc_obs, "encoder.visible_layer_encoders.obs_1d", c.obs_dim + 2 * c.goal_dim, c.enc_hidden,
+          c.n_enc_hidden, c.enc_features, top);
+  add_mlp(a, a->joiner, "encoder.joiner", c.enc_features, c.joint_hidden, c.n_joint_hidden, c.latent, top);
+  a->tgt_begin = top;
+  const int pi_out = c.discrete ? c.act_dim : 2 * c.act_dim;
+  add_mlp(a, a->actor, "actor_critic.actor", c.latent, c.pi_hidden, c.n_pi_hidden, pi_out, top);
+  a->crit_begin = top;
+  a->critic.resize(c.n_critics);
+  for (int k = 0; k < c.n_critics; ++k)
+    add_mlp(a, a->critic[k], "actor_critic.critic.nets." + std::to_string(k), c.latent + c.act_dim, c.critic_hidden,
+            c.n_critic_hidden, c.n_quantiles, top);
+  a->crit_end = top;
+  a->tgt_end = top;
+  a->log_alpha_off = top;
+  a->tensors.push_back({"actor_critic.log_alpha", 0, top, 0, 0});
+  top += 4;
+  a->n_train = top;
+  // mirrored arenas
+  const size_t n0 = a->tensors.size();
+  for (size_t i = 0; i < n0; ++i) {
+    const TensorInfo &t = a->tensors[i];
+    if (t.off >= a->tgt_begin && t.off < a->tgt_end) {
+      TensorInfo u = t;
+      u.arena = 1;
+      u.off = t.off - a->tgt_begin;
+      size_t p;
+      if ((p = u.name.find(".actor.")) != std::string::npos) u.name.replace(p, 7, ".actor_target.");
+      else if ((p = u.name.find(".critic.")) != std::string::npos) u.name.replace(p, 8, ".critic_target.");
+      a->tensors.push_back(u);
+    }
+  }
+  for (size_t i = 0; i < n0; ++i) {
+    const TensorInfo &t = a->tensors[i];
+    if (t.off >= a->crit_begin && t.off < a->crit_end) {
+      TensorInfo u = t;
+      u.arena = 2;
+      u.off = t.off - a->crit_begin;
+      const size_t p = u.name.find(".critic.");
+      u.name.replace(p, 8, ".critic_frozen.");
+      a->tensors.push_back(u);
+    }
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------ workspace
+void carve(fdql_agent *a) {
+  a->carve_top = 0;
+  a->named.clear();
+  const fdql_agent_config_t &c = a->cfg;
+  const int64_t N = a->N, M = a->M, Nq = a->Nq;
+  a->alloc("dev_state", 64);
+  a->alloc("scalars", 16);
+  a->alloc("w", M);
+  a->alloc("is_contiguous", M);
+  auto mlp_bufs = [&](const std::string &p, const MlpDesc &d, int64_t rows, bool bwd, bool out) {
+    for (size_t i = 0; i < d.hid.size(); ++i) {
+      a->alloc(p + ".h" + std::to_string(i), rows * d.hid[i]);
+      if (bwd) a->alloc(p + ".dpre" + std::to_string(i), M * d.hid[i]);
+    }
+    if (out) a->alloc(p + ".out", rows * d.dout);
+  };
+  mlp_bufs("enc_obs", a->enc_obs, N, true, true);
+  mlp_bufs("joiner", a->joiner, N, true, false);
+  a->alloc("state", N * c.latent);
+  mlp_bufs("actor_t", a->actor, M, false, true);
+  mlp_bufs("actor", a->actor, M, true, true);
+  a->alloc("next_action", M * c.act_dim);
+  a->alloc("next_log_pi", M);
+  a->alloc("pi", M * c.act_dim);
+  a->alloc("log_pi", M);
+  a->alloc("noise_actor", M * c.act_dim);
+  for (int k = 0; k < c.n_critics; ++k) {
+    const std::string s = std::to_string(k);
+    mlp_bufs("crit_t" + s, a->critic[k], M, false, false);
+    mlp_bufs("crit" + s, a->critic[k], M, true, false);
+    mlp_bufs("crit_f" + s, a->critic[k], M, true, false);
+  }
+  a->alloc("next_z", M * Nq);
+  a->alloc("q_pred", M * Nq);
+  a->alloc("q_frozen", M * Nq);
+  a->alloc("td_target", M * (a->Nt > 0 ? a->Nt : 1));
+  a->alloc("dz", M * Nq);
+  a->alloc("dzf", M * Nq);
+  a->alloc("q_loss", M);
+  a->alloc("pi_loss", M);
+  a->alloc("alpha_loss", M);
+  a->alloc("dpi", M * c.act_dim);
+  a->alloc("dlogits", M * a->actor.dout);
+  a->alloc("dstate", M * c.latent);
+  a->alloc("denc", M * c.enc_features);
+  a->alloc("loss_partials", (int64_t)loss_blocks((int)M, 256) * LOSS_NPART + (int64_t)M * LOSS_NPART);
+  a->alloc("slabs", (int64_t)a->nsplit * a->n_train);
+}
+
+// --------------------------------------------------------------------------- plan builder
+struct Builder {
+  fdql_agent *a;
+  std::vector<Stage> &st;
+  Builder(fdql_agent *ag) : a(ag), st(ag->stages) {}
+
+  Stage &gemm_stage(const std::string &name) {
+    st.emplace_back();
+    st.back().kind = ST_GEMM;
+    st.back().name = name;
+    return st.back();
+  }
+  Stage &sfwd_stage(const std::string &name) {
+    st.emplace_back();
+    st.back().kind = ST_SKINNY_FWD;
+    st.back().name = name;
+    return st.back();
+  }
+  Stage &func_stage(const std::string &name, std::function<hipError_t(hipStream_t)> fn, int phase = FDQL_PHASE_GRAD) {
+    st.emplace_back();
+    st.back().kind = ST_FUNC;
+    st.back().name = name;
+    st.back().fn = std::move(fn);
+    st.back().phase = phase;
+    return st.back();
+  }
+
+  static GemmProblem new_gemm(int M, int N, float *C, int ldc) {
+    GemmProblem p;
+    memset(&p, 0, sizeof(p));
+    p.M = M; p.N = N; p.C = C; p.ldc = ldc; p.ksplit = 1;
+    return p;
+  }
+  static void add_seg(GemmProblem &p, const float *A, int lda, int a_kc, const float *B, int ldb, int b_kc, int K) {
+    if (K <= 0) return;
+    GemmSeg &s = p.seg[p.nseg++];
+    s.A = A; s.lda = lda; s.a_kc = a_kc; s.B = B; s.ldb = ldb; s.b_kc = b_kc; s.K = K;
+  }
+
+  // forward hidden layer i of inst -> problem
+  GemmProblem fwd_layer(const MlpInst &m, int i) {
+    const MlpDesc &d = *m.d;
+    GemmProblem p = new_gemm(m.rows, d.hid[i], m.h[i], d.hid[i]);
+    if (i == 0) {
+      int col = 0;
+      for (const SegIn &s : m.in) {
+        add_seg(p, s.ptr, s.ld, 1, m.W(0) + col, d.din, 1, s.width);
+        col += s.width;
+      }
+    } else {
+      add_seg(p, m.h[i - 1], d.hid[i - 1], 1, m.W(i), d.hid[i - 1], 1, d.hid[i - 1]);
+    }
+    p.bias = m.Bv(i);
+    p.epi = EPI_LRELU;
+    return p;
+  }
+  // head: out = W_head cat(in, h_0..h_{n-1}) + b   (mlp.py:93-94)
+  void fwd_head(const MlpInst &m, Stage *gs, Stage *ss) {
+    const MlpDesc &d = *m.d;
+    const int ld = d.head_ld();
+    if (d.dout > SKINNY_MAX_OUT) {
+      GemmProblem p = new_gemm(m.rows, d.dout, m.out, m.ldout);
+      int col = 0;
+      for (const SegIn &s : m.in) { add_seg(p, s.ptr, s.ld, 1, m.HW() + col, ld, 1, s.width); col += s.width; }
+      for (size_t i = 0; i < d.hid.size(); ++i) { add_seg(p, m.h[i], d.hid[i], 1, m.HW() + col, ld, 1, d.hid[i]); col += d.hid[i]; }
+      p.bias = m.HB();
+      gs->gemm.push_back(p);
+    } else {
+      SkinnyFwdProblem p;
+      memset(&p, 0, sizeof(p));
+      p.M = m.rows; p.Nout = d.dout; p.Y = m.out; p.ldy = m.ldout; p.bias = m.HB();
+      int col = 0;
+      auto seg = [&](const float *X, int ldx, int K) {
+        SkinnySeg &s = p.seg[p.nseg++];
+        s.X = X; s.ldx = ldx; s.K = K; s.W = m.HW() + col; s.wsn = ld; s.wsk = 1;
+        col += K;
+      };
+      for (const SegIn &s : m.in) seg(s.ptr, s.ld, s.width);
+      for (size_t i = 0; i < d.hid.size(); ++i) seg(m.h[i], d.hid[i], d.hid[i]);
+      ss->sfwd.push_back(p);
+    }
+  }
+  int head_col_of_hidden(const MlpDesc &d, int i) const {
+    int col = d.din;
+    for (int j = 0; j < i; ++j) col += d.hid[j];
+    return col;
+  }
+  // dpre_i = (dY Wh[:, cols(h_i)] + dpre_{i+1} W_{i+1}) * lrelu'(h_i)
+  GemmProblem bwd_dpre(const MlpInst &m, int i, const float *dY, int lddy) {
+    const MlpDesc &d = *m.d;
+    GemmProblem p = new_gemm(m.rows, d.hid[i], m.dpre[i], d.hid[i]);
+    add_seg(p, dY, lddy, 1, m.HW() + head_col_of_hidden(d, i), d.head_ld(), 0, d.dout);
+    if (i + 1 < (int)d.hid.size()) add_seg(p, m.dpre[i + 1], d.hid[i + 1], 1, m.W(i + 1), d.hid[i], 0, d.hid[i + 1]);
+    p.epi = EPI_LRELU_GRAD;
+    p.ref = m.h[i];
+    p.ldref = d.hid[i];
+    return p;
+  }
+  // K-segments of d(input columns [col, col+width)) = dY Wh[:, cols] + dpre_0 W_0[:, cols]
+  void input_grad_segs(const MlpInst &m, const float *dY, int lddy, int col, GemmProblem &p) {
+    const MlpDesc &d = *m.d;
+    add_seg(p, dY, lddy, 1, m.HW() + col, d.head_ld(), 0, d.dout);
+    if (!d.hid.empty()) add_seg(p, m.dpre[0], d.hid[0], 1, m.W(0) + col, d.din, 0, d.hid[0]);
+  }
+  void input_grad_skinny(const MlpInst &m, const float *dY, int lddy, int col, SkinnyFwdProblem &p) {
+    const MlpDesc &d = *m.d;
+    SkinnySeg &s = p.seg[p.nseg++];
+    s.X = dY; s.ldx = lddy; s.K = d.dout; s.W = m.HW() + col; s.wsn = 1; s.wsk = d.head_ld();
+    if (!d.hid.empty()) {
+      SkinnySeg &t = p.seg[p.nseg++];
+      t.X = m.dpre[0]; t.ldx = d.hid[0]; t.K = d.hid[0]; t.W = m.W(0) + col; t.wsn = 1; t.wsk = d.din;
+    }
+  }
+
+  // all weight / bias gradients of one MLP instance into the slabs
+  void wgrads(const MlpInst &m, const float *dY, int lddy, Stage &gs, Stage &ws) {
+    const MlpDesc &d = *m.d;
+    float *slab = a->buf("slabs");
+    const long long P = a->n_train;
+    const int S = a->nsplit, R = m.rows;
+    auto gemm_w = [&](const float *dOut, int ldo, int nout, const float *X, int ldx, int width, float *dst, int ldw) {
+      if (width <= 0) return;
+      if (width > SKINNY_MAX_OUT && nout > SKINNY_MAX_OUT) {
+        GemmProblem p = new_gemm(nout, width, dst, ldw);
+        add_seg(p, dOut, ldo, 0, X, ldx, 0, R);
+        p.ksplit = S;
+        p.split_stride = P;
+        gs.gemm.push_back(p);
+      } else if (nout <= SKINNY_MAX_OUT) {
+        SkinnyWgradProblem p;
+        memset(&p, 0, sizeof(p));
+        p.M = R; p.Nout = nout; p.K = width; p.dY = dOut; p.lddy = ldo; p.X = X; p.ldx = ldx;
+        p.dW = dst; p.sq = ldw; p.sk = 1; p.split_stride = P; p.nsplit = S;
+        ws.swg.push_back(p);
+      } else {  // few input columns, many outputs: transposed roles
+        SkinnyWgradProblem p;
+        memset(&p, 0, sizeof(p));
+        p.M = R; p.Nout = width; p.K = nout; p.dY = X; p.lddy = ldx; p.X = dOut; p.ldx = ldo;
+        p.dW = dst; p.sq = 1; p.sk = ldw; p.split_stride = P; p.nsplit = S;
+        ws.swg.push_back(p);
+      }
+    };
+    auto bias_w = [&](const float *dOut, int ldo, int nout, float *dst) {
+      SkinnyWgradProblem p;
+      memset(&p, 0, sizeof(p));
+      p.M = R; p.Nout = 1; p.K = nout; p.dY = nullptr; p.X = dOut; p.ldx = ldo;
+      p.dW = dst; p.sq = 0; p.sk = 1; p.split_stride = P; p.nsplit = S;
+      ws.swg.push_back(p);
+    };
+    for (size_t i = 0; i < d.hid.size(); ++i) {
+      float *dst = slab + d.w_off[i];
+      if (i == 0) {
+        int col = 0;
+        for (const SegIn &s : m.in) { gemm_w(m.dpre[0], d.hid[0], d.hid[0], s.ptr, s.ld, s.width, dst + col, d.din); col += s.width; }
+      } else {
+        gemm_w(m.dpre[i], d.hid[i], d.hid[i], m.h[i - 1], d.hid[i - 1], d.hid[i - 1], dst, d.hid[i - 1]);
+      }
+      bias_w(m.dpre[i], d.hid[i], d.hid[i], slab + d.b_off[i]);
+    }
+    float *dst = slab + d.hw_off;
+    const int ld = d.head_ld();
+    int col = 0;
+    for (const SegIn &s : m.in) { gemm_w(dY, lddy, d.dout, s.ptr, s.ld, s.width, dst + col, ld); col += s.width; }
+    for (size_t i = 0; i < d.hid.size(); ++i) { gemm_w(dY, lddy, d.dout, m.h[i], d.hid[i], d.hid[i], dst + col, ld); col += d.hid[i]; }
+    bias_w(dY, lddy, d.dout, slab + d.hb_off);
+  }
+};
+
+MlpInst make_inst(fdql_agent *a, const MlpDesc &d, const std::string &p, const float *wbase, int64_t worigin, int rows,
+                  bool bwd) {
+  MlpInst m;
+  m.d = &d;
+  m.wbase = wbase;
+  m.worigin = worigin;
+  m.rows = rows;
+  for (size_t i = 0; i < d.hid.size(); ++i) {
+    m.h.push_back(a->buf(p + ".h" + std::to_string(i)));
+    if (bwd) m.dpre.push_back(a->buf(p + ".dpre" + std::to_string(i)));
+  }
+  return m;
+}
+
+int upload_tables(fdql_agent *a) {
+  size_t total = 0;
+  for (Stage &s : a->stages) {
+    if (s.kind == ST_GEMM) total += (s.gemm.size() * sizeof(GemmProblem) + 255) / 256 * 256;
+    if (s.kind == ST_SKINNY_FWD) total += (s.sfwd.size() * sizeof(SkinnyFwdProblem) + 255) / 256 * 256;
+    if (s.kind == ST_SKINNY_WGRAD) total += (s.swg.size() * sizeof(SkinnyWgradProblem) + 255) / 256 * 256;
+  }
+  if (a->tables_dev) { FDQL_HIP(hipFree(a->tables_dev)); a->tables_dev = nullptr; }
+  FDQL_HIP(hipMalloc(&a->tables_dev, total ? total : 256));
+  std::vector<char> host(total);
+  size_t off = 0;
+  for (Stage &s : a->stages) {
+    size_t bytes = 0;
+    const void *src = nullptr;
+    if (s.kind == ST_GEMM) {
+      s.blocks = gemm_finalize(s.gemm.data(), (int)s.gemm.size());
+      s.flops = 0;
+      for (auto &p : s.gemm) s.flops += gemm_flops(p);
+      bytes = s.gemm.size() * sizeof(GemmProblem); src = s.gemm.data();
+    } else if (s.kind == ST_SKINNY_FWD) {
+      s.blocks = skinny_fwd_finalize(s.sfwd.data(), (int)s.sfwd.size());
+      s.flops = 0; s.bytes = 0;
+      for (auto &p : s.sfwd) {
+        double k = 0;
+        for (int j = 0; j < p.nseg; ++j) k += p.seg[j].K;
+        s.flops += 2.0 * p.M * k * p.Nout;
+        s.bytes += 4.0 * p.M * (k + p.Nout);
+      }
+      bytes = s.sfwd.size() * sizeof(SkinnyFwdProblem); src = s.sfwd.data();
+    } else if (s.kind == ST_SKINNY_WGRAD) {
+      s.blocks = skinny_wgrad_finalize(s.swg.data(), (int)s.swg.size());
+      s.flops = 0; s.bytes = 0;
+      for (auto &p : s.swg) {
+        s.flops += 2.0 * p.M * (double)p.K * p.Nout;
+        s.bytes += 4.0 * p.M * ((double)p.K + (p.dY ? p.Nout : 0));
+      }
+      bytes = s.swg.size() * sizeof(SkinnyWgradProblem); src = s.swg.data();
+    } else {
+      continue;
+    }
+    memcpy(host.data() + off, src, bytes);
+    s.dev = (char *)a->tables_dev + off;
+    off += (bytes + 255) / 256 * 256;
+  }
+  if (total) FDQL_HIP(hipMemcpy(a->tables_dev, host.data(), total, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int build_plan(fdql_agent *a) {
+  const fdql_agent_config_t &c = a->cfg;
+  a->stages.clear();
+  Builder b(a);
+  const int N = a->N, M = a->M, B = a->B, L = c.latent, A = c.act_dim, C = c.n_critics, Q = c.n_quantiles, Nq = a->Nq;
+  const fdql_batch_t &x = a->batch;
+  float *params = a->params, *targets = a->targets;
+
+  // ---- instances
+  MlpInst eo = make_inst(a, a->enc_obs, "enc_obs", params, 0, N, true);
+  eo.in.push_back({x.obs_1d, c.obs_dim, c.obs_dim});
+  if (c.goal_dim) {
+    eo.in.push_back({x.achieved_goal, c.goal_dim, c.goal_dim});
+    eo.in.push_back({x.desired_goal, c.goal_dim, c.goal_dim});
+  }
+  eo.out = a->buf("enc_obs.out"); eo.ldout = c.enc_features;
+  MlpInst jo = make_inst(a, a->joiner, "joiner", params, 0, N, true);
+  jo.in.push_back({eo.out, c.enc_features, c.enc_features});
+  float *state = a->buf("state");
+  jo.out = state; jo.ldout = L;
+  const float *s_cur = state, *s_nxt = state + (int64_t)B * L;
+
+  MlpInst at = make_inst(a, a->actor, "actor_t", targets, a->tgt_begin, M, false);
+  at.in.push_back({s_nxt, L, L});
+  at.out = a->buf("actor_t.out"); at.ldout = a->actor.dout;
+  MlpInst ao = make_inst(a, a->actor, "actor", params, 0, M, true);
+  ao.in.push_back({s_cur, L, L});
+  ao.out = a->buf("actor.out"); ao.ldout = a->actor.dout;
+
+  std::vector<MlpInst> ct, co, cf;
+  for (int k = 0; k < C; ++k) {
+    const std::string s = std::to_string(k);
+    MlpInst t = make_inst(a, a->critic[k], "crit_t" + s, targets, a->tgt_begin, M, false);
+    t.in.push_back({s_nxt, L, L});
+    t.in.push_back({a->buf("next_action"), A, A});
+    t.out = a->buf("next_z") + k * Q; t.ldout = Nq;
+    ct.push_back(t);
+    MlpInst o = make_inst(a, a->critic[k], "crit" + s, params, 0, M, true);
+    o.in.push_back({s_cur, L, L});
+    o.in.push_back({x.action, A, A});
+    o.out = a->buf("q_pred") + k * Q; o.ldout = Nq;
+    co.push_back(o);
+    MlpInst f = make_inst(a, a->critic[k], "crit_f" + s, params, 0, M, true);
+    f.in.push_back({s_cur, L, L});
+    f.in.push_back({a->buf("pi"), A, A});
+    f.out = a->buf("q_frozen") + k * Q; f.ldout = Nq;
+    cf.push_back(f);
+  }
+
+  DevState *dst = a->st();
+  const float *log_alpha = params + a->log_alpha_off;
+
+  // ---- stage 0: tick + prep
+  {
+    b.func_stage("tick_alpha", [=](hipStream_t s) { return tick_alpha_launch(dst, log_alpha, s); });
+    const float inv_gb = 1.0f / (float)(B * (c.world_size > 0 ? c.world_size : 1));
+    float *w = a->buf("w"), *ic = a->buf("is_contiguous");
+    const float *td = x.task_done, *es = x.episode_step;
+    const int T = a->T;
+    b.func_stage("prep", [=](hipStream_t s) { return prep_launch(td, es, T, B, inv_gb, w, ic, s); });
+  }
+  // ---- encoder forward (encoder.py:52-67)
+  auto fwd_chain = [&](std::vector<MlpInst *> group, const std::string &name) {
+    const size_t nh = group[0]->d->hid.size();
+    for (size_t i = 0; i < nh; ++i) {
+      Stage &gs = b.gemm_stage(name + ".fwd" + std::to_string(i));
+      for (MlpInst *m : group) gs.gemm.push_back(b.fwd_layer(*m, (int)i));
+    }
+    // heads: wide ones through the GEMM, narrow ones through the skinny kernel
+    std::vector<GemmProblem> gp;
+    std::vector<SkinnyFwdProblem> sp;
+    Stage tmpg, tmps;
+    for (MlpInst *m : group) b.fwd_head(*m, &tmpg, &tmps);
+    if (!tmpg.gemm.empty()) { Stage &gs = b.gemm_stage(name + ".head"); gs.gemm = tmpg.gemm; }
+    if (!tmps.sfwd.empty()) { Stage &ss = b.sfwd_stage(name + ".head"); ss.sfwd = tmps.sfwd; }
+  };
+  fwd_chain({&eo}, "enc_obs");
+  fwd_chain({&jo}, "joiner");
+  fwd_chain({&at, &ao}, "actors");
+  // ---- policy sampling (gaussian_mlp.py:15-39)
+  {
+    PolicyFwdArgs p0{at.out, nullptr, nullptr, a->buf("next_action"), a->buf("next_log_pi"), 0u};
+    PolicyFwdArgs p1{ao.out, nullptr, a->buf("noise_actor"), a->buf("pi"), a->buf("log_pi"), 1u};
+    fdql_agent *ag = a;
+    b.func_stage("policy_fwd", [=](hipStream_t s) {
+      PolicyFwdArgs q0 = p0, q1 = p1;
+      q0.noise = ag->noise_t;
+      q1.noise = ag->noise_a;
+      return policy_fwd_launch(q0, q1, 2, M, A, dst, ag->seed, s);
+    });
+  }
+  // ---- critics forward: target(next, a'), online(cur, a), frozen(cur, pi)
+  {
+    std::vector<MlpInst *> g;
+    for (int k = 0; k < C; ++k) { g.push_back(&ct[k]); g.push_back(&co[k]); g.push_back(&cf[k]); }
+    fwd_chain(g, "critics");
+  }
+  // ---- loss
+  {
+    LossArgs la;
+    memset(&la, 0, sizeof(la));
+    la.M = M; la.B = B; la.Nq = Nq; la.Nt = a->Nt;
+    int G = 8;
+    while (G < Nq) G <<= 1;
+    la.G = G;
+    la.distributional = c.distributional; la.lowerbound = c.use_lowerbound; la.max_entropy = c.use_max_entropy;
+    la.gamma = (float)c.gamma; la.target_entropy = -(float)A; la.half_inv_nq = (float)(0.5 / (double)Nq);
+    la.st = dst; la.log_alpha = log_alpha;
+    la.z_target = a->buf("next_z"); la.q_pred = a->buf("q_pred"); la.z_frozen = a->buf("q_frozen");
+    la.logp_next = a->buf("next_log_pi"); la.logp = a->buf("log_pi");
+    la.reward = x.reward; la.task_done = x.task_done; la.mc_return = c.use_lowerbound ? x.mc_return : nullptr;
+    la.w = a->buf("w"); la.dz = a->buf("dz"); la.dzf = a->buf("dzf"); la.td_target = a->buf("td_target");
+    la.q_loss = a->buf("q_loss"); la.pi_loss = a->buf("pi_loss"); la.alpha_loss = a->buf("alpha_loss");
+    la.partials = a->buf("loss_partials");
+    b.func_stage("loss", [=](hipStream_t s) { return loss_launch(la, s); });
+    const int nblocks = loss_blocks(M, G);
+    float *scal = a->buf("scalars");
+    float *dla = a->buf("slabs") + a->log_alpha_off;
+    const float *parts = la.partials;
+    b.func_stage("loss_finish", [=](hipStream_t s) { return loss_finish_launch(parts, nblocks, M, Nq, dst, scal, dla, s); });
+  }
+  // ---- critic backward (online: wgrad + d state; frozen: d pi only)
+  {
+    const size_t nh = a->critic[0].hid.size();
+    for (int i = (int)nh - 1; i >= 0; --i) {
+      Stage &gs = b.gemm_stage("critics.dpre" + std::to_string(i));
+      for (int k = 0; k < C; ++k) {
+        gs.gemm.push_back(b.bwd_dpre(co[k], i, a->buf("dz") + k * Q, Nq));
+        gs.gemm.push_back(b.bwd_dpre(cf[k], i, a->buf("dzf") + k * Q, Nq));
+      }
+    }
+    // d pi = sum_c input-grad of the frozen critics' action columns
+    if (A <= SKINNY_MAX_OUT) {
+      Stage &ss = b.sfwd_stage("dpi");
+      SkinnyFwdProblem p;
+      memset(&p, 0, sizeof(p));
+      p.M = M; p.Nout = A; p.Y = a->buf("dpi"); p.ldy = A;
+      for (int k = 0; k < C; ++k) b.input_grad_skinny(cf[k], a->buf("dzf") + k * Q, Nq, L, p);
+      ss.sfwd.push_back(p);
+    } else {
+      Stage &gs = b.gemm_stage("dpi");
+      GemmProblem p = Builder::new_gemm(M, A, a->buf("dpi"), A);
+      for (int k = 0; k < C; ++k) b.input_grad_segs(cf[k], a->buf("dzf") + k * Q, Nq, L, p);
+      gs.gemm.push_back(p);
+    }
+  }
+  // ---- policy backward
+  {
+    const float *lo = ao.out, *nz = a->buf("noise_actor"), *pi = a->buf("pi"), *dpi = a->buf("dpi"), *w = a->buf("w");
+    float *dlo = a->buf("dlogits");
+    b.func_stage("policy_bwd", [=](hipStream_t s) { return policy_bwd_launch(lo, nz, pi, dpi, w, dst, M, A, dlo, s); });
+  }
+  // ---- actor backward
+  for (int i = (int)a->actor.hid.size() - 1; i >= 0; --i) {
+    Stage &gs = b.gemm_stage("actor.dpre" + std::to_string(i));
+    gs.gemm.push_back(b.bwd_dpre(ao, i, a->buf("dlogits"), a->actor.dout));
+  }
+  // ---- d state = sum over online critics and the actor
+  {
+    Stage &gs = b.gemm_stage("dstate");
+    GemmProblem p = Builder::new_gemm(M, L, a->buf("dstate"), L);
+    for (int k = 0; k < C; ++k) b.input_grad_segs(co[k], a->buf("dz") + k * Q, Nq, 0, p);
+    b.input_grad_segs(ao, a->buf("dlogits"), a->actor.dout, 0, p);
+    gs.gemm.push_back(p);
+  }
+  // ---- encoder backward over the M rows that carry gradient (next-only rows get none)
+  MlpInst jb = jo, eb = eo;
+  jb.rows = M; eb.rows = M;
+  for (int i = (int)a->joiner.hid.size() - 1; i >= 0; --i) {
+    Stage &gs = b.gemm_stage("joiner.dpre" + std::to_string(i));
+    gs.gemm.push_back(b.bwd_dpre(jb, i, a->buf("dstate"), L));
+  }
+  {
+    Stage &gs = b.gemm_stage("denc");
+    GemmProblem p = Builder::new_gemm(M, c.enc_features, a->buf("denc"), c.enc_features);
+    b.input_grad_segs(jb, a->buf("dstate"), L, 0, p);
+    gs.gemm.push_back(p);
+  }
+  for (int i = (int)a->enc_obs.hid.size() - 1; i >= 0; --i) {
+    Stage &gs = b.gemm_stage("enc_obs.dpre" + std::to_string(i));
+    gs.gemm.push_back(b.bwd_dpre(eb, i, a->buf("denc"), c.enc_features));
+  }
+  // ---- all weight gradients: one grouped MFMA launch + one skinny launch, into K-split slabs
+  {
+    Stage gs, ws;
+    gs.kind = ST_GEMM; gs.name = "wgrad";
+    ws.kind = ST_SKINNY_WGRAD; ws.name = "wgrad_skinny";
+    for (int k = 0; k < C; ++k) b.wgrads(co[k], a->buf("dz") + k * Q, Nq, gs, ws);
+    b.wgrads(ao, a->buf("dlogits"), a->actor.dout, gs, ws);
+    b.wgrads(jb, a->buf("dstate"), L, gs, ws);
+    b.wgrads(eb, a->buf("denc"), c.enc_features, gs, ws);
+    a->stages.push_back(gs);
+    a->stages.push_back(ws);
+  }
+  {
+    const float *slabs = a->buf("slabs");
+    float *grads = a->grads;
+    const int S = a->nsplit;
+    const long long P = a->n_train;
+    b.func_stage("reduce_slabs", [=](hipStream_t s) { return reduce_slabs_launch(slabs, S, P, grads, s); });
+  }
+  // ---- Adam + polyak (+ frozen copy)
+  {
+    AdamArgs ad;
+    memset(&ad, 0, sizeof(ad));
+    ad.n = a->n_train; ad.params = a->params; ad.m = a->adam_m; ad.v = a->adam_v; ad.grads = a->grads;
+    ad.grad_scale = 1.0f;
+    ad.one_minus_b1 = (float)(1.0 - c.beta1); ad.b2 = (float)c.beta2; ad.one_minus_b2 = (float)(1.0 - c.beta2);
+    ad.eps = (float)c.adam_eps; ad.st = dst; ad.targets = a->targets; ad.tgt_begin = a->tgt_begin; ad.tgt_end = a->tgt_end;
+    ad.tau = (float)c.tau; ad.one_minus_tau = (float)(1.0 - c.tau); ad.hard = c.hard_updates;
+    ad.frozen = c.keep_frozen_copy ? a->frozen : nullptr; ad.frozen_begin = a->crit_begin; ad.frozen_end = a->crit_end;
+    const double lr = c.lr, b1 = c.beta1, b2 = c.beta2;
+    b.func_stage("tick_adam", [=](hipStream_t s) { return tick_adam_launch(dst, lr, b1, b2, s); }, FDQL_PHASE_APPLY);
+    b.func_stage("adam_polyak", [=](hipStream_t s) { return adam_launch(ad, s); }, FDQL_PHASE_APPLY);
+  }
+  int rc = upload_tables(a);
+  if (rc) return rc;
+  a->plan_ready = true;
+  return 0;
+}
+
+hipError_t run_stage(fdql_agent *a, Stage &s, hipStream_t stream) {
+  switch (s.kind) {
+    case ST_GEMM: return gemm_launch((const GemmProblem *)s.dev, (int)s.gemm.size(), s.blocks, stream);
+    case ST_SKINNY_FWD: return skinny_fwd_launch_host(s.sfwd.data(), (const SkinnyFwdProblem *)s.dev, (int)s.sfwd.size(), s.blocks, stream);
+    case ST_SKINNY_WGRAD: return skinny_wgrad_launch_host(s.swg.data(), (const SkinnyWgradProblem *)s.dev, (int)s.swg.size(), s.blocks, stream);
+    case ST_FUNC: return s.fn(stream);
+  }
+  return hipSuccess;
+}
+
+int prepare_update(fdql_agent *a, const fdql_batch_t *batch, const float *noise_target, const float *noise_actor,
+                   uint64_t seed) {
+  if (!a || !a->bound) { set_error("fdql_agent_update: agent not bound"); return FDQL_ESTATE; }
+  FDQL_REQUIRE(batch && batch->obs_1d && batch->action && batch->reward && batch->task_done && batch->episode_step,
+               "fdql_agent_update: batch needs obs_1d, action, reward, task_done, episode_step");
+  FDQL_REQUIRE(!a->cfg.goal_dim || (batch->achieved_goal && batch->desired_goal), "goal_dim > 0 needs achieved/desired goal");
+  FDQL_REQUIRE(!a->cfg.use_lowerbound || batch->mc_return, "use_lowerbound needs mc_return");
+  if (!a->plan_ready || memcmp(&a->batch, batch, sizeof(*batch)) != 0) {
+    a->batch = *batch;
+    int rc = build_plan(a);
+    if (rc) return rc;
+  }
+  a->noise_t = noise_target;
+  a->noise_a = noise_actor;
+  a->seed = seed;
+  return 0;
+}
+
+}  // namespace
+
+// ======================================================================================= C ABI
+extern "C" {
+
+const char *fdql_last_error(void) { return g_err; }
+int fdql_version(void) { return 1; }
+
+int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {
+  FDQL_REQUIRE(out && cfg, "null argument");
+  const fdql_agent_config_t &c = *cfg;
+  FDQL_REQUIRE(c.obs_dim > 0 && c.act_dim > 0 && c.goal_dim >= 0, "bad obs/act/goal dims");
+  FDQL_REQUIRE(!c.discrete, "discrete (Gumbel-softmax) actor is not implemented in the HIP path yet");
+  FDQL_REQUIRE(c.n_critics > 0 && c.n_quantiles > 0 && c.n_critics * c.n_quantiles <= 256, "need 0 < C*Q <= 256");
+  FDQL_REQUIRE(2 * c.n_critics + 2 <= GEMM_MAX_SEG, "too many critics for one d(state) GEMM");
+  FDQL_REQUIRE(c.T >= 2 && c.B >= 1, "need T >= 2, B >= 1");
+  FDQL_REQUIRE(c.n_enc_hidden >= 0 && c.n_enc_hidden <= FDQL_MAX_HIDDEN && c.n_joint_hidden >= 0 &&
+                   c.n_joint_hidden <= FDQL_MAX_HIDDEN && c.n_pi_hidden >= 0 && c.n_pi_hidden <= FDQL_MAX_HIDDEN &&
+                   c.n_critic_hidden >= 0 && c.n_critic_hidden <= FDQL_MAX_HIDDEN, "bad hidden layer counts");
+  FDQL_REQUIRE(c.latent > 0 && c.enc_features > 0, "bad latent dims");
+  FDQL_REQUIRE(c.n_critic_hidden + 1 + 1 <= SKINNY_MAX_SEG && c.n_quantiles <= SKINNY_MAX_OUT,
+               "critic head too wide for the skinny head kernel (Q <= 32)");
+  fdql_agent *a = new fdql_agent();
+  a->cfg = c;
+  a->T = c.T; a->B = c.B; a->N = c.T * c.B; a->M = (c.T - 1) * c.B; a->A = c.act_dim; a->L = c.latent;
+  a->Nq = c.n_critics * c.n_quantiles;
+  if (c.distributional) {
+    const int drop = (int)(c.drop_frac * a->Nq);
+    a->Nt = drop > 0 ? a->Nq - drop : 0;  // quirk q6: [:-0] is empty
+    if (a->Nt <= 0) { delete a; set_error("top_quantiles_to_drop leaves no target atoms (reference slice [:-0] is empty)"); return FDQL_EINVAL; }
+  } else {
+    a->Nt = 1;
+  }
+  int s = a->M / 512;
+  a->nsplit = s < 1 ? 1 : (s > 8 ? 8 : s);
+  layout(a);
+  carve(a);
+  a->ws_need = a->carve_top;
+  *out = a;
+  return 0;
+}
+
+int fdql_agent_destroy(fdql_agent_t *a) {
+  if (!a) return 0;
+  if (a->tables_dev) (void)hipFree(a->tables_dev);
+  delete a;
+  return 0;
+}
+
+int64_t fdql_agent_arena_floats(const fdql_agent_t *a, int32_t which) {
+  if (!a) return -1;
+  if (which == 0) return a->n_train;
+  if (which == 1) return a->tgt_end - a->tgt_begin;
+  if (which == 2) return a->crit_end - a->crit_begin;
+  return -1;
+}
+
+int32_t fdql_agent_tensor_info(const fdql_agent_t *a, int32_t index, char *name, int32_t name_cap, int32_t *arena,
+                               int64_t *offset_floats, int32_t *shape2) {
+  if (!a) return -1;
+  if (index < 0) return (int32_t)a->tensors.size();
+  if (index >= (int32_t)a->tensors.size()) return -1;
+  const TensorInfo &t = a->tensors[index];
+  if (name && name_cap > 0) { strncpy(name, t.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+  if (arena) *arena = t.arena;
+  if (offset_floats) *offset_floats = t.off;
+  if (shape2) { shape2[0] = t.rows; shape2[1] = t.cols; }
+  return 0;
+}
+
+int64_t fdql_agent_workspace_bytes(const fdql_agent_t *a) { return a ? a->ws_need : -1; }
+
+int fdql_agent_bind(fdql_agent_t *a, float *params, float *grads, float *adam_m, float *adam_v, float *targets,
+                    float *frozen, void *workspace, int64_t workspace_bytes) {
+  FDQL_REQUIRE(a && params && grads && adam_m && adam_v && targets && workspace, "null pointer in bind");
+  FDQL_REQUIRE(workspace_bytes >= a->ws_need, "workspace too small: %lld < %lld", (long long)workspace_bytes, (long long)a->ws_need);
+  FDQL_REQUIRE(!a->cfg.keep_frozen_copy || frozen, "keep_frozen_copy needs a frozen arena");
+  FDQL_REQUIRE((reinterpret_cast<uintptr_t>(params) & 15) == 0 && (reinterpret_cast<uintptr_t>(grads) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(targets) & 15) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0,
+               "arenas must be 16-byte aligned and the workspace 256-byte aligned");
+  a->params = params; a->grads = grads; a->adam_m = adam_m; a->adam_v = adam_v; a->targets = targets; a->frozen = frozen;
+  a->ws = (char *)workspace;
+  a->ws_bytes = workspace_bytes;
+  carve(a);
+  FDQL_HIP(hipMemset(workspace, 0, a->ws_need));
+  FDQL_HIP(hipMemset(grads, 0, a->n_train * 4));
+  FDQL_HIP(hipMemset(adam_m, 0, a->n_train * 4));
+  FDQL_HIP(hipMemset(adam_v, 0, a->n_train * 4));
+  DevState st;
+  memset(&st, 0, sizeof(st));
+  st.alpha_next = (float)exp(a->cfg.init_log_alpha);  // soft_actor_critic.py:41 (float64 exp)
+  st.alpha_cur = st.alpha_next;
+  FDQL_HIP(hipMemcpy(a->st(), &st, sizeof(st), hipMemcpyHostToDevice));
+  FDQL_HIP(hipDeviceSynchronize());
+  a->bound = true;
+  a->plan_ready = false;
+  return 0;
+}
+
+int fdql_agent_update(fdql_agent_t *a, const fdql_batch_t *batch, const float *noise_target, const float *noise_actor,
+                      uint64_t seed, int32_t phase, void *stream) {
+  if (phase != FDQL_PHASE_APPLY) {
+    int rc = prepare_update(a, batch, noise_target, noise_actor, seed);
+    if (rc) return rc;
+  } else if (!a || !a->plan_ready) {
+    set_error("FDQL_PHASE_APPLY before any FDQL_PHASE_GRAD");
+    return FDQL_ESTATE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  for (Stage &st : a->stages) {
+    if (phase != FDQL_PHASE_ALL && st.phase != phase) continue;
+    hipError_t e = run_stage(a, st, s);
+    if (e != hipSuccess) { set_error("stage %s: %s", st.name.c_str(), hipGetErrorString(e)); return FDQL_EHIP; }
+  }
+  return 0;
+}
+
+int32_t fdql_agent_profile_update(fdql_agent_t *a, const fdql_batch_t *batch, const float *noise_target,
+                                  const float *noise_actor, uint64_t seed, fdql_kernel_time_t *out, int32_t cap,
+                                  void *stream) {
+  int rc = prepare_update(a, batch, noise_target, noise_actor, seed);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n = a->stages.size();
+  std::vector<hipEvent_t> ev(n + 1);
+  for (auto &e : ev) FDQL_HIP(hipEventCreate(&e));
+  FDQL_HIP(hipEventRecord(ev[0], s));
+  for (size_t i = 0; i < n; ++i) {
+    hipError_t e = run_stage(a, a->stages[i], s);
+    if (e != hipSuccess) { set_error("stage %s: %s", a->stages[i].name.c_str(), hipGetErrorString(e)); return FDQL_EHIP; }
+    FDQL_HIP(hipEventRecord(ev[i + 1], s));
+  }
+  FDQL_HIP(hipStreamSynchronize(s));
+  int32_t cnt = 0;
+  for (size_t i = 0; i < n && cnt < cap; ++i, ++cnt) {
+    float ms = 0;
+    FDQL_HIP(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+    const Stage &st = a->stages[i];
+    const char *kind = st.kind == ST_GEMM ? "gemm:" : st.kind == ST_SKINNY_FWD ? "skinny_fwd:" : st.kind == ST_SKINNY_WGRAD ? "skinny_wgrad:" : "k:";
+    snprintf(out[cnt].name, sizeof(out[cnt].name), "%s%s", kind, st.name.c_str());
+    out[cnt].ms = ms;
+    out[cnt].flops = st.flops;
+    out[cnt].bytes = st.bytes;
+  }
+  for (auto &e : ev) (void)hipEventDestroy(e);
+  return cnt;
+}
+
+int fdql_agent_scalars(fdql_agent_t *a, float *host_out8, void *stream) {
+  if (!a || !a->bound) { set_error("agent not bound"); return FDQL_ESTATE; }
+  DevState st;
+  FDQL_HIP(hipMemcpyAsync(host_out8, a->buf("scalars"), 8 * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  FDQL_HIP(hipMemcpyAsync(&st, a->st(), sizeof(st), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  FDQL_HIP(hipStreamSynchronize((hipStream_t)stream));
+  host_out8[7] = (float)st.step;  // optimiser steps applied so far
+  return 0;
+}
+
+int fdql_agent_set_alpha(fdql_agent_t *a, float alpha, void *stream) {
+  if (!a || !a->bound) { set_error("agent not bound"); return FDQL_ESTATE; }
+  DevState st;
+  FDQL_HIP(hipStreamSynchronize((hipStream_t)stream));
+  FDQL_HIP(hipMemcpy(&st, a->st(), sizeof(st), hipMemcpyDeviceToHost));
+  st.alpha_next = alpha;
+  st.alpha_cur = alpha;
+  FDQL_HIP(hipMemcpy(a->st(), &st, sizeof(st), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int fdql_agent_set_step(fdql_agent_t *a, int32_t step, void *stream) {
+  if (!a || !a->bound) { set_error("agent not bound"); return FDQL_ESTATE; }
+  DevState st;
+  FDQL_HIP(hipStreamSynchronize((hipStream_t)stream));
+  FDQL_HIP(hipMemcpy(&st, a->st(), sizeof(st), hipMemcpyDeviceToHost));
+  st.step = step;
+  FDQL_HIP(hipMemcpy(a->st(), &st, sizeof(st), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int fdql_agent_debug_ptr(fdql_agent_t *a, const char *name, const float **dev_ptr, int64_t *count) {
+  if (!a || !a->bound) { set_error("agent not bound"); return FDQL_ESTATE; }
+  auto it = a->named.find(name);
+  FDQL_REQUIRE(it != a->named.end(), "unknown buffer '%s'", name);
+  *dev_ptr = reinterpret_cast<const float *>(a->ws + it->second.first);
+  if (count) *count = it->second.second;
+  return 0;
+}
+
+int fdql_agent_stats(const fdql_agent_t *a, fdql_agent_stats_t *out) {
+  FDQL_REQUIRE(a && out, "null argument");
+  memset(out, 0, sizeof(*out));
+  out->params = a->n_train;
+  for (const Stage &s : a->stages) {
+    out->n_launches++;
+    if (s.kind == ST_GEMM) { out->gemm_flops += s.flops; out->n_gemm_launches++; }
+    if (s.kind == ST_SKINNY_FWD || s.kind == ST_SKINNY_WGRAD) out->skinny_flops += s.flops;
+  }
+  return 0;
+}
+
+int fdql_test_gemm(const float *A, int32_t lda, int32_t a_kc, const float *B, int32_t ldb, int32_t b_kc,
+                   const float *bias, float *C, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t epilogue,
+                   const float *ref, int32_t ldref, int32_t ksplit, void *stream) {
+  GemmProblem p;
+  memset(&p, 0, sizeof(p));
+  p.M = M; p.N = N; p.C = C; p.ldc = ldc; p.ksplit = ksplit < 1 ? 1 : ksplit; p.split_stride = (long long)M * ldc;
+  p.bias = bias; p.epi = epilogue; p.ref = ref; p.ldref = ldref;
+  p.nseg = 1;
+  p.seg[0].A = A; p.seg[0].lda = lda; p.seg[0].a_kc = a_kc; p.seg[0].B = B; p.seg[0].ldb = ldb; p.seg[0].b_kc = b_kc; p.seg[0].K = K;
+  const int blocks = gemm_finalize(&p, 1);
+  GemmProblem *dev = nullptr;
+  FDQL_HIP(hipMalloc(&dev, sizeof(p)));
+  FDQL_HIP(hipMemcpy(dev, &p, sizeof(p), hipMemcpyHostToDevice));
+  hipError_t e = gemm_launch(dev, 1, blocks, (hipStream_t)stream);
+  if (e != hipSuccess) { set_error("gemm launch: %s", hipGetErrorString(e)); (void)hipFree(dev); return FDQL_EHIP; }
+  FDQL_HIP(hipStreamSynchronize((hipStream_t)stream));
+  FDQL_HIP(hipFree(dev));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,108 @@
+// Internal declarations shared by the HIP translation units of libfdql_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/fdql.h"
+
+namespace fdql {
+
+void set_error(const char *fmt, ...);
+
+#define FDQL_HIP(call)                                                                        \
+  do {                                                                                        \
+    hipError_t _e = (call);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      fdql::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return FDQL_EHIP;                                                                       \
+    }                                                                                         \
+  } while (0)
+
+#define FDQL_REQUIRE(cond, ...)      \
+  do {                               \
+    if (!(cond)) {                   \
+      fdql::set_error(__VA_ARGS__);  \
+      return FDQL_EINVAL;            \
+    }                                \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------
+// Grouped, K-segmented fp32 MFMA GEMM (gemm.hip)
+//   C[M,N] (+split slabs) = epi( sum_seg A_seg[M,K_seg] * B_seg[K_seg,N] + bias )
+// Operand element (r,k): kc=1 -> P[r*ld + k] (K contiguous), kc=0 -> P[k*ld + r].
+// ---------------------------------------------------------------------------------------
+constexpr int GEMM_MAX_SEG = 24;
+
+struct GemmSeg {
+  const float *A;
+  const float *B;
+  int lda, ldb;
+  int K;
+  int a_kc, b_kc;
+};
+
+enum GemmEpilogue { EPI_NONE = 0, EPI_LRELU = 1, EPI_LRELU_GRAD = 2 };
+
+struct GemmProblem {
+  int M, N;
+  int nseg;
+  int ksplit;              // >1 only with nseg == 1: K range cut in ksplit slabs
+  float *C;
+  int ldc;
+  long long split_stride;  // floats between consecutive K-split slabs of C
+  const float *bias;       // [N] or null
+  int epi;
+  const float *ref;        // EPI_LRELU_GRAD: activation output whose sign gates the gradient
+  int ldref;
+  int tiles_m, tiles_n;    // filled by gemm_finalize
+  int tile_start;          // first block id of this problem in its launch
+  GemmSeg seg[GEMM_MAX_SEG];
+};
+
+// Fills tiles_* / tile_start for a launch group; returns the total number of blocks.
+int gemm_finalize(GemmProblem *probs, int nprob);
+double gemm_flops(const GemmProblem &p);
+// probs_dev: device copy of the finalized group.
+hipError_t gemm_launch(const GemmProblem *probs_dev, int nprob, int total_blocks, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------
+// Skinny ops (kernels.hip): heads with N_out <= 32, bias/colsum reductions
+// ---------------------------------------------------------------------------------------
+constexpr int SKINNY_MAX_SEG = 24;
+constexpr int SKINNY_MAX_OUT = 32;
+
+struct SkinnySeg {
+  const float *X;  // [M, K] row-major, ld
+  int ldx, K;
+  const float *W;  // weight element (n, k) = W[n*wsn + k*wsk]
+  int wsn, wsk;
+};
+struct SkinnyFwdProblem {
+  int M, Nout, nseg;
+  float *Y;
+  int ldy;
+  const float *bias;  // [Nout] or null
+  int row_start;      // filled by finalize: first block id
+  SkinnySeg seg[SKINNY_MAX_SEG];
+};
+int skinny_fwd_finalize(SkinnyFwdProblem *p, int n);
+
+// dW(q, k) (slab s) = sum_{m in split s} dY[m, q] * X[m, k], written to dW[q*sq + k*sk].
+// dY == null: dY = 1, Nout = 1 (column sums of X: bias gradients).
+struct SkinnyWgradProblem {
+  int M, Nout, K;
+  const float *dY;
+  int lddy;
+  const float *X;
+  int ldx;
+  float *dW;               // slab 0 destination
+  long long sq, sk;
+  long long split_stride;
+  int nsplit;
+  int block_start, col_blocks;
+};
+int skinny_wgrad_finalize(SkinnyWgradProblem *p, int n);
+
+}  // namespace fdql

@@ -1,0 +1,582 @@
+// Non-GEMM kernels of the SAC/TQC update: skinny heads, policy sampling, the TQC/SAC
+// loss with its analytic gradient, slab reduction, Adam + polyak.  gfx950, wave64.
+#include "common.h"
+#include "update_kernels.h"
+
+namespace fdql {
+
+// ======================================================================================
+// Skinny forward: Y[m, q] = sum_seg sum_k X_seg[m, k] * W_seg(q, k) + bias[q],  Nout <= 32
+// One wave per row, lanes stride over k (coalesced), weights staged once per block in LDS
+// as [k][Nout(+pad)], butterfly reduction per output.  Used for the critic heads (Nout=Q),
+// the actor head (Nout = 2A) and the d(pi) dgrad of the frozen critics.
+// ======================================================================================
+constexpr int SK_ROWS_PER_BLOCK = 64;
+constexpr int SK_THREADS = 256;
+
+template <int NOUT_MAX>
+__global__ __launch_bounds__(SK_THREADS) void k_skinny_fwd(const SkinnyFwdProblem *__restrict__ probs, int nprob) {
+  extern __shared__ __attribute__((aligned(16))) float wlds[];
+  const int bid = blockIdx.x;
+  int pi = 0;
+  for (int i = 1; i < nprob; ++i)
+    if (bid >= probs[i].row_start) pi = i;
+  const SkinnyFwdProblem &P = probs[pi];
+  const int Nout = P.Nout, NP = Nout | 1, nseg = P.nseg, M = P.M;
+  const int tid = threadIdx.x;
+
+  // stage all weights: wlds[(koff + k) * NP + q]
+  int koff = 0;
+  for (int s = 0; s < nseg; ++s) {
+    const SkinnySeg &S = P.seg[s];
+    const int tot = S.K * Nout;
+    for (int e = tid; e < tot; e += SK_THREADS) {
+      int k, q;
+      if (S.wsk == 1) { q = e / S.K; k = e - q * S.K; }   // consecutive threads walk k (contiguous in memory)
+      else { k = e / Nout; q = e - k * Nout; }            // consecutive threads walk q
+      wlds[(koff + k) * NP + q] = S.W[(long long)q * S.wsn + (long long)k * S.wsk];
+    }
+    koff += S.K;
+  }
+  __syncthreads();
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int row0 = (bid - P.row_start) * SK_ROWS_PER_BLOCK;
+  for (int rr = wave; rr < SK_ROWS_PER_BLOCK; rr += SK_THREADS / 64) {
+    const int m = row0 + rr;
+    if (m >= M) break;
+    float acc[NOUT_MAX];
+#pragma unroll
+    for (int q = 0; q < NOUT_MAX; ++q) acc[q] = 0.f;
+    int ko = 0;
+    for (int s = 0; s < nseg; ++s) {
+      const SkinnySeg &S = P.seg[s];
+      const float *x = S.X + (long long)m * S.ldx;
+      for (int k = lane; k < S.K; k += 64) {
+        const float xv = x[k];
+        const float *w = &wlds[(ko + k) * NP];
+#pragma unroll
+        for (int q = 0; q < NOUT_MAX; ++q)
+          if (q < Nout) acc[q] = fmaf(xv, w[q], acc[q]);
+      }
+      ko += S.K;
+    }
+#pragma unroll
+    for (int q = 0; q < NOUT_MAX; ++q) {
+      if (q < Nout) {
+        float v = acc[q];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) P.Y[(long long)m * P.ldy + q] = v + (P.bias ? P.bias[q] : 0.f);
+      }
+    }
+  }
+}
+
+int skinny_fwd_finalize(SkinnyFwdProblem *p, int n) {
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    p[i].row_start = total;
+    total += (p[i].M + SK_ROWS_PER_BLOCK - 1) / SK_ROWS_PER_BLOCK;
+  }
+  return total;
+}
+
+hipError_t skinny_fwd_launch_host(const SkinnyFwdProblem *host, const SkinnyFwdProblem *dev, int n, int total_blocks,
+                                  hipStream_t s) {
+  if (total_blocks <= 0) return hipSuccess;
+  int max_out = 0;
+  size_t lds = 0;
+  for (int i = 0; i < n; ++i) {
+    max_out = host[i].Nout > max_out ? host[i].Nout : max_out;
+    size_t k = 0;
+    for (int j = 0; j < host[i].nseg; ++j) k += host[i].seg[j].K;
+    size_t b = k * (size_t)(host[i].Nout | 1) * sizeof(float);
+    lds = b > lds ? b : lds;
+  }
+  if (max_out <= 4) hipLaunchKernelGGL(k_skinny_fwd<4>, dim3(total_blocks), dim3(SK_THREADS), lds, s, dev, n);
+  else if (max_out <= 16) hipLaunchKernelGGL(k_skinny_fwd<16>, dim3(total_blocks), dim3(SK_THREADS), lds, s, dev, n);
+  else hipLaunchKernelGGL(k_skinny_fwd<32>, dim3(total_blocks), dim3(SK_THREADS), lds, s, dev, n);
+  return hipGetLastError();
+}
+
+// ======================================================================================
+// Skinny wgrad / column sums: dW[q, k] (slab) = sum_{m in split} dY[m, q] * X[m, k]
+// Block = 64 columns x 4 row lanes (one wave per row lane, so dY[m, q] is wave-uniform);
+// LDS reduction over the 4 row lanes; one slab per split (deterministic, no atomics).
+// dY == null: dY = 1 (column sums of X -> bias gradients), Nout = 1.
+// ======================================================================================
+constexpr int SW_COLS = 64, SW_THREADS = 256;
+
+template <int NOUT_MAX>
+__global__ __launch_bounds__(SW_THREADS) void k_skinny_wgrad(const SkinnyWgradProblem *__restrict__ probs, int nprob) {
+  __shared__ float red[3][NOUT_MAX][SW_COLS];
+  const int bid = blockIdx.x;
+  int pi = 0;
+  for (int i = 1; i < nprob; ++i)
+    if (bid >= probs[i].block_start) pi = i;
+  const SkinnyWgradProblem &P = probs[pi];
+  const int local = bid - P.block_start;
+  const int split = local / P.col_blocks;
+  const int cb = local - split * P.col_blocks;
+  const int tid = threadIdx.x, lane = tid & 63, rg = tid >> 6;
+  const int k = cb * SW_COLS + lane;
+  const int Nout = P.Nout;
+  const int per = (P.M + P.nsplit - 1) / P.nsplit;
+  const int m0 = split * per, m1 = min(P.M, m0 + per);
+  const bool kin = k < P.K;
+
+  float acc[NOUT_MAX];
+#pragma unroll
+  for (int q = 0; q < NOUT_MAX; ++q) acc[q] = 0.f;
+  const float *X = P.X;
+  const float *dY = P.dY;
+  for (int m = m0 + rg; m < m1; m += 4) {
+    const float xv = (kin && X) ? X[(long long)m * P.ldx + k] : 1.f;
+    if (dY) {
+      const float *d = dY + (long long)m * P.lddy;
+#pragma unroll
+      for (int q = 0; q < NOUT_MAX; ++q)
+        if (q < Nout) acc[q] = fmaf(d[q], xv, acc[q]);
+    } else {
+      acc[0] += xv;
+    }
+  }
+  if (rg > 0) {
+#pragma unroll
+    for (int q = 0; q < NOUT_MAX; ++q)
+      if (q < Nout) red[rg - 1][q][lane] = acc[q];
+  }
+  __syncthreads();
+  if (rg == 0 && kin) {
+    float *dst = P.dW + (long long)split * P.split_stride;
+#pragma unroll
+    for (int q = 0; q < NOUT_MAX; ++q)
+      if (q < Nout) dst[(long long)q * P.sq + (long long)k * P.sk] = ((acc[q] + red[0][q][lane]) + red[1][q][lane]) + red[2][q][lane];
+  }
+}
+
+int skinny_wgrad_finalize(SkinnyWgradProblem *p, int n) {
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    p[i].col_blocks = (p[i].K + SW_COLS - 1) / SW_COLS;
+    p[i].block_start = total;
+    total += p[i].col_blocks * p[i].nsplit;
+  }
+  return total;
+}
+
+hipError_t skinny_wgrad_launch_host(const SkinnyWgradProblem *host, const SkinnyWgradProblem *dev, int n,
+                                    int total_blocks, hipStream_t s) {
+  if (total_blocks <= 0) return hipSuccess;
+  int max_out = 1;
+  for (int i = 0; i < n; ++i) max_out = host[i].Nout > max_out ? host[i].Nout : max_out;
+  if (max_out <= 4) hipLaunchKernelGGL(k_skinny_wgrad<4>, dim3(total_blocks), dim3(SW_THREADS), 0, s, dev, n);
+  else if (max_out <= 16) hipLaunchKernelGGL(k_skinny_wgrad<16>, dim3(total_blocks), dim3(SW_THREADS), 0, s, dev, n);
+  else hipLaunchKernelGGL(k_skinny_wgrad<32>, dim3(total_blocks), dim3(SW_THREADS), 0, s, dev, n);
+  return hipGetLastError();
+}
+
+// ======================================================================================
+// Philox4x32-10 (counter-based RNG for perf runs; parity runs pass noise in)
+// ======================================================================================
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ float u32_to_unit_open(uint32_t x) {  // (0, 1)
+  return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+
+// one N(0,1) (continuous) or U(0,1) (discrete) draw for element e of stream `which`
+__device__ __forceinline__ float device_noise(uint64_t seed, uint32_t step, uint32_t which, uint32_t e, bool normal) {
+  uint32_t r[4];
+  philox4x32_10(e >> 1, step, which, 0x5eedu, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+  if (!normal) return u32_to_unit_open(r[(e & 1) * 2]);
+  const float u1 = u32_to_unit_open(r[0]), u2 = u32_to_unit_open(r[1]);
+  const float rad = sqrtf(-2.0f * logf(u1));
+  float sn, cs;
+  sincosf(6.28318530717958647692f * u2, &sn, &cs);
+  return (e & 1) ? rad * sn : rad * cs;
+}
+
+// ======================================================================================
+// prep: mask / is_contiguous / per-window normaliser -> per-row loss weight
+//   deepQlearning.py:201-203, 222-225, 249
+// ======================================================================================
+__global__ void k_prep(const float *__restrict__ task_done, const float *__restrict__ episode_step, int T, int B,
+                       float inv_global_batch, float *__restrict__ w, float *__restrict__ contig) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float cnt = 0.f;
+  for (int t = 0; t < T - 1; ++t) {
+    const int m = t * B + b;
+    const bool c = (episode_step[m + B] == episode_step[m] + 1.0f) && (task_done[m] == 0.f);
+    contig[m] = c ? 1.f : 0.f;
+    cnt += c ? 1.f : 0.f;
+  }
+  const float denom = cnt + 1e-4f;
+  for (int t = 0; t < T - 1; ++t) {
+    const int m = t * B + b;
+    w[m] = ((contig[m] / denom) * inv_global_batch) / (float)T;
+  }
+}
+
+// ======================================================================================
+// tick: optimiser step counter, Adam bias corrections (double, like the Python floats in
+// torch.optim.Adam), and the one-step-lagged alpha (soft_actor_critic.py:41,152)
+// ======================================================================================
+__global__ void k_tick_alpha(DevState *st, const float *log_alpha) {
+  // get_losses() side effect in the reference: curr_alpha <- exp(log_alpha) AFTER it was used
+  st->alpha_cur = st->alpha_next;
+  st->alpha_next = expf(*log_alpha);
+}
+
+__global__ void k_tick_adam(DevState *st, double lr, double b1, double b2) {
+  st->step += 1;
+  const double bc1 = 1.0 - pow(b1, (double)st->step);
+  const double bc2 = 1.0 - pow(b2, (double)st->step);
+  st->neg_step_size = (float)(-(lr / bc1));
+  st->bc2_sqrt = (float)sqrt(bc2);
+}
+
+// ======================================================================================
+// tanh-Gaussian policy head: sample, log-prob (gaussian_mlp.py:15-39) and its backward
+// ======================================================================================
+__global__ void k_policy_fwd(PolicyFwdArgs a0, PolicyFwdArgs a1, int nprob, int M, int A, const DevState *st,
+                             uint64_t seed) {
+#pragma clang fp contract(off)
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int p = gid / M;
+  if (p >= nprob) return;
+  const int m = gid - p * M;
+  const PolicyFwdArgs &a = p == 0 ? a0 : a1;
+  const float *lo = a.logits + (long long)m * 2 * A;
+  float logp = 0.f;
+  for (int j = 0; j < A; ++j) {
+    const float mean = lo[j];
+    const float ls = fminf(fmaxf(lo[A + j], -20.f), 2.f);
+    // transcendental functions through double, rounded once to f32: the log-prob below is
+    // ill-conditioned near |a| -> 1 (d logp = 2a/(1-a^2+1e-4) da), so every ulp of exp/tanh/log
+    // matters when comparing with the CPU path's (<= 1 ulp) vector math library.
+    const float sd = (float)exp((double)ls);
+    const float eps = a.noise ? a.noise[(long long)m * A + j]
+                              : device_noise(seed, (uint32_t)st->step, a.which, (uint32_t)(m * A + j), true);
+    if (a.noise_out) a.noise_out[(long long)m * A + j] = eps;
+    const float x = mean + eps * sd;
+    const float d = x - mean;
+    float lp = -(d * d) / (2.f * (sd * sd)) - (float)log((double)sd) - 0.91893853320467274178f;
+    const float act = (float)tanh((double)x);
+    lp -= (float)log((double)((1.f - act * act) + 1e-4f));
+    logp += lp;
+    a.action[(long long)m * A + j] = act;
+  }
+  a.logp[m] = logp;
+}
+
+// d logits from d pi (through the frozen critics) and d logp = w*alpha.
+__global__ void k_policy_bwd(const float *__restrict__ logits, const float *__restrict__ noise,
+                             const float *__restrict__ action, const float *__restrict__ dpi,
+                             const float *__restrict__ w, const DevState *st, int M, int A, float *__restrict__ dlogits) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const float glp = w[m] * st->alpha_cur;
+  const float *lo = logits + (long long)m * 2 * A;
+  for (int j = 0; j < A; ++j) {
+    const float lsr = lo[A + j];
+    const float ls = fminf(fmaxf(lsr, -20.f), 2.f);
+    const float sd = (float)exp((double)ls);
+    const float eps = noise[(long long)m * A + j];
+    const float act = action[(long long)m * A + j];
+    const float om = 1.f - act * act;
+    const float dx = dpi[(long long)m * A + j] * om + glp * (2.f * act * om / (om + 1e-4f));
+    const float dsd = dx * eps - glp / sd;
+    float dls = dsd * sd;
+    if (lsr < -20.f || lsr > 2.f) dls = 0.f;
+    dlogits[(long long)m * 2 * A + j] = dx;
+    dlogits[(long long)m * 2 * A + A + j] = dls;
+  }
+}
+
+// ======================================================================================
+// Loss: TQC (sort pooled atoms, drop the top, entropy bonus, pairwise quantile-Huber with
+// tau over the pooled index; distributional_soft_actor_critic.py:40-103) or SAC-min
+// (soft_actor_critic.py:63-134); n-step lower bound; actor / alpha loss
+// (soft_actor_critic.py:136-154); analytic d loss / d q_pred; per-block partial sums.
+// G threads per row (G = pow2 >= Nq), 256/G rows per block.
+// ======================================================================================
+__device__ __forceinline__ float group_sum(float v, float *scratch, int g, int i, int G) {
+  // scratch: [rows][G]; all threads of the block call this together
+  scratch[g * G + i] = v;
+  __syncthreads();
+  for (int off = G >> 1; off >= 1; off >>= 1) {
+    if (i < off) scratch[g * G + i] += scratch[g * G + i + off];
+    __syncthreads();
+  }
+  const float r = scratch[g * G];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(256) void k_loss(LossArgs a) {
+  extern __shared__ float sm[];
+  const int G = a.G, RPB = 256 / G;
+  float *zs = sm;                 // [RPB][G]
+  float *ys = sm + RPB * G;       // [RPB][G]
+  float *scratch = sm + 2 * RPB * G;  // [RPB][G]
+  float *bsum = sm + 3 * RPB * G;     // [RPB][LOSS_NPART]
+  const int tid = threadIdx.x, g = tid / G, i = tid - g * G;
+  const int m = blockIdx.x * RPB + g;
+  const bool row_ok = m < a.M;
+  const int mm = row_ok ? m : a.M - 1;
+  const int Nq = a.Nq, Nt = a.Nt;
+  const bool act = row_ok && i < Nq;
+  const float alpha = a.st->alpha_cur;
+  const float log_alpha = *a.log_alpha;
+
+  const float zi = (i < Nq) ? a.z_target[(long long)mm * Nq + i] : INFINITY;
+  const float lpn = a.logp_next[mm];
+  const float ent = alpha * (-lpn);
+  const float rew = a.reward[mm + a.B];
+  const float maskg = (a.task_done[mm + a.B] == 0.f ? 1.f : 0.f) * a.gamma;
+  const float qi = (i < Nq) ? a.q_pred[(long long)mm * Nq + i] : 0.f;
+  const float mc = a.mc_return ? a.mc_return[mm + a.B] : 0.f;
+  const float wm = a.w[mm];
+
+  float loss_i = 0.f, grad_i = 0.f, lb_i = 0.f;
+  zs[g * G + i] = zi;
+  __syncthreads();
+  if (a.distributional) {
+    int rank = 0;
+    for (int j = 0; j < Nq; ++j) {
+      const float zj = zs[g * G + j];
+      rank += (zj < zi || (zj == zi && j < i)) ? 1 : 0;
+    }
+    if (i < Nq && rank < Nt) {
+      float tq = zi;
+      if (a.max_entropy) tq = tq + ent;
+      const float y = rew + maskg * tq;
+      ys[g * G + rank] = y;
+      if (row_ok) a.td_target[(long long)m * Nt + rank] = y;
+    }
+    __syncthreads();
+    if (i < Nq) {
+      const float tau = (float)i / (float)Nq + a.half_inv_nq;
+      float sl = 0.f, sg = 0.f;
+      for (int j = 0; j < Nt; ++j) {
+        const float d = ys[g * G + j] - qi;
+        const float ad = fabsf(d);
+        const float hub = ad > 1.f ? ad - 0.5f : d * d * 0.5f;
+        const float wt = fabsf(tau - (d < 0.f ? 1.f : 0.f));
+        sl += wt * hub;
+        const float dh = ad > 1.f ? (d > 0.f ? 1.f : -1.f) : d;
+        sg -= wt * dh;
+      }
+      const float inv = 1.f / (float)(Nq * Nt);
+      loss_i = sl * inv;
+      grad_i = sg * inv;
+      if (a.lowerbound) {
+        const float lb = mc - qi;
+        if (lb > 0.f) { lb_i = lb / (float)Nq; grad_i -= 1.f / (float)Nq; }
+      }
+    }
+  } else {
+    // SAC: min over all heads of (z + alpha*H), one target per row
+    float tq = zi;
+    if (a.max_entropy && i < Nq) tq = zi + ent;
+    ys[g * G + i] = tq;
+    __syncthreads();
+    float mn = INFINITY;
+    for (int j = 0; j < Nq; ++j) mn = fminf(mn, ys[g * G + j]);
+    const float y = rew + maskg * mn;
+    if (row_ok && i == 0) a.td_target[m] = y;
+    if (i < Nq) {
+      const float x = qi - y;
+      const float ax = fabsf(x);
+      float l = ax < 1.f ? 0.5f * x * x : ax - 0.5f;
+      float gq = ax < 1.f ? x : (x > 0.f ? 1.f : -1.f);
+      if (a.lowerbound) {
+        const float lb = fmaxf(mc - qi, 0.f);
+        if (lb != 0.f) { l = lb; gq = -1.f; }
+      }
+      loss_i = l / (float)Nq;
+      grad_i = gq / (float)Nq;
+    }
+  }
+  if (act) {
+    a.dz[(long long)m * Nq + i] = wm * grad_i;
+    a.dzf[(long long)m * Nq + i] = -wm / (float)Nq;
+  }
+  const float zf = (i < Nq) ? a.z_frozen[(long long)mm * Nq + i] : 0.f;
+  const float qloss = group_sum(loss_i + lb_i, scratch, g, i, G);
+  const float zfsum = group_sum(zf, scratch, g, i, G);
+  const float qsum = group_sum(i < Nq ? qi : 0.f, scratch, g, i, G);
+  const float viol = group_sum((a.lowerbound && i < Nq && (mc - qi) > 0.f) ? 1.f : 0.f, scratch, g, i, G);
+
+  if (i == 0) {
+    float part[LOSS_NPART];
+#pragma unroll
+    for (int k = 0; k < LOSS_NPART; ++k) part[k] = 0.f;
+    if (row_ok) {
+      const float lp = a.logp[m];
+      const float qpi = zfsum / (float)Nq;
+      const float pil = -(alpha * (-lp)) - qpi;
+      const float all = -(log_alpha * (a.target_entropy - (-lp)));
+      a.q_loss[m] = qloss;
+      a.pi_loss[m] = pil;
+      a.alpha_loss[m] = all;
+      part[0] = wm * ((qloss + pil) + all);
+      part[1] = qloss; part[2] = pil; part[3] = all;
+      part[4] = qsum; part[5] = viol;
+      part[6] = -wm * (a.target_entropy + lp);   // d loss / d log_alpha
+    }
+#pragma unroll
+    for (int k = 0; k < LOSS_NPART; ++k) bsum[g * LOSS_NPART + k] = part[k];
+  }
+  __syncthreads();
+  if (tid < LOSS_NPART) {
+    float s = 0.f;
+    for (int r = 0; r < RPB; ++r) s += bsum[r * LOSS_NPART + tid];
+    a.partials[(long long)blockIdx.x * LOSS_NPART + tid] = s;
+  }
+}
+
+hipError_t loss_launch(const LossArgs &a, hipStream_t s) {
+  const int RPB = 256 / a.G;
+  const int blocks = (a.M + RPB - 1) / RPB;
+  const size_t lds = (size_t)(3 * RPB * a.G + RPB * LOSS_NPART) * sizeof(float);
+  hipLaunchKernelGGL(k_loss, dim3(blocks), dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+
+// Sums the per-block partials in a fixed order; publishes the scalars and d log_alpha.
+__global__ __launch_bounds__(256) void k_loss_finish(const float *__restrict__ partials, int nblocks, int M, int Nq,
+                                                     const DevState *st, float *__restrict__ scalars,
+                                                     float *__restrict__ dlog_alpha) {
+  __shared__ float red[256][LOSS_NPART];
+  const int tid = threadIdx.x;
+  float acc[LOSS_NPART];
+#pragma unroll
+  for (int k = 0; k < LOSS_NPART; ++k) acc[k] = 0.f;
+  for (int b = tid; b < nblocks; b += 256)
+#pragma unroll
+    for (int k = 0; k < LOSS_NPART; ++k) acc[k] += partials[(long long)b * LOSS_NPART + k];
+#pragma unroll
+  for (int k = 0; k < LOSS_NPART; ++k) red[tid][k] = acc[k];
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if (tid < off)
+#pragma unroll
+      for (int k = 0; k < LOSS_NPART; ++k) red[tid][k] += red[tid + off][k];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    scalars[0] = red[0][0];
+    scalars[1] = red[0][1] / (float)M;
+    scalars[2] = red[0][2] / (float)M;
+    scalars[3] = red[0][3] / (float)M;
+    scalars[4] = red[0][4] / ((float)M * (float)Nq);
+    scalars[5] = red[0][5] / ((float)M * (float)Nq);
+    scalars[6] = st->alpha_cur;
+    scalars[7] = (float)st->step;
+    *dlog_alpha = red[0][6];
+  }
+}
+
+hipError_t loss_finish_launch(const float *partials, int nblocks, int M, int Nq, const DevState *st, float *scalars,
+                              float *dlog_alpha, hipStream_t s) {
+  hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(256), 0, s, partials, nblocks, M, Nq, st, scalars, dlog_alpha);
+  return hipGetLastError();
+}
+
+// ======================================================================================
+// Slab reduction, Adam + polyak (+ critic_frozen copy)
+// ======================================================================================
+__global__ void k_reduce_slabs(const float4 *__restrict__ slabs, int nslab, long long n4, float4 *__restrict__ grads) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 s = slabs[i];
+  for (int k = 1; k < nslab; ++k) {
+    const float4 v = slabs[(long long)k * n4 + i];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  grads[i] = s;
+}
+
+hipError_t reduce_slabs_launch(const float *slabs, int nslab, long long n, float *grads, hipStream_t s) {
+  const long long n4 = n / 4;
+  const int blocks = (int)((n4 + 255) / 256);
+  hipLaunchKernelGGL(k_reduce_slabs, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4 *>(slabs), nslab, n4,
+                     reinterpret_cast<float4 *>(grads));
+  return hipGetLastError();
+}
+
+__global__ void k_adam_polyak(AdamArgs a) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const float g = a.grads[i] * a.grad_scale;
+  const float p = a.params[i];
+  float m = a.m[i], v = a.v[i];
+  m = m + a.one_minus_b1 * (g - m);                 // exp_avg.lerp_(grad, 1 - beta1)
+  v = v * a.b2 + (a.one_minus_b2 * g) * g;          // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+  const float denom = sqrtf(v) / a.st->bc2_sqrt + a.eps;
+  const float pn = p + (a.st->neg_step_size * m) / denom;   // param.addcdiv_(m, denom, -step_size)
+  a.m[i] = m;
+  a.v[i] = v;
+  a.params[i] = pn;
+  if (i >= a.tgt_begin && i < a.tgt_end) {          // common.py:10-19
+    const long long j = i - a.tgt_begin;
+    a.targets[j] = a.hard ? pn : a.targets[j] * a.one_minus_tau + pn * a.tau;
+  }
+  if (a.frozen && i >= a.frozen_begin && i < a.frozen_end) a.frozen[i - a.frozen_begin] = p;
+}
+
+hipError_t adam_launch(const AdamArgs &a, hipStream_t s) {
+  const int blocks = (int)((a.n + 255) / 256);
+  hipLaunchKernelGGL(k_adam_polyak, dim3(blocks), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t prep_launch(const float *task_done, const float *episode_step, int T, int B, float inv_gb, float *w,
+                       float *contig, hipStream_t s) {
+  hipLaunchKernelGGL(k_prep, dim3((B + 255) / 256), dim3(256), 0, s, task_done, episode_step, T, B, inv_gb, w, contig);
+  return hipGetLastError();
+}
+
+hipError_t tick_alpha_launch(DevState *st, const float *log_alpha, hipStream_t s) {
+  hipLaunchKernelGGL(k_tick_alpha, dim3(1), dim3(1), 0, s, st, log_alpha);
+  return hipGetLastError();
+}
+
+hipError_t tick_adam_launch(DevState *st, double lr, double b1, double b2, hipStream_t s) {
+  hipLaunchKernelGGL(k_tick_adam, dim3(1), dim3(1), 0, s, st, lr, b1, b2);
+  return hipGetLastError();
+}
+
+hipError_t policy_fwd_launch(const PolicyFwdArgs &a0, const PolicyFwdArgs &a1, int nprob, int M, int A,
+                             const DevState *st, uint64_t seed, hipStream_t s) {
+  const int total = nprob * M;
+  hipLaunchKernelGGL(k_policy_fwd, dim3((total + 255) / 256), dim3(256), 0, s, a0, a1, nprob, M, A, st, seed);
+  return hipGetLastError();
+}
+
+hipError_t policy_bwd_launch(const float *logits, const float *noise, const float *action, const float *dpi,
+                             const float *w, const DevState *st, int M, int A, float *dlogits, hipStream_t s) {
+  hipLaunchKernelGGL(k_policy_bwd, dim3((M + 255) / 256), dim3(256), 0, s, logits, noise, action, dpi, w, st, M, A,
+                     dlogits);
+  return hipGetLastError();
+}
+
+}  // namespace fdql

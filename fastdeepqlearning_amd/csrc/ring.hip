@@ -1,0 +1,461 @@
+// HBM-resident structure-of-arrays replay ring + windowed minibatch gather + write-time
+// episode transforms (n-step return, hindsight relabel).  gfx950, wave64.
+//
+// Layout: one [maxlen, dim_k] f32 block per key (obs_1d, action, reward, ...), so a window
+// of T consecutive slots of one key is one contiguous run of T*dim_k floats (modulo the
+// wrap at `len`).  The gather writes the reference's [T, B, dim] batch layout
+// (franQ/Replay/replay_memory.py:62-70).
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+
+namespace fdql {
+
+constexpr int RING_MAX_KEYS = 16;
+constexpr int GATHER_THREADS = 256;
+constexpr int STAGE_WINDOWS = 16;        // windows per block in the LDS-staged path
+constexpr int STAGE_LDS_FLOATS = 12288;  // 48 KiB of staging per block
+
+struct GatherKey {
+  const float *src;  // [maxlen, dim]
+  float *dst;        // [T, B, dim]
+  int dim;
+  int staged;        // 1: LDS-staged transposition (narrow rows), 0: direct row copy (wide rows)
+  int tchunk;        // staged: time steps per block
+  int block_start;
+  int blocks_b, blocks_t;
+};
+struct GatherArgs {
+  int nkeys, T, B;
+  long long len;
+  const long long *starts;  // [B]
+  GatherKey key[RING_MAX_KEYS];
+};
+
+// Philox-free tiny hash would do, but keep one generator family in the library.
+__device__ __forceinline__ void philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                        uint32_t (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// start[b] uniform in [0, range)  (replay_memory.py:59 draws numpy randint(0, len - T, B))
+__global__ void k_draw_starts(long long *starts, int B, long long range, uint64_t seed, uint64_t counter) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  uint32_t r[4];
+  philox4((uint32_t)b, (uint32_t)counter, (uint32_t)(counter >> 32), 0x72696e67u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+  const uint64_t x = ((uint64_t)r[0] << 32) | r[1];
+  starts[b] = (long long)(((unsigned __int128)x * (unsigned __int128)(uint64_t)range) >> 64);
+}
+
+// One launch gathers every key.  Narrow keys (dim*4 < 256 B): a block takes 16 windows x
+// tchunk steps, reads each window's contiguous run into LDS with the window starts staged
+// in LDS, and writes [t][16 windows][dim] runs; both sides are >= 16*dim*4-byte bursts.
+// Wide keys: every (t, b) row is already a long contiguous run on both sides; plain
+// coalesced row copy (float4 when dim % 4 == 0).
+__global__ __launch_bounds__(GATHER_THREADS) void k_gather_windows(GatherArgs a) {
+  __shared__ __attribute__((aligned(16))) float stage[STAGE_LDS_FLOATS];
+  __shared__ long long sstart[STAGE_WINDOWS];
+  const int bid = blockIdx.x, tid = threadIdx.x;
+  int ki = 0;
+  for (int i = 1; i < a.nkeys; ++i)
+    if (bid >= a.key[i].block_start) ki = i;
+  const GatherKey &K = a.key[ki];
+  const int local = bid - K.block_start;
+  const int dim = K.dim, T = a.T, B = a.B;
+  const long long len = a.len;
+  if (K.staged) {
+    const int bb = local % K.blocks_b, tb = local / K.blocks_b;
+    const int b0 = bb * STAGE_WINDOWS, t0 = tb * K.tchunk;
+    const int nw = min(STAGE_WINDOWS, B - b0), nt = min(K.tchunk, T - t0);
+    if (tid < nw) sstart[tid] = a.starts[b0 + tid];
+    __syncthreads();
+    const int run = nt * dim;  // floats per window in this chunk
+    for (int e = tid; e < nw * run; e += GATHER_THREADS) {
+      const int w = e / run, r = e - w * run;
+      const int t = r / dim, c = r - t * dim;
+      const long long row = (sstart[w] + t0 + t) % len;
+      stage[e] = K.src[row * dim + c];
+    }
+    __syncthreads();
+    const int wrun = nw * dim;  // floats per time step written by this block
+    for (int e = tid; e < nt * wrun; e += GATHER_THREADS) {
+      const int t = e / wrun, r = e - t * wrun;
+      const int w = r / dim, c = r - w * dim;
+      K.dst[((long long)(t0 + t) * B + b0) * dim + r] = stage[w * run + t * dim + c];
+    }
+  } else {
+    const long long rows = (long long)T * B;
+    if ((dim & 3) == 0) {
+      const int d4 = dim >> 2;
+      const long long total = rows * d4;
+      for (long long e = (long long)local * GATHER_THREADS + tid; e < total; e += (long long)K.blocks_b * GATHER_THREADS) {
+        const long long row = e / d4;
+        const int c = (int)(e - row * d4);
+        const int t = (int)(row / B), b = (int)(row - (long long)t * B);
+        const long long srow = (a.starts[b] + t) % len;
+        reinterpret_cast<float4 *>(K.dst)[e] = reinterpret_cast<const float4 *>(K.src)[srow * d4 + c];
+      }
+    } else {
+      const long long total = rows * dim;
+      for (long long e = (long long)local * GATHER_THREADS + tid; e < total; e += (long long)K.blocks_b * GATHER_THREADS) {
+        const long long row = e / dim;
+        const int c = (int)(e - row * dim);
+        const int t = (int)(row / B), b = (int)(row - (long long)t * B);
+        const long long srow = (a.starts[b] + t) % len;
+        K.dst[e] = K.src[srow * dim + c];
+      }
+    }
+  }
+}
+
+// packed AoS rows [n, rowfloats] -> SoA ring slots (top + i) % maxlen
+struct ScatterArgs {
+  int nkeys;
+  long long n, top, maxlen;
+  int rowfloats;
+  const float *rows;
+  float *dst[RING_MAX_KEYS];
+  int dim[RING_MAX_KEYS];
+  int off[RING_MAX_KEYS];
+};
+__global__ void k_scatter_rows(ScatterArgs a) {
+  const long long total = a.n * a.rowfloats;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long i = e / a.rowfloats;
+    const int c = (int)(e - i * a.rowfloats);
+    int k = 0;
+    for (int j = 1; j < a.nkeys; ++j)
+      if (c >= a.off[j]) k = j;
+    const long long slot = (a.top + i) % a.maxlen;
+    a.dst[k][slot * a.dim[k] + (c - a.off[k])] = a.rows[e];
+  }
+}
+
+// nstep_return.py:60-72: ret[i] = r[i] + gamma * ret[i+1] for OLDEST-FIRST arrays, float32
+// multiply then add (no fma: the reference loop rounds the product before the add).
+__global__ void k_mc_return(const float *__restrict__ r, float *__restrict__ ret, int n, float gamma) {
+#pragma clang fp contract(off)
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  float acc = 0.f;
+  for (int i = n - 1; i >= 0; --i) {
+    float prod = acc * gamma;      // rounded product, then rounded sum (no fma)
+    acc = (i == n - 1) ? r[i] : r[i] + prod;
+    ret[i] = acc;
+  }
+}
+
+__device__ __forceinline__ float reward_fn(const fdql_reward_fn_t &fn, const float *ag, const float *g, int gd) {
+#pragma clang fp contract(off)
+  float s = 0.f;
+  for (int j = 0; j < gd; ++j) {
+    const float d = ag[j] - g[j];
+    const float sq = d * d;
+    s = s + sq;
+  }
+  return sqrtf(s) > fn.threshold ? fn.miss_reward : 0.f;
+}
+
+// her.py:55-95.  Pass 1 (all threads): relabelled reward and done per step.  Pass 2: the
+// synthetic sub-episode of step i starts after the last relabelled-done step BEFORE i, so
+// episode_step'[i] = step[i] - step[p(i) + 1] with p = exclusive prefix-max of
+// (done[j] ? j : -1): a wavefront scan carried across 64-step chunks.
+__global__ __launch_bounds__(64) void k_her_relabel(const float *reward, const float *estep, const float *ag,
+                                                    const float *dg, const float *goal, int n, int gd,
+                                                    fdql_reward_fn_t fn, float *r_out, float *d_out, float *s_out) {
+  const int lane = threadIdx.x;
+  int carry = -1;  // last done index seen in earlier chunks
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    int flag = -1;
+    if (i < n) {
+      const float gr = reward_fn(fn, ag + (long long)i * gd, goal, gd);
+      const float dr = reward_fn(fn, ag + (long long)i * gd, dg + (long long)i * gd, gd);
+      r_out[i] = (reward[i] - dr) + gr;
+      const bool done = (gr == 0.f);
+      d_out[i] = done ? 1.f : 0.f;
+      flag = done ? i : -1;
+    }
+    // inclusive prefix max over the wave
+    int incl = flag;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl = max(incl, o);
+    }
+    int excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = -1;
+    excl = max(excl, carry);
+    if (i < n) s_out[i] = estep[i] - estep[excl + 1];
+    carry = max(carry, __shfl(incl, 63, 64));
+  }
+}
+
+}  // namespace fdql
+
+using namespace fdql;
+
+struct fdql_ring {
+  int64_t maxlen = 0;
+  int nkeys = 0;
+  int dims[RING_MAX_KEYS] = {};
+  int offs[RING_MAX_KEYS] = {};
+  int rowfloats = 0;
+  float *data[RING_MAX_KEYS] = {};
+  // bookkeeping (replay_memory.py:45-46)
+  int64_t top = 0, len = 0;
+  // staging
+  float *pinned = nullptr;
+  float *dev_stage = nullptr;
+  int64_t stage_cap = 0, staged = 0, stage_top = 0;
+  hipEvent_t stage_done = nullptr;
+  bool stage_inflight = false;
+  long long *starts = nullptr;
+  int starts_cap = 0;
+};
+
+namespace {
+
+void advance(fdql_ring *r, int64_t n) {
+  // n sequential adds of replay_memory.py:45-46
+  for (int64_t done = 0; done < n;) {
+    const int64_t step = std::min<int64_t>(n - done, r->maxlen - r->top);
+    const int64_t newtop = (r->top + step) % r->maxlen;
+    // len = max(top, len) after each add: the running max of top over this contiguous run
+    const int64_t peak = (newtop == 0) ? (step > 1 ? r->maxlen - 1 : 0) : newtop;
+    r->len = std::max(r->len, peak);
+    r->top = newtop;
+    done += step;
+  }
+}
+
+int scatter(fdql_ring *r, const float *dev_rows, int64_t n, int64_t top, hipStream_t s) {
+  ScatterArgs a;
+  memset(&a, 0, sizeof(a));
+  a.nkeys = r->nkeys; a.n = n; a.top = top; a.maxlen = r->maxlen; a.rowfloats = r->rowfloats; a.rows = dev_rows;
+  for (int k = 0; k < r->nkeys; ++k) { a.dst[k] = r->data[k]; a.dim[k] = r->dims[k]; a.off[k] = r->offs[k]; }
+  const long long total = n * r->rowfloats;
+  const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_scatter_rows, dim3(blocks), dim3(256), 0, s, a);
+  FDQL_HIP(hipGetLastError());
+  return 0;
+}
+
+int flush(fdql_ring *r, hipStream_t s) {
+  if (r->staged == 0) return 0;
+  FDQL_HIP(hipMemcpyAsync(r->dev_stage, r->pinned, r->staged * r->rowfloats * sizeof(float), hipMemcpyHostToDevice, s));
+  int rc = scatter(r, r->dev_stage, r->staged, r->stage_top, s);
+  if (rc) return rc;
+  FDQL_HIP(hipEventRecord(r->stage_done, s));
+  r->stage_inflight = true;
+  r->staged = 0;
+  return 0;
+}
+
+int ensure_starts(fdql_ring *r, int B) {
+  if (B <= r->starts_cap) return 0;
+  if (r->starts) FDQL_HIP(hipFree(r->starts));
+  FDQL_HIP(hipMalloc(&r->starts, sizeof(long long) * B));
+  r->starts_cap = B;
+  return 0;
+}
+
+int gather(fdql_ring *r, int T, int B, const long long *starts, float *const *out, hipStream_t s) {
+  GatherArgs a;
+  memset(&a, 0, sizeof(a));
+  a.nkeys = r->nkeys; a.T = T; a.B = B; a.len = r->len; a.starts = starts;
+  int total = 0;
+  for (int k = 0; k < r->nkeys; ++k) {
+    GatherKey &g = a.key[k];
+    g.src = r->data[k]; g.dst = out[k]; g.dim = r->dims[k];
+    FDQL_REQUIRE(g.dst != nullptr, "output pointer for key %d is null", k);
+    g.block_start = total;
+    if (g.dim * 4 < 256 && T > 1) {
+      g.staged = 1;
+      int tc = STAGE_LDS_FLOATS / (STAGE_WINDOWS * g.dim);
+      g.tchunk = std::max(1, std::min(T, tc));
+      g.blocks_b = (B + STAGE_WINDOWS - 1) / STAGE_WINDOWS;
+      g.blocks_t = (T + g.tchunk - 1) / g.tchunk;
+      total += g.blocks_b * g.blocks_t;
+    } else {
+      g.staged = 0;
+      const long long elems = (long long)T * B * ((g.dim & 3) == 0 ? g.dim / 4 : g.dim);
+      g.blocks_b = (int)std::max<long long>(1, std::min<long long>((elems + GATHER_THREADS * 4 - 1) / (GATHER_THREADS * 4), 2048));
+      g.blocks_t = 1;
+      total += g.blocks_b;
+    }
+  }
+  hipLaunchKernelGGL(k_gather_windows, dim3(total), dim3(GATHER_THREADS), 0, s, a);
+  FDQL_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fdql_ring_create(fdql_ring_t **out, int64_t maxlen, int32_t n_keys, const int32_t *dims) {
+  FDQL_REQUIRE(out && dims && maxlen > 0 && n_keys > 0 && n_keys <= RING_MAX_KEYS, "bad ring arguments");
+  fdql_ring *r = new fdql_ring();
+  r->maxlen = maxlen;
+  r->nkeys = n_keys;
+  for (int k = 0; k < n_keys; ++k) {
+    if (dims[k] <= 0) { delete r; set_error("key %d has dim %d", k, dims[k]); return FDQL_EINVAL; }
+    r->dims[k] = dims[k];
+    r->offs[k] = r->rowfloats;
+    r->rowfloats += dims[k];
+  }
+  for (int k = 0; k < n_keys; ++k) {
+    const size_t bytes = (size_t)maxlen * dims[k] * sizeof(float);
+    hipError_t e = hipMalloc(&r->data[k], bytes);
+    if (e == hipSuccess) e = hipMemset(r->data[k], 0, bytes);  // replay_memory.py:35 np.zeros
+    if (e != hipSuccess) { set_error("ring alloc of key %d (%zu bytes): %s", k, bytes, hipGetErrorString(e)); fdql_ring_destroy(r); return FDQL_ENOMEM; }
+  }
+  r->stage_cap = std::max<int64_t>(1, std::min<int64_t>(maxlen, (int64_t)(8 << 20) / (r->rowfloats * 4)));
+  FDQL_HIP(hipHostMalloc(&r->pinned, r->stage_cap * r->rowfloats * sizeof(float)));
+  FDQL_HIP(hipMalloc(&r->dev_stage, r->stage_cap * r->rowfloats * sizeof(float)));
+  FDQL_HIP(hipEventCreateWithFlags(&r->stage_done, hipEventDisableTiming));
+  *out = r;
+  return 0;
+}
+
+int fdql_ring_destroy(fdql_ring_t *r) {
+  if (!r) return 0;
+  for (int k = 0; k < r->nkeys; ++k)
+    if (r->data[k]) (void)hipFree(r->data[k]);
+  if (r->pinned) (void)hipHostFree(r->pinned);
+  if (r->dev_stage) (void)hipFree(r->dev_stage);
+  if (r->starts) (void)hipFree(r->starts);
+  if (r->stage_done) (void)hipEventDestroy(r->stage_done);
+  delete r;
+  return 0;
+}
+
+int fdql_ring_add(fdql_ring_t *r, const float *host_rows, int64_t n, void *stream) {
+  FDQL_REQUIRE(r && host_rows && n >= 0, "bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  while (n > 0) {
+    if (r->staged == 0) {
+      if (r->stage_inflight) { FDQL_HIP(hipEventSynchronize(r->stage_done)); r->stage_inflight = false; }
+      r->stage_top = r->top;
+    }
+    const int64_t take = std::min(n, r->stage_cap - r->staged);
+    memcpy(r->pinned + r->staged * r->rowfloats, host_rows, take * r->rowfloats * sizeof(float));
+    r->staged += take;
+    advance(r, take);
+    host_rows += take * r->rowfloats;
+    n -= take;
+    if (r->staged == r->stage_cap) { int rc = flush(r, s); if (rc) return rc; }
+  }
+  return 0;
+}
+
+int fdql_ring_add_device(fdql_ring_t *r, const float *dev_rows, int64_t n, void *stream) {
+  FDQL_REQUIRE(r && dev_rows && n >= 0, "bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = flush(r, s);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  rc = scatter(r, dev_rows, n, r->top, s);
+  if (rc) return rc;
+  advance(r, n);
+  return 0;
+}
+
+int fdql_ring_flush(fdql_ring_t *r, void *stream) {
+  FDQL_REQUIRE(r, "null ring");
+  return flush(r, (hipStream_t)stream);
+}
+
+int64_t fdql_ring_len(const fdql_ring_t *r) { return r ? r->len : -1; }
+int64_t fdql_ring_top(const fdql_ring_t *r) { return r ? r->top : -1; }
+int64_t fdql_ring_row_floats(const fdql_ring_t *r) { return r ? r->rowfloats : -1; }
+
+int fdql_ring_key_ptr(fdql_ring_t *r, int32_t key, float **dev_ptr) {
+  FDQL_REQUIRE(r && dev_ptr && key >= 0 && key < r->nkeys, "bad key");
+  *dev_ptr = r->data[key];
+  return 0;
+}
+
+int fdql_ring_sample_windows(fdql_ring_t *r, int32_t T, int32_t B, const int64_t *starts_dev, uint64_t seed,
+                             uint64_t counter, float *const *out, int64_t *starts_out_dev, void *stream) {
+  FDQL_REQUIRE(r && out && T >= 1 && B >= 1, "bad arguments");
+  if (r->len < 2 * (int64_t)T || r->len < B) {  // replay_memory.py:57-58
+    set_error("Trying to sample more memories than available! (len=%lld, T=%d, B=%d)", (long long)r->len, T, B);
+    return FDQL_EOVERSAMPLE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  int rc = flush(r, s);
+  if (rc) return rc;
+  const long long *starts = reinterpret_cast<const long long *>(starts_dev);
+  if (!starts) {
+    rc = ensure_starts(r, B);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_draw_starts, dim3((B + 255) / 256), dim3(256), 0, s, r->starts, B, (long long)(r->len - T), seed, counter);
+    FDQL_HIP(hipGetLastError());
+    starts = r->starts;
+  }
+  if (starts_out_dev && (const void *)starts_out_dev != (const void *)starts)
+    FDQL_HIP(hipMemcpyAsync(starts_out_dev, starts, sizeof(long long) * B, hipMemcpyDeviceToDevice, s));
+  return gather(r, T, B, starts, out, s);
+}
+
+int fdql_ring_sample_rows(fdql_ring_t *r, int32_t B, const int64_t *idx_dev, uint64_t seed, uint64_t counter,
+                          float *const *out, int64_t *idx_out_dev, void *stream) {
+  FDQL_REQUIRE(r && out && B >= 1, "bad arguments");
+  if (r->len < B) {  // replay_memory.py:50
+    set_error("Trying to sample more memories than available! (len=%lld, B=%d)", (long long)r->len, B);
+    return FDQL_EOVERSAMPLE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  int rc = flush(r, s);
+  if (rc) return rc;
+  const long long *idx = reinterpret_cast<const long long *>(idx_dev);
+  if (!idx) {
+    rc = ensure_starts(r, B);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_draw_starts, dim3((B + 255) / 256), dim3(256), 0, s, r->starts, B, (long long)r->len, seed, counter);
+    FDQL_HIP(hipGetLastError());
+    idx = r->starts;
+  }
+  if (idx_out_dev && (const void *)idx_out_dev != (const void *)idx)
+    FDQL_HIP(hipMemcpyAsync(idx_out_dev, idx, sizeof(long long) * B, hipMemcpyDeviceToDevice, s));
+  return gather(r, 1, B, idx, out, s);
+}
+
+int fdql_episode_mc_return(const float *reward_dev, float *ret_dev, int32_t n, float gamma, void *stream) {
+  FDQL_REQUIRE(reward_dev && ret_dev && n >= 0, "bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_mc_return, dim3(1), dim3(64), 0, (hipStream_t)stream, reward_dev, ret_dev, n, gamma);
+  FDQL_HIP(hipGetLastError());
+  return 0;
+}
+
+int fdql_episode_her_relabel(const float *reward, const float *episode_step, const float *achieved_goal,
+                             const float *desired_goal, const float *goal, int32_t n, int32_t goal_dim,
+                             const fdql_reward_fn_t *fn, float *reward_out, float *task_done_out,
+                             float *episode_step_out, void *stream) {
+  FDQL_REQUIRE(reward && episode_step && achieved_goal && desired_goal && goal && fn && reward_out && task_done_out &&
+                   episode_step_out && n >= 0 && goal_dim > 0, "bad arguments");
+  FDQL_REQUIRE(fn->kind == 0, "unknown reward function kind %d", fn->kind);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_her_relabel, dim3(1), dim3(64), 0, (hipStream_t)stream, reward, episode_step, achieved_goal,
+                     desired_goal, goal, n, goal_dim, *fn, reward_out, task_done_out, episode_step_out);
+  FDQL_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

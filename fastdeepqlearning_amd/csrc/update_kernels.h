@@ -1,0 +1,81 @@
+// Argument blocks and launchers of the non-GEMM update kernels (kernels.hip).
+#pragma once
+#include "common.h"
+
+namespace fdql {
+
+// Small state that lives on the device so a captured graph can be replayed unchanged.
+struct DevState {
+  int step;             // optimiser step (torch.optim.Adam state['step'])
+  float alpha_cur;      // exp(log_alpha) as of the previous step (soft_actor_critic.py:41,152)
+  float alpha_next;
+  float neg_step_size;  // -lr / (1 - beta1^step)
+  float bc2_sqrt;       // sqrt(1 - beta2^step)
+  float pad[3];
+};
+
+constexpr int LOSS_NPART = 8;
+
+struct PolicyFwdArgs {
+  const float *logits;  // [M, 2A]
+  const float *noise;   // [M, A] or null -> Philox
+  float *noise_out;     // [M, A] or null
+  float *action;        // [M, A]
+  float *logp;          // [M]
+  uint32_t which;       // RNG stream id
+};
+
+struct LossArgs {
+  int M, B, Nq, Nt, G;
+  int distributional, lowerbound, max_entropy;
+  float gamma, target_entropy, half_inv_nq;
+  const DevState *st;
+  const float *log_alpha;
+  const float *z_target;   // [M, Nq]
+  const float *q_pred;     // [M, Nq]
+  const float *z_frozen;   // [M, Nq]
+  const float *logp_next;  // [M]
+  const float *logp;       // [M]
+  const float *reward, *task_done, *mc_return;  // [T*B]; row m reads m + B (the "next" record)
+  const float *w;          // [M]
+  float *dz, *dzf;         // [M, Nq]
+  float *td_target;        // [M, Nt]
+  float *q_loss, *pi_loss, *alpha_loss;  // [M]
+  float *partials;         // [blocks, LOSS_NPART]
+};
+
+struct AdamArgs {
+  long long n;
+  float *params, *m, *v;
+  const float *grads;
+  float grad_scale, one_minus_b1, b2, one_minus_b2, eps;
+  const DevState *st;
+  float *targets;
+  long long tgt_begin, tgt_end;
+  float tau, one_minus_tau;
+  int hard;
+  float *frozen;
+  long long frozen_begin, frozen_end;
+};
+
+hipError_t skinny_fwd_launch_host(const SkinnyFwdProblem *host, const SkinnyFwdProblem *dev, int n, int total_blocks,
+                                  hipStream_t s);
+hipError_t skinny_wgrad_launch_host(const SkinnyWgradProblem *host, const SkinnyWgradProblem *dev, int n,
+                                    int total_blocks, hipStream_t s);
+hipError_t loss_launch(const LossArgs &a, hipStream_t s);
+hipError_t loss_finish_launch(const float *partials, int nblocks, int M, int Nq, const DevState *st, float *scalars,
+                              float *dlog_alpha, hipStream_t s);
+hipError_t reduce_slabs_launch(const float *slabs, int nslab, long long n, float *grads, hipStream_t s);
+hipError_t adam_launch(const AdamArgs &a, hipStream_t s);
+hipError_t prep_launch(const float *task_done, const float *episode_step, int T, int B, float inv_gb, float *w,
+                       float *contig, hipStream_t s);
+hipError_t tick_alpha_launch(DevState *st, const float *log_alpha, hipStream_t s);
+hipError_t tick_adam_launch(DevState *st, double lr, double b1, double b2, hipStream_t s);
+hipError_t policy_fwd_launch(const PolicyFwdArgs &a0, const PolicyFwdArgs &a1, int nprob, int M, int A,
+                             const DevState *st, uint64_t seed, hipStream_t s);
+hipError_t policy_bwd_launch(const float *logits, const float *noise, const float *action, const float *dpi,
+                             const float *w, const DevState *st, int M, int A, float *dlogits, hipStream_t s);
+
+inline int loss_blocks(int M, int G) { return (M + (256 / G) - 1) / (256 / G); }
+
+}  // namespace fdql

