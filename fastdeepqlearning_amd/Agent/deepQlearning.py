@@ -1,0 +1,233 @@
+"""DeepQLearning: the franQ trainer/actor object over the native update.
+
+Reference: franQ/Agent/deepQlearning.py:23-280.  Same public surface (``enable_training``,
+``train_step``, ``get_losses``, ``act``, ``state_dict``/``load_state_dict``, ``save`` /
+``load_from_file``, ``iteration``, ``param_queue``, ``get_random_hidden``, ``reset``,
+``update_targets``) so franQ.Runner / Evaluator can drive it unchanged.  ``train_step`` is ONE
+call into libfdql_hip.so per replay shard; weights are zero-copy views of the device arenas
+under the reference's state_dict names.
+"""
+import copy
+import itertools
+import logging
+import threading
+from collections import OrderedDict
+from pathlib import Path
+from queue import Queue
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .. import _native as N
+from ..common_utils import AttrDict
+from ..core import NativeAgent, make_config
+from ..Replay.wrappers import TorchDataLoader
+
+
+def _space_dim(space):
+    return int(np.prod(space.shape))
+
+
+def native_config_from_conf(conf):
+    """Translate a franQ conf (conf.py:8-98, encoder.py:16-33) into the C-ABI config."""
+    spaces = conf.obs_space.spaces
+    if "obs_2d" in spaces:
+        raise NotImplementedError("obs_2d: the reference's pixel encoder is dead code (encoder.py:16-23)")
+    ec = conf.encoder_conf
+    if getattr(ec, "joiner_mode", None) is not None and getattr(ec.joiner_mode, "name", "feedforward") != "feedforward":
+        raise NotImplementedError("GRU joiner is out of scope of the native path (SURVEY 8f rank 4)")
+    obs = _space_dim(spaces["obs_1d"]) if "obs_1d" in spaces else 0
+    goal = _space_dim(spaces["desired_goal"]) if "desired_goal" in spaces else 0
+    if conf.discrete:
+        act = int(conf.action_space.n)
+    else:
+        act = int(conf.action_space.shape[-1])
+    if getattr(conf, "use_bootstrap_minibatch_nstep", False):
+        raise NotImplementedError("use_bootstrap_minibatch_nstep is off by default in the reference and not built")
+    return make_config(obs, act, int(conf.temporal_len), int(conf.batch_size), goal_dim=goal, discrete=bool(conf.discrete),
+                       n_critics=int(conf.num_critics), n_quantiles=int(conf.num_q_predictions),
+                       latent=int(conf.latent_state_dim), enc_features=int(ec.hidden_features),
+                       enc_hidden=tuple(ec.obs_1d_hidden_dims), joint_hidden=tuple(ec.joint_hidden_dims),
+                       pi_hidden=tuple(conf.pi_hidden_dims), critic_hidden=tuple(conf.critic_hidden_dims),
+                       distributional=bool(conf.use_distributional_sac), use_lowerbound=bool(conf.use_nStep_lowerbounds),
+                       use_max_entropy=bool(conf.use_max_entropy_q), hard_updates=bool(conf.use_hard_updates),
+                       keep_frozen_copy=True, world_size=int(getattr(conf, "world_size", 1) or 1),
+                       gamma=float(conf.gamma), tau=float(conf.tau), lr=float(conf.learning_rate),
+                       init_log_alpha=float(conf.init_log_alpha), drop_frac=float(conf.top_quantiles_to_drop))
+
+
+STATE_DICT_ORDER = ("encoder.", "actor_critic.log_alpha", "actor_critic.critic.", "actor_critic.critic_target.",
+                    "actor_critic.critic_frozen.", "actor_critic.actor.", "actor_critic.actor_target.")
+
+
+class DeepQLearning:
+    def __init__(self, conf, **kwargs):
+        conf = conf if isinstance(conf, AttrDict) else AttrDict(conf)
+        self.conf = conf
+        self.param_queue = kwargs.get("param_queue", Queue(maxsize=1))
+        self.device = torch.device(conf.training_device)
+        self.native = NativeAgent(native_config_from_conf(conf), self.device)
+        self.native.init_weights(seed=int(kwargs.get("seed", 0)))
+        self.replays = []
+        self._seed = int(kwargs.get("seed", 0))
+        self._last_xp = None
+        self._trainer = None
+        if kwargs.get("train_process", False):   # reference signature: run the trainer loop in place
+            self._initialize_trainer_members(kwargs["replays"])
+            self._infinite_loop_for_async_training_process()
+
+    # ------------------------------------------------------------------ training
+    def enable_training(self, replays):
+        self._initialize_trainer_members(replays)
+        if self.conf.use_async_train:
+            # the reference forks a trainer process; the GPU is asynchronous already, so a host
+            # thread that enqueues kernels is enough and the weights stay shared (no state_dict pickling)
+            self._trainer = threading.Thread(target=self._infinite_loop_for_async_training_process, daemon=True)
+            self._trainer.start()
+
+    def _initialize_trainer_members(self, replays):
+        self.replays = [TorchDataLoader(r, self.device, torch.float32) for r in replays]
+
+    def _infinite_loop_for_async_training_process(self):
+        import time
+        for step_train in itertools.count():
+            if not all(r.ready() for r in self.replays):
+                time.sleep(0.05)
+                continue
+            self.train_step()
+            if (step_train % self.conf.param_update_interval) == 0 and not self.param_queue.full():
+                try:
+                    self.param_queue.put_nowait(OrderedDict((k, v.to("cpu")) for k, v in self.state_dict().items()))
+                except Exception:
+                    pass
+
+    def _distributed(self):
+        return int(getattr(self.conf, "world_size", 1) or 1) > 1
+
+    def train_step(self):
+        """deepQlearning.py:105-127: for every shard: sample -> loss -> backward -> Adam -> polyak."""
+        for replay in self.replays:
+            xp = replay.temporal_sample()
+            self._last_xp = xp
+            if self._distributed():
+                import torch.distributed as dist
+                self.native.update(xp, seed=self._seed, phase=N.PHASE_GRAD)
+                dist.all_reduce(self.native.grads)
+                self.native.update(None, phase=N.PHASE_APPLY)
+            else:
+                self.native.update(xp, seed=self._seed, phase=N.PHASE_ALL)
+            self.conf.train_step.value += 1
+
+    def get_losses(self, xp, noise_target=None, noise_actor=None):
+        """deepQlearning.py:198-249: loss of one [T,B,*] batch (also leaves d loss/d theta in the
+        gradient arena and, like the reference's actor_loss, advances the lagged alpha)."""
+        self.native.update(xp, noise_target, noise_actor, seed=self._seed, phase=N.PHASE_GRAD)
+        ws = self.native.debug("scalars")
+        return ws[0]
+
+    def update_targets(self):
+        """Polyak/hard target update is fused into the optimiser kernel (FDQL_PHASE_APPLY)."""
+
+    def reset(self):
+        pass
+
+    def get_random_hidden(self):
+        return None  # feed-forward joiner (encoder.py:99-100)
+
+    @property
+    def iteration(self):
+        return int(self.conf.train_step.value)
+
+    def parameters(self, *args, **kwargs):
+        return [self.native.tensors[k] for k in self.native.trainable]
+
+    def to(self, device):
+        assert torch.device(device) == self.device, "the native agent lives on conf.training_device"
+        return self
+
+    # ------------------------------------------------------------------ weights
+    def state_dict(self):
+        t = self.native.tensors
+        out = OrderedDict()
+        for prefix in STATE_DICT_ORDER:
+            for k, v in t.items():
+                if k.startswith(prefix):
+                    out[k] = v
+        return out
+
+    def load_state_dict(self, sd):
+        missing = [k for k in self.native.tensors if k not in sd]
+        if missing:
+            raise KeyError(f"missing keys in state_dict: {missing[:4]}...")
+        self.native.load_tensors(sd)
+
+    def save(self, logdir):
+        """deepQlearning.py:260-267: conf.tch + state_dict.tch (plus optimiser state, which the
+        reference does not save, in opt_state.tch)."""
+        logdir = Path(logdir)
+        logdir.mkdir(parents=True, exist_ok=True)
+        conf = copy.copy(self.conf)
+        conf.train_step = conf.train_step.value
+        torch.save(conf, logdir / "conf.tch")
+        torch.save(OrderedDict((k, v.detach().cpu().clone()) for k, v in self.state_dict().items()), logdir / "state_dict.tch")
+        sc = self.native.scalars()
+        torch.save({"adam_m": {k: v.cpu().clone() for k, v in self.native.m_views.items()},
+                    "adam_v": {k: v.cpu().clone() for k, v in self.native.v_views.items()},
+                    "step": int(sc["step"])}, logdir / "opt_state.tch")
+
+    @staticmethod
+    def load_from_file(logdir):
+        from torch import multiprocessing as mp
+        logdir = Path(logdir)
+        conf = torch.load(logdir / "conf.tch", weights_only=False)
+        conf.train_step = mp.Value("i", conf.train_step)
+        agent = DeepQLearning(conf)
+        agent.load_state_dict(torch.load(logdir / "state_dict.tch", weights_only=False))
+        opt = logdir / "opt_state.tch"
+        if opt.exists():
+            o = torch.load(opt, weights_only=False)
+            agent.native.load_opt_state(o["adam_m"], o["adam_v"], o["step"])
+        return agent
+
+    # ------------------------------------------------------------------ inference
+    def _mlp(self, prefix, x, n_hidden):
+        t = self.native.tensors
+        feats, h = [x], x
+        for i in range(n_hidden):
+            h = F.leaky_relu(F.linear(h, t[f"{prefix}.feature_extractor.{i}.0.weight"],
+                                      t[f"{prefix}.feature_extractor.{i}.0.bias"]), 0.01)
+            feats.append(h)
+        return F.linear(torch.cat(feats, -1), t[f"{prefix}.head.weight"], t[f"{prefix}.head.bias"])
+
+    def act(self, experiences):
+        """deepQlearning.py:155-187: small-batch inference for the env actors.  NOT part of the
+        accelerated path: torch eager on the shared weight arena, so the
+        actors always see the trainer's current weights without a state_dict hop."""
+        conf = self.conf
+        if not conf.use_async_train and self.replays and all(r.ready() for r in self.replays):
+            self.train_step()
+        with torch.no_grad():
+            info = {}
+            dev = self.device
+            x = torch.as_tensor(experiences["obs_1d"], dtype=torch.float32, device=dev)
+            if "achieved_goal" in experiences:
+                x = torch.cat((x, torch.as_tensor(experiences["achieved_goal"], dtype=torch.float32, device=dev),
+                               torch.as_tensor(experiences["desired_goal"], dtype=torch.float32, device=dev)), -1)
+            ec = conf.encoder_conf
+            e = self._mlp("encoder.visible_layer_encoders.obs_1d", x, len(ec.obs_1d_hidden_dims))
+            s = self._mlp("encoder.joiner", e, len(ec.joint_hidden_dims))
+            logits = self._mlp("actor_critic.actor", s, len(conf.pi_hidden_dims))
+            mean, log_std = torch.chunk(logits, 2, dim=-1)
+            log_std = torch.clamp(log_std, -20.0, 2.0)
+            std = log_std.exp()
+            xt = mean + std * torch.randn_like(mean)
+            explore = torch.tanh(xt)
+            log_prob = (-((xt - mean) ** 2) / (2 * std ** 2) - std.log() - 0.9189385332046727
+                        - torch.log(1 - explore.pow(2) + 1e-4)).sum(-1, keepdim=True)
+            exploit = torch.tanh(mean)
+            mask = torch.as_tensor(experiences["exploit_mask"], device=dev)
+            action = (exploit * mask) + (explore * torch.logical_not(mask))
+            if (conf.train_step.value % conf.log_interval) == 0:
+                info["log_prob"], info["explore_action"], info["exploit_action"] = log_prob, explore, exploit
+            return action, None, info

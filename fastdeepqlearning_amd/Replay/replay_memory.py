@@ -1,0 +1,126 @@
+"""franQ.Replay.ReplayMemory / AsyncReplayMemory shapes over the HBM ring.
+
+Reference: franQ/Replay/replay_memory.py:9-73 (ring), async_replay_memory.py:9-70 (proxy),
+wrappers/torch_dataloader.py:11-50 (host->device, f32 cast).  Here the ring lives in HBM, so
+one object plays all three roles: ``add`` stages rows host-side (pinned) and the gather kernel
+returns float32 device tensors directly — no child process, no queues, no per-key H2D copy.
+"""
+import numpy as np
+import torch
+
+from .. import _native as N
+from ..core import NativeRing
+
+OversampleError = N.OversampleError
+
+
+def _is_numeric(v):
+    return isinstance(v, (np.ndarray, np.generic, int, float, bool)) or (isinstance(v, torch.Tensor))
+
+
+class ReplayMemory:
+    """Same constructor and methods as the reference; returns torch device tensors (float32),
+    i.e. what ``TorchDataLoader(ReplayMemory(...))`` returns in the reference."""
+
+    def __init__(self, maxlen, batch_size, temporal_len, device=None, seed=0, **kwargs):
+        self._batch_size, self._temporal_len, self._maxlen = int(batch_size), int(temporal_len), int(maxlen)
+        self.batch_size, self.temporal_len = self._batch_size, self._temporal_len
+        self.device = torch.device(device if device is not None else "cuda:0")
+        self._seed, self._counter = int(seed), 0
+        self._ring = None
+        self._keys, self._shapes, self._dims = [], [], []
+
+    # ---------------------------------------------------------------- write
+    def _jit_initialize(self, experience_dict):
+        """replay_memory.py:18-35: arrays keep their shape, scalars/bools become [1] float32.
+        Non-numeric values (the runner's ``info`` dict) are not stored."""
+        for k, v in experience_dict.items():
+            if not _is_numeric(v):
+                continue
+            a = np.asarray(v.cpu() if isinstance(v, torch.Tensor) else v)
+            shape = tuple(a.shape) if a.ndim > 0 else (1,)
+            self._keys.append(k)
+            self._shapes.append(shape)
+            self._dims.append(int(np.prod(shape)) if shape else 1)
+        self._offsets = np.cumsum([0] + self._dims)
+        self._ring = NativeRing(self._maxlen, self._dims, self.device)
+
+    def _pack(self, experience_dict, out):
+        for j, k in enumerate(self._keys):
+            v = experience_dict[k]
+            if isinstance(v, torch.Tensor):
+                v = v.detach().cpu().numpy()
+            out[self._offsets[j]:self._offsets[j + 1]] = np.asarray(v, dtype=np.float32).reshape(-1)
+
+    def add(self, experience_dict):
+        if self._ring is None:
+            self._jit_initialize(experience_dict)
+        row = np.empty(self._offsets[-1], np.float32)
+        self._pack(experience_dict, row)
+        self._ring.add_rows(row[None])
+
+    def add_rows(self, rows):
+        """Bulk append of packed float32 rows [n, sum(dims)] (host numpy or device tensor)."""
+        self._ring.add_rows(rows)
+
+    # ---------------------------------------------------------------- read
+    def _named(self, outs, lead):
+        return {k: o.view(tuple(lead) + s) for k, s, o in zip(self._keys, self._shapes, outs)}
+
+    def _check_init(self):
+        if self._ring is None:
+            raise OversampleError("Trying to sample more memories than available!")
+
+    def sample(self, idxes=None):
+        """replay_memory.py:48-52: [B, *shape] per key."""
+        self._check_init()
+        self._counter += 1
+        outs = self._ring.sample_rows(self._batch_size, idx=idxes, seed=self._seed, counter=self._counter)
+        return self._named(outs, (self._batch_size,))
+
+    def temporal_sample(self, starts=None):
+        """replay_memory.py:54-65: [T, B, *shape] per key; raises OversampleError when
+        len < 2T or len < B."""
+        self._check_init()
+        self._counter += 1
+        outs = self._ring.sample_windows(self._temporal_len, self._batch_size, starts=starts, seed=self._seed,
+                                         counter=self._counter)
+        return self._named(outs, (self._temporal_len, self._batch_size))
+
+    def __getitem__(self, idxes):
+        """replay_memory.py:67-70: gather arbitrary index arrays (any shape)."""
+        self._check_init()
+        idx = torch.as_tensor(np.asarray(idxes), dtype=torch.int64)
+        flat = idx.reshape(-1)
+        saveB = self._batch_size
+        outs = self._ring.sample_rows(int(flat.numel()), idx=flat)
+        return {k: o.view(tuple(idx.shape) + s) for k, s, o in zip(self._keys, self._shapes, outs)}
+
+    def __len__(self):
+        return len(self._ring) if self._ring is not None else 0
+
+    def ready(self):
+        n = len(self)
+        return n >= 2 * self._temporal_len and n >= self._batch_size
+
+
+class AsyncReplayMemory(ReplayMemory):
+    """Name kept for drop-in use.  The reference's proxy keeps its own saturating counter
+    (async_replay_memory.py:27-29) which, unlike the ring's, reaches ``maxlen``; the HBM ring is
+    "asynchronous" by construction (adds and samples are ordered on one HIP stream)."""
+
+    def __init__(self, maxlen, batch_size, temporal_len, **kwargs):
+        kwargs.pop("log_dir", None)
+        super().__init__(maxlen, batch_size, temporal_len, **kwargs)
+        self._len = 0
+
+    def add(self, experience_dict):
+        self._len = min(self._len + 1, self._maxlen)
+        super().add(experience_dict)
+
+    def __len__(self):
+        return self._len
+
+    def ready(self):
+        n = ReplayMemory.__len__(self)
+        return n >= 2 * self._temporal_len and n >= self._batch_size

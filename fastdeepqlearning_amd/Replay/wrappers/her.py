@@ -1,0 +1,80 @@
+"""HindsightNStepReplay: write-time hindsight relabel, modes "final" / "random".
+Reference: franQ/Replay/wrappers/her.py:7-95.  With a ``SparseL2Reward`` the relabel (two reward
+evaluations per step + the sub-episode rebase, a prefix-max scan) runs on the device; any other
+``compute_reward`` callable is user/env code and is evaluated on the host, as in the reference."""
+import random
+
+import numpy as np
+import torch
+
+from .wrapper_base_class import ReplayMemoryWrapper
+from .episode_ops import SparseL2Reward, her_relabel_device
+
+
+class HindsightNStepReplay(ReplayMemoryWrapper):
+    def __init__(self, replay_buffer, compute_reward, ignore_keys=("info",), mode="random", device=None):
+        ReplayMemoryWrapper.__init__(self, replay_buffer)
+        self.compute_reward = compute_reward
+        self._ignored_keys = ignore_keys
+        self._mode = mode
+        self._device = torch.device(device) if device is not None else getattr(replay_buffer, "device", torch.device("cuda:0"))
+        self._reset()
+
+    def _reset(self):
+        self.buffer = []  # oldest first
+
+    def add(self, experience):
+        self.buffer.append(experience)
+        if experience["episode_done"]:
+            self._flush()
+            self._hindsight_flush()
+            self._reset()
+
+    def _strip(self, row):
+        return {k: v for k, v in row.items() if k not in self._ignored_keys}
+
+    def _flush(self):
+        for row in self.buffer:
+            self.replay_buffer.add(self._strip(row))
+
+    def _select_virtual_goal(self):
+        newest_first = [r["achieved_goal"] for r in reversed(self.buffer)]
+        if self._mode == "final":
+            return newest_first[0]
+        if self._mode == "random":
+            return random.choice(newest_first)
+        raise ValueError(f"unknown her mode {self._mode}")
+
+    def _relabel_host(self, goal):
+        n = len(self.buffer)
+        r_new, d_new, s_new = [None] * n, [None] * n, [None] * n
+        groups = []
+        for pos, i in enumerate(range(n - 1, -1, -1)):
+            row = self.buffer[i]
+            goal_reward, d = self.compute_reward(row["achieved_goal"], goal)
+            agnostic = row["reward"] - self.compute_reward(row["achieved_goal"], row["desired_goal"])[0]
+            r_new[i], d_new[i] = agnostic + goal_reward, d
+            if d or pos == 0:
+                groups.append([])
+            groups[-1].append(i)
+        for g in groups:
+            base = self.buffer[g[-1]]["episode_step"]
+            for i in g:
+                s_new[i] = self.buffer[i]["episode_step"] - base
+        return r_new, d_new, s_new
+
+    def _hindsight_flush(self):
+        goal = self._select_virtual_goal()
+        if isinstance(self.compute_reward, SparseL2Reward):
+            r, d, s = her_relabel_device([x["reward"] for x in self.buffer], [x["episode_step"] for x in self.buffer],
+                                         [x["achieved_goal"] for x in self.buffer],
+                                         [x["desired_goal"] for x in self.buffer], goal, self.compute_reward, self._device)
+        else:
+            r, d, s = self._relabel_host(goal)
+        for i, row in enumerate(self.buffer):
+            out = self._strip(row)
+            out["desired_goal"] = goal
+            out["task_done"] = bool(d[i])
+            out["episode_step"] = s[i]
+            out["reward"] = r[i]
+            self.replay_buffer.add(out)

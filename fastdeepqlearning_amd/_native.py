@@ -71,6 +71,7 @@ _vp, _i32, _i64, _u64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_
 SIGNATURES = {
     "fdql_last_error": (C.c_char_p, []),
     "fdql_version": (C.c_int, []),
+    "fdql_abi_sizes": (None, [C.POINTER(C.c_int32)]),
     "fdql_ring_create": (C.c_int, [C.POINTER(_vp), _i64, _i32, C.POINTER(_i32)]),
     "fdql_ring_destroy": (C.c_int, [_vp]),
     "fdql_ring_add": (C.c_int, [_vp, _vp, _i64, _vp]),
@@ -118,6 +119,11 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args
+    sizes = (C.c_int32 * 5)()
+    lib.fdql_abi_sizes(sizes)
+    mine = [C.sizeof(x) for x in (AgentConfig, Batch, AgentStats, KernelTime, RewardFn)]
+    if list(sizes) != mine:
+        raise ImportError(f"struct layout mismatch between _native.py {mine} and libfdql_hip.so {list(sizes)}")
     _lib = lib
     return lib
 

@@ -37,6 +37,10 @@ extern "C" {
 
 const char *fdql_last_error(void);
 int fdql_version(void);
+/* sizeof() of the structs below as this library was compiled, so a binding can verify its
+ * own mirror: out[0]=fdql_agent_config_t, [1]=fdql_batch_t, [2]=fdql_agent_stats_t,
+ * [3]=fdql_kernel_time_t, [4]=fdql_reward_fn_t. */
+void fdql_abi_sizes(int32_t *out5);
 
 /* ------------------------------------------------------------------------------------ */
 /* Replay ring: structure-of-arrays ring in HBM                                          */

@@ -54,6 +54,7 @@ class Spec:
     drop: float = 0.2             # top_quantiles_to_drop
     T: int = 50
     B: int = 256
+    world_size: int = 1           # data-parallel ranks: loss is normalised by B * world_size
 
     @property
     def enc_in(self):             # encoder.py:26-32
@@ -273,7 +274,7 @@ def losses(p, spec: Spec, xp, noise_target, noise_actor, alpha):
     alpha_loss = -(p["actor_critic.log_alpha"] * (spec.target_entropy - (-logp)).detach())
     w = contig.float()
     loss = ((q_loss + pi_loss + alpha_loss) * w).sum(0) / (w.sum(0) + 1e-4)   # :222-224
-    loss = loss.mean() / spec.T                                            # :225, :249
+    loss = loss.sum() / (loss.numel() * spec.world_size) / spec.T          # :225 (.mean over B), :249
     aux.update(state=state, next_action=a_n, next_log_pi=logp_n, next_z=z, td_target=td, q_pred=q,
                q_loss=q_loss, pi=pi, log_pi=logp, q_frozen=None, pi_loss=pi_loss, alpha_loss=alpha_loss,
                is_contiguous=w, qpi=qpi)

@@ -1,0 +1,220 @@
+"""GPU tests of the franQ-shaped facade (Replay / Agent) — the reference's own replay tests
+restated against the native objects, the write wrappers against the reference's emitted
+sequences, and the agent object's life cycle."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from golden_io import load, spec_from_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def test_reference_test_size(dev):
+    """tests/test_replays.py:36-57 (AsyncReplayMemory length counts up to and saturates at maxlen)."""
+    from fastdeepqlearning_amd.Replay import AsyncReplayMemory
+    maxlen = 500
+    r = AsyncReplayMemory(maxlen=maxlen, batch_size=32, temporal_len=10, device=dev)
+    for i in range(maxlen * 2):
+        r.add({"obs": np.random.uniform(size=[10]), "action": 2})
+        if i < maxlen:
+            assert len(r) == i + 1
+        assert (1 + i) - maxlen <= len(r) <= i + 1
+    for i in range(maxlen):
+        r.add({"obs": np.random.uniform(size=[10]), "action": 2})
+    assert len(r) == maxlen
+
+
+def test_reference_test_temporal_consistency(dev):
+    """tests/test_replays.py:60-84: obs[1:] == obs[:-1] + 1 on every window while the ring has not wrapped."""
+    from fastdeepqlearning_amd.Replay import AsyncReplayMemory
+    from fastdeepqlearning_amd.Replay.wrappers import TorchDataLoader
+    maxlen, B, T, obs_size = 5000, 256, 10, 10
+    r = AsyncReplayMemory(maxlen=maxlen, batch_size=B, temporal_len=T, device=dev)
+    for i in range(maxlen // 2):
+        r.add({"obs": np.ones([obs_size]) * i, "action": 2})
+    l = TorchDataLoader(r, dev)
+    for _ in range(20):
+        xp = l.temporal_sample()
+        obs = xp["obs"]
+        assert tuple(obs.shape) == (T, B, obs_size) and obs.dtype == torch.float32 and obs.is_cuda
+        assert (obs[1:] == (obs[:-1] + 1)).all()
+        assert tuple(xp["action"].shape) == (T, B, 1)
+
+
+def test_reference_test_nstep_return(dev):
+    """tests/test_replays.py:16-33 through the native wrapper + ring."""
+    from fastdeepqlearning_amd import Replay
+    discount, n_step = 0.99, 1000
+    replay = Replay.ReplayMemory(1001, batch_size=128, temporal_len=1, device=dev)
+    replay = Replay.wrappers.NStepReturn(replay, n_step=n_step, discount=discount)
+    for i in range(n_step):
+        replay.add({"reward": float(i == (n_step - 1)), "episode_done": i == (n_step - 1), "step": i})
+    for j in range(20):
+        s = replay.sample()
+        assert np.allclose(s["mc_return"].cpu().numpy(), discount ** (n_step - 1 - s["step"].cpu().numpy()))
+
+
+class Sink:
+    def __init__(self, dev):
+        self.rows, self.device = [], dev
+
+    def add(self, d):
+        self.rows.append(dict(d))
+
+    def stacked(self):
+        keys = sorted(self.rows[0].keys())
+        return {k: np.stack([np.asarray(r[k], np.float64).reshape(-1) for r in self.rows]) for k in keys}
+
+
+@pytest.mark.parametrize("case", ["sparse_1000", "dense_two_eps", "pop_quirk", "single_step"])
+def test_nstep_wrapper_matches_reference_sequence(dev, case):
+    from fastdeepqlearning_amd.Replay.wrappers import NStepReturn
+    g = load("nstep")[case]
+    sink = Sink(dev)
+    w = NStepReturn(sink, int(g["n_step"]), float(g["gamma"]))
+    inp = g["in"]
+    for i in range(inp["reward"].shape[0]):
+        w.add({"reward": float(inp["reward"][i, 0]), "episode_done": bool(inp["episode_done"][i, 0]),
+               "episode_step": int(inp["episode_step"][i, 0]), "obs_1d": inp["obs_1d"][i]})
+    out = sink.stacked()
+    for k, v in g["out"].items():
+        np.testing.assert_array_equal(out[k].astype(np.float32), np.asarray(v, np.float32), err_msg=k)
+
+
+@pytest.mark.parametrize("case", ["final", "random", "final_nstep"])
+def test_her_wrapper_matches_reference_sequence(dev, case):
+    from fastdeepqlearning_amd.Replay.wrappers import HindsightNStepReplay, NStepReturn, SparseL2Reward
+    g = load("her")[case]
+    sink = Sink(dev)
+    inner = NStepReturn(sink, 1000, float(g["gamma"])) if int(g["nstep"]) else sink
+    random.seed(3)
+    w = HindsightNStepReplay(inner, SparseL2Reward(float(g["thr"]), -1.0), mode=str(g["mode"]), device=dev)
+    inp = g["in"]
+    for i in range(inp["reward"].shape[0]):
+        w.add({"obs_1d": inp["obs_1d"][i], "achieved_goal": inp["achieved_goal"][i], "desired_goal": inp["desired_goal"][i],
+               "action": inp["action"][i], "reward": float(inp["reward"][i, 0]), "task_done": bool(inp["task_done"][i, 0]),
+               "episode_done": bool(inp["episode_done"][i, 0]), "episode_step": int(inp["episode_step"][i, 0]), "info": {}})
+    out = sink.stacked()
+    for k, v in g["out"].items():
+        np.testing.assert_allclose(out[k], np.asarray(v, np.float64), rtol=0, atol=1e-6, err_msg=k)
+
+
+class _Space:
+    def __init__(self, shape=None, n=None, spaces=None):
+        if shape is not None:
+            self.shape = tuple(shape)
+        if n is not None:
+            self.n = n
+        if spaces is not None:
+            self.spaces = spaces
+
+
+def _conf(dev, T=4, B=16):
+    from fastdeepqlearning_amd.Agent import AgentConf
+    conf = AgentConf()
+    conf.obs_space = _Space(spaces={"obs_1d": _Space(shape=(5,))})
+    conf.action_space = _Space(shape=(3,))
+    conf.discrete = False
+    conf.training_device = conf.inference_device = dev
+    conf.batch_size, conf.temporal_len, conf.replay_size = B, T, 4000
+    conf.num_critics, conf.num_q_predictions, conf.latent_state_dim = 3, 4, 32
+    conf.pi_hidden_dims, conf.critic_hidden_dims = [32], [32, 32]
+    conf.encoder_conf.hidden_features = 32
+    conf.encoder_conf.obs_1d_hidden_dims, conf.encoder_conf.joint_hidden_dims = (32,), (32,)
+    conf.use_async_train = False
+    conf.num_instances = 2
+    return conf
+
+
+def test_agent_facade_life_cycle(dev, tmp_path):
+    """Replay.make + Agent.make wired like franQ.Runner.__init__ (runner.py:30-42): feed records
+    through the write heads, train from the read heads, save / load."""
+    from fastdeepqlearning_amd import Agent, Replay
+    conf = _conf(dev)
+    g = load("update_tqc_small")
+    read_heads, write_heads = Replay.make(conf)
+    agent = Agent.make(conf)
+    assert set(agent.state_dict().keys()) == set(g["init"].keys())      # SURVEY a22 names
+    for k, v in agent.state_dict().items():
+        assert tuple(v.shape) == tuple(g["init"][k].shape), k
+    agent.enable_training(read_heads)
+    rng = np.random.RandomState(0)
+    for ep in range(6):
+        for i in range(120):
+            row = {"obs_1d": rng.standard_normal(5), "action": rng.uniform(-1, 1, 3).astype(np.float32),
+                   "reward": float(rng.standard_normal()), "task_done": bool(rng.rand() < 0.01),
+                   "episode_done": i == 119, "episode_step": i, "idx": 0}
+            for w in write_heads:
+                w.add(dict(row))
+    before = {k: v.clone() for k, v in agent.state_dict().items()}
+    for _ in range(3):
+        agent.train_step()
+    assert agent.iteration == 3 * len(read_heads)
+    sc = agent.native.scalars()
+    assert np.isfinite(sc["loss"]) and sc["step"] == 6
+    after = agent.state_dict()
+    assert any(not torch.equal(before[k], after[k]) for k in before)
+    action, hidden, info = agent.act({"obs_1d": torch.randn(7, 5), "exploit_mask": torch.zeros(7, 1, dtype=torch.bool)})
+    assert tuple(action.shape) == (7, 3) and hidden is None and float(action.abs().max()) <= 1.0
+    agent.save(tmp_path)
+    agent2 = type(agent).load_from_file(tmp_path)
+    for k, v in agent.state_dict().items():
+        assert torch.equal(v, agent2.state_dict()[k]), k
+    assert agent2.iteration == agent.iteration
+
+
+def test_phase_split_equals_single_call(dev):
+    """FDQL_PHASE_GRAD + FDQL_PHASE_APPLY (the multi-GPU sequence, all-reduce in between) gives
+    bit-identical weights to FDQL_PHASE_ALL."""
+    from fastdeepqlearning_amd import _native as nat
+    from test_gpu_parity import _agent_for
+    g = load("update_tqc_small")
+    spec = spec_from_case(g["case"])
+    rec = g["step0"]
+    xp = {k: torch.tensor(v).to(dev) for k, v in rec["batch"].items()}
+    nt, na = torch.tensor(rec["noise_target"]).to(dev), torch.tensor(rec["noise_actor"]).to(dev)
+    a1, a2 = _agent_for(spec, dev), _agent_for(spec, dev)
+    for a in (a1, a2):
+        a.load_tensors({k: torch.tensor(v) for k, v in g["init"].items()})
+    a1.update(xp, nt, na)
+    a2.update(xp, nt, na, phase=nat.PHASE_GRAD)
+    a2.update(None, phase=nat.PHASE_APPLY)
+    for k in a1.tensors:
+        assert torch.equal(a1.tensors[k], a2.tensors[k]), k
+
+
+def test_device_noise_statistics_and_determinism(dev):
+    """Philox path (perf runs): same seed/step -> same result; actions inside (-1, 1); noise ~ N(0,1)."""
+    from test_gpu_parity import _agent_for
+    g = load("update_tqc_small")
+    spec = spec_from_case(g["case"])
+    xp = {k: torch.tensor(v).to(dev) for k, v in g["step0"]["batch"].items()}
+    outs = []
+    for rep in range(2):
+        a = _agent_for(spec, dev)
+        a.load_tensors({k: torch.tensor(v) for k, v in g["init"].items()})
+        a.update(xp, seed=77)
+        outs.append((a.debug("pi").clone(), a.debug("noise_actor").clone(), a.scalars()["loss"]))
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][2] == outs[1][2]
+    assert float(outs[0][0].abs().max()) <= 1.0   # tanh saturates to exactly 1 in fp32, as on the CPU
+    from fastdeepqlearning_amd.core import NativeAgent, make_config
+    big = NativeAgent(make_config(5, 3, 50, 256, n_critics=2, n_quantiles=5, latent=32, enc_features=32, enc_hidden=(32,),
+                                  joint_hidden=(32,), pi_hidden=(32,), critic_hidden=(32, 32)), dev)
+    big.init_weights(0)
+    T, B = 50, 256
+    xpb = {"obs_1d": torch.randn(T, B, 5, device=dev), "action": torch.rand(T, B, 3, device=dev) * 2 - 1,
+           "reward": torch.randn(T, B, 1, device=dev), "mc_return": torch.randn(T, B, 1, device=dev),
+           "task_done": torch.zeros(T, B, 1, device=dev),
+           "episode_step": torch.arange(T, device=dev).view(T, 1, 1).expand(T, B, 1).float().contiguous()}
+    big.update(xpb, seed=5)
+    z = big.debug("noise_actor")
+    assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1.0) < 0.02
