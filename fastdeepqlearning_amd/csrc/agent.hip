@@ -66,19 +66,26 @@ struct MlpInst {
   float *out = nullptr;
   int ldout = 0;
   std::vector<float *> dpre;
+  std::vector<float *> dpre_cs;  // per hidden layer: [ceil(rows/128), hid] column sums of dpre (bias gradients)
   const float *W(int i) const { return wbase + (d->w_off[i] - worigin); }
   const float *Bv(int i) const { return wbase + (d->b_off[i] - worigin); }
   const float *HW() const { return wbase + (d->hw_off - worigin); }
   const float *HB() const { return wbase + (d->hb_off - worigin); }
 };
 
-enum StageKind { ST_GEMM, ST_SKINNY_FWD, ST_SKINNY_WGRAD, ST_FUNC };
+enum StageKind { ST_GEMM, ST_SKINNY_WGRAD, ST_FUNC };
+
+struct GemmSub {
+  std::vector<GemmProblem> probs;
+  void *dev = nullptr;
+  int blocks = 0;
+};
 
 struct Stage {
   StageKind kind;
   std::string name;
   std::vector<GemmProblem> gemm;
-  std::vector<SkinnyFwdProblem> sfwd;
+  GemmSub sub[GEMM_NSHAPES];  // the problems of `gemm`, grouped by tile shape (one launch each)
   std::vector<SkinnyWgradProblem> swg;
   void *dev = nullptr;  // device copy of the table
   int blocks = 0;
@@ -215,7 +222,10 @@ void carve(fdql_agent *a) {
   auto mlp_bufs = [&](const std::string &p, const MlpDesc &d, int64_t rows, bool bwd, bool out) {
     for (size_t i = 0; i < d.hid.size(); ++i) {
       a->alloc(p + ".h" + std::to_string(i), rows * d.hid[i]);
-      if (bwd) a->alloc(p + ".dpre" + std::to_string(i), M * d.hid[i]);
+      if (bwd) {
+        a->alloc(p + ".dpre" + std::to_string(i), M * d.hid[i]);
+        a->alloc(p + ".cs" + std::to_string(i), ((M + 127) / 128) * d.hid[i]);
+      }
     }
     if (out) a->alloc(p + ".out", rows * d.dout);
   };
@@ -248,6 +258,8 @@ void carve(fdql_agent *a) {
   a->alloc("dlogits", M * a->actor.dout);
   a->alloc("dstate", M * c.latent);
   a->alloc("denc", M * c.enc_features);
+  a->alloc("cs.dstate", ((M + 127) / 128) * c.latent);
+  a->alloc("cs.denc", ((M + 127) / 128) * c.enc_features);
   a->alloc("loss_partials", (int64_t)loss_blocks((int)M, 256) * LOSS_NPART + (int64_t)M * LOSS_NPART);
   a->alloc("slabs", (int64_t)a->nsplit * a->n_train);
 }
@@ -261,12 +273,6 @@ struct Builder {
   Stage &gemm_stage(const std::string &name) {
     st.emplace_back();
     st.back().kind = ST_GEMM;
-    st.back().name = name;
-    return st.back();
-  }
-  Stage &sfwd_stage(const std::string &name) {
-    st.emplace_back();
-    st.back().kind = ST_SKINNY_FWD;
     st.back().name = name;
     return st.back();
   }
@@ -308,31 +314,16 @@ struct Builder {
     p.epi = EPI_LRELU;
     return p;
   }
-  // head: out = W_head cat(in, h_0..h_{n-1}) + b   (mlp.py:93-94)
-  void fwd_head(const MlpInst &m, Stage *gs, Stage *ss) {
+  // head: out = W_head cat(in, h_0..h_{n-1}) + b   (mlp.py:93-94); narrow heads get the 128x32 tile
+  GemmProblem fwd_head(const MlpInst &m) {
     const MlpDesc &d = *m.d;
     const int ld = d.head_ld();
-    if (d.dout > SKINNY_MAX_OUT) {
-      GemmProblem p = new_gemm(m.rows, d.dout, m.out, m.ldout);
-      int col = 0;
-      for (const SegIn &s : m.in) { add_seg(p, s.ptr, s.ld, 1, m.HW() + col, ld, 1, s.width); col += s.width; }
-      for (size_t i = 0; i < d.hid.size(); ++i) { add_seg(p, m.h[i], d.hid[i], 1, m.HW() + col, ld, 1, d.hid[i]); col += d.hid[i]; }
-      p.bias = m.HB();
-      gs->gemm.push_back(p);
-    } else {
-      SkinnyFwdProblem p;
-      memset(&p, 0, sizeof(p));
-      p.M = m.rows; p.Nout = d.dout; p.Y = m.out; p.ldy = m.ldout; p.bias = m.HB();
-      int col = 0;
-      auto seg = [&](const float *X, int ldx, int K) {
-        SkinnySeg &s = p.seg[p.nseg++];
-        s.X = X; s.ldx = ldx; s.K = K; s.W = m.HW() + col; s.wsn = ld; s.wsk = 1;
-        col += K;
-      };
-      for (const SegIn &s : m.in) seg(s.ptr, s.ld, s.width);
-      for (size_t i = 0; i < d.hid.size(); ++i) seg(m.h[i], d.hid[i], d.hid[i]);
-      ss->sfwd.push_back(p);
-    }
+    GemmProblem p = new_gemm(m.rows, d.dout, m.out, m.ldout);
+    int col = 0;
+    for (const SegIn &s : m.in) { add_seg(p, s.ptr, s.ld, 1, m.HW() + col, ld, 1, s.width); col += s.width; }
+    for (size_t i = 0; i < d.hid.size(); ++i) { add_seg(p, m.h[i], d.hid[i], 1, m.HW() + col, ld, 1, d.hid[i]); col += d.hid[i]; }
+    p.bias = m.HB();
+    return p;
   }
   int head_col_of_hidden(const MlpDesc &d, int i) const {
     int col = d.din;
@@ -348,6 +339,7 @@ struct Builder {
     p.epi = EPI_LRELU_GRAD;
     p.ref = m.h[i];
     p.ldref = d.hid[i];
+    p.colsum = m.dpre_cs[i];
     return p;
   }
   // K-segments of d(input columns [col, col+width)) = dY Wh[:, cols] + dpre_0 W_0[:, cols]
@@ -356,48 +348,29 @@ struct Builder {
     add_seg(p, dY, lddy, 1, m.HW() + col, d.head_ld(), 0, d.dout);
     if (!d.hid.empty()) add_seg(p, m.dpre[0], d.hid[0], 1, m.W(0) + col, d.din, 0, d.hid[0]);
   }
-  void input_grad_skinny(const MlpInst &m, const float *dY, int lddy, int col, SkinnyFwdProblem &p) {
-    const MlpDesc &d = *m.d;
-    SkinnySeg &s = p.seg[p.nseg++];
-    s.X = dY; s.ldx = lddy; s.K = d.dout; s.W = m.HW() + col; s.wsn = 1; s.wsk = d.head_ld();
-    if (!d.hid.empty()) {
-      SkinnySeg &t = p.seg[p.nseg++];
-      t.X = m.dpre[0]; t.ldx = d.hid[0]; t.K = d.hid[0]; t.W = m.W(0) + col; t.wsn = 1; t.wsk = d.din;
-    }
-  }
-
-  // all weight / bias gradients of one MLP instance into the slabs
-  void wgrads(const MlpInst &m, const float *dY, int lddy, Stage &gs, Stage &ws) {
+  // all weight / bias gradients of one MLP instance into the K-split slabs.  Every weight
+  // gradient is a K-split GEMM (the narrow ones on the 128x32 / 32x128 tiles); bias gradients
+  // come from the per-tile column sums the dgrad GEMMs leave behind (dy_cs / dpre_cs), or
+  // directly from dY when dY is narrow (dz, d logits).
+  void wgrads(const MlpInst &m, const float *dY, int lddy, const float *dy_cs, Stage &gs, Stage &ws) {
     const MlpDesc &d = *m.d;
     float *slab = a->buf("slabs");
     const long long P = a->n_train;
     const int S = a->nsplit, R = m.rows;
     auto gemm_w = [&](const float *dOut, int ldo, int nout, const float *X, int ldx, int width, float *dst, int ldw) {
       if (width <= 0) return;
-      if (width > SKINNY_MAX_OUT && nout > SKINNY_MAX_OUT) {
-        GemmProblem p = new_gemm(nout, width, dst, ldw);
-        add_seg(p, dOut, ldo, 0, X, ldx, 0, R);
-        p.ksplit = S;
-        p.split_stride = P;
-        gs.gemm.push_back(p);
-      } else if (nout <= SKINNY_MAX_OUT) {
-        SkinnyWgradProblem p;
-        memset(&p, 0, sizeof(p));
-        p.M = R; p.Nout = nout; p.K = width; p.dY = dOut; p.lddy = ldo; p.X = X; p.ldx = ldx;
-        p.dW = dst; p.sq = ldw; p.sk = 1; p.split_stride = P; p.nsplit = S;
-        ws.swg.push_back(p);
-      } else {  // few input columns, many outputs: transposed roles
-        SkinnyWgradProblem p;
-        memset(&p, 0, sizeof(p));
-        p.M = R; p.Nout = width; p.K = nout; p.dY = X; p.lddy = ldx; p.X = dOut; p.ldx = ldo;
-        p.dW = dst; p.sq = 1; p.sk = ldw; p.split_stride = P; p.nsplit = S;
-        ws.swg.push_back(p);
-      }
+      GemmProblem p = new_gemm(nout, width, dst, ldw);
+      add_seg(p, dOut, ldo, 0, X, ldx, 0, R);
+      p.ksplit = S;
+      p.split_stride = P;
+      gs.gemm.push_back(p);
     };
-    auto bias_w = [&](const float *dOut, int ldo, int nout, float *dst) {
+    auto bias_w = [&](const float *dOut, int ldo, int nout, const float *cs, float *dst) {
       SkinnyWgradProblem p;
       memset(&p, 0, sizeof(p));
-      p.M = R; p.Nout = 1; p.K = nout; p.dY = nullptr; p.X = dOut; p.ldx = ldo;
+      p.Nout = 1; p.K = nout; p.dY = nullptr;
+      if (cs) { p.M = (R + 127) / 128; p.X = cs; p.ldx = nout; }
+      else { p.M = R; p.X = dOut; p.ldx = ldo; }
       p.dW = dst; p.sq = 0; p.sk = 1; p.split_stride = P; p.nsplit = S;
       ws.swg.push_back(p);
     };
@@ -409,14 +382,14 @@ struct Builder {
       } else {
         gemm_w(m.dpre[i], d.hid[i], d.hid[i], m.h[i - 1], d.hid[i - 1], d.hid[i - 1], dst, d.hid[i - 1]);
       }
-      bias_w(m.dpre[i], d.hid[i], d.hid[i], slab + d.b_off[i]);
+      bias_w(m.dpre[i], d.hid[i], d.hid[i], m.dpre_cs[i], slab + d.b_off[i]);
     }
     float *dst = slab + d.hw_off;
     const int ld = d.head_ld();
     int col = 0;
     for (const SegIn &s : m.in) { gemm_w(dY, lddy, d.dout, s.ptr, s.ld, s.width, dst + col, ld); col += s.width; }
     for (size_t i = 0; i < d.hid.size(); ++i) { gemm_w(dY, lddy, d.dout, m.h[i], d.hid[i], d.hid[i], dst + col, ld); col += d.hid[i]; }
-    bias_w(dY, lddy, d.dout, slab + d.hb_off);
+    bias_w(dY, lddy, d.dout, dy_cs, slab + d.hb_off);
   }
 };
 
@@ -429,40 +402,42 @@ MlpInst make_inst(fdql_agent *a, const MlpDesc &d, const std::string &p, const f
   m.rows = rows;
   for (size_t i = 0; i < d.hid.size(); ++i) {
     m.h.push_back(a->buf(p + ".h" + std::to_string(i)));
-    if (bwd) m.dpre.push_back(a->buf(p + ".dpre" + std::to_string(i)));
+    if (bwd) {
+      m.dpre.push_back(a->buf(p + ".dpre" + std::to_string(i)));
+      m.dpre_cs.push_back(a->buf(p + ".cs" + std::to_string(i)));
+    }
   }
   return m;
 }
 
 int upload_tables(fdql_agent *a) {
+  auto pad = [](size_t b) { return (b + 255) / 256 * 256; };
   size_t total = 0;
   for (Stage &s : a->stages) {
-    if (s.kind == ST_GEMM) total += (s.gemm.size() * sizeof(GemmProblem) + 255) / 256 * 256;
-    if (s.kind == ST_SKINNY_FWD) total += (s.sfwd.size() * sizeof(SkinnyFwdProblem) + 255) / 256 * 256;
-    if (s.kind == ST_SKINNY_WGRAD) total += (s.swg.size() * sizeof(SkinnyWgradProblem) + 255) / 256 * 256;
+    if (s.kind == ST_GEMM) {
+      for (auto &sub : s.sub) sub.probs.clear();
+      for (auto &p : s.gemm) s.sub[gemm_pick_shape(p)].probs.push_back(p);
+      for (auto &sub : s.sub) total += pad(sub.probs.size() * sizeof(GemmProblem));
+    }
+    if (s.kind == ST_SKINNY_WGRAD) total += pad(s.swg.size() * sizeof(SkinnyWgradProblem));
   }
   if (a->tables_dev) { FDQL_HIP(hipFree(a->tables_dev)); a->tables_dev = nullptr; }
   FDQL_HIP(hipMalloc(&a->tables_dev, total ? total : 256));
   std::vector<char> host(total);
   size_t off = 0;
   for (Stage &s : a->stages) {
-    size_t bytes = 0;
-    const void *src = nullptr;
     if (s.kind == ST_GEMM) {
-      s.blocks = gemm_finalize(s.gemm.data(), (int)s.gemm.size());
-      s.flops = 0;
-      for (auto &p : s.gemm) s.flops += gemm_flops(p);
-      bytes = s.gemm.size() * sizeof(GemmProblem); src = s.gemm.data();
-    } else if (s.kind == ST_SKINNY_FWD) {
-      s.blocks = skinny_fwd_finalize(s.sfwd.data(), (int)s.sfwd.size());
       s.flops = 0; s.bytes = 0;
-      for (auto &p : s.sfwd) {
-        double k = 0;
-        for (int j = 0; j < p.nseg; ++j) k += p.seg[j].K;
-        s.flops += 2.0 * p.M * k * p.Nout;
-        s.bytes += 4.0 * p.M * (k + p.Nout);
+      for (auto &p : s.gemm) { s.flops += gemm_flops(p); s.bytes += gemm_bytes(p); }
+      for (int sh = 0; sh < GEMM_NSHAPES; ++sh) {
+        GemmSub &sub = s.sub[sh];
+        if (sub.probs.empty()) { sub.blocks = 0; sub.dev = nullptr; continue; }
+        sub.blocks = gemm_finalize(sub.probs.data(), (int)sub.probs.size(), sh);
+        const size_t bytes = sub.probs.size() * sizeof(GemmProblem);
+        memcpy(host.data() + off, sub.probs.data(), bytes);
+        sub.dev = (char *)a->tables_dev + off;
+        off += pad(bytes);
       }
-      bytes = s.sfwd.size() * sizeof(SkinnyFwdProblem); src = s.sfwd.data();
     } else if (s.kind == ST_SKINNY_WGRAD) {
       s.blocks = skinny_wgrad_finalize(s.swg.data(), (int)s.swg.size());
       s.flops = 0; s.bytes = 0;
@@ -470,13 +445,11 @@ int upload_tables(fdql_agent *a) {
         s.flops += 2.0 * p.M * (double)p.K * p.Nout;
         s.bytes += 4.0 * p.M * ((double)p.K + (p.dY ? p.Nout : 0));
       }
-      bytes = s.swg.size() * sizeof(SkinnyWgradProblem); src = s.swg.data();
-    } else {
-      continue;
+      const size_t bytes = s.swg.size() * sizeof(SkinnyWgradProblem);
+      memcpy(host.data() + off, s.swg.data(), bytes);
+      s.dev = (char *)a->tables_dev + off;
+      off += pad(bytes);
     }
-    memcpy(host.data() + off, src, bytes);
-    s.dev = (char *)a->tables_dev + off;
-    off += (bytes + 255) / 256 * 256;
   }
   if (total) FDQL_HIP(hipMemcpy(a->tables_dev, host.data(), total, hipMemcpyHostToDevice));
   return 0;
@@ -550,13 +523,8 @@ int build_plan(fdql_agent *a) {
       Stage &gs = b.gemm_stage(name + ".fwd" + std::to_string(i));
       for (MlpInst *m : group) gs.gemm.push_back(b.fwd_layer(*m, (int)i));
     }
-    // heads: wide ones through the GEMM, narrow ones through the skinny kernel
-    std::vector<GemmProblem> gp;
-    std::vector<SkinnyFwdProblem> sp;
-    Stage tmpg, tmps;
-    for (MlpInst *m : group) b.fwd_head(*m, &tmpg, &tmps);
-    if (!tmpg.gemm.empty()) { Stage &gs = b.gemm_stage(name + ".head"); gs.gemm = tmpg.gemm; }
-    if (!tmps.sfwd.empty()) { Stage &ss = b.sfwd_stage(name + ".head"); ss.sfwd = tmps.sfwd; }
+    Stage &hs = b.gemm_stage(name + ".head");
+    for (MlpInst *m : group) hs.gemm.push_back(b.fwd_head(*m));
   };
   fwd_chain({&eo}, "enc_obs");
   fwd_chain({&jo}, "joiner");
@@ -613,15 +581,8 @@ int build_plan(fdql_agent *a) {
         gs.gemm.push_back(b.bwd_dpre(cf[k], i, a->buf("dzf") + k * Q, Nq));
       }
     }
-    // d pi = sum_c input-grad of the frozen critics' action columns
-    if (A <= SKINNY_MAX_OUT) {
-      Stage &ss = b.sfwd_stage("dpi");
-      SkinnyFwdProblem p;
-      memset(&p, 0, sizeof(p));
-      p.M = M; p.Nout = A; p.Y = a->buf("dpi"); p.ldy = A;
-      for (int k = 0; k < C; ++k) b.input_grad_skinny(cf[k], a->buf("dzf") + k * Q, Nq, L, p);
-      ss.sfwd.push_back(p);
-    } else {
+    // d pi = sum_c input-grad of the frozen critics' action columns (narrow output: 128x32 tile)
+    {
       Stage &gs = b.gemm_stage("dpi");
       GemmProblem p = Builder::new_gemm(M, A, a->buf("dpi"), A);
       for (int k = 0; k < C; ++k) b.input_grad_segs(cf[k], a->buf("dzf") + k * Q, Nq, L, p);
@@ -645,6 +606,7 @@ int build_plan(fdql_agent *a) {
     GemmProblem p = Builder::new_gemm(M, L, a->buf("dstate"), L);
     for (int k = 0; k < C; ++k) b.input_grad_segs(co[k], a->buf("dz") + k * Q, Nq, 0, p);
     b.input_grad_segs(ao, a->buf("dlogits"), a->actor.dout, 0, p);
+    p.colsum = a->buf("cs.dstate");
     gs.gemm.push_back(p);
   }
   // ---- encoder backward over the M rows that carry gradient (next-only rows get none)
@@ -658,6 +620,7 @@ int build_plan(fdql_agent *a) {
     Stage &gs = b.gemm_stage("denc");
     GemmProblem p = Builder::new_gemm(M, c.enc_features, a->buf("denc"), c.enc_features);
     b.input_grad_segs(jb, a->buf("dstate"), L, 0, p);
+    p.colsum = a->buf("cs.denc");
     gs.gemm.push_back(p);
   }
   for (int i = (int)a->enc_obs.hid.size() - 1; i >= 0; --i) {
@@ -669,10 +632,10 @@ int build_plan(fdql_agent *a) {
     Stage gs, ws;
     gs.kind = ST_GEMM; gs.name = "wgrad";
     ws.kind = ST_SKINNY_WGRAD; ws.name = "wgrad_skinny";
-    for (int k = 0; k < C; ++k) b.wgrads(co[k], a->buf("dz") + k * Q, Nq, gs, ws);
-    b.wgrads(ao, a->buf("dlogits"), a->actor.dout, gs, ws);
-    b.wgrads(jb, a->buf("dstate"), L, gs, ws);
-    b.wgrads(eb, a->buf("denc"), c.enc_features, gs, ws);
+    for (int k = 0; k < C; ++k) b.wgrads(co[k], a->buf("dz") + k * Q, Nq, nullptr, gs, ws);
+    b.wgrads(ao, a->buf("dlogits"), a->actor.dout, nullptr, gs, ws);
+    b.wgrads(jb, a->buf("dstate"), L, a->buf("cs.dstate"), gs, ws);
+    b.wgrads(eb, a->buf("denc"), c.enc_features, a->buf("cs.denc"), gs, ws);
     a->stages.push_back(gs);
     a->stages.push_back(ws);
   }
@@ -705,8 +668,14 @@ int build_plan(fdql_agent *a) {
 
 hipError_t run_stage(fdql_agent *a, Stage &s, hipStream_t stream) {
   switch (s.kind) {
-    case ST_GEMM: return gemm_launch((const GemmProblem *)s.dev, (int)s.gemm.size(), s.blocks, stream);
-    case ST_SKINNY_FWD: return skinny_fwd_launch_host(s.sfwd.data(), (const SkinnyFwdProblem *)s.dev, (int)s.sfwd.size(), s.blocks, stream);
+    case ST_GEMM:
+      for (int sh = 0; sh < GEMM_NSHAPES; ++sh) {
+        const GemmSub &sub = s.sub[sh];
+        if (sub.blocks <= 0) continue;
+        hipError_t e = gemm_launch((const GemmProblem *)sub.dev, (int)sub.probs.size(), sub.blocks, sh, stream);
+        if (e != hipSuccess) return e;
+      }
+      return hipSuccess;
     case ST_SKINNY_WGRAD: return skinny_wgrad_launch_host(s.swg.data(), (const SkinnyWgradProblem *)s.dev, (int)s.swg.size(), s.blocks, stream);
     case ST_FUNC: return s.fn(stream);
   }
@@ -758,8 +727,6 @@ int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {
                    c.n_joint_hidden <= FDQL_MAX_HIDDEN && c.n_pi_hidden >= 0 && c.n_pi_hidden <= FDQL_MAX_HIDDEN &&
                    c.n_critic_hidden >= 0 && c.n_critic_hidden <= FDQL_MAX_HIDDEN, "bad hidden layer counts");
   FDQL_REQUIRE(c.latent > 0 && c.enc_features > 0, "bad latent dims");
-  FDQL_REQUIRE(c.n_critic_hidden + 1 + 1 <= SKINNY_MAX_SEG && c.n_quantiles <= SKINNY_MAX_OUT,
-               "critic head too wide for the skinny head kernel (Q <= 32)");
   fdql_agent *a = new fdql_agent();
   a->cfg = c;
   a->T = c.T; a->B = c.B; a->N = c.T * c.B; a->M = (c.T - 1) * c.B; a->A = c.act_dim; a->L = c.latent;
@@ -876,7 +843,7 @@ int32_t fdql_agent_profile_update(fdql_agent_t *a, const fdql_batch_t *batch, co
     float ms = 0;
     FDQL_HIP(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
     const Stage &st = a->stages[i];
-    const char *kind = st.kind == ST_GEMM ? "gemm:" : st.kind == ST_SKINNY_FWD ? "skinny_fwd:" : st.kind == ST_SKINNY_WGRAD ? "skinny_wgrad:" : "k:";
+    const char *kind = st.kind == ST_GEMM ? "gemm:" : st.kind == ST_SKINNY_WGRAD ? "colsum:" : "k:";
     snprintf(out[cnt].name, sizeof(out[cnt].name), "%s%s", kind, st.name.c_str());
     out[cnt].ms = ms;
     out[cnt].flops = st.flops;
@@ -932,8 +899,11 @@ int fdql_agent_stats(const fdql_agent_t *a, fdql_agent_stats_t *out) {
   out->params = a->n_train;
   for (const Stage &s : a->stages) {
     out->n_launches++;
-    if (s.kind == ST_GEMM) { out->gemm_flops += s.flops; out->n_gemm_launches++; }
-    if (s.kind == ST_SKINNY_FWD || s.kind == ST_SKINNY_WGRAD) out->skinny_flops += s.flops;
+    if (s.kind == ST_GEMM) {
+      out->gemm_flops += s.flops;
+      for (const auto &sub : s.sub) if (sub.blocks > 0) out->n_gemm_launches++;
+    }
+    if (s.kind == ST_SKINNY_WGRAD) out->skinny_flops += s.flops;
   }
   return 0;
 }
@@ -947,11 +917,12 @@ int fdql_test_gemm(const float *A, int32_t lda, int32_t a_kc, const float *B, in
   p.bias = bias; p.epi = epilogue; p.ref = ref; p.ldref = ldref;
   p.nseg = 1;
   p.seg[0].A = A; p.seg[0].lda = lda; p.seg[0].a_kc = a_kc; p.seg[0].B = B; p.seg[0].ldb = ldb; p.seg[0].b_kc = b_kc; p.seg[0].K = K;
-  const int blocks = gemm_finalize(&p, 1);
+  const int shape = gemm_pick_shape(p);
+  const int blocks = gemm_finalize(&p, 1, shape);
   GemmProblem *dev = nullptr;
   FDQL_HIP(hipMalloc(&dev, sizeof(p)));
   FDQL_HIP(hipMemcpy(dev, &p, sizeof(p), hipMemcpyHostToDevice));
-  hipError_t e = gemm_launch(dev, 1, blocks, (hipStream_t)stream);
+  hipError_t e = gemm_launch(dev, 1, blocks, shape, (hipStream_t)stream);
   if (e != hipSuccess) { set_error("gemm launch: %s", hipGetErrorString(e)); (void)hipFree(dev); return FDQL_EHIP; }
   FDQL_HIP(hipStreamSynchronize((hipStream_t)stream));
   FDQL_HIP(hipFree(dev));

@@ -44,6 +44,7 @@ struct GemmSeg {
 };
 
 enum GemmEpilogue { EPI_NONE = 0, EPI_LRELU = 1, EPI_LRELU_GRAD = 2 };
+enum GemmShape { GEMM_128x128 = 0, GEMM_128x32 = 1, GEMM_32x128 = 2, GEMM_NSHAPES = 3 };
 
 struct GemmProblem {
   int M, N;
@@ -56,38 +57,24 @@ struct GemmProblem {
   int epi;
   const float *ref;        // EPI_LRELU_GRAD: activation output whose sign gates the gradient
   int ldref;
+  float *colsum;           // optional [ceil(M/128), N]: per-tile column sums of the stored values
   int tiles_m, tiles_n;    // filled by gemm_finalize
   int tile_start;          // first block id of this problem in its launch
   GemmSeg seg[GEMM_MAX_SEG];
 };
 
 // Fills tiles_* / tile_start for a launch group; returns the total number of blocks.
-int gemm_finalize(GemmProblem *probs, int nprob);
+int gemm_finalize(GemmProblem *probs, int nprob, int shape);
+int gemm_pick_shape(const GemmProblem &p);
 double gemm_flops(const GemmProblem &p);
-// probs_dev: device copy of the finalized group.
-hipError_t gemm_launch(const GemmProblem *probs_dev, int nprob, int total_blocks, hipStream_t stream);
+double gemm_bytes(const GemmProblem &p);
+// probs_dev: device copy of the finalized group (all problems of one tile shape).
+hipError_t gemm_launch(const GemmProblem *probs_dev, int nprob, int total_blocks, int shape, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------
-// Skinny ops (kernels.hip): heads with N_out <= 32, bias/colsum reductions
+// Column-sum / narrow reductions (kernels.hip): bias gradients
 // ---------------------------------------------------------------------------------------
-constexpr int SKINNY_MAX_SEG = 24;
 constexpr int SKINNY_MAX_OUT = 32;
-
-struct SkinnySeg {
-  const float *X;  // [M, K] row-major, ld
-  int ldx, K;
-  const float *W;  // weight element (n, k) = W[n*wsn + k*wsk]
-  int wsn, wsk;
-};
-struct SkinnyFwdProblem {
-  int M, Nout, nseg;
-  float *Y;
-  int ldy;
-  const float *bias;  // [Nout] or null
-  int row_start;      // filled by finalize: first block id
-  SkinnySeg seg[SKINNY_MAX_SEG];
-};
-int skinny_fwd_finalize(SkinnyFwdProblem *p, int n);
 
 // dW(q, k) (slab s) = sum_{m in split s} dY[m, q] * X[m, k], written to dW[q*sq + k*sk].
 // dY == null: dY = 1, Nout = 1 (column sums of X: bias gradients).

@@ -21,22 +21,36 @@
 
 namespace fdql {
 
-constexpr int BM = 128, BN = 128, BK = 16, PITCH = 132, GEMM_THREADS = 256;
+constexpr int BK = 16, GEMM_THREADS = 256;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Tile shapes (rows x cols per workgroup; 4 waves, each TM x TN MFMA tiles of 32x32):
+//   GEMM_128x128: waves 2x2, wave tile 2x2  — the dense layers
+//   GEMM_128x32 : waves 4x1, wave tile 1x1  — narrow outputs (heads with N<=32, d pi, few-column wgrads)
+//   GEMM_32x128 : waves 1x4, wave tile 1x1  — few-row outputs (head weight gradients, K-split)
+// The narrow shapes waste MFMA lanes on padding but those problems are bandwidth-bound: what
+// matters is that they stream their big operand through the same coalesced LDS staging.
+template <int SHAPE> struct TileCfg;
+template <> struct TileCfg<GEMM_128x128> { static constexpr int WM = 2, WN = 2, TM = 2, TN = 2; };
+template <> struct TileCfg<GEMM_128x32> { static constexpr int WM = 4, WN = 1, TM = 1, TN = 1; };
+template <> struct TileCfg<GEMM_32x128> { static constexpr int WM = 1, WN = 4, TM = 1, TN = 1; };
 
 __device__ __forceinline__ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 __device__ __forceinline__ bool aligned8(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
 
-// Load this thread's share (2 x 4 floats) of a [128 rows x 16 k] operand chunk.
-// kc: element (r,k) at P[r*ld + k]; thread -> rows (tid>>2)+{0,64}, k = (tid&3)*4 + j.
-__device__ __forceinline__ void load_chunk_kc(const float *__restrict__ P, int ld, int R, int kend, int r0, int k0,
-                                              int tid, float (&v)[8]) {
-  const int kq = k0 + (tid & 3) * 4;
+// Load this thread's share of a [R rows x 16 k] operand chunk: NV float4 slots per thread
+// (NV = ceil(R*4/256)).  kc: element (r,k) at P[r*ld + k]; slot -> row = slot>>2, k = (slot&3)*4 + j.
+template <int R, int NV>
+__device__ __forceinline__ void load_chunk_kc(const float *__restrict__ P, int ld, int Rmax, int kend, int r0, int k0,
+                                              int tid, float (&v)[4 * NV]) {
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int r = r0 + (tid >> 2) + 64 * h;
+  for (int h = 0; h < NV; ++h) {
+    const int slot = tid + GEMM_THREADS * h;
+    const int kq = k0 + (slot & 3) * 4;
+    const int r = r0 + (slot >> 2);
+    const bool in_tile = (slot >> 2) < R;
     const float *p = P + (long long)r * ld + kq;
-    if (r < R && kq + 3 < kend) {
+    if (in_tile && r < Rmax && kq + 3 < kend) {
       if (aligned16(p)) {
         const float4 x = *reinterpret_cast<const float4 *>(p);
         v[4 * h + 0] = x.x; v[4 * h + 1] = x.y; v[4 * h + 2] = x.z; v[4 * h + 3] = x.w;
@@ -50,20 +64,25 @@ __device__ __forceinline__ void load_chunk_kc(const float *__restrict__ P, int l
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[4 * h + j] = (r < R && kq + j < kend) ? p[j] : 0.f;
+      for (int j = 0; j < 4; ++j) v[4 * h + j] = (in_tile && r < Rmax && kq + j < kend) ? p[j] : 0.f;
     }
   }
 }
 
-// ks: element (r,k) at P[k*ld + r]; thread -> k = (tid>>5)+{0,8}, rows (tid&31)*4 + j.
-__device__ __forceinline__ void load_chunk_ks(const float *__restrict__ P, int ld, int R, int kend, int r0, int k0,
-                                              int tid, float (&v)[8]) {
-  const int rq = r0 + (tid & 31) * 4;
+// ks: element (r,k) at P[k*ld + r]; slot -> k = slot / (R/4), rows (slot % (R/4))*4 + j.
+template <int R, int NV>
+__device__ __forceinline__ void load_chunk_ks(const float *__restrict__ P, int ld, int Rmax, int kend, int r0, int k0,
+                                              int tid, float (&v)[4 * NV]) {
+  constexpr int RQ = R / 4;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int k = k0 + (tid >> 5) + 8 * h;
+  for (int h = 0; h < NV; ++h) {
+    const int slot = tid + GEMM_THREADS * h;
+    const int kl = slot / RQ;
+    const int rq = r0 + (slot - kl * RQ) * 4;
+    const int k = k0 + kl;
+    const bool in_tile = kl < BK;
     const float *p = P + (long long)k * ld + rq;
-    if (k < kend && rq + 3 < R) {
+    if (in_tile && k < kend && rq + 3 < Rmax) {
       if (aligned16(p)) {
         const float4 x = *reinterpret_cast<const float4 *>(p);
         v[4 * h + 0] = x.x; v[4 * h + 1] = x.y; v[4 * h + 2] = x.z; v[4 * h + 3] = x.w;
@@ -77,32 +96,45 @@ __device__ __forceinline__ void load_chunk_ks(const float *__restrict__ P, int l
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[4 * h + j] = (k < kend && rq + j < R) ? p[j] : 0.f;
+      for (int j = 0; j < 4; ++j) v[4 * h + j] = (in_tile && k < kend && rq + j < Rmax) ? p[j] : 0.f;
     }
   }
 }
 
-__device__ __forceinline__ void store_chunk_kc(float *__restrict__ lds, int tid, const float (&v)[8]) {
-  const int kq = (tid & 3) * 4;
+template <int R, int NV>
+__device__ __forceinline__ void store_chunk_kc(float *__restrict__ lds, int tid, const float (&v)[4 * NV]) {
+  constexpr int PITCH = R + 4;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int r = (tid >> 2) + 64 * h;
+  for (int h = 0; h < NV; ++h) {
+    const int slot = tid + GEMM_THREADS * h;
+    const int kq = (slot & 3) * 4, r = slot >> 2;
+    if (r < R) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) lds[(kq + j) * PITCH + r] = v[4 * h + j];
+      for (int j = 0; j < 4; ++j) lds[(kq + j) * PITCH + r] = v[4 * h + j];
+    }
   }
 }
 
-__device__ __forceinline__ void store_chunk_ks(float *__restrict__ lds, int tid, const float (&v)[8]) {
-  const int rq = (tid & 31) * 4;
+template <int R, int NV>
+__device__ __forceinline__ void store_chunk_ks(float *__restrict__ lds, int tid, const float (&v)[4 * NV]) {
+  constexpr int PITCH = R + 4, RQ = R / 4;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int k = (tid >> 5) + 8 * h;
-    *reinterpret_cast<float4 *>(&lds[k * PITCH + rq]) = make_float4(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
+  for (int h = 0; h < NV; ++h) {
+    const int slot = tid + GEMM_THREADS * h;
+    const int kl = slot / RQ, rq = (slot - kl * RQ) * 4;
+    if (kl < BK)
+      *reinterpret_cast<float4 *>(&lds[kl * PITCH + rq]) = make_float4(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
   }
 }
 
+template <int SHAPE>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_grouped(const GemmProblem *__restrict__ probs, int nprob) {
-  __shared__ __attribute__((aligned(16))) float lds[2][2][BK * PITCH];
+  using Cfg = TileCfg<SHAPE>;
+  constexpr int BM = Cfg::WM * Cfg::TM * 32, BN = Cfg::WN * Cfg::TN * 32;
+  constexpr int PA = BM + 4, PB = BN + 4;
+  constexpr int NVA = (BM * 4 + GEMM_THREADS - 1) / GEMM_THREADS, NVB = (BN * 4 + GEMM_THREADS - 1) / GEMM_THREADS;
+  constexpr int TM = Cfg::TM, TN = Cfg::TN;
+  __shared__ __attribute__((aligned(16))) float lds[2][BK * (PA + PB)];
 
   const int tid = threadIdx.x;
   const int bid = blockIdx.x;
@@ -128,16 +160,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_grouped(const GemmProb
     ke0 = min(P.seg[0].K, kb0 + per);
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < TM; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
   const int li = lane & 31, lh = lane >> 5;
 
   // first non-empty chunk
@@ -148,17 +180,22 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_grouped(const GemmProb
   }
   bool have = (s < nseg) && (ksplit == 1 || s == 0);
 
-  float va[8], vb[8];
-  int cur_akc = 1, cur_bkc = 1;
+  float va[4 * NVA], vb[4 * NVB];
   if (have) {
     const GemmSeg &S = P.seg[s];
-    cur_akc = S.a_kc; cur_bkc = S.b_kc;
-    if (cur_akc) load_chunk_kc(S.A, S.lda, M, ke, r0, k, tid, va); else load_chunk_ks(S.A, S.lda, M, ke, r0, k, tid, va);
-    if (cur_bkc) load_chunk_kc(S.B, S.ldb, N, ke, c0, k, tid, vb); else load_chunk_ks(S.B, S.ldb, N, ke, c0, k, tid, vb);
-    if (cur_akc) store_chunk_kc(lds[0][0], tid, va); else store_chunk_ks(lds[0][0], tid, va);
-    if (cur_bkc) store_chunk_kc(lds[0][1], tid, vb); else store_chunk_ks(lds[0][1], tid, vb);
+    if (S.a_kc) load_chunk_kc<BM, NVA>(S.A, S.lda, M, ke, r0, k, tid, va); else load_chunk_ks<BM, NVA>(S.A, S.lda, M, ke, r0, k, tid, va);
+    if (S.b_kc) load_chunk_kc<BN, NVB>(S.B, S.ldb, N, ke, c0, k, tid, vb); else load_chunk_ks<BN, NVB>(S.B, S.ldb, N, ke, c0, k, tid, vb);
+    if (S.a_kc) store_chunk_kc<BM, NVA>(lds[0], tid, va); else store_chunk_ks<BM, NVA>(lds[0], tid, va);
+    if (S.b_kc) store_chunk_kc<BN, NVB>(lds[0] + BK * PA, tid, vb); else store_chunk_ks<BN, NVB>(lds[0] + BK * PA, tid, vb);
   }
   __syncthreads();
+#ifdef FDQL_GEMM_DEBUG
+  if (P.ref && P.epi == 99) {  // debug: dump the first staged chunk
+    float *dbg = const_cast<float *>(P.ref);
+    for (int e = tid; e < BK * (PA + PB); e += GEMM_THREADS) dbg[e] = lds[0][e];
+    __syncthreads();
+  }
+#endif
 
   int cur = 0;
   while (have) {
@@ -175,26 +212,34 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_grouped(const GemmProb
     if (has_next) {
       const GemmSeg &S = P.seg[ns];
       n_akc = S.a_kc; n_bkc = S.b_kc;
-      if (n_akc) load_chunk_kc(S.A, S.lda, M, nke, r0, nk, tid, va); else load_chunk_ks(S.A, S.lda, M, nke, r0, nk, tid, va);
-      if (n_bkc) load_chunk_kc(S.B, S.ldb, N, nke, c0, nk, tid, vb); else load_chunk_ks(S.B, S.ldb, N, nke, c0, nk, tid, vb);
+      if (n_akc) load_chunk_kc<BM, NVA>(S.A, S.lda, M, nke, r0, nk, tid, va); else load_chunk_ks<BM, NVA>(S.A, S.lda, M, nke, r0, nk, tid, va);
+      if (n_bkc) load_chunk_kc<BN, NVB>(S.B, S.ldb, N, nke, c0, nk, tid, vb); else load_chunk_ks<BN, NVB>(S.B, S.ldb, N, nke, c0, nk, tid, vb);
     }
 
-    const float *la = lds[cur][0] + wm * 64 + li;
-    const float *lb = lds[cur][1] + wn * 64 + li;
+    const float *la = lds[cur] + wm * (TM * 32) + li;
+    const float *lb = lds[cur] + BK * PA + wn * (TN * 32) + li;
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
-      const int row = (2 * kk + lh) * PITCH;
-      const float a0 = la[row], a1 = la[row + 32];
-      const float b0 = lb[row], b1 = lb[row + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      float a[TM], b[TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) a[t] = la[(2 * kk + lh) * PA + 32 * t];
+#pragma unroll
+      for (int t = 0; t < TN; ++t) b[t] = lb[(2 * kk + lh) * PB + 32 * t];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
     }
+    // Keep the fragment base addresses live past the last read of the chunk.  Without this hipcc
+    // (ROCm 7.2) lets the chunk's final `ds_read_b32` overwrite its own address VGPR
+    // (vdst == vaddr); on gfx950 that read returned zeros in lanes 27/31/59/63 of every wave of the
+    // 128x32 tile variant (observed, reproducible; LDS contents verified correct by a dump).
+    asm volatile("" ::"v"(la), "v"(lb));
 
     if (!has_next) break;
-    if (n_akc) store_chunk_kc(lds[cur ^ 1][0], tid, va); else store_chunk_ks(lds[cur ^ 1][0], tid, va);
-    if (n_bkc) store_chunk_kc(lds[cur ^ 1][1], tid, vb); else store_chunk_ks(lds[cur ^ 1][1], tid, vb);
+    if (n_akc) store_chunk_kc<BM, NVA>(lds[cur ^ 1], tid, va); else store_chunk_ks<BM, NVA>(lds[cur ^ 1], tid, va);
+    if (n_bkc) store_chunk_kc<BN, NVB>(lds[cur ^ 1] + BK * PA, tid, vb); else store_chunk_ks<BN, NVB>(lds[cur ^ 1] + BK * PA, tid, vb);
     __syncthreads();
     cur ^= 1;
     s = ns; k = nk; ke = nke;
@@ -206,16 +251,19 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_grouped(const GemmProb
   const float *bias = P.bias;
   const float *ref = P.ref;
   const int ldref = P.ldref;
+  float csum[TN];
 #pragma unroll
-  for (int tm = 0; tm < 2; ++tm) {
+  for (int tn = 0; tn < TN; ++tn) csum[tn] = 0.f;
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-      const int col = c0 + wn * 64 + tn * 32 + li;
+  for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = c0 + (wn * TN + tn) * 32 + li;
       if (col >= N) continue;
       const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = r0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int row = r0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (row >= M) continue;
         float x = acc[tm][tn][r] + bv;
         if (epi == EPI_LRELU) {
@@ -225,22 +273,51 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_grouped(const GemmProb
           x = a > 0.f ? x : 0.01f * x;
         }
         C[(long long)row * ldc + col] = x;
+        csum[tn] += x;
       }
+    }
+  }
+  // optional column sums of this tile (bias gradients): fixed-order reduction through LDS,
+  // one partial row per tile_m: colsum[tile_m][N]
+  if (P.colsum) {
+    __syncthreads();  // every wave is done reading the staging buffers
+    float *red = lds[0];  // [WM][2][BN]
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) red[(wm * 2 + lh) * BN + (wn * TN + tn) * 32 + li] = csum[tn];
+    __syncthreads();
+    if (tid < BN && c0 + tid < N) {
+      float t = 0.f;
+#pragma unroll
+      for (int j = 0; j < Cfg::WM * 2; ++j) t += red[j * BN + tid];
+      P.colsum[(long long)tile_m * N + c0 + tid] = t;
     }
   }
 }
 
-int gemm_finalize(GemmProblem *probs, int nprob) {
+static void shape_dims(int shape, int &bm, int &bn) {
+  bm = shape == GEMM_32x128 ? 32 : 128;
+  bn = shape == GEMM_128x32 ? 32 : 128;
+}
+
+int gemm_finalize(GemmProblem *probs, int nprob, int shape) {
+  int bm, bn;
+  shape_dims(shape, bm, bn);
   int total = 0;
   for (int i = 0; i < nprob; ++i) {
     GemmProblem &p = probs[i];
-    p.tiles_m = (p.M + BM - 1) / BM;
-    p.tiles_n = (p.N + BN - 1) / BN;
+    p.tiles_m = (p.M + bm - 1) / bm;
+    p.tiles_n = (p.N + bn - 1) / bn;
     if (p.ksplit < 1) p.ksplit = 1;
     p.tile_start = total;
     total += p.tiles_m * p.tiles_n * p.ksplit;
   }
   return total;
+}
+
+int gemm_pick_shape(const GemmProblem &p) {
+  if (p.N <= 32) return GEMM_128x32;
+  if (p.M <= 32 && !p.colsum) return GEMM_32x128;
+  return GEMM_128x128;
 }
 
 double gemm_flops(const GemmProblem &p) {
@@ -249,9 +326,20 @@ double gemm_flops(const GemmProblem &p) {
   return 2.0 * p.M * (double)p.N * k;
 }
 
-hipError_t gemm_launch(const GemmProblem *probs_dev, int nprob, int total_blocks, hipStream_t stream) {
+double gemm_bytes(const GemmProblem &p) {
+  double b = 0;
+  for (int s = 0; s < p.nseg; ++s) b += 4.0 * p.seg[s].K * ((double)p.M + p.N);
+  return b + 4.0 * p.M * (double)p.N * p.ksplit;
+}
+
+hipError_t gemm_launch(const GemmProblem *probs_dev, int nprob, int total_blocks, int shape, hipStream_t stream) {
   if (total_blocks <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_gemm_grouped, dim3(total_blocks), dim3(GEMM_THREADS), 0, stream, probs_dev, nprob);
+  if (shape == GEMM_128x128)
+    hipLaunchKernelGGL(k_gemm_grouped<GEMM_128x128>, dim3(total_blocks), dim3(GEMM_THREADS), 0, stream, probs_dev, nprob);
+  else if (shape == GEMM_128x32)
+    hipLaunchKernelGGL(k_gemm_grouped<GEMM_128x32>, dim3(total_blocks), dim3(GEMM_THREADS), 0, stream, probs_dev, nprob);
+  else
+    hipLaunchKernelGGL(k_gemm_grouped<GEMM_32x128>, dim3(total_blocks), dim3(GEMM_THREADS), 0, stream, probs_dev, nprob);
   return hipGetLastError();
 }
 

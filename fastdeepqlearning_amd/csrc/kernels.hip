@@ -6,101 +6,6 @@
 namespace fdql {
 
 // ======================================================================================
-// Skinny forward: Y[m, q] = sum_seg sum_k X_seg[m, k] * W_seg(q, k) + bias[q],  Nout <= 32
-// One wave per row, lanes stride over k (coalesced), weights staged once per block in LDS
-// as [k][Nout(+pad)], butterfly reduction per output.  Used for the critic heads (Nout=Q),
-// the actor head (Nout = 2A) and the d(pi) dgrad of the frozen critics.
-// ======================================================================================
-constexpr int SK_ROWS_PER_BLOCK = 64;
-constexpr int SK_THREADS = 256;
-
-template <int NOUT_MAX>
-__global__ __launch_bounds__(SK_THREADS) void k_skinny_fwd(const SkinnyFwdProblem *__restrict__ probs, int nprob) {
-  extern __shared__ __attribute__((aligned(16))) float wlds[];
-  const int bid = blockIdx.x;
-  int pi = 0;
-  for (int i = 1; i < nprob; ++i)
-    if (bid >= probs[i].row_start) pi = i;
-  const SkinnyFwdProblem &P = probs[pi];
-  const int Nout = P.Nout, NP = Nout | 1, nseg = P.nseg, M = P.M;
-  const int tid = threadIdx.x;
-
-  // stage all weights: wlds[(koff + k) * NP + q]
-  int koff = 0;
-  for (int s = 0; s < nseg; ++s) {
-    const SkinnySeg &S = P.seg[s];
-    const int tot = S.K * Nout;
-    for (int e = tid; e < tot; e += SK_THREADS) {
-      int k, q;
-      if (S.wsk == 1) { q = e / S.K; k = e - q * S.K; }   // consecutive threads walk k (contiguous in memory)
-      else { k = e / Nout; q = e - k * Nout; }            // consecutive threads walk q
-      wlds[(koff + k) * NP + q] = S.W[(long long)q * S.wsn + (long long)k * S.wsk];
-    }
-    koff += S.K;
-  }
-  __syncthreads();
-
-  const int lane = tid & 63, wave = tid >> 6;
-  const int row0 = (bid - P.row_start) * SK_ROWS_PER_BLOCK;
-  for (int rr = wave; rr < SK_ROWS_PER_BLOCK; rr += SK_THREADS / 64) {
-    const int m = row0 + rr;
-    if (m >= M) break;
-    float acc[NOUT_MAX];
-#pragma unroll
-    for (int q = 0; q < NOUT_MAX; ++q) acc[q] = 0.f;
-    int ko = 0;
-    for (int s = 0; s < nseg; ++s) {
-      const SkinnySeg &S = P.seg[s];
-      const float *x = S.X + (long long)m * S.ldx;
-      for (int k = lane; k < S.K; k += 64) {
-        const float xv = x[k];
-        const float *w = &wlds[(ko + k) * NP];
-#pragma unroll
-        for (int q = 0; q < NOUT_MAX; ++q)
-          if (q < Nout) acc[q] = fmaf(xv, w[q], acc[q]);
-      }
-      ko += S.K;
-    }
-#pragma unroll
-    for (int q = 0; q < NOUT_MAX; ++q) {
-      if (q < Nout) {
-        float v = acc[q];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-        if (lane == 0) P.Y[(long long)m * P.ldy + q] = v + (P.bias ? P.bias[q] : 0.f);
-      }
-    }
-  }
-}
-
-int skinny_fwd_finalize(SkinnyFwdProblem *p, int n) {
-  int total = 0;
-  for (int i = 0; i < n; ++i) {
-    p[i].row_start = total;
-    total += (p[i].M + SK_ROWS_PER_BLOCK - 1) / SK_ROWS_PER_BLOCK;
-  }
-  return total;
-}
-
-hipError_t skinny_fwd_launch_host(const SkinnyFwdProblem *host, const SkinnyFwdProblem *dev, int n, int total_blocks,
-                                  hipStream_t s) {
-  if (total_blocks <= 0) return hipSuccess;
-  int max_out = 0;
-  size_t lds = 0;
-  for (int i = 0; i < n; ++i) {
-    max_out = host[i].Nout > max_out ? host[i].Nout : max_out;
-    size_t k = 0;
-    for (int j = 0; j < host[i].nseg; ++j) k += host[i].seg[j].K;
-    size_t b = k * (size_t)(host[i].Nout | 1) * sizeof(float);
-    lds = b > lds ? b : lds;
-  }
-  if (max_out <= 4) hipLaunchKernelGGL(k_skinny_fwd<4>, dim3(total_blocks), dim3(SK_THREADS), lds, s, dev, n);
-  else if (max_out <= 16) hipLaunchKernelGGL(k_skinny_fwd<16>, dim3(total_blocks), dim3(SK_THREADS), lds, s, dev, n);
-  else hipLaunchKernelGGL(k_skinny_fwd<32>, dim3(total_blocks), dim3(SK_THREADS), lds, s, dev, n);
-  return hipGetLastError();
-}
-
-// ======================================================================================
 // Skinny wgrad / column sums: dW[q, k] (slab) = sum_{m in split} dY[m, q] * X[m, k]
 // Block = 64 columns x 4 row lanes (one wave per row lane, so dY[m, q] is wave-uniform);
 // LDS reduction over the 4 row lanes; one slab per split (deterministic, no atomics).
@@ -216,21 +121,33 @@ __device__ __forceinline__ float device_noise(uint64_t seed, uint32_t step, uint
 // prep: mask / is_contiguous / per-window normaliser -> per-row loss weight
 //   deepQlearning.py:201-203, 222-225, 249
 // ======================================================================================
-__global__ void k_prep(const float *__restrict__ task_done, const float *__restrict__ episode_step, int T, int B,
-                       float inv_global_batch, float *__restrict__ w, float *__restrict__ contig) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  float cnt = 0.f;
-  for (int t = 0; t < T - 1; ++t) {
-    const int m = t * B + b;
-    const bool c = (episode_step[m + B] == episode_step[m] + 1.0f) && (task_done[m] == 0.f);
-    contig[m] = c ? 1.f : 0.f;
-    cnt += c ? 1.f : 0.f;
+// block = 16 windows x 16 time lanes; consecutive threads -> consecutive b (coalesced rows)
+__global__ __launch_bounds__(256) void k_prep(const float *__restrict__ task_done, const float *__restrict__ episode_step,
+                                              int T, int B, float inv_global_batch, float *__restrict__ w,
+                                              float *__restrict__ contig) {
+  __shared__ float cnt[16][17];
+  const int bl = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  const int b = blockIdx.x * 16 + bl;
+  float c_local = 0.f;
+  if (b < B) {
+    for (int t = tl; t < T - 1; t += 16) {
+      const int m = t * B + b;
+      const bool c = (episode_step[m + B] == episode_step[m] + 1.0f) && (task_done[m] == 0.f);
+      contig[m] = c ? 1.f : 0.f;
+      c_local += c ? 1.f : 0.f;
+    }
   }
-  const float denom = cnt + 1e-4f;
-  for (int t = 0; t < T - 1; ++t) {
-    const int m = t * B + b;
-    w[m] = ((contig[m] / denom) * inv_global_batch) / (float)T;
+  cnt[tl][bl] = c_local;
+  __syncthreads();
+  float total = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) total += cnt[j][bl];   // exact: a count of at most T-1 ones
+  const float denom = total + 1e-4f;
+  if (b < B) {
+    for (int t = tl; t < T - 1; t += 16) {
+      const int m = t * B + b;
+      w[m] = ((contig[m] / denom) * inv_global_batch) / (float)T;
+    }
   }
 }
 
@@ -551,7 +468,7 @@ hipError_t adam_launch(const AdamArgs &a, hipStream_t s) {
 
 hipError_t prep_launch(const float *task_done, const float *episode_step, int T, int B, float inv_gb, float *w,
                        float *contig, hipStream_t s) {
-  hipLaunchKernelGGL(k_prep, dim3((B + 255) / 256), dim3(256), 0, s, task_done, episode_step, T, B, inv_gb, w, contig);
+  hipLaunchKernelGGL(k_prep, dim3((B + 15) / 16), dim3(256), 0, s, task_done, episode_step, T, B, inv_gb, w, contig);
   return hipGetLastError();
 }
 

@@ -15,8 +15,8 @@ namespace fdql {
 
 constexpr int RING_MAX_KEYS = 16;
 constexpr int GATHER_THREADS = 256;
-constexpr int STAGE_WINDOWS = 16;        // windows per block in the LDS-staged path
-constexpr int STAGE_LDS_FLOATS = 12288;  // 48 KiB of staging per block
+constexpr int STAGE_WINDOWS = 8;         // windows per block in the LDS-staged path
+constexpr int STAGE_LDS_FLOATS = 8192;   // 32 KiB of staging per block
 
 struct GatherKey {
   const float *src;  // [maxlen, dim]
@@ -70,6 +70,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather_windows(GatherArgs a)
   __shared__ __attribute__((aligned(16))) float stage[STAGE_LDS_FLOATS];
   __shared__ long long sstart[STAGE_WINDOWS];
   const int bid = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
   int ki = 0;
   for (int i = 1; i < a.nkeys; ++i)
     if (bid >= a.key[i].block_start) ki = i;
@@ -81,42 +82,49 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather_windows(GatherArgs a)
     const int bb = local % K.blocks_b, tb = local / K.blocks_b;
     const int b0 = bb * STAGE_WINDOWS, t0 = tb * K.tchunk;
     const int nw = min(STAGE_WINDOWS, B - b0), nt = min(K.tchunk, T - t0);
-    if (tid < nw) sstart[tid] = a.starts[b0 + tid];
+    if (tid < nw) sstart[tid] = (a.starts[b0 + tid] + t0) % len;   // index block staged in LDS
     __syncthreads();
-    const int run = nt * dim;  // floats per window in this chunk
-    for (int e = tid; e < nw * run; e += GATHER_THREADS) {
-      const int w = e / run, r = e - w * run;
-      const int t = r / dim, c = r - t * dim;
-      const long long row = (sstart[w] + t0 + t) % len;
-      stage[e] = K.src[row * dim + c];
+    const int run = nt * dim;  // floats per window in this chunk: ONE contiguous source run
+    for (int w = wave; w < nw; w += GATHER_THREADS / 64) {
+      const long long s0 = sstart[w];
+      float *dstl = stage + w * run;
+      if (s0 + nt <= len) {
+        const float *src = K.src + s0 * dim;
+        for (int e = lane; e < run; e += 64) dstl[e] = src[e];
+      } else {  // the window crosses the wrap point (only with caller-supplied starts)
+        for (int e = lane; e < run; e += 64) {
+          const int t = e / dim;
+          long long row = s0 + t;
+          if (row >= len) row -= len;
+          dstl[e] = K.src[row * dim + (e - t * dim)];
+        }
+      }
     }
     __syncthreads();
-    const int wrun = nw * dim;  // floats per time step written by this block
-    for (int e = tid; e < nt * wrun; e += GATHER_THREADS) {
-      const int t = e / wrun, r = e - t * wrun;
+    const int wrun = nw * dim;  // floats per time step written by this block (contiguous in the output)
+    float *dst0 = K.dst + ((long long)t0 * B + b0) * dim;
+    const long long tstride = (long long)B * dim;
+    for (int r = tid; r < wrun; r += GATHER_THREADS) {
       const int w = r / dim, c = r - w * dim;
-      K.dst[((long long)(t0 + t) * B + b0) * dim + r] = stage[w * run + t * dim + c];
+      const float *sp = stage + w * run + c;
+      float *dp = dst0 + r;
+      for (int t = 0; t < nt; ++t) dp[t * tstride] = sp[t * dim];
     }
   } else {
-    const long long rows = (long long)T * B;
-    if ((dim & 3) == 0) {
-      const int d4 = dim >> 2;
-      const long long total = rows * d4;
-      for (long long e = (long long)local * GATHER_THREADS + tid; e < total; e += (long long)K.blocks_b * GATHER_THREADS) {
-        const long long row = e / d4;
-        const int c = (int)(e - row * d4);
-        const int t = (int)(row / B), b = (int)(row - (long long)t * B);
-        const long long srow = (a.starts[b] + t) % len;
-        reinterpret_cast<float4 *>(K.dst)[e] = reinterpret_cast<const float4 *>(K.src)[srow * d4 + c];
-      }
-    } else {
-      const long long total = rows * dim;
-      for (long long e = (long long)local * GATHER_THREADS + tid; e < total; e += (long long)K.blocks_b * GATHER_THREADS) {
-        const long long row = e / dim;
-        const int c = (int)(e - row * dim);
-        const int t = (int)(row / B), b = (int)(row - (long long)t * B);
-        const long long srow = (a.starts[b] + t) % len;
-        K.dst[e] = K.src[srow * dim + c];
+    // wide rows: one (t, b) row per wave iteration, lanes stride over the row
+    const int rows = T * B;
+    const int waves_total = K.blocks_b * (GATHER_THREADS / 64);
+    for (int row = local * (GATHER_THREADS / 64) + wave; row < rows; row += waves_total) {
+      const int t = row / B, b = row - t * B;
+      long long srow = a.starts[b] + t;
+      if (srow >= len) srow %= len;
+      const float *src = K.src + srow * dim;
+      float *dst = K.dst + (long long)row * dim;
+      if ((dim & 3) == 0) {
+        for (int e = lane; e < (dim >> 2); e += 64)
+          reinterpret_cast<float4 *>(dst)[e] = reinterpret_cast<const float4 *>(src)[e];
+      } else {
+        for (int e = lane; e < dim; e += 64) dst[e] = src[e];
       }
     }
   }
@@ -292,8 +300,8 @@ int gather(fdql_ring *r, int T, int B, const long long *starts, float *const *ou
       total += g.blocks_b * g.blocks_t;
     } else {
       g.staged = 0;
-      const long long elems = (long long)T * B * ((g.dim & 3) == 0 ? g.dim / 4 : g.dim);
-      g.blocks_b = (int)std::max<long long>(1, std::min<long long>((elems + GATHER_THREADS * 4 - 1) / (GATHER_THREADS * 4), 2048));
+      const long long rows = (long long)T * B;   // 4 rows per block pass; cap the grid and stride the rest
+      g.blocks_b = (int)std::max<long long>(1, std::min<long long>((rows + 3) / 4, 4096));
       g.blocks_t = 1;
       total += g.blocks_b;
     }

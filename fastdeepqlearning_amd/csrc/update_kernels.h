@@ -58,8 +58,6 @@ struct AdamArgs {
   long long frozen_begin, frozen_end;
 };
 
-hipError_t skinny_fwd_launch_host(const SkinnyFwdProblem *host, const SkinnyFwdProblem *dev, int n, int total_blocks,
-                                  hipStream_t s);
 hipError_t skinny_wgrad_launch_host(const SkinnyWgradProblem *host, const SkinnyWgradProblem *dev, int n,
                                     int total_blocks, hipStream_t s);
 hipError_t loss_launch(const LossArgs &a, hipStream_t s);
