@@ -224,7 +224,7 @@ void carve(fdql_agent *a) {
       a->alloc(p + ".h" + std::to_string(i), rows * d.hid[i]);
       if (bwd) {
         a->alloc(p + ".dpre" + std::to_string(i), M * d.hid[i]);
-        a->alloc(p + ".cs" + std::to_string(i), ((M + 127) / 128) * d.hid[i]);
+        a->alloc(p + ".cs" + std::to_string(i), ((M + 63) / 64) * d.hid[i]);
       }
     }
     if (out) a->alloc(p + ".out", rows * d.dout);
@@ -258,8 +258,9 @@ void carve(fdql_agent *a) {
   a->alloc("dlogits", M * a->actor.dout);
   a->alloc("dstate", M * c.latent);
   a->alloc("denc", M * c.enc_features);
-  a->alloc("cs.dstate", ((M + 127) / 128) * c.latent);
-  a->alloc("cs.denc", ((M + 127) / 128) * c.enc_features);
+  a->alloc("cs.dstate", ((M + 63) / 64) * c.latent);
+  a->alloc("cs.denc", ((M + 63) / 64) * c.enc_features);
+  a->alloc("dpi_part", (int64_t)c.n_critics * M * c.act_dim);
   a->alloc("loss_partials", (int64_t)loss_blocks((int)M, 256) * LOSS_NPART + (int64_t)M * LOSS_NPART);
   a->alloc("slabs", (int64_t)a->nsplit * a->n_train);
 }
@@ -369,7 +370,7 @@ struct Builder {
       SkinnyWgradProblem p;
       memset(&p, 0, sizeof(p));
       p.Nout = 1; p.K = nout; p.dY = nullptr;
-      if (cs) { p.M = (R + 127) / 128; p.X = cs; p.ldx = nout; }
+      if (cs) { p.M = (R + 63) / 64; p.X = cs; p.ldx = nout; }
       else { p.M = R; p.X = dOut; p.ldx = ldo; }
       p.dW = dst; p.sq = 0; p.sk = 1; p.split_stride = P; p.nsplit = S;
       ws.swg.push_back(p);
@@ -416,7 +417,12 @@ int upload_tables(fdql_agent *a) {
   for (Stage &s : a->stages) {
     if (s.kind == ST_GEMM) {
       for (auto &sub : s.sub) sub.probs.clear();
-      for (auto &p : s.gemm) s.sub[gemm_pick_shape(p)].probs.push_back(p);
+      long long tiles128 = 0;  // workgroups this stage would get from its dense problems on 128x128 tiles
+      for (auto &p : s.gemm)
+        if (gemm_pick_shape(p, false) == GEMM_128x128)
+          tiles128 += (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * (p.ksplit > 1 ? p.ksplit : 1);
+      const bool few = tiles128 < 512;
+      for (auto &p : s.gemm) s.sub[gemm_pick_shape(p, few)].probs.push_back(p);
       for (auto &sub : s.sub) total += pad(sub.probs.size() * sizeof(GemmProblem));
     }
     if (s.kind == ST_SKINNY_WGRAD) total += pad(s.swg.size() * sizeof(SkinnyWgradProblem));
@@ -581,19 +587,22 @@ int build_plan(fdql_agent *a) {
         gs.gemm.push_back(b.bwd_dpre(cf[k], i, a->buf("dzf") + k * Q, Nq));
       }
     }
-    // d pi = sum_c input-grad of the frozen critics' action columns (narrow output: 128x32 tile)
+    // d pi: input-grad of each frozen critic's action columns as its own narrow (128x32) problem
+    // -> C partials [C][M][A], summed in fixed order by the policy backward kernel
     {
       Stage &gs = b.gemm_stage("dpi");
-      GemmProblem p = Builder::new_gemm(M, A, a->buf("dpi"), A);
-      for (int k = 0; k < C; ++k) b.input_grad_segs(cf[k], a->buf("dzf") + k * Q, Nq, L, p);
-      gs.gemm.push_back(p);
+      for (int k = 0; k < C; ++k) {
+        GemmProblem p = Builder::new_gemm(M, A, a->buf("dpi_part") + (int64_t)k * M * A, A);
+        b.input_grad_segs(cf[k], a->buf("dzf") + k * Q, Nq, L, p);
+        gs.gemm.push_back(p);
+      }
     }
   }
   // ---- policy backward
   {
-    const float *lo = ao.out, *nz = a->buf("noise_actor"), *pi = a->buf("pi"), *dpi = a->buf("dpi"), *w = a->buf("w");
-    float *dlo = a->buf("dlogits");
-    b.func_stage("policy_bwd", [=](hipStream_t s) { return policy_bwd_launch(lo, nz, pi, dpi, w, dst, M, A, dlo, s); });
+    const float *lo = ao.out, *nz = a->buf("noise_actor"), *pi = a->buf("pi"), *dpi = a->buf("dpi_part"), *w = a->buf("w");
+    float *dlo = a->buf("dlogits"), *dpi_sum = a->buf("dpi");
+    b.func_stage("policy_bwd", [=](hipStream_t s) { return policy_bwd_launch(lo, nz, pi, dpi, C, dpi_sum, w, dst, M, A, dlo, s); });
   }
   // ---- actor backward
   for (int i = (int)a->actor.hid.size() - 1; i >= 0; --i) {
@@ -917,7 +926,7 @@ int fdql_test_gemm(const float *A, int32_t lda, int32_t a_kc, const float *B, in
   p.bias = bias; p.epi = epilogue; p.ref = ref; p.ldref = ldref;
   p.nseg = 1;
   p.seg[0].A = A; p.seg[0].lda = lda; p.seg[0].a_kc = a_kc; p.seg[0].B = B; p.seg[0].ldb = ldb; p.seg[0].b_kc = b_kc; p.seg[0].K = K;
-  const int shape = gemm_pick_shape(p);
+  const int shape = gemm_pick_shape(p, ((M + 127) / 128) * ((N + 127) / 128) * p.ksplit < 512);
   const int blocks = gemm_finalize(&p, 1, shape);
   GemmProblem *dev = nullptr;
   FDQL_HIP(hipMalloc(&dev, sizeof(p)));

@@ -44,7 +44,7 @@ struct GemmSeg {
 };
 
 enum GemmEpilogue { EPI_NONE = 0, EPI_LRELU = 1, EPI_LRELU_GRAD = 2 };
-enum GemmShape { GEMM_128x128 = 0, GEMM_128x32 = 1, GEMM_32x128 = 2, GEMM_NSHAPES = 3 };
+enum GemmShape { GEMM_128x128 = 0, GEMM_128x32 = 1, GEMM_32x128 = 2, GEMM_64x128 = 3, GEMM_NSHAPES = 4 };
 
 struct GemmProblem {
   int M, N;
@@ -57,7 +57,7 @@ struct GemmProblem {
   int epi;
   const float *ref;        // EPI_LRELU_GRAD: activation output whose sign gates the gradient
   int ldref;
-  float *colsum;           // optional [ceil(M/128), N]: per-tile column sums of the stored values
+  float *colsum;           // optional [ceil(M/64), N]: column sums of the stored values per 64-row block
   int tiles_m, tiles_n;    // filled by gemm_finalize
   int tile_start;          // first block id of this problem in its launch
   GemmSeg seg[GEMM_MAX_SEG];
@@ -65,7 +65,8 @@ struct GemmProblem {
 
 // Fills tiles_* / tile_start for a launch group; returns the total number of blocks.
 int gemm_finalize(GemmProblem *probs, int nprob, int shape);
-int gemm_pick_shape(const GemmProblem &p);
+// few_tiles: the launch group would put fewer than ~2 workgroups per CU on 128x128 tiles
+int gemm_pick_shape(const GemmProblem &p, bool few_tiles);
 double gemm_flops(const GemmProblem &p);
 double gemm_bytes(const GemmProblem &p);
 // probs_dev: device copy of the finalized group (all problems of one tile shape).

@@ -28,12 +28,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //   GEMM_128x128: waves 2x2, wave tile 2x2  — the dense layers
 //   GEMM_128x32 : waves 4x1, wave tile 1x1  — narrow outputs (heads with N<=32, d pi, few-column wgrads)
 //   GEMM_32x128 : waves 1x4, wave tile 1x1  — few-row outputs (head weight gradients, K-split)
+//   GEMM_64x128 : waves 2x2, wave tile 1x2  — dense layers of a single network (M x 256 gives only
+//                 196 tiles of 128x128 on 256 CUs; halving the tile doubles the workgroups)
 // The narrow shapes waste MFMA lanes on padding but those problems are bandwidth-bound: what
 // matters is that they stream their big operand through the same coalesced LDS staging.
 template <int SHAPE> struct TileCfg;
 template <> struct TileCfg<GEMM_128x128> { static constexpr int WM = 2, WN = 2, TM = 2, TN = 2; };
 template <> struct TileCfg<GEMM_128x32> { static constexpr int WM = 4, WN = 1, TM = 1, TN = 1; };
 template <> struct TileCfg<GEMM_32x128> { static constexpr int WM = 1, WN = 4, TM = 1, TN = 1; };
+template <> struct TileCfg<GEMM_64x128> { static constexpr int WM = 2, WN = 2, TM = 1, TN = 2; };
 
 __device__ __forceinline__ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 __device__ __forceinline__ bool aligned8(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
@@ -277,25 +280,31 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_grouped(const GemmProb
       }
     }
   }
-  // optional column sums of this tile (bias gradients): fixed-order reduction through LDS,
-  // one partial row per tile_m: colsum[tile_m][N]
+  // optional column sums (bias gradients): fixed-order reduction through LDS, one partial row
+  // per 64 output rows: colsum[row/64][N]
   if (P.colsum) {
+    constexpr int RW = TM * 32;                       // rows per wave
+    constexpr int WPG = RW >= 64 ? 1 : 64 / RW;       // waves (along M) per 64-row block
+    constexpr int GROUPS = (BM + 63) / 64;
     __syncthreads();  // every wave is done reading the staging buffers
     float *red = lds[0];  // [WM][2][BN]
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) red[(wm * 2 + lh) * BN + (wn * TN + tn) * 32 + li] = csum[tn];
     __syncthreads();
-    if (tid < BN && c0 + tid < N) {
-      float t = 0.f;
+    for (int e = tid; e < GROUPS * BN; e += GEMM_THREADS) {
+      const int g = e / BN, c = e - g * BN;
+      if (c0 + c < N && r0 + g * 64 < M) {
+        float t = 0.f;
 #pragma unroll
-      for (int j = 0; j < Cfg::WM * 2; ++j) t += red[j * BN + tid];
-      P.colsum[(long long)tile_m * N + c0 + tid] = t;
+        for (int j = 0; j < WPG * 2; ++j) t += red[(g * WPG * 2 + j) * BN + c];
+        P.colsum[(long long)(r0 / 64 + g) * N + c0 + c] = t;
+      }
     }
   }
 }
 
 static void shape_dims(int shape, int &bm, int &bn) {
-  bm = shape == GEMM_32x128 ? 32 : 128;
+  bm = shape == GEMM_32x128 ? 32 : (shape == GEMM_64x128 ? 64 : 128);
   bn = shape == GEMM_128x32 ? 32 : 128;
 }
 
@@ -314,9 +323,10 @@ int gemm_finalize(GemmProblem *probs, int nprob, int shape) {
   return total;
 }
 
-int gemm_pick_shape(const GemmProblem &p) {
+int gemm_pick_shape(const GemmProblem &p, bool few_tiles) {
   if (p.N <= 32) return GEMM_128x32;
   if (p.M <= 32 && !p.colsum) return GEMM_32x128;
+  if (few_tiles && p.M > 64) return GEMM_64x128;
   return GEMM_128x128;
 }
 
@@ -338,6 +348,8 @@ hipError_t gemm_launch(const GemmProblem *probs_dev, int nprob, int total_blocks
     hipLaunchKernelGGL(k_gemm_grouped<GEMM_128x128>, dim3(total_blocks), dim3(GEMM_THREADS), 0, stream, probs_dev, nprob);
   else if (shape == GEMM_128x32)
     hipLaunchKernelGGL(k_gemm_grouped<GEMM_128x32>, dim3(total_blocks), dim3(GEMM_THREADS), 0, stream, probs_dev, nprob);
+  else if (shape == GEMM_64x128)
+    hipLaunchKernelGGL(k_gemm_grouped<GEMM_64x128>, dim3(total_blocks), dim3(GEMM_THREADS), 0, stream, probs_dev, nprob);
   else
     hipLaunchKernelGGL(k_gemm_grouped<GEMM_32x128>, dim3(total_blocks), dim3(GEMM_THREADS), 0, stream, probs_dev, nprob);
   return hipGetLastError();

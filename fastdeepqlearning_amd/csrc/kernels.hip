@@ -31,11 +31,37 @@ __global__ __launch_bounds__(SW_THREADS) void k_skinny_wgrad(const SkinnyWgradPr
   const int m0 = split * per, m1 = min(P.M, m0 + per);
   const bool kin = k < P.K;
 
+  const float *X = P.X;
+  const float *dY = P.dY;
+  if (!dY && P.K <= 16 && P.col_blocks == 1) {
+    // narrow column sums (d z, d logits): threads take different ROWS, then reduce
+    float a16[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a16[c] = 0.f;
+    for (int m = m0 + tid; m < m1; m += SW_THREADS) {
+      const float *x = X + (long long)m * P.ldx;
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        if (c < P.K) a16[c] += x[c];
+    }
+    __shared__ float nred[SW_THREADS / 64][16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      float v = a16[c];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) nred[rg][c] = v;
+    }
+    __syncthreads();
+    if (tid < P.K) {
+      float *dst = P.dW + (long long)split * P.split_stride;
+      dst[(long long)tid * P.sk] = ((nred[0][tid] + nred[1][tid]) + nred[2][tid]) + nred[3][tid];
+    }
+    return;
+  }
   float acc[NOUT_MAX];
 #pragma unroll
   for (int q = 0; q < NOUT_MAX; ++q) acc[q] = 0.f;
-  const float *X = P.X;
-  const float *dY = P.dY;
   for (int m = m0 + rg; m < m1; m += 4) {
     const float xv = (kin && X) ? X[(long long)m * P.ldx + k] : 1.f;
     if (dY) {
@@ -205,8 +231,9 @@ __global__ void k_policy_fwd(PolicyFwdArgs a0, PolicyFwdArgs a1, int nprob, int 
 
 // d logits from d pi (through the frozen critics) and d logp = w*alpha.
 __global__ void k_policy_bwd(const float *__restrict__ logits, const float *__restrict__ noise,
-                             const float *__restrict__ action, const float *__restrict__ dpi,
-                             const float *__restrict__ w, const DevState *st, int M, int A, float *__restrict__ dlogits) {
+                             const float *__restrict__ action, const float *__restrict__ dpi_parts, int nparts,
+                             float *__restrict__ dpi_sum, const float *__restrict__ w, const DevState *st, int M, int A,
+                             float *__restrict__ dlogits) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
   const float glp = w[m] * st->alpha_cur;
@@ -218,7 +245,10 @@ __global__ void k_policy_bwd(const float *__restrict__ logits, const float *__re
     const float eps = noise[(long long)m * A + j];
     const float act = action[(long long)m * A + j];
     const float om = 1.f - act * act;
-    const float dx = dpi[(long long)m * A + j] * om + glp * (2.f * act * om / (om + 1e-4f));
+    float g = 0.f;   // d loss / d pi_j = sum over the frozen critics' partials, fixed order
+    for (int c = 0; c < nparts; ++c) g += dpi_parts[((long long)c * M + m) * A + j];
+    dpi_sum[(long long)m * A + j] = g;
+    const float dx = g * om + glp * (2.f * act * om / (om + 1e-4f));
     const float dsd = dx * eps - glp / sd;
     float dls = dsd * sd;
     if (lsr < -20.f || lsr > 2.f) dls = 0.f;
@@ -489,10 +519,11 @@ hipError_t policy_fwd_launch(const PolicyFwdArgs &a0, const PolicyFwdArgs &a1, i
   return hipGetLastError();
 }
 
-hipError_t policy_bwd_launch(const float *logits, const float *noise, const float *action, const float *dpi,
-                             const float *w, const DevState *st, int M, int A, float *dlogits, hipStream_t s) {
-  hipLaunchKernelGGL(k_policy_bwd, dim3((M + 255) / 256), dim3(256), 0, s, logits, noise, action, dpi, w, st, M, A,
-                     dlogits);
+hipError_t policy_bwd_launch(const float *logits, const float *noise, const float *action, const float *dpi_parts,
+                             int nparts, float *dpi_sum, const float *w, const DevState *st, int M, int A,
+                             float *dlogits, hipStream_t s) {
+  hipLaunchKernelGGL(k_policy_bwd, dim3((M + 255) / 256), dim3(256), 0, s, logits, noise, action, dpi_parts, nparts,
+                     dpi_sum, w, st, M, A, dlogits);
   return hipGetLastError();
 }
 
