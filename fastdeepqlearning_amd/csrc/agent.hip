@@ -917,6 +917,12 @@ int fdql_agent_stats(const fdql_agent_t *a, fdql_agent_stats_t *out) {
   return 0;
 }
 
+int fdql_debug_set_gemm_variant(int32_t variant) {
+  FDQL_REQUIRE(variant >= 0 && variant <= 3, "variant must be 0..3");
+  gemm_set_variant(variant);
+  return 0;
+}
+
 int fdql_test_gemm(const float *A, int32_t lda, int32_t a_kc, const float *B, int32_t ldb, int32_t b_kc,
                    const float *bias, float *C, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t epilogue,
                    const float *ref, int32_t ldref, int32_t ksplit, void *stream) {

@@ -71,6 +71,9 @@ double gemm_flops(const GemmProblem &p);
 double gemm_bytes(const GemmProblem &p);
 // probs_dev: device copy of the finalized group (all problems of one tile shape).
 hipError_t gemm_launch(const GemmProblem *probs_dev, int nprob, int total_blocks, int shape, hipStream_t stream);
+constexpr int GEMM_DEFAULT_VARIANT = 1;
+int gemm_variant();
+void gemm_set_variant(int v);
 
 // ---------------------------------------------------------------------------------------
 // Column-sum / narrow reductions (kernels.hip): bias gradients

@@ -18,10 +18,11 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 namespace fdql {
 
-constexpr int BK = 16, GEMM_THREADS = 256;
+constexpr int GEMM_THREADS = 256;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Tile shapes (rows x cols per workgroup; 4 waves, each TM x TN MFMA tiles of 32x32):
@@ -38,28 +39,41 @@ template <> struct TileCfg<GEMM_128x32> { static constexpr int WM = 4, WN = 1, T
 template <> struct TileCfg<GEMM_32x128> { static constexpr int WM = 1, WN = 4, TM = 1, TN = 1; };
 template <> struct TileCfg<GEMM_64x128> { static constexpr int WM = 2, WN = 2, TM = 1, TN = 2; };
 
-__device__ __forceinline__ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-__device__ __forceinline__ bool aligned8(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
+// Pointers that come out of the problem tables are generic to the compiler, which would emit
+// FLAT loads: those also count on lgkmcnt, so the `s_waitcnt lgkmcnt(0)` in front of the MFMAs
+// (meant for the LDS fragment reads) would wait for the NEXT chunk's prefetch and serialise the
+// pipeline.  Casting to the global address space yields global_load/global_store (vmcnt only).
+typedef const __attribute__((address_space(1))) float *gcf;
+typedef __attribute__((address_space(1))) float *gf;
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) v4f *gcf4;
+typedef const __attribute__((address_space(1))) v2f *gcf2;
 
-// Load this thread's share of a [R rows x 16 k] operand chunk: NV float4 slots per thread
-// (NV = ceil(R*4/256)).  kc: element (r,k) at P[r*ld + k]; slot -> row = slot>>2, k = (slot&3)*4 + j.
-template <int R, int NV>
+__device__ __forceinline__ bool aligned16(gcf p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+__device__ __forceinline__ bool aligned8(gcf p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
+
+// Load this thread's share of a [R rows x BKT k] operand chunk: NV float4 slots per thread
+// (NV = ceil(R*BKT/4/256)).  kc: element (r,k) at P[r*ld + k]; slot -> row = slot / (BKT/4),
+// k = (slot % (BKT/4))*4 + j  (BKT = 32: eight lanes cover one full 128-byte line of a row).
+template <int R, int NV, int BKT>
 __device__ __forceinline__ void load_chunk_kc(const float *__restrict__ P, int ld, int Rmax, int kend, int r0, int k0,
                                               int tid, float (&v)[4 * NV]) {
+  constexpr int KQ = BKT / 4;
 #pragma unroll
   for (int h = 0; h < NV; ++h) {
     const int slot = tid + GEMM_THREADS * h;
-    const int kq = k0 + (slot & 3) * 4;
-    const int r = r0 + (slot >> 2);
-    const bool in_tile = (slot >> 2) < R;
-    const float *p = P + (long long)r * ld + kq;
+    const int kq = k0 + (slot % KQ) * 4;
+    const int r = r0 + (slot / KQ);
+    const bool in_tile = (slot / KQ) < R;
+    gcf p = (gcf)(P + (long long)r * ld + kq);
     if (in_tile && r < Rmax && kq + 3 < kend) {
       if (aligned16(p)) {
-        const float4 x = *reinterpret_cast<const float4 *>(p);
+        const v4f x = *(gcf4)p;
         v[4 * h + 0] = x.x; v[4 * h + 1] = x.y; v[4 * h + 2] = x.z; v[4 * h + 3] = x.w;
       } else if (aligned8(p)) {
-        const float2 x = *reinterpret_cast<const float2 *>(p);
-        const float2 y = *reinterpret_cast<const float2 *>(p + 2);
+        const v2f x = *(gcf2)p;
+        const v2f y = *(gcf2)(p + 2);
         v[4 * h + 0] = x.x; v[4 * h + 1] = x.y; v[4 * h + 2] = y.x; v[4 * h + 3] = y.y;
       } else {
 #pragma unroll
@@ -73,7 +87,7 @@ __device__ __forceinline__ void load_chunk_kc(const float *__restrict__ P, int l
 }
 
 // ks: element (r,k) at P[k*ld + r]; slot -> k = slot / (R/4), rows (slot % (R/4))*4 + j.
-template <int R, int NV>
+template <int R, int NV, int BKT>
 __device__ __forceinline__ void load_chunk_ks(const float *__restrict__ P, int ld, int Rmax, int kend, int r0, int k0,
                                               int tid, float (&v)[4 * NV]) {
   constexpr int RQ = R / 4;
@@ -83,15 +97,15 @@ __device__ __forceinline__ void load_chunk_ks(const float *__restrict__ P, int l
     const int kl = slot / RQ;
     const int rq = r0 + (slot - kl * RQ) * 4;
     const int k = k0 + kl;
-    const bool in_tile = kl < BK;
-    const float *p = P + (long long)k * ld + rq;
+    const bool in_tile = kl < BKT;
+    gcf p = (gcf)(P + (long long)k * ld + rq);
     if (in_tile && k < kend && rq + 3 < Rmax) {
       if (aligned16(p)) {
-        const float4 x = *reinterpret_cast<const float4 *>(p);
+        const v4f x = *(gcf4)p;
         v[4 * h + 0] = x.x; v[4 * h + 1] = x.y; v[4 * h + 2] = x.z; v[4 * h + 3] = x.w;
       } else if (aligned8(p)) {
-        const float2 x = *reinterpret_cast<const float2 *>(p);
-        const float2 y = *reinterpret_cast<const float2 *>(p + 2);
+        const v2f x = *(gcf2)p;
+        const v2f y = *(gcf2)(p + 2);
         v[4 * h + 0] = x.x; v[4 * h + 1] = x.y; v[4 * h + 2] = y.x; v[4 * h + 3] = y.y;
       } else {
 #pragma unroll
@@ -104,13 +118,13 @@ __device__ __forceinline__ void load_chunk_ks(const float *__restrict__ P, int l
   }
 }
 
-template <int R, int NV>
+template <int R, int NV, int BKT>
 __device__ __forceinline__ void store_chunk_kc(float *__restrict__ lds, int tid, const float (&v)[4 * NV]) {
-  constexpr int PITCH = R + 4;
+  constexpr int PITCH = R + 4, KQ = BKT / 4;
 #pragma unroll
   for (int h = 0; h < NV; ++h) {
     const int slot = tid + GEMM_THREADS * h;
-    const int kq = (slot & 3) * 4, r = slot >> 2;
+    const int kq = (slot % KQ) * 4, r = slot / KQ;
     if (r < R) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) lds[(kq + j) * PITCH + r] = v[4 * h + j];
@@ -118,24 +132,24 @@ __device__ __forceinline__ void store_chunk_kc(float *__restrict__ lds, int tid,
   }
 }
 
-template <int R, int NV>
+template <int R, int NV, int BKT>
 __device__ __forceinline__ void store_chunk_ks(float *__restrict__ lds, int tid, const float (&v)[4 * NV]) {
   constexpr int PITCH = R + 4, RQ = R / 4;
 #pragma unroll
   for (int h = 0; h < NV; ++h) {
     const int slot = tid + GEMM_THREADS * h;
     const int kl = slot / RQ, rq = (slot - kl * RQ) * 4;
-    if (kl < BK)
+    if (kl < BKT)
       *reinterpret_cast<float4 *>(&lds[kl * PITCH + rq]) = make_float4(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
   }
 }
 
-template <int SHAPE>
+template <int SHAPE, int BK, int PIPE>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_grouped(const GemmProblem *__restrict__ probs, int nprob) {
   using Cfg = TileCfg<SHAPE>;
   constexpr int BM = Cfg::WM * Cfg::TM * 32, BN = Cfg::WN * Cfg::TN * 32;
   constexpr int PA = BM + 4, PB = BN + 4;
-  constexpr int NVA = (BM * 4 + GEMM_THREADS - 1) / GEMM_THREADS, NVB = (BN * 4 + GEMM_THREADS - 1) / GEMM_THREADS;
+  constexpr int NVA = (BM * BK / 4 + GEMM_THREADS - 1) / GEMM_THREADS, NVB = (BN * BK / 4 + GEMM_THREADS - 1) / GEMM_THREADS;
   constexpr int TM = Cfg::TM, TN = Cfg::TN;
   __shared__ __attribute__((aligned(16))) float lds[2][BK * (PA + PB)];
 
@@ -186,10 +200,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_grouped(const GemmProb
   float va[4 * NVA], vb[4 * NVB];
   if (have) {
     const GemmSeg &S = P.seg[s];
-    if (S.a_kc) load_chunk_kc<BM, NVA>(S.A, S.lda, M, ke, r0, k, tid, va); else load_chunk_ks<BM, NVA>(S.A, S.lda, M, ke, r0, k, tid, va);
-    if (S.b_kc) load_chunk_kc<BN, NVB>(S.B, S.ldb, N, ke, c0, k, tid, vb); else load_chunk_ks<BN, NVB>(S.B, S.ldb, N, ke, c0, k, tid, vb);
-    if (S.a_kc) store_chunk_kc<BM, NVA>(lds[0], tid, va); else store_chunk_ks<BM, NVA>(lds[0], tid, va);
-    if (S.b_kc) store_chunk_kc<BN, NVB>(lds[0] + BK * PA, tid, vb); else store_chunk_ks<BN, NVB>(lds[0] + BK * PA, tid, vb);
+    if (S.a_kc) load_chunk_kc<BM, NVA, BK>(S.A, S.lda, M, ke, r0, k, tid, va); else load_chunk_ks<BM, NVA, BK>(S.A, S.lda, M, ke, r0, k, tid, va);
+    if (S.b_kc) load_chunk_kc<BN, NVB, BK>(S.B, S.ldb, N, ke, c0, k, tid, vb); else load_chunk_ks<BN, NVB, BK>(S.B, S.ldb, N, ke, c0, k, tid, vb);
+    if (S.a_kc) store_chunk_kc<BM, NVA, BK>(lds[0], tid, va); else store_chunk_ks<BM, NVA, BK>(lds[0], tid, va);
+    if (S.b_kc) store_chunk_kc<BN, NVB, BK>(lds[0] + BK * PA, tid, vb); else store_chunk_ks<BN, NVB, BK>(lds[0] + BK * PA, tid, vb);
   }
   __syncthreads();
 #ifdef FDQL_GEMM_DEBUG
@@ -215,24 +229,48 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_grouped(const GemmProb
     if (has_next) {
       const GemmSeg &S = P.seg[ns];
       n_akc = S.a_kc; n_bkc = S.b_kc;
-      if (n_akc) load_chunk_kc<BM, NVA>(S.A, S.lda, M, nke, r0, nk, tid, va); else load_chunk_ks<BM, NVA>(S.A, S.lda, M, nke, r0, nk, tid, va);
-      if (n_bkc) load_chunk_kc<BN, NVB>(S.B, S.ldb, N, nke, c0, nk, tid, vb); else load_chunk_ks<BN, NVB>(S.B, S.ldb, N, nke, c0, nk, tid, vb);
+      if (n_akc) load_chunk_kc<BM, NVA, BK>(S.A, S.lda, M, nke, r0, nk, tid, va); else load_chunk_ks<BM, NVA, BK>(S.A, S.lda, M, nke, r0, nk, tid, va);
+      if (n_bkc) load_chunk_kc<BN, NVB, BK>(S.B, S.ldb, N, nke, c0, nk, tid, vb); else load_chunk_ks<BN, NVB, BK>(S.B, S.ldb, N, nke, c0, nk, tid, vb);
     }
 
     const float *la = lds[cur] + wm * (TM * 32) + li;
     const float *lb = lds[cur] + BK * PA + wn * (TN * 32) + li;
+    if (PIPE) {
+      // fragments of k-step kk+1 are requested before the MFMAs of k-step kk are issued, so the
+      // LDS latency hides behind 4 x 64 MFMA cycles instead of stalling every step
+      float a[2][TM], b[2][TN];
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      float a[TM], b[TN];
+      for (int t = 0; t < TM; ++t) a[0][t] = la[lh * PA + 32 * t];
 #pragma unroll
-      for (int t = 0; t < TM; ++t) a[t] = la[(2 * kk + lh) * PA + 32 * t];
+      for (int t = 0; t < TN; ++t) b[0][t] = lb[lh * PB + 32 * t];
 #pragma unroll
-      for (int t = 0; t < TN; ++t) b[t] = lb[(2 * kk + lh) * PB + 32 * t];
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        if (kk + 1 < BK / 2) {
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
+          for (int t = 0; t < TM; ++t) a[(kk + 1) & 1][t] = la[(2 * kk + 2 + lh) * PA + 32 * t];
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+          for (int t = 0; t < TN; ++t) b[(kk + 1) & 1][t] = lb[(2 * kk + 2 + lh) * PB + 32 * t];
+        }
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk & 1][tm], b[kk & 1][tn], acc[tm][tn], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        float a[TM], b[TN];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) a[t] = la[(2 * kk + lh) * PA + 32 * t];
+#pragma unroll
+        for (int t = 0; t < TN; ++t) b[t] = lb[(2 * kk + lh) * PB + 32 * t];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+      }
     }
     // Keep the fragment base addresses live past the last read of the chunk.  Without this hipcc
     // (ROCm 7.2) lets the chunk's final `ds_read_b32` overwrite its own address VGPR
@@ -241,18 +279,18 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_grouped(const GemmProb
     asm volatile("" ::"v"(la), "v"(lb));
 
     if (!has_next) break;
-    if (n_akc) store_chunk_kc<BM, NVA>(lds[cur ^ 1], tid, va); else store_chunk_ks<BM, NVA>(lds[cur ^ 1], tid, va);
-    if (n_bkc) store_chunk_kc<BN, NVB>(lds[cur ^ 1] + BK * PA, tid, vb); else store_chunk_ks<BN, NVB>(lds[cur ^ 1] + BK * PA, tid, vb);
+    if (n_akc) store_chunk_kc<BM, NVA, BK>(lds[cur ^ 1], tid, va); else store_chunk_ks<BM, NVA, BK>(lds[cur ^ 1], tid, va);
+    if (n_bkc) store_chunk_kc<BN, NVB, BK>(lds[cur ^ 1] + BK * PA, tid, vb); else store_chunk_ks<BN, NVB, BK>(lds[cur ^ 1] + BK * PA, tid, vb);
     __syncthreads();
     cur ^= 1;
     s = ns; k = nk; ke = nke;
   }
 
   // epilogue: D[i][j] of a 32x32 tile sits at col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  float *C = P.C + (long long)split * P.split_stride;
+  gf C = (gf)(P.C + (long long)split * P.split_stride);
   const int ldc = P.ldc, epi = P.epi;
-  const float *bias = P.bias;
-  const float *ref = P.ref;
+  gcf bias = (gcf)P.bias;
+  gcf ref = (gcf)P.ref;
   const int ldref = P.ldref;
   float csum[TN];
 #pragma unroll
@@ -297,7 +335,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_grouped(const GemmProb
         float t = 0.f;
 #pragma unroll
         for (int j = 0; j < WPG * 2; ++j) t += red[(g * WPG * 2 + j) * BN + c];
-        P.colsum[(long long)(r0 / 64 + g) * N + c0 + c] = t;
+        ((gf)P.colsum)[(long long)(r0 / 64 + g) * N + c0 + c] = t;
       }
     }
   }
@@ -342,16 +380,35 @@ double gemm_bytes(const GemmProblem &p) {
   return b + 4.0 * p.M * (double)p.N * p.ksplit;
 }
 
+template <int SHAPE>
+static void launch_shape(const GemmProblem *probs_dev, int nprob, int total_blocks, int variant, hipStream_t stream) {
+  const dim3 g(total_blocks), b(GEMM_THREADS);
+  switch (variant) {
+    case 1: hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 16, 1>), g, b, 0, stream, probs_dev, nprob); break;
+    case 2: hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 32, 0>), g, b, 0, stream, probs_dev, nprob); break;
+    case 3: hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 32, 1>), g, b, 0, stream, probs_dev, nprob); break;
+    default: hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 16, 0>), g, b, 0, stream, probs_dev, nprob); break;
+  }
+}
+
+// variant: K-chunk / fragment-pipelining build of the kernel (FDQL_GEMM_VARIANT overrides, for experiments)
+static int g_variant = -1;
+int gemm_variant() {
+  if (g_variant < 0) {
+    const char *e = getenv("FDQL_GEMM_VARIANT");
+    g_variant = e ? atoi(e) : GEMM_DEFAULT_VARIANT;
+  }
+  return g_variant;
+}
+void gemm_set_variant(int v) { g_variant = v; }
+
 hipError_t gemm_launch(const GemmProblem *probs_dev, int nprob, int total_blocks, int shape, hipStream_t stream) {
   if (total_blocks <= 0) return hipSuccess;
-  if (shape == GEMM_128x128)
-    hipLaunchKernelGGL(k_gemm_grouped<GEMM_128x128>, dim3(total_blocks), dim3(GEMM_THREADS), 0, stream, probs_dev, nprob);
-  else if (shape == GEMM_128x32)
-    hipLaunchKernelGGL(k_gemm_grouped<GEMM_128x32>, dim3(total_blocks), dim3(GEMM_THREADS), 0, stream, probs_dev, nprob);
-  else if (shape == GEMM_64x128)
-    hipLaunchKernelGGL(k_gemm_grouped<GEMM_64x128>, dim3(total_blocks), dim3(GEMM_THREADS), 0, stream, probs_dev, nprob);
-  else
-    hipLaunchKernelGGL(k_gemm_grouped<GEMM_32x128>, dim3(total_blocks), dim3(GEMM_THREADS), 0, stream, probs_dev, nprob);
+  const int v = gemm_variant();
+  if (shape == GEMM_128x128) launch_shape<GEMM_128x128>(probs_dev, nprob, total_blocks, v, stream);
+  else if (shape == GEMM_128x32) launch_shape<GEMM_128x32>(probs_dev, nprob, total_blocks, v, stream);
+  else if (shape == GEMM_64x128) launch_shape<GEMM_64x128>(probs_dev, nprob, total_blocks, v, stream);
+  else launch_shape<GEMM_32x128>(probs_dev, nprob, total_blocks, v, stream);
   return hipGetLastError();
 }
 

@@ -31,15 +31,17 @@ __global__ __launch_bounds__(SW_THREADS) void k_skinny_wgrad(const SkinnyWgradPr
   const int m0 = split * per, m1 = min(P.M, m0 + per);
   const bool kin = k < P.K;
 
-  const float *X = P.X;
-  const float *dY = P.dY;
+  typedef const __attribute__((address_space(1))) float *gcf;   // table pointers: force global_load (not flat)
+  typedef __attribute__((address_space(1))) float *gf;
+  gcf X = (gcf)P.X;
+  gcf dY = (gcf)P.dY;
   if (!dY && P.K <= 16 && P.col_blocks == 1) {
     // narrow column sums (d z, d logits): threads take different ROWS, then reduce
     float a16[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) a16[c] = 0.f;
     for (int m = m0 + tid; m < m1; m += SW_THREADS) {
-      const float *x = X + (long long)m * P.ldx;
+      gcf x = X + (long long)m * P.ldx;
 #pragma unroll
       for (int c = 0; c < 16; ++c)
         if (c < P.K) a16[c] += x[c];
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_skinny_wgrad(const SkinnyWgradPr
     }
     __syncthreads();
     if (tid < P.K) {
-      float *dst = P.dW + (long long)split * P.split_stride;
+      gf dst = (gf)(P.dW + (long long)split * P.split_stride);
       dst[(long long)tid * P.sk] = ((nred[0][tid] + nred[1][tid]) + nred[2][tid]) + nred[3][tid];
     }
     return;
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_skinny_wgrad(const SkinnyWgradPr
   for (int m = m0 + rg; m < m1; m += 4) {
     const float xv = (kin && X) ? X[(long long)m * P.ldx + k] : 1.f;
     if (dY) {
-      const float *d = dY + (long long)m * P.lddy;
+      gcf d = dY + (long long)m * P.lddy;
 #pragma unroll
       for (int q = 0; q < NOUT_MAX; ++q)
         if (q < Nout) acc[q] = fmaf(d[q], xv, acc[q]);
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_skinny_wgrad(const SkinnyWgradPr
   }
   __syncthreads();
   if (rg == 0 && kin) {
-    float *dst = P.dW + (long long)split * P.split_stride;
+    gf dst = (gf)(P.dW + (long long)split * P.split_stride);
 #pragma unroll
     for (int q = 0; q < NOUT_MAX; ++q)
       if (q < Nout) dst[(long long)q * P.sq + (long long)k * P.sk] = ((acc[q] + red[0][q][lane]) + red[1][q][lane]) + red[2][q][lane];

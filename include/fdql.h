@@ -225,6 +225,9 @@ int fdql_test_gemm(const float *A, int32_t lda, int32_t a_kc, const float *B, in
                    const float *bias, float *C, int32_t ldc, int32_t M, int32_t N, int32_t K,
                    int32_t epilogue, const float *ref, int32_t ldref, int32_t ksplit, void *stream);
 
+/* Tuning hook: select the K-chunk / pipelining build of the GEMM kernel (0..3); affects speed only. */
+int fdql_debug_set_gemm_variant(int32_t variant);
+
 #ifdef __cplusplus
 }
 #endif

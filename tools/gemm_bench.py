@@ -8,7 +8,9 @@ lib = nat.load()
 dev = torch.device("cuda:0")
 shapes = [(4096, 4096, 4096, "nt"), (8192, 8192, 1024, "nt"), (188160, 256, 256, "nt"), (188160, 256, 262, "nt"),
           (12544, 256, 256, "nt"), (12544, 256, 1558, "nn"), (256, 256, 12544, "tn"), (125440, 256, 256, "nn")]
-for M, N, K, form in shapes:
+import itertools
+for (M, N, K, form), variant in itertools.product(shapes, [0, 1, 2, 3]):
+    lib.fdql_debug_set_gemm_variant(variant)
     if form == "nt":
         A = torch.randn(M, K, device=dev); B = torch.randn(N, K, device=dev); lda, akc, ldb, bkc = K, 1, K, 1
     elif form == "nn":
@@ -28,4 +30,9 @@ for M, N, K, form in shapes:
     for _ in range(10):
         e0.record(); run(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
     ms = sorted(ts)[len(ts)//2]
-    print(f"{form} M={M} N={N} K={K} ksplit={ks}: {ms:.4f} ms  {2.0*M*N*K/ms/1e9:.1f} TFLOP/s (includes table upload+sync overhead)")
+    err = ""
+    if variant and M * N <= 70_000_000 and form != "tn":
+        lib.fdql_debug_set_gemm_variant(0); ref = torch.empty_like(Cm)
+        nat.check(lib.fdql_test_gemm(nat.ptr(A), lda, akc, nat.ptr(B), ldb, bkc, None, nat.ptr(ref), N, M, N, K, 0, None, 0, ks, nat.current_stream()))
+        err = f" maxdiff_vs_v0={float((ref - Cm).abs().max()):.2e}"
+    print(f"v{variant} {form} M={M} N={N} K={K} ksplit={ks}: {ms:.4f} ms  {2.0*M*N*K/ms/1e9:.1f} TFLOP/s "+err)
