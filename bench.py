@@ -84,18 +84,29 @@ def cpu_baseline(T, B, seconds_budget=25.0):
         nt, na = torch.randn(T - 1, B, ACT, generator=g), torch.randn(T - 1, B, ACT, generator=g)
         oup.train_step(st, spec, xp, nt, na)
 
-    one()  # warm-up
-    t0 = time.perf_counter()
-    n = 0
-    while True:
-        one()
-        n += 1
-        el = time.perf_counter() - t0
-        if el > seconds_budget or n >= 200:
-            break
-    return {"value": n / el, "unit": "steps/s", "cores": threads, "kind": "port",
+    def timed(nthreads, budget):
+        torch.set_num_threads(nthreads)
+        one()  # warm-up
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            one()
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget or n >= 200:
+                break
+        return n / el, n, el
+
+    # eager torch-CPU on small GEMMs does not scale to a whole socket: time all cores and 16 threads, report the faster
+    results = [(timed(threads, seconds_budget / 2), threads)]
+    if threads > 16:
+        results.append((timed(16, seconds_budget / 2), 16))
+    torch.set_num_threads(threads)
+    (rate, n, el), used = max(results, key=lambda r: r[0][0])
+    detail = "; ".join(f"{t} threads: {r[0]:.3f} steps/s" for r, t in results)
+    return {"value": rate, "unit": "steps/s", "cores": used, "kind": "port",
             "sample": f"{n} train_steps (numpy ring sample + torch-CPU update) of the same config, T={T}, B={B}, "
-                      f"{threads} torch threads, {el:.1f} s"}
+                      f"{el:.1f} s [{detail}]"}
 
 
 def main():
