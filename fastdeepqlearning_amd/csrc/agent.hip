@@ -354,7 +354,7 @@ struct Builder {
   // gradient is a K-split GEMM (the narrow ones on the 128x32 / 32x128 tiles); bias gradients
   // come from the per-tile column sums the dgrad GEMMs leave behind (dy_cs / dpre_cs), or
   // directly from dY when dY is narrow (dz, d logits).
-  void wgrads(const MlpInst &m, const float *dY, int lddy, const float *dy_cs, Stage &gs, Stage &ws) {
+  void wgrads(const MlpInst &m, const float *dY, int lddy, const float *dy_cs, Stage &gs, Stage &narrow, Stage &ws) {
     const MlpDesc &d = *m.d;
     float *slab = a->buf("slabs");
     const long long P = a->n_train;
@@ -365,7 +365,8 @@ struct Builder {
       add_seg(p, dOut, ldo, 0, X, ldx, 0, R);
       p.ksplit = S;
       p.split_stride = P;
-      gs.gemm.push_back(p);
+      // narrow problems (other tile shapes = other launches) are pooled in one stage at the end
+      (gemm_pick_shape(p, false) == GEMM_64x128 || gemm_pick_shape(p, false) == GEMM_128x128 ? gs : narrow).gemm.push_back(p);
     };
     auto bias_w = [&](const float *dOut, int ldo, int nout, const float *cs, float *dst) {
       SkinnyWgradProblem p;
@@ -418,12 +419,9 @@ int upload_tables(fdql_agent *a) {
   for (Stage &s : a->stages) {
     if (s.kind == ST_GEMM) {
       for (auto &sub : s.sub) sub.probs.clear();
-      long long tiles128 = 0;  // workgroups this stage would get from its dense problems on 128x128 tiles
-      for (auto &p : s.gemm)
-        if (gemm_pick_shape(p, false) == GEMM_128x128)
-          tiles128 += (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * (p.ksplit > 1 ? p.ksplit : 1);
-      const bool few = tiles128 < 512;
-      for (auto &p : s.gemm) s.sub[gemm_pick_shape(p, few)].probs.push_back(p);
+      int force = -1;
+      if (const char *e = getenv("FDQL_GEMM_DENSE_SHAPE")) force = atoi(e);  // tuning hook: 0 = 128x128, 3 = 64x128
+      for (auto &p : s.gemm) s.sub[gemm_pick_shape(p, force == GEMM_128x128)].probs.push_back(p);
       for (auto &sub : s.sub) total += pad(sub.probs.size() * sizeof(GemmProblem));
     }
     if (s.kind == ST_SKINNY_WGRAD) total += pad(s.swg.size() * sizeof(SkinnyWgradProblem));
@@ -606,9 +604,14 @@ int build_plan(fdql_agent *a) {
     b.func_stage("policy_bwd", [=](hipStream_t s) { return policy_bwd_launch(lo, nz, pi, dpi, C, dpi_sum, w, dst, M, A, dlo, s); });
   }
   // ---- actor backward
+  // The weight gradients of a network only need that network's own dpre/dY, so instead of one big
+  // wgrad stage at the end they ride along with the small single-network dgrad launches that follow
+  // (same tile shape -> same launch): those launches have only ~400 workgroups of their own.
+  std::vector<size_t> hosts;  // stage indices of the dense dgrad launches after the critics' backward
   for (int i = (int)a->actor.hid.size() - 1; i >= 0; --i) {
     Stage &gs = b.gemm_stage("actor.dpre" + std::to_string(i));
     gs.gemm.push_back(b.bwd_dpre(ao, i, a->buf("dlogits"), a->actor.dout));
+    hosts.push_back(a->stages.size() - 1);
   }
   // ---- d state = sum over online critics and the actor
   {
@@ -618,13 +621,16 @@ int build_plan(fdql_agent *a) {
     b.input_grad_segs(ao, a->buf("dlogits"), a->actor.dout, 0, p);
     p.colsum = a->buf("cs.dstate");
     gs.gemm.push_back(p);
+    hosts.push_back(a->stages.size() - 1);
   }
+  const size_t idx_dstate = a->stages.size() - 1;
   // ---- encoder backward over the M rows that carry gradient (next-only rows get none)
   MlpInst jb = jo, eb = eo;
   jb.rows = M; eb.rows = M;
   for (int i = (int)a->joiner.hid.size() - 1; i >= 0; --i) {
     Stage &gs = b.gemm_stage("joiner.dpre" + std::to_string(i));
     gs.gemm.push_back(b.bwd_dpre(jb, i, a->buf("dstate"), L));
+    hosts.push_back(a->stages.size() - 1);
   }
   {
     Stage &gs = b.gemm_stage("denc");
@@ -632,21 +638,27 @@ int build_plan(fdql_agent *a) {
     b.input_grad_segs(jb, a->buf("dstate"), L, 0, p);
     p.colsum = a->buf("cs.denc");
     gs.gemm.push_back(p);
+    hosts.push_back(a->stages.size() - 1);
   }
+  const size_t idx_denc = a->stages.size() - 1;
   for (int i = (int)a->enc_obs.hid.size() - 1; i >= 0; --i) {
     Stage &gs = b.gemm_stage("enc_obs.dpre" + std::to_string(i));
     gs.gemm.push_back(b.bwd_dpre(eb, i, a->buf("denc"), c.enc_features));
+    hosts.push_back(a->stages.size() - 1);
   }
-  // ---- all weight gradients: one grouped MFMA launch + one skinny launch, into K-split slabs
+  // ---- weight gradients (K-split slabs) + column sums
   {
-    Stage gs, ws;
-    gs.kind = ST_GEMM; gs.name = "wgrad";
-    ws.kind = ST_SKINNY_WGRAD; ws.name = "wgrad_skinny";
-    for (int k = 0; k < C; ++k) b.wgrads(co[k], a->buf("dz") + k * Q, Nq, nullptr, gs, ws);
-    b.wgrads(ao, a->buf("dlogits"), a->actor.dout, nullptr, gs, ws);
-    b.wgrads(jb, a->buf("dstate"), L, a->buf("cs.dstate"), gs, ws);
-    b.wgrads(eb, a->buf("denc"), c.enc_features, a->buf("cs.denc"), gs, ws);
-    a->stages.push_back(gs);
+    Stage tail, ws;
+    tail.kind = ST_GEMM; tail.name = "wgrad.enc";
+    ws.kind = ST_SKINNY_WGRAD; ws.name = "colsums";
+    // critics: spread over the dgrad launches that follow their backward (they are ready by then)
+    for (int k = 0; k < C; ++k) b.wgrads(co[k], a->buf("dz") + k * Q, Nq, nullptr, a->stages[hosts[k % hosts.size()]], tail, ws);
+    // actor: needs d logits / its dpre -> from the d state launch on
+    b.wgrads(ao, a->buf("dlogits"), a->actor.dout, nullptr, a->stages[idx_dstate], tail, ws);
+    // joiner: needs d state and its dpre -> the d enc launch; encoder MLP: needs d enc and its dpre -> the tail
+    b.wgrads(jb, a->buf("dstate"), L, a->buf("cs.dstate"), a->stages[idx_denc], tail, ws);
+    b.wgrads(eb, a->buf("denc"), c.enc_features, a->buf("cs.denc"), tail, tail, ws);
+    a->stages.push_back(tail);
     a->stages.push_back(ws);
   }
   {
@@ -844,26 +856,50 @@ int32_t fdql_agent_profile_update(fdql_agent_t *a, const fdql_batch_t *batch, co
   int rc = prepare_update(a, batch, noise_target, noise_actor, seed);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  const size_t n = a->stages.size();
+  // one entry per kernel launch: GEMM stages launch one kernel per tile shape
+  struct Part { Stage *st; int shape; };
+  std::vector<Part> parts;
+  for (Stage &st : a->stages) {
+    if (st.kind == ST_GEMM) {
+      for (int sh = 0; sh < GEMM_NSHAPES; ++sh)
+        if (st.sub[sh].blocks > 0) parts.push_back({&st, sh});
+    } else {
+      parts.push_back({&st, -1});
+    }
+  }
+  const size_t n = parts.size();
   std::vector<hipEvent_t> ev(n + 1);
   for (auto &e : ev) FDQL_HIP(hipEventCreate(&e));
   FDQL_HIP(hipEventRecord(ev[0], s));
   for (size_t i = 0; i < n; ++i) {
-    hipError_t e = run_stage(a, a->stages[i], s);
-    if (e != hipSuccess) { set_error("stage %s: %s", a->stages[i].name.c_str(), hipGetErrorString(e)); return FDQL_EHIP; }
+    hipError_t e;
+    if (parts[i].shape >= 0) {
+      const GemmSub &sub = parts[i].st->sub[parts[i].shape];
+      e = gemm_launch((const GemmProblem *)sub.dev, (int)sub.probs.size(), sub.blocks, parts[i].shape, s);
+    } else {
+      e = run_stage(a, *parts[i].st, s);
+    }
+    if (e != hipSuccess) { set_error("stage %s: %s", parts[i].st->name.c_str(), hipGetErrorString(e)); return FDQL_EHIP; }
     FDQL_HIP(hipEventRecord(ev[i + 1], s));
   }
   FDQL_HIP(hipStreamSynchronize(s));
+  static const char *shape_names[GEMM_NSHAPES] = {"128x128", "128x32", "32x128", "64x128"};
   int32_t cnt = 0;
   for (size_t i = 0; i < n && cnt < cap; ++i, ++cnt) {
     float ms = 0;
     FDQL_HIP(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
-    const Stage &st = a->stages[i];
-    const char *kind = st.kind == ST_GEMM ? "gemm:" : st.kind == ST_SKINNY_WGRAD ? "colsum:" : "k:";
-    snprintf(out[cnt].name, sizeof(out[cnt].name), "%s%s", kind, st.name.c_str());
+    const Stage &st = *parts[i].st;
+    double flops = st.flops, bytes = st.bytes;
+    if (parts[i].shape >= 0) {
+      flops = 0; bytes = 0;
+      for (const auto &p : st.sub[parts[i].shape].probs) { flops += gemm_flops(p); bytes += gemm_bytes(p); }
+      snprintf(out[cnt].name, sizeof(out[cnt].name), "gemm%s:%s", shape_names[parts[i].shape], st.name.c_str());
+    } else {
+      snprintf(out[cnt].name, sizeof(out[cnt].name), "%s%s", st.kind == ST_SKINNY_WGRAD ? "colsum:" : "k:", st.name.c_str());
+    }
     out[cnt].ms = ms;
-    out[cnt].flops = st.flops;
-    out[cnt].bytes = st.bytes;
+    out[cnt].flops = flops;
+    out[cnt].bytes = bytes;
   }
   for (auto &e : ev) (void)hipEventDestroy(e);
   return cnt;
@@ -925,7 +961,7 @@ int fdql_agent_stats(const fdql_agent_t *a, fdql_agent_stats_t *out) {
 }
 
 int fdql_debug_set_gemm_variant(int32_t variant) {
-  FDQL_REQUIRE(variant >= 0 && variant <= 3, "variant must be 0..3");
+  FDQL_REQUIRE(variant >= 0 && variant <= 4, "variant must be 0..4");
   gemm_set_variant(variant);
   return 0;
 }
@@ -939,7 +975,7 @@ int fdql_test_gemm(const float *A, int32_t lda, int32_t a_kc, const float *B, in
   p.bias = bias; p.epi = epilogue; p.ref = ref; p.ldref = ldref;
   p.nseg = 1;
   p.seg[0].A = A; p.seg[0].lda = lda; p.seg[0].a_kc = a_kc; p.seg[0].B = B; p.seg[0].ldb = ldb; p.seg[0].b_kc = b_kc; p.seg[0].K = K;
-  const int shape = gemm_pick_shape(p, ((M + 127) / 128) * ((N + 127) / 128) * p.ksplit < 512);
+  const int shape = gemm_pick_shape(p, false);
   const int blocks = gemm_finalize(&p, 1, shape);
   GemmProblem *dev = nullptr;
   FDQL_HIP(hipMalloc(&dev, sizeof(p)));

@@ -65,8 +65,7 @@ struct GemmProblem {
 
 // Fills tiles_* / tile_start for a launch group; returns the total number of blocks.
 int gemm_finalize(GemmProblem *probs, int nprob, int shape);
-// few_tiles: the launch group would put fewer than ~2 workgroups per CU on 128x128 tiles
-int gemm_pick_shape(const GemmProblem &p, bool few_tiles);
+int gemm_pick_shape(const GemmProblem &p, bool prefer_128);
 double gemm_flops(const GemmProblem &p);
 double gemm_bytes(const GemmProblem &p);
 // probs_dev: device copy of the finalized group (all problems of one tile shape).
