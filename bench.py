@@ -126,11 +126,17 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
     import torch.distributed as dist
-    dev = torch.device(f"cuda:{local_rank}")
+    # FDQL_BENCH_BACKEND=gloo: rehearsal of the N>1 code path on a box with fewer GPUs than ranks
+    # (ranks share devices, the gradient all-reduce goes through the host); the driver uses nccl (= RCCL)
+    backend = os.environ.get("FDQL_BENCH_BACKEND", "nccl")
+    dev = torch.device(f"cuda:{local_rank % max(torch.cuda.device_count(), 1)}")
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from fastdeepqlearning_amd.core import NativeAgent, NativeRing, make_config
     from fastdeepqlearning_amd import _native as nat
@@ -156,7 +162,12 @@ def main():
             agent.update(xp, seed=seed)
         else:
             agent.update(xp, seed=seed, phase=nat.PHASE_GRAD)
-            dist.all_reduce(agent.grads)                     # RCCL sum over xGMI; loss already carries 1/(B*world)
+            if backend == "nccl":
+                dist.all_reduce(agent.grads)                 # RCCL sum over xGMI; loss already carries 1/(B*world)
+            else:
+                g = agent.grads.cpu()
+                dist.all_reduce(g)
+                agent.grads.copy_(g)
             agent.update(None, phase=nat.PHASE_APPLY)
 
     def sync():
@@ -173,7 +184,7 @@ def main():
     sync()
     el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        t = torch.tensor([el], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     ms_per_step = 1e3 * el / max(args.steps, 1)
@@ -189,18 +200,21 @@ def main():
                 a = acc.setdefault(name, [0.0, fl, by, 0])
                 a[0] += ms
                 a[3] += 1
-        # dominant kernel = the 128x128-tile instantiation of the grouped fp32-MFMA GEMM (rocprofv3 agrees:
-        # profiles/*kernel_stats*.csv); the other tile shapes run the narrow, bandwidth-bound problems
-        dom = {k: v for k, v in acc.items() if k.startswith("gemm128x128:")}
+        # dominant kernel = the tile-shape instantiation of the grouped fp32-MFMA GEMM with the largest total
+        # time (rocprofv3 agrees: profiles/*kernel_stats*.csv); the narrow shapes run bandwidth-bound problems
         allg = {k: v for k, v in acc.items() if k.startswith("gemm")}
+        by_shape = {}
+        for k, v in allg.items():
+            by_shape.setdefault(k.split(":")[0], {})[k] = v
+        dom_name, dom = max(by_shape.items(), key=lambda kv: sum(v[0] for v in kv[1].values()))
         gemm_ms = sum(v[0] for v in dom.values()) / reps
         gemm_fl = sum(v[1] * v[3] for v in dom.values()) / reps
         n_gemm = sum(v[3] for v in dom.values()) // reps
         all_ms = sum(v[0] for v in allg.values()) / reps
         all_fl = sum(v[1] * v[3] for v in allg.values()) / reps
         total_ms = sum(v[0] for v in acc.values()) / reps
-        tf = gemm_fl / (gemm_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "k_gemm_grouped<128x128> (fp32 v_mfma_f32_32x32x2_f32)",
+        tf = gemm_fl / max(gemm_ms * 1e-3, 1e-12) / 1e12
+        roofline = {"bound": "mfma", "kernel": f"k_gemm_grouped<{dom_name[4:]} tile> (fp32 v_mfma_f32_32x32x2_f32)",
                     "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
                     "launches_per_step": int(n_gemm), "flops_per_launch": gemm_fl / max(n_gemm, 1),

@@ -404,3 +404,46 @@ def test_update_matches_oracle_config2(dev, T, B, hid):
         ref["after"] = {n: st.params[n] for n in ag.tensors if "_frozen." not in n}
         _check_step(rep, step, ag, spec, ref, before, alpha, log_alpha, step + 1)
     rep.finish()
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("config4 dims (Humanoid obs 376, act 17, 5x25 quantiles)", dict(obs=376, act=17, C=5, Q=25, T=3, B=96)),
+    ("config3 dims (obs 28 + goals 10, HER-style batch)", dict(obs=28, goal=10, act=6, C=5, Q=2, T=4, B=64)),
+    ("config1 dims (Pendulum SAC-min, 2 critics)", dict(obs=3, act=1, C=2, Q=1, T=5, B=128, distributional=False)),
+    ("deep nets (3-layer critic, 2-layer actor/encoder)", dict(obs=9, act=4, C=3, Q=5, T=4, B=40, critic_hidden=(64, 96, 64),
+                                                               pi_hidden=(64, 48), enc_hidden=(80, 64), joint_hidden=(64, 64),
+                                                               latent=64, enc_features=48)),
+])
+def test_update_matches_oracle_other_configs(dev, name, kw):
+    """The remaining BASELINE configs' shapes (and non-default depths) against the CPU oracle, one step."""
+    from oracle import update as oup
+    kw = dict(kw)
+    T, B = kw.pop("T"), kw.pop("B")
+    base = dict(latent=256, enc_features=256, enc_hidden=(256,), joint_hidden=(256,), pi_hidden=(256,), critic_hidden=(256, 256))
+    base.update(kw)
+    spec = oup.Spec(T=T, B=B, **base)
+    params = oup.init_params(spec, seed=5)
+    st = oup.new_state(spec, params)
+    ag = _agent_for(spec, dev)
+    ag.load_tensors(params)
+    g = torch.Generator().manual_seed(9)
+    A = spec.act
+    xp = {"obs_1d": torch.randn(T, B, spec.obs, generator=g), "action": torch.rand(T, B, A, generator=g) * 2 - 1,
+          "reward": torch.randn(T, B, 1, generator=g), "mc_return": torch.randn(T, B, 1, generator=g) * 2,
+          "task_done": (torch.rand(T, B, 1, generator=g) < 0.1).float(),
+          "episode_step": (torch.arange(T).view(T, 1, 1) + torch.randint(0, 50, (1, B, 1), generator=g)).float()}
+    if spec.goal:
+        xp["achieved_goal"] = torch.randn(T, B, spec.goal, generator=g)
+        xp["desired_goal"] = torch.randn(T, B, spec.goal, generator=g)
+    xp["episode_step"][T // 2:, ::5] = 0.0
+    nt, na = torch.randn(T - 1, B, A, generator=g), torch.randn(T - 1, B, A, generator=g)
+    alpha, log_alpha = st.alpha, float(st.params["actor_critic.log_alpha"])
+    loss, aux = oup.train_step(st, spec, xp, nt, na)
+    before = _snapshot(ag)
+    ag.update({k: v.to(dev) for k, v in xp.items()}, nt.to(dev), na.to(dev))
+    rep = Report("oracle:" + name)
+    ref = {k: (v.detach().numpy() if isinstance(v, torch.Tensor) else v) for k, v in aux.items() if k != "grad"}
+    ref["loss"], ref["grad"] = float(loss), aux["grad"]
+    ref["after"] = {n: st.params[n] for n in ag.tensors if "_frozen." not in n}
+    _check_step(rep, 0, ag, spec, ref, before, alpha, log_alpha, 1)
+    rep.finish()
