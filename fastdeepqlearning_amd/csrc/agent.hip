@@ -240,6 +240,7 @@ void carve(fdql_agent *a) {
   a->alloc("pi", M * c.act_dim);
   a->alloc("log_pi", M);
   a->alloc("noise_actor", M * c.act_dim);
+  if (c.discrete) a->alloc("action_onehot", N * c.act_dim);
   for (int k = 0; k < c.n_critics; ++k) {
     const std::string s = std::to_string(k);
     mlp_bufs("crit_t" + s, a->critic[k], M, false, false);
@@ -499,7 +500,7 @@ int build_plan(fdql_agent *a) {
     ct.push_back(t);
     MlpInst o = make_inst(a, a->critic[k], "crit" + s, params, 0, M, true);
     o.in.push_back({s_cur, L, L});
-    o.in.push_back({x.action, A, A});
+    o.in.push_back({c.discrete ? a->buf("action_onehot") : x.action, A, A});
     o.out = a->buf("q_pred") + k * Q; o.ldout = Nq;
     co.push_back(o);
     MlpInst f = make_inst(a, a->critic[k], "crit_f" + s, params, 0, M, true);
@@ -520,6 +521,11 @@ int build_plan(fdql_agent *a) {
     const float *td = x.task_done, *es = x.episode_step;
     const int T = a->T;
     b.func_stage("prep", [=](hipStream_t s) { return prep_launch(td, es, T, B, inv_gb, w, ic, s); });
+    if (c.discrete) {   // stored action index -> one-hot critic input (deepQlearning.py:206-210)
+      const float *act = x.action;
+      float *oh = a->buf("action_onehot");
+      b.func_stage("onehot", [=](hipStream_t s) { return onehot_launch(act, N, A, oh, s); });
+    }
   }
   // ---- encoder forward (encoder.py:52-67)
   auto fwd_chain = [&](std::vector<MlpInst *> group, const std::string &name) {
@@ -543,7 +549,7 @@ int build_plan(fdql_agent *a) {
       PolicyFwdArgs q0 = p0, q1 = p1;
       q0.noise = ag->noise_t;
       q1.noise = ag->noise_a;
-      return policy_fwd_launch(q0, q1, 2, M, A, dst, ag->seed, s);
+      return policy_fwd_launch(q0, q1, 2, M, A, dst, ag->seed, ag->cfg.discrete, s);
     });
   }
   // ---- critics forward: target(next, a'), online(cur, a), frozen(cur, pi)
@@ -601,7 +607,8 @@ int build_plan(fdql_agent *a) {
   {
     const float *lo = ao.out, *nz = a->buf("noise_actor"), *pi = a->buf("pi"), *dpi = a->buf("dpi_part"), *w = a->buf("w");
     float *dlo = a->buf("dlogits"), *dpi_sum = a->buf("dpi");
-    b.func_stage("policy_bwd", [=](hipStream_t s) { return policy_bwd_launch(lo, nz, pi, dpi, C, dpi_sum, w, dst, M, A, dlo, s); });
+    const int disc = c.discrete;
+    b.func_stage("policy_bwd", [=](hipStream_t s) { return policy_bwd_launch(lo, nz, pi, dpi, C, dpi_sum, w, dst, M, A, dlo, disc, s); });
   }
   // ---- actor backward
   // The weight gradients of a network only need that network's own dpre/dY, so instead of one big
@@ -741,7 +748,7 @@ int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {
   FDQL_REQUIRE(out && cfg, "null argument");
   const fdql_agent_config_t &c = *cfg;
   FDQL_REQUIRE(c.obs_dim > 0 && c.act_dim > 0 && c.goal_dim >= 0, "bad obs/act/goal dims");
-  FDQL_REQUIRE(!c.discrete, "discrete (Gumbel-softmax) actor is not implemented in the HIP path yet");
+  FDQL_REQUIRE(!c.discrete || c.act_dim <= 32, "discrete actor: at most 32 actions");
   FDQL_REQUIRE(c.n_critics > 0 && c.n_quantiles > 0 && c.n_critics * c.n_quantiles <= 256, "need 0 < C*Q <= 256");
   FDQL_REQUIRE(2 * c.n_critics + 2 <= GEMM_MAX_SEG, "too many critics for one d(state) GEMM");
   FDQL_REQUIRE(c.T >= 2 && c.B >= 1, "need T >= 2, B >= 1");

@@ -260,6 +260,110 @@ __global__ void k_policy_bwd(const float *__restrict__ logits, const float *__re
 }
 
 // ======================================================================================
+// Discrete actor: Gumbel-softmax straight-through sample and log-prob
+// (franQ/Agent/models/gumbel_mlp.py:7-54 on torch's ExpRelaxedCategorical.rsample, temperature 1)
+// and its backward.  One thread per row, n <= 32 actions.
+// ======================================================================================
+constexpr int GUMBEL_MAXN = 32;
+
+__device__ __forceinline__ float row_logsumexp(const float *x, int n) {
+  float mx = -INFINITY;
+  for (int j = 0; j < n; ++j) mx = fmaxf(mx, x[j]);
+  float s = 0.f;
+  for (int j = 0; j < n; ++j) s += (float)exp((double)(x[j] - mx));
+  return mx + (float)log((double)s);
+}
+
+// forward pieces shared by fwd and bwd: norm = logits - lse, relaxed = softmax(norm + gumbel), hard index
+__device__ __forceinline__ int gumbel_forward(const float *lo, const float *u, int n, float *norm, float *relaxed) {
+  const float tiny = 1.1920928955078125e-07f;  // torch.finfo(float32).eps (clamp_probs)
+  float sc[GUMBEL_MAXN];
+  const float lse = row_logsumexp(lo, n);
+  for (int j = 0; j < n; ++j) {
+    norm[j] = lo[j] - lse;
+    const float uc = fminf(fmaxf(u[j], tiny), 1.f - tiny);
+    const float g = -(float)log((double)(-(float)log((double)uc)));
+    sc[j] = (norm[j] + g) / 1.0f;
+  }
+  const float lse2 = row_logsumexp(sc, n);
+  int best = 0;
+  for (int j = 0; j < n; ++j) {
+    relaxed[j] = (float)exp((double)(sc[j] - lse2));
+    if (relaxed[j] > relaxed[best]) best = j;   // first maximum, like torch.argmax
+  }
+  return best;
+}
+
+__global__ void k_policy_fwd_gumbel(PolicyFwdArgs a0, PolicyFwdArgs a1, int nprob, int M, int n, const DevState *st,
+                                    uint64_t seed) {
+#pragma clang fp contract(off)
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int p = gid / M;
+  if (p >= nprob) return;
+  const int m = gid - p * M;
+  const PolicyFwdArgs &a = p == 0 ? a0 : a1;
+  float lo[GUMBEL_MAXN], u[GUMBEL_MAXN], norm[GUMBEL_MAXN], relaxed[GUMBEL_MAXN];
+  for (int j = 0; j < n; ++j) {
+    lo[j] = a.logits[(long long)m * n + j];
+    u[j] = a.noise ? a.noise[(long long)m * n + j] : device_noise(seed, (uint32_t)st->step, a.which, (uint32_t)(m * n + j), false);
+    if (a.noise_out) a.noise_out[(long long)m * n + j] = u[j];
+  }
+  const int best = gumbel_forward(lo, u, n, norm, relaxed);
+  const float lse3 = row_logsumexp(norm, n);   // log_softmax of the already normalised logits
+  float logp = 0.f;
+  for (int j = 0; j < n; ++j) {
+    const float hard = j == best ? 1.f : 0.f;
+    const float stv = (hard - relaxed[j]) + relaxed[j];   // straight-through value, same fp order as torch
+    a.action[(long long)m * n + j] = stv;
+    logp += -stv * (norm[j] - lse3);
+  }
+  a.logp[m] = -logp;
+}
+
+__global__ void k_policy_bwd_gumbel(const float *__restrict__ logits, const float *__restrict__ noise,
+                                    const float *__restrict__ dpi_parts, int nparts, float *__restrict__ dpi_sum,
+                                    const float *__restrict__ w, const DevState *st, int M, int n,
+                                    float *__restrict__ dlogits) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  float lo[GUMBEL_MAXN], u[GUMBEL_MAXN], norm[GUMBEL_MAXN], relaxed[GUMBEL_MAXN], gst[GUMBEL_MAXN], dnorm[GUMBEL_MAXN];
+  for (int j = 0; j < n; ++j) { lo[j] = logits[(long long)m * n + j]; u[j] = noise[(long long)m * n + j]; }
+  const int best = gumbel_forward(lo, u, n, norm, relaxed);
+  const float lse3 = row_logsumexp(norm, n);
+  const float glp = w[m] * st->alpha_cur;   // d loss / d logp
+  float dot_st = 0.f, sum_glogsm = 0.f;
+  for (int j = 0; j < n; ++j) {
+    float g = 0.f;
+    for (int c = 0; c < nparts; ++c) g += dpi_parts[((long long)c * M + m) * n + j];
+    dpi_sum[(long long)m * n + j] = g;
+    const float logsm = norm[j] - lse3;
+    gst[j] = g + glp * logsm;                       // logp = sum st * logsm
+    dot_st += gst[j] * relaxed[j];
+    const float hard = j == best ? 1.f : 0.f;
+    sum_glogsm += glp * ((hard - relaxed[j]) + relaxed[j]);
+  }
+  float sum_dnorm = 0.f;
+  for (int j = 0; j < n; ++j) {
+    const float hard = j == best ? 1.f : 0.f;
+    const float stv = (hard - relaxed[j]) + relaxed[j];
+    const float d_scores = relaxed[j] * (gst[j] - dot_st);                                     // softmax backward
+    const float d_logsm = glp * stv - (float)exp((double)(norm[j] - lse3)) * sum_glogsm;       // log_softmax backward
+    dnorm[j] = d_scores + d_logsm;
+    sum_dnorm += dnorm[j];
+  }
+  for (int j = 0; j < n; ++j)
+    dlogits[(long long)m * n + j] = dnorm[j] - (float)exp((double)norm[j]) * sum_dnorm;        // norm = logits - lse
+}
+
+// one-hot of the stored action index (deepQlearning.py:206-210)
+__global__ void k_onehot(const float *__restrict__ action, int rows, int n, float *__restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= rows * n) return;
+  const int m = e / n, j = e - m * n;
+  out[e] = ((int)action[m] == j) ? 1.f : 0.f;
+}
+
+// ======================================================================================
 // Loss: TQC (sort pooled atoms, drop the top, entropy bonus, pairwise quantile-Huber with
 // tau over the pooled index; distributional_soft_actor_critic.py:40-103) or SAC-min
 // (soft_actor_critic.py:63-134); n-step lower bound; actor / alpha loss
@@ -515,17 +619,29 @@ hipError_t tick_adam_launch(DevState *st, double lr, double b1, double b2, hipSt
 }
 
 hipError_t policy_fwd_launch(const PolicyFwdArgs &a0, const PolicyFwdArgs &a1, int nprob, int M, int A,
-                             const DevState *st, uint64_t seed, hipStream_t s) {
+                             const DevState *st, uint64_t seed, int discrete, hipStream_t s) {
   const int total = nprob * M;
-  hipLaunchKernelGGL(k_policy_fwd, dim3((total + 255) / 256), dim3(256), 0, s, a0, a1, nprob, M, A, st, seed);
+  if (discrete)
+    hipLaunchKernelGGL(k_policy_fwd_gumbel, dim3((total + 63) / 64), dim3(64), 0, s, a0, a1, nprob, M, A, st, seed);
+  else
+    hipLaunchKernelGGL(k_policy_fwd, dim3((total + 255) / 256), dim3(256), 0, s, a0, a1, nprob, M, A, st, seed);
+  return hipGetLastError();
+}
+
+hipError_t onehot_launch(const float *action, int rows, int n, float *out, hipStream_t s) {
+  hipLaunchKernelGGL(k_onehot, dim3((rows * n + 255) / 256), dim3(256), 0, s, action, rows, n, out);
   return hipGetLastError();
 }
 
 hipError_t policy_bwd_launch(const float *logits, const float *noise, const float *action, const float *dpi_parts,
                              int nparts, float *dpi_sum, const float *w, const DevState *st, int M, int A,
-                             float *dlogits, hipStream_t s) {
-  hipLaunchKernelGGL(k_policy_bwd, dim3((M + 255) / 256), dim3(256), 0, s, logits, noise, action, dpi_parts, nparts,
-                     dpi_sum, w, st, M, A, dlogits);
+                             float *dlogits, int discrete, hipStream_t s) {
+  if (discrete)
+    hipLaunchKernelGGL(k_policy_bwd_gumbel, dim3((M + 63) / 64), dim3(64), 0, s, logits, noise, dpi_parts, nparts, dpi_sum,
+                       w, st, M, A, dlogits);
+  else
+    hipLaunchKernelGGL(k_policy_bwd, dim3((M + 255) / 256), dim3(256), 0, s, logits, noise, action, dpi_parts, nparts,
+                       dpi_sum, w, st, M, A, dlogits);
   return hipGetLastError();
 }
 

@@ -70,10 +70,11 @@ hipError_t prep_launch(const float *task_done, const float *episode_step, int T,
 hipError_t tick_alpha_launch(DevState *st, const float *log_alpha, hipStream_t s);
 hipError_t tick_adam_launch(DevState *st, double lr, double b1, double b2, hipStream_t s);
 hipError_t policy_fwd_launch(const PolicyFwdArgs &a0, const PolicyFwdArgs &a1, int nprob, int M, int A,
-                             const DevState *st, uint64_t seed, hipStream_t s);
+                             const DevState *st, uint64_t seed, int discrete, hipStream_t s);
+hipError_t onehot_launch(const float *action, int rows, int n, float *out, hipStream_t s);
 hipError_t policy_bwd_launch(const float *logits, const float *noise, const float *action, const float *dpi_parts,
                              int nparts, float *dpi_sum, const float *w, const DevState *st, int M, int A,
-                             float *dlogits, hipStream_t s);
+                             float *dlogits, int discrete, hipStream_t s);
 
 inline int loss_blocks(int M, int G) { return (M + (256 / G) - 1) / (256 / G); }
 

@@ -294,8 +294,8 @@ def _check_step(rep, s, ag, spec, ref, before, alpha, log_alpha, lr_steps):
               "next_z": (T - 1, B, spec.Nq), "q_pred": (T - 1, B, spec.Nq), "pi": (T - 1, B, spec.act),
               "log_pi": (T - 1, B, 1), "q_frozen": (T - 1, B, spec.Nq), "q_loss": (T - 1, B, 1),
               "pi_loss": (T - 1, B, 1), "alpha_loss": (T - 1, B, 1), "is_contiguous": (T - 1, B, 1)}
-    cn = logp_cond(ref["next_action"]) if "next_action" in ref else 0.0
-    cc = logp_cond(ref["pi"]) if "pi" in ref else 0.0
+    cn = logp_cond(ref["next_action"]) if "next_action" in ref and not spec.discrete else 0.0
+    cc = logp_cond(ref["pi"]) if "pi" in ref and not spec.discrete else 0.0
     ent = 1.0 if spec.max_entropy else 0.0
     extra = {"log_pi": cc, "next_log_pi": cn, "q_loss": ent * alpha * spec.gamma * cn, "pi_loss": alpha * cc,
              "alpha_loss": abs(log_alpha) * cc}
@@ -342,7 +342,7 @@ def _check_step(rep, s, ag, spec, ref, before, alpha, log_alpha, lr_steps):
                 rep.bad.append((f"s{s}.after.{n}", frac, frac, 0.02))
 
 
-CONT_CASES = ["tqc_small", "tqc_c5q2", "tqc_goal", "sac_min", "tqc_nolb"]
+CONT_CASES = ["tqc_small", "tqc_c5q2", "tqc_goal", "sac_min", "tqc_nolb", "tqc_discrete"]
 
 
 @pytest.mark.parametrize("case", CONT_CASES)
@@ -410,6 +410,7 @@ def test_update_matches_oracle_config2(dev, T, B, hid):
     ("config4 dims (Humanoid obs 376, act 17, 5x25 quantiles)", dict(obs=376, act=17, C=5, Q=25, T=3, B=96)),
     ("config3 dims (obs 28 + goals 10, HER-style batch)", dict(obs=28, goal=10, act=6, C=5, Q=2, T=4, B=64)),
     ("config1 dims (Pendulum SAC-min, 2 critics)", dict(obs=3, act=1, C=2, Q=1, T=5, B=128, distributional=False)),
+    ("config5 head (discrete SAC, 6 actions, Gumbel-softmax)", dict(obs=64, act=6, discrete=True, C=2, Q=5, T=4, B=128)),
     ("deep nets (3-layer critic, 2-layer actor/encoder)", dict(obs=9, act=4, C=3, Q=5, T=4, B=40, critic_hidden=(64, 96, 64),
                                                                pi_hidden=(64, 48), enc_hidden=(80, 64), joint_hidden=(64, 64),
                                                                latent=64, enc_features=48)),
@@ -432,11 +433,15 @@ def test_update_matches_oracle_other_configs(dev, name, kw):
           "reward": torch.randn(T, B, 1, generator=g), "mc_return": torch.randn(T, B, 1, generator=g) * 2,
           "task_done": (torch.rand(T, B, 1, generator=g) < 0.1).float(),
           "episode_step": (torch.arange(T).view(T, 1, 1) + torch.randint(0, 50, (1, B, 1), generator=g)).float()}
+    if spec.discrete:
+        xp["action"] = torch.randint(0, A, (T, B, 1), generator=g).float()
     if spec.goal:
         xp["achieved_goal"] = torch.randn(T, B, spec.goal, generator=g)
         xp["desired_goal"] = torch.randn(T, B, spec.goal, generator=g)
     xp["episode_step"][T // 2:, ::5] = 0.0
     nt, na = torch.randn(T - 1, B, A, generator=g), torch.randn(T - 1, B, A, generator=g)
+    if spec.discrete:
+        nt, na = torch.rand(T - 1, B, A, generator=g), torch.rand(T - 1, B, A, generator=g)
     alpha, log_alpha = st.alpha, float(st.params["actor_critic.log_alpha"])
     loss, aux = oup.train_step(st, spec, xp, nt, na)
     before = _snapshot(ag)
