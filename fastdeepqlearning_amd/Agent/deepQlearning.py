@@ -218,6 +218,17 @@ class DeepQLearning:
             e = self._mlp("encoder.visible_layer_encoders.obs_1d", x, len(ec.obs_1d_hidden_dims))
             s = self._mlp("encoder.joiner", e, len(ec.joint_hidden_dims))
             logits = self._mlp("actor_critic.actor", s, len(conf.pi_hidden_dims))
+            mask = torch.as_tensor(experiences["exploit_mask"], device=dev)
+            if conf.discrete:   # gumbel_mlp.py:13-21 + deepQlearning.py:175-178 (argmax of the sampled / raw logits)
+                u = torch.rand_like(logits).clamp_(1.1920929e-07, 1 - 1.1920929e-07)
+                norm = logits - logits.logsumexp(-1, keepdim=True)
+                explore = (norm - torch.log(-torch.log(u))).argmax(-1, True)
+                log_prob = torch.gather(norm, -1, explore)
+                exploit = logits.argmax(-1, True)
+                action = (exploit * mask) + (explore * torch.logical_not(mask))
+                if (conf.train_step.value % conf.log_interval) == 0:
+                    info["log_prob"], info["explore_action"], info["exploit_action"] = log_prob, explore, exploit
+                return action, None, info
             mean, log_std = torch.chunk(logits, 2, dim=-1)
             log_std = torch.clamp(log_std, -20.0, 2.0)
             std = log_std.exp()
@@ -226,7 +237,6 @@ class DeepQLearning:
             log_prob = (-((xt - mean) ** 2) / (2 * std ** 2) - std.log() - 0.9189385332046727
                         - torch.log(1 - explore.pow(2) + 1e-4)).sum(-1, keepdim=True)
             exploit = torch.tanh(mean)
-            mask = torch.as_tensor(experiences["exploit_mask"], device=dev)
             action = (exploit * mask) + (explore * torch.logical_not(mask))
             if (conf.train_step.value % conf.log_interval) == 0:
                 info["log_prob"], info["explore_action"], info["exploit_action"] = log_prob, explore, exploit

@@ -452,3 +452,38 @@ def test_update_matches_oracle_other_configs(dev, name, kw):
     ref["after"] = {n: st.params[n] for n in ag.tensors if "_frozen." not in n}
     _check_step(rep, 0, ag, spec, ref, before, alpha, log_alpha, 1)
     rep.finish()
+
+
+def test_ring_full_size_properties(dev):
+    """BASELINE size (1M-slot ring, T=50, B=256): size-independent properties instead of an oracle copy.
+    Slot i stores its own index, so every gathered element is checkable in closed form:
+    out[t, b] == (start[b] + t) % len, windows are consecutive, sample() rows equal their index,
+    re-sampling with the same (seed, counter) is idempotent, and the wrap leaves len = maxlen - 1."""
+    from fastdeepqlearning_amd.core import NativeRing
+    maxlen, T, B = 1_000_000, 50, 256
+    dims = [17, 6, 1, 1]
+    ring = NativeRing(maxlen, dims, dev)
+    n = maxlen + 12_345                      # wraps once
+    for c0 in range(0, n, 250_000):
+        m = min(250_000, n - c0)
+        idx = torch.arange(c0, c0 + m, device=dev, dtype=torch.float32)
+        rows = torch.cat([(idx % 4099).view(-1, 1).expand(m, 17), idx.view(-1, 1).expand(m, 6) % 7,
+                          (idx % maxlen).view(-1, 1), torch.ones(m, 1, device=dev)], dim=1).contiguous()
+        ring.add_rows(rows)
+    assert len(ring) == maxlen - 1 and ring.top == n % maxlen
+    outs, starts = ring.sample_windows(T, B, seed=3, counter=7, return_starts=True)
+    slot = outs[2][..., 0]                   # the stored slot index
+    want = (starts.view(1, B) + torch.arange(T, device=dev).view(T, 1)) % len(ring)
+    assert torch.equal(slot.long(), want)
+    step = (slot[1:] - slot[:-1])
+    assert bool(((step == 1) | (step == 1 - len(ring))).all())
+    # rows written after the wrap hold index (slot + maxlen) in the other keys
+    logical = torch.where(slot < ring.top, slot + maxlen, slot)
+    assert torch.equal(outs[0][..., 5], logical % 4099) and torch.equal(outs[1][..., 2], logical % 7)
+    assert float(outs[3].sum()) == T * B
+    outs2, starts2 = ring.sample_windows(T, B, seed=3, counter=7, return_starts=True)
+    assert torch.equal(starts, starts2) and all(torch.equal(a, b) for a, b in zip(outs, outs2))
+    flat = ring.sample_rows(4096, seed=5, counter=1)
+    assert bool((flat[2][:, 0] < len(ring)).all()) and bool((flat[2][:, 0] >= 0).all())
+    hist = torch.histc(starts.float(), bins=8, min=0, max=len(ring))
+    assert float(hist.min()) > 0             # starts spread over the whole ring
