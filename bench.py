@@ -222,6 +222,15 @@ def main():
                     "all_gemm_tile_shapes": {"flops_per_step": all_fl, "ms_per_step": round(all_ms, 4),
                                              "achieved": round(all_fl / (all_ms * 1e-3) / 1e12, 2),
                                              "share_of_step": round(all_ms / total_ms, 3)}}
+        # HBM traffic of the dominant kernel cannot be measured from inside this process (PMC needs rocprofv3):
+        # it is taken from the committed rocprofv3 --pmc summary of the SAME workload when one is present
+        tj = os.path.join(ROOT, "profiles", "r01_dominant_kernel_traffic.json")
+        if os.path.exists(tj) and T == 50 and B == 256:
+            tr = json.load(open(tj))
+            roofline["traffic"] = tr["hbm_bytes_per_launch"]
+            roofline["traffic_unit"] = "bytes/launch (HBM read+write, PMC FETCH_SIZE x2 + WRITE_SIZE)"
+            roofline["traffic_source"] = "profiles/r01_hbm_traffic_pmc.txt (" + tr["source"] + ")"
+            roofline["algorithmic_bytes_per_launch"] = sum(v[2] * v[3] for v in dom.values()) / reps / max(n_gemm, 1)
         breakdown = {k: round(v[0] / reps, 4) for k, v in sorted(acc.items(), key=lambda kv: -kv[1][0])[:12]}
         # sampler on its own: HBM-bound gather, algorithmic bytes = 2*T*B*rowbytes + 8*B
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
