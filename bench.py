@@ -78,9 +78,12 @@ def cpu_baseline(T, B, seconds_budget=25.0):
     rng = np.random.RandomState(0)
     g = torch.Generator().manual_seed(0)
 
-    def one():
+    def sample_only():
         xp = cast_like_loader(ring.temporal_sample(rng=rng))
-        xp = {k: torch.from_numpy(v) for k, v in xp.items()}
+        return {k: torch.from_numpy(v) for k, v in xp.items()}
+
+    def one():
+        xp = sample_only()
         nt, na = torch.randn(T - 1, B, ACT, generator=g), torch.randn(T - 1, B, ACT, generator=g)
         oup.train_step(st, spec, xp, nt, na)
 
@@ -102,9 +105,14 @@ def cpu_baseline(T, B, seconds_budget=25.0):
     if threads > 16:
         results.append((timed(16, seconds_budget / 2), 16))
     torch.set_num_threads(threads)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        sample_only()
+    sample_ms = (time.perf_counter() - t0) / 20 * 1e3
     (rate, n, el), used = max(results, key=lambda r: r[0][0])
     detail = "; ".join(f"{t} threads: {r[0]:.3f} steps/s" for r, t in results)
     return {"value": rate, "unit": "steps/s", "cores": used, "kind": "port",
+            "sample_only_ms": round(sample_ms, 3), "update_only_ms": round(1e3 / rate - sample_ms, 3),
             "sample": f"{n} train_steps (numpy ring sample + torch-CPU update) of the same config, T={T}, B={B}, "
                       f"{el:.1f} s [{detail}]"}
 

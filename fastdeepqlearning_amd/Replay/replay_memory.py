@@ -87,6 +87,21 @@ class ReplayMemory:
                                          counter=self._counter)
         return self._named(outs, (self._temporal_len, self._batch_size))
 
+    def temporal_sample_select(self, select, starts=None):
+        """Windowed sample with per-key column selection (read side of HER-vmap).
+        select: {key: None (drop) | (offset, dim)}; other keys are gathered whole."""
+        self._check_init()
+        self._counter += 1
+        sel = {self._keys.index(k): v for k, v in select.items() if k in self._keys}
+        outs = self._ring.sample_windows(self._temporal_len, self._batch_size, starts=starts, seed=self._seed,
+                                         counter=self._counter, select=sel)
+        res = {}
+        for k, shp, o in zip(self._keys, self._shapes, outs):
+            if o is None:
+                continue
+            res[k] = o if self._keys.index(k) in sel else o.view((self._temporal_len, self._batch_size) + shp)
+        return res
+
     def __getitem__(self, idxes):
         """replay_memory.py:67-70: gather arbitrary index arrays (any shape)."""
         self._check_init()

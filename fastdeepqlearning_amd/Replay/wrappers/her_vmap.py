@@ -1,0 +1,96 @@
+"""HER with K virtual goals stored per step and ONE picked at read time ("vmap" mode).
+
+Reference: franQ/Replay/wrappers/her_vmap.py:10-123.  PARITY UNPINNED — the reference file needs jax and
+cannot be executed in the build image; semantics restated from its text (see oracle/replay.py):
+write: K goals ``achieved_goal[randint(0, n, K)]`` per finished episode; per step the K relabelled rewards /
+dones plus the real ones as column K; read: one column for the WHOLE batch (quirk q11) replaces
+desired_goal / reward / task_done / mc_return.  The relabel runs on the device (fdql_episode_her_vmap); the
+column select is done inside the gather kernel (fdql_ring_sample_windows_sel)."""
+import ctypes as C
+import random
+
+import numpy as np
+import torch
+
+from ... import _native as N
+from .wrapper_base_class import ReplayMemoryWrapper
+from .episode_ops import SparseL2Reward, _dev
+
+
+class HindsightVmapWrite(ReplayMemoryWrapper):
+    def __init__(self, replay_buffer, compute_reward, ignore_keys=("info",), num_virtual_goals=32, device=None):
+        super().__init__(replay_buffer)
+        if not isinstance(compute_reward, SparseL2Reward):
+            raise NotImplementedError("her_mode='vmap' evaluates K x n rewards per episode on the device and needs a "
+                                      "SparseL2Reward; arbitrary Python callables are only supported by 'final'/'random'")
+        self.compute_reward = compute_reward
+        self._ignored_keys = ignore_keys
+        self.num_virtual_goals = num_virtual_goals
+        self._device = torch.device(device) if device is not None else getattr(replay_buffer, "device", torch.device("cuda:0"))
+        self._reset()
+
+    def _reset(self):
+        self.buffer = []  # oldest first
+
+    def add(self, experience):
+        self.buffer.append(experience)
+        if experience["episode_done"]:
+            self._hindsight_flush()
+            self._reset()
+
+    def _draw_goal_indices(self, n):
+        """her_vmap.py:75 draws indices into the NEWEST-first buffer; converted to oldest-first."""
+        newest_first = np.random.randint(0, n, size=self.num_virtual_goals)
+        return (n - 1 - newest_first).astype(np.int32)
+
+    def _hindsight_flush(self):
+        lib = N.load()
+        n, K = len(self.buffer), self.num_virtual_goals
+        dev = self._device
+        col = lambda k: np.asarray([np.asarray(x[k], np.float32).reshape(-1) for x in self.buffer], np.float32)
+        ag, dg = col("achieved_goal"), col("desired_goal")
+        g = ag.shape[1]
+        r, td = _dev(col("reward")[:, 0], dev), _dev(col("task_done")[:, 0], dev)
+        idx = torch.as_tensor(self._draw_goal_indices(n), dtype=torch.int32, device=dev)
+        agd, dgd = _dev(ag, dev), _dev(dg, dev)
+        vg = torch.empty(n, (K + 1) * g, device=dev)
+        vr, vd = torch.empty(n, K + 1, device=dev), torch.empty(n, K + 1, device=dev)
+        fn = self.compute_reward.native()
+        with torch.cuda.device(dev):
+            N.check(lib.fdql_episode_her_vmap(N.ptr(r), N.ptr(td), N.ptr(agd), N.ptr(dgd), C.c_void_p(idx.data_ptr()), n, g,
+                                              K, C.byref(fn), N.ptr(vg), N.ptr(vr), N.ptr(vd), N.current_stream(dev)))
+        vg, vr, vd = vg.cpu().numpy().reshape(n, K + 1, g), vr.cpu().numpy(), vd.cpu().numpy()
+        for i, row in enumerate(self.buffer):
+            out = {k: v for k, v in row.items() if k not in self._ignored_keys}
+            out["virtual_goals"] = vg[i]
+            out["virtual_rewards"] = vr[i]
+            out["virtual_dones"] = vd[i]
+            self.replay_buffer.add(out)
+
+
+class HindsightVmapRead(ReplayMemoryWrapper):
+    """her_vmap.py:93-123: replaces goal / reward / done (/ mc_return) by ONE virtual column per batch."""
+
+    VIRTUAL = {"virtual_goals": "desired_goal", "virtual_rewards": "reward", "virtual_dones": "task_done",
+               "virtual_mc_return": "mc_return"}
+
+    def temporal_sample(self):
+        rb = self.replay_buffer
+        keys, shapes = rb._keys, dict(zip(rb._keys, rb._shapes))
+        k1 = shapes["virtual_rewards"][0]                      # K + 1 stored columns
+        idx = random.randint(0, k1 - 1)                        # her_vmap.py:107-108 (inclusive bounds)
+        g = int(np.prod(shapes["virtual_goals"])) // k1
+        select = {"virtual_goals": (idx * g, g), "virtual_rewards": (idx, 1), "virtual_dones": (idx, 1),
+                  "desired_goal": None, "reward": None, "task_done": None}
+        if "virtual_mc_return" in keys:
+            select["virtual_mc_return"] = (idx, 1)
+            select["mc_return"] = None
+        xp = rb.temporal_sample_select(select)
+        for src, dst in self.VIRTUAL.items():
+            if src in xp:
+                xp[dst] = xp.pop(src)
+        return xp
+
+    def ready(self):
+        r = getattr(self.replay_buffer, "ready", None)
+        return bool(r()) if r is not None else True

@@ -82,8 +82,12 @@ SIGNATURES = {
     "fdql_ring_row_floats": (_i64, [_vp]),
     "fdql_ring_key_ptr": (C.c_int, [_vp, _i32, C.POINTER(_vp)]),
     "fdql_ring_sample_windows": (C.c_int, [_vp, _i32, _i32, _vp, _u64, _u64, C.POINTER(_vp), _vp, _vp]),
+    "fdql_ring_sample_windows_sel": (C.c_int, [_vp, _i32, _i32, _vp, _u64, _u64, C.POINTER(_vp), C.POINTER(_i32),
+                                               C.POINTER(_i32), _vp, _vp]),
     "fdql_ring_sample_rows": (C.c_int, [_vp, _i32, _vp, _u64, _u64, C.POINTER(_vp), _vp, _vp]),
     "fdql_episode_mc_return": (C.c_int, [_vp, _vp, _i32, _f32, _vp]),
+    "fdql_episode_her_vmap": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, C.POINTER(RewardFn), _vp, _vp, _vp, _vp]),
+    "fdql_episode_mc_return_vmap": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f32, _vp]),
     "fdql_episode_her_relabel": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, C.POINTER(RewardFn), _vp, _vp, _vp, _vp]),
     "fdql_agent_create": (C.c_int, [C.POINTER(_vp), C.POINTER(AgentConfig)]),
     "fdql_agent_destroy": (C.c_int, [_vp]),

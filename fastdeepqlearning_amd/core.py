@@ -63,8 +63,12 @@ class NativeRing:
         arr = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
         return outs, arr
 
-    def sample_windows(self, T, B, starts=None, seed=0, counter=0, outs=None, return_starts=False):
-        """[T, B, dim_k] per key.  starts: optional int64 device tensor [B]."""
+    def sample_windows(self, T, B, starts=None, seed=0, counter=0, outs=None, return_starts=False, select=None):
+        """[T, B, dim_k] per key.  starts: optional int64 device tensor [B].
+        select: optional {key_index: None (skip the key) | (offset, dim) (gather a sub-row)} — the read side
+        of HER-vmap; returns a list with None for skipped keys."""
+        if select is not None:
+            return self._sample_windows_sel(T, B, starts, seed, counter, select, return_starts)
         if outs is None:
             outs, arr = self._outs((T, B))
         else:
@@ -78,6 +82,36 @@ class NativeRing:
             N.check(self.lib.fdql_ring_sample_windows(self.handle, T, B, sp, seed, counter, arr,
                                                       C.c_void_p(so.data_ptr()) if so is not None else None,
                                                       N.current_stream(self.device)))
+        return (outs, so) if return_starts else outs
+
+    def _sample_windows_sel(self, T, B, starts, seed, counter, select, return_starts):
+        nk = len(self.dims)
+        outs, ptrs = [], (C.c_void_p * nk)()
+        off, dim = (C.c_int32 * nk)(), (C.c_int32 * nk)()
+        for k in range(nk):
+            sel = select.get(k, "all")
+            if sel is None:
+                outs.append(None)
+                ptrs[k] = None
+                continue
+            if sel == "all":
+                off[k], dim[k] = 0, 0
+                d = self.dims[k]
+            else:
+                off[k], dim[k] = int(sel[0]), int(sel[1])
+                d = int(sel[1])
+            t = torch.empty((T, B, d), dtype=torch.float32, device=self.device)
+            outs.append(t)
+            ptrs[k] = t.data_ptr()
+        sp = None
+        if starts is not None:
+            starts = torch.as_tensor(starts, dtype=torch.int64, device=self.device).contiguous()
+            sp = C.c_void_p(starts.data_ptr())
+        so = torch.empty(B, dtype=torch.int64, device=self.device) if return_starts else None
+        with torch.cuda.device(self.device):
+            N.check(self.lib.fdql_ring_sample_windows_sel(self.handle, T, B, sp, seed, counter, ptrs, off, dim,
+                                                          C.c_void_p(so.data_ptr()) if so is not None else None,
+                                                          N.current_stream(self.device)))
         return (outs, so) if return_starts else outs
 
     def sample_rows(self, B, idx=None, seed=0, counter=0):

@@ -19,9 +19,10 @@ constexpr int STAGE_WINDOWS = 8;         // windows per block in the LDS-staged 
 constexpr int STAGE_LDS_FLOATS = 8192;   // 32 KiB of staging per block
 
 struct GatherKey {
-  const float *src;  // [maxlen, dim]
+  const float *src;  // [maxlen, pitch] (+ column offset already applied)
   float *dst;        // [T, B, dim]
-  int dim;
+  int dim;           // floats gathered per row
+  int pitch;         // floats between rows of the ring block
   int staged;        // 1: LDS-staged transposition (narrow rows), 0: direct row copy (wide rows)
   int tchunk;        // staged: time steps per block
   int block_start;
@@ -88,15 +89,20 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather_windows(GatherArgs a)
     for (int w = wave; w < nw; w += GATHER_THREADS / 64) {
       const long long s0 = sstart[w];
       float *dstl = stage + w * run;
-      if (s0 + nt <= len) {
+      if (s0 + nt <= len && K.pitch == dim) {
         const float *src = K.src + s0 * dim;
         for (int e = lane; e < run; e += 64) dstl[e] = src[e];
+      } else if (s0 + nt <= len) {   // sub-row selection: runs of `dim` floats, `pitch` apart
+        for (int e = lane; e < run; e += 64) {
+          const int t = e / dim;
+          dstl[e] = K.src[(s0 + t) * K.pitch + (e - t * dim)];
+        }
       } else {  // the window crosses the wrap point (only with caller-supplied starts)
         for (int e = lane; e < run; e += 64) {
           const int t = e / dim;
           long long row = s0 + t;
           if (row >= len) row -= len;
-          dstl[e] = K.src[row * dim + (e - t * dim)];
+          dstl[e] = K.src[row * K.pitch + (e - t * dim)];
         }
       }
     }
@@ -118,9 +124,9 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather_windows(GatherArgs a)
       const int t = row / B, b = row - t * B;
       long long srow = a.starts[b] + t;
       if (srow >= len) srow %= len;
-      const float *src = K.src + srow * dim;
+      const float *src = K.src + srow * K.pitch;
       float *dst = K.dst + (long long)row * dim;
-      if ((dim & 3) == 0) {
+      if ((dim & 3) == 0 && (K.pitch & 3) == 0 && ((reinterpret_cast<uintptr_t>(K.src) & 15) == 0)) {
         for (int e = lane; e < (dim >> 2); e += 64)
           reinterpret_cast<float4 *>(dst)[e] = reinterpret_cast<const float4 *>(src)[e];
       } else {
@@ -212,6 +218,44 @@ __global__ __launch_bounds__(64) void k_her_relabel(const float *reward, const f
   }
 }
 
+// her_vmap.py:30-45: one thread per (step, virtual goal column); the last column is the real one
+__global__ void k_her_vmap(const float *reward, const float *task_done, const float *ag, const float *dg,
+                           const int *goal_idx, int n, int gd, int K, fdql_reward_fn_t fn, float *vgoals,
+                           float *vrew, float *vdone) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int K1 = K + 1;
+  if (e >= n * K1) return;
+  const int i = e / K1, k = e - i * K1;
+  const float *ag_i = ag + (long long)i * gd;
+  const float *goal = k < K ? ag + (long long)goal_idx[k] * gd : dg + (long long)i * gd;
+  float *vg = vgoals + ((long long)i * K1 + k) * gd;
+  for (int j = 0; j < gd; ++j) vg[j] = goal[j];
+  if (k == K) {
+    vrew[e] = reward[i];
+    vdone[e] = task_done[i] != 0.f ? 1.f : 0.f;
+    return;
+  }
+  const float dr = reward_fn(fn, ag_i, dg + (long long)i * gd, gd);
+  const float vr = reward_fn(fn, ag_i, goal, gd);
+  vrew[e] = (reward[i] - dr) + vr;
+  const bool agnostic_done = (task_done[i] != 0.f) && !(dr == 0.f);
+  vdone[e] = (agnostic_done || vr == 0.f) ? 1.f : 0.f;
+}
+
+// nstep_return_vmap.py:71-74, one thread per column, float32 with the product rounded before the add
+__global__ void k_mc_return_vmap(const float *__restrict__ r, const float *__restrict__ d, float *__restrict__ ret,
+                                 int n, int cols, float gamma) {
+#pragma clang fp contract(off)
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float acc = 0.f;
+  for (int i = n - 1; i >= 0; --i) {
+    const float prod = (acc * gamma) * (d[(long long)i * cols + c] != 0.f ? 1.f : 0.f);
+    acc = (i == n - 1) ? r[(long long)i * cols + c] : r[(long long)i * cols + c] + prod;
+    ret[(long long)i * cols + c] = acc;
+  }
+}
+
 }  // namespace fdql
 
 using namespace fdql;
@@ -281,15 +325,22 @@ int ensure_starts(fdql_ring *r, int B) {
   return 0;
 }
 
-int gather(fdql_ring *r, int T, int B, const long long *starts, float *const *out, hipStream_t s) {
+int gather(fdql_ring *r, int T, int B, const long long *starts, float *const *out, const int32_t *sel_off,
+           const int32_t *sel_dim, hipStream_t s) {
   GatherArgs a;
   memset(&a, 0, sizeof(a));
-  a.nkeys = r->nkeys; a.T = T; a.B = B; a.len = r->len; a.starts = starts;
+  a.T = T; a.B = B; a.len = r->len; a.starts = starts;
   int total = 0;
   for (int k = 0; k < r->nkeys; ++k) {
-    GatherKey &g = a.key[k];
-    g.src = r->data[k]; g.dst = out[k]; g.dim = r->dims[k];
-    FDQL_REQUIRE(g.dst != nullptr, "output pointer for key %d is null", k);
+    if (!out[k]) {
+      FDQL_REQUIRE(sel_dim != nullptr, "output pointer for key %d is null", k);   // skipping keys needs the _sel entry point
+      continue;
+    }
+    GatherKey &g = a.key[a.nkeys++];
+    const int off = (sel_off && sel_dim && sel_dim[k] > 0) ? sel_off[k] : 0;
+    const int dim = (sel_dim && sel_dim[k] > 0) ? sel_dim[k] : r->dims[k];
+    FDQL_REQUIRE(off >= 0 && off + dim <= r->dims[k], "selection [%d, %d) outside key %d of width %d", off, off + dim, k, r->dims[k]);
+    g.src = r->data[k] + off; g.dst = out[k]; g.dim = dim; g.pitch = r->dims[k];
     g.block_start = total;
     if (g.dim * 4 < 256 && T > 1) {
       g.staged = 1;
@@ -306,6 +357,7 @@ int gather(fdql_ring *r, int T, int B, const long long *starts, float *const *ou
       total += g.blocks_b;
     }
   }
+  if (total == 0) return 0;
   hipLaunchKernelGGL(k_gather_windows, dim3(total), dim3(GATHER_THREADS), 0, s, a);
   FDQL_HIP(hipGetLastError());
   return 0;
@@ -400,6 +452,12 @@ int fdql_ring_key_ptr(fdql_ring_t *r, int32_t key, float **dev_ptr) {
 
 int fdql_ring_sample_windows(fdql_ring_t *r, int32_t T, int32_t B, const int64_t *starts_dev, uint64_t seed,
                              uint64_t counter, float *const *out, int64_t *starts_out_dev, void *stream) {
+  return fdql_ring_sample_windows_sel(r, T, B, starts_dev, seed, counter, out, nullptr, nullptr, starts_out_dev, stream);
+}
+
+int fdql_ring_sample_windows_sel(fdql_ring_t *r, int32_t T, int32_t B, const int64_t *starts_dev, uint64_t seed,
+                                 uint64_t counter, float *const *out, const int32_t *sel_off, const int32_t *sel_dim,
+                                 int64_t *starts_out_dev, void *stream) {
   FDQL_REQUIRE(r && out && T >= 1 && B >= 1, "bad arguments");
   if (r->len < 2 * (int64_t)T || r->len < B) {  // replay_memory.py:57-58
     set_error("Trying to sample more memories than available! (len=%lld, T=%d, B=%d)", (long long)r->len, T, B);
@@ -418,7 +476,7 @@ int fdql_ring_sample_windows(fdql_ring_t *r, int32_t T, int32_t B, const int64_t
   }
   if (starts_out_dev && (const void *)starts_out_dev != (const void *)starts)
     FDQL_HIP(hipMemcpyAsync(starts_out_dev, starts, sizeof(long long) * B, hipMemcpyDeviceToDevice, s));
-  return gather(r, T, B, starts, out, s);
+  return gather(r, T, B, starts, out, sel_off, sel_dim, s);
 }
 
 int fdql_ring_sample_rows(fdql_ring_t *r, int32_t B, const int64_t *idx_dev, uint64_t seed, uint64_t counter,
@@ -441,13 +499,39 @@ int fdql_ring_sample_rows(fdql_ring_t *r, int32_t B, const int64_t *idx_dev, uin
   }
   if (idx_out_dev && (const void *)idx_out_dev != (const void *)idx)
     FDQL_HIP(hipMemcpyAsync(idx_out_dev, idx, sizeof(long long) * B, hipMemcpyDeviceToDevice, s));
-  return gather(r, 1, B, idx, out, s);
+  return gather(r, 1, B, idx, out, nullptr, nullptr, s);
 }
 
 int fdql_episode_mc_return(const float *reward_dev, float *ret_dev, int32_t n, float gamma, void *stream) {
   FDQL_REQUIRE(reward_dev && ret_dev && n >= 0, "bad arguments");
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_mc_return, dim3(1), dim3(64), 0, (hipStream_t)stream, reward_dev, ret_dev, n, gamma);
+  FDQL_HIP(hipGetLastError());
+  return 0;
+}
+
+int fdql_episode_her_vmap(const float *reward, const float *task_done, const float *achieved_goal,
+                          const float *desired_goal, const int32_t *goal_idx, int32_t n, int32_t goal_dim, int32_t K,
+                          const fdql_reward_fn_t *fn, float *virtual_goals, float *virtual_rewards,
+                          float *virtual_dones, void *stream) {
+  FDQL_REQUIRE(reward && task_done && achieved_goal && desired_goal && goal_idx && fn && virtual_goals &&
+                   virtual_rewards && virtual_dones && n >= 0 && goal_dim > 0 && K >= 0, "bad arguments");
+  FDQL_REQUIRE(fn->kind == 0, "unknown reward function kind %d", fn->kind);
+  if (n == 0) return 0;
+  const int total = n * (K + 1);
+  hipLaunchKernelGGL(k_her_vmap, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, reward, task_done,
+                     achieved_goal, desired_goal, goal_idx, n, goal_dim, K, *fn, virtual_goals, virtual_rewards,
+                     virtual_dones);
+  FDQL_HIP(hipGetLastError());
+  return 0;
+}
+
+int fdql_episode_mc_return_vmap(const float *rewards, const float *dones, float *ret, int32_t n, int32_t cols,
+                                float gamma, void *stream) {
+  FDQL_REQUIRE(rewards && dones && ret && n >= 0 && cols > 0, "bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_mc_return_vmap, dim3((cols + 63) / 64), dim3(64), 0, (hipStream_t)stream, rewards, dones, ret, n,
+                     cols, gamma);
   FDQL_HIP(hipGetLastError());
   return 0;
 }

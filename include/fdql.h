@@ -81,6 +81,15 @@ int fdql_ring_key_ptr(fdql_ring_t *ring, int32_t key, float **dev_ptr);
 int fdql_ring_sample_windows(fdql_ring_t *ring, int32_t T, int32_t B, const int64_t *starts_dev,
                              uint64_t seed, uint64_t counter, float *const *out_dev_ptrs,
                              int64_t *starts_out_dev, void *stream);
+/* Same gather with per-key sub-row selection, for the read side of HER-vmap
+ * (franQ/Replay/wrappers/her_vmap.py:104-123 picks ONE of the K+1 stored virtual columns):
+ *   out_dev_ptrs[k] == NULL      : key k is not gathered;
+ *   sel_off / sel_dim (or NULL)  : out[k] is [T, B, sel_dim[k]] = ring[k][row, sel_off[k] : sel_off[k]+sel_dim[k]]
+ *                                  (sel_dim[k] <= 0 means the whole row). */
+int fdql_ring_sample_windows_sel(fdql_ring_t *ring, int32_t T, int32_t B, const int64_t *starts_dev,
+                                 uint64_t seed, uint64_t counter, float *const *out_dev_ptrs,
+                                 const int32_t *sel_off, const int32_t *sel_dim, int64_t *starts_out_dev,
+                                 void *stream);
 /* replay_memory.py:48-52 sample(): out[k] is [B, dims[k]]; idx as for starts (range [0,len)). */
 int fdql_ring_sample_rows(fdql_ring_t *ring, int32_t B, const int64_t *idx_dev, uint64_t seed,
                           uint64_t counter, float *const *out_dev_ptrs, int64_t *idx_out_dev,
@@ -110,6 +119,22 @@ int fdql_episode_her_relabel(const float *reward, const float *episode_step, con
                              const float *desired_goal, const float *goal, int32_t n, int32_t goal_dim,
                              const fdql_reward_fn_t *fn, float *reward_out, float *task_done_out,
                              float *episode_step_out, void *stream);
+
+/* her_vmap.py:30-45,66-90 for one finished episode (oldest-first device arrays): K virtual goals
+ * achieved_goal[goal_idx[k]]; per step i and virtual goal k
+ *   r'[i,k] = (reward[i] - R(ag_i, dg_i)) + R(ag_i, g_k),
+ *   d'[i,k] = (task_done[i] && !done(ag_i, dg_i)) || done(ag_i, g_k),
+ * plus the real column last.  Outputs (f32): virtual_goals[n, (K+1)*g] (the K goals then the step's own
+ * desired goal), virtual_rewards[n, K+1], virtual_dones[n, K+1].  PARITY UNPINNED: the reference file needs
+ * jax and cannot be executed; restated from its text (oracle/replay.py).                              */
+int fdql_episode_her_vmap(const float *reward, const float *task_done, const float *achieved_goal,
+                          const float *desired_goal, const int32_t *goal_idx, int32_t n, int32_t goal_dim,
+                          int32_t K, const fdql_reward_fn_t *fn, float *virtual_goals, float *virtual_rewards,
+                          float *virtual_dones, void *stream);
+/* nstep_return_vmap.py:61-74 per column (oldest-first rows [n, cols]):
+ *   ret[i] = r[i] + ret[i+1] * gamma * done[i]      (quirk q10: multiplies by done, not 1-done) */
+int fdql_episode_mc_return_vmap(const float *rewards, const float *dones, float *ret, int32_t n, int32_t cols,
+                                float gamma, void *stream);
 
 /* ------------------------------------------------------------------------------------ */
 /* Agent update: one SAC/TQC gradient step                                               */

@@ -218,3 +218,122 @@ def test_device_noise_statistics_and_determinism(dev):
     big.update(xpb, seed=5)
     z = big.debug("noise_actor")
     assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1.0) < 0.02
+
+
+# --------------------------------------------------------------------------- HER-vmap (parity unpinned: vs the text restatement)
+def test_her_vmap_kernels_match_restatement(dev):
+    """fdql_episode_her_vmap / fdql_episode_mc_return_vmap against oracle.replay.vmap_* (her_vmap.py:30-45,
+    nstep_return_vmap.py:61-74 restated from text; the reference file itself cannot run without jax)."""
+    import ctypes as C
+    from fastdeepqlearning_amd import _native as nat
+    from fastdeepqlearning_amd.Replay.wrappers import SparseL2Reward
+    from oracle import replay as orp
+    lib = nat.load()
+    rng = np.random.RandomState(2)
+    n, g, K = 37, 3, 8
+    ag = rng.uniform(-1, 1, (n, g)).astype(np.float32)
+    ag[5] = ag[20]; ag[11] = ag[30]                      # revisits so some virtual goals are reached
+    dg = np.tile(rng.uniform(-1, 1, (1, g)).astype(np.float32), (n, 1))
+    dg[-1] = ag[-1]                                      # real goal reached at the end
+    fn = SparseL2Reward(0.3, -1.0)
+    reward = np.asarray([fn(ag[i], dg[i])[0] + 0.25 * (i % 3) for i in range(n)], np.float32)
+    done = np.asarray([fn(ag[i], dg[i])[1] for i in range(n)], np.float32)
+    idx = rng.randint(0, n, K).astype(np.int32)
+    want_r, want_d = orp.vmap_virtual_episode(ag[idx], ag, dg, reward, done, fn)
+    t = lambda a: torch.tensor(np.ascontiguousarray(a)).to(dev)
+    vg, vr, vd = torch.empty(n, (K + 1) * g, device=dev), torch.empty(n, K + 1, device=dev), torch.empty(n, K + 1, device=dev)
+    nf = fn.native()
+    r_d, d_d, ag_d, dg_d, idx_d = t(reward), t(done), t(ag), t(dg), t(idx)     # keep the device inputs alive
+    nat.check(lib.fdql_episode_her_vmap(nat.ptr(r_d), nat.ptr(d_d), nat.ptr(ag_d), nat.ptr(dg_d),
+                                        C.c_void_p(idx_d.data_ptr()), n, g, K, C.byref(nf), nat.ptr(vg), nat.ptr(vr),
+                                        nat.ptr(vd), nat.current_stream()))
+    vr, vd, vg = vr.cpu().numpy(), vd.cpu().numpy(), vg.cpu().numpy().reshape(n, K + 1, g)
+    np.testing.assert_allclose(vr[:, :K], want_r.T, rtol=0, atol=1e-6)
+    np.testing.assert_array_equal(vd[:, :K] != 0, want_d.T)
+    np.testing.assert_array_equal(vr[:, K], reward)
+    np.testing.assert_array_equal(vd[:, K], done)
+    np.testing.assert_array_equal(vg[:, :K], np.broadcast_to(ag[idx], (n, K, g)))
+    np.testing.assert_array_equal(vg[:, K], dg)
+    # per-column return, quirk q10 (multiplies by done[i])
+    out = torch.empty(n, K + 1, device=dev)
+    vr_d, vd_d = t(vr), t(vd)
+    nat.check(lib.fdql_episode_mc_return_vmap(nat.ptr(vr_d), nat.ptr(vd_d), nat.ptr(out), n, K + 1, 0.97, nat.current_stream()))
+    out = out.cpu().numpy()
+    for c in range(K + 1):
+        want = orp.vmap_return_newest_first(vr[::-1, c], vd[::-1, c] != 0, 0.97)[::-1]
+        np.testing.assert_array_equal(out[:, c], want)
+
+
+def test_her_vmap_replay_stack(dev):
+    """Replay.make(her_mode='vmap'): HindsightVmapWrite -> NStepReturnVmap -> ring; the read head replaces goal /
+    reward / done / mc_return by ONE stored column for the whole batch (her_vmap.py:104-123), selected in the gather."""
+    from fastdeepqlearning_amd import Replay
+    from fastdeepqlearning_amd.Replay.wrappers import SparseL2Reward
+    conf = _conf(dev, T=4, B=8)
+    conf.use_HER, conf.her_mode, conf.num_instances, conf.replay_size = True, "vmap", 1, 600
+    read_heads, write_heads = Replay.make(conf, compute_reward=SparseL2Reward(0.3, -1.0))
+    rng = np.random.RandomState(0)
+    np.random.seed(0)
+    for ep in range(5):
+        dg = rng.uniform(-1, 1, 2).astype(np.float32)
+        for i in range(40):
+            ag = rng.uniform(-1, 1, 2).astype(np.float32)
+            write_heads[0].add({"obs_1d": rng.standard_normal(5).astype(np.float32), "achieved_goal": ag, "desired_goal": dg,
+                                "action": rng.uniform(-1, 1, 3).astype(np.float32), "reward": -1.0, "task_done": False,
+                                "episode_done": i == 39, "episode_step": i, "info": {}})
+    rb = read_heads[0].replay_buffer
+    assert len(rb) == 200
+    K1 = 33
+    starts = torch.arange(8) * 20
+    full = rb.temporal_sample(starts=starts)
+    assert tuple(full["virtual_goals"].shape) == (4, 8, K1, 2) and tuple(full["virtual_mc_return"].shape) == (4, 8, K1)
+    for idx in (0, 7, K1 - 1):
+        sel = rb.temporal_sample_select({"virtual_goals": (idx * 2, 2), "virtual_rewards": (idx, 1), "virtual_dones": (idx, 1),
+                                         "virtual_mc_return": (idx, 1), "desired_goal": None, "reward": None,
+                                         "task_done": None}, starts=starts)
+        assert "desired_goal" not in sel and "reward" not in sel
+        assert torch.equal(sel["virtual_goals"], full["virtual_goals"][:, :, idx])
+        assert torch.equal(sel["virtual_rewards"], full["virtual_rewards"][:, :, idx, None])
+        assert torch.equal(sel["virtual_dones"], full["virtual_dones"][:, :, idx, None])
+        assert torch.equal(sel["virtual_mc_return"], full["virtual_mc_return"][:, :, idx, None])
+        assert torch.equal(sel["obs_1d"], full["obs_1d"])
+    # the real column (index K) carries the environment's own goal / reward
+    assert torch.equal(full["virtual_goals"][:, :, K1 - 1], full["desired_goal"])
+    assert torch.equal(full["virtual_rewards"][:, :, K1 - 1, None], full["reward"])
+    xp = read_heads[0].temporal_sample()
+    assert set(xp) == {"obs_1d", "achieved_goal", "desired_goal", "action", "reward", "task_done", "episode_done",
+                       "episode_step", "mc_return"}
+    assert tuple(xp["desired_goal"].shape) == (4, 8, 2) and tuple(xp["mc_return"].shape) == (4, 8, 1)
+
+
+# --------------------------------------------------------------------------- C-ABI error behaviour
+def test_c_abi_error_paths(dev):
+    """Status codes + fdql_last_error(): bad config, update before bind, short workspace, oversample."""
+    import ctypes as C
+    from fastdeepqlearning_amd import _native as nat
+    from fastdeepqlearning_amd.core import make_config, NativeRing
+    lib = nat.load()
+    h = C.c_void_p()
+    bad = make_config(5, 3, 1, 8)                               # T = 1: no TD pair
+    assert lib.fdql_agent_create(C.byref(h), C.byref(bad)) == nat.FDQL_EINVAL
+    assert b"T >= 2" in lib.fdql_last_error()
+    q6 = make_config(5, 3, 4, 8, n_critics=2, n_quantiles=2)    # int(0.2 * 4) == 0: the reference's [:-0] slice is empty (q6)
+    assert lib.fdql_agent_create(C.byref(h), C.byref(q6)) == nat.FDQL_EINVAL
+    ok = make_config(5, 3, 4, 8, n_critics=2, n_quantiles=5, latent=32, enc_features=32, enc_hidden=(32,), joint_hidden=(32,),
+                     pi_hidden=(32,), critic_hidden=(32, 32))
+    nat.check(lib.fdql_agent_create(C.byref(h), C.byref(ok)))
+    b = nat.Batch()
+    assert lib.fdql_agent_update(h, C.byref(b), None, None, 0, 0, None) == nat.FDQL_ESTATE      # not bound yet
+    n = lib.fdql_agent_arena_floats(h, 0)
+    bufs = [torch.zeros(n, device=dev) for _ in range(4)] + [torch.zeros(lib.fdql_agent_arena_floats(h, 1), device=dev),
+                                                            torch.zeros(lib.fdql_agent_arena_floats(h, 2), device=dev)]
+    ws = torch.zeros(1024, dtype=torch.uint8, device=dev)
+    rc = lib.fdql_agent_bind(h, *[C.c_void_p(t.data_ptr()) for t in bufs], C.c_void_p(ws.data_ptr()), 1024)
+    assert rc == nat.FDQL_EINVAL and b"workspace too small" in lib.fdql_last_error()
+    lib.fdql_agent_destroy(h)
+    ring = NativeRing(64, [2], dev)
+    ring.add_rows(np.zeros((5, 2), np.float32))
+    with pytest.raises(nat.OversampleError):
+        ring.sample_windows(4, 2)
+    with pytest.raises(nat.FdqlError):
+        NativeRing(64, [0], dev)
