@@ -17,7 +17,6 @@ from queue import Queue
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from .. import _native as N
 from ..common_utils import AttrDict
@@ -191,53 +190,28 @@ class DeepQLearning:
         return agent
 
     # ------------------------------------------------------------------ inference
-    def _mlp(self, prefix, x, n_hidden):
-        t = self.native.tensors
-        feats, h = [x], x
-        for i in range(n_hidden):
-            h = F.leaky_relu(F.linear(h, t[f"{prefix}.feature_extractor.{i}.0.weight"],
-                                      t[f"{prefix}.feature_extractor.{i}.0.bias"]), 0.01)
-            feats.append(h)
-        return F.linear(torch.cat(feats, -1), t[f"{prefix}.head.weight"], t[f"{prefix}.head.bias"])
-
-    def act(self, experiences):
-        """deepQlearning.py:155-187: small-batch inference for the env actors.  NOT part of the
-        accelerated path: torch eager on the shared weight arena, so the
-        actors always see the trainer's current weights without a state_dict hop."""
+    def act(self, experiences, noise=None):
+        """deepQlearning.py:155-187: small-batch inference for the env actors, one
+        `fdql_agent_act` call (encoder -> joiner -> actor -> sample/select kernels) on the weight
+        arena the trainer updates in place, so the actors always see the current weights without
+        the reference's state_dict hop (deepQlearning.py:136-148).  Returns the reference's
+        (action, hidden_state, info); hidden_state is None for the feed-forward joiner
+        (encoder.py:63-65).  `noise` ([rows, A] N(0,1) / U(0,1) draws) replays a fixed sample
+        (parity tests); by default the device draws Philox noise keyed by (seed, call count)."""
         conf = self.conf
         if not conf.use_async_train and self.replays and all(r.ready() for r in self.replays):
             self.train_step()
-        with torch.no_grad():
-            info = {}
-            dev = self.device
-            x = torch.as_tensor(experiences["obs_1d"], dtype=torch.float32, device=dev)
-            if "achieved_goal" in experiences:
-                x = torch.cat((x, torch.as_tensor(experiences["achieved_goal"], dtype=torch.float32, device=dev),
-                               torch.as_tensor(experiences["desired_goal"], dtype=torch.float32, device=dev)), -1)
-            ec = conf.encoder_conf
-            e = self._mlp("encoder.visible_layer_encoders.obs_1d", x, len(ec.obs_1d_hidden_dims))
-            s = self._mlp("encoder.joiner", e, len(ec.joint_hidden_dims))
-            logits = self._mlp("actor_critic.actor", s, len(conf.pi_hidden_dims))
-            mask = torch.as_tensor(experiences["exploit_mask"], device=dev)
-            if conf.discrete:   # gumbel_mlp.py:13-21 + deepQlearning.py:175-178 (argmax of the sampled / raw logits)
-                u = torch.rand_like(logits).clamp_(1.1920929e-07, 1 - 1.1920929e-07)
-                norm = logits - logits.logsumexp(-1, keepdim=True)
-                explore = (norm - torch.log(-torch.log(u))).argmax(-1, True)
-                log_prob = torch.gather(norm, -1, explore)
-                exploit = logits.argmax(-1, True)
-                action = (exploit * mask) + (explore * torch.logical_not(mask))
-                if (conf.train_step.value % conf.log_interval) == 0:
-                    info["log_prob"], info["explore_action"], info["exploit_action"] = log_prob, explore, exploit
-                return action, None, info
-            mean, log_std = torch.chunk(logits, 2, dim=-1)
-            log_std = torch.clamp(log_std, -20.0, 2.0)
-            std = log_std.exp()
-            xt = mean + std * torch.randn_like(mean)
-            explore = torch.tanh(xt)
-            log_prob = (-((xt - mean) ** 2) / (2 * std ** 2) - std.log() - 0.9189385332046727
-                        - torch.log(1 - explore.pow(2) + 1e-4)).sum(-1, keepdim=True)
-            exploit = torch.tanh(mean)
-            action = (exploit * mask) + (explore * torch.logical_not(mask))
-            if (conf.train_step.value % conf.log_interval) == 0:
-                info["log_prob"], info["explore_action"], info["exploit_action"] = log_prob, explore, exploit
-            return action, None, info
+        log_now = (conf.train_step.value % conf.log_interval) == 0
+        self._act_calls = getattr(self, "_act_calls", 0) + 1
+        action, log_prob, explore, exploit = self.native.act(
+            experiences["obs_1d"], experiences.get("achieved_goal"), experiences.get("desired_goal"),
+            experiences.get("exploit_mask"), noise=noise, seed=self._seed ^ 0xAC7, counter=self._act_calls,
+            want_info=log_now)
+        info = {}
+        if conf.discrete:   # deepQlearning.py:175-178: argmax(-1, True) -> int64 indices
+            action = action.long()
+        if log_now:
+            if conf.discrete:
+                explore, exploit = explore.long(), exploit.long()
+            info["log_prob"], info["explore_action"], info["exploit_action"] = log_prob, explore, exploit
+        return action, None, info

@@ -100,6 +100,8 @@ SIGNATURES = {
     "fdql_agent_set_alpha": (C.c_int, [_vp, _f32, _vp]),
     "fdql_agent_set_step": (C.c_int, [_vp, _i32, _vp]),
     "fdql_agent_debug_ptr": (C.c_int, [_vp, C.c_char_p, C.POINTER(_vp), C.POINTER(_i64)]),
+    "fdql_agent_act_workspace_bytes": (_i64, [_vp, _i32]),
+    "fdql_agent_act": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "fdql_agent_stats": (C.c_int, [_vp, C.POINTER(AgentStats)]),
     "fdql_agent_profile_update": (_i32, [_vp, C.POINTER(Batch), _vp, _vp, _u64, C.POINTER(KernelTime), _i32, _vp]),
     "fdql_debug_set_gemm_variant": (C.c_int, [_i32]),

@@ -240,6 +240,48 @@ class NativeAgent:
             N.check(n)
         return [(arr[i].name.decode(), float(arr[i].ms), float(arr[i].flops), float(arr[i].bytes)) for i in range(n)]
 
+    def act(self, obs_1d, achieved_goal=None, desired_goal=None, exploit_mask=None, noise=None, seed=0, counter=0,
+            want_info=True):
+        """deepQlearning.py:155-187 on `rows` observations: encoder -> actor on the online weights in the
+        shared arena.  Returns (action, log_prob, explore_action, exploit_action); the last three are None
+        unless want_info.  Asynchronous on the current torch stream."""
+        dev, cfg = self.device, self.cfg
+        f32 = lambda x: torch.as_tensor(x, dtype=torch.float32, device=dev).contiguous()
+        obs = f32(obs_1d)
+        rows = obs.shape[0]
+        if obs.dim() != 2 or obs.shape[1] != cfg.obs_dim:
+            raise ValueError(f"act(): obs_1d must be [rows, {cfg.obs_dim}], got {tuple(obs.shape)}")
+        ag = dg = None
+        if cfg.goal_dim:
+            ag, dg = f32(achieved_goal), f32(desired_goal)
+            if tuple(ag.shape) != (rows, cfg.goal_dim) or tuple(dg.shape) != (rows, cfg.goal_dim):
+                raise ValueError("act(): goal tensors must be [rows, goal_dim]")
+        mask = None
+        if exploit_mask is not None:
+            mask = torch.as_tensor(exploit_mask, device=dev).reshape(-1).to(torch.uint8).contiguous()
+            if mask.numel() != rows:
+                raise ValueError("act(): exploit_mask must have one entry per row")
+        if noise is not None:
+            noise = f32(noise)
+            if tuple(noise.shape) != (rows, cfg.act_dim):
+                raise ValueError(f"act(): noise must be [rows, {cfg.act_dim}]")
+        need = self.lib.fdql_agent_act_workspace_bytes(self.handle, rows)
+        if getattr(self, "_act_ws", None) is None or self._act_ws.numel() < need:
+            self._act_ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+        adim = 1 if cfg.discrete else cfg.act_dim
+        action = torch.empty(rows, adim, device=dev)
+        logp = torch.empty(rows, 1, device=dev) if want_info else None
+        explore = torch.empty(rows, adim, device=dev) if want_info else None
+        exploit = torch.empty(rows, adim, device=dev) if want_info else None
+        self._act_keep = (obs, ag, dg, mask, noise)
+        with torch.cuda.device(dev):
+            N.check(self.lib.fdql_agent_act(self.handle, N.ptr(obs), N.ptr(ag), N.ptr(dg),
+                                            C.c_void_p(mask.data_ptr()) if mask is not None else None, N.ptr(noise),
+                                            int(seed), int(counter), rows, N.ptr(action), N.ptr(logp), N.ptr(explore),
+                                            N.ptr(exploit), C.c_void_p(self._act_ws.data_ptr()), self._act_ws.numel(),
+                                            N.current_stream(dev)))
+        return action, logp, explore, exploit
+
     def scalars(self):
         out = (C.c_float * 8)()
         with torch.cuda.device(self.device):

@@ -912,6 +912,89 @@ int32_t fdql_agent_profile_update(fdql_agent_t *a, const fdql_batch_t *batch, co
   return cnt;
 }
 
+// ---- act(): encoder -> joiner -> actor on a few rows (deepQlearning.py:155-187)
+static int64_t act_mlp_floats(const MlpDesc &d, int64_t rows) {
+  int64_t n = 0;
+  for (int h : d.hid) n += pad4(rows * h);
+  return n + pad4(rows * d.dout);
+}
+
+int64_t fdql_agent_act_workspace_bytes(const fdql_agent_t *a, int32_t rows) {
+  if (!a || rows < 0) return -1;
+  return 4 * (act_mlp_floats(a->enc_obs, rows) + act_mlp_floats(a->joiner, rows) + act_mlp_floats(a->actor, rows));
+}
+
+namespace {
+// hidden layers then the skip head over cat(in, h_0..h_{n-1}) (mlp.py:88-94); returns the output buffer
+hipError_t act_mlp(const fdql_agent *a, const MlpDesc &d, const ActSeg *in, int nin, int rows, float *&top, float **out,
+                   hipStream_t s) {
+  ActSeg feats[ACT_MAX_SEG];
+  int nf = 0;
+  for (int i = 0; i < nin; ++i) feats[nf++] = in[i];
+  for (size_t i = 0; i < d.hid.size(); ++i) {
+    ActLayerArgs l;
+    memset(&l, 0, sizeof(l));
+    if (i == 0) { for (int j = 0; j < nin; ++j) l.in[j] = in[j]; l.nseg = nin; }
+    else { l.in[0] = feats[nf - 1]; l.nseg = 1; }
+    l.W = a->params + d.w_off[i]; l.ldw = d.in_of((int)i); l.bias = a->params + d.b_off[i];
+    l.out = top; l.ldo = d.hid[i]; l.N = d.hid[i]; l.rows = rows; l.leaky = 1;
+    hipError_t e = act_layer_launch(l, s);
+    if (e != hipSuccess) return e;
+    feats[nf++] = {top, d.hid[i], d.hid[i]};
+    top += pad4((int64_t)rows * d.hid[i]);
+  }
+  ActLayerArgs l;
+  memset(&l, 0, sizeof(l));
+  for (int j = 0; j < nf; ++j) l.in[j] = feats[j];
+  l.nseg = nf;
+  l.W = a->params + d.hw_off; l.ldw = d.head_ld(); l.bias = a->params + d.hb_off;
+  l.out = top; l.ldo = d.dout; l.N = d.dout; l.rows = rows; l.leaky = 0;
+  *out = top;
+  top += pad4((int64_t)rows * d.dout);
+  return act_layer_launch(l, s);
+}
+}  // namespace
+
+int fdql_agent_act(fdql_agent_t *a, const float *obs_1d, const float *achieved_goal, const float *desired_goal,
+                   const uint8_t *exploit_mask, const float *noise, uint64_t seed, uint64_t counter, int32_t rows,
+                   float *action, float *log_prob, float *explore_action, float *exploit_action, void *workspace,
+                   int64_t workspace_bytes, void *stream) {
+  if (!a || !a->bound) { set_error("fdql_agent_act: agent not bound"); return FDQL_ESTATE; }
+  FDQL_REQUIRE(rows >= 0, "fdql_agent_act: rows < 0");
+  if (rows == 0) return 0;
+  const fdql_agent_config_t &c = a->cfg;
+  FDQL_REQUIRE(obs_1d && action, "fdql_agent_act: obs_1d and action are required");
+  FDQL_REQUIRE(!c.goal_dim || (achieved_goal && desired_goal), "goal_dim > 0 needs achieved/desired goal");
+  FDQL_REQUIRE(workspace && workspace_bytes >= fdql_agent_act_workspace_bytes(a, rows) &&
+                   (reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
+               "fdql_agent_act: workspace too small or misaligned (need %lld bytes)",
+               (long long)fdql_agent_act_workspace_bytes(a, rows));
+  FDQL_REQUIRE((int)a->enc_obs.hid.size() + 3 <= ACT_MAX_SEG, "too many hidden layers for act()");
+  hipStream_t s = (hipStream_t)stream;
+  float *top = (float *)workspace;
+  ActSeg in[3];
+  int nin = 0;
+  in[nin++] = {obs_1d, c.obs_dim, c.obs_dim};
+  if (c.goal_dim) {  // encoder.py:54-58: cat(obs_1d, achieved_goal, desired_goal) as K-segments
+    in[nin++] = {achieved_goal, c.goal_dim, c.goal_dim};
+    in[nin++] = {desired_goal, c.goal_dim, c.goal_dim};
+  }
+  float *enc = nullptr, *state = nullptr, *logits = nullptr;
+  hipError_t e = act_mlp(a, a->enc_obs, in, nin, rows, top, &enc, s);
+  if (e == hipSuccess) { ActSeg x = {enc, a->enc_obs.dout, a->enc_obs.dout}; e = act_mlp(a, a->joiner, &x, 1, rows, top, &state, s); }
+  if (e == hipSuccess) { ActSeg x = {state, a->joiner.dout, a->joiner.dout}; e = act_mlp(a, a->actor, &x, 1, rows, top, &logits, s); }
+  if (e == hipSuccess) {
+    ActPolicyArgs p;
+    memset(&p, 0, sizeof(p));
+    p.logits = logits; p.ld = a->actor.dout; p.rows = rows; p.A = c.act_dim; p.discrete = c.discrete;
+    p.exploit_mask = exploit_mask; p.noise = noise; p.seed = seed; p.counter = counter;
+    p.action = action; p.log_prob = log_prob; p.explore = explore_action; p.exploit = exploit_action;
+    e = act_policy_launch(p, s);
+  }
+  if (e != hipSuccess) { set_error("fdql_agent_act: %s", hipGetErrorString(e)); return FDQL_EHIP; }
+  return 0;
+}
+
 int fdql_agent_scalars(fdql_agent_t *a, float *host_out8, void *stream) {
   if (!a || !a->bound) { set_error("agent not bound"); return FDQL_ESTATE; }
   DevState st;

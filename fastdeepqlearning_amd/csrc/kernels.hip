@@ -645,4 +645,156 @@ hipError_t policy_bwd_launch(const float *logits, const float *noise, const floa
   return hipGetLastError();
 }
 
+// ======================================================================================
+// act(): small-batch inference for the env actors (deepQlearning.py:155-187)
+//   One launch per Linear layer of encoder -> joiner -> actor.  The batch is a handful of rows
+//   (one per env instance), so a layer is a skinny product bound by the latency of streaming
+//   its weights: a wave owns two output columns, its lanes stride over K (coalesced weight
+//   rows), ACT_RCH batch rows share every weight load, and N/8 workgroups spread the weight
+//   matrix over the chip.  cat(x, h_1..h_n) of the skip head is read as K-segments.
+// ======================================================================================
+constexpr int ACT_RCH = 8;
+constexpr int ACT_KT = 1024;   // K-tile of the input rows staged in LDS (8 x 1024 floats = 32 KB)
+
+__global__ __launch_bounds__(256) void k_act_layer(ActLayerArgs a) {
+  __shared__ float xs[ACT_RCH * ACT_KT];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = (blockIdx.x * 4 + wave) * 2;
+  const bool live = n0 < a.N;  // wave-uniform; dead waves still help staging and hit the barriers
+  const bool has1 = n0 + 1 < a.N;
+  const int r0 = blockIdx.y * ACT_RCH;
+  const int nr = min(ACT_RCH, a.rows - r0);
+  float acc0[ACT_RCH], acc1[ACT_RCH];
+#pragma unroll
+  for (int r = 0; r < ACT_RCH; ++r) acc0[r] = acc1[r] = 0.f;
+  const float *w0 = a.W + (long long)(live ? n0 : 0) * a.ldw;
+  const float *w1 = has1 ? w0 + a.ldw : w0;
+  int ktot = 0;
+  for (int s = 0; s < a.nseg; ++s) ktot += a.in[s].width;
+  for (int kt0 = 0; kt0 < ktot; kt0 += ACT_KT) {
+    const int kt = min(ACT_KT, ktot - kt0);
+    __syncthreads();
+    // stage rows r0..r0+7 of cat(segments)[kt0 : kt0+kt] (rows past the batch as zeros)
+    int soff = 0;
+    for (int s = 0; s < a.nseg; ++s) {
+      const ActSeg sg = a.in[s];
+      const int lo = max(soff, kt0), hi = min(soff + sg.width, kt0 + kt);
+      const int w = hi - lo;
+      if (w > 0) {
+        for (int idx = threadIdx.x; idx < ACT_RCH * w; idx += 256) {
+          const int r = idx / w, k = idx - r * w;
+          xs[r * ACT_KT + (lo - kt0) + k] = r < nr ? sg.ptr[(long long)(r0 + r) * sg.ld + (lo - soff) + k] : 0.f;
+        }
+      }
+      soff += sg.width;
+    }
+    __syncthreads();
+    if (live) {
+#pragma unroll 4
+      for (int k = lane; k < kt; k += 64) {
+        const float x0 = w0[kt0 + k], x1 = w1[kt0 + k];
+#pragma unroll
+        for (int r = 0; r < ACT_RCH; ++r) {
+          const float v = xs[r * ACT_KT + k];
+          acc0[r] = fmaf(v, x0, acc0[r]);
+          acc1[r] = fmaf(v, x1, acc1[r]);
+        }
+      }
+    }
+  }
+  if (!live) return;
+#pragma unroll
+  for (int r = 0; r < ACT_RCH; ++r) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      acc0[r] += __shfl_xor(acc0[r], off);
+      acc1[r] += __shfl_xor(acc1[r], off);
+    }
+  }
+  if (lane == 0) {
+    const float b0 = a.bias[n0], b1 = has1 ? a.bias[n0 + 1] : 0.f;
+#pragma unroll
+    for (int r = 0; r < ACT_RCH; ++r) {
+      if (r < nr) {
+        float y0 = acc0[r] + b0, y1 = acc1[r] + b1;
+        if (a.leaky) {
+          y0 = y0 > 0.f ? y0 : 0.01f * y0;
+          y1 = y1 > 0.f ? y1 : 0.01f * y1;
+        }
+        float *o = a.out + (long long)(r0 + r) * a.ldo + n0;
+        o[0] = y0;
+        if (has1) o[1] = y1;
+      }
+    }
+  }
+}
+
+// explore / exploit actions, log-prob of the explored one, and the exploit_mask select
+// (gaussian_mlp.py:15-39 or gumbel_mlp.py:7-54, then deepQlearning.py:175-180)
+__global__ void k_act_policy(ActPolicyArgs a) {
+#pragma clang fp contract(off)
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= a.rows) return;
+  const bool use_exploit = a.exploit_mask && a.exploit_mask[m] != 0;
+  const int A = a.A;
+  if (a.discrete) {
+    float lo[GUMBEL_MAXN], u[GUMBEL_MAXN], norm[GUMBEL_MAXN], relaxed[GUMBEL_MAXN];
+    int greedy = 0;
+    for (int j = 0; j < A; ++j) {
+      lo[j] = a.logits[(long long)m * a.ld + j];
+      u[j] = a.noise ? a.noise[(long long)m * A + j]
+                     : device_noise(a.seed, (uint32_t)a.counter, 7u, (uint32_t)(m * A + j), false);
+      if (lo[j] > lo[greedy]) greedy = j;
+    }
+    const int best = gumbel_forward(lo, u, A, norm, relaxed);
+    const float lse3 = row_logsumexp(norm, A);
+    float logp = 0.f;
+    int best_st = 0;
+    float best_v = -INFINITY;
+    for (int j = 0; j < A; ++j) {
+      const float hard = j == best ? 1.f : 0.f;
+      const float stv = (hard - relaxed[j]) + relaxed[j];
+      if (stv > best_v) { best_v = stv; best_st = j; }   // argmax of the straight-through sample
+      logp += -stv * (norm[j] - lse3);
+    }
+    if (a.log_prob) a.log_prob[m] = -logp;
+    if (a.explore) a.explore[m] = (float)best_st;
+    if (a.exploit) a.exploit[m] = (float)greedy;
+    a.action[m] = (float)(use_exploit ? greedy : best_st);
+    return;
+  }
+  const float *lo = a.logits + (long long)m * a.ld;
+  float logp = 0.f;
+  for (int j = 0; j < A; ++j) {
+    const float mean = lo[j];
+    const float ls = fminf(fmaxf(lo[A + j], -20.f), 2.f);
+    const float sd = (float)exp((double)ls);
+    const float eps = a.noise ? a.noise[(long long)m * A + j]
+                              : device_noise(a.seed, (uint32_t)a.counter, 7u, (uint32_t)(m * A + j), true);
+    const float x = mean + eps * sd;
+    const float d = x - mean;
+    float lp = -(d * d) / (2.f * (sd * sd)) - (float)log((double)sd) - 0.91893853320467274178f;
+    const float ex = (float)tanh((double)x);
+    lp -= (float)log((double)((1.f - ex * ex) + 1e-4f));
+    logp += lp;
+    const float gr = (float)tanh((double)mean);
+    if (a.explore) a.explore[(long long)m * A + j] = ex;
+    if (a.exploit) a.exploit[(long long)m * A + j] = gr;
+    a.action[(long long)m * A + j] = use_exploit ? gr : ex;
+  }
+  if (a.log_prob) a.log_prob[m] = logp;
+}
+
+hipError_t act_layer_launch(const ActLayerArgs &a, hipStream_t s) {
+  if (a.rows <= 0 || a.N <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_act_layer, dim3((a.N + 7) / 8, (a.rows + ACT_RCH - 1) / ACT_RCH), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t act_policy_launch(const ActPolicyArgs &a, hipStream_t s) {
+  if (a.rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_act_policy, dim3((a.rows + 63) / 64), dim3(64), 0, s, a);
+  return hipGetLastError();
+}
+
 }  // namespace fdql

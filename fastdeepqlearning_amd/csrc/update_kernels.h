@@ -58,6 +58,33 @@ struct AdamArgs {
   long long frozen_begin, frozen_end;
 };
 
+// ---- act(): one Linear layer over a few rows, input = K-segments (cat never materialised)
+constexpr int ACT_MAX_SEG = 8;
+struct ActSeg {
+  const float *ptr;
+  int ld, width;
+};
+struct ActLayerArgs {
+  ActSeg in[ACT_MAX_SEG];
+  int nseg;
+  const float *W;     // [N, ldw] row-major (torch Linear.weight)
+  int ldw;
+  const float *bias;  // [N]
+  float *out;         // [rows, ldo]
+  int ldo, N, rows, leaky;
+};
+struct ActPolicyArgs {
+  const float *logits;  // [rows, ld]: (mean | log_std) or discrete logits
+  int ld, rows, A, discrete;
+  const uint8_t *exploit_mask;  // [rows] or null (= explore everywhere)
+  const float *noise;           // [rows, A] N(0,1) (continuous) / U(0,1) (discrete), or null -> Philox(seed, counter)
+  uint64_t seed, counter;
+  float *action;                // [rows, A] continuous; [rows] action index as float (discrete)
+  float *log_prob, *explore, *exploit;  // optional
+};
+hipError_t act_layer_launch(const ActLayerArgs &a, hipStream_t s);
+hipError_t act_policy_launch(const ActPolicyArgs &a, hipStream_t s);
+
 hipError_t skinny_wgrad_launch_host(const SkinnyWgradProblem *host, const SkinnyWgradProblem *dev, int n,
                                     int total_blocks, hipStream_t s);
 hipError_t loss_launch(const LossArgs &a, hipStream_t s);

@@ -220,6 +220,29 @@ int fdql_agent_set_step(fdql_agent_t *agent, int32_t step, void *stream);
  * "alpha_loss", "is_contiguous", "td_target").  Pointer into the workspace.             */
 int fdql_agent_debug_ptr(fdql_agent_t *agent, const char *name, const float **dev_ptr, int64_t *count);
 
+/* franQ.Agent.DeepQLearning.act (Agent/deepQlearning.py:155-187; called by Runner._agent_handler,
+ * Runner/runner.py:133): encoder.forward_eval (components/encoder.py:52-76, feed-forward joiner)
+ * -> actor (models/gaussian_mlp.py:15-39 | gumbel_mlp.py:7-54) on `rows` observations (one per env
+ * instance), reading the ONLINE weights straight from the bound parameter arena - the actors see
+ * the trainer's current weights with no state_dict hop (the reference ships a full state_dict
+ * through a queue every 50 steps, deepQlearning.py:136-148).
+ *   obs_1d [rows, obs_dim]; achieved_goal / desired_goal [rows, goal_dim] iff goal_dim > 0;
+ *   exploit_mask [rows] bytes (1 = return the greedy action; Runner/runner.py:120-123) or NULL;
+ *   noise [rows, act_dim]: N(0,1) draws (continuous) / U(0,1) draws (discrete) or NULL -> Philox4x32
+ *   keyed by (seed, counter);
+ *   action [rows, act_dim] (continuous) or [rows] action index as float (discrete) =
+ *   exploit*mask + explore*!mask; log_prob [rows], explore_action, exploit_action: optional (the
+ *   reference's `info` dict).  The hidden state of the reference's return triple is always None
+ *   for the feed-forward joiner.  workspace: caller-owned device scratch of at least
+ *   fdql_agent_act_workspace_bytes(agent, rows) bytes, 16-byte aligned, private to this call
+ *   stream (it may run beside fdql_agent_update on another stream; it then reads whatever mix of
+ *   pre/post-step weights is in the arena, like any lock-free actor).  No host sync.          */
+int64_t fdql_agent_act_workspace_bytes(const fdql_agent_t *agent, int32_t rows);
+int fdql_agent_act(fdql_agent_t *agent, const float *obs_1d, const float *achieved_goal, const float *desired_goal,
+                   const uint8_t *exploit_mask, const float *noise, uint64_t seed, uint64_t counter, int32_t rows,
+                   float *action, float *log_prob, float *explore_action, float *exploit_action, void *workspace,
+                   int64_t workspace_bytes, void *stream);
+
 /* Algorithmic work of one update, for roofline accounting: dense GEMM flops
  * (2*MAC) and the number/flops of launches by kind. */
 typedef struct {

@@ -217,6 +217,24 @@ def policy(p, spec, which, s, noise):
     return gumbel_policy(p, spec, which, s, noise) if spec.discrete else gaussian_policy(p, spec, which, s, noise)
 
 
+def act(p, spec: Spec, xp, noise):
+    """deepQlearning.py:155-187: encoder.forward_eval (encoder.py:52-76) -> online actor ->
+    explore/exploit select by ``xp["exploit_mask"]`` ([rows, 1] bool), with the policy's noise draw
+    supplied by the caller.  Returns (action, log_prob, explore_action, exploit_action)."""
+    with torch.no_grad():
+        s = encoder(p, spec, xp)
+        explore, logp = policy(p, spec, "actor", s, noise)
+        logits = skip_head_mlp(p, "actor_critic.actor", s, len(spec.pi_hidden))
+        if spec.discrete:                                       # deepQlearning.py:175-178
+            explore = explore.argmax(-1, True)
+            exploit = logits.argmax(-1, True)                   # gumbel_mlp.py:21 returns the raw logits
+        else:
+            exploit = torch.tanh(torch.chunk(logits, 2, dim=-1)[0])   # gaussian_mlp.py:38 tanh(mean)
+        mask = xp["exploit_mask"]
+        action = (exploit * mask) + (explore * torch.logical_not(mask))
+        return action, logp, explore, exploit
+
+
 # ---------------------------------------------------------------------------------------
 # losses
 # ---------------------------------------------------------------------------------------

@@ -420,6 +420,45 @@ def golden_update(name, case, n_steps=3):
     save(name, out)
 
 
+def golden_act(name, case, rows=7):
+    """DeepQLearning.act (deepQlearning.py:155-187) on a small inference batch: weights after
+    `torch.manual_seed`, observations, exploit_mask, the policy's own noise draw (tapped) and the
+    returned action / info tensors."""
+    torch.manual_seed(case.get("seed", 0) + 1000)
+    conf = make_conf(case)
+    conf.use_async_train = True          # act() must not take a train step (deepQlearning.py:157-160)
+    conf.log_extra_debug_info = False
+    agent = DeepQLearning(conf)
+    # one "training-like" perturbation so biases are not all zero (xavier init leaves them 0)
+    with torch.no_grad():
+        for p in agent.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    g = np.random.RandomState(77 + case.get("seed", 0))
+    xp = {"obs_1d": torch.tensor(g.standard_normal((rows, case["obs"])), dtype=torch.float32)}
+    if case.get("goal", 0):
+        xp["achieved_goal"] = torch.tensor(g.standard_normal((rows, case["goal"])), dtype=torch.float32)
+        xp["desired_goal"] = torch.tensor(g.standard_normal((rows, case["goal"])), dtype=torch.float32)
+    xp["exploit_mask"] = torch.tensor((np.arange(rows) % 3 == 1).reshape(-1, 1))
+    out = {"case": {k: np.asarray(v) for k, v in case.items()},
+           "init": {k: v.clone() for k, v in agent.state_dict().items()
+                    if k.startswith("encoder.") or k.startswith("actor_critic.actor.")},
+           "xp": {k: v.clone() for k, v in xp.items()}}
+    assert conf.train_step.value % conf.log_interval == 0
+    with NoiseTap() as tap:
+        action, hidden, info = agent.act(xp)
+    assert hidden is None
+    draws = tap.uniform if conf.discrete else tap.normal
+    assert len(draws) == 1 and len(tap.uniform) + len(tap.normal) == 1
+    out["noise"] = draws[0]
+    out["action"] = action
+    out["log_prob"], out["explore_action"], out["exploit_action"] = (info["log_prob"], info["explore_action"],
+                                                                    info["exploit_action"])
+    save(name, out)
+
+
+ACT_CASES = ("tqc_c5q2", "tqc_goal", "tqc_discrete")
+
+
 UPDATE_CASES = OrderedDict(
     tqc_small=dict(obs=5, act=3, C=3, Q=4, latent=32, enc_features=32, enc_hidden=(32,), joint_hidden=(32,),
                    pi_hidden=(32,), critic_hidden=(32, 32), T=6, B=8, seed=0),
@@ -437,11 +476,19 @@ UPDATE_CASES = OrderedDict(
 
 
 def main():
-    golden_ring()
-    golden_nstep()
-    golden_her()
-    for name, case in UPDATE_CASES.items():
-        golden_update("update_" + name, case)
+    only = set(sys.argv[1:])   # e.g. `make_golden.py act` regenerates the act fixtures alone
+    if not only or "ring" in only:
+        golden_ring()
+    if not only or "nstep" in only:
+        golden_nstep()
+    if not only or "her" in only:
+        golden_her()
+    if not only or "update" in only:
+        for name, case in UPDATE_CASES.items():
+            golden_update("update_" + name, case)
+    if not only or "act" in only:
+        for name in ACT_CASES:
+            golden_act("act_" + name, UPDATE_CASES[name])
 
 
 if __name__ == "__main__":

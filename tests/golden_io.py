@@ -32,3 +32,4 @@ def spec_from_case(case, hyper=None):
 
 
 UPDATE_CASES = ["tqc_small", "tqc_c5q2", "tqc_goal", "sac_min", "tqc_discrete", "tqc_nolb"]
+ACT_CASES = ["tqc_c5q2", "tqc_goal", "tqc_discrete"]

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_io import load, spec_from_case
+from golden_io import load, spec_from_case, ACT_CASES
 
 pytestmark = pytest.mark.gpu
 
@@ -499,3 +499,108 @@ def test_ring_full_size_properties(dev):
     assert bool((flat[2][:, 0] < len(ring)).all()) and bool((flat[2][:, 0] >= 0).all())
     hist = torch.histc(starts.float(), bins=8, min=0, max=len(ring))
     assert float(hist.min()) > 0             # starts spread over the whole ring
+
+
+# ---------------------------------------------------------------------------------------
+# act(): SURVEY 8f rank 1 - device-resident inference on the trainer's weight arena
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ACT_CASES)
+def test_act_matches_reference_golden(dev, case):
+    """fdql_agent_act == franQ DeepQLearning.act (deepQlearning.py:155-187) on the reference's own
+    noise draw: integer actions exact, float outputs within TOL (log_prob beyond its conditioning)."""
+    g = load("act_" + case)
+    spec = spec_from_case(g["case"])
+    ag = _agent_for(spec, dev)
+    ag.load_tensors(g["init"])
+    xp = g["xp"]
+    action, logp, explore, exploit = ag.act(xp["obs_1d"], xp.get("achieved_goal"), xp.get("desired_goal"),
+                                            xp["exploit_mask"], noise=g["noise"])
+    rep = Report(f"act golden {case}")
+    if spec.discrete:
+        for got, key in ((action, "action"), (explore, "explore_action"), (exploit, "exploit_action")):
+            assert np.array_equal(got.cpu().numpy().astype(np.int64), g[key]), key
+        rep.check("log_prob", logp, g["log_prob"])
+    else:
+        rep.check("action", action, g["action"])
+        rep.check("explore_action", explore, g["explore_action"])
+        rep.check("exploit_action", exploit, g["exploit_action"])
+        rep.check("log_prob", logp, g["log_prob"], extra=logp_cond(g["explore_action"]))
+        m = g["xp"]["exploit_mask"].reshape(-1)
+        assert torch.equal(action[torch.as_tensor(m)], exploit[torch.as_tensor(m)])
+        assert torch.equal(action[torch.as_tensor(~m)], explore[torch.as_tensor(~m)])
+    rep.finish()
+
+
+@pytest.mark.parametrize("rows,kw", [
+    (1, {}), (8, {}), (9, {}), (33, dict(goal=3)), (300, {}),
+    (5, dict(enc_hidden=(), joint_hidden=(), pi_hidden=())),            # head-only MLPs
+    (12, dict(enc_hidden=(40, 24), joint_hidden=(24, 24, 16), pi_hidden=(48, 40))),
+    (17, dict(discrete=True, act=5)),
+])
+def test_act_matches_oracle(dev, rows, kw):
+    """Ragged row counts (1, one past a row chunk, many chunks), goal segments, head-only and deep
+    MLPs, discrete head - against the CPU oracle on the same weights and noise."""
+    from oracle import update as oup
+    base = dict(obs=17, act=6, C=3, Q=2, latent=64, enc_features=48, enc_hidden=(64,), joint_hidden=(48,),
+                pi_hidden=(64,), critic_hidden=(32,), T=2, B=4)
+    base.update(kw)
+    spec = oup.Spec(**base)
+    params = oup.init_params(spec, seed=rows)
+    gen = torch.Generator().manual_seed(rows)
+    for k in params:   # non-zero biases
+        params[k] = params[k] + 0.05 * torch.randn(params[k].shape, generator=gen)
+    ag = _agent_for(spec, dev)
+    ag.load_tensors(params)
+    xp = {"obs_1d": torch.randn(rows, spec.obs, generator=gen)}
+    if spec.goal:
+        xp["achieved_goal"] = torch.randn(rows, spec.goal, generator=gen)
+        xp["desired_goal"] = torch.randn(rows, spec.goal, generator=gen)
+    xp["exploit_mask"] = (torch.rand(rows, 1, generator=gen) < 0.4)
+    noise = torch.rand(rows, spec.act, generator=gen) if spec.discrete else torch.randn(rows, spec.act, generator=gen)
+    want = oup.act(params, spec, xp, noise)
+    got = ag.act(xp["obs_1d"], xp.get("achieved_goal"), xp.get("desired_goal"), xp["exploit_mask"], noise=noise)
+    rep = Report(f"act oracle rows={rows} {kw}")
+    if spec.discrete:
+        for gt, wt, key in zip(got[:1] + got[2:], want[:1] + want[2:], ("action", "explore", "exploit")):
+            assert np.array_equal(gt.cpu().numpy().astype(np.int64), wt.numpy()), key
+        rep.check("log_prob", got[1], want[1])
+    else:
+        rep.check("action", got[0], want[0])
+        rep.check("explore", got[2], want[2])
+        rep.check("exploit", got[3], want[3])
+        rep.check("log_prob", got[1], want[1], extra=logp_cond(want[2].numpy()))
+    rep.finish()
+
+
+def test_act_device_noise_and_live_weights(dev):
+    """Without caller noise the device draws Philox noise keyed by (seed, counter): reproducible per
+    key, different across counters, N(0,1) through the tanh-Gaussian; exploit rows ignore it; and
+    act() reads the arena the trainer writes (no parameter copy to refresh)."""
+    from oracle import update as oup
+    spec = oup.Spec(obs=17, act=6, C=3, Q=2, latent=64, enc_features=48, enc_hidden=(64,), joint_hidden=(48,),
+                    pi_hidden=(64,), critic_hidden=(32,), T=2, B=4)
+    ag = _agent_for(spec, dev)
+    params = oup.init_params(spec, seed=3)
+    ag.load_tensors(params)
+    rows = 4096
+    obs = torch.randn(rows, spec.obs)
+    mask = torch.zeros(rows, 1, dtype=torch.bool)
+    mask[::2] = True
+    a1, lp1, ex1, gr1 = ag.act(obs, exploit_mask=mask, seed=5, counter=1)
+    a2, *_ = ag.act(obs, exploit_mask=mask, seed=5, counter=1)
+    a3, _, ex3, gr3 = ag.act(obs, exploit_mask=mask, seed=5, counter=2)
+    assert torch.equal(a1, a2)
+    assert torch.equal(a1[::2], a3[::2]) and torch.equal(gr1, gr3)          # greedy rows: no noise
+    assert not torch.equal(ex1, ex3)
+    # recover eps from the explore action: atanh(a) = mean + std * eps
+    s = oup.encoder(params, spec, {"obs_1d": obs})
+    logits = oup.skip_head_mlp(params, "actor_critic.actor", s, 1)
+    mean, log_std = torch.chunk(logits, 2, -1)
+    eps = (torch.atanh(ex1.cpu().double().clamp(-1 + 1e-9, 1 - 1e-9)) - mean.double()) / log_std.clamp(-20, 2).exp().double()
+    inside = ((ex1.cpu().abs() < 0.9999) & (eps.abs() < 1.0)).double().mean()   # P(|eps| < 1) = 0.6827
+    assert abs(float(inside) - 0.6827) < 0.012, float(inside)
+    assert abs(float(torch.sign(eps).mean())) < 0.03
+    # live weights: an in-place change of the arena is seen by the next act()
+    ag.tensors["actor_critic.actor.head.bias"].add_(0.25)
+    _, _, _, gr4 = ag.act(obs, exploit_mask=mask, seed=5, counter=1)
+    assert not torch.equal(gr1, gr4)

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_io import load, spec_from_case, UPDATE_CASES
+from golden_io import load, spec_from_case, UPDATE_CASES, ACT_CASES
 from oracle import replay as orp
 from oracle import update as oup
 
@@ -158,3 +158,22 @@ def test_update_matches_reference(case):
                 assert rel_err(st.adam_m[n], v) < 5e-5, (s, n)
             for n, v in rec["adam_v"].items():
                 assert rel_err(st.adam_v[n], v) < 5e-5, (s, n)
+
+
+@pytest.mark.parametrize("case", ACT_CASES)
+def test_act_matches_reference(case):
+    """oracle.update.act == franQ DeepQLearning.act (deepQlearning.py:155-187) on the tapped noise draw."""
+    torch.set_num_threads(1)
+    g = load("act_" + case)
+    spec = spec_from_case(g["case"])
+    params = {k: torch.tensor(v) for k, v in g["init"].items()}
+    xp = {k: torch.tensor(v) for k, v in g["xp"].items()}
+    action, logp, explore, exploit = oup.act(params, spec, xp, torch.tensor(g["noise"]))
+    if spec.discrete:   # integer actions: exact
+        for got, key in ((action, "action"), (explore, "explore_action"), (exploit, "exploit_action")):
+            assert np.array_equal(got.numpy(), g[key]), key
+        assert set(np.unique(g["xp"]["exploit_mask"])) == {False, True}
+    else:
+        for got, key in ((action, "action"), (explore, "explore_action"), (exploit, "exploit_action")):
+            np.testing.assert_allclose(got.numpy(), g[key], rtol=1e-6, atol=1e-7, err_msg=key)
+    np.testing.assert_allclose(logp.numpy(), g["log_prob"], rtol=1e-5, atol=1e-6)
