@@ -63,6 +63,37 @@ class ReplayMemory:
         """Bulk append of packed float32 rows [n, sum(dims)] (host numpy or device tensor)."""
         self._ring.add_rows(rows)
 
+    def append_episode(self, records, return_name=None, n_step=0, discount=0.0, emit_pop=False, her=None):
+        """Write-path ingestion: a finished episode's records (list of dicts, oldest
+        first) go to the ring in one call; the Monte-Carlo return (``return_name``; nstep_return.py:36-72)
+        and the hindsight copy (``her = (goal_row, SparseL2Reward)``; her.py:55-95) are computed on the
+        device, in the order the reference's wrapper stack would have added them.  Returns rows appended."""
+        if not records:
+            return 0
+        if self._ring is None:
+            template = dict(records[0])
+            if return_name is not None:
+                template[return_name] = 0.0     # NStepReturn adds the key last (nstep_return.py:44-46)
+            self._jit_initialize(template)
+        rows = np.zeros((len(records), int(self._offsets[-1])), np.float32)
+        for j, k in enumerate(self._keys):
+            if k == return_name:
+                continue
+            col = [r[k].detach().cpu().numpy() if isinstance(r[k], torch.Tensor) else r[k] for r in records]
+            rows[:, self._offsets[j]:self._offsets[j + 1]] = np.asarray(col, dtype=np.float32).reshape(len(records), -1)
+        key = lambda name: self._keys.index(name) if name in self._keys else -1
+        sp = N.EpisodeSpec()
+        sp.reward_key, sp.return_key = key("reward"), key(return_name) if return_name is not None else -1
+        sp.emit_pop, sp.n_step, sp.gamma = int(bool(emit_pop)), int(n_step), float(discount)
+        if her is not None:
+            goal_row, fn = her
+            sp.her = 1
+            sp.achieved_key, sp.desired_key = key("achieved_goal"), key("desired_goal")
+            sp.task_done_key, sp.step_key = key("task_done"), key("episode_step")
+            sp.goal_row = int(goal_row)
+            sp.reward_fn = fn.native()
+        return self._ring.append_episode(rows, sp)
+
     # ---------------------------------------------------------------- read
     def _named(self, outs, lead):
         return {k: o.view(tuple(lead) + s) for k, s, o in zip(self._keys, self._shapes, outs)}
@@ -132,6 +163,11 @@ class AsyncReplayMemory(ReplayMemory):
     def add(self, experience_dict):
         self._len = min(self._len + 1, self._maxlen)
         super().add(experience_dict)
+
+    def append_episode(self, records, **kw):
+        n = super().append_episode(records, **kw)
+        self._len = min(self._len + n, self._maxlen)
+        return n
 
     def __len__(self):
         return self._len

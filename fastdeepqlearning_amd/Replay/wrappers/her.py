@@ -26,9 +26,31 @@ class HindsightNStepReplay(ReplayMemoryWrapper):
     def add(self, experience):
         self.buffer.append(experience)
         if experience["episode_done"]:
-            self._flush()
-            self._hindsight_flush()
+            if not self._fused_flush():
+                self._flush()
+                self._hindsight_flush()
             self._reset()
+
+    def _fused_flush(self):
+        """Device reward function and (NStepReturn over) the ring directly underneath: real records,
+        hindsight copy and both Monte-Carlo scans in one fdql_ring_append_episode call, rows in the order
+        the per-record path adds them (incl. NStepReturn._pop's duplicate, quirk q3)."""
+        from .nstep_return import NStepReturn
+        if not isinstance(self.compute_reward, SparseL2Reward) or self._mode not in ("final", "random"):
+            return False
+        inner, kw = self.replay_buffer, {}
+        if isinstance(inner, NStepReturn):
+            if inner.buffer or inner.reward_name != "reward" or inner.done_name != "episode_done":
+                return False
+            kw = dict(return_name=inner.return_name, n_step=inner.n_step, discount=inner.discount, emit_pop=True)
+            inner = inner.replay_buffer
+        if isinstance(inner, ReplayMemoryWrapper) or not hasattr(inner, "append_episode"):
+            return False
+        n = len(self.buffer)
+        # same draw as random.choice over the newest-first list (her.py:51-53)
+        goal_row = n - 1 if self._mode == "final" else n - 1 - random.choice(range(n))
+        inner.append_episode([self._strip(r) for r in self.buffer], her=(goal_row, self.compute_reward), **kw)
+        return True
 
     def _strip(self, row):
         return {k: v for k, v in row.items() if k not in self._ignored_keys}

@@ -33,7 +33,20 @@ class NStepReturn(ReplayMemoryWrapper):
         rewards = np.asarray([np.asarray(x[self.reward_name], np.float32).reshape(()) for x in self.buffer], np.float32)
         return mc_return_device(rewards, self.discount, self._device)
 
+    def _fused_target(self):
+        """The ring underneath when this wrapper sits directly on it (then a finished episode is one
+        fdql_ring_append_episode call instead of one add per record)."""
+        rb = self.replay_buffer
+        return rb if hasattr(rb, "append_episode") and not isinstance(rb, ReplayMemoryWrapper) else None
+
     def _flush(self):
+        ring = self._fused_target()
+        if ring is not None and self.reward_name == "reward" and self.done_name == "episode_done":
+            # _pop (if it fired) has already emitted its record at the reference's point in time
+            ring.append_episode(self.buffer, return_name=self.return_name, n_step=self.n_step, discount=self.discount,
+                                emit_pop=False)
+            self._reset()
+            return
         ret = self._returns()
         for row, g in zip(self.buffer, ret):
             out = dict(row)

@@ -66,6 +66,13 @@ class RewardFn(C.Structure):
     _fields_ = [("kind", C.c_int32), ("threshold", C.c_float), ("miss_reward", C.c_float)]
 
 
+class EpisodeSpec(C.Structure):
+    _fields_ = [("reward_key", C.c_int32), ("return_key", C.c_int32), ("emit_pop", C.c_int32), ("n_step", C.c_int32),
+                ("gamma", C.c_float), ("her", C.c_int32), ("achieved_key", C.c_int32), ("desired_key", C.c_int32),
+                ("task_done_key", C.c_int32), ("step_key", C.c_int32), ("goal_row", C.c_int32),
+                ("reward_fn", RewardFn)]
+
+
 # Every symbol include/fdql.h declares, with its ctypes signature (restype, argtypes).
 _vp, _i32, _i64, _u64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
 SIGNATURES = {
@@ -77,6 +84,7 @@ SIGNATURES = {
     "fdql_ring_add": (C.c_int, [_vp, _vp, _i64, _vp]),
     "fdql_ring_add_device": (C.c_int, [_vp, _vp, _i64, _vp]),
     "fdql_ring_flush": (C.c_int, [_vp, _vp]),
+    "fdql_ring_append_episode": (C.c_int, [_vp, _vp, _i64, C.POINTER(EpisodeSpec), C.POINTER(_i64), _vp]),
     "fdql_ring_len": (_i64, [_vp]),
     "fdql_ring_top": (_i64, [_vp]),
     "fdql_ring_row_floats": (_i64, [_vp]),
@@ -126,9 +134,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args
-    sizes = (C.c_int32 * 5)()
+    sizes = (C.c_int32 * 6)()
     lib.fdql_abi_sizes(sizes)
-    mine = [C.sizeof(x) for x in (AgentConfig, Batch, AgentStats, KernelTime, RewardFn)]
+    mine = [C.sizeof(x) for x in (AgentConfig, Batch, AgentStats, KernelTime, RewardFn, EpisodeSpec)]
     if list(sizes) != mine:
         raise ImportError(f"struct layout mismatch between _native.py {mine} and libfdql_hip.so {list(sizes)}")
     _lib = lib

@@ -55,6 +55,16 @@ class NativeRing:
         N.check(self.lib.fdql_ring_add(self.handle, rows.ctypes.data_as(C.c_void_p), rows.shape[0],
                                        N.current_stream(self.device)))
 
+    def append_episode(self, rows, spec):
+        """One finished episode (packed float32 rows [n, row_floats], oldest first, host) -> ring with the
+        n-step scan / hindsight relabel on the device (fdql_ring_append_episode); returns rows appended."""
+        rows = np.ascontiguousarray(rows, dtype=np.float32).reshape(-1, self.row_floats)
+        out = C.c_int64(0)
+        with torch.cuda.device(self.device):
+            N.check(self.lib.fdql_ring_append_episode(self.handle, rows.ctypes.data_as(C.c_void_p), rows.shape[0],
+                                                      C.byref(spec), C.byref(out), N.current_stream(self.device)))
+        return int(out.value)
+
     def flush(self):
         N.check(self.lib.fdql_ring_flush(self.handle, N.current_stream(self.device)))
 

@@ -736,12 +736,13 @@ extern "C" {
 
 const char *fdql_last_error(void) { return g_err; }
 int fdql_version(void) { return 1; }
-void fdql_abi_sizes(int32_t *out5) {
-  out5[0] = (int32_t)sizeof(fdql_agent_config_t);
-  out5[1] = (int32_t)sizeof(fdql_batch_t);
-  out5[2] = (int32_t)sizeof(fdql_agent_stats_t);
-  out5[3] = (int32_t)sizeof(fdql_kernel_time_t);
-  out5[4] = (int32_t)sizeof(fdql_reward_fn_t);
+void fdql_abi_sizes(int32_t *out6) {
+  out6[0] = (int32_t)sizeof(fdql_agent_config_t);
+  out6[1] = (int32_t)sizeof(fdql_batch_t);
+  out6[2] = (int32_t)sizeof(fdql_agent_stats_t);
+  out6[3] = (int32_t)sizeof(fdql_kernel_time_t);
+  out6[4] = (int32_t)sizeof(fdql_reward_fn_t);
+  out6[5] = (int32_t)sizeof(fdql_episode_spec_t);
 }
 
 int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {

@@ -161,15 +161,17 @@ __global__ void k_scatter_rows(ScatterArgs a) {
 
 // nstep_return.py:60-72: ret[i] = r[i] + gamma * ret[i+1] for OLDEST-FIRST arrays, float32
 // multiply then add (no fma: the reference loop rounds the product before the add).
-__global__ void k_mc_return(const float *__restrict__ r, float *__restrict__ ret, int n, float gamma) {
+__global__ void k_mc_return(const float *__restrict__ r, float *__restrict__ ret, int n, float gamma, long long sr,
+                            long long sret, float *__restrict__ first_only) {
 #pragma clang fp contract(off)
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   float acc = 0.f;
   for (int i = n - 1; i >= 0; --i) {
     float prod = acc * gamma;      // rounded product, then rounded sum (no fma)
-    acc = (i == n - 1) ? r[i] : r[i] + prod;
-    ret[i] = acc;
+    acc = (i == n - 1) ? r[i * sr] : r[i * sr] + prod;
+    if (!first_only) ret[i * sret] = acc;
   }
+  if (first_only && n > 0) *first_only = acc;   // NStepReturn._pop: only record 0's return is used
 }
 
 __device__ __forceinline__ float reward_fn(const fdql_reward_fn_t &fn, const float *ag, const float *g, int gd) {
@@ -187,20 +189,27 @@ __device__ __forceinline__ float reward_fn(const fdql_reward_fn_t &fn, const flo
 // synthetic sub-episode of step i starts after the last relabelled-done step BEFORE i, so
 // episode_step'[i] = step[i] - step[p(i) + 1] with p = exclusive prefix-max of
 // (done[j] ? j : -1): a wavefront scan carried across 64-step chunks.
+struct HerStrides {
+  long long reward, estep, ag, dg, r_out, d_out, s_out;  // floats between consecutive steps
+  int dup_prev;  // also write step 0's outputs one stride earlier (the _pop record's slot)
+};
 __global__ __launch_bounds__(64) void k_her_relabel(const float *reward, const float *estep, const float *ag,
                                                     const float *dg, const float *goal, int n, int gd,
-                                                    fdql_reward_fn_t fn, float *r_out, float *d_out, float *s_out) {
+                                                    fdql_reward_fn_t fn, float *r_out, float *d_out, float *s_out,
+                                                    HerStrides st) {
   const int lane = threadIdx.x;
   int carry = -1;  // last done index seen in earlier chunks
   for (int base = 0; base < n; base += 64) {
     const int i = base + lane;
     int flag = -1;
     if (i < n) {
-      const float gr = reward_fn(fn, ag + (long long)i * gd, goal, gd);
-      const float dr = reward_fn(fn, ag + (long long)i * gd, dg + (long long)i * gd, gd);
-      r_out[i] = (reward[i] - dr) + gr;
+      const float gr = reward_fn(fn, ag + i * st.ag, goal, gd);
+      const float dr = reward_fn(fn, ag + i * st.ag, dg + i * st.dg, gd);
+      const float rn = (reward[i * st.reward] - dr) + gr;
       const bool done = (gr == 0.f);
-      d_out[i] = done ? 1.f : 0.f;
+      r_out[i * st.r_out] = rn;
+      d_out[i * st.d_out] = done ? 1.f : 0.f;
+      if (st.dup_prev && i == 0) { r_out[-st.r_out] = rn; d_out[-st.d_out] = done ? 1.f : 0.f; }
       flag = done ? i : -1;
     }
     // inclusive prefix max over the wave
@@ -213,8 +222,38 @@ __global__ __launch_bounds__(64) void k_her_relabel(const float *reward, const f
     int excl = __shfl_up(incl, 1, 64);
     if (lane == 0) excl = -1;
     excl = max(excl, carry);
-    if (i < n) s_out[i] = estep[i] - estep[excl + 1];
+    if (i < n) {
+      const float sn = estep[i * st.estep] - estep[(excl + 1) * st.estep];
+      s_out[i * st.s_out] = sn;
+      if (st.dup_prev && i == 0) s_out[-st.s_out] = sn;
+    }
     carry = max(carry, __shfl(incl, 63, 64));
+  }
+}
+
+// Episode append: copy the n staged rows into `parts` blocks of (pop + n) rows (block 1 = the
+// hindsight copy with desired_goal := the virtual goal); a block's first row, when pop, is the
+// duplicate of record 0 that NStepReturn._pop emits (quirk q3).
+struct ExpandArgs {
+  const float *in;
+  float *out;
+  long long n;
+  int F, pop, parts;
+  int dg_off, ag_off, gd;
+  long long goal_row;
+};
+__global__ void k_episode_expand(ExpandArgs a) {
+  const long long per = a.n + a.pop;
+  const long long total = per * a.parts * a.F;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long o = e / a.F;
+    const int c = (int)(e - o * a.F);
+    const int part = (int)(o / per);
+    const long long j = o - part * per;
+    const long long i = a.pop ? (j > 0 ? j - 1 : 0) : j;
+    float v = a.in[i * a.F + c];
+    if (part == 1 && c >= a.dg_off && c < a.dg_off + a.gd) v = a.in[a.goal_row * a.F + a.ag_off + (c - a.dg_off)];
+    a.out[e] = v;
   }
 }
 
@@ -277,6 +316,11 @@ struct fdql_ring {
   bool stage_inflight = false;
   long long *starts = nullptr;
   int starts_cap = 0;
+  // episode append staging (fdql_ring_append_episode)
+  float *ep_pinned = nullptr, *ep_in = nullptr, *ep_out = nullptr;
+  int64_t ep_in_cap = 0, ep_out_cap = 0;   // rows
+  hipEvent_t ep_done = nullptr;
+  bool ep_inflight = false;
 };
 
 namespace {
@@ -400,6 +444,10 @@ int fdql_ring_destroy(fdql_ring_t *r) {
   if (r->dev_stage) (void)hipFree(r->dev_stage);
   if (r->starts) (void)hipFree(r->starts);
   if (r->stage_done) (void)hipEventDestroy(r->stage_done);
+  if (r->ep_pinned) (void)hipHostFree(r->ep_pinned);
+  if (r->ep_in) (void)hipFree(r->ep_in);
+  if (r->ep_out) (void)hipFree(r->ep_out);
+  if (r->ep_done) (void)hipEventDestroy(r->ep_done);
   delete r;
   return 0;
 }
@@ -438,6 +486,95 @@ int fdql_ring_add_device(fdql_ring_t *r, const float *dev_rows, int64_t n, void 
 int fdql_ring_flush(fdql_ring_t *r, void *stream) {
   FDQL_REQUIRE(r, "null ring");
   return flush(r, (hipStream_t)stream);
+}
+
+int fdql_ring_append_episode(fdql_ring_t *r, const float *host_rows, int64_t n, const fdql_episode_spec_t *sp,
+                             int64_t *appended, void *stream) {
+  FDQL_REQUIRE(r && host_rows && sp && n >= 0, "bad arguments");
+  if (appended) *appended = 0;
+  if (n == 0) return 0;
+  auto scalar_key = [&](int k) { return k >= 0 && k < r->nkeys && r->dims[k] == 1; };
+  FDQL_REQUIRE(sp->return_key < 0 || (scalar_key(sp->return_key) && scalar_key(sp->reward_key)),
+               "append_episode: reward / mc_return must be keys of width 1");
+  FDQL_REQUIRE(sp->return_key < 0 || !sp->emit_pop || sp->n_step >= 1, "append_episode: n_step must be >= 1");
+  int gd = 0;
+  if (sp->her) {
+    FDQL_REQUIRE(sp->reward_fn.kind == 0, "unknown reward function kind %d", sp->reward_fn.kind);
+    FDQL_REQUIRE(scalar_key(sp->reward_key) && scalar_key(sp->task_done_key) && scalar_key(sp->step_key),
+                 "append_episode: reward / task_done / episode_step must be keys of width 1");
+    FDQL_REQUIRE(sp->achieved_key >= 0 && sp->achieved_key < r->nkeys && sp->desired_key >= 0 && sp->desired_key < r->nkeys &&
+                     r->dims[sp->achieved_key] == r->dims[sp->desired_key],
+                 "append_episode: achieved_goal / desired_goal keys must exist with equal width");
+    FDQL_REQUIRE(sp->goal_row >= 0 && sp->goal_row < n, "append_episode: goal_row %d outside the episode", sp->goal_row);
+    gd = r->dims[sp->achieved_key];
+  }
+  const int pop = (sp->return_key >= 0 && sp->emit_pop && n > sp->n_step) ? 1 : 0;
+  const int parts = sp->her ? 2 : 1;
+  const int64_t per = n + pop, n_out = per * parts;
+  FDQL_REQUIRE(n_out <= r->maxlen, "append_episode: %lld rows do not fit a ring of %lld slots", (long long)n_out, (long long)r->maxlen);
+  hipStream_t s = (hipStream_t)stream;
+  int rc = flush(r, s);
+  if (rc) return rc;
+  const int F = r->rowfloats;
+  if (r->ep_inflight) { FDQL_HIP(hipEventSynchronize(r->ep_done)); r->ep_inflight = false; }
+  if (!r->ep_done) FDQL_HIP(hipEventCreateWithFlags(&r->ep_done, hipEventDisableTiming));
+  if (n > r->ep_in_cap) {
+    const int64_t cap = std::max<int64_t>(n, 2 * r->ep_in_cap);
+    if (r->ep_pinned) FDQL_HIP(hipHostFree(r->ep_pinned));
+    if (r->ep_in) FDQL_HIP(hipFree(r->ep_in));
+    r->ep_pinned = nullptr; r->ep_in = nullptr; r->ep_in_cap = 0;
+    FDQL_HIP(hipHostMalloc(&r->ep_pinned, cap * F * sizeof(float)));
+    FDQL_HIP(hipMalloc(&r->ep_in, cap * F * sizeof(float)));
+    r->ep_in_cap = cap;
+  }
+  if (n_out > r->ep_out_cap) {
+    const int64_t cap = std::max<int64_t>(n_out, 2 * r->ep_out_cap);
+    if (r->ep_out) FDQL_HIP(hipFree(r->ep_out));
+    r->ep_out = nullptr; r->ep_out_cap = 0;
+    FDQL_HIP(hipMalloc(&r->ep_out, cap * F * sizeof(float)));
+    r->ep_out_cap = cap;
+  }
+  memcpy(r->ep_pinned, host_rows, n * F * sizeof(float));
+  FDQL_HIP(hipMemcpyAsync(r->ep_in, r->ep_pinned, n * F * sizeof(float), hipMemcpyHostToDevice, s));
+  ExpandArgs ea;
+  memset(&ea, 0, sizeof(ea));
+  ea.in = r->ep_in; ea.out = r->ep_out; ea.n = n; ea.F = F; ea.pop = pop; ea.parts = parts;
+  if (sp->her) { ea.dg_off = r->offs[sp->desired_key]; ea.ag_off = r->offs[sp->achieved_key]; ea.gd = gd; ea.goal_row = sp->goal_row; }
+  {
+    const long long total = n_out * F;
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_episode_expand, dim3(blocks), dim3(256), 0, s, ea);
+    FDQL_HIP(hipGetLastError());
+  }
+  if (sp->her) {   // her.py:55-95 into block 1 (and its _pop duplicate)
+    float *hb = r->ep_out + (per + pop) * F;   // hindsight record 0
+    const HerStrides st = {F, F, F, F, F, F, F, pop};
+    hipLaunchKernelGGL(k_her_relabel, dim3(1), dim3(64), 0, s, r->ep_in + r->offs[sp->reward_key],
+                       r->ep_in + r->offs[sp->step_key], r->ep_in + r->offs[sp->achieved_key],
+                       r->ep_in + r->offs[sp->desired_key], r->ep_in + sp->goal_row * (int64_t)F + r->offs[sp->achieved_key],
+                       (int)n, gd, sp->reward_fn, hb + r->offs[sp->reward_key], hb + r->offs[sp->task_done_key],
+                       hb + r->offs[sp->step_key], st);
+    FDQL_HIP(hipGetLastError());
+  }
+  if (sp->return_key >= 0) {   // nstep_return.py:36-57 per block: the flush scan, and _pop's scan of the first n_step rewards
+    for (int p = 0; p < parts; ++p) {
+      float *blk = r->ep_out + p * per * F;
+      float *rec0 = blk + pop * F;
+      hipLaunchKernelGGL(k_mc_return, dim3(1), dim3(64), 0, s, rec0 + r->offs[sp->reward_key], rec0 + r->offs[sp->return_key],
+                         (int)n, sp->gamma, (long long)F, (long long)F, (float *)nullptr);
+      if (pop)
+        hipLaunchKernelGGL(k_mc_return, dim3(1), dim3(64), 0, s, rec0 + r->offs[sp->reward_key], (float *)nullptr, sp->n_step,
+                           sp->gamma, (long long)F, (long long)F, blk + r->offs[sp->return_key]);
+      FDQL_HIP(hipGetLastError());
+    }
+  }
+  rc = scatter(r, r->ep_out, n_out, r->top, s);
+  if (rc) return rc;
+  advance(r, n_out);
+  FDQL_HIP(hipEventRecord(r->ep_done, s));
+  r->ep_inflight = true;
+  if (appended) *appended = n_out;
+  return 0;
 }
 
 int64_t fdql_ring_len(const fdql_ring_t *r) { return r ? r->len : -1; }
@@ -505,7 +642,8 @@ int fdql_ring_sample_rows(fdql_ring_t *r, int32_t B, const int64_t *idx_dev, uin
 int fdql_episode_mc_return(const float *reward_dev, float *ret_dev, int32_t n, float gamma, void *stream) {
   FDQL_REQUIRE(reward_dev && ret_dev && n >= 0, "bad arguments");
   if (n == 0) return 0;
-  hipLaunchKernelGGL(k_mc_return, dim3(1), dim3(64), 0, (hipStream_t)stream, reward_dev, ret_dev, n, gamma);
+  hipLaunchKernelGGL(k_mc_return, dim3(1), dim3(64), 0, (hipStream_t)stream, reward_dev, ret_dev, n, gamma, 1LL, 1LL,
+                     (float *)nullptr);
   FDQL_HIP(hipGetLastError());
   return 0;
 }
@@ -544,8 +682,9 @@ int fdql_episode_her_relabel(const float *reward, const float *episode_step, con
                    episode_step_out && n >= 0 && goal_dim > 0, "bad arguments");
   FDQL_REQUIRE(fn->kind == 0, "unknown reward function kind %d", fn->kind);
   if (n == 0) return 0;
+  const HerStrides st = {1, 1, goal_dim, goal_dim, 1, 1, 1, 0};
   hipLaunchKernelGGL(k_her_relabel, dim3(1), dim3(64), 0, (hipStream_t)stream, reward, episode_step, achieved_goal,
-                     desired_goal, goal, n, goal_dim, *fn, reward_out, task_done_out, episode_step_out);
+                     desired_goal, goal, n, goal_dim, *fn, reward_out, task_done_out, episode_step_out, st);
   FDQL_HIP(hipGetLastError());
   return 0;
 }

@@ -39,8 +39,8 @@ const char *fdql_last_error(void);
 int fdql_version(void);
 /* sizeof() of the structs below as this library was compiled, so a binding can verify its
  * own mirror: out[0]=fdql_agent_config_t, [1]=fdql_batch_t, [2]=fdql_agent_stats_t,
- * [3]=fdql_kernel_time_t, [4]=fdql_reward_fn_t. */
-void fdql_abi_sizes(int32_t *out5);
+ * [3]=fdql_kernel_time_t, [4]=fdql_reward_fn_t, [5]=fdql_episode_spec_t. */
+void fdql_abi_sizes(int32_t *out6);
 
 /* ------------------------------------------------------------------------------------ */
 /* Replay ring: structure-of-arrays ring in HBM                                          */
@@ -119,6 +119,33 @@ int fdql_episode_her_relabel(const float *reward, const float *episode_step, con
                              const float *desired_goal, const float *goal, int32_t n, int32_t goal_dim,
                              const fdql_reward_fn_t *fn, float *reward_out, float *task_done_out,
                              float *episode_step_out, void *stream);
+
+/* Write-path ingestion: one finished episode -> ring, in ONE call.
+ * Replaces the per-record emit of HindsightNStepReplay -> NStepReturn -> ReplayMemory.add
+ * (franQ/Replay/wrappers/her.py:28-95, nstep_return.py:24-57, replay_memory.py:37-46; driven one dict
+ * at a time by Runner._replay_handler, Runner/runner.py:177-191): the episode's packed rows
+ * [n, row_floats] (oldest first, host memory) are staged through pinned memory with one H2D copy, the
+ * n-step scan and the hindsight relabel run on the device, and the resulting rows are scattered into
+ * the SoA ring in exactly the order the reference's wrapper stack would have added them:
+ *   [ _pop's duplicate of record 0 with the return over the first n_step rewards (quirk q3), iff
+ *     emit_pop and n > n_step ] + the n records with mc_return;  then, iff her, the same block again
+ *   for the hindsight copy (desired_goal := achieved_goal[goal_row]; reward, task_done,
+ *   episode_step relabelled as in fdql_episode_her_relabel; mc_return over the relabelled rewards).
+ * The mc_return column of the input rows is ignored.  *appended = ring rows written.  No host sync
+ * (the pinned staging buffer of the previous episode is waited for before it is reused).       */
+typedef struct {
+  int32_t reward_key;     /* key index of "reward" (width 1)                                         */
+  int32_t return_key;     /* key index of "mc_return" (width 1), or -1: no n-step return              */
+  int32_t emit_pop;       /* 1: also emit NStepReturn._pop's record (nstep_return.py:33-34, 50-57)    */
+  int32_t n_step;         /* conf.nStep_return_steps                                                  */
+  float gamma;
+  int32_t her;            /* 0: real records only; 1: append the hindsight copy (her.py:55-95)        */
+  int32_t achieved_key, desired_key, task_done_key, step_key;
+  int32_t goal_row;       /* record whose achieved_goal is the virtual goal ("final": n-1)            */
+  fdql_reward_fn_t reward_fn;
+} fdql_episode_spec_t;
+int fdql_ring_append_episode(fdql_ring_t *ring, const float *host_rows, int64_t n, const fdql_episode_spec_t *spec,
+                             int64_t *appended, void *stream);
 
 /* her_vmap.py:30-45,66-90 for one finished episode (oldest-first device arrays): K virtual goals
  * achieved_goal[goal_idx[k]]; per step i and virtual goal k
