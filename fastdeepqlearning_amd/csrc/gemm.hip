@@ -50,6 +50,16 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) v4f *gcf4;
 typedef const __attribute__((address_space(1))) v2f *gcf2;
 
+// Values read from the problem table are wave-uniform, but the table lives in memory the kernel may
+// also write (hipcc cannot prove otherwise), so they arrive through vector loads.  Pinning them into
+// SGPRs makes every branch on them a scalar branch and lets base pointers stay in scalar registers.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ const float *uni(const float *p) {
+  const uintptr_t u = reinterpret_cast<uintptr_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+  return reinterpret_cast<const float *>(((uintptr_t)hi << 32) | lo);
+}
+
 __device__ __forceinline__ bool aligned16(gcf p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 __device__ __forceinline__ bool aligned8(gcf p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
 
@@ -118,6 +128,61 @@ __device__ __forceinline__ void load_chunk_ks(const float *__restrict__ P, int l
   }
 }
 
+// Both operand chunks -> registers.  Interior, aligned chunks (the common case: the tile inside the
+// matrix, a whole K-chunk, ld % 4 == 0, 16-byte bases) take a straight-line path: every address is
+// formed FIRST, then the loads issue back to back.  The order matters: hipcc reuses the (dead)
+// destination registers of the staging loads as address temporaries, and a temporary written while
+// an earlier load of this chunk is in flight costs an `s_waitcnt vmcnt(0)` - one exposed global-load
+// latency per chunk (seen in the ISA of the guarded loaders below, which remain for edge tiles and
+// ragged operands).  All conditions are wave-uniform (problem table + tile position only).
+template <int R, int BKT>
+__device__ __forceinline__ bool operand_fast(const float *P, int ld, int Rmax, int kend, int r0, int k0) {
+  constexpr bool EXACT = (R * BKT / 4) % GEMM_THREADS == 0;
+  return EXACT && (r0 + R <= Rmax) && (k0 + BKT <= kend) && ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(P) & 15) == 0);
+}
+// per-lane element offset of slot 0 of an operand chunk (constant for a segment) and the uniform
+// distance between a thread's slots
+template <int R, int BKT>
+__device__ __forceinline__ unsigned operand_lane_off(int ld, int kc, int tid) {
+  constexpr int KQ = BKT / 4, RQ = R / 4;
+  return kc ? (unsigned)((tid / KQ) * ld + (tid % KQ) * 4) : (unsigned)((tid / RQ) * ld + (tid % RQ) * 4);
+}
+template <int R, int BKT>
+__device__ __forceinline__ long long operand_slot_stride(int ld, int kc) {
+  constexpr int KQ = BKT / 4, RQ = R / 4;
+  return (long long)(kc ? GEMM_THREADS / KQ : GEMM_THREADS / RQ) * ld;
+}
+
+template <int BMT, int BNT, int NVA, int NVB, int BKT>
+__device__ __forceinline__ void load_operands(const float *A, int lda, int akc, int M, const float *B, int ldb, int bkc,
+                                              int N, int kend, int r0, int c0, int k0, int tid, unsigned voa, unsigned vob,
+                                              float (&va)[4 * NVA], float (&vb)[4 * NVB]) {
+  if (operand_fast<BMT, BKT>(A, lda, M, kend, r0, k0) && operand_fast<BNT, BKT>(B, ldb, N, kend, c0, k0)) {
+    gcf baseA = (gcf)(akc ? A + (long long)r0 * lda + k0 : A + (long long)k0 * lda + r0);   // scalar
+    gcf baseB = (gcf)(bkc ? B + (long long)c0 * ldb + k0 : B + (long long)k0 * ldb + c0);
+    const long long hsa = operand_slot_stride<BMT, BKT>(lda, akc), hsb = operand_slot_stride<BNT, BKT>(ldb, bkc);
+    gcf4 pa[NVA], pb[NVB];
+#pragma unroll
+    for (int h = 0; h < NVA; ++h) pa[h] = (gcf4)(baseA + h * hsa + voa);
+#pragma unroll
+    for (int h = 0; h < NVB; ++h) pb[h] = (gcf4)(baseB + h * hsb + vob);
+    __builtin_amdgcn_sched_barrier(0);
+    v4f xa[NVA], xb[NVB];
+#pragma unroll
+    for (int h = 0; h < NVA; ++h) xa[h] = *pa[h];
+#pragma unroll
+    for (int h = 0; h < NVB; ++h) xb[h] = *pb[h];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int h = 0; h < NVA; ++h) { va[4 * h] = xa[h].x; va[4 * h + 1] = xa[h].y; va[4 * h + 2] = xa[h].z; va[4 * h + 3] = xa[h].w; }
+#pragma unroll
+    for (int h = 0; h < NVB; ++h) { vb[4 * h] = xb[h].x; vb[4 * h + 1] = xb[h].y; vb[4 * h + 2] = xb[h].z; vb[4 * h + 3] = xb[h].w; }
+    return;
+  }
+  if (akc) load_chunk_kc<BMT, NVA, BKT>(A, lda, M, kend, r0, k0, tid, va); else load_chunk_ks<BMT, NVA, BKT>(A, lda, M, kend, r0, k0, tid, va);
+  if (bkc) load_chunk_kc<BNT, NVB, BKT>(B, ldb, N, kend, c0, k0, tid, vb); else load_chunk_ks<BNT, NVB, BKT>(B, ldb, N, kend, c0, k0, tid, vb);
+}
+
 template <int R, int NV, int BKT>
 __device__ __forceinline__ void store_chunk_kc(float *__restrict__ lds, int tid, const float (&v)[4 * NV]) {
   constexpr int PITCH = R + 4, KQ = BKT / 4;
@@ -160,21 +225,23 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_grouped(const GemmProb
     if (bid >= probs[i].tile_start) pi = i;
   const GemmProblem &P = probs[pi];
 
-  const int M = P.M, N = P.N, nseg = P.nseg, ksplit = P.ksplit;
-  const int local = bid - P.tile_start;
-  const int tiles_mn = P.tiles_m * P.tiles_n;
+  const int M = uni(P.M), N = uni(P.N), nseg = uni(P.nseg), ksplit = uni(P.ksplit);
+  const int tiles_n = uni(P.tiles_n);
+  const int local = bid - uni(P.tile_start);
+  const int tiles_mn = uni(P.tiles_m) * tiles_n;
   const int split = local / tiles_mn;
   const int rem = local - split * tiles_mn;
-  const int tile_m = rem / P.tiles_n;
-  const int tile_n = rem - tile_m * P.tiles_n;
+  const int tile_m = rem / tiles_n;
+  const int tile_n = rem - tile_m * tiles_n;
   const int r0 = tile_m * BM, c0 = tile_n * BN;
 
   // K range of segment 0 when the problem is K-split (wgrad); whole segments otherwise.
-  int kb0 = 0, ke0 = P.seg[0].K;
+  const int K0 = uni(P.seg[0].K);
+  int kb0 = 0, ke0 = K0;
   if (ksplit > 1) {
-    const int per = ((P.seg[0].K + ksplit - 1) / ksplit + BK - 1) / BK * BK;
+    const int per = ((K0 + ksplit - 1) / ksplit + BK - 1) / BK * BK;
     kb0 = split * per;
-    ke0 = min(P.seg[0].K, kb0 + per);
+    ke0 = min(K0, kb0 + per);
   }
 
   f32x16 acc[TM][TN];
@@ -193,17 +260,27 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_grouped(const GemmProb
   int s = 0, k = kb0, ke = ke0;
   while (s < nseg && k >= ke) {
     ++s;
-    if (s < nseg) { k = 0; ke = P.seg[s].K; }
+    if (s < nseg) { k = 0; ke = uni(P.seg[s].K); }
   }
   bool have = (s < nseg) && (ksplit == 1 || s == 0);
 
+  // Descriptor of the segment chunks are being loaded from, held in (scalar) registers and re-read
+  // from the problem table only at a segment switch - not once per chunk.
+  const float *sA = nullptr, *sB = nullptr;
+  int slda = 0, sldb = 0, sakc = 1, sbkc = 1;
+  unsigned voa = 0, vob = 0;   // per-lane offsets of the straight-line loader, constant for a segment
+  auto fetch_seg = [&](int idx) {
+    const GemmSeg &S = P.seg[idx];
+    sA = uni(S.A); sB = uni(S.B); slda = uni(S.lda); sldb = uni(S.ldb); sakc = uni(S.a_kc); sbkc = uni(S.b_kc);
+    voa = operand_lane_off<BM, BK>(slda, sakc, tid);
+    vob = operand_lane_off<BN, BK>(sldb, sbkc, tid);
+  };
   float va[4 * NVA], vb[4 * NVB];
   if (have) {
-    const GemmSeg &S = P.seg[s];
-    if (S.a_kc) load_chunk_kc<BM, NVA, BK>(S.A, S.lda, M, ke, r0, k, tid, va); else load_chunk_ks<BM, NVA, BK>(S.A, S.lda, M, ke, r0, k, tid, va);
-    if (S.b_kc) load_chunk_kc<BN, NVB, BK>(S.B, S.ldb, N, ke, c0, k, tid, vb); else load_chunk_ks<BN, NVB, BK>(S.B, S.ldb, N, ke, c0, k, tid, vb);
-    if (S.a_kc) store_chunk_kc<BM, NVA, BK>(lds[0], tid, va); else store_chunk_ks<BM, NVA, BK>(lds[0], tid, va);
-    if (S.b_kc) store_chunk_kc<BN, NVB, BK>(lds[0] + BK * PA, tid, vb); else store_chunk_ks<BN, NVB, BK>(lds[0] + BK * PA, tid, vb);
+    fetch_seg(s);
+    load_operands<BM, BN, NVA, NVB, BK>(sA, slda, sakc, M, sB, sldb, sbkc, N, ke, r0, c0, k, tid, voa, vob, va, vb);
+    if (sakc) store_chunk_kc<BM, NVA, BK>(lds[0], tid, va); else store_chunk_ks<BM, NVA, BK>(lds[0], tid, va);
+    if (sbkc) store_chunk_kc<BN, NVB, BK>(lds[0] + BK * PA, tid, vb); else store_chunk_ks<BN, NVB, BK>(lds[0] + BK * PA, tid, vb);
   }
   __syncthreads();
 #ifdef FDQL_GEMM_DEBUG
@@ -221,21 +298,49 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_grouped(const GemmProb
     if (nk >= ke) {
       ns = s + 1;
       nk = 0;
-      while (ns < nseg && P.seg[ns].K <= 0) ++ns;
-      if (ns < nseg) nke = P.seg[ns].K;
+      while (ns < nseg && uni(P.seg[ns].K) <= 0) ++ns;
+      if (ns < nseg) nke = uni(P.seg[ns].K);
     }
     const bool has_next = (ns < nseg) && (ksplit == 1 || ns == 0);
-    int n_akc = 1, n_bkc = 1;
     if (has_next) {
-      const GemmSeg &S = P.seg[ns];
-      n_akc = S.a_kc; n_bkc = S.b_kc;
-      if (n_akc) load_chunk_kc<BM, NVA, BK>(S.A, S.lda, M, nke, r0, nk, tid, va); else load_chunk_ks<BM, NVA, BK>(S.A, S.lda, M, nke, r0, nk, tid, va);
-      if (n_bkc) load_chunk_kc<BN, NVB, BK>(S.B, S.ldb, N, nke, c0, nk, tid, vb); else load_chunk_ks<BN, NVB, BK>(S.B, S.ldb, N, nke, c0, nk, tid, vb);
+      if (ns != s) fetch_seg(ns);
+      load_operands<BM, BN, NVA, NVB, BK>(sA, slda, sakc, M, sB, sldb, sbkc, N, nke, r0, c0, nk, tid, voa, vob, va, vb);
     }
+    const int n_akc = sakc, n_bkc = sbkc;   // layout of the chunk just requested (stored below)
 
     const float *la = lds[cur] + wm * (TM * 32) + li;
     const float *lb = lds[cur] + BK * PA + wn * (TN * 32) + li;
-    if (PIPE) {
+    if (PIPE == 2) {
+      // Fragments of k-steps kk+1 and kk+2 are in flight while the MFMAs of k-step kk issue.  The
+      // scheduling barriers pin that order: left alone, hipcc sinks each ds_read next to its use and
+      // waits lgkmcnt(0) before every MFMA pair, exposing the LDS latency once per k-step.
+      constexpr int NS = BK / 2;
+      float a[3][TM], b[3][TN];
+#pragma unroll
+      for (int p = 0; p < 2 && p < NS; ++p) {
+#pragma unroll
+        for (int t = 0; t < TM; ++t) a[p][t] = la[(2 * p + lh) * PA + 32 * t];
+#pragma unroll
+        for (int t = 0; t < TN; ++t) b[p][t] = lb[(2 * p + lh) * PB + 32 * t];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < NS; ++kk) {
+        if (kk + 2 < NS) {
+#pragma unroll
+          for (int t = 0; t < TM; ++t) a[(kk + 2) % 3][t] = la[(2 * kk + 4 + lh) * PA + 32 * t];
+#pragma unroll
+          for (int t = 0; t < TN; ++t) b[(kk + 2) % 3][t] = lb[(2 * kk + 4 + lh) * PB + 32 * t];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk % 3][tm], b[kk % 3][tn], acc[tm][tn], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else if (PIPE) {
       // fragments of k-step kk+1 are requested before the MFMAs of k-step kk are issued, so the
       // LDS latency hides behind 4 x 64 MFMA cycles instead of stalling every step
       float a[2][TM], b[2][TN];
@@ -279,6 +384,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_grouped(const GemmProb
     asm volatile("" ::"v"(la), "v"(lb));
 
     if (!has_next) break;
+    // Unconditional vmcnt(0) (s_waitcnt simm16 0x0F70: lgkmcnt/expcnt left open).  The staged registers
+    // are needed now anyway; stated here, on every path, it also tells hipcc's wait-count pass that
+    // no load is pending at the loop back-edge.  Without it the pass (which sees the guarded LDS stores
+    // below as skippable) waits vmcnt(0) in the NEXT iteration between issuing the A loads and forming
+    // the B addresses - exposing one full global-load latency per chunk.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     if (n_akc) store_chunk_kc<BM, NVA, BK>(lds[cur ^ 1], tid, va); else store_chunk_ks<BM, NVA, BK>(lds[cur ^ 1], tid, va);
     if (n_bkc) store_chunk_kc<BN, NVB, BK>(lds[cur ^ 1] + BK * PA, tid, vb); else store_chunk_ks<BN, NVB, BK>(lds[cur ^ 1] + BK * PA, tid, vb);
     __syncthreads();
@@ -392,7 +503,7 @@ static void launch_shape(const GemmProblem *probs_dev, int nprob, int total_bloc
     case 1: hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 16, 1>), g, b, 0, stream, probs_dev, nprob); break;
     case 2: hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 32, 0>), g, b, 0, stream, probs_dev, nprob); break;
     case 3: hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 32, 1>), g, b, 0, stream, probs_dev, nprob); break;
-    case 4: hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 8, 1>), g, b, 0, stream, probs_dev, nprob); break;
+    case 4: hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 16, 2>), g, b, 0, stream, probs_dev, nprob); break;
     default: hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 16, 0>), g, b, 0, stream, probs_dev, nprob); break;
   }
 }

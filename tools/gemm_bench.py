@@ -9,7 +9,7 @@ dev = torch.device("cuda:0")
 shapes = [(4096, 4096, 4096, "nt"), (8192, 8192, 1024, "nt"), (188160, 256, 256, "nt"), (188160, 256, 262, "nt"),
           (12544, 256, 256, "nt"), (12544, 256, 1558, "nn"), (256, 256, 12544, "tn"), (125440, 256, 256, "nn")]
 import itertools
-for (M, N, K, form), variant in itertools.product(shapes, [0, 1, 2, 3]):
+for (M, N, K, form), variant in itertools.product(shapes, [int(v) for v in os.environ.get("VARIANTS", "0,1,2,3").split(",")]):
     lib.fdql_debug_set_gemm_variant(variant)
     if form == "nt":
         A = torch.randn(M, K, device=dev); B = torch.randn(N, K, device=dev); lda, akc, ldb, bkc = K, 1, K, 1
