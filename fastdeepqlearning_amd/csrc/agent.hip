@@ -74,7 +74,7 @@ struct MlpInst {
   const float *HB() const { return wbase + (d->hb_off - worigin); }
 };
 
-enum StageKind { ST_GEMM, ST_SKINNY_WGRAD, ST_FUNC };
+enum StageKind { ST_GEMM, ST_SKINNY_WGRAD, ST_FUNC, ST_HEAD_DGRAD };
 
 struct GemmSub {
   std::vector<GemmProblem> probs;
@@ -88,6 +88,7 @@ struct Stage {
   std::vector<GemmProblem> gemm;
   GemmSub sub[GEMM_NSHAPES];  // the problems of `gemm`, grouped by tile shape (one launch each)
   std::vector<SkinnyWgradProblem> swg;
+  std::vector<HeadDgradProblem> hdg;
   void *dev = nullptr;  // device copy of the table
   int blocks = 0;
   double flops = 0, bytes = 0;
@@ -345,6 +346,20 @@ struct Builder {
     p.colsum = m.dpre_cs[i];
     return p;
   }
+  // last hidden layer under a narrow head: the rank-dout outer product as a streaming kernel
+  static bool narrow_head_last(const MlpDesc &d, int i) {
+    return i + 1 == (int)d.hid.size() && d.dout <= HEAD_DGRAD_MAXQ;
+  }
+  HeadDgradProblem bwd_dpre_head(const MlpInst &m, int i, const float *dY, int lddy) {
+    const MlpDesc &d = *m.d;
+    HeadDgradProblem p;
+    memset(&p, 0, sizeof(p));
+    p.M = m.rows; p.N = d.hid[i]; p.Q = d.dout;
+    p.dY = dY; p.lddy = lddy;
+    p.Wh = m.HW() + head_col_of_hidden(d, i); p.ldw = d.head_ld();
+    p.h = m.h[i]; p.dpre = m.dpre[i]; p.colsum = m.dpre_cs[i];
+    return p;
+  }
   // K-segments of d(input columns [col, col+width)) = dY Wh[:, cols] + dpre_0 W_0[:, cols]
   void input_grad_segs(const MlpInst &m, const float *dY, int lddy, int col, GemmProblem &p) {
     const MlpDesc &d = *m.d;
@@ -426,6 +441,7 @@ int upload_tables(fdql_agent *a) {
       for (auto &sub : s.sub) total += pad(sub.probs.size() * sizeof(GemmProblem));
     }
     if (s.kind == ST_SKINNY_WGRAD) total += pad(s.swg.size() * sizeof(SkinnyWgradProblem));
+    if (s.kind == ST_HEAD_DGRAD) total += pad(s.hdg.size() * sizeof(HeadDgradProblem));
   }
   if (a->tables_dev) { FDQL_HIP(hipFree(a->tables_dev)); a->tables_dev = nullptr; }
   FDQL_HIP(hipMalloc(&a->tables_dev, total ? total : 256));
@@ -453,6 +469,17 @@ int upload_tables(fdql_agent *a) {
       }
       const size_t bytes = s.swg.size() * sizeof(SkinnyWgradProblem);
       memcpy(host.data() + off, s.swg.data(), bytes);
+      s.dev = (char *)a->tables_dev + off;
+      off += pad(bytes);
+    } else if (s.kind == ST_HEAD_DGRAD) {
+      s.blocks = head_dgrad_finalize(s.hdg.data(), (int)s.hdg.size());
+      s.flops = 0; s.bytes = 0;
+      for (auto &p : s.hdg) {
+        s.flops += 2.0 * p.M * (double)p.N * p.Q;
+        s.bytes += 8.0 * p.M * (double)p.N;   // read h, write dpre
+      }
+      const size_t bytes = s.hdg.size() * sizeof(HeadDgradProblem);
+      memcpy(host.data() + off, s.hdg.data(), bytes);
       s.dev = (char *)a->tables_dev + off;
       off += pad(bytes);
     }
@@ -586,6 +613,16 @@ int build_plan(fdql_agent *a) {
   {
     const size_t nh = a->critic[0].hid.size();
     for (int i = (int)nh - 1; i >= 0; --i) {
+      if (Builder::narrow_head_last(a->critic[0], i)) {
+        Stage st;
+        st.kind = ST_HEAD_DGRAD; st.name = "critics.dpre" + std::to_string(i);
+        for (int k = 0; k < C; ++k) {
+          st.hdg.push_back(b.bwd_dpre_head(co[k], i, a->buf("dz") + k * Q, Nq));
+          st.hdg.push_back(b.bwd_dpre_head(cf[k], i, a->buf("dzf") + k * Q, Nq));
+        }
+        a->stages.push_back(st);
+        continue;
+      }
       Stage &gs = b.gemm_stage("critics.dpre" + std::to_string(i));
       for (int k = 0; k < C; ++k) {
         gs.gemm.push_back(b.bwd_dpre(co[k], i, a->buf("dz") + k * Q, Nq));
@@ -707,6 +744,7 @@ hipError_t run_stage(fdql_agent *a, Stage &s, hipStream_t stream) {
       return hipSuccess;
     case ST_SKINNY_WGRAD: return skinny_wgrad_launch_host(s.swg.data(), (const SkinnyWgradProblem *)s.dev, (int)s.swg.size(), s.blocks, stream);
     case ST_FUNC: return s.fn(stream);
+    case ST_HEAD_DGRAD: return head_dgrad_launch((const HeadDgradProblem *)s.dev, (int)s.hdg.size(), s.blocks, stream);
   }
   return hipSuccess;
 }

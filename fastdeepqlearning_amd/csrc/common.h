@@ -95,4 +95,22 @@ struct SkinnyWgradProblem {
 };
 int skinny_wgrad_finalize(SkinnyWgradProblem *p, int n);
 
+// Gradient of the LAST hidden layer of an MLP whose head is narrow (dout <= HEAD_DGRAD_MAXQ, e.g. the
+// Q quantile outputs of a critic):  dpre[m][n] = LeakyReLU'(h[m][n]) * sum_q dY[m][q] * Wh[q][n]
+// - a rank-Q outer product, pure HBM streaming (read h, write dpre), not worth an MFMA tile -
+// plus the per-64-row column sums the bias gradient is reduced from.
+constexpr int HEAD_DGRAD_MAXQ = 8;
+struct HeadDgradProblem {
+  int M, N, Q;
+  const float *dY;         // [M, lddy], columns 0..Q-1 used
+  int lddy;
+  const float *Wh;         // head weight rows q, already offset to this layer's columns: Wh[q*ldw + n]
+  int ldw;
+  const float *h;          // [M, N] activation output of the layer
+  float *dpre;             // [M, N]
+  float *colsum;           // [ceil(M/64), N]
+  int block_start, col_blocks;
+};
+int head_dgrad_finalize(HeadDgradProblem *p, int n);
+
 }  // namespace fdql

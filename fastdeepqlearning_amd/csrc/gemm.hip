@@ -53,12 +53,17 @@ typedef const __attribute__((address_space(1))) v2f *gcf2;
 // Values read from the problem table are wave-uniform, but the table lives in memory the kernel may
 // also write (hipcc cannot prove otherwise), so they arrive through vector loads.  Pinning them into
 // SGPRs makes every branch on them a scalar branch and lets base pointers stay in scalar registers.
+#ifdef FDQL_DBG_NO_UNI
+__device__ __forceinline__ int uni(int v) { return v; }
+__device__ __forceinline__ const float *uni(const float *p) { return p; }
+#else
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ const float *uni(const float *p) {
   const uintptr_t u = reinterpret_cast<uintptr_t>(p);
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
   return reinterpret_cast<const float *>(((uintptr_t)hi << 32) | lo);
 }
+#endif
 
 __device__ __forceinline__ bool aligned16(gcf p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 __device__ __forceinline__ bool aligned8(gcf p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
@@ -209,6 +214,56 @@ __device__ __forceinline__ void store_chunk_ks(float *__restrict__ lds, int tid,
   }
 }
 
+// ---- LDS fragment reads (see the comment in the main loop)
+__device__ __forceinline__ unsigned lds_addr(const float *p) {
+  return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)p;
+}
+template <int OFF_BYTES>
+__device__ __forceinline__ void lds_read_b32(float &d, unsigned addr) {
+  static_assert(OFF_BYTES >= 0 && OFF_BYTES < 65536, "ds_read_b32 offset field is 16 bits");
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=&v"(d) : "v"(addr), "n"(OFF_BYTES));
+}
+// T fragments of k-step KK: element t at (2*KK*PITCH + 32*t) floats past the lane's base
+template <int T, int KK, int PITCH>
+__device__ __forceinline__ void frag_read(float (&f)[T], unsigned addr) {
+  lds_read_b32<(2 * KK * PITCH) * 4>(f[0], addr);
+  if constexpr (T > 1) lds_read_b32<(2 * KK * PITCH + 32) * 4>(f[1], addr);
+  if constexpr (T > 2) lds_read_b32<(2 * KK * PITCH + 64) * 4>(f[2], addr);
+  if constexpr (T > 3) lds_read_b32<(2 * KK * PITCH + 96) * 4>(f[3], addr);
+}
+// kk is a compile-time constant after unrolling; dispatch it onto the template parameter
+template <int T, int PITCH>
+__device__ __forceinline__ void frag_read_dyn(float (&f)[T], unsigned addr, int kk) {
+  switch (kk) {
+    case 1: frag_read<T, 1, PITCH>(f, addr); break;
+    case 2: frag_read<T, 2, PITCH>(f, addr); break;
+    case 3: frag_read<T, 3, PITCH>(f, addr); break;
+    case 4: frag_read<T, 4, PITCH>(f, addr); break;
+    case 5: frag_read<T, 5, PITCH>(f, addr); break;
+    case 6: frag_read<T, 6, PITCH>(f, addr); break;
+    case 7: frag_read<T, 7, PITCH>(f, addr); break;
+    case 8: frag_read<T, 8, PITCH>(f, addr); break;
+    case 9: frag_read<T, 9, PITCH>(f, addr); break;
+    case 10: frag_read<T, 10, PITCH>(f, addr); break;
+    case 11: frag_read<T, 11, PITCH>(f, addr); break;
+    case 12: frag_read<T, 12, PITCH>(f, addr); break;
+    case 13: frag_read<T, 13, PITCH>(f, addr); break;
+    case 14: frag_read<T, 14, PITCH>(f, addr); break;
+    case 15: frag_read<T, 15, PITCH>(f, addr); break;
+    default: frag_read<T, 0, PITCH>(f, addr); break;
+  }
+}
+template <int N>
+__device__ __forceinline__ void lds_wait() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+// orders the uses of the fragments after the wait above (an asm the values pass through)
+template <int T>
+__device__ __forceinline__ void frag_ready(float (&f)[T]) {
+#pragma unroll
+  for (int t = 0; t < T; ++t) asm volatile("" : "+v"(f[t]));
+}
+
 template <int SHAPE, int BK, int PIPE>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_grouped(const GemmProblem *__restrict__ probs, int nprob) {
   using Cfg = TileCfg<SHAPE>;
@@ -308,88 +363,49 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_grouped(const GemmProb
     }
     const int n_akc = sakc, n_bkc = sbkc;   // layout of the chunk just requested (stored below)
 
-    const float *la = lds[cur] + wm * (TM * 32) + li;
-    const float *lb = lds[cur] + BK * PA + wn * (TN * 32) + li;
-    if (PIPE == 2) {
-      // Fragments of k-steps kk+1 and kk+2 are in flight while the MFMAs of k-step kk issue.  The
-      // scheduling barriers pin that order: left alone, hipcc sinks each ds_read next to its use and
-      // waits lgkmcnt(0) before every MFMA pair, exposing the LDS latency once per k-step.
-      constexpr int NS = BK / 2;
-      float a[3][TM], b[3][TN];
+    // Fragment reads are written as inline `ds_read_b32` with EARLY-CLOBBER destinations and explicit
+    // lgkmcnt waits.  Reason (observed twice on gfx950, reproducible, LDS contents verified by a dump):
+    // when hipcc allocates a fragment's destination VGPR on top of that read's own address VGPR
+    // (`ds_read_b32 v45, v45 offset:...`), lanes 27/31/59/63 of the wave can come back with wrong data,
+    // depending on what surrounds the read - parity tests then fail on output rows 27 and 31 of a
+    // tile.  With "=&v" the destination can never alias the address, whatever the allocator does;
+    // immediates (<= 64 KB) address the whole staged tile from two base registers.
+    const unsigned la = lds_addr(lds[cur] + wm * (TM * 32) + li + lh * PA);
+    const unsigned lb = lds_addr(lds[cur] + BK * PA + wn * (TN * 32) + li + lh * PB);
+    constexpr int NS = BK / 2;
+    float a[2][TM], b[2][TN];
+    frag_read<TM, 0, PA>(a[0], la);
+    frag_read<TN, 0, PB>(b[0], lb);
 #pragma unroll
-      for (int p = 0; p < 2 && p < NS; ++p) {
-#pragma unroll
-        for (int t = 0; t < TM; ++t) a[p][t] = la[(2 * p + lh) * PA + 32 * t];
-#pragma unroll
-        for (int t = 0; t < TN; ++t) b[p][t] = lb[(2 * p + lh) * PB + 32 * t];
+    for (int kk = 0; kk < NS; ++kk) {
+      float(&ac)[TM] = a[kk & 1];
+      float(&bc)[TN] = b[kk & 1];
+      if (PIPE && kk + 1 < NS) {
+        // next k-step's fragments are requested before this step's MFMAs issue; LDS returns in order,
+        // so "at most TM+TN reads outstanding" means this step's fragments have landed
+        frag_read_dyn<TM, PA>(a[(kk + 1) & 1], la, kk + 1);
+        frag_read_dyn<TN, PB>(b[(kk + 1) & 1], lb, kk + 1);
+        lds_wait<TM + TN>();
+      } else {
+        lds_wait<0>();
       }
-      __builtin_amdgcn_sched_barrier(0);
+      frag_ready<TM>(ac);
+      frag_ready<TN>(bc);
 #pragma unroll
-      for (int kk = 0; kk < NS; ++kk) {
-        if (kk + 2 < NS) {
+      for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-          for (int t = 0; t < TM; ++t) a[(kk + 2) % 3][t] = la[(2 * kk + 4 + lh) * PA + 32 * t];
-#pragma unroll
-          for (int t = 0; t < TN; ++t) b[(kk + 2) % 3][t] = lb[(2 * kk + 4 + lh) * PB + 32 * t];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk % 3][tm], b[kk % 3][tn], acc[tm][tn], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else if (PIPE) {
-      // fragments of k-step kk+1 are requested before the MFMAs of k-step kk are issued, so the
-      // LDS latency hides behind 4 x 64 MFMA cycles instead of stalling every step
-      float a[2][TM], b[2][TN];
-#pragma unroll
-      for (int t = 0; t < TM; ++t) a[0][t] = la[lh * PA + 32 * t];
-#pragma unroll
-      for (int t = 0; t < TN; ++t) b[0][t] = lb[lh * PB + 32 * t];
-#pragma unroll
-      for (int kk = 0; kk < BK / 2; ++kk) {
-        if (kk + 1 < BK / 2) {
-#pragma unroll
-          for (int t = 0; t < TM; ++t) a[(kk + 1) & 1][t] = la[(2 * kk + 2 + lh) * PA + 32 * t];
-#pragma unroll
-          for (int t = 0; t < TN; ++t) b[(kk + 1) & 1][t] = lb[(2 * kk + 2 + lh) * PB + 32 * t];
-        }
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk & 1][tm], b[kk & 1][tn], acc[tm][tn], 0, 0, 0);
-      }
-    } else {
-#pragma unroll
-      for (int kk = 0; kk < BK / 2; ++kk) {
-        float a[TM], b[TN];
-#pragma unroll
-        for (int t = 0; t < TM; ++t) a[t] = la[(2 * kk + lh) * PA + 32 * t];
-#pragma unroll
-        for (int t = 0; t < TN; ++t) b[t] = lb[(2 * kk + lh) * PB + 32 * t];
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[tm], bc[tn], acc[tm][tn], 0, 0, 0);
+      if (!PIPE && kk + 1 < NS) {
+        frag_read_dyn<TM, PA>(a[(kk + 1) & 1], la, kk + 1);
+        frag_read_dyn<TN, PB>(b[(kk + 1) & 1], lb, kk + 1);
       }
     }
-    // Keep the fragment base addresses live past the last read of the chunk.  Without this hipcc
-    // (ROCm 7.2) lets the chunk's final `ds_read_b32` overwrite its own address VGPR
-    // (vdst == vaddr); on gfx950 that read returned zeros in lanes 27/31/59/63 of every wave of the
-    // 128x32 tile variant (observed, reproducible; LDS contents verified correct by a dump).
+    // the two base registers stay reserved until every read of the chunk has returned, so no
+    // fragment destination is ever allocated on top of an address still in use by an in-flight read
     asm volatile("" ::"v"(la), "v"(lb));
 
     if (!has_next) break;
-    // Unconditional vmcnt(0) (s_waitcnt simm16 0x0F70: lgkmcnt/expcnt left open).  The staged registers
-    // are needed now anyway; stated here, on every path, it also tells hipcc's wait-count pass that
-    // no load is pending at the loop back-edge.  Without it the pass (which sees the guarded LDS stores
-    // below as skippable) waits vmcnt(0) in the NEXT iteration between issuing the A loads and forming
-    // the B addresses - exposing one full global-load latency per chunk.
-    __builtin_amdgcn_s_waitcnt(0x0F70);
     if (n_akc) store_chunk_kc<BM, NVA, BK>(lds[cur ^ 1], tid, va); else store_chunk_ks<BM, NVA, BK>(lds[cur ^ 1], tid, va);
     if (n_bkc) store_chunk_kc<BN, NVB, BK>(lds[cur ^ 1] + BK * PA, tid, vb); else store_chunk_ks<BN, NVB, BK>(lds[cur ^ 1] + BK * PA, tid, vb);
     __syncthreads();
@@ -503,7 +519,7 @@ static void launch_shape(const GemmProblem *probs_dev, int nprob, int total_bloc
     case 1: hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 16, 1>), g, b, 0, stream, probs_dev, nprob); break;
     case 2: hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 32, 0>), g, b, 0, stream, probs_dev, nprob); break;
     case 3: hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 32, 1>), g, b, 0, stream, probs_dev, nprob); break;
-    case 4: hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 16, 2>), g, b, 0, stream, probs_dev, nprob); break;
+    case 4: hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 8, 1>), g, b, 0, stream, probs_dev, nprob); break;
     default: hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 16, 0>), g, b, 0, stream, probs_dev, nprob); break;
   }
 }

@@ -111,6 +111,64 @@ hipError_t skinny_wgrad_launch_host(const SkinnyWgradProblem *host, const Skinny
 }
 
 // ======================================================================================
+// d(pre-activation) of the last hidden layer under a narrow head (rank-Q outer product)
+//   block = 64 rows x 256 columns of one problem; thread = one column: its Q head weights sit in
+//   registers, the 64 x Q dY block in LDS, h is read and dpre written row by row (1 KB coalesced).
+// ======================================================================================
+int head_dgrad_finalize(HeadDgradProblem *p, int n) {
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    p[i].block_start = total;
+    p[i].col_blocks = (p[i].N + 255) / 256;
+    total += ((p[i].M + 63) / 64) * p[i].col_blocks;
+  }
+  return total;
+}
+
+__global__ __launch_bounds__(256) void k_head_dgrad(const HeadDgradProblem *__restrict__ probs, int nprob) {
+  __shared__ float dys[64 * HEAD_DGRAD_MAXQ];
+  int pi = 0;
+  for (int i = 1; i < nprob; ++i)
+    if ((int)blockIdx.x >= probs[i].block_start) pi = i;
+  const HeadDgradProblem P = probs[pi];
+  const int local = blockIdx.x - P.block_start;
+  const int rb = local / P.col_blocks, cb = local - rb * P.col_blocks;
+  const int r0 = rb * 64, n = cb * 256 + threadIdx.x;
+  const int Q = P.Q;
+  for (int e = threadIdx.x; e < 64 * Q; e += 256) {
+    const int r = e / Q, q = e - r * Q;
+    dys[e] = (r0 + r < P.M) ? P.dY[(long long)(r0 + r) * P.lddy + q] : 0.f;
+  }
+  float w[HEAD_DGRAD_MAXQ];
+#pragma unroll
+  for (int q = 0; q < HEAD_DGRAD_MAXQ; ++q) w[q] = (q < Q && n < P.N) ? P.Wh[(long long)q * P.ldw + n] : 0.f;
+  __syncthreads();
+  if (n >= P.N) return;
+  const int nr = min(64, P.M - r0);
+  const float *h = P.h + (long long)r0 * P.N + n;
+  float *out = P.dpre + (long long)r0 * P.N + n;
+  float csum = 0.f;
+#pragma unroll 8
+  for (int r = 0; r < nr; ++r) {
+    float g = 0.f;
+#pragma unroll
+    for (int q = 0; q < HEAD_DGRAD_MAXQ; ++q)
+      if (q < Q) g = fmaf(dys[r * Q + q], w[q], g);
+    const float a = h[(long long)r * P.N];
+    const float x = a > 0.f ? g : 0.01f * g;
+    out[(long long)r * P.N] = x;
+    csum += x;
+  }
+  if (P.colsum) P.colsum[(long long)rb * P.N + n] = csum;
+}
+
+hipError_t head_dgrad_launch(const HeadDgradProblem *dev, int n, int total_blocks, hipStream_t s) {
+  if (total_blocks <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_head_dgrad, dim3(total_blocks), dim3(256), 0, s, dev, n);
+  return hipGetLastError();
+}
+
+// ======================================================================================
 // Philox4x32-10 (counter-based RNG for perf runs; parity runs pass noise in)
 // ======================================================================================
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,

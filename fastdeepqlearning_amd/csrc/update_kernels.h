@@ -85,6 +85,7 @@ struct ActPolicyArgs {
 hipError_t act_layer_launch(const ActLayerArgs &a, hipStream_t s);
 hipError_t act_policy_launch(const ActPolicyArgs &a, hipStream_t s);
 
+hipError_t head_dgrad_launch(const HeadDgradProblem *dev, int n, int total_blocks, hipStream_t s);
 hipError_t skinny_wgrad_launch_host(const SkinnyWgradProblem *host, const SkinnyWgradProblem *dev, int n,
                                     int total_blocks, hipStream_t s);
 hipError_t loss_launch(const LossArgs &a, hipStream_t s);
