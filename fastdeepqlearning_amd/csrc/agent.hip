@@ -241,6 +241,7 @@ void carve(fdql_agent *a) {
   a->alloc("pi", M * c.act_dim);
   a->alloc("log_pi", M);
   a->alloc("noise_actor", M * c.act_dim);
+  a->alloc("pi_diff", M * c.act_dim);
   if (c.discrete) a->alloc("action_onehot", N * c.act_dim);
   for (int k = 0; k < c.n_critics; ++k) {
     const std::string s = std::to_string(k);
@@ -292,7 +293,7 @@ struct Builder {
   static GemmProblem new_gemm(int M, int N, float *C, int ldc) {
     GemmProblem p;
     memset(&p, 0, sizeof(p));
-    p.M = M; p.N = N; p.C = C; p.ldc = ldc; p.ksplit = 1;
+    p.M = M; p.N = N; p.C = C; p.ldc = ldc; p.ksplit = 1; p.emit_seg = -1;
     return p;
   }
   static void add_seg(GemmProblem &p, const float *A, int lda, int a_kc, const float *B, int ldb, int b_kc, int K) {
@@ -569,8 +570,9 @@ int build_plan(fdql_agent *a) {
   fwd_chain({&at, &ao}, "actors");
   // ---- policy sampling (gaussian_mlp.py:15-39)
   {
-    PolicyFwdArgs p0{at.out, nullptr, nullptr, a->buf("next_action"), a->buf("next_log_pi"), 0u};
-    PolicyFwdArgs p1{ao.out, nullptr, a->buf("noise_actor"), a->buf("pi"), a->buf("log_pi"), 1u};
+    PolicyFwdArgs p0{at.out, nullptr, nullptr, a->buf("next_action"), a->buf("next_log_pi"), 0u, nullptr, nullptr};
+    PolicyFwdArgs p1{ao.out, nullptr, a->buf("noise_actor"), a->buf("pi"), a->buf("log_pi"), 1u,
+                     c.discrete ? a->buf("action_onehot") : x.action, a->buf("pi_diff")};
     fdql_agent *ag = a;
     b.func_stage("policy_fwd", [=](hipStream_t s) {
       PolicyFwdArgs q0 = p0, q1 = p1;
@@ -581,9 +583,37 @@ int build_plan(fdql_agent *a) {
   }
   // ---- critics forward: target(next, a'), online(cur, a), frozen(cur, pi)
   {
-    std::vector<MlpInst *> g;
-    for (int k = 0; k < C; ++k) { g.push_back(&ct[k]); g.push_back(&co[k]); g.push_back(&cf[k]); }
-    fwd_chain(g, "critics");
+    // critic_frozen is a copy of critic taken when the actor loss is formed (soft_actor_critic.py:142),
+    // so both read the online weights and layer 0 of q(s, a) and q(s, pi) shares s.Ws: ONE problem per
+    // critic accumulates cat(s, a), stores h0 of the online pass, continues with (pi - a).Wa and stores
+    // h0 of the frozen pass (GemmProblem::emit_seg) - 10 layer-0 problems instead of 15.
+    const size_t nh = a->critic[0].hid.size();
+    if (nh > 0 && getenv("FDQL_NO_DUAL") == nullptr) {
+      Stage &gs = b.gemm_stage("critics.fwd0");
+      for (int k = 0; k < C; ++k) {
+        GemmProblem pt = b.fwd_layer(ct[k], 0);
+        pt.emit_seg = pt.nseg - 1;   // no tail: rides in the same launch as the dual problems
+        gs.gemm.push_back(pt);
+        GemmProblem p = b.fwd_layer(co[k], 0);
+        Builder::add_seg(p, a->buf("pi_diff"), A, 1, co[k].W(0) + L, a->critic[k].din, 1, A);
+        p.emit_seg = p.nseg - 2;
+        p.C2 = cf[k].h[0];
+        p.ldc2 = a->critic[k].hid[0];
+        gs.gemm.push_back(p);
+      }
+      for (size_t i = 1; i < nh; ++i) {
+        Stage &ls = b.gemm_stage("critics.fwd" + std::to_string(i));
+        for (int k = 0; k < C; ++k)
+          for (MlpInst *m : {&ct[k], &co[k], &cf[k]}) ls.gemm.push_back(b.fwd_layer(*m, (int)i));
+      }
+      Stage &hs = b.gemm_stage("critics.head");
+      for (int k = 0; k < C; ++k)
+        for (MlpInst *m : {&ct[k], &co[k], &cf[k]}) hs.gemm.push_back(b.fwd_head(*m));
+    } else {
+      std::vector<MlpInst *> g;
+      for (int k = 0; k < C; ++k) { g.push_back(&ct[k]); g.push_back(&co[k]); g.push_back(&cf[k]); }
+      fwd_chain(g, "critics");
+    }
   }
   // ---- loss
   {
@@ -929,7 +959,7 @@ int32_t fdql_agent_profile_update(fdql_agent_t *a, const fdql_batch_t *batch, co
     FDQL_HIP(hipEventRecord(ev[i + 1], s));
   }
   FDQL_HIP(hipStreamSynchronize(s));
-  static const char *shape_names[GEMM_NSHAPES] = {"128x128", "128x32", "32x128", "64x128"};
+  static const char *shape_names[GEMM_NSHAPES] = {"128x128", "128x32", "32x128", "64x128", "64x128dual"};
   int32_t cnt = 0;
   for (size_t i = 0; i < n && cnt < cap; ++i, ++cnt) {
     float ms = 0;
@@ -1100,6 +1130,7 @@ int fdql_test_gemm(const float *A, int32_t lda, int32_t a_kc, const float *B, in
                    const float *ref, int32_t ldref, int32_t ksplit, void *stream) {
   GemmProblem p;
   memset(&p, 0, sizeof(p));
+  p.emit_seg = -1;
   p.M = M; p.N = N; p.C = C; p.ldc = ldc; p.ksplit = ksplit < 1 ? 1 : ksplit; p.split_stride = (long long)M * ldc;
   p.bias = bias; p.epi = epilogue; p.ref = ref; p.ldref = ldref;
   p.nseg = 1;

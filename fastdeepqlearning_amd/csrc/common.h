@@ -44,7 +44,7 @@ struct GemmSeg {
 };
 
 enum GemmEpilogue { EPI_NONE = 0, EPI_LRELU = 1, EPI_LRELU_GRAD = 2 };
-enum GemmShape { GEMM_128x128 = 0, GEMM_128x32 = 1, GEMM_32x128 = 2, GEMM_64x128 = 3, GEMM_NSHAPES = 4 };
+enum GemmShape { GEMM_128x128 = 0, GEMM_128x32 = 1, GEMM_32x128 = 2, GEMM_64x128 = 3, GEMM_64x128_DUAL = 4, GEMM_NSHAPES = 5 };
 
 struct GemmProblem {
   int M, N;
@@ -58,6 +58,9 @@ struct GemmProblem {
   const float *ref;        // EPI_LRELU_GRAD: activation output whose sign gates the gradient
   int ldref;
   float *colsum;           // optional [ceil(M/64), N]: column sums of the stored values per 64-row block
+  int emit_seg;            // -1, or a DUAL problem (64x128 tiles): C = f(sum over segments <= emit_seg),
+  float *C2;               //   C2 = f(sum over ALL segments), same bias / activation: two outputs that share
+  int ldc2;                //   their leading K-segments in one pass (ksplit == 1, no colsum)
   int tiles_m, tiles_n;    // filled by gemm_finalize
   int tile_start;          // first block id of this problem in its launch
   GemmSeg seg[GEMM_MAX_SEG];

@@ -34,10 +34,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // The narrow shapes waste MFMA lanes on padding but those problems are bandwidth-bound: what
 // matters is that they stream their big operand through the same coalesced LDS staging.
 template <int SHAPE> struct TileCfg;
-template <> struct TileCfg<GEMM_128x128> { static constexpr int WM = 2, WN = 2, TM = 2, TN = 2; };
-template <> struct TileCfg<GEMM_128x32> { static constexpr int WM = 4, WN = 1, TM = 1, TN = 1; };
-template <> struct TileCfg<GEMM_32x128> { static constexpr int WM = 1, WN = 4, TM = 1, TN = 1; };
-template <> struct TileCfg<GEMM_64x128> { static constexpr int WM = 2, WN = 2, TM = 1, TN = 2; };
+template <> struct TileCfg<GEMM_128x128> { static constexpr int WM = 2, WN = 2, TM = 2, TN = 2; static constexpr bool DUAL = false; };
+template <> struct TileCfg<GEMM_128x32> { static constexpr int WM = 4, WN = 1, TM = 1, TN = 1; static constexpr bool DUAL = false; };
+template <> struct TileCfg<GEMM_32x128> { static constexpr int WM = 1, WN = 4, TM = 1, TN = 1; static constexpr bool DUAL = false; };
+template <> struct TileCfg<GEMM_64x128> { static constexpr int WM = 2, WN = 2, TM = 1, TN = 2; static constexpr bool DUAL = false; };
+// 64x128 tiles, two outputs: C = f(sum over segments <= emit_seg), C2 = f(sum over all segments) -
+// critic layer 0 of q(s, a) and q(s, pi) in one pass over s.Ws
+//   (no second accumulator: the tile is stored, the tail segments are added, the tile is stored again)
+template <> struct TileCfg<GEMM_64x128_DUAL> { static constexpr int WM = 2, WN = 2, TM = 1, TN = 2; static constexpr bool DUAL = true; };
 
 // Pointers that come out of the problem tables are generic to the compiler, which would emit
 // FLAT loads: those also count on lgkmcnt, so the `s_waitcnt lgkmcnt(0)` in front of the MFMAs
@@ -299,6 +303,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_grouped(const GemmProb
     ke0 = min(K0, kb0 + per);
   }
 
+  constexpr bool DUAL = Cfg::DUAL;
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int a = 0; a < TM; ++a)
@@ -306,6 +311,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_grouped(const GemmProb
     for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  // DUAL: the pipelined main loop covers segments <= emit_seg; the (narrow) tail segments follow the
+  // first tile store in a plain load / stage / multiply loop
+  const int nseg_all = nseg;
+  const int nseg_main = DUAL ? uni(P.emit_seg) + 1 : nseg;
 
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
@@ -313,11 +322,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_grouped(const GemmProb
 
   // first non-empty chunk
   int s = 0, k = kb0, ke = ke0;
-  while (s < nseg && k >= ke) {
+  while (s < nseg_main && k >= ke) {
     ++s;
-    if (s < nseg) { k = 0; ke = uni(P.seg[s].K); }
+    if (s < nseg_main) { k = 0; ke = uni(P.seg[s].K); }
   }
-  bool have = (s < nseg) && (ksplit == 1 || s == 0);
+  bool have = (s < nseg_main) && (ksplit == 1 || s == 0);
 
   // Descriptor of the segment chunks are being loaded from, held in (scalar) registers and re-read
   // from the problem table only at a segment switch - not once per chunk.
@@ -347,22 +356,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_grouped(const GemmProb
 #endif
 
   int cur = 0;
-  while (have) {
-    // locate the next chunk
-    int ns = s, nk = k + BK, nke = ke;
-    if (nk >= ke) {
-      ns = s + 1;
-      nk = 0;
-      while (ns < nseg && uni(P.seg[ns].K) <= 0) ++ns;
-      if (ns < nseg) nke = uni(P.seg[ns].K);
-    }
-    const bool has_next = (ns < nseg) && (ksplit == 1 || ns == 0);
-    if (has_next) {
-      if (ns != s) fetch_seg(ns);
-      load_operands<BM, BN, NVA, NVB, BK>(sA, slda, sakc, M, sB, sldb, sbkc, N, nke, r0, c0, nk, tid, voa, vob, va, vb);
-    }
-    const int n_akc = sakc, n_bkc = sbkc;   // layout of the chunk just requested (stored below)
-
+  // MFMAs of the chunk staged in lds[cur] (k, ke: its position in the current segment)
+  auto run_chunk = [&]() {
     // Fragment reads are written as inline `ds_read_b32` with EARLY-CLOBBER destinations and explicit
     // lgkmcnt waits.  Reason (observed twice on gfx950, reproducible, LDS contents verified by a dump):
     // when hipcc allocates a fragment's destination VGPR on top of that read's own address VGPR
@@ -373,11 +368,18 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_grouped(const GemmProb
     const unsigned la = lds_addr(lds[cur] + wm * (TM * 32) + li + lh * PA);
     const unsigned lb = lds_addr(lds[cur] + BK * PA + wn * (TN * 32) + li + lh * PB);
     constexpr int NS = BK / 2;
+    // k-steps that hold data: a ragged last chunk (or a narrow segment such as the Q columns of dz or
+    // the 6 action columns) stops early instead of multiplying staged zeros
+    const int ksteps = min(NS, (ke - k + 1) >> 1);
     float a[2][TM], b[2][TN];
     frag_read<TM, 0, PA>(a[0], la);
     frag_read<TN, 0, PB>(b[0], lb);
 #pragma unroll
     for (int kk = 0; kk < NS; ++kk) {
+      if (kk >= ksteps) {   // wave-uniform
+        lds_wait<0>();      // drain the prefetch issued by the previous step
+        break;
+      }
       float(&ac)[TM] = a[kk & 1];
       float(&bc)[TN] = b[kk & 1];
       if (PIPE && kk + 1 < NS) {
@@ -404,6 +406,24 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_grouped(const GemmProb
     // the two base registers stay reserved until every read of the chunk has returned, so no
     // fragment destination is ever allocated on top of an address still in use by an in-flight read
     asm volatile("" ::"v"(la), "v"(lb));
+  };
+  while (have) {
+    // locate the next chunk
+    int ns = s, nk = k + BK, nke = ke;
+    if (nk >= ke) {
+      ns = s + 1;
+      nk = 0;
+      while (ns < nseg_main && uni(P.seg[ns].K) <= 0) ++ns;
+      if (ns < nseg_main) nke = uni(P.seg[ns].K);
+    }
+    const bool has_next = (ns < nseg_main) && (ksplit == 1 || ns == 0);
+    if (has_next) {
+      if (ns != s) fetch_seg(ns);
+      load_operands<BM, BN, NVA, NVB, BK>(sA, slda, sakc, M, sB, sldb, sbkc, N, nke, r0, c0, nk, tid, voa, vob, va, vb);
+    }
+    const int n_akc = sakc, n_bkc = sbkc;   // layout of the chunk just requested (stored below)
+
+    run_chunk();
 
     if (!has_next) break;
     if (n_akc) store_chunk_kc<BM, NVA, BK>(lds[cur ^ 1], tid, va); else store_chunk_ks<BM, NVA, BK>(lds[cur ^ 1], tid, va);
@@ -414,36 +434,56 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_grouped(const GemmProb
   }
 
   // epilogue: D[i][j] of a 32x32 tile sits at col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  gf C = (gf)(P.C + (long long)split * P.split_stride);
-  const int ldc = P.ldc, epi = P.epi;
+  const int epi = P.epi;
   gcf bias = (gcf)P.bias;
   gcf ref = (gcf)P.ref;
   const int ldref = P.ldref;
   float csum[TN];
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) csum[tn] = 0.f;
+  auto store_tile = [&](gf C, int ldc, bool second) {
 #pragma unroll
-  for (int tm = 0; tm < TM; ++tm) {
+    for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      const int col = c0 + (wn * TN + tn) * 32 + li;
-      if (col >= N) continue;
-      const float bv = bias ? bias[col] : 0.f;
+      for (int tn = 0; tn < TN; ++tn) {
+        const int col = c0 + (wn * TN + tn) * 32 + li;
+        if (col >= N) continue;
+        const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = r0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row >= M) continue;
-        float x = acc[tm][tn][r] + bv;
-        if (epi == EPI_LRELU) {
-          x = x > 0.f ? x : 0.01f * x;
-        } else if (epi == EPI_LRELU_GRAD) {
-          const float a = ref[(long long)row * ldref + col];
-          x = a > 0.f ? x : 0.01f * x;
+        for (int r = 0; r < 16; ++r) {
+          const int row = r0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (row >= M) continue;
+          float x = acc[tm][tn][r];
+          x += bv;
+          if (epi == EPI_LRELU) {
+            x = x > 0.f ? x : 0.01f * x;
+          } else if (epi == EPI_LRELU_GRAD) {
+            const float a = ref[(long long)row * ldref + col];
+            x = a > 0.f ? x : 0.01f * x;
+          }
+          C[(long long)row * ldc + col] = x;
+          if (!second) csum[tn] += x;
         }
-        C[(long long)row * ldc + col] = x;
-        csum[tn] += x;
       }
     }
+  };
+  store_tile((gf)(P.C + (long long)split * P.split_stride), P.ldc, false);
+  if constexpr (DUAL) {
+    // tail segments (e.g. the 6 columns of pi - a): accumulate on top of the stored sum, store again
+    for (int ts = nseg_main; ts < nseg_all; ++ts) {
+      fetch_seg(ts);
+      ke = uni(P.seg[ts].K);
+      for (k = 0; k < ke; k += BK) {
+        __syncthreads();   // every wave is done reading the staging buffer
+        load_operands<BM, BN, NVA, NVB, BK>(sA, slda, sakc, M, sB, sldb, sbkc, N, ke, r0, c0, k, tid, voa, vob, va, vb);
+        if (sakc) store_chunk_kc<BM, NVA, BK>(lds[0], tid, va); else store_chunk_ks<BM, NVA, BK>(lds[0], tid, va);
+        if (sbkc) store_chunk_kc<BN, NVB, BK>(lds[0] + BK * PA, tid, vb); else store_chunk_ks<BN, NVB, BK>(lds[0] + BK * PA, tid, vb);
+        __syncthreads();
+        cur = 0;
+        run_chunk();
+      }
+    }
+    if (nseg_all > nseg_main) store_tile((gf)P.C2, P.ldc2, true);   // a problem without tail is an ordinary one
   }
   // optional column sums (bias gradients): fixed-order reduction through LDS, one partial row
   // per 64 output rows: colsum[row/64][N]
@@ -469,7 +509,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_grouped(const GemmProb
 }
 
 static void shape_dims(int shape, int &bm, int &bn) {
-  bm = shape == GEMM_32x128 ? 32 : (shape == GEMM_64x128 ? 64 : 128);
+  bm = shape == GEMM_32x128 ? 32 : ((shape == GEMM_64x128 || shape == GEMM_64x128_DUAL) ? 64 : 128);
   bn = shape == GEMM_128x32 ? 32 : 128;
 }
 
@@ -494,6 +534,7 @@ int gemm_finalize(GemmProblem *probs, int nprob, int shape) {
 // better than the bigger tile's higher MFMA:LDS ratio helps.  `prefer_128` keeps the big tile
 // selectable for experiments (FDQL_GEMM_DENSE_SHAPE).
 int gemm_pick_shape(const GemmProblem &p, bool prefer_128) {
+  if (p.emit_seg >= 0) return GEMM_64x128_DUAL;
   if (p.N <= 32) return GEMM_128x32;
   if (p.M <= 32 && !p.colsum) return GEMM_32x128;
   if (prefer_128 || p.M <= 64) return GEMM_128x128;
@@ -541,6 +582,7 @@ hipError_t gemm_launch(const GemmProblem *probs_dev, int nprob, int total_blocks
   if (shape == GEMM_128x128) launch_shape<GEMM_128x128>(probs_dev, nprob, total_blocks, v, stream);
   else if (shape == GEMM_128x32) launch_shape<GEMM_128x32>(probs_dev, nprob, total_blocks, v, stream);
   else if (shape == GEMM_64x128) launch_shape<GEMM_64x128>(probs_dev, nprob, total_blocks, v, stream);
+  else if (shape == GEMM_64x128_DUAL) launch_shape<GEMM_64x128_DUAL>(probs_dev, nprob, total_blocks, v, stream);
   else launch_shape<GEMM_32x128>(probs_dev, nprob, total_blocks, v, stream);
   return hipGetLastError();
 }

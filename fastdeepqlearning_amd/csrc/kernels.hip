@@ -285,6 +285,7 @@ __global__ void k_policy_fwd(PolicyFwdArgs a0, PolicyFwdArgs a1, int nprob, int 
     lp -= (float)log((double)((1.f - act * act) + 1e-4f));
     logp += lp;
     a.action[(long long)m * A + j] = act;
+    if (a.diff) a.diff[(long long)m * A + j] = act - a.sub[(long long)m * A + j];
   }
   a.logp[m] = logp;
 }
@@ -373,6 +374,7 @@ __global__ void k_policy_fwd_gumbel(PolicyFwdArgs a0, PolicyFwdArgs a1, int npro
     const float hard = j == best ? 1.f : 0.f;
     const float stv = (hard - relaxed[j]) + relaxed[j];   // straight-through value, same fp order as torch
     a.action[(long long)m * n + j] = stv;
+    if (a.diff) a.diff[(long long)m * n + j] = stv - a.sub[(long long)m * n + j];
     logp += -stv * (norm[j] - lse3);
   }
   a.logp[m] = -logp;

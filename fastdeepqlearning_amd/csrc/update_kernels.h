@@ -23,6 +23,8 @@ struct PolicyFwdArgs {
   float *action;        // [M, A]
   float *logp;          // [M]
   uint32_t which;       // RNG stream id
+  const float *sub;     // optional [M, A]: also write diff = action - sub (the critic-input delta between
+  float *diff;          //   cat(s, pi) and cat(s, a); see the dual layer-0 problem in agent.hip)
 };
 
 struct LossArgs {
