@@ -125,6 +125,9 @@ def main():
     ap.add_argument("--temporal-len", type=int, default=50)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--also-t2", action="store_true",
+                    help="add the temporal_len=2 figure (off by default so that a rocprofv3 summary of the "
+                         "default command holds launches of ONE workload only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -254,6 +257,32 @@ def main():
                    "achieved": round(s_bytes / (s_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": round(s_bytes / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes": s_bytes}
 
+    # ---- secondary figure ("reports both T=50 and T=2"): the same workload as plain 1-step
+    # minibatches (temporal_len 2 = one TD pair per window), rank 0 at N=1 only; never `value`
+    t2 = None
+    if rank == 0 and world == 1 and T != 2 and args.also_t2:
+        cfg2 = make_config(OBS, ACT, 2, B, n_critics=C, n_quantiles=Q, latent=HID, enc_features=HID, enc_hidden=(HID,),
+                           joint_hidden=(HID,), pi_hidden=(HID,), critic_hidden=(HID, HID), world_size=1,
+                           keep_frozen_copy=True)
+        ag2 = NativeAgent(cfg2, dev)
+        ag2.init_weights(seed=0)
+        outs2 = [torch.empty(2, B, d, device=dev) for d in DIMS]
+        xp2 = dict(zip(KEYS, outs2))
+        for i in range(20):
+            ring.sample_windows(2, B, seed=seed, counter=20_000 + i, outs=outs2)
+            ag2.update(xp2, seed=seed)
+        torch.cuda.synchronize(dev)
+        n2 = 200
+        t0 = time.perf_counter()
+        for i in range(n2):
+            ring.sample_windows(2, B, seed=seed, counter=30_000 + i, outs=outs2)
+            ag2.update(xp2, seed=seed)
+        torch.cuda.synchronize(dev)
+        e2 = time.perf_counter() - t0
+        t2 = {"temporal_len": 2, "value": round(n2 / e2, 1), "unit": "steps/s", "ms_per_step": round(1e3 * e2 / n2, 4),
+              "transitions_per_step": 2 * B, "note": "launch/latency-bound: 2.6 GFLOP per step"}
+        del ag2
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(T, B)
@@ -272,7 +301,7 @@ def main():
                        "global_batch_windows": B * world, "temporal_len": T, "transitions_per_step": B * world * T,
                        "ring": RING, "parallelism": f"dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu,
-            "sampler_roofline": sampler, "kernel_ms_top": breakdown,
+            "sampler_roofline": sampler, "kernel_ms_top": breakdown, "also_temporal_len_2": t2,
         }
         print(json.dumps(out))
 

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Regenerates the evidence under profiles/ on a GPU box (run through gpurun from the repo root):
+#   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh'
+# Writes into gpurun_out/profiles_new/ (merged back by gpurun); copy what should be judged into profiles/.
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/profiles_new
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+# 1. bench line (N=1) and its rocprofv3 kernel stats (same command)
+python3 $R/bench.py --steps 50 --warmup 10 > $OUT/bench_n1.json 2> $OUT/bench_n1.err || exit 1
+python3 $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline --also-t2 > $OUT/bench_n1_with_t2.json 2>> $OUT/bench_n1.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.err || exit 1
+# 2. per-stage times (HIP events inside the library)
+python3 $R/tools/profile_stages.py > $OUT/stage_times.txt 2>&1 || exit 1
+# 3. HBM traffic of every kernel of one update: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (TCC slots)
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/tools/profile_stages.py --reps 1 > $OUT/pmc_fetch.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/tools/profile_stages.py --reps 1 > $OUT/pmc_write.log 2>&1 || exit 1
+python3 $R/tools/summarize_profiles.py $OUT

@@ -1,0 +1,62 @@
+"""Condense the rocprofv3 outputs of tools/collect_profiles.sh into the small files kept under profiles/."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+out = sys.argv[1]
+
+
+def counter_rows(sub):
+    f = glob.glob(os.path.join(out, sub, "**", "*_counter_collection.csv"), recursive=True)
+    return list(csv.DictReader(open(f[0]))) if f else []
+
+
+def per_kernel(rows, counter):
+    """(kernel name, grid) -> mean counter value per dispatch, in dispatch order of first appearance."""
+    acc = collections.OrderedDict()
+    for r in rows:
+        if r["Counter_Name"] != counter or "fdql::" not in r["Kernel_Name"]:
+            continue
+        key = (r["Kernel_Name"].split("(")[0], int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0))
+        a = acc.setdefault(key, [0.0, 0])
+        a[0] += float(r["Counter_Value"])
+        a[1] += 1
+    return acc
+
+
+fetch = per_kernel(counter_rows("pmc_fetch"), "FETCH_SIZE")
+write = per_kernel(counter_rows("pmc_write"), "WRITE_SIZE")
+lines = ["# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, --kernel-trace only) over",
+         "# tools/profile_stages.py (config 2, T=50, B=256); mean per dispatch.  HBM_read = 2 x FETCH_SIZE KiB (gfx950",
+         "# reports half of wide coalesced reads, MI355X_MICROARCH.md; check: k_reduce_slabs must read 32 slabs x 4.07 MB",
+         "# = 130 MB).  HBM_write = WRITE_SIZE KiB.  Values are L2<->fabric traffic (Infinity-Cache hits included)."]
+tot = collections.defaultdict(lambda: [0.0, 0.0, 0])
+for key in fetch:
+    rd = 2.0 * fetch[key][0] / fetch[key][1] * 1024 / 1e6
+    wr = (write[key][0] / write[key][1] * 1024 / 1e6) if key in write else float("nan")
+    lines.append(f"{key[0]:60s} grid={key[1]:9d} dispatches={fetch[key][1]:4d} HBM_read_MB={rd:9.2f} HBM_write_MB={wr:9.2f}")
+    t = tot[key[0]]
+    t[0] += rd * fetch[key][1]
+    t[1] += wr * fetch[key][1]
+    t[2] += fetch[key][1]
+open(os.path.join(out, "hbm_traffic_pmc.txt"), "w").write("\n".join(lines) + "\n")
+# dominant kernel = the 64x128 instantiation of the grouped GEMM
+dom = [k for k in tot if "k_gemm_grouped<3" in k]
+if dom:
+    t = tot[dom[0]]
+    json.dump({"kernel": dom[0], "dispatches_measured": t[2], "hbm_read_MB_per_launch": t[0] / t[2],
+               "hbm_write_MB_per_launch": t[1] / t[2], "hbm_bytes_per_launch": (t[0] + t[1]) / t[2] * 1e6,
+               "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE doubled (gfx950)",
+               "workload": "config 2, T=50, B=256"}, open(os.path.join(out, "dominant_kernel_traffic.json"), "w"), indent=1)
+# kernel stats csv of the bench run
+st = glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True)
+if st:
+    rows = list(csv.DictReader(open(st[0])))
+    with open(os.path.join(out, "rocprofv3_kernel_stats_bench.csv"), "w") as f:
+        w = csv.DictWriter(f, fieldnames=rows[0].keys())
+        w.writeheader()
+        w.writerows(rows)
+print("summaries written to", out)
