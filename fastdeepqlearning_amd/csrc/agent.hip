@@ -439,6 +439,16 @@ int upload_tables(fdql_agent *a) {
       int force = -1;
       if (const char *e = getenv("FDQL_GEMM_DENSE_SHAPE")) force = atoi(e);  // tuning hook: 0 = 128x128, 3 = 64x128
       for (auto &p : s.gemm) s.sub[gemm_pick_shape(p, force == GEMM_128x128)].probs.push_back(p);
+      // a launch with too few 64x128 tiles to give each SIMD a second wave runs on 64x64 tiles instead
+      {
+        static const int small_max = getenv("FDQL_SMALL_TILE_MAX") ? atoi(getenv("FDQL_SMALL_TILE_MAX")) : 1 << 30;
+        long long tiles = 0;
+        for (auto &p : s.sub[GEMM_64x128].probs) tiles += (long long)((p.M + 63) / 64) * ((p.N + 127) / 128) * (p.ksplit > 1 ? p.ksplit : 1);
+        if (tiles > 0 && tiles <= small_max) {
+          for (auto &p : s.sub[GEMM_64x128].probs) s.sub[GEMM_64x64].probs.push_back(p);
+          s.sub[GEMM_64x128].probs.clear();
+        }
+      }
       for (auto &sub : s.sub) total += pad(sub.probs.size() * sizeof(GemmProblem));
     }
     if (s.kind == ST_SKINNY_WGRAD) total += pad(s.swg.size() * sizeof(SkinnyWgradProblem));
@@ -959,7 +969,7 @@ int32_t fdql_agent_profile_update(fdql_agent_t *a, const fdql_batch_t *batch, co
     FDQL_HIP(hipEventRecord(ev[i + 1], s));
   }
   FDQL_HIP(hipStreamSynchronize(s));
-  static const char *shape_names[GEMM_NSHAPES] = {"128x128", "128x32", "32x128", "64x128", "64x128dual"};
+  static const char *shape_names[GEMM_NSHAPES] = {"128x128", "128x32", "32x128", "64x128", "64x128dual", "64x64"};
   int32_t cnt = 0;
   for (size_t i = 0; i < n && cnt < cap; ++i, ++cnt) {
     float ms = 0;

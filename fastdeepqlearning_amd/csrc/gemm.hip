@@ -33,6 +33,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //                 196 tiles of 128x128 on 256 CUs; halving the tile doubles the workgroups)
 // The narrow shapes waste MFMA lanes on padding but those problems are bandwidth-bound: what
 // matters is that they stream their big operand through the same coalesced LDS staging.
+#ifndef FDQL_DUAL_TN
+#define FDQL_DUAL_TN 1   // dual-output tiles: 64 x (64 * FDQL_DUAL_TN)
+#endif
 template <int SHAPE> struct TileCfg;
 template <> struct TileCfg<GEMM_128x128> { static constexpr int WM = 2, WN = 2, TM = 2, TN = 2; static constexpr bool DUAL = false; };
 template <> struct TileCfg<GEMM_128x32> { static constexpr int WM = 4, WN = 1, TM = 1, TN = 1; static constexpr bool DUAL = false; };
@@ -41,7 +44,10 @@ template <> struct TileCfg<GEMM_64x128> { static constexpr int WM = 2, WN = 2, T
 // 64x128 tiles, two outputs: C = f(sum over segments <= emit_seg), C2 = f(sum over all segments) -
 // critic layer 0 of q(s, a) and q(s, pi) in one pass over s.Ws
 //   (no second accumulator: the tile is stored, the tail segments are added, the tile is stored again)
-template <> struct TileCfg<GEMM_64x128_DUAL> { static constexpr int WM = 2, WN = 2, TM = 1, TN = 2; static constexpr bool DUAL = true; };
+// 64x64: for launches with too few 64x128 tiles to give every SIMD more than one wave (a single network's
+// layer at 12.5 k rows is 392 tiles on 256 CUs): twice the workgroups, one 32x32 MFMA tile per wave
+template <> struct TileCfg<GEMM_64x64> { static constexpr int WM = 2, WN = 2, TM = 1, TN = 1; static constexpr bool DUAL = false; };
+template <> struct TileCfg<GEMM_64x128_DUAL> { static constexpr int WM = 2, WN = 2, TM = 1, TN = FDQL_DUAL_TN; static constexpr bool DUAL = true; };
 
 // Pointers that come out of the problem tables are generic to the compiler, which would emit
 // FLAT loads: those also count on lgkmcnt, so the `s_waitcnt lgkmcnt(0)` in front of the MFMAs
@@ -509,8 +515,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_grouped(const GemmProb
 }
 
 static void shape_dims(int shape, int &bm, int &bn) {
-  bm = shape == GEMM_32x128 ? 32 : ((shape == GEMM_64x128 || shape == GEMM_64x128_DUAL) ? 64 : 128);
-  bn = shape == GEMM_128x32 ? 32 : 128;
+  bm = shape == GEMM_32x128 ? 32 : ((shape == GEMM_64x128 || shape == GEMM_64x128_DUAL || shape == GEMM_64x64) ? 64 : 128);
+  bn = shape == GEMM_128x32 ? 32 : (shape == GEMM_64x64 ? 64 : (shape == GEMM_64x128_DUAL ? 64 * FDQL_DUAL_TN : 128));
 }
 
 int gemm_finalize(GemmProblem *probs, int nprob, int shape) {
@@ -583,6 +589,7 @@ hipError_t gemm_launch(const GemmProblem *probs_dev, int nprob, int total_blocks
   else if (shape == GEMM_128x32) launch_shape<GEMM_128x32>(probs_dev, nprob, total_blocks, v, stream);
   else if (shape == GEMM_64x128) launch_shape<GEMM_64x128>(probs_dev, nprob, total_blocks, v, stream);
   else if (shape == GEMM_64x128_DUAL) launch_shape<GEMM_64x128_DUAL>(probs_dev, nprob, total_blocks, v, stream);
+  else if (shape == GEMM_64x64) launch_shape<GEMM_64x64>(probs_dev, nprob, total_blocks, v, stream);
   else launch_shape<GEMM_32x128>(probs_dev, nprob, total_blocks, v, stream);
   return hipGetLastError();
 }
