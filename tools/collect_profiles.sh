@@ -5,6 +5,7 @@
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_new
+rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # 1. bench line (N=1) and its rocprofv3 kernel stats (same command)

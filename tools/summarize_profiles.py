@@ -10,8 +10,8 @@ out = sys.argv[1]
 
 
 def counter_rows(sub):
-    f = glob.glob(os.path.join(out, sub, "**", "*_counter_collection.csv"), recursive=True)
-    return list(csv.DictReader(open(f[0]))) if f else []
+    f = sorted(glob.glob(os.path.join(out, sub, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    return list(csv.DictReader(open(f[-1]))) if f else []   # newest run (gpurun merges runs into one directory)
 
 
 def per_kernel(rows, counter):
@@ -43,8 +43,16 @@ for key in fetch:
     t[1] += wr * fetch[key][1]
     t[2] += fetch[key][1]
 open(os.path.join(out, "hbm_traffic_pmc.txt"), "w").write("\n".join(lines) + "\n")
-# dominant kernel = the 64x128 instantiation of the grouped GEMM
-dom = [k for k in tot if "k_gemm_grouped<3" in k]
+# dominant kernel = the tile-shape instantiation bench.py names in its roofline object
+shape_id = {"128x128": 0, "128x32": 1, "32x128": 2, "64x128": 3, "64x128dual": 4, "64x64": 5}
+dom_shape = "64x64"
+try:
+    for line in open(os.path.join(out, "bench_n1.json")):
+        if line.startswith("{"):
+            dom_shape = json.loads(line)["roofline"]["kernel"].split("<")[1].split(" ")[0]
+except (OSError, KeyError, IndexError, ValueError):
+    pass
+dom = [k for k in tot if f"k_gemm_grouped<{shape_id[dom_shape]}," in k]
 if dom:
     t = tot[dom[0]]
     json.dump({"kernel": dom[0], "dispatches_measured": t[2], "hbm_read_MB_per_launch": t[0] / t[2],
@@ -52,9 +60,9 @@ if dom:
                "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE doubled (gfx950)",
                "workload": "config 2, T=50, B=256"}, open(os.path.join(out, "dominant_kernel_traffic.json"), "w"), indent=1)
 # kernel stats csv of the bench run
-st = glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True)
+st = sorted(glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
 if st:
-    rows = list(csv.DictReader(open(st[0])))
+    rows = list(csv.DictReader(open(st[-1])))
     with open(os.path.join(out, "rocprofv3_kernel_stats_bench.csv"), "w") as f:
         w = csv.DictWriter(f, fieldnames=rows[0].keys())
         w.writeheader()
