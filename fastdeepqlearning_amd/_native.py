@@ -11,7 +11,8 @@ import os
 import torch  # noqa: F401  (must precede loading the HIP library; see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfdql_hip.so")
+# FDQL_LIB_PATH: load another build of the same library (A/B runs of kernel variants on one GPU box)
+LIB_PATH = os.environ.get("FDQL_LIB_PATH") or os.path.join(_HERE, "libfdql_hip.so")
 
 FDQL_OK, FDQL_EINVAL, FDQL_EHIP, FDQL_EOVERSAMPLE, FDQL_ESTATE, FDQL_ENOMEM = 0, -1, -2, -3, -4, -5
 PHASE_ALL, PHASE_GRAD, PHASE_APPLY = 0, 1, 2

@@ -33,21 +33,24 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //                 196 tiles of 128x128 on 256 CUs; halving the tile doubles the workgroups)
 // The narrow shapes waste MFMA lanes on padding but those problems are bandwidth-bound: what
 // matters is that they stream their big operand through the same coalesced LDS staging.
+#ifndef FDQL_NARROW_MINB
+#define FDQL_NARROW_MINB 6   // occupancy target of the narrow (bandwidth-bound) shapes: 72 VGPR, 7 waves/SIMD (92 / 5 without)
+#endif
 #ifndef FDQL_DUAL_TN
 #define FDQL_DUAL_TN 1   // dual-output tiles: 64 x (64 * FDQL_DUAL_TN)
 #endif
 template <int SHAPE> struct TileCfg;
-template <> struct TileCfg<GEMM_128x128> { static constexpr int WM = 2, WN = 2, TM = 2, TN = 2; static constexpr bool DUAL = false; };
-template <> struct TileCfg<GEMM_128x32> { static constexpr int WM = 4, WN = 1, TM = 1, TN = 1; static constexpr bool DUAL = false; };
-template <> struct TileCfg<GEMM_32x128> { static constexpr int WM = 1, WN = 4, TM = 1, TN = 1; static constexpr bool DUAL = false; };
-template <> struct TileCfg<GEMM_64x128> { static constexpr int WM = 2, WN = 2, TM = 1, TN = 2; static constexpr bool DUAL = false; };
+template <> struct TileCfg<GEMM_128x128> { static constexpr int WM = 2, WN = 2, TM = 2, TN = 2; static constexpr bool DUAL = false; static constexpr int MINB = 2; };
+template <> struct TileCfg<GEMM_128x32> { static constexpr int WM = 4, WN = 1, TM = 1, TN = 1; static constexpr bool DUAL = false; static constexpr int MINB = FDQL_NARROW_MINB; };
+template <> struct TileCfg<GEMM_32x128> { static constexpr int WM = 1, WN = 4, TM = 1, TN = 1; static constexpr bool DUAL = false; static constexpr int MINB = FDQL_NARROW_MINB; };
+template <> struct TileCfg<GEMM_64x128> { static constexpr int WM = 2, WN = 2, TM = 1, TN = 2; static constexpr bool DUAL = false; static constexpr int MINB = 2; };
 // 64x128 tiles, two outputs: C = f(sum over segments <= emit_seg), C2 = f(sum over all segments) -
 // critic layer 0 of q(s, a) and q(s, pi) in one pass over s.Ws
 //   (no second accumulator: the tile is stored, the tail segments are added, the tile is stored again)
 // 64x64: for launches with too few 64x128 tiles to give every SIMD more than one wave (a single network's
 // layer at 12.5 k rows is 392 tiles on 256 CUs): twice the workgroups, one 32x32 MFMA tile per wave
-template <> struct TileCfg<GEMM_64x64> { static constexpr int WM = 2, WN = 2, TM = 1, TN = 1; static constexpr bool DUAL = false; };
-template <> struct TileCfg<GEMM_64x128_DUAL> { static constexpr int WM = 2, WN = 2, TM = 1, TN = FDQL_DUAL_TN; static constexpr bool DUAL = true; };
+template <> struct TileCfg<GEMM_64x64> { static constexpr int WM = 2, WN = 2, TM = 1, TN = 1; static constexpr bool DUAL = false; static constexpr int MINB = 2; };
+template <> struct TileCfg<GEMM_64x128_DUAL> { static constexpr int WM = 2, WN = 2, TM = 1, TN = FDQL_DUAL_TN; static constexpr bool DUAL = true; static constexpr int MINB = 2; };
 
 // Pointers that come out of the problem tables are generic to the compiler, which would emit
 // FLAT loads: those also count on lgkmcnt, so the `s_waitcnt lgkmcnt(0)` in front of the MFMAs
@@ -275,7 +278,7 @@ __device__ __forceinline__ void frag_ready(float (&f)[T]) {
 }
 
 template <int SHAPE, int BK, int PIPE>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_grouped(const GemmProblem *__restrict__ probs, int nprob) {
+__global__ __launch_bounds__(GEMM_THREADS, TileCfg<SHAPE>::MINB) void k_gemm_grouped(const GemmProblem *__restrict__ probs, int nprob) {
   using Cfg = TileCfg<SHAPE>;
   constexpr int BM = Cfg::WM * Cfg::TM * 32, BN = Cfg::WN * Cfg::TN * 32;
   constexpr int PA = BM + 4, PB = BN + 4;
