@@ -114,6 +114,7 @@ SIGNATURES = {
     "fdql_agent_stats": (C.c_int, [_vp, C.POINTER(AgentStats)]),
     "fdql_agent_profile_update": (_i32, [_vp, C.POINTER(Batch), _vp, _vp, _u64, C.POINTER(KernelTime), _i32, _vp]),
     "fdql_debug_set_gemm_variant": (C.c_int, [_i32]),
+    "fdql_debug_set_gemm_dense_shape": (C.c_int, [_i32]),
     "fdql_test_gemm": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32,
                                  _i32, _vp]),
 }

@@ -383,7 +383,7 @@ struct Builder {
       p.ksplit = S;
       p.split_stride = P;
       // narrow problems (other tile shapes = other launches) are pooled in one stage at the end
-      (gemm_pick_shape(p, false) == GEMM_64x128 || gemm_pick_shape(p, false) == GEMM_128x128 ? gs : narrow).gemm.push_back(p);
+      (gemm_shape_is_dense(gemm_pick_shape(p, gemm_dense_shape())) ? gs : narrow).gemm.push_back(p);
     };
     auto bias_w = [&](const float *dOut, int ldo, int nout, const float *cs, float *dst) {
       SkinnyWgradProblem p;
@@ -436,19 +436,7 @@ int upload_tables(fdql_agent *a) {
   for (Stage &s : a->stages) {
     if (s.kind == ST_GEMM) {
       for (auto &sub : s.sub) sub.probs.clear();
-      int force = -1;
-      if (const char *e = getenv("FDQL_GEMM_DENSE_SHAPE")) force = atoi(e);  // tuning hook: 0 = 128x128, 3 = 64x128
-      for (auto &p : s.gemm) s.sub[gemm_pick_shape(p, force == GEMM_128x128)].probs.push_back(p);
-      // a launch with too few 64x128 tiles to give each SIMD a second wave runs on 64x64 tiles instead
-      {
-        static const int small_max = getenv("FDQL_SMALL_TILE_MAX") ? atoi(getenv("FDQL_SMALL_TILE_MAX")) : 1 << 30;
-        long long tiles = 0;
-        for (auto &p : s.sub[GEMM_64x128].probs) tiles += (long long)((p.M + 63) / 64) * ((p.N + 127) / 128) * (p.ksplit > 1 ? p.ksplit : 1);
-        if (tiles > 0 && tiles <= small_max) {
-          for (auto &p : s.sub[GEMM_64x128].probs) s.sub[GEMM_64x64].probs.push_back(p);
-          s.sub[GEMM_64x128].probs.clear();
-        }
-      }
+      for (auto &p : s.gemm) s.sub[gemm_pick_shape(p, gemm_dense_shape())].probs.push_back(p);
       for (auto &sub : s.sub) total += pad(sub.probs.size() * sizeof(GemmProblem));
     }
     if (s.kind == ST_SKINNY_WGRAD) total += pad(s.swg.size() * sizeof(SkinnyWgradProblem));
@@ -1135,6 +1123,12 @@ int fdql_debug_set_gemm_variant(int32_t variant) {
   return 0;
 }
 
+int fdql_debug_set_gemm_dense_shape(int32_t shape) {
+  FDQL_REQUIRE(gemm_shape_is_dense(shape), "dense shape must be 0 (128x128), 3 (64x128) or 5 (64x64)");
+  gemm_set_dense_shape(shape);
+  return 0;
+}
+
 int fdql_test_gemm(const float *A, int32_t lda, int32_t a_kc, const float *B, int32_t ldb, int32_t b_kc,
                    const float *bias, float *C, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t epilogue,
                    const float *ref, int32_t ldref, int32_t ksplit, void *stream) {
@@ -1145,7 +1139,7 @@ int fdql_test_gemm(const float *A, int32_t lda, int32_t a_kc, const float *B, in
   p.bias = bias; p.epi = epilogue; p.ref = ref; p.ldref = ldref;
   p.nseg = 1;
   p.seg[0].A = A; p.seg[0].lda = lda; p.seg[0].a_kc = a_kc; p.seg[0].B = B; p.seg[0].ldb = ldb; p.seg[0].b_kc = b_kc; p.seg[0].K = K;
-  const int shape = gemm_pick_shape(p, false);
+  const int shape = gemm_pick_shape(p, gemm_dense_shape());
   const int blocks = gemm_finalize(&p, 1, shape);
   GemmProblem *dev = nullptr;
   FDQL_HIP(hipMalloc(&dev, sizeof(p)));

@@ -68,7 +68,10 @@ struct GemmProblem {
 
 // Fills tiles_* / tile_start for a launch group; returns the total number of blocks.
 int gemm_finalize(GemmProblem *probs, int nprob, int shape);
-int gemm_pick_shape(const GemmProblem &p, bool prefer_128);
+void gemm_set_dense_shape(int shape);
+int gemm_dense_shape();                         // tile shape of the dense problems (FDQL_GEMM_DENSE_SHAPE)
+int gemm_pick_shape(const GemmProblem &p, int dense_shape);
+bool gemm_shape_is_dense(int shape);
 double gemm_flops(const GemmProblem &p);
 double gemm_bytes(const GemmProblem &p);
 // probs_dev: device copy of the finalized group (all problems of one tile shape).

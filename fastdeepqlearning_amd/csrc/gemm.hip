@@ -542,13 +542,25 @@ int gemm_finalize(GemmProblem *probs, int nprob, int shape) {
 // more, smaller workgroups (5 per CU at 92 VGPRs / 25.6 KB LDS) hide the per-chunk load latency
 // better than the bigger tile's higher MFMA:LDS ratio helps.  `prefer_128` keeps the big tile
 // selectable for experiments (FDQL_GEMM_DENSE_SHAPE).
-int gemm_pick_shape(const GemmProblem &p, bool prefer_128) {
+static int g_dense_shape = -1;
+void gemm_set_dense_shape(int shape) { g_dense_shape = shape; }
+int gemm_dense_shape() {
+  if (g_dense_shape < 0) {
+    const char *e = getenv("FDQL_GEMM_DENSE_SHAPE");   // tuning hook: 0 = 128x128, 3 = 64x128, 5 = 64x64 (default)
+    const int v = e ? atoi(e) : (int)GEMM_64x64;
+    g_dense_shape = (v == GEMM_128x128 || v == GEMM_64x128 || v == GEMM_64x64) ? v : (int)GEMM_64x64;
+  }
+  return g_dense_shape;
+}
+
+int gemm_pick_shape(const GemmProblem &p, int dense_shape) {
   if (p.emit_seg >= 0) return GEMM_64x128_DUAL;
   if (p.N <= 32) return GEMM_128x32;
   if (p.M <= 32 && !p.colsum) return GEMM_32x128;
-  if (prefer_128 || p.M <= 64) return GEMM_128x128;
-  return GEMM_64x128;
+  return dense_shape;
 }
+
+bool gemm_shape_is_dense(int shape) { return shape == GEMM_128x128 || shape == GEMM_64x128 || shape == GEMM_64x64; }
 
 double gemm_flops(const GemmProblem &p) {
   double k = 0;

@@ -302,6 +302,9 @@ int fdql_test_gemm(const float *A, int32_t lda, int32_t a_kc, const float *B, in
 
 /* Tuning hook: select the K-chunk / pipelining build of the GEMM kernel (0..3); affects speed only. */
 int fdql_debug_set_gemm_variant(int32_t variant);
+/* Tuning / test hook: tile shape of the dense problems: 5 = 64x64 (default), 3 = 64x128, 0 = 128x128.
+ * Applies to plans built afterwards and to fdql_test_gemm. */
+int fdql_debug_set_gemm_dense_shape(int32_t shape);
 
 #ifdef __cplusplus
 }

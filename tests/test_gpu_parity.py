@@ -38,9 +38,11 @@ def dev():
 @pytest.mark.parametrize("M,N,K", [(128, 128, 16), (256, 256, 256), (200, 70, 33), (1000, 262, 258), (64, 6, 300),
                                    (513, 129, 17)])
 @pytest.mark.parametrize("form", ["nt", "nn", "tn"])
-def test_gemm_forms(dev, M, N, K, form):
+@pytest.mark.parametrize("dense", [5, 3, 0])     # 64x64 (default), 64x128, 128x128 tiles
+def test_gemm_forms(dev, M, N, K, form, dense):
     from fastdeepqlearning_amd import _native as nat
     lib = nat.load()
+    nat.check(lib.fdql_debug_set_gemm_dense_shape(dense))
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
     A = torch.randn(M, K, generator=g)
     Bm = torch.randn(K, N, generator=g)
@@ -59,6 +61,7 @@ def test_gemm_forms(dev, M, N, K, form):
     c_d = torch.full((M, N), float("nan"), device=dev)
     nat.check(lib.fdql_test_gemm(nat.ptr(a_d), lda, akc, nat.ptr(b_d), ldb, bkc, nat.ptr(bias_d), nat.ptr(c_d), N,
                                  M, N, K, 0, None, 0, 1, nat.current_stream()))
+    nat.check(lib.fdql_debug_set_gemm_dense_shape(5))
     assert rel_err(c_d, ref) < 2e-6
 
 
