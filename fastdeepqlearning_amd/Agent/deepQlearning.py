@@ -42,15 +42,18 @@ def native_config_from_conf(conf):
         act = int(conf.action_space.n)
     else:
         act = int(conf.action_space.shape[-1])
-    if getattr(conf, "use_bootstrap_minibatch_nstep", False):
-        raise NotImplementedError("use_bootstrap_minibatch_nstep is off by default in the reference and not built")
+    boot = bool(getattr(conf, "use_bootstrap_minibatch_nstep", False))
+    if boot and (conf.use_distributional_sac or not conf.use_nStep_lowerbounds):
+        # the reference multiplies `None` in these combinations (deepQlearning.py:227; the term only exists in
+        # SoftActorCritic.q_loss under use_nStep_lowerbounds, soft_actor_critic.py:92-102)
+        raise ValueError("use_bootstrap_minibatch_nstep needs use_distributional_sac=False and use_nStep_lowerbounds=True")
     return make_config(obs, act, int(conf.temporal_len), int(conf.batch_size), goal_dim=goal, discrete=bool(conf.discrete),
                        n_critics=int(conf.num_critics), n_quantiles=int(conf.num_q_predictions),
                        latent=int(conf.latent_state_dim), enc_features=int(ec.hidden_features),
                        enc_hidden=tuple(ec.obs_1d_hidden_dims), joint_hidden=tuple(ec.joint_hidden_dims),
                        pi_hidden=tuple(conf.pi_hidden_dims), critic_hidden=tuple(conf.critic_hidden_dims),
                        distributional=bool(conf.use_distributional_sac), use_lowerbound=bool(conf.use_nStep_lowerbounds),
-                       use_max_entropy=bool(conf.use_max_entropy_q), hard_updates=bool(conf.use_hard_updates),
+                       use_max_entropy=bool(conf.use_max_entropy_q), bootstrap_nstep=boot, hard_updates=bool(conf.use_hard_updates),
                        keep_frozen_copy=True, world_size=int(getattr(conf, "world_size", 1) or 1),
                        gamma=float(conf.gamma), tau=float(conf.tau), lr=float(conf.learning_rate),
                        init_log_alpha=float(conf.init_log_alpha), drop_frac=float(conf.top_quantiles_to_drop))

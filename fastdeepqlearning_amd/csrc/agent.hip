@@ -265,7 +265,7 @@ void carve(fdql_agent *a) {
   a->alloc("cs.dstate", ((M + 63) / 64) * c.latent);
   a->alloc("cs.denc", ((M + 63) / 64) * c.enc_features);
   a->alloc("dpi_part", (int64_t)c.n_critics * M * c.act_dim);
-  a->alloc("loss_partials", (int64_t)loss_blocks((int)M, 256) * LOSS_NPART + (int64_t)M * LOSS_NPART);
+  a->alloc("loss_partials", (int64_t)loss_blocks((int)M, 256) * LOSS_NPART + (int64_t)M * LOSS_NPART + LOSS_NPART);
   a->alloc("slabs", (int64_t)a->nsplit * a->n_train);
 }
 
@@ -631,7 +631,18 @@ int build_plan(fdql_agent *a) {
     la.q_loss = a->buf("q_loss"); la.pi_loss = a->buf("pi_loss"); la.alpha_loss = a->buf("alpha_loss");
     la.partials = a->buf("loss_partials");
     b.func_stage("loss", [=](hipStream_t s) { return loss_launch(la, s); });
-    const int nblocks = loss_blocks(M, G);
+    int nblocks = loss_blocks(M, G);
+    if (c.bootstrap_nstep) {   // soft_actor_critic.py:102-132: its loss value rides as one more partial row
+      BootArgs ba;
+      memset(&ba, 0, sizeof(ba));
+      ba.T = a->T; ba.B = B; ba.Nq = Nq; ba.gamma = (float)c.gamma;
+      ba.scale = (float)(1.0 / ((double)B * Nq * (c.world_size > 0 ? c.world_size : 1) * a->T));
+      ba.reward = x.reward; ba.task_done = x.task_done; ba.contig = a->buf("is_contiguous");
+      ba.td_target = a->buf("td_target"); ba.q_pred = a->buf("q_pred"); ba.dz = a->buf("dz");
+      ba.partial_row = a->buf("loss_partials") + (int64_t)nblocks * LOSS_NPART;
+      b.func_stage("boot_lowerbound", [=](hipStream_t s) { return boot_lowerbound_launch(ba, s); });
+      ++nblocks;
+    }
     float *scal = a->buf("scalars");
     float *dla = a->buf("slabs") + a->log_alpha_off;
     const float *parts = la.partials;
@@ -823,6 +834,9 @@ int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {
                    c.n_joint_hidden <= FDQL_MAX_HIDDEN && c.n_pi_hidden >= 0 && c.n_pi_hidden <= FDQL_MAX_HIDDEN &&
                    c.n_critic_hidden >= 0 && c.n_critic_hidden <= FDQL_MAX_HIDDEN, "bad hidden layer counts");
   FDQL_REQUIRE(c.latent > 0 && c.enc_features > 0, "bad latent dims");
+  FDQL_REQUIRE(!c.bootstrap_nstep || (!c.distributional && c.use_lowerbound),
+               "bootstrap_nstep needs distributional == 0 and use_lowerbound == 1 (the reference forms the term only in "
+               "SoftActorCritic.q_loss under use_nStep_lowerbounds)");
   fdql_agent *a = new fdql_agent();
   a->cfg = c;
   a->T = c.T; a->B = c.B; a->N = c.T * c.B; a->M = (c.T - 1) * c.B; a->A = c.act_dim; a->L = c.latent;

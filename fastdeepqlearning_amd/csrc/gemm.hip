@@ -579,8 +579,6 @@ static void launch_shape(const GemmProblem *probs_dev, int nprob, int total_bloc
   const dim3 g(total_blocks), b(GEMM_THREADS);
   switch (variant) {
     case 1: hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 16, 1>), g, b, 0, stream, probs_dev, nprob); break;
-    case 2: hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 32, 0>), g, b, 0, stream, probs_dev, nprob); break;
-    case 3: hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 32, 1>), g, b, 0, stream, probs_dev, nprob); break;
     case 4: hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 8, 1>), g, b, 0, stream, probs_dev, nprob); break;
     default: hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 16, 0>), g, b, 0, stream, probs_dev, nprob); break;
   }

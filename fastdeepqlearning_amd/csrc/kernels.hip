@@ -608,6 +608,46 @@ __global__ __launch_bounds__(256) void k_loss_finish(const float *__restrict__ p
   }
 }
 
+// window-long n-step lower bound on q(t=0): one thread per window walks its T-1 transitions
+// (B threads, a few hundred floats each: latency-bound, off the critical path of nothing else)
+__global__ __launch_bounds__(256) void k_boot_lowerbound(BootArgs a) {
+  __shared__ float red[256];
+  float local = 0.f;
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < a.B; b += gridDim.x * blockDim.x) {
+    float ret = 0.f, valid = 1.f, gp = 1.f;
+    for (int t = 0; t < a.T - 1; ++t) {
+      const int m = t * a.B + b;
+      ret += a.reward[m + a.B] * gp;                        // next_xp["reward"] * gamma^t
+      gp *= a.gamma;
+      valid *= (a.task_done[m + a.B] == 0.f ? 1.f : 0.f);   // next_xp["mask"].prod(0)
+      valid *= a.contig[m];                                 // xp["is_contiguous"].prod(0)
+    }
+    const float bound = ret + gp * a.td_target[(long long)(a.T - 2) * a.B + b];   // gp == gamma^(T-1); SAC: Nt == 1
+    for (int j = 0; j < a.Nq; ++j) {
+      const float x = bound - a.q_pred[(long long)b * a.Nq + j];
+      if (x > 0.f && valid != 0.f) {
+        local += x;
+        a.dz[(long long)b * a.Nq + j] -= a.scale;
+      }
+    }
+  }
+  red[threadIdx.x] = local;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    for (int k = 0; k < LOSS_NPART; ++k) a.partial_row[k] = 0.f;
+    a.partial_row[0] = red[0] * a.scale;
+  }
+}
+
+hipError_t boot_lowerbound_launch(const BootArgs &a, hipStream_t s) {
+  hipLaunchKernelGGL(k_boot_lowerbound, dim3(1), dim3(256), 0, s, a);   // one block: the row is a plain store
+  return hipGetLastError();
+}
+
 hipError_t loss_finish_launch(const float *partials, int nblocks, int M, int Nq, const DevState *st, float *scalars,
                               float *dlog_alpha, hipStream_t s) {
   hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(256), 0, s, partials, nblocks, M, Nq, st, scalars, dlog_alpha);

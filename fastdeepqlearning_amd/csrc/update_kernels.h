@@ -91,6 +91,18 @@ hipError_t head_dgrad_launch(const HeadDgradProblem *dev, int n, int total_block
 hipError_t skinny_wgrad_launch_host(const SkinnyWgradProblem *host, const SkinnyWgradProblem *dev, int n,
                                     int total_blocks, hipStream_t s);
 hipError_t loss_launch(const LossArgs &a, hipStream_t s);
+// use_bootstrap_minibatch_nstep (soft_actor_critic.py:102-132, deepQlearning.py:226-228), SAC-min only:
+//   bound[b] = sum_t gamma^t r[t+1][b] + gamma^(T-1) td_target[T-2][b];
+//   term[b][j] = prod_t mask[t+1][b] * relu(bound[b] - q_pred[0][b][j]) * prod_t is_contiguous[t][b]
+// loss += mean_{b,j} term / (world * T); d loss / d q_pred[0] added into dz; loss value -> partial_row[0]
+struct BootArgs {
+  int T, B, Nq;
+  float gamma, scale;           // scale = 1 / (B * Nq * world_size * T)
+  const float *reward, *task_done, *contig, *td_target, *q_pred;
+  float *dz;
+  float *partial_row;           // [LOSS_NPART]
+};
+hipError_t boot_lowerbound_launch(const BootArgs &a, hipStream_t s);
 hipError_t loss_finish_launch(const float *partials, int nblocks, int M, int Nq, const DevState *st, float *scalars,
                               float *dlog_alpha, hipStream_t s);
 hipError_t reduce_slabs_launch(const float *slabs, int nslab, long long n, float *grads, hipStream_t s);

@@ -190,6 +190,9 @@ typedef struct {
   int32_t use_max_entropy;          /* conf.use_max_entropy_q                                */
   int32_t hard_updates;             /* conf.use_hard_updates                                 */
   int32_t keep_frozen_copy;         /* materialise critic_frozen (state_dict parity)         */
+  int32_t bootstrap_nstep;          /* conf.use_bootstrap_minibatch_nstep (soft_actor_critic.py:102-132,
+                                       deepQlearning.py:226-228): window-long n-step lower bound on
+                                       q(t=0); needs !distributional && use_lowerbound, as in the reference */
   /* batch geometry: this rank's [T, B, *] minibatch; loss is normalised by B*world_size    */
   int32_t T, B, world_size;
   /* hyper-parameters */

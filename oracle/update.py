@@ -55,6 +55,7 @@ class Spec:
     T: int = 50
     B: int = 256
     world_size: int = 1           # data-parallel ranks: loss is normalised by B * world_size
+    bootstrap: bool = False       # use_bootstrap_minibatch_nstep (SAC-min with lower bounds only)
 
     @property
     def enc_in(self):             # encoder.py:26-32
@@ -292,7 +293,17 @@ def losses(p, spec: Spec, xp, noise_target, noise_actor, alpha):
     alpha_loss = -(p["actor_critic.log_alpha"] * (spec.target_entropy - (-logp)).detach())
     w = contig.float()
     loss = ((q_loss + pi_loss + alpha_loss) * w).sum(0) / (w.sum(0) + 1e-4)   # :222-224
-    loss = loss.sum() / (loss.numel() * spec.world_size) / spec.T          # :225 (.mean over B), :249
+    loss = loss.sum() / (loss.numel() * spec.world_size)                   # :225 (.mean over B)
+    if spec.bootstrap:       # soft_actor_critic.py:102-132, deepQlearning.py:226-228
+        # discounted reward over the whole window + bootstrap from the last TD target: lower bound on q(t=0)
+        assert not spec.distributional and spec.lowerbound, "the reference only forms this term in SoftActorCritic.q_loss"
+        g_pow = spec.gamma ** torch.arange(spec.T - 1, dtype=q.dtype).view(-1, 1, 1)
+        mb_return = (xp["reward"][1:] * g_pow).sum(0)
+        mb_mask = mask[1:].to(q.dtype).prod(0)
+        boot = mb_mask * ((mb_return + (spec.gamma ** (spec.T - 1)) * td[-1]) - q[0]).relu()      # [B, Nq]
+        loss = loss + (boot * w.prod(0)).mean() / spec.world_size
+        aux["bootstrap_lowerbound"] = boot
+    loss = loss / spec.T                                                   # :249
     aux.update(state=state, next_action=a_n, next_log_pi=logp_n, next_z=z, td_target=td, q_pred=q,
                q_loss=q_loss, pi=pi, log_pi=logp, q_frozen=None, pi_loss=pi_loss, alpha_loss=alpha_loss,
                is_contiguous=w, qpi=qpi)

@@ -268,6 +268,7 @@ def make_conf(case):
     conf.use_nStep_lowerbounds = bool(case.get("lowerbound", True))
     conf.use_max_entropy_q = bool(case.get("max_entropy", True))
     conf.use_hard_updates = bool(case.get("hard_updates", False))
+    conf.use_bootstrap_minibatch_nstep = bool(case.get("bootstrap", False))
     conf.encoder_conf.hidden_features = case["enc_features"]
     conf.encoder_conf.obs_1d_hidden_dims = tuple(case["enc_hidden"])
     conf.encoder_conf.joint_hidden_dims = tuple(case["joint_hidden"])
@@ -288,12 +289,12 @@ def make_batch(case, seed):
         xp["action"] = g.uniform(-1, 1, (T, B, case["act"]))
     xp["reward"] = g.standard_normal((T, B, 1))
     xp["mc_return"] = 2.0 * g.standard_normal((T, B, 1))
-    xp["task_done"] = (g.rand(T, B, 1) < 0.12).astype(np.float64)
+    xp["task_done"] = (g.rand(T, B, 1) < case.get("p_done", 0.12)).astype(np.float64)
     step = np.zeros((T, B, 1))
     edone = np.zeros((T, B, 1))
     for b in range(B):
         s = g.randint(0, 40)
-        brk = g.randint(1, T) if g.rand() < 0.6 else -1
+        brk = g.randint(1, T) if g.rand() < case.get("p_break", 0.6) else -1
         for t in range(T):
             if t == brk:
                 s = 0
@@ -470,6 +471,9 @@ UPDATE_CASES = OrderedDict(
                  pi_hidden=(32,), critic_hidden=(32, 32), T=6, B=8, seed=3, distributional=False),
     tqc_discrete=dict(obs=6, act=4, discrete=True, C=3, Q=4, latent=32, enc_features=32, enc_hidden=(32,),
                       joint_hidden=(32,), pi_hidden=(32,), critic_hidden=(32, 32), T=5, B=8, seed=4),
+    sac_boot=dict(obs=3, act=2, C=2, Q=2, latent=32, enc_features=32, enc_hidden=(32,), joint_hidden=(32,),
+                  pi_hidden=(32,), critic_hidden=(32, 32), T=5, B=24, seed=6, distributional=False, bootstrap=True,
+                  p_done=0.02, p_break=0.1),
     tqc_nolb=dict(obs=5, act=3, C=3, Q=4, latent=32, enc_features=32, enc_hidden=(32,), joint_hidden=(32,),
                   pi_hidden=(32,), critic_hidden=(32, 32), T=3, B=4, seed=5, lowerbound=False, max_entropy=False),
 )
@@ -483,9 +487,11 @@ def main():
         golden_nstep()
     if not only or "her" in only:
         golden_her()
-    if not only or "update" in only:
+    picked = {a.split(":", 1)[1] for a in only if a.startswith("update:")}   # e.g. `update:sac_boot`
+    if not only or "update" in only or picked:
         for name, case in UPDATE_CASES.items():
-            golden_update("update_" + name, case)
+            if not picked or name in picked:
+                golden_update("update_" + name, case)
     if not only or "act" in only:
         for name in ACT_CASES:
             golden_act("act_" + name, UPDATE_CASES[name])

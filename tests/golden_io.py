@@ -28,8 +28,9 @@ def spec_from_case(case, hyper=None):
                 enc_hidden=g("enc_hidden"), joint_hidden=g("joint_hidden"), pi_hidden=g("pi_hidden"),
                 critic_hidden=g("critic_hidden"), distributional=bool(g("distributional", True)),
                 lowerbound=bool(g("lowerbound", True)), max_entropy=bool(g("max_entropy", True)),
-                hard_updates=bool(g("hard_updates", False)), T=g("T"), B=g("B"))
+                hard_updates=bool(g("hard_updates", False)), T=g("T"), B=g("B"),
+                bootstrap=bool(g("bootstrap", False)))
 
 
-UPDATE_CASES = ["tqc_small", "tqc_c5q2", "tqc_goal", "sac_min", "tqc_discrete", "tqc_nolb"]
+UPDATE_CASES = ["tqc_small", "tqc_c5q2", "tqc_goal", "sac_min", "tqc_discrete", "tqc_nolb", "sac_boot"]
 ACT_CASES = ["tqc_c5q2", "tqc_goal", "tqc_discrete"]

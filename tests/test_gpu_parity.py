@@ -282,7 +282,7 @@ def _agent_for(spec, dev, **kw):
                       critic_hidden=spec.critic_hidden, distributional=spec.distributional,
                       use_lowerbound=spec.lowerbound, use_max_entropy=spec.max_entropy,
                       hard_updates=spec.hard_updates, gamma=spec.gamma, tau=spec.tau, lr=spec.lr,
-                      init_log_alpha=spec.init_log_alpha, drop_frac=spec.drop, **kw)
+                      init_log_alpha=spec.init_log_alpha, drop_frac=spec.drop, bootstrap_nstep=spec.bootstrap, **kw)
     return NativeAgent(cfg, dev)
 
 
@@ -347,7 +347,7 @@ def _check_step(rep, s, ag, spec, ref, before, alpha, log_alpha, lr_steps):
                 rep.bad.append((f"s{s}.after.{n}", frac, frac, 0.02))
 
 
-CONT_CASES = ["tqc_small", "tqc_c5q2", "tqc_goal", "sac_min", "tqc_nolb", "tqc_discrete"]
+CONT_CASES = ["tqc_small", "tqc_c5q2", "tqc_goal", "sac_min", "tqc_nolb", "tqc_discrete", "sac_boot"]
 
 
 @pytest.mark.parametrize("case", CONT_CASES)
@@ -415,6 +415,8 @@ def test_update_matches_oracle_config2(dev, T, B, hid):
     ("config4 dims (Humanoid obs 376, act 17, 5x25 quantiles)", dict(obs=376, act=17, C=5, Q=25, T=3, B=96)),
     ("config3 dims (obs 28 + goals 10, HER-style batch)", dict(obs=28, goal=10, act=6, C=5, Q=2, T=4, B=64)),
     ("config1 dims (Pendulum SAC-min, 2 critics)", dict(obs=3, act=1, C=2, Q=1, T=5, B=128, distributional=False)),
+    ("SAC-min + window-long bootstrap lower bound (use_bootstrap_minibatch_nstep), T=50",
+     dict(obs=3, act=1, C=2, Q=1, T=50, B=64, distributional=False, bootstrap=True)),
     ("config5 head (discrete SAC, 6 actions, Gumbel-softmax)", dict(obs=64, act=6, discrete=True, C=2, Q=5, T=4, B=128)),
     ("ragged sizes (B=7, odd widths 18/33/21: unaligned rows, partial tiles, M < one tile)",
      dict(obs=3, act=2, C=2, Q=3, T=3, B=7, critic_hidden=(33, 18), pi_hidden=(21,), enc_hidden=(18,), joint_hidden=(33,),
@@ -446,7 +448,7 @@ def test_update_matches_oracle_other_configs(dev, name, kw):
     A = spec.act
     xp = {"obs_1d": torch.randn(T, B, spec.obs, generator=g), "action": torch.rand(T, B, A, generator=g) * 2 - 1,
           "reward": torch.randn(T, B, 1, generator=g), "mc_return": torch.randn(T, B, 1, generator=g) * 2,
-          "task_done": (torch.rand(T, B, 1, generator=g) < 0.1).float(),
+          "task_done": (torch.rand(T, B, 1, generator=g) < (0.002 if spec.bootstrap else 0.1)).float(),
           "episode_step": (torch.arange(T).view(T, 1, 1) + torch.randint(0, 50, (1, B, 1), generator=g)).float()}
     if spec.discrete:
         xp["action"] = torch.randint(0, A, (T, B, 1), generator=g).float()
@@ -459,6 +461,8 @@ def test_update_matches_oracle_other_configs(dev, name, kw):
         nt, na = torch.rand(T - 1, B, A, generator=g), torch.rand(T - 1, B, A, generator=g)
     alpha, log_alpha = st.alpha, float(st.params["actor_critic.log_alpha"])
     loss, aux = oup.train_step(st, spec, xp, nt, na)
+    if spec.bootstrap:   # the window-long bound must actually bind somewhere, or the case tests nothing
+        assert int(((aux["bootstrap_lowerbound"] * aux["is_contiguous"].prod(0)) > 0).sum()) >= 8
     before = _snapshot(ag)
     ag.update({k: v.to(dev) for k, v in xp.items()}, nt.to(dev), na.to(dev))
     rep = Report("oracle:" + name)
