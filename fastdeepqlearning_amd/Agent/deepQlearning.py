@@ -53,7 +53,8 @@ def native_config_from_conf(conf):
                        enc_hidden=tuple(ec.obs_1d_hidden_dims), joint_hidden=tuple(ec.joint_hidden_dims),
                        pi_hidden=tuple(conf.pi_hidden_dims), critic_hidden=tuple(conf.critic_hidden_dims),
                        distributional=bool(conf.use_distributional_sac), use_lowerbound=bool(conf.use_nStep_lowerbounds),
-                       use_max_entropy=bool(conf.use_max_entropy_q), bootstrap_nstep=boot, hard_updates=bool(conf.use_hard_updates),
+                       use_max_entropy=bool(conf.use_max_entropy_q), bootstrap_nstep=boot,
+                       burn_in_steps=int(conf.temporal_len * ec.burn_in_portion) if getattr(ec, "use_burn_in", False) else 0, hard_updates=bool(conf.use_hard_updates),
                        keep_frozen_copy=True, world_size=int(getattr(conf, "world_size", 1) or 1),
                        gamma=float(conf.gamma), tau=float(conf.tau), lr=float(conf.learning_rate),
                        init_log_alpha=float(conf.init_log_alpha), drop_frac=float(conf.top_quantiles_to_drop))

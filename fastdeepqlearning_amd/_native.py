@@ -42,7 +42,7 @@ class AgentConfig(C.Structure):
         ("n_pi_hidden", C.c_int32), ("pi_hidden", C.c_int32 * MAX_HIDDEN),
         ("n_critic_hidden", C.c_int32), ("critic_hidden", C.c_int32 * MAX_HIDDEN),
         ("distributional", C.c_int32), ("use_lowerbound", C.c_int32), ("use_max_entropy", C.c_int32),
-        ("hard_updates", C.c_int32), ("keep_frozen_copy", C.c_int32), ("bootstrap_nstep", C.c_int32),
+        ("hard_updates", C.c_int32), ("keep_frozen_copy", C.c_int32), ("bootstrap_nstep", C.c_int32), ("burn_in_steps", C.c_int32),
         ("T", C.c_int32), ("B", C.c_int32), ("world_size", C.c_int32),
         ("gamma", C.c_double), ("tau", C.c_double), ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double),
         ("adam_eps", C.c_double), ("init_log_alpha", C.c_double), ("drop_frac", C.c_double),

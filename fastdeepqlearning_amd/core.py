@@ -140,7 +140,7 @@ def make_config(obs_dim, act_dim, T, B, goal_dim=0, discrete=False, n_critics=2,
                 enc_features=256, enc_hidden=(256,), joint_hidden=(256,), pi_hidden=(256,), critic_hidden=(256, 256),
                 distributional=True, use_lowerbound=True, use_max_entropy=True, hard_updates=False,
                 keep_frozen_copy=True, world_size=1, gamma=0.99, tau=5e-2, lr=3e-4, beta1=0.9, beta2=0.999,
-                adam_eps=1e-8, init_log_alpha=-2.0, drop_frac=0.2, bootstrap_nstep=False):
+                adam_eps=1e-8, init_log_alpha=-2.0, drop_frac=0.2, bootstrap_nstep=False, burn_in_steps=0):
     c = N.AgentConfig()
     c.obs_dim, c.goal_dim, c.act_dim, c.discrete = obs_dim, goal_dim, act_dim, int(discrete)
     c.n_critics, c.n_quantiles, c.latent, c.enc_features = n_critics, n_quantiles, latent, enc_features
@@ -156,6 +156,7 @@ def make_config(obs_dim, act_dim, T, B, goal_dim=0, discrete=False, n_critics=2,
     c.distributional, c.use_lowerbound, c.use_max_entropy = int(distributional), int(use_lowerbound), int(use_max_entropy)
     c.hard_updates, c.keep_frozen_copy = int(hard_updates), int(keep_frozen_copy)
     c.bootstrap_nstep = int(bootstrap_nstep)
+    c.burn_in_steps = int(burn_in_steps)
     c.T, c.B, c.world_size = T, B, world_size
     c.gamma, c.tau, c.lr, c.beta1, c.beta2, c.adam_eps = gamma, tau, lr, beta1, beta2, adam_eps
     c.init_log_alpha, c.drop_frac = init_log_alpha, drop_frac

@@ -546,7 +546,8 @@ int build_plan(fdql_agent *a) {
     float *w = a->buf("w"), *ic = a->buf("is_contiguous");
     const float *td = x.task_done, *es = x.episode_step;
     const int T = a->T;
-    b.func_stage("prep", [=](hipStream_t s) { return prep_launch(td, es, T, B, inv_gb, w, ic, s); });
+    const int burn = c.burn_in_steps;
+    b.func_stage("prep", [=](hipStream_t s) { return prep_launch(td, es, T, B, burn, inv_gb, w, ic, s); });
     if (c.discrete) {   // stored action index -> one-hot critic input (deepQlearning.py:206-210)
       const float *act = x.action;
       float *oh = a->buf("action_onehot");
@@ -834,6 +835,7 @@ int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {
                    c.n_joint_hidden <= FDQL_MAX_HIDDEN && c.n_pi_hidden >= 0 && c.n_pi_hidden <= FDQL_MAX_HIDDEN &&
                    c.n_critic_hidden >= 0 && c.n_critic_hidden <= FDQL_MAX_HIDDEN, "bad hidden layer counts");
   FDQL_REQUIRE(c.latent > 0 && c.enc_features > 0, "bad latent dims");
+  FDQL_REQUIRE(c.burn_in_steps >= 0 && c.burn_in_steps <= c.T - 1, "burn_in_steps outside [0, T-1]");
   FDQL_REQUIRE(!c.bootstrap_nstep || (!c.distributional && c.use_lowerbound),
                "bootstrap_nstep needs distributional == 0 and use_lowerbound == 1 (the reference forms the term only in "
                "SoftActorCritic.q_loss under use_nStep_lowerbounds)");

@@ -209,8 +209,8 @@ __device__ __forceinline__ float device_noise(uint64_t seed, uint32_t step, uint
 // ======================================================================================
 // block = 16 windows x 16 time lanes; consecutive threads -> consecutive b (coalesced rows)
 __global__ __launch_bounds__(256) void k_prep(const float *__restrict__ task_done, const float *__restrict__ episode_step,
-                                              int T, int B, float inv_global_batch, float *__restrict__ w,
-                                              float *__restrict__ contig) {
+                                              int T, int B, int burn_in, float inv_global_batch,
+                                              float *__restrict__ w, float *__restrict__ contig) {
   __shared__ float cnt[16][17];
   const int bl = threadIdx.x & 15, tl = threadIdx.x >> 4;
   const int b = blockIdx.x * 16 + bl;
@@ -218,7 +218,8 @@ __global__ __launch_bounds__(256) void k_prep(const float *__restrict__ task_don
   if (b < B) {
     for (int t = tl; t < T - 1; t += 16) {
       const int m = t * B + b;
-      const bool c = (episode_step[m + B] == episode_step[m] + 1.0f) && (task_done[m] == 0.f);
+      // deepQlearning.py:219-220: the first burn_in rows carry no loss
+      const bool c = t >= burn_in && (episode_step[m + B] == episode_step[m] + 1.0f) && (task_done[m] == 0.f);
       contig[m] = c ? 1.f : 0.f;
       c_local += c ? 1.f : 0.f;
     }
@@ -702,9 +703,9 @@ hipError_t adam_launch(const AdamArgs &a, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t prep_launch(const float *task_done, const float *episode_step, int T, int B, float inv_gb, float *w,
-                       float *contig, hipStream_t s) {
-  hipLaunchKernelGGL(k_prep, dim3((B + 15) / 16), dim3(256), 0, s, task_done, episode_step, T, B, inv_gb, w, contig);
+hipError_t prep_launch(const float *task_done, const float *episode_step, int T, int B, int burn_in, float inv_gb,
+                       float *w, float *contig, hipStream_t s) {
+  hipLaunchKernelGGL(k_prep, dim3((B + 15) / 16), dim3(256), 0, s, task_done, episode_step, T, B, burn_in, inv_gb, w, contig);
   return hipGetLastError();
 }
 

@@ -107,8 +107,8 @@ hipError_t loss_finish_launch(const float *partials, int nblocks, int M, int Nq,
                               float *dlog_alpha, hipStream_t s);
 hipError_t reduce_slabs_launch(const float *slabs, int nslab, long long n, float *grads, hipStream_t s);
 hipError_t adam_launch(const AdamArgs &a, hipStream_t s);
-hipError_t prep_launch(const float *task_done, const float *episode_step, int T, int B, float inv_gb, float *w,
-                       float *contig, hipStream_t s);
+hipError_t prep_launch(const float *task_done, const float *episode_step, int T, int B, int burn_in, float inv_gb,
+                       float *w, float *contig, hipStream_t s);
 hipError_t tick_alpha_launch(DevState *st, const float *log_alpha, hipStream_t s);
 hipError_t tick_adam_launch(DevState *st, double lr, double b1, double b2, hipStream_t s);
 hipError_t policy_fwd_launch(const PolicyFwdArgs &a0, const PolicyFwdArgs &a1, int nprob, int M, int A,

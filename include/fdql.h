@@ -193,6 +193,8 @@ typedef struct {
   int32_t bootstrap_nstep;          /* conf.use_bootstrap_minibatch_nstep (soft_actor_critic.py:102-132,
                                        deepQlearning.py:226-228): window-long n-step lower bound on
                                        q(t=0); needs !distributional && use_lowerbound, as in the reference */
+  int32_t burn_in_steps;            /* EncoderConf.use_burn_in: int(T * burn_in_portion) leading rows of
+                                       is_contiguous are zeroed (deepQlearning.py:219-220); 0 = off        */
   /* batch geometry: this rank's [T, B, *] minibatch; loss is normalised by B*world_size    */
   int32_t T, B, world_size;
   /* hyper-parameters */

@@ -56,6 +56,7 @@ class Spec:
     B: int = 256
     world_size: int = 1           # data-parallel ranks: loss is normalised by B * world_size
     bootstrap: bool = False       # use_bootstrap_minibatch_nstep (SAC-min with lower bounds only)
+    burn_in: int = 0              # int(T * burn_in_portion) when EncoderConf.use_burn_in, else 0
 
     @property
     def enc_in(self):             # encoder.py:26-32
@@ -292,6 +293,9 @@ def losses(p, spec: Spec, xp, noise_target, noise_actor, alpha):
     pi_loss = -(alpha * (-logp)) - qpi
     alpha_loss = -(p["actor_critic.log_alpha"] * (spec.target_entropy - (-logp)).detach())
     w = contig.float()
+    if spec.burn_in:                                                       # deepQlearning.py:219-220
+        w = w.clone()
+        w[:spec.burn_in] = 0
     loss = ((q_loss + pi_loss + alpha_loss) * w).sum(0) / (w.sum(0) + 1e-4)   # :222-224
     loss = loss.sum() / (loss.numel() * spec.world_size)                   # :225 (.mean over B)
     if spec.bootstrap:       # soft_actor_critic.py:102-132, deepQlearning.py:226-228

@@ -269,6 +269,9 @@ def make_conf(case):
     conf.use_max_entropy_q = bool(case.get("max_entropy", True))
     conf.use_hard_updates = bool(case.get("hard_updates", False))
     conf.use_bootstrap_minibatch_nstep = bool(case.get("bootstrap", False))
+    if case.get("burn_in_portion", 0):
+        conf.encoder_conf.use_burn_in = True
+        conf.encoder_conf.burn_in_portion = float(case["burn_in_portion"])
     conf.encoder_conf.hidden_features = case["enc_features"]
     conf.encoder_conf.obs_1d_hidden_dims = tuple(case["enc_hidden"])
     conf.encoder_conf.joint_hidden_dims = tuple(case["joint_hidden"])
@@ -474,6 +477,8 @@ UPDATE_CASES = OrderedDict(
     sac_boot=dict(obs=3, act=2, C=2, Q=2, latent=32, enc_features=32, enc_hidden=(32,), joint_hidden=(32,),
                   pi_hidden=(32,), critic_hidden=(32, 32), T=5, B=24, seed=6, distributional=False, bootstrap=True,
                   p_done=0.02, p_break=0.1),
+    tqc_burn=dict(obs=5, act=3, C=3, Q=4, latent=32, enc_features=32, enc_hidden=(32,), joint_hidden=(32,),
+                  pi_hidden=(32,), critic_hidden=(32, 32), T=6, B=8, seed=7, burn_in_portion=0.4, p_break=0.3),
     tqc_nolb=dict(obs=5, act=3, C=3, Q=4, latent=32, enc_features=32, enc_hidden=(32,), joint_hidden=(32,),
                   pi_hidden=(32,), critic_hidden=(32, 32), T=3, B=4, seed=5, lowerbound=False, max_entropy=False),
 )

@@ -282,7 +282,8 @@ def _agent_for(spec, dev, **kw):
                       critic_hidden=spec.critic_hidden, distributional=spec.distributional,
                       use_lowerbound=spec.lowerbound, use_max_entropy=spec.max_entropy,
                       hard_updates=spec.hard_updates, gamma=spec.gamma, tau=spec.tau, lr=spec.lr,
-                      init_log_alpha=spec.init_log_alpha, drop_frac=spec.drop, bootstrap_nstep=spec.bootstrap, **kw)
+                      init_log_alpha=spec.init_log_alpha, drop_frac=spec.drop, bootstrap_nstep=spec.bootstrap,
+                      burn_in_steps=spec.burn_in, **kw)
     return NativeAgent(cfg, dev)
 
 
@@ -347,7 +348,7 @@ def _check_step(rep, s, ag, spec, ref, before, alpha, log_alpha, lr_steps):
                 rep.bad.append((f"s{s}.after.{n}", frac, frac, 0.02))
 
 
-CONT_CASES = ["tqc_small", "tqc_c5q2", "tqc_goal", "sac_min", "tqc_nolb", "tqc_discrete", "sac_boot"]
+CONT_CASES = ["tqc_small", "tqc_c5q2", "tqc_goal", "sac_min", "tqc_nolb", "tqc_discrete", "sac_boot", "tqc_burn"]
 
 
 @pytest.mark.parametrize("case", CONT_CASES)
