@@ -177,7 +177,9 @@ class DeepQLearning:
         sc = self.native.scalars()
         torch.save({"adam_m": {k: v.cpu().clone() for k, v in self.native.m_views.items()},
                     "adam_v": {k: v.cpu().clone() for k, v in self.native.v_views.items()},
-                    "step": int(sc["step"])}, logdir / "opt_state.tch")
+                    "step": int(sc["step"]),
+                    # DevState.alpha_next: the lagged alpha the NEXT update will use (update_kernels.h)
+                    "alpha": float(self.native.debug("dev_state")[2])}, logdir / "opt_state.tch")
 
     @staticmethod
     def load_from_file(logdir):
@@ -190,7 +192,9 @@ class DeepQLearning:
         opt = logdir / "opt_state.tch"
         if opt.exists():
             o = torch.load(opt, weights_only=False)
-            agent.native.load_opt_state(o["adam_m"], o["adam_v"], o["step"])
+            # alpha: the one-step-lagged exp(log_alpha) (soft_actor_critic.py:41,152), which the reference
+            # would restart from exp(init_log_alpha)
+            agent.native.load_opt_state(o["adam_m"], o["adam_v"], o["step"], o.get("alpha"))
         return agent
 
     # ------------------------------------------------------------------ inference

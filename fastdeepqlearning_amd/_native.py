@@ -86,6 +86,8 @@ SIGNATURES = {
     "fdql_ring_add_device": (C.c_int, [_vp, _vp, _i64, _vp]),
     "fdql_ring_flush": (C.c_int, [_vp, _vp]),
     "fdql_ring_append_episode": (C.c_int, [_vp, _vp, _i64, C.POINTER(EpisodeSpec), C.POINTER(_i64), _vp]),
+    "fdql_ring_snapshot": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "fdql_ring_restore": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp]),
     "fdql_ring_len": (_i64, [_vp]),
     "fdql_ring_top": (_i64, [_vp]),
     "fdql_ring_row_floats": (_i64, [_vp]),

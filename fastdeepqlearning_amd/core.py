@@ -68,6 +68,22 @@ class NativeRing:
     def flush(self):
         N.check(self.lib.fdql_ring_flush(self.handle, N.current_stream(self.device)))
 
+    def snapshot(self):
+        """(rows [n_slots, row_floats] float32 in slot order, top, len): everything a restart needs."""
+        n_len, top = len(self), self.top
+        n_slots = self.maxlen if n_len == self.maxlen - 1 else top   # every slot is written once the ring wrapped
+        rows = np.empty((n_slots, self.row_floats), np.float32)
+        with torch.cuda.device(self.device):
+            N.check(self.lib.fdql_ring_snapshot(self.handle, rows.ctypes.data_as(C.c_void_p), n_slots,
+                                                N.current_stream(self.device)))
+        return rows, top, n_len
+
+    def restore(self, rows, top, length):
+        rows = np.ascontiguousarray(rows, dtype=np.float32).reshape(-1, self.row_floats)
+        with torch.cuda.device(self.device):
+            N.check(self.lib.fdql_ring_restore(self.handle, rows.ctypes.data_as(C.c_void_p), rows.shape[0], int(top),
+                                               int(length), N.current_stream(self.device)))
+
     def _outs(self, lead):
         outs = [torch.empty(tuple(lead) + (d,), dtype=torch.float32, device=self.device) for d in self.dims]
         arr = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])

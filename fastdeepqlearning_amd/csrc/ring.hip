@@ -159,6 +159,20 @@ __global__ void k_scatter_rows(ScatterArgs a) {
   }
 }
 
+// inverse of k_scatter_rows for a run of slots [slot0, slot0 + n): SoA -> packed rows (ring checkpoint)
+__global__ void k_pack_slots(ScatterArgs a) {
+  const long long total = a.n * a.rowfloats;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long i = e / a.rowfloats;
+    const int c = (int)(e - i * a.rowfloats);
+    int k = 0;
+    for (int j = 1; j < a.nkeys; ++j)
+      if (c >= a.off[j]) k = j;
+    const long long slot = a.top + i;
+    const_cast<float *>(a.rows)[e] = a.dst[k][slot * a.dim[k] + (c - a.off[k])];
+  }
+}
+
 // nstep_return.py:60-72: ret[i] = r[i] + gamma * ret[i+1] for OLDEST-FIRST arrays, float32
 // multiply then add (no fma: the reference loop rounds the product before the add).
 __global__ void k_mc_return(const float *__restrict__ r, float *__restrict__ ret, int n, float gamma, long long sr,
@@ -574,6 +588,55 @@ int fdql_ring_append_episode(fdql_ring_t *r, const float *host_rows, int64_t n, 
   FDQL_HIP(hipEventRecord(r->ep_done, s));
   r->ep_inflight = true;
   if (appended) *appended = n_out;
+  return 0;
+}
+
+int fdql_ring_snapshot(fdql_ring_t *r, float *host_rows_out, int64_t n_slots, void *stream) {
+  FDQL_REQUIRE(r && host_rows_out && n_slots >= 0 && n_slots <= r->maxlen, "bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = flush(r, s);
+  if (rc) return rc;
+  if (r->stage_inflight) { FDQL_HIP(hipEventSynchronize(r->stage_done)); r->stage_inflight = false; }
+  const int F = r->rowfloats;
+  for (int64_t done = 0; done < n_slots;) {   // through the staging buffers, stage_cap slots at a time
+    const int64_t n = std::min<int64_t>(r->stage_cap, n_slots - done);
+    ScatterArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nkeys = r->nkeys; a.n = n; a.top = done; a.maxlen = r->maxlen; a.rowfloats = F; a.rows = r->dev_stage;
+    for (int k = 0; k < r->nkeys; ++k) { a.dst[k] = r->data[k]; a.dim[k] = r->dims[k]; a.off[k] = r->offs[k]; }
+    const long long total = n * F;
+    hipLaunchKernelGGL(k_pack_slots, dim3((int)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, s, a);
+    FDQL_HIP(hipGetLastError());
+    FDQL_HIP(hipMemcpyAsync(r->pinned, r->dev_stage, total * sizeof(float), hipMemcpyDeviceToHost, s));
+    FDQL_HIP(hipStreamSynchronize(s));
+    memcpy(host_rows_out + done * F, r->pinned, total * sizeof(float));
+    done += n;
+  }
+  return 0;
+}
+
+int fdql_ring_restore(fdql_ring_t *r, const float *host_rows, int64_t n_slots, int64_t top, int64_t len, void *stream) {
+  FDQL_REQUIRE(r && (host_rows || n_slots == 0) && n_slots >= 0 && n_slots <= r->maxlen, "bad arguments");
+  FDQL_REQUIRE(top >= 0 && top < r->maxlen && len >= 0 && len < r->maxlen && len <= n_slots,
+               "restore: (top=%lld, len=%lld) inconsistent with %lld slots of a ring of %lld", (long long)top,
+               (long long)len, (long long)n_slots, (long long)r->maxlen);
+  hipStream_t s = (hipStream_t)stream;
+  int rc = flush(r, s);
+  if (rc) return rc;
+  const int F = r->rowfloats;
+  for (int64_t done = 0; done < n_slots;) {
+    if (r->stage_inflight) { FDQL_HIP(hipEventSynchronize(r->stage_done)); r->stage_inflight = false; }
+    const int64_t n = std::min<int64_t>(r->stage_cap, n_slots - done);
+    memcpy(r->pinned, host_rows + done * F, n * F * sizeof(float));
+    FDQL_HIP(hipMemcpyAsync(r->dev_stage, r->pinned, n * F * sizeof(float), hipMemcpyHostToDevice, s));
+    rc = scatter(r, r->dev_stage, n, done, s);
+    if (rc) return rc;
+    FDQL_HIP(hipEventRecord(r->stage_done, s));
+    r->stage_inflight = true;
+    done += n;
+  }
+  r->top = top;
+  r->len = len;
   return 0;
 }
 

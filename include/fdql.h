@@ -65,6 +65,13 @@ int fdql_ring_flush(fdql_ring_t *ring, void *stream);
 
 /* replay_memory.py:45-46,72-73: __len__ including the max(top,len) quirk (caps at
  * maxlen-1 after the first wrap) and the write cursor. Counts staged rows too. */
+/* Checkpoint of the ring contents (true resume; the reference keeps its ring in host memory and does not
+ * save it - SURVEY 8f rank 3).  snapshot: slots [0, n_slots) in slot order as packed rows
+ * [n_slots, row_floats] into host memory (synchronises `stream`).  restore: the inverse, then the
+ * write position and length are set to (top, len) as fdql_ring_top / fdql_ring_len reported them.  */
+int fdql_ring_snapshot(fdql_ring_t *ring, float *host_rows_out, int64_t n_slots, void *stream);
+int fdql_ring_restore(fdql_ring_t *ring, const float *host_rows, int64_t n_slots, int64_t top, int64_t len,
+                      void *stream);
 int64_t fdql_ring_len(const fdql_ring_t *ring);
 int64_t fdql_ring_top(const fdql_ring_t *ring);
 int64_t fdql_ring_row_floats(const fdql_ring_t *ring);
