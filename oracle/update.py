@@ -57,6 +57,8 @@ class Spec:
     world_size: int = 1           # data-parallel ranks: loss is normalised by B * world_size
     bootstrap: bool = False       # use_bootstrap_minibatch_nstep (SAC-min with lower bounds only)
     burn_in: int = 0              # int(T * burn_in_portion) when EncoderConf.use_burn_in, else 0
+    gru: str = ""                 # "" = feed-forward joiner; else EncoderConf.JoinerModeEnum.gru with the latent-state
+                                  # training mode "zero" | "learned" | "store" (encoder.py:40-42, 78-94)
 
     @property
     def enc_in(self):             # encoder.py:26-32
@@ -103,6 +105,11 @@ def net_shapes(spec: Spec, which: str):
     if which == "encoder.obs":
         return mlp_shapes("encoder.visible_layer_encoders.obs_1d", spec.enc_in, spec.enc_hidden, spec.enc_features)
     if which == "encoder.joiner":
+        if spec.gru:    # nn.GRU(hidden_features, latent, num_layers=1) + the learnable initial state (encoder.py:41-42)
+            L, F_ = spec.latent, spec.enc_features
+            return [("encoder.joiner.weight_ih_l0", (3 * L, F_)), ("encoder.joiner.weight_hh_l0", (3 * L, L)),
+                    ("encoder.joiner.bias_ih_l0", (3 * L,)), ("encoder.joiner.bias_hh_l0", (3 * L,)),
+                    ("encoder.hidden_state", (L,))]
         return mlp_shapes("encoder.joiner", spec.enc_features, spec.joint_hidden, spec.latent)
     if which in ("actor", "actor_target"):
         return mlp_shapes(f"actor_critic.{which}", spec.latent, spec.pi_hidden, spec.pi_out)
@@ -140,7 +147,12 @@ def init_params(spec: Spec, seed=0) -> Dict[str, Tensor]:
     g = torch.Generator().manual_seed(seed)
     p = {}
     for name, shape in all_shapes(spec):
-        if name.endswith("weight"):
+        if name.startswith("encoder.joiner.") and spec.gru:       # nn.GRU.reset_parameters: U(-1/sqrt(L), 1/sqrt(L))
+            k = 1.0 / math.sqrt(spec.latent)
+            p[name] = (torch.rand(shape, generator=g, dtype=torch.float32) * 2 - 1) * k
+        elif name == "encoder.hidden_state":                       # encoder.py:42, 117: torch.rand(out_features)
+            p[name] = torch.rand(shape, generator=g, dtype=torch.float32)
+        elif name.endswith("weight"):
             fan_out, fan_in = shape
             a = math.sqrt(6.0 / (fan_in + fan_out))
             p[name] = (torch.rand(shape, generator=g, dtype=torch.float32) * 2 - 1) * a
@@ -168,13 +180,36 @@ def skip_head_mlp(p, prefix, x, n_hidden):
     return F.linear(torch.cat(feats, dim=-1), p[f"{prefix}.head.weight"], p[f"{prefix}.head.bias"])
 
 
-def encoder(p, spec: Spec, xp):
-    """encoder.py:52-67 (feed-forward joiner)."""
+def gru_cell(p, x_t, h):
+    """One step of torch.nn.GRU (gate order r, z, n):
+    r = s(W_ir x + b_ir + W_hr h + b_hr); z = s(W_iz x + b_iz + W_hz h + b_hz);
+    n = tanh(W_in x + b_in + r * (W_hn h + b_hn)); h' = (1 - z) * n + z * h."""
+    gi = F.linear(x_t, p["encoder.joiner.weight_ih_l0"], p["encoder.joiner.bias_ih_l0"])
+    gh = F.linear(h, p["encoder.joiner.weight_hh_l0"], p["encoder.joiner.bias_hh_l0"])
+    i_r, i_z, i_n = gi.chunk(3, -1)
+    h_r, h_z, h_n = gh.chunk(3, -1)
+    r = torch.sigmoid(i_r + h_r)
+    z = torch.sigmoid(i_z + h_z)
+    n = torch.tanh(i_n + r * h_n)
+    return (1 - z) * n + z * h
+
+
+def encoder(p, spec: Spec, xp, h0=None, return_hidden=False):
+    """encoder.py:52-67: obs MLP, then the feed-forward joiner or (spec.gru) one GRU layer scanned over the
+    leading (time) axis from ``h0`` [B, L] (zeros when None)."""
     x = xp["obs_1d"]
     if spec.goal:
         x = torch.cat((x, xp["achieved_goal"], xp["desired_goal"]), dim=-1)
     e = skip_head_mlp(p, "encoder.visible_layer_encoders.obs_1d", x, len(spec.enc_hidden))
-    return skip_head_mlp(p, "encoder.joiner", e, len(spec.joint_hidden))
+    if not spec.gru:
+        return skip_head_mlp(p, "encoder.joiner", e, len(spec.joint_hidden))
+    h = h0 if h0 is not None else torch.zeros(e.shape[1:-1] + (spec.latent,), dtype=e.dtype)
+    ys = []
+    for t in range(e.shape[0]):
+        h = gru_cell(p, e[t], h)
+        ys.append(h)
+    y = torch.stack(ys, 0)
+    return (y, h) if return_hidden else y
 
 
 def ensemble(p, spec: Spec, which, x):
@@ -224,7 +259,13 @@ def act(p, spec: Spec, xp, noise):
     explore/exploit select by ``xp["exploit_mask"]`` ([rows, 1] bool), with the policy's noise draw
     supplied by the caller.  Returns (action, log_prob, explore_action, exploit_action)."""
     with torch.no_grad():
-        s = encoder(p, spec, xp)
+        hidden = None
+        if spec.gru:   # forward_eval: one GRU step from xp["agent_state"] (encoder.py:72-76; runner.py:103-106)
+            s, hidden = encoder(p, spec, {k: v.unsqueeze(0) for k, v in xp.items()}, h0=xp.get("agent_state"),
+                                return_hidden=True)
+            s = s[0]
+        else:
+            s = encoder(p, spec, xp)
         explore, logp = policy(p, spec, "actor", s, noise)
         logits = skip_head_mlp(p, "actor_critic.actor", s, len(spec.pi_hidden))
         if spec.discrete:                                       # deepQlearning.py:175-178
@@ -234,7 +275,7 @@ def act(p, spec: Spec, xp, noise):
             exploit = torch.tanh(torch.chunk(logits, 2, dim=-1)[0])   # gaussian_mlp.py:38 tanh(mean)
         mask = xp["exploit_mask"]
         action = (exploit * mask) + (explore * torch.logical_not(mask))
-        return action, logp, explore, exploit
+        return (action, logp, explore, exploit, hidden) if spec.gru else (action, logp, explore, exploit)
 
 
 # ---------------------------------------------------------------------------------------
@@ -260,7 +301,14 @@ def losses(p, spec: Spec, xp, noise_target, noise_actor, alpha):
     action = xp["action"]
     if spec.discrete:                                                      # :206-210
         action = torch.eye(spec.act)[action.view(action.shape[:-1]).long()]
-    state = encoder(p, spec, xp)                                           # :213
+    h0 = None
+    if spec.gru:                                                           # encoder.py:78-94 (forward_train)
+        contig = torch.cumprod(contig.to(torch.int64), dim=0).bool()       # a window is valid up to its first break
+        if spec.gru == "store":
+            h0 = xp["agent_state"][0]
+        elif spec.gru == "learned":
+            h0 = p["encoder.hidden_state"].view(1, -1).repeat(contig.shape[1], 1)
+    state = encoder(p, spec, xp, h0=h0)                                    # :213
     s_cur, s_nxt = state[:-1], state[1:]                                   # :251-258
     with torch.no_grad():                                                  # q_loss target
         a_n, logp_n = policy(p, spec, "actor_target", s_nxt, noise_target)

@@ -269,6 +269,10 @@ def make_conf(case):
     conf.use_max_entropy_q = bool(case.get("max_entropy", True))
     conf.use_hard_updates = bool(case.get("hard_updates", False))
     conf.use_bootstrap_minibatch_nstep = bool(case.get("bootstrap", False))
+    if case.get("gru"):      # encoder.py:40-42: nn.GRU joiner; `gru` names the latent-state training mode
+        ec = conf.encoder_conf
+        ec.joiner_mode = type(ec).JoinerModeEnum.gru
+        ec.rnn_latent_state_training_mode = type(ec).RnnLatentStateTrainMode[case["gru"]]
     if case.get("burn_in_portion", 0):
         conf.encoder_conf.use_burn_in = True
         conf.encoder_conf.burn_in_portion = float(case["burn_in_portion"])
@@ -309,6 +313,8 @@ def make_batch(case, seed):
     xp["episode_step"] = step
     xp["episode_done"] = edone
     xp["idx"] = np.zeros((T, B, 1))
+    if case.get("gru") == "store":   # hidden state the actor had when it took the step (runner.py:157)
+        xp["agent_state"] = g.uniform(0, 1, (T, B, case["latent"]))
     return {k: torch.tensor(v, dtype=torch.float32) for k, v in xp.items()}
 
 
@@ -411,12 +417,17 @@ def golden_update(name, case, n_steps=3):
         names = {id(p): n for n, p in agent.named_parameters()}
         # keep the fixtures small: full tensors for the first and last step only
         if step in (0, n_steps - 1):
-            rec["grad"] = {names[id(p)]: p.grad.detach().clone() for p in agent.parameters()}
+            # a parameter the loss does not reach has no .grad and torch's Adam skips it (encoder.hidden_state
+            # outside the `learned` mode): recorded as zeros, which updates nothing either
+            rec["grad"] = {names[id(p)]: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p))
+                           for p in agent.parameters()}
             rec["after"] = {k: v.clone() for k, v in agent.state_dict().items()}
         if step == n_steps - 1:
             opt = agent.optimizers[0]
-            rec["adam_m"] = {names[id(p)]: opt.state[p]["exp_avg"].clone() for p in agent.parameters()}
-            rec["adam_v"] = {names[id(p)]: opt.state[p]["exp_avg_sq"].clone() for p in agent.parameters()}
+            rec["adam_m"] = {names[id(p)]: (opt.state[p]["exp_avg"].clone() if p in opt.state else torch.zeros_like(p))
+                             for p in agent.parameters()}
+            rec["adam_v"] = {names[id(p)]: (opt.state[p]["exp_avg_sq"].clone() if p in opt.state else torch.zeros_like(p))
+                             for p in agent.parameters()}
         out[f"step{step}"] = rec
     out["param_order"] = np.asarray([n for n, _ in agent.named_parameters()
                                      if any(p is q for q in agent.parameters() for p in [_])])
@@ -442,6 +453,8 @@ def golden_act(name, case, rows=7):
     if case.get("goal", 0):
         xp["achieved_goal"] = torch.tensor(g.standard_normal((rows, case["goal"])), dtype=torch.float32)
         xp["desired_goal"] = torch.tensor(g.standard_normal((rows, case["goal"])), dtype=torch.float32)
+    if case.get("gru"):      # the hidden state the runner carries between steps (runner.py:103-106, 157)
+        xp["agent_state"] = torch.tensor(g.uniform(0, 1, (rows, case["latent"])), dtype=torch.float32)
     xp["exploit_mask"] = torch.tensor((np.arange(rows) % 3 == 1).reshape(-1, 1))
     out = {"case": {k: np.asarray(v) for k, v in case.items()},
            "init": {k: v.clone() for k, v in agent.state_dict().items()
@@ -450,7 +463,9 @@ def golden_act(name, case, rows=7):
     assert conf.train_step.value % conf.log_interval == 0
     with NoiseTap() as tap:
         action, hidden, info = agent.act(xp)
-    assert hidden is None
+    assert (hidden is None) == (not case.get("gru"))
+    if hidden is not None:
+        out["hidden_state"] = hidden
     draws = tap.uniform if conf.discrete else tap.normal
     assert len(draws) == 1 and len(tap.uniform) + len(tap.normal) == 1
     out["noise"] = draws[0]
@@ -460,7 +475,7 @@ def golden_act(name, case, rows=7):
     save(name, out)
 
 
-ACT_CASES = ("tqc_c5q2", "tqc_goal", "tqc_discrete")
+ACT_CASES = ("tqc_c5q2", "tqc_goal", "tqc_discrete", "gru_store")
 
 
 UPDATE_CASES = OrderedDict(
@@ -479,6 +494,12 @@ UPDATE_CASES = OrderedDict(
                   p_done=0.02, p_break=0.1),
     tqc_burn=dict(obs=5, act=3, C=3, Q=4, latent=32, enc_features=32, enc_hidden=(32,), joint_hidden=(32,),
                   pi_hidden=(32,), critic_hidden=(32, 32), T=6, B=8, seed=7, burn_in_portion=0.4, p_break=0.3),
+    gru_zero=dict(obs=5, act=3, C=3, Q=4, latent=32, enc_features=24, enc_hidden=(32,), joint_hidden=(32,),
+                  pi_hidden=(32,), critic_hidden=(32, 32), T=6, B=8, seed=8, gru="zero", p_break=0.3, p_done=0.05),
+    gru_learned=dict(obs=5, act=3, C=3, Q=4, latent=32, enc_features=24, enc_hidden=(32,), joint_hidden=(32,),
+                     pi_hidden=(32,), critic_hidden=(32, 32), T=5, B=8, seed=9, gru="learned", p_break=0.3, p_done=0.05),
+    gru_store=dict(obs=5, act=3, C=3, Q=4, latent=32, enc_features=24, enc_hidden=(32,), joint_hidden=(32,),
+                   pi_hidden=(32,), critic_hidden=(32, 32), T=5, B=8, seed=10, gru="store", p_break=0.3, p_done=0.05),
     tqc_nolb=dict(obs=5, act=3, C=3, Q=4, latent=32, enc_features=32, enc_hidden=(32,), joint_hidden=(32,),
                   pi_hidden=(32,), critic_hidden=(32, 32), T=3, B=4, seed=5, lowerbound=False, max_entropy=False),
 )

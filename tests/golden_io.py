@@ -30,8 +30,9 @@ def spec_from_case(case, hyper=None):
                 lowerbound=bool(g("lowerbound", True)), max_entropy=bool(g("max_entropy", True)),
                 hard_updates=bool(g("hard_updates", False)), T=g("T"), B=g("B"),
                 bootstrap=bool(g("bootstrap", False)),
-                burn_in=int(g("T") * float(g("burn_in_portion", 0) or 0)))
+                burn_in=int(g("T") * float(g("burn_in_portion", 0) or 0)),
+                gru=str(case["gru"]) if "gru" in case else "")
 
 
-UPDATE_CASES = ["tqc_small", "tqc_c5q2", "tqc_goal", "sac_min", "tqc_discrete", "tqc_nolb", "sac_boot", "tqc_burn"]
-ACT_CASES = ["tqc_c5q2", "tqc_goal", "tqc_discrete"]
+UPDATE_CASES = ["tqc_small", "tqc_c5q2", "tqc_goal", "sac_min", "tqc_discrete", "tqc_nolb", "sac_boot", "tqc_burn", "gru_zero", "gru_learned", "gru_store"]
+ACT_CASES = ["tqc_c5q2", "tqc_goal", "tqc_discrete", "gru_store"]
