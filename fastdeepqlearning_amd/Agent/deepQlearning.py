@@ -34,8 +34,8 @@ def native_config_from_conf(conf):
     if "obs_2d" in spaces:
         raise NotImplementedError("obs_2d: the reference's pixel encoder is dead code (encoder.py:16-23)")
     ec = conf.encoder_conf
-    if getattr(ec, "joiner_mode", None) is not None and getattr(ec.joiner_mode, "name", "feedforward") != "feedforward":
-        raise NotImplementedError("GRU joiner is out of scope of the native path (SURVEY 8f rank 4)")
+    gru = getattr(getattr(ec, "joiner_mode", None), "name", "feedforward") == "gru"
+    gru_mode = getattr(getattr(ec, "rnn_latent_state_training_mode", None), "name", "zero")
     obs = _space_dim(spaces["obs_1d"]) if "obs_1d" in spaces else 0
     goal = _space_dim(spaces["desired_goal"]) if "desired_goal" in spaces else 0
     if conf.discrete:
@@ -53,7 +53,7 @@ def native_config_from_conf(conf):
                        enc_hidden=tuple(ec.obs_1d_hidden_dims), joint_hidden=tuple(ec.joint_hidden_dims),
                        pi_hidden=tuple(conf.pi_hidden_dims), critic_hidden=tuple(conf.critic_hidden_dims),
                        distributional=bool(conf.use_distributional_sac), use_lowerbound=bool(conf.use_nStep_lowerbounds),
-                       use_max_entropy=bool(conf.use_max_entropy_q), bootstrap_nstep=boot,
+                       use_max_entropy=bool(conf.use_max_entropy_q), bootstrap_nstep=boot, joiner_gru=gru, gru_state_mode=gru_mode,
                        burn_in_steps=int(conf.temporal_len * ec.burn_in_portion) if getattr(ec, "use_burn_in", False) else 0, hard_updates=bool(conf.use_hard_updates),
                        keep_frozen_copy=True, world_size=int(getattr(conf, "world_size", 1) or 1),
                        gamma=float(conf.gamma), tau=float(conf.tau), lr=float(conf.learning_rate),
@@ -136,7 +136,10 @@ class DeepQLearning:
         pass
 
     def get_random_hidden(self):
-        return None  # feed-forward joiner (encoder.py:99-100)
+        """encoder.py:113-117: None for the feed-forward joiner, torch.rand(latent) for the GRU."""
+        if not self.native.cfg.joiner_gru:
+            return None
+        return torch.rand(int(self.native.cfg.latent))
 
     @property
     def iteration(self):
@@ -211,10 +214,12 @@ class DeepQLearning:
             self.train_step()
         log_now = (conf.train_step.value % conf.log_interval) == 0
         self._act_calls = getattr(self, "_act_calls", 0) + 1
-        action, log_prob, explore, exploit = self.native.act(
+        res = self.native.act(
             experiences["obs_1d"], experiences.get("achieved_goal"), experiences.get("desired_goal"),
             experiences.get("exploit_mask"), noise=noise, seed=self._seed ^ 0xAC7, counter=self._act_calls,
-            want_info=log_now)
+            want_info=log_now, agent_state=experiences.get("agent_state"))
+        action, log_prob, explore, exploit = res[:4]
+        hidden = res[4] if len(res) > 4 else None   # GRU joiner: the state the runner feeds back (runner.py:157)
         info = {}
         if conf.discrete:   # deepQlearning.py:175-178: argmax(-1, True) -> int64 indices
             action = action.long()
@@ -222,4 +227,4 @@ class DeepQLearning:
             if conf.discrete:
                 explore, exploit = explore.long(), exploit.long()
             info["log_prob"], info["explore_action"], info["exploit_action"] = log_prob, explore, exploit
-        return action, None, info
+        return action, hidden, info

@@ -41,6 +41,7 @@ class AgentConfig(C.Structure):
         ("n_joint_hidden", C.c_int32), ("joint_hidden", C.c_int32 * MAX_HIDDEN),
         ("n_pi_hidden", C.c_int32), ("pi_hidden", C.c_int32 * MAX_HIDDEN),
         ("n_critic_hidden", C.c_int32), ("critic_hidden", C.c_int32 * MAX_HIDDEN),
+        ("joiner_gru", C.c_int32), ("gru_state_mode", C.c_int32),
         ("distributional", C.c_int32), ("use_lowerbound", C.c_int32), ("use_max_entropy", C.c_int32),
         ("hard_updates", C.c_int32), ("keep_frozen_copy", C.c_int32), ("bootstrap_nstep", C.c_int32), ("burn_in_steps", C.c_int32),
         ("T", C.c_int32), ("B", C.c_int32), ("world_size", C.c_int32),
@@ -51,7 +52,7 @@ class AgentConfig(C.Structure):
 
 class Batch(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("obs_1d", "achieved_goal", "desired_goal", "action", "reward", "mc_return",
-                                          "task_done", "episode_step")]
+                                          "task_done", "episode_step", "agent_state")]
 
 
 class AgentStats(C.Structure):
@@ -112,7 +113,8 @@ SIGNATURES = {
     "fdql_agent_set_step": (C.c_int, [_vp, _i32, _vp]),
     "fdql_agent_debug_ptr": (C.c_int, [_vp, C.c_char_p, C.POINTER(_vp), C.POINTER(_i64)]),
     "fdql_agent_act_workspace_bytes": (_i64, [_vp, _i32]),
-    "fdql_agent_act": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "fdql_agent_act": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
+                                 _vp]),
     "fdql_agent_stats": (C.c_int, [_vp, C.POINTER(AgentStats)]),
     "fdql_agent_profile_update": (_i32, [_vp, C.POINTER(Batch), _vp, _vp, _u64, C.POINTER(KernelTime), _i32, _vp]),
     "fdql_debug_set_gemm_variant": (C.c_int, [_i32]),

@@ -156,7 +156,8 @@ def make_config(obs_dim, act_dim, T, B, goal_dim=0, discrete=False, n_critics=2,
                 enc_features=256, enc_hidden=(256,), joint_hidden=(256,), pi_hidden=(256,), critic_hidden=(256, 256),
                 distributional=True, use_lowerbound=True, use_max_entropy=True, hard_updates=False,
                 keep_frozen_copy=True, world_size=1, gamma=0.99, tau=5e-2, lr=3e-4, beta1=0.9, beta2=0.999,
-                adam_eps=1e-8, init_log_alpha=-2.0, drop_frac=0.2, bootstrap_nstep=False, burn_in_steps=0):
+                adam_eps=1e-8, init_log_alpha=-2.0, drop_frac=0.2, bootstrap_nstep=False, burn_in_steps=0, joiner_gru=False,
+                gru_state_mode=0):
     c = N.AgentConfig()
     c.obs_dim, c.goal_dim, c.act_dim, c.discrete = obs_dim, goal_dim, act_dim, int(discrete)
     c.n_critics, c.n_quantiles, c.latent, c.enc_features = n_critics, n_quantiles, latent, enc_features
@@ -173,13 +174,16 @@ def make_config(obs_dim, act_dim, T, B, goal_dim=0, discrete=False, n_critics=2,
     c.hard_updates, c.keep_frozen_copy = int(hard_updates), int(keep_frozen_copy)
     c.bootstrap_nstep = int(bootstrap_nstep)
     c.burn_in_steps = int(burn_in_steps)
+    c.joiner_gru = int(bool(joiner_gru))
+    c.gru_state_mode = {"zero": 0, "store": 1, "learned": 2}.get(gru_state_mode, gru_state_mode) if joiner_gru else 0
     c.T, c.B, c.world_size = T, B, world_size
     c.gamma, c.tau, c.lr, c.beta1, c.beta2, c.adam_eps = gamma, tau, lr, beta1, beta2, adam_eps
     c.init_log_alpha, c.drop_frac = init_log_alpha, drop_frac
     return c
 
 
-BATCH_KEYS = ("obs_1d", "achieved_goal", "desired_goal", "action", "reward", "mc_return", "task_done", "episode_step")
+BATCH_KEYS = ("obs_1d", "achieved_goal", "desired_goal", "action", "reward", "mc_return", "task_done", "episode_step",
+              "agent_state")
 
 
 class NativeAgent:
@@ -269,7 +273,7 @@ class NativeAgent:
         return [(arr[i].name.decode(), float(arr[i].ms), float(arr[i].flops), float(arr[i].bytes)) for i in range(n)]
 
     def act(self, obs_1d, achieved_goal=None, desired_goal=None, exploit_mask=None, noise=None, seed=0, counter=0,
-            want_info=True):
+            want_info=True, agent_state=None):
         """deepQlearning.py:155-187 on `rows` observations: encoder -> actor on the online weights in the
         shared arena.  Returns (action, log_prob, explore_action, exploit_action); the last three are None
         unless want_info.  Asynchronous on the current torch stream."""
@@ -301,13 +305,23 @@ class NativeAgent:
         logp = torch.empty(rows, 1, device=dev) if want_info else None
         explore = torch.empty(rows, adim, device=dev) if want_info else None
         exploit = torch.empty(rows, adim, device=dev) if want_info else None
-        self._act_keep = (obs, ag, dg, mask, noise)
+        hs_in = hs_out = None
+        if cfg.joiner_gru:
+            hs_out = torch.empty(rows, cfg.latent, device=dev)
+            if agent_state is not None:
+                hs_in = f32(agent_state)
+                if tuple(hs_in.shape) != (rows, cfg.latent):
+                    raise ValueError(f"act(): agent_state must be [rows, {cfg.latent}]")
+        self._act_keep = (obs, ag, dg, mask, noise, hs_in)
         with torch.cuda.device(dev):
-            N.check(self.lib.fdql_agent_act(self.handle, N.ptr(obs), N.ptr(ag), N.ptr(dg),
+            N.check(self.lib.fdql_agent_act(self.handle, N.ptr(obs), N.ptr(ag), N.ptr(dg), N.ptr(hs_in),
                                             C.c_void_p(mask.data_ptr()) if mask is not None else None, N.ptr(noise),
                                             int(seed), int(counter), rows, N.ptr(action), N.ptr(logp), N.ptr(explore),
-                                            N.ptr(exploit), C.c_void_p(self._act_ws.data_ptr()), self._act_ws.numel(),
+                                            N.ptr(exploit), N.ptr(hs_out), C.c_void_p(self._act_ws.data_ptr()),
+                                            self._act_ws.numel(),
                                             N.current_stream(dev)))
+        if cfg.joiner_gru:
+            return action, logp, explore, exploit, hs_out
         return action, logp, explore, exploit
 
     def scalars(self):
@@ -360,7 +374,12 @@ class NativeAgent:
         (franQ/Agent/models/mlp.py:5-8,86; soft_actor_critic.py:34,38)."""
         g = torch.Generator(device="cpu").manual_seed(seed)
         for k, v in self.tensors.items():
-            if k.endswith("weight"):
+            if k.startswith("encoder.joiner.") and self.cfg.joiner_gru:   # nn.GRU.reset_parameters
+                a = 1.0 / float(self.cfg.latent) ** 0.5
+                v.copy_(((torch.rand(v.shape, generator=g) * 2 - 1) * a).to(self.device))
+            elif k == "encoder.hidden_state":                              # encoder.py:42,117
+                v.copy_(torch.rand(v.shape, generator=g).to(self.device))
+            elif k.endswith("weight"):
                 fan_out, fan_in = v.shape
                 a = (6.0 / (fan_in + fan_out)) ** 0.5
                 v.copy_(((torch.rand(v.shape, generator=g) * 2 - 1) * a).to(self.device))

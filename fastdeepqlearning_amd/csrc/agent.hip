@@ -105,6 +105,9 @@ struct fdql_agent {
   MlpDesc enc_obs, joiner, actor;
   std::vector<MlpDesc> critic;
   int64_t log_alpha_off = 0;
+  // GRU joiner (cfg.joiner_gru): offsets of weight_ih_l0 [3L,F], weight_hh_l0 [3L,L], bias_ih_l0, bias_hh_l0 [3L],
+  // encoder.hidden_state [L] in the trainable arena
+  int64_t gru_wih = 0, gru_whh = 0, gru_bih = 0, gru_bhh = 0, gru_h0 = 0;
   int64_t n_train = 0, tgt_begin = 0, tgt_end = 0, crit_begin = 0, crit_end = 0;
   std::vector<TensorInfo> tensors;
 
@@ -168,7 +171,23 @@ int layout(fdql_agent *a) {
   int64_t top = 0;
   add_mlp(a, a->enc_obs, "encoder.visible_layer_encoders.obs_1d", c.obs_dim + 2 * c.goal_dim, c.enc_hidden,
           c.n_enc_hidden, c.enc_features, top);
-  add_mlp(a, a->joiner, "encoder.joiner", c.enc_features, c.joint_hidden, c.n_joint_hidden, c.latent, top);
+  if (c.joiner_gru) {   // nn.GRU(hidden_features, latent, 1) + learnable start state (encoder.py:41-42)
+    const int L3 = 3 * c.latent;
+    a->joiner = MlpDesc();
+    a->joiner.din = c.enc_features; a->joiner.dout = c.latent;
+    a->tensors.push_back({"encoder.hidden_state", 0, top, c.latent, 0});
+    a->gru_h0 = top; top += pad4(c.latent);
+    a->tensors.push_back({"encoder.joiner.weight_ih_l0", 0, top, L3, c.enc_features});
+    a->gru_wih = top; top += pad4((int64_t)L3 * c.enc_features);
+    a->tensors.push_back({"encoder.joiner.weight_hh_l0", 0, top, L3, c.latent});
+    a->gru_whh = top; top += pad4((int64_t)L3 * c.latent);
+    a->tensors.push_back({"encoder.joiner.bias_ih_l0", 0, top, L3, 0});
+    a->gru_bih = top; top += pad4(L3);
+    a->tensors.push_back({"encoder.joiner.bias_hh_l0", 0, top, L3, 0});
+    a->gru_bhh = top; top += pad4(L3);
+  } else {
+    add_mlp(a, a->joiner, "encoder.joiner", c.enc_features, c.joint_hidden, c.n_joint_hidden, c.latent, top);
+  }
   a->tgt_begin = top;
   const int pi_out = c.discrete ? c.act_dim : 2 * c.act_dim;
   add_mlp(a, a->actor, "actor_critic.actor", c.latent, c.pi_hidden, c.n_pi_hidden, pi_out, top);
@@ -232,7 +251,20 @@ void carve(fdql_agent *a) {
     if (out) a->alloc(p + ".out", rows * d.dout);
   };
   mlp_bufs("enc_obs", a->enc_obs, N, true, true);
-  mlp_bufs("joiner", a->joiner, N, true, false);
+  if (c.joiner_gru) {
+    const int64_t L3 = 3 * c.latent, Bw = a->B;
+    a->alloc("gru.gi", N * L3);          // W_ih e + b_ih for every row
+    a->alloc("gru.gh", N * L3);          // W_hh h_{t-1} + b_hh, step by step
+    a->alloc("gru.hprev", N * c.latent); // h_{t-1} per row (start state for t = 0)
+    a->alloc("gru.h0", Bw * c.latent);
+    a->alloc("gru.dgi", M * L3);
+    a->alloc("gru.dgh", M * L3);
+    a->alloc("gru.dhz0", Bw * c.latent); // direct part of d h_{t-1} (dh * z), double-buffered over t
+    a->alloc("gru.dhz1", Bw * c.latent);
+    a->alloc("gru.dhw", Bw * c.latent);  // part of d h_{t-1} through W_hh
+  } else {
+    mlp_bufs("joiner", a->joiner, N, true, false);
+  }
   a->alloc("state", N * c.latent);
   mlp_bufs("actor_t", a->actor, M, false, true);
   mlp_bufs("actor", a->actor, M, true, true);
@@ -367,6 +399,27 @@ struct Builder {
     add_seg(p, dY, lddy, 1, m.HW() + col, d.head_ld(), 0, d.dout);
     if (!d.hid.empty()) add_seg(p, m.dpre[0], d.hid[0], 1, m.W(0) + col, d.din, 0, d.hid[0]);
   }
+  // dW[nout, width] (slabs) = dOut[R, nout]^T X[R, width], K-split over the R rows
+  void wgrad_gemm(int R, const float *dOut, int ldo, int nout, const float *X, int ldx, int width, float *dst, int ldw,
+                  Stage &gs, Stage &narrow) {
+    if (width <= 0) return;
+    GemmProblem p = new_gemm(nout, width, dst, ldw);
+    add_seg(p, dOut, ldo, 0, X, ldx, 0, R);
+    p.ksplit = a->nsplit;
+    p.split_stride = a->n_train;
+    // narrow problems (other tile shapes = other launches) are pooled in one stage at the end
+    (gemm_shape_is_dense(gemm_pick_shape(p, gemm_dense_shape())) ? gs : narrow).gemm.push_back(p);
+  }
+  // bias gradient = column sums of dOut over R rows, from per-64-row partials `cs` when the dgrad GEMM left them
+  void wgrad_bias(int R, const float *dOut, int ldo, int nout, const float *cs, float *dst, Stage &ws) {
+    SkinnyWgradProblem p;
+    memset(&p, 0, sizeof(p));
+    p.Nout = 1; p.K = nout; p.dY = nullptr;
+    if (cs) { p.M = (R + 63) / 64; p.X = cs; p.ldx = nout; }
+    else { p.M = R; p.X = dOut; p.ldx = ldo; }
+    p.dW = dst; p.sq = 0; p.sk = 1; p.split_stride = a->n_train; p.nsplit = a->nsplit;
+    ws.swg.push_back(p);
+  }
   // all weight / bias gradients of one MLP instance into the K-split slabs.  Every weight
   // gradient is a K-split GEMM (the narrow ones on the 128x32 / 32x128 tiles); bias gradients
   // come from the per-tile column sums the dgrad GEMMs leave behind (dy_cs / dpre_cs), or
@@ -377,22 +430,10 @@ struct Builder {
     const long long P = a->n_train;
     const int S = a->nsplit, R = m.rows;
     auto gemm_w = [&](const float *dOut, int ldo, int nout, const float *X, int ldx, int width, float *dst, int ldw) {
-      if (width <= 0) return;
-      GemmProblem p = new_gemm(nout, width, dst, ldw);
-      add_seg(p, dOut, ldo, 0, X, ldx, 0, R);
-      p.ksplit = S;
-      p.split_stride = P;
-      // narrow problems (other tile shapes = other launches) are pooled in one stage at the end
-      (gemm_shape_is_dense(gemm_pick_shape(p, gemm_dense_shape())) ? gs : narrow).gemm.push_back(p);
+      wgrad_gemm(R, dOut, ldo, nout, X, ldx, width, dst, ldw, gs, narrow);
     };
     auto bias_w = [&](const float *dOut, int ldo, int nout, const float *cs, float *dst) {
-      SkinnyWgradProblem p;
-      memset(&p, 0, sizeof(p));
-      p.Nout = 1; p.K = nout; p.dY = nullptr;
-      if (cs) { p.M = (R + 63) / 64; p.X = cs; p.ldx = nout; }
-      else { p.M = R; p.X = dOut; p.ldx = ldo; }
-      p.dW = dst; p.sq = 0; p.sk = 1; p.split_stride = P; p.nsplit = S;
-      ws.swg.push_back(p);
+      wgrad_bias(R, dOut, ldo, nout, cs, dst, ws);
     };
     for (size_t i = 0; i < d.hid.size(); ++i) {
       float *dst = slab + d.w_off[i];
@@ -503,10 +544,14 @@ int build_plan(fdql_agent *a) {
     eo.in.push_back({x.desired_goal, c.goal_dim, c.goal_dim});
   }
   eo.out = a->buf("enc_obs.out"); eo.ldout = c.enc_features;
-  MlpInst jo = make_inst(a, a->joiner, "joiner", params, 0, N, true);
-  jo.in.push_back({eo.out, c.enc_features, c.enc_features});
+  const bool gru = c.joiner_gru != 0;
+  MlpInst jo;
   float *state = a->buf("state");
-  jo.out = state; jo.ldout = L;
+  if (!gru) {
+    jo = make_inst(a, a->joiner, "joiner", params, 0, N, true);
+    jo.in.push_back({eo.out, c.enc_features, c.enc_features});
+    jo.out = state; jo.ldout = L;
+  }
   const float *s_cur = state, *s_nxt = state + (int64_t)B * L;
 
   MlpInst at = make_inst(a, a->actor, "actor_t", targets, a->tgt_begin, M, false);
@@ -547,7 +592,8 @@ int build_plan(fdql_agent *a) {
     const float *td = x.task_done, *es = x.episode_step;
     const int T = a->T;
     const int burn = c.burn_in_steps;
-    b.func_stage("prep", [=](hipStream_t s) { return prep_launch(td, es, T, B, burn, inv_gb, w, ic, s); });
+    const int cumprod = gru ? 1 : 0;   // encoder.py:80
+    b.func_stage("prep", [=](hipStream_t s) { return prep_launch(td, es, T, B, burn, cumprod, inv_gb, w, ic, s); });
     if (c.discrete) {   // stored action index -> one-hot critic input (deepQlearning.py:206-210)
       const float *act = x.action;
       float *oh = a->buf("action_onehot");
@@ -565,7 +611,38 @@ int build_plan(fdql_agent *a) {
     for (MlpInst *m : group) hs.gemm.push_back(b.fwd_head(*m));
   };
   fwd_chain({&eo}, "enc_obs");
-  fwd_chain({&jo}, "joiner");
+  if (!gru) {
+    fwd_chain({&jo}, "joiner");
+  } else {
+    // GRU joiner (encoder.py:40-42, 63-65): the input projection of all T*B rows is one GEMM; the scan over t is
+    // T x (recurrent GEMM [B, L] x [L, 3L] + gate kernel) - sequential by nature and latency-bound at B = 256
+    const int L3 = 3 * L, F = c.enc_features, T = a->T;
+    float *gi = a->buf("gru.gi"), *gh = a->buf("gru.gh"), *hprev = a->buf("gru.hprev"), *h0 = a->buf("gru.h0");
+    const float *wih = params + a->gru_wih, *whh = params + a->gru_whh, *bih = params + a->gru_bih, *bhh = params + a->gru_bhh;
+    {
+      Stage &gs = b.gemm_stage("gru.gi");
+      GemmProblem p = Builder::new_gemm(N, L3, gi, L3);
+      Builder::add_seg(p, eo.out, F, 1, wih, F, 1, F);
+      p.bias = bih;
+      gs.gemm.push_back(p);
+    }
+    {
+      const int mode = c.gru_state_mode;
+      const float *src = mode == 1 ? x.agent_state : (mode == 2 ? params + a->gru_h0 : nullptr);
+      b.func_stage("gru.h0", [=](hipStream_t s) { return gru_h0_launch(mode, src, h0, B, L, s); });
+    }
+    for (int t = 0; t < T; ++t) {
+      const float *hp = t == 0 ? h0 : state + (int64_t)(t - 1) * B * L;
+      float *gh_t = gh + (int64_t)t * B * L3, *h_t = state + (int64_t)t * B * L, *hs_t = hprev + (int64_t)t * B * L;
+      const float *gi_t = gi + (int64_t)t * B * L3;
+      Stage &gs = b.gemm_stage("gru.gh");
+      GemmProblem p = Builder::new_gemm(B, L3, gh_t, L3);
+      Builder::add_seg(p, hp, L, 1, whh, L, 1, L);
+      p.bias = bhh;
+      gs.gemm.push_back(p);
+      b.func_stage("gru.cell", [=](hipStream_t s) { return gru_cell_fwd_launch(gi_t, gh_t, hp, h_t, hs_t, B, L, s); });
+    }
+  }
   fwd_chain({&at, &ao}, "actors");
   // ---- policy sampling (gaussian_mlp.py:15-39)
   {
@@ -716,10 +793,38 @@ int build_plan(fdql_agent *a) {
     gs.gemm.push_back(b.bwd_dpre(jb, i, a->buf("dstate"), L));
     hosts.push_back(a->stages.size() - 1);
   }
+  if (gru) {
+    // back-propagation through time over the T-1 rows that carry gradient (h_{T-1} only feeds no_grad targets):
+    //   dh_t = d state[t] + dh_{t+1} * z_{t+1} + d gh_{t+1} W_hh
+    const int L3 = 3 * L, T = a->T;
+    float *dgi = a->buf("gru.dgi"), *dgh = a->buf("gru.dgh"), *dhw = a->buf("gru.dhw");
+    float *dhz[2] = {a->buf("gru.dhz0"), a->buf("gru.dhz1")};
+    const float *gi = a->buf("gru.gi"), *gh = a->buf("gru.gh"), *hprev = a->buf("gru.hprev"), *dstate = a->buf("dstate");
+    const float *whh = params + a->gru_whh;
+    for (int t = T - 2; t >= 0; --t) {
+      const int64_t r3 = (int64_t)t * B * L3, r1 = (int64_t)t * B * L;
+      const bool last = t == T - 2;
+      const float *ca = last ? nullptr : dhz[(t + 1) & 1], *cb = last ? nullptr : dhw;
+      float *out_z = dhz[t & 1];
+      b.func_stage("gru.cell_bwd", [=](hipStream_t s) {
+        return gru_cell_bwd_launch(dstate + r1, ca, cb, gi + r3, gh + r3, hprev + r1, dgi + r3, dgh + r3, out_z, B, L, s);
+      });
+      Stage &gs = b.gemm_stage("gru.dh_prev");
+      GemmProblem p = Builder::new_gemm(B, L, dhw, L);
+      Builder::add_seg(p, dgh + r3, L3, 1, whh, L, 0, L3);
+      gs.gemm.push_back(p);
+    }
+    if (c.gru_state_mode == 2) {   // learned start state: d hidden_state = sum_b d h_{-1}
+      float *out = a->buf("slabs") + a->gru_h0;
+      const float *za = dhz[0];
+      b.func_stage("gru.dh0", [=](hipStream_t s) { return gru_dh0_launch(za, dhw, B, L, out, s); });
+    }
+  }
   {
     Stage &gs = b.gemm_stage("denc");
     GemmProblem p = Builder::new_gemm(M, c.enc_features, a->buf("denc"), c.enc_features);
-    b.input_grad_segs(jb, a->buf("dstate"), L, 0, p);
+    if (gru) Builder::add_seg(p, a->buf("gru.dgi"), 3 * L, 1, params + a->gru_wih, c.enc_features, 0, 3 * L);
+    else b.input_grad_segs(jb, a->buf("dstate"), L, 0, p);
     p.colsum = a->buf("cs.denc");
     gs.gemm.push_back(p);
     hosts.push_back(a->stages.size() - 1);
@@ -740,7 +845,17 @@ int build_plan(fdql_agent *a) {
     // actor: needs d logits / its dpre -> from the d state launch on
     b.wgrads(ao, a->buf("dlogits"), a->actor.dout, nullptr, a->stages[idx_dstate], tail, ws);
     // joiner: needs d state and its dpre -> the d enc launch; encoder MLP: needs d enc and its dpre -> the tail
-    b.wgrads(jb, a->buf("dstate"), L, a->buf("cs.dstate"), a->stages[idx_denc], tail, ws);
+    if (!gru) {
+      b.wgrads(jb, a->buf("dstate"), L, a->buf("cs.dstate"), a->stages[idx_denc], tail, ws);
+    } else {   // GRU weights: dW_hh = d gh^T h_prev, dW_ih = d gi^T e, biases = column sums (all over the M rows)
+      const int L3 = 3 * L, F = c.enc_features;
+      float *slab = a->buf("slabs");
+      Stage &host = a->stages[idx_denc];
+      b.wgrad_gemm(M, a->buf("gru.dgh"), L3, L3, a->buf("gru.hprev"), L, L, slab + a->gru_whh, L, host, tail);
+      b.wgrad_gemm(M, a->buf("gru.dgi"), L3, L3, eo.out, F, F, slab + a->gru_wih, F, host, tail);
+      b.wgrad_bias(M, a->buf("gru.dgh"), L3, L3, nullptr, slab + a->gru_bhh, ws);
+      b.wgrad_bias(M, a->buf("gru.dgi"), L3, L3, nullptr, slab + a->gru_bih, ws);
+    }
     b.wgrads(eb, a->buf("denc"), c.enc_features, a->buf("cs.denc"), tail, tail, ws);
     a->stages.push_back(tail);
     a->stages.push_back(ws);
@@ -796,6 +911,8 @@ int prepare_update(fdql_agent *a, const fdql_batch_t *batch, const float *noise_
                "fdql_agent_update: batch needs obs_1d, action, reward, task_done, episode_step");
   FDQL_REQUIRE(!a->cfg.goal_dim || (batch->achieved_goal && batch->desired_goal), "goal_dim > 0 needs achieved/desired goal");
   FDQL_REQUIRE(!a->cfg.use_lowerbound || batch->mc_return, "use_lowerbound needs mc_return");
+  FDQL_REQUIRE(!(a->cfg.joiner_gru && a->cfg.gru_state_mode == 1) || batch->agent_state,
+               "GRU joiner in store mode needs batch.agent_state");
   if (!a->plan_ready || memcmp(&a->batch, batch, sizeof(*batch)) != 0) {
     a->batch = *batch;
     int rc = build_plan(a);
@@ -835,6 +952,10 @@ int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {
                    c.n_joint_hidden <= FDQL_MAX_HIDDEN && c.n_pi_hidden >= 0 && c.n_pi_hidden <= FDQL_MAX_HIDDEN &&
                    c.n_critic_hidden >= 0 && c.n_critic_hidden <= FDQL_MAX_HIDDEN, "bad hidden layer counts");
   FDQL_REQUIRE(c.latent > 0 && c.enc_features > 0, "bad latent dims");
+  FDQL_REQUIRE(!c.joiner_gru || c.n_joint_hidden == 1,
+               "GRU joiner: one layer only (len(joint_hidden_dims) == 1) - the reference's own hidden-state plumbing "
+               "(encoder.py:83-87, 117) carries a [latent] vector per row");
+  FDQL_REQUIRE(!c.joiner_gru || (c.gru_state_mode >= 0 && c.gru_state_mode <= 2), "gru_state_mode must be 0, 1 or 2");
   FDQL_REQUIRE(c.burn_in_steps >= 0 && c.burn_in_steps <= c.T - 1, "burn_in_steps outside [0, T-1]");
   FDQL_REQUIRE(!c.bootstrap_nstep || (!c.distributional && c.use_lowerbound),
                "bootstrap_nstep needs distributional == 0 and use_lowerbound == 1 (the reference forms the term only in "
@@ -1004,7 +1125,10 @@ static int64_t act_mlp_floats(const MlpDesc &d, int64_t rows) {
 
 int64_t fdql_agent_act_workspace_bytes(const fdql_agent_t *a, int32_t rows) {
   if (!a || rows < 0) return -1;
-  return 4 * (act_mlp_floats(a->enc_obs, rows) + act_mlp_floats(a->joiner, rows) + act_mlp_floats(a->actor, rows));
+  int64_t joiner = act_mlp_floats(a->joiner, rows);
+  if (a->cfg.joiner_gru)   // gi, gh [rows, 3L], zero start state and the new state [rows, L]
+    joiner = 2 * pad4((int64_t)rows * 3 * a->cfg.latent) + 2 * pad4((int64_t)rows * a->cfg.latent);
+  return 4 * (act_mlp_floats(a->enc_obs, rows) + joiner + act_mlp_floats(a->actor, rows));
 }
 
 namespace {
@@ -1039,9 +1163,9 @@ hipError_t act_mlp(const fdql_agent *a, const MlpDesc &d, const ActSeg *in, int 
 }  // namespace
 
 int fdql_agent_act(fdql_agent_t *a, const float *obs_1d, const float *achieved_goal, const float *desired_goal,
-                   const uint8_t *exploit_mask, const float *noise, uint64_t seed, uint64_t counter, int32_t rows,
-                   float *action, float *log_prob, float *explore_action, float *exploit_action, void *workspace,
-                   int64_t workspace_bytes, void *stream) {
+                   const float *agent_state, const uint8_t *exploit_mask, const float *noise, uint64_t seed,
+                   uint64_t counter, int32_t rows, float *action, float *log_prob, float *explore_action,
+                   float *exploit_action, float *hidden_state, void *workspace, int64_t workspace_bytes, void *stream) {
   if (!a || !a->bound) { set_error("fdql_agent_act: agent not bound"); return FDQL_ESTATE; }
   FDQL_REQUIRE(rows >= 0, "fdql_agent_act: rows < 0");
   if (rows == 0) return 0;
@@ -1064,7 +1188,29 @@ int fdql_agent_act(fdql_agent_t *a, const float *obs_1d, const float *achieved_g
   }
   float *enc = nullptr, *state = nullptr, *logits = nullptr;
   hipError_t e = act_mlp(a, a->enc_obs, in, nin, rows, top, &enc, s);
-  if (e == hipSuccess) { ActSeg x = {enc, a->enc_obs.dout, a->enc_obs.dout}; e = act_mlp(a, a->joiner, &x, 1, rows, top, &state, s); }
+  if (e == hipSuccess && !c.joiner_gru) {
+    ActSeg x = {enc, a->enc_obs.dout, a->enc_obs.dout};
+    e = act_mlp(a, a->joiner, &x, 1, rows, top, &state, s);
+  } else if (e == hipSuccess) {
+    // one GRU step from the carried hidden state (encoder.py:63-65, 72-76; NULL = zeros like nn.GRU's default)
+    const int L = c.latent, L3 = 3 * c.latent, F = c.enc_features;
+    float *gi = top; top += pad4((int64_t)rows * L3);
+    float *gh = top; top += pad4((int64_t)rows * L3);
+    float *hz = top; top += pad4((int64_t)rows * L);
+    float *hn = top; top += pad4((int64_t)rows * L);
+    const float *hp = agent_state;
+    if (!hp) { e = gru_h0_launch(0, nullptr, hz, rows, L, s); hp = hz; }
+    ActLayerArgs l;
+    memset(&l, 0, sizeof(l));
+    l.in[0] = {enc, F, F}; l.nseg = 1; l.W = a->params + a->gru_wih; l.ldw = F; l.bias = a->params + a->gru_bih;
+    l.out = gi; l.ldo = L3; l.N = L3; l.rows = rows; l.leaky = 0;
+    if (e == hipSuccess) e = act_layer_launch(l, s);
+    l.in[0] = {hp, L, L}; l.W = a->params + a->gru_whh; l.ldw = L; l.bias = a->params + a->gru_bhh; l.out = gh;
+    if (e == hipSuccess) e = act_layer_launch(l, s);
+    float *hout = hidden_state ? hidden_state : hn;
+    if (e == hipSuccess) e = gru_cell_fwd_launch(gi, gh, hp, hout, nullptr, rows, L, s);
+    state = hout;
+  }
   if (e == hipSuccess) { ActSeg x = {state, a->joiner.dout, a->joiner.dout}; e = act_mlp(a, a->actor, &x, 1, rows, top, &logits, s); }
   if (e == hipSuccess) {
     ActPolicyArgs p;

@@ -209,23 +209,39 @@ __device__ __forceinline__ float device_noise(uint64_t seed, uint32_t step, uint
 // ======================================================================================
 // block = 16 windows x 16 time lanes; consecutive threads -> consecutive b (coalesced rows)
 __global__ __launch_bounds__(256) void k_prep(const float *__restrict__ task_done, const float *__restrict__ episode_step,
-                                              int T, int B, int burn_in, float inv_global_batch,
+                                              int T, int B, int burn_in, int cumprod, float inv_global_batch,
                                               float *__restrict__ w, float *__restrict__ contig) {
   __shared__ float cnt[16][17];
   const int bl = threadIdx.x & 15, tl = threadIdx.x >> 4;
   const int b = blockIdx.x * 16 + bl;
   float c_local = 0.f;
   if (b < B) {
-    for (int t = tl; t < T - 1; t += 16) {
-      const int m = t * B + b;
-      // deepQlearning.py:219-220: the first burn_in rows carry no loss
-      const bool c = t >= burn_in && (episode_step[m + B] == episode_step[m] + 1.0f) && (task_done[m] == 0.f);
-      contig[m] = c ? 1.f : 0.f;
-      c_local += c ? 1.f : 0.f;
+    if (cumprod) {
+      // GRU joiner (encoder.py:80): is_contiguous <- cumprod over t, THEN the burn-in rows are zeroed
+      // (deepQlearning.py:219-220): a sequential walk per window, done by its first time lane
+      if (tl == 0) {
+        float run = 1.f;
+        for (int t = 0; t < T - 1; ++t) {
+          const int m = t * B + b;
+          const bool c = (episode_step[m + B] == episode_step[m] + 1.0f) && (task_done[m] == 0.f);
+          run = c ? run : 0.f;
+          const float v = t >= burn_in ? run : 0.f;
+          contig[m] = v;
+          c_local += v;
+        }
+      }
+    } else {
+      for (int t = tl; t < T - 1; t += 16) {
+        const int m = t * B + b;
+        // deepQlearning.py:219-220: the first burn_in rows carry no loss
+        const bool c = t >= burn_in && (episode_step[m + B] == episode_step[m] + 1.0f) && (task_done[m] == 0.f);
+        contig[m] = c ? 1.f : 0.f;
+        c_local += c ? 1.f : 0.f;
+      }
     }
   }
   cnt[tl][bl] = c_local;
-  __syncthreads();
+  __syncthreads();   // also orders lane 0's contig[] stores before the other lanes' reads below (same block)
   float total = 0.f;
 #pragma unroll
   for (int j = 0; j < 16; ++j) total += cnt[j][bl];   // exact: a count of at most T-1 ones
@@ -703,9 +719,10 @@ hipError_t adam_launch(const AdamArgs &a, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t prep_launch(const float *task_done, const float *episode_step, int T, int B, int burn_in, float inv_gb,
-                       float *w, float *contig, hipStream_t s) {
-  hipLaunchKernelGGL(k_prep, dim3((B + 15) / 16), dim3(256), 0, s, task_done, episode_step, T, B, burn_in, inv_gb, w, contig);
+hipError_t prep_launch(const float *task_done, const float *episode_step, int T, int B, int burn_in, int cumprod,
+                       float inv_gb, float *w, float *contig, hipStream_t s) {
+  hipLaunchKernelGGL(k_prep, dim3((B + 15) / 16), dim3(256), 0, s, task_done, episode_step, T, B, burn_in, cumprod, inv_gb, w,
+                     contig);
   return hipGetLastError();
 }
 
@@ -743,6 +760,88 @@ hipError_t policy_bwd_launch(const float *logits, const float *noise, const floa
   else
     hipLaunchKernelGGL(k_policy_bwd, dim3((M + 255) / 256), dim3(256), 0, s, logits, noise, action, dpi_parts, nparts,
                        dpi_sum, w, st, M, A, dlogits);
+  return hipGetLastError();
+}
+
+// ======================================================================================
+// GRU joiner: torch.nn.GRU cell (gate order r, z, n) forward / backward for one time step
+//   r = s(gi_r + gh_r), z = s(gi_z + gh_z), n = tanh(gi_n + r * gh_n), h = (1 - z) n + z h_prev
+// gi = W_ih x + b_ih and gh = W_hh h_prev + b_hh come from the GEMM kernel; sigmoid / tanh through
+// double, rounded once (like the policy kernels: the CPU path's vector math is <= 1 ulp).
+// ======================================================================================
+__device__ __forceinline__ float sigmoid_f(float x) { return (float)(1.0 / (1.0 + exp(-(double)x))); }
+
+__global__ void k_gru_h0(int mode, const float *__restrict__ src, float *__restrict__ h0, int B, int L) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * L) return;
+  h0[i] = mode == 0 ? 0.f : (mode == 1 ? src[i] : src[i % L]);
+}
+
+__global__ void k_gru_cell_fwd(const float *__restrict__ gi, const float *__restrict__ gh, const float *__restrict__ hprev,
+                               float *__restrict__ h, float *__restrict__ hprev_save, int rows, int L) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * L) return;
+  const int b = i / L, l = i - b * L;
+  const long long g = (long long)b * 3 * L + l;
+  const float r = sigmoid_f(gi[g] + gh[g]);
+  const float z = sigmoid_f(gi[g + L] + gh[g + L]);
+  const float n = (float)tanh((double)(gi[g + 2 * L] + r * gh[g + 2 * L]));
+  const float hp = hprev[i];
+  h[i] = (1.f - z) * n + z * hp;
+  if (hprev_save) hprev_save[i] = hp;
+}
+
+__global__ void k_gru_cell_bwd(const float *__restrict__ dstate, const float *__restrict__ carry_a,
+                               const float *__restrict__ carry_b, const float *__restrict__ gi,
+                               const float *__restrict__ gh, const float *__restrict__ hprev, float *__restrict__ dgi,
+                               float *__restrict__ dgh, float *__restrict__ dh_direct, int rows, int L) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * L) return;
+  const int b = i / L, l = i - b * L;
+  const long long g = (long long)b * 3 * L + l;
+  float dh = dstate ? dstate[i] : 0.f;
+  if (carry_a) dh += carry_a[i] + carry_b[i];
+  const float hn = gh[g + 2 * L];
+  const float r = sigmoid_f(gi[g] + gh[g]);
+  const float z = sigmoid_f(gi[g + L] + gh[g + L]);
+  const float n = (float)tanh((double)(gi[g + 2 * L] + r * hn));
+  const float hp = hprev[i];
+  const float dn_pre = (dh * (1.f - z)) * (1.f - n * n);
+  const float dz_pre = (dh * (hp - n)) * (z * (1.f - z));
+  const float dr_pre = (dn_pre * hn) * (r * (1.f - r));
+  dgi[g] = dr_pre; dgi[g + L] = dz_pre; dgi[g + 2 * L] = dn_pre;
+  dgh[g] = dr_pre; dgh[g + L] = dz_pre; dgh[g + 2 * L] = dn_pre * r;
+  dh_direct[i] = dh * z;
+}
+
+__global__ void k_gru_dh0(const float *__restrict__ a, const float *__restrict__ b, int B, int L, float *__restrict__ out) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= L) return;
+  float s = 0.f;
+  for (int r = 0; r < B; ++r) s += a[(long long)r * L + l] + b[(long long)r * L + l];
+  out[l] = s;
+}
+
+hipError_t gru_h0_launch(int mode, const float *src, float *h0, int B, int L, hipStream_t s) {
+  hipLaunchKernelGGL(k_gru_h0, dim3((B * L + 255) / 256), dim3(256), 0, s, mode, src, h0, B, L);
+  return hipGetLastError();
+}
+hipError_t gru_cell_fwd_launch(const float *gi, const float *gh, const float *hprev, float *h, float *hprev_save, int rows,
+                               int L, hipStream_t s) {
+  hipLaunchKernelGGL(k_gru_cell_fwd, dim3((rows * L + 255) / 256), dim3(256), 0, s, gi, gh, hprev, h, hprev_save, rows, L);
+  return hipGetLastError();
+}
+hipError_t gru_cell_bwd_launch(const float *dstate, const float *carry_a, const float *carry_b, const float *gi,
+                               const float *gh, const float *hprev, float *dgi, float *dgh, float *dh_direct, int rows,
+                               int L, hipStream_t s) {
+  hipLaunchKernelGGL(k_gru_cell_bwd, dim3((rows * L + 255) / 256), dim3(256), 0, s, dstate, carry_a, carry_b, gi, gh, hprev, dgi,
+                     dgh, dh_direct, rows, L);
+  return hipGetLastError();
+}
+hipError_t gru_dh0_launch(const float *a, const float *b, int B, int L, float *out, hipStream_t s) {
+  hipLaunchKernelGGL(k_gru_dh0, dim3((L + 63) / 64), dim3(64), 0, s, a, b, B, L, out);
   return hipGetLastError();
 }
 

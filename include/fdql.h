@@ -191,6 +191,12 @@ typedef struct {
   int32_t n_joint_hidden, joint_hidden[FDQL_MAX_HIDDEN];
   int32_t n_pi_hidden, pi_hidden[FDQL_MAX_HIDDEN];
   int32_t n_critic_hidden, critic_hidden[FDQL_MAX_HIDDEN];
+  /* encoder joiner: 0 = SkipHeadMLP (EncoderConf.JoinerModeEnum.feedforward), 1 = one nn.GRU layer scanned
+   * over the T axis (JoinerModeEnum.gru; encoder.py:40-42, 78-94).  gru_state_mode = where the scan starts
+   * (EncoderConf.RnnLatentStateTrainMode): 0 zero, 1 store (batch.agent_state[0]), 2 learned
+   * (parameter encoder.hidden_state repeated over the batch).  With the GRU, is_contiguous becomes its
+   * cumulative product over t (a window counts up to its first break). */
+  int32_t joiner_gru, gru_state_mode;
   /* algorithm switches */
   int32_t distributional;           /* conf.use_distributional_sac                           */
   int32_t use_lowerbound;           /* conf.use_nStep_lowerbounds                            */
@@ -233,6 +239,8 @@ int fdql_agent_bind(fdql_agent_t *agent, float *params, float *grads, float *ada
 typedef struct {
   const float *obs_1d, *achieved_goal, *desired_goal, *action;
   const float *reward, *mc_return, *task_done, *episode_step;
+  const float *agent_state;   /* [T,B,latent]: hidden state the actor had at each step (runner.py:157); read iff
+                                 joiner_gru && gru_state_mode == 1, row block t = 0 only (encoder.py:83-84)     */
 } fdql_batch_t;
 
 #define FDQL_PHASE_ALL 0   /* loss + backward + Adam + polyak                               */
@@ -271,16 +279,17 @@ int fdql_agent_debug_ptr(fdql_agent_t *agent, const char *name, const float **de
  *   keyed by (seed, counter);
  *   action [rows, act_dim] (continuous) or [rows] action index as float (discrete) =
  *   exploit*mask + explore*!mask; log_prob [rows], explore_action, exploit_action: optional (the
- *   reference's `info` dict).  The hidden state of the reference's return triple is always None
- *   for the feed-forward joiner.  workspace: caller-owned device scratch of at least
+ *   reference's `info` dict).  GRU joiner: agent_state [rows, latent] is the hidden state the runner carries
+ *   (NULL = zeros) and hidden_state [rows, latent] receives the next one (encoder.py:72-76); both are NULL
+ *   for the feed-forward joiner, whose hidden state is None in the reference's return triple.  workspace: caller-owned device scratch of at least
  *   fdql_agent_act_workspace_bytes(agent, rows) bytes, 16-byte aligned, private to this call
  *   stream (it may run beside fdql_agent_update on another stream; it then reads whatever mix of
  *   pre/post-step weights is in the arena, like any lock-free actor).  No host sync.          */
 int64_t fdql_agent_act_workspace_bytes(const fdql_agent_t *agent, int32_t rows);
 int fdql_agent_act(fdql_agent_t *agent, const float *obs_1d, const float *achieved_goal, const float *desired_goal,
-                   const uint8_t *exploit_mask, const float *noise, uint64_t seed, uint64_t counter, int32_t rows,
-                   float *action, float *log_prob, float *explore_action, float *exploit_action, void *workspace,
-                   int64_t workspace_bytes, void *stream);
+                   const float *agent_state, const uint8_t *exploit_mask, const float *noise, uint64_t seed,
+                   uint64_t counter, int32_t rows, float *action, float *log_prob, float *explore_action,
+                   float *exploit_action, float *hidden_state, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* Algorithmic work of one update, for roofline accounting: dense GEMM flops
  * (2*MAC) and the number/flops of launches by kind. */

@@ -283,7 +283,7 @@ def _agent_for(spec, dev, **kw):
                       use_lowerbound=spec.lowerbound, use_max_entropy=spec.max_entropy,
                       hard_updates=spec.hard_updates, gamma=spec.gamma, tau=spec.tau, lr=spec.lr,
                       init_log_alpha=spec.init_log_alpha, drop_frac=spec.drop, bootstrap_nstep=spec.bootstrap,
-                      burn_in_steps=spec.burn_in, **kw)
+                      burn_in_steps=spec.burn_in, joiner_gru=bool(spec.gru), gru_state_mode=spec.gru or 0, **kw)
     return NativeAgent(cfg, dev)
 
 
@@ -348,7 +348,7 @@ def _check_step(rep, s, ag, spec, ref, before, alpha, log_alpha, lr_steps):
                 rep.bad.append((f"s{s}.after.{n}", frac, frac, 0.02))
 
 
-CONT_CASES = ["tqc_small", "tqc_c5q2", "tqc_goal", "sac_min", "tqc_nolb", "tqc_discrete", "sac_boot", "tqc_burn"]
+CONT_CASES = ["tqc_small", "tqc_c5q2", "tqc_goal", "sac_min", "tqc_nolb", "tqc_discrete", "sac_boot", "tqc_burn", "gru_zero", "gru_learned", "gru_store"]
 
 
 @pytest.mark.parametrize("case", CONT_CASES)
@@ -521,9 +521,12 @@ def test_act_matches_reference_golden(dev, case):
     ag = _agent_for(spec, dev)
     ag.load_tensors(g["init"])
     xp = g["xp"]
-    action, logp, explore, exploit = ag.act(xp["obs_1d"], xp.get("achieved_goal"), xp.get("desired_goal"),
-                                            xp["exploit_mask"], noise=g["noise"])
+    res = ag.act(xp["obs_1d"], xp.get("achieved_goal"), xp.get("desired_goal"), xp["exploit_mask"], noise=g["noise"],
+                 agent_state=xp.get("agent_state"))
+    action, logp, explore, exploit = res[:4]
     rep = Report(f"act golden {case}")
+    if spec.gru:
+        rep.check("hidden_state", res[4], g["hidden_state"])
     if spec.discrete:
         for got, key in ((action, "action"), (explore, "explore_action"), (exploit, "exploit_action")):
             assert np.array_equal(got.cpu().numpy().astype(np.int64), g[key]), key

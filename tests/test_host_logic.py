@@ -77,8 +77,15 @@ def test_conf_translation_matches_reference_defaults():
     assert c.distributional == 1 and c.use_lowerbound == 1 and c.use_max_entropy == 1
     # attribute == item access (franQ/common_utils.py:59-67)
     assert conf["gamma"] == conf.gamma
+    # GRU joiner + latent-state training mode (encoder.py:40-42, 78-94)
     conf.encoder_conf.joiner_mode = conf.encoder_conf.JoinerModeEnum.gru
-    with pytest.raises(NotImplementedError):
+    conf.encoder_conf.rnn_latent_state_training_mode = conf.encoder_conf.RnnLatentStateTrainMode.learned
+    c = native_config_from_conf(conf)
+    assert c.joiner_gru == 1 and c.gru_state_mode == 2
+    conf.encoder_conf.use_burn_in = True
+    assert native_config_from_conf(conf).burn_in_steps == int(50 * 0.2)
+    conf.use_bootstrap_minibatch_nstep = True      # only defined for SAC-min with lower bounds in the reference
+    with pytest.raises(ValueError):
         native_config_from_conf(conf)
 
 
