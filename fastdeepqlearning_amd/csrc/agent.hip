@@ -74,6 +74,10 @@ struct MlpInst {
   const float *HB() const { return wbase + (d->hb_off - worigin); }
 };
 
+// K-split of the per-step recurrent GEMMs of the GRU scan ([B, L] x [L, 3L] forward, [B, 3L] x [3L, L] backward):
+// at B = 256 they are 16-48 workgroups walking K serially; the splits trade that for a partial sum in the gate kernel
+constexpr int GRU_KSPLIT_FWD = 4, GRU_KSPLIT_BWD = 8;
+
 enum StageKind { ST_GEMM, ST_SKINNY_WGRAD, ST_FUNC, ST_HEAD_DGRAD };
 
 struct GemmSub {
@@ -261,7 +265,8 @@ void carve(fdql_agent *a) {
     a->alloc("gru.dgh", M * L3);
     a->alloc("gru.dhz0", Bw * c.latent); // direct part of d h_{t-1} (dh * z), double-buffered over t
     a->alloc("gru.dhz1", Bw * c.latent);
-    a->alloc("gru.dhw", Bw * c.latent);  // part of d h_{t-1} through W_hh
+    a->alloc("gru.dhw", GRU_KSPLIT_BWD * Bw * c.latent);  // part of d h_{t-1} through W_hh, K-split partials
+    a->alloc("gru.ghp", GRU_KSPLIT_FWD * Bw * L3);        // K-split partials of W_hh h_{t-1} for the current step
   } else {
     mlp_bufs("joiner", a->joiner, N, true, false);
   }
@@ -635,12 +640,16 @@ int build_plan(fdql_agent *a) {
       const float *hp = t == 0 ? h0 : state + (int64_t)(t - 1) * B * L;
       float *gh_t = gh + (int64_t)t * B * L3, *h_t = state + (int64_t)t * B * L, *hs_t = hprev + (int64_t)t * B * L;
       const float *gi_t = gi + (int64_t)t * B * L3;
+      float *ghp = a->buf("gru.ghp");
       Stage &gs = b.gemm_stage("gru.gh");
-      GemmProblem p = Builder::new_gemm(B, L3, gh_t, L3);
+      GemmProblem p = Builder::new_gemm(B, L3, ghp, L3);
       Builder::add_seg(p, hp, L, 1, whh, L, 1, L);
-      p.bias = bhh;
+      p.ksplit = GRU_KSPLIT_FWD;
+      p.split_stride = (long long)B * L3;
       gs.gemm.push_back(p);
-      b.func_stage("gru.cell", [=](hipStream_t s) { return gru_cell_fwd_launch(gi_t, gh_t, hp, h_t, hs_t, B, L, s); });
+      b.func_stage("gru.cell", [=](hipStream_t s) {
+        return gru_cell_fwd_launch(gi_t, gh_t, ghp, GRU_KSPLIT_FWD, bhh, hp, h_t, hs_t, B, L, s);
+      });
     }
   }
   fwd_chain({&at, &ao}, "actors");
@@ -807,17 +816,20 @@ int build_plan(fdql_agent *a) {
       const float *ca = last ? nullptr : dhz[(t + 1) & 1], *cb = last ? nullptr : dhw;
       float *out_z = dhz[t & 1];
       b.func_stage("gru.cell_bwd", [=](hipStream_t s) {
-        return gru_cell_bwd_launch(dstate + r1, ca, cb, gi + r3, gh + r3, hprev + r1, dgi + r3, dgh + r3, out_z, B, L, s);
+        return gru_cell_bwd_launch(dstate + r1, ca, cb, GRU_KSPLIT_BWD, gi + r3, gh + r3, hprev + r1, dgi + r3, dgh + r3, out_z,
+                                   B, L, s);
       });
       Stage &gs = b.gemm_stage("gru.dh_prev");
       GemmProblem p = Builder::new_gemm(B, L, dhw, L);
       Builder::add_seg(p, dgh + r3, L3, 1, whh, L, 0, L3);
+      p.ksplit = GRU_KSPLIT_BWD;
+      p.split_stride = (long long)B * L;
       gs.gemm.push_back(p);
     }
     if (c.gru_state_mode == 2) {   // learned start state: d hidden_state = sum_b d h_{-1}
       float *out = a->buf("slabs") + a->gru_h0;
       const float *za = dhz[0];
-      b.func_stage("gru.dh0", [=](hipStream_t s) { return gru_dh0_launch(za, dhw, B, L, out, s); });
+      b.func_stage("gru.dh0", [=](hipStream_t s) { return gru_dh0_launch(za, dhw, GRU_KSPLIT_BWD, B, L, out, s); });
     }
   }
   {
@@ -1208,7 +1220,7 @@ int fdql_agent_act(fdql_agent_t *a, const float *obs_1d, const float *achieved_g
     l.in[0] = {hp, L, L}; l.W = a->params + a->gru_whh; l.ldw = L; l.bias = a->params + a->gru_bhh; l.out = gh;
     if (e == hipSuccess) e = act_layer_launch(l, s);
     float *hout = hidden_state ? hidden_state : hn;
-    if (e == hipSuccess) e = gru_cell_fwd_launch(gi, gh, hp, hout, nullptr, rows, L, s);
+    if (e == hipSuccess) e = gru_cell_fwd_launch(gi, gh, nullptr, 0, nullptr, hp, hout, nullptr, rows, L, s);
     state = hout;
   }
   if (e == hipSuccess) { ActSeg x = {state, a->joiner.dout, a->joiner.dout}; e = act_mlp(a, a->actor, &x, 1, rows, top, &logits, s); }

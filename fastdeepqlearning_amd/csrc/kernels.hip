@@ -777,23 +777,35 @@ __global__ void k_gru_h0(int mode, const float *__restrict__ src, float *__restr
   h0[i] = mode == 0 ? 0.f : (mode == 1 ? src[i] : src[i % L]);
 }
 
-__global__ void k_gru_cell_fwd(const float *__restrict__ gi, const float *__restrict__ gh, const float *__restrict__ hprev,
+__global__ void k_gru_cell_fwd(const float *__restrict__ gi, float *__restrict__ gh, const float *__restrict__ gh_parts,
+                               int nparts, const float *__restrict__ b_hh, const float *__restrict__ hprev,
                                float *__restrict__ h, float *__restrict__ hprev_save, int rows, int L) {
 #pragma clang fp contract(off)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * L) return;
   const int b = i / L, l = i - b * L;
   const long long g = (long long)b * 3 * L + l;
-  const float r = sigmoid_f(gi[g] + gh[g]);
-  const float z = sigmoid_f(gi[g + L] + gh[g + L]);
-  const float n = (float)tanh((double)(gi[g + 2 * L] + r * gh[g + 2 * L]));
+  float hr, hz, hn;
+  if (nparts > 0) {   // K-split recurrent product: fixed-order sum of the partials, bias once
+    const long long ps = (long long)rows * 3 * L;
+    hr = b_hh[l]; hz = b_hh[L + l]; hn = b_hh[2 * L + l];
+    for (int p = 0; p < nparts; ++p) {
+      hr += gh_parts[p * ps + g]; hz += gh_parts[p * ps + g + L]; hn += gh_parts[p * ps + g + 2 * L];
+    }
+    gh[g] = hr; gh[g + L] = hz; gh[g + 2 * L] = hn;
+  } else {
+    hr = gh[g]; hz = gh[g + L]; hn = gh[g + 2 * L];
+  }
+  const float r = sigmoid_f(gi[g] + hr);
+  const float z = sigmoid_f(gi[g + L] + hz);
+  const float n = (float)tanh((double)(gi[g + 2 * L] + r * hn));
   const float hp = hprev[i];
   h[i] = (1.f - z) * n + z * hp;
   if (hprev_save) hprev_save[i] = hp;
 }
 
 __global__ void k_gru_cell_bwd(const float *__restrict__ dstate, const float *__restrict__ carry_a,
-                               const float *__restrict__ carry_b, const float *__restrict__ gi,
+                               const float *__restrict__ carry_b, int nparts_b, const float *__restrict__ gi,
                                const float *__restrict__ gh, const float *__restrict__ hprev, float *__restrict__ dgi,
                                float *__restrict__ dgh, float *__restrict__ dh_direct, int rows, int L) {
 #pragma clang fp contract(off)
@@ -802,7 +814,10 @@ __global__ void k_gru_cell_bwd(const float *__restrict__ dstate, const float *__
   const int b = i / L, l = i - b * L;
   const long long g = (long long)b * 3 * L + l;
   float dh = dstate ? dstate[i] : 0.f;
-  if (carry_a) dh += carry_a[i] + carry_b[i];
+  if (carry_a) {
+    dh += carry_a[i];
+    for (int p = 0; p < nparts_b; ++p) dh += carry_b[(long long)p * rows * L + i];
+  }
   const float hn = gh[g + 2 * L];
   const float r = sigmoid_f(gi[g] + gh[g]);
   const float z = sigmoid_f(gi[g + L] + gh[g + L]);
@@ -816,32 +831,49 @@ __global__ void k_gru_cell_bwd(const float *__restrict__ dstate, const float *__
   dh_direct[i] = dh * z;
 }
 
-__global__ void k_gru_dh0(const float *__restrict__ a, const float *__restrict__ b, int B, int L, float *__restrict__ out) {
-  const int l = blockIdx.x * blockDim.x + threadIdx.x;
-  if (l >= L) return;
+// block = 32 columns x 8 row groups; fixed-order reduction through LDS
+__global__ __launch_bounds__(256) void k_gru_dh0(const float *__restrict__ a, const float *__restrict__ b, int nparts_b,
+                                                 int B, int L, float *__restrict__ out) {
+  __shared__ float red[8][33];
+  const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int l = blockIdx.x * 32 + c;
   float s = 0.f;
-  for (int r = 0; r < B; ++r) s += a[(long long)r * L + l] + b[(long long)r * L + l];
-  out[l] = s;
+  if (l < L) {
+    for (int r = rg; r < B; r += 8) {
+      float v = a[(long long)r * L + l];
+      for (int p = 0; p < nparts_b; ++p) v += b[((long long)p * B + r) * L + l];
+      s += v;
+    }
+  }
+  red[rg][c] = s;
+  __syncthreads();
+  if (rg == 0 && l < L) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t += red[j][c];
+    out[l] = t;
+  }
 }
 
 hipError_t gru_h0_launch(int mode, const float *src, float *h0, int B, int L, hipStream_t s) {
   hipLaunchKernelGGL(k_gru_h0, dim3((B * L + 255) / 256), dim3(256), 0, s, mode, src, h0, B, L);
   return hipGetLastError();
 }
-hipError_t gru_cell_fwd_launch(const float *gi, const float *gh, const float *hprev, float *h, float *hprev_save, int rows,
-                               int L, hipStream_t s) {
-  hipLaunchKernelGGL(k_gru_cell_fwd, dim3((rows * L + 255) / 256), dim3(256), 0, s, gi, gh, hprev, h, hprev_save, rows, L);
+hipError_t gru_cell_fwd_launch(const float *gi, float *gh, const float *gh_parts, int nparts, const float *b_hh,
+                               const float *hprev, float *h, float *hprev_save, int rows, int L, hipStream_t s) {
+  hipLaunchKernelGGL(k_gru_cell_fwd, dim3((rows * L + 255) / 256), dim3(256), 0, s, gi, gh, gh_parts, nparts, b_hh, hprev, h,
+                     hprev_save, rows, L);
   return hipGetLastError();
 }
-hipError_t gru_cell_bwd_launch(const float *dstate, const float *carry_a, const float *carry_b, const float *gi,
-                               const float *gh, const float *hprev, float *dgi, float *dgh, float *dh_direct, int rows,
-                               int L, hipStream_t s) {
-  hipLaunchKernelGGL(k_gru_cell_bwd, dim3((rows * L + 255) / 256), dim3(256), 0, s, dstate, carry_a, carry_b, gi, gh, hprev, dgi,
-                     dgh, dh_direct, rows, L);
+hipError_t gru_cell_bwd_launch(const float *dstate, const float *carry_a, const float *carry_b, int nparts_b,
+                               const float *gi, const float *gh, const float *hprev, float *dgi, float *dgh,
+                               float *dh_direct, int rows, int L, hipStream_t s) {
+  hipLaunchKernelGGL(k_gru_cell_bwd, dim3((rows * L + 255) / 256), dim3(256), 0, s, dstate, carry_a, carry_b, nparts_b, gi, gh,
+                     hprev, dgi, dgh, dh_direct, rows, L);
   return hipGetLastError();
 }
-hipError_t gru_dh0_launch(const float *a, const float *b, int B, int L, float *out, hipStream_t s) {
-  hipLaunchKernelGGL(k_gru_dh0, dim3((L + 63) / 64), dim3(64), 0, s, a, b, B, L, out);
+hipError_t gru_dh0_launch(const float *a, const float *b, int nparts_b, int B, int L, float *out, hipStream_t s) {
+  hipLaunchKernelGGL(k_gru_dh0, dim3((L + 31) / 32), dim3(256), 0, s, a, b, nparts_b, B, L, out);
   return hipGetLastError();
 }
 

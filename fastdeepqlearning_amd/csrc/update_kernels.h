@@ -114,15 +114,18 @@ hipError_t prep_launch(const float *task_done, const float *episode_step, int T,
 hipError_t gru_h0_launch(int mode, const float *src, float *h0, int B, int L, hipStream_t s);
 // one time step over `rows` rows: gi, gh [rows, 3L] (input / recurrent pre-activations incl. biases), hprev, h [rows, L];
 // hprev_save (optional): copy of hprev in the [N, L] table the W_hh weight gradient reads
-hipError_t gru_cell_fwd_launch(const float *gi, const float *gh, const float *hprev, float *h, float *hprev_save, int rows,
-                               int L, hipStream_t s);
+// gh_parts: nparts K-split partial sums [nparts][rows, 3L] of W_hh h_prev (no bias) -> summed with b_hh into gh
+// (kept for the backward pass); nparts == 0: gh already holds the complete pre-activation
+hipError_t gru_cell_fwd_launch(const float *gi, float *gh, const float *gh_parts, int nparts, const float *b_hh,
+                               const float *hprev, float *h, float *hprev_save, int rows, int L, hipStream_t s);
 // backward of one step: dh = dstate (or 0) + carry_a + carry_b (or 0); gates recomputed from gi, gh;
 // writes d gi, d gh [rows, 3L] and the direct part of d hprev (dh * z); the part through W_hh is a GEMM on d gh
-hipError_t gru_cell_bwd_launch(const float *dstate, const float *carry_a, const float *carry_b, const float *gi,
-                               const float *gh, const float *hprev, float *dgi, float *dgh, float *dh_direct, int rows,
-                               int L, hipStream_t s);
+// carry_b: nparts_b K-split partial sums [nparts_b][rows, L] of d gh_{t+1} W_hh
+hipError_t gru_cell_bwd_launch(const float *dstate, const float *carry_a, const float *carry_b, int nparts_b,
+                               const float *gi, const float *gh, const float *hprev, float *dgi, float *dgh,
+                               float *dh_direct, int rows, int L, hipStream_t s);
 // d encoder.hidden_state[l] = sum_b (a[b][l] + b[b][l])  (learned start state), fixed order
-hipError_t gru_dh0_launch(const float *a, const float *b, int B, int L, float *out, hipStream_t s);
+hipError_t gru_dh0_launch(const float *a, const float *b, int nparts_b, int B, int L, float *out, hipStream_t s);
 hipError_t tick_alpha_launch(DevState *st, const float *log_alpha, hipStream_t s);
 hipError_t tick_adam_launch(DevState *st, double lr, double b1, double b2, hipStream_t s);
 hipError_t policy_fwd_launch(const PolicyFwdArgs &a0, const PolicyFwdArgs &a1, int nprob, int M, int A,

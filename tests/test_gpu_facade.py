@@ -468,3 +468,46 @@ def test_checkpoint_resume_is_exact(dev, tmp_path):
         agent2.train_step()
     for k, v in agent2.state_dict().items():
         assert torch.equal(v, want[k]), k
+
+
+def test_gru_agent_life_cycle(dev):
+    """EncoderConf.JoinerModeEnum.gru through the facade like franQ.Runner drives it: act() takes the carried
+    agent_state and returns the next one (runner.py:103-106, 157), the replay stores it, train_step scans from
+    the stored state (RnnLatentStateTrainMode.store)."""
+    from fastdeepqlearning_amd import Agent, Replay
+    conf = _conf(dev, T=4, B=16)
+    conf.num_instances = 1
+    ec = conf.encoder_conf
+    ec.joiner_mode = ec.JoinerModeEnum.gru
+    ec.rnn_latent_state_training_mode = ec.RnnLatentStateTrainMode.store
+    try:
+        read_heads, write_heads = Replay.make(conf)
+        agent = Agent.make(conf)
+        assert "encoder.joiner.weight_hh_l0" in agent.state_dict() and "encoder.hidden_state" in agent.state_dict()
+        assert tuple(agent.state_dict()["encoder.joiner.weight_ih_l0"].shape) == (96, 32)
+        h = agent.get_random_hidden()
+        assert tuple(h.shape) == (32,)
+        rng = np.random.RandomState(1)
+        hidden = h.view(1, -1).to(dev)
+        for ep in range(3):
+            for i in range(60):
+                obs = rng.standard_normal(5).astype(np.float32)
+                action, hidden_next, info = agent.act({"obs_1d": torch.tensor(obs).view(1, -1), "agent_state": hidden,
+                                                       "exploit_mask": torch.zeros(1, 1, dtype=torch.bool)})
+                assert tuple(hidden_next.shape) == (1, 32) and not torch.equal(hidden_next, hidden)
+                write_heads[0].add({"obs_1d": obs, "action": action[0].cpu().numpy(), "reward": float(rng.standard_normal()),
+                                    "task_done": False, "episode_done": i == 59, "episode_step": i, "idx": 0,
+                                    "agent_state": hidden[0].cpu().numpy()})
+                hidden = hidden_next
+        agent.enable_training(read_heads)      # after collection: in sync mode act() would train as soon as the ring is ready
+        before = {k: v.clone() for k, v in agent.state_dict().items()}
+        for _ in range(2):
+            agent.train_step()
+        sc = agent.native.scalars()
+        assert np.isfinite(sc["loss"]) and sc["step"] == 2
+        after = agent.state_dict()
+        assert not torch.equal(before["encoder.joiner.weight_hh_l0"], after["encoder.joiner.weight_hh_l0"])
+        assert torch.equal(before["encoder.hidden_state"], after["encoder.hidden_state"])   # unused in store mode
+    finally:
+        ec.joiner_mode = ec.JoinerModeEnum.feedforward      # EncoderConf attributes are class-level defaults
+        ec.rnn_latent_state_training_mode = ec.RnnLatentStateTrainMode.zero

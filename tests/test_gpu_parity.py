@@ -418,6 +418,12 @@ def test_update_matches_oracle_config2(dev, T, B, hid):
     ("config1 dims (Pendulum SAC-min, 2 critics)", dict(obs=3, act=1, C=2, Q=1, T=5, B=128, distributional=False)),
     ("SAC-min + window-long bootstrap lower bound (use_bootstrap_minibatch_nstep), T=50",
      dict(obs=3, act=1, C=2, Q=1, T=50, B=64, distributional=False, bootstrap=True)),
+    ("GRU joiner, learned start state, T=50 scan (encoder.py:40-42, 78-94)",
+     dict(obs=9, act=3, C=2, Q=3, T=50, B=48, gru="learned", latent=64, enc_features=48, enc_hidden=(64,), joint_hidden=(64,),
+          pi_hidden=(64,), critic_hidden=(64, 64))),
+    ("GRU joiner, stored start state + burn-in rows", dict(obs=9, act=3, C=2, Q=3, T=12, B=40, gru="store", burn_in=2,
+                                                          latent=64, enc_features=48, enc_hidden=(64,), joint_hidden=(64,),
+                                                          pi_hidden=(64,), critic_hidden=(64, 64))),
     ("config5 head (discrete SAC, 6 actions, Gumbel-softmax)", dict(obs=64, act=6, discrete=True, C=2, Q=5, T=4, B=128)),
     ("ragged sizes (B=7, odd widths 18/33/21: unaligned rows, partial tiles, M < one tile)",
      dict(obs=3, act=2, C=2, Q=3, T=3, B=7, critic_hidden=(33, 18), pi_hidden=(21,), enc_hidden=(18,), joint_hidden=(33,),
@@ -457,6 +463,8 @@ def test_update_matches_oracle_other_configs(dev, name, kw):
         xp["achieved_goal"] = torch.randn(T, B, spec.goal, generator=g)
         xp["desired_goal"] = torch.randn(T, B, spec.goal, generator=g)
     xp["episode_step"][T // 2:, ::5] = 0.0
+    if spec.gru == "store":
+        xp["agent_state"] = torch.rand(T, B, spec.latent, generator=g)
     nt, na = torch.randn(T - 1, B, A, generator=g), torch.randn(T - 1, B, A, generator=g)
     if spec.discrete:
         nt, na = torch.rand(T - 1, B, A, generator=g), torch.rand(T - 1, B, A, generator=g)
