@@ -28,7 +28,7 @@ class ReplayMemory:
         self.device = torch.device(device if device is not None else "cuda:0")
         self._seed, self._counter = int(seed), 0
         self._ring = None
-        self._keys, self._shapes, self._dims = [], [], []
+        self._keys, self._shapes, self._dims, self._dtypes = [], [], [], []
 
     # ---------------------------------------------------------------- write
     def _jit_initialize(self, experience_dict):
@@ -42,8 +42,10 @@ class ReplayMemory:
             self._keys.append(k)
             self._shapes.append(shape)
             self._dims.append(int(np.prod(shape)) if shape else 1)
+            # replay_memory.py:26-35 keeps the source dtype: uint8 frames stay one byte per element in HBM
+            self._dtypes.append("u8" if a.dtype == np.uint8 and a.ndim > 0 else "f32")
         self._offsets = np.cumsum([0] + self._dims)
-        self._ring = NativeRing(self._maxlen, self._dims, self.device)
+        self._ring = NativeRing(self._maxlen, self._dims, self.device, dtypes=self._dtypes)
 
     def _pack(self, experience_dict, out):
         for j, k in enumerate(self._keys):
@@ -158,7 +160,7 @@ class ReplayMemory:
                     "counter": self._counter, "maxlen": self._maxlen}
         rows, top, n = self._ring.snapshot()
         return {"keys": list(self._keys), "shapes": [tuple(s) for s in self._shapes], "rows": rows, "top": top, "len": n,
-                "counter": self._counter, "maxlen": self._maxlen}
+                "counter": self._counter, "maxlen": self._maxlen, "dtypes": list(self._dtypes)}
 
     def load_state_dict(self, sd):
         if int(sd["maxlen"]) != self._maxlen:
@@ -169,19 +171,22 @@ class ReplayMemory:
         self._keys, self._shapes = list(sd["keys"]), [tuple(s) for s in sd["shapes"]]
         self._dims = [int(np.prod(s)) if s else 1 for s in self._shapes]
         self._offsets = np.cumsum([0] + self._dims)
-        self._ring = NativeRing(self._maxlen, self._dims, self.device)
+        self._dtypes = list(sd.get("dtypes") or ["f32"] * len(self._keys))
+        self._ring = NativeRing(self._maxlen, self._dims, self.device, dtypes=self._dtypes)
         self._ring.restore(sd["rows"], sd["top"], sd["len"])
 
     def save(self, path):
         sd = self.state_dict()
         np.savez(path, rows=sd["rows"], keys=np.asarray(sd["keys"]), top=sd["top"], len=sd["len"], counter=sd["counter"],
-                 maxlen=sd["maxlen"], shapes=np.asarray([",".join(str(int(x)) for x in s) for s in sd["shapes"]]))
+                 maxlen=sd["maxlen"], shapes=np.asarray([",".join(str(int(x)) for x in s) for s in sd["shapes"]]),
+                 dtypes=np.asarray(sd.get("dtypes", [])))
 
     def load(self, path):
         z = np.load(path if str(path).endswith(".npz") else str(path) + ".npz", allow_pickle=False)
         self.load_state_dict({"rows": z["rows"], "keys": [str(k) for k in z["keys"]], "top": int(z["top"]),
                               "len": int(z["len"]), "counter": int(z["counter"]), "maxlen": int(z["maxlen"]),
-                              "shapes": [tuple(int(x) for x in s.split(",") if x) for s in z["shapes"]]})
+                              "shapes": [tuple(int(x) for x in s.split(",") if x) for s in z["shapes"]],
+                              "dtypes": [str(t) for t in z["dtypes"]] if "dtypes" in z.files else None})
 
 
 class AsyncReplayMemory(ReplayMemory):

@@ -82,6 +82,7 @@ SIGNATURES = {
     "fdql_version": (C.c_int, []),
     "fdql_abi_sizes": (None, [C.POINTER(C.c_int32)]),
     "fdql_ring_create": (C.c_int, [C.POINTER(_vp), _i64, _i32, C.POINTER(_i32)]),
+    "fdql_ring_create_typed": (C.c_int, [C.POINTER(_vp), _i64, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "fdql_ring_destroy": (C.c_int, [_vp]),
     "fdql_ring_add": (C.c_int, [_vp, _vp, _i64, _vp]),
     "fdql_ring_add_device": (C.c_int, [_vp, _vp, _i64, _vp]),

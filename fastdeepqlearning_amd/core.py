@@ -17,15 +17,19 @@ class NativeRing:
     """SoA replay ring in HBM (include/fdql.h `fdql_ring_*`;
     reference franQ/Replay/replay_memory.py:18-73)."""
 
-    def __init__(self, maxlen, dims, device="cuda:0"):
+    def __init__(self, maxlen, dims, device="cuda:0", dtypes=None):
+        """dtypes: optional per-key storage type, "f32" (default) or "u8" (pixel keys: one byte per element in
+        HBM, widened to float32 by the gather, like the reference's uint8 ring + TorchDataLoader cast)."""
         self.lib = N.load()
         self.device = torch.device(device)
         self.dims = [int(d) for d in dims]
+        self.dtypes = ["f32"] * len(self.dims) if dtypes is None else [str(t) for t in dtypes]
         self.maxlen = int(maxlen)
         self.handle = C.c_void_p()
         arr = (C.c_int32 * len(self.dims))(*self.dims)
+        types = (C.c_int32 * len(self.dims))(*[{"f32": 0, "u8": 1}[t] for t in self.dtypes])
         with torch.cuda.device(self.device):
-            N.check(self.lib.fdql_ring_create(C.byref(self.handle), self.maxlen, len(self.dims), arr))
+            N.check(self.lib.fdql_ring_create_typed(C.byref(self.handle), self.maxlen, len(self.dims), arr, types))
         self.row_floats = sum(self.dims)
 
     def __del__(self):

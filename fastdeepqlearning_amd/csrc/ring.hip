@@ -24,6 +24,7 @@ struct GatherKey {
   int dim;           // floats gathered per row
   int pitch;         // floats between rows of the ring block
   int staged;        // 1: LDS-staged transposition (narrow rows), 0: direct row copy (wide rows)
+  int u8;            // the ring block holds bytes (src is really `const uint8_t *`, pitch / offsets in elements)
   int tchunk;        // staged: time steps per block
   int block_start;
   int blocks_b, blocks_t;
@@ -124,8 +125,20 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather_windows(GatherArgs a)
       const int t = row / B, b = row - t * B;
       long long srow = a.starts[b] + t;
       if (srow >= len) srow %= len;
-      const float *src = K.src + srow * K.pitch;
       float *dst = K.dst + (long long)row * dim;
+      if (K.u8) {   // widen bytes to float32 (torch_dataloader.py:36), 4 elements per lane step when aligned
+        const uint8_t *sb = reinterpret_cast<const uint8_t *>(K.src) + srow * K.pitch;
+        if ((dim & 3) == 0 && ((reinterpret_cast<uintptr_t>(sb) & 3) == 0)) {
+          for (int e = lane; e < (dim >> 2); e += 64) {
+            const uchar4 v = reinterpret_cast<const uchar4 *>(sb)[e];
+            reinterpret_cast<float4 *>(dst)[e] = make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
+          }
+        } else {
+          for (int e = lane; e < dim; e += 64) dst[e] = (float)sb[e];
+        }
+        continue;
+      }
+      const float *src = K.src + srow * K.pitch;
       if ((dim & 3) == 0 && (K.pitch & 3) == 0 && ((reinterpret_cast<uintptr_t>(K.src) & 15) == 0)) {
         for (int e = lane; e < (dim >> 2); e += 64)
           reinterpret_cast<float4 *>(dst)[e] = reinterpret_cast<const float4 *>(src)[e];
@@ -145,6 +158,7 @@ struct ScatterArgs {
   float *dst[RING_MAX_KEYS];
   int dim[RING_MAX_KEYS];
   int off[RING_MAX_KEYS];
+  int u8[RING_MAX_KEYS];   // the key's block holds bytes
 };
 __global__ void k_scatter_rows(ScatterArgs a) {
   const long long total = a.n * a.rowfloats;
@@ -155,7 +169,9 @@ __global__ void k_scatter_rows(ScatterArgs a) {
     for (int j = 1; j < a.nkeys; ++j)
       if (c >= a.off[j]) k = j;
     const long long slot = (a.top + i) % a.maxlen;
-    a.dst[k][slot * a.dim[k] + (c - a.off[k])] = a.rows[e];
+    const long long at = slot * a.dim[k] + (c - a.off[k]);
+    if (a.u8[k]) reinterpret_cast<uint8_t *>(a.dst[k])[at] = (uint8_t)fminf(fmaxf(a.rows[e], 0.f), 255.f);
+    else a.dst[k][at] = a.rows[e];
   }
 }
 
@@ -169,7 +185,8 @@ __global__ void k_pack_slots(ScatterArgs a) {
     for (int j = 1; j < a.nkeys; ++j)
       if (c >= a.off[j]) k = j;
     const long long slot = a.top + i;
-    const_cast<float *>(a.rows)[e] = a.dst[k][slot * a.dim[k] + (c - a.off[k])];
+    const long long at = slot * a.dim[k] + (c - a.off[k]);
+    const_cast<float *>(a.rows)[e] = a.u8[k] ? (float)reinterpret_cast<const uint8_t *>(a.dst[k])[at] : a.dst[k][at];
   }
 }
 
@@ -319,7 +336,8 @@ struct fdql_ring {
   int dims[RING_MAX_KEYS] = {};
   int offs[RING_MAX_KEYS] = {};
   int rowfloats = 0;
-  float *data[RING_MAX_KEYS] = {};
+  float *data[RING_MAX_KEYS] = {};   // uint8 keys: really `uint8_t *` (element offsets, not float offsets)
+  int u8[RING_MAX_KEYS] = {};
   // bookkeeping (replay_memory.py:45-46)
   int64_t top = 0, len = 0;
   // staging
@@ -356,7 +374,7 @@ int scatter(fdql_ring *r, const float *dev_rows, int64_t n, int64_t top, hipStre
   ScatterArgs a;
   memset(&a, 0, sizeof(a));
   a.nkeys = r->nkeys; a.n = n; a.top = top; a.maxlen = r->maxlen; a.rowfloats = r->rowfloats; a.rows = dev_rows;
-  for (int k = 0; k < r->nkeys; ++k) { a.dst[k] = r->data[k]; a.dim[k] = r->dims[k]; a.off[k] = r->offs[k]; }
+  for (int k = 0; k < r->nkeys; ++k) { a.dst[k] = r->data[k]; a.dim[k] = r->dims[k]; a.off[k] = r->offs[k]; a.u8[k] = r->u8[k]; }
   const long long total = n * r->rowfloats;
   const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
   hipLaunchKernelGGL(k_scatter_rows, dim3(blocks), dim3(256), 0, s, a);
@@ -398,9 +416,11 @@ int gather(fdql_ring *r, int T, int B, const long long *starts, float *const *ou
     const int off = (sel_off && sel_dim && sel_dim[k] > 0) ? sel_off[k] : 0;
     const int dim = (sel_dim && sel_dim[k] > 0) ? sel_dim[k] : r->dims[k];
     FDQL_REQUIRE(off >= 0 && off + dim <= r->dims[k], "selection [%d, %d) outside key %d of width %d", off, off + dim, k, r->dims[k]);
-    g.src = r->data[k] + off; g.dst = out[k]; g.dim = dim; g.pitch = r->dims[k];
+    g.u8 = r->u8[k];
+    g.src = g.u8 ? reinterpret_cast<const float *>(reinterpret_cast<const uint8_t *>(r->data[k]) + off) : r->data[k] + off;
+    g.dst = out[k]; g.dim = dim; g.pitch = r->dims[k];
     g.block_start = total;
-    if (g.dim * 4 < 256 && T > 1) {
+    if (g.dim * 4 < 256 && T > 1 && !g.u8) {
       g.staged = 1;
       int tc = STAGE_LDS_FLOATS / (STAGE_WINDOWS * g.dim);
       g.tchunk = std::max(1, std::min(T, tc));
@@ -426,8 +446,15 @@ int gather(fdql_ring *r, int T, int B, const long long *starts, float *const *ou
 extern "C" {
 
 int fdql_ring_create(fdql_ring_t **out, int64_t maxlen, int32_t n_keys, const int32_t *dims) {
+  return fdql_ring_create_typed(out, maxlen, n_keys, dims, nullptr);
+}
+
+int fdql_ring_create_typed(fdql_ring_t **out, int64_t maxlen, int32_t n_keys, const int32_t *dims, const int32_t *dtypes) {
   FDQL_REQUIRE(out && dims && maxlen > 0 && n_keys > 0 && n_keys <= RING_MAX_KEYS, "bad ring arguments");
+  for (int k = 0; dtypes && k < n_keys; ++k)
+    FDQL_REQUIRE(dtypes[k] == FDQL_F32 || dtypes[k] == FDQL_U8, "key %d: unknown storage type %d", k, dtypes[k]);
   fdql_ring *r = new fdql_ring();
+  for (int k = 0; dtypes && k < n_keys; ++k) r->u8[k] = dtypes[k] == FDQL_U8;
   r->maxlen = maxlen;
   r->nkeys = n_keys;
   for (int k = 0; k < n_keys; ++k) {
@@ -437,7 +464,7 @@ int fdql_ring_create(fdql_ring_t **out, int64_t maxlen, int32_t n_keys, const in
     r->rowfloats += dims[k];
   }
   for (int k = 0; k < n_keys; ++k) {
-    const size_t bytes = (size_t)maxlen * dims[k] * sizeof(float);
+    const size_t bytes = (size_t)maxlen * dims[k] * (r->u8[k] ? 1 : sizeof(float));
     hipError_t e = hipMalloc(&r->data[k], bytes);
     if (e == hipSuccess) e = hipMemset(r->data[k], 0, bytes);  // replay_memory.py:35 np.zeros
     if (e != hipSuccess) { set_error("ring alloc of key %d (%zu bytes): %s", k, bytes, hipGetErrorString(e)); fdql_ring_destroy(r); return FDQL_ENOMEM; }
@@ -603,7 +630,7 @@ int fdql_ring_snapshot(fdql_ring_t *r, float *host_rows_out, int64_t n_slots, vo
     ScatterArgs a;
     memset(&a, 0, sizeof(a));
     a.nkeys = r->nkeys; a.n = n; a.top = done; a.maxlen = r->maxlen; a.rowfloats = F; a.rows = r->dev_stage;
-    for (int k = 0; k < r->nkeys; ++k) { a.dst[k] = r->data[k]; a.dim[k] = r->dims[k]; a.off[k] = r->offs[k]; }
+    for (int k = 0; k < r->nkeys; ++k) { a.dst[k] = r->data[k]; a.dim[k] = r->dims[k]; a.off[k] = r->offs[k]; a.u8[k] = r->u8[k]; }
     const long long total = n * F;
     hipLaunchKernelGGL(k_pack_slots, dim3((int)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, s, a);
     FDQL_HIP(hipGetLastError());
@@ -646,6 +673,7 @@ int64_t fdql_ring_row_floats(const fdql_ring_t *r) { return r ? r->rowfloats : -
 
 int fdql_ring_key_ptr(fdql_ring_t *r, int32_t key, float **dev_ptr) {
   FDQL_REQUIRE(r && dev_ptr && key >= 0 && key < r->nkeys, "bad key");
+  FDQL_REQUIRE(!r->u8[key], "key %d is stored as uint8", key);
   *dev_ptr = r->data[key];
   return 0;
 }

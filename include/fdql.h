@@ -53,6 +53,15 @@ typedef struct fdql_ring fdql_ring_t;
 /* One f32 column block per key: ring[k] is [maxlen, dims[k]] float32 in HBM.  The f32 cast
  * the reference applies at read time (torch_dataloader.py:36) is applied at write time. */
 int fdql_ring_create(fdql_ring_t **out, int64_t maxlen, int32_t n_keys, const int32_t *dims);
+/* Same, with a storage type per key: 0 = float32, 1 = uint8.  The reference ring keeps every key in its
+ * source dtype (replay_memory.py:26-35: a uint8 frame stack stays uint8, 28 224 B per 4x84x84 observation
+ * instead of 113 KB) and TorchDataLoader casts to float32 at read time (torch_dataloader.py:36).  A uint8
+ * key does exactly that: rows still enter and leave the C ABI as float32 (integral values 0..255), the
+ * ring block holds one byte per element and the gather kernel widens on the fly.                        */
+#define FDQL_F32 0
+#define FDQL_U8 1
+int fdql_ring_create_typed(fdql_ring_t **out, int64_t maxlen, int32_t n_keys, const int32_t *dims,
+                           const int32_t *dtypes);
 int fdql_ring_destroy(fdql_ring_t *ring);
 
 /* replay_memory.py:38-46 add(): append `n` packed host rows (sum(dims) floats each, keys in
@@ -76,7 +85,7 @@ int64_t fdql_ring_len(const fdql_ring_t *ring);
 int64_t fdql_ring_top(const fdql_ring_t *ring);
 int64_t fdql_ring_row_floats(const fdql_ring_t *ring);
 /* Device base pointer of key k ([maxlen, dims[k]] f32) — for tests and bulk fills. */
-int fdql_ring_key_ptr(fdql_ring_t *ring, int32_t key, float **dev_ptr);
+int fdql_ring_key_ptr(fdql_ring_t *ring, int32_t key, float **dev_ptr);   /* float32 keys only */
 
 /* replay_memory.py:54-70 temporal_sample(): out[k] is [T, B, dims[k]] f32 (device, caller
  * owned), out[k][t,b,:] = ring[k][(start[b] + t) % len, :].

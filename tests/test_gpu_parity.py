@@ -482,6 +482,52 @@ def test_update_matches_oracle_other_configs(dev, name, kw):
     rep.finish()
 
 
+def test_ring_uint8_keys(dev):
+    """Pixel keys stored as one byte per element (replay_memory.py:26-35 keeps uint8; torch_dataloader.py:36 casts at
+    read time): windows, single rows, sub-row selection and checkpoint round trip are bit-exact against the numpy
+    ring; the HBM block really is maxlen * dim bytes."""
+    from fastdeepqlearning_amd.core import NativeRing
+    from oracle.replay import RingOracle
+    maxlen, T, B = 300, 5, 12
+    dims, dtypes = [4 * 6 * 6, 3, 1, 5], ["u8", "f32", "f32", "u8"]
+    keys = ["frames", "action", "episode_step", "odd_u8"]
+    rng = np.random.RandomState(0)
+    n = 470   # wraps
+    cols = [rng.randint(0, 256, (n, dims[0])).astype(np.float32), rng.standard_normal((n, 3)).astype(np.float32),
+            (np.arange(n) % 40).astype(np.float32).reshape(n, 1), rng.randint(0, 256, (n, 5)).astype(np.float32)]
+    rows = np.concatenate(cols, 1)
+    free0 = torch.cuda.mem_get_info(dev)[0]
+    big = NativeRing(4_000_000, [dims[0]], dev, dtypes=["u8"])
+    used = free0 - torch.cuda.mem_get_info(dev)[0]
+    assert used < 1.25 * 4_000_000 * dims[0] + (64 << 20), used     # ~0.58 GB as bytes; 2.3 GB if it were float32
+    del big
+    ring = NativeRing(maxlen, dims, dev, dtypes=dtypes)
+    ring.add_rows(rows[:200])
+    ring.add_rows(torch.tensor(rows[200:]).to(dev))       # device append path
+    orc = RingOracle(maxlen, B, T)
+    for i in range(n):
+        orc.add({k: c[i] for k, c in zip(keys, cols)})
+    assert len(ring) == len(orc)
+    outs, starts = ring.sample_windows(T, B, seed=3, counter=1, return_starts=True)
+    want = orc.temporal_sample(starts=starts.cpu().numpy())
+    for k, o in zip(keys, outs):
+        assert np.array_equal(o.cpu().numpy(), want[k].astype(np.float32)), k
+    idx = torch.tensor(rng.randint(0, len(ring), 17))
+    got = ring.sample_rows(17, idx=idx)
+    for k, o in zip(keys, got):
+        assert np.array_equal(o.cpu().numpy(), orc.gather(idx.numpy())[k].astype(np.float32)), k
+    sel = ring.sample_windows(T, B, starts=starts, select={0: (36, 72), 3: (1, 3), 1: None})
+    assert sel[1] is None
+    assert np.array_equal(sel[0].cpu().numpy(), want["frames"][..., 36:108].astype(np.float32))
+    assert np.array_equal(sel[3].cpu().numpy(), want["odd_u8"][..., 1:4].astype(np.float32))
+    snap, top, ln = ring.snapshot()
+    ring2 = NativeRing(maxlen, dims, dev, dtypes=dtypes)
+    ring2.restore(snap, top, ln)
+    outs2 = ring2.sample_windows(T, B, starts=starts)
+    for a, b in zip(outs, outs2):
+        assert torch.equal(a, b)
+
+
 def test_ring_full_size_properties(dev):
     """BASELINE size (1M-slot ring, T=50, B=256): size-independent properties instead of an oracle copy.
     Slot i stores its own index, so every gathered element is checkable in closed form:
