@@ -1,5 +1,6 @@
-"""Agent hyper-parameters with the reference's field names and defaults
-(reference: franQ/Agent/conf.py:8-98)."""
+"""Agent hyper-parameters under the reference's field names and defaults (franQ/Agent/conf.py:8-98), so that a conf
+object built for franQ drives this package unchanged.  Attribute and item access are interchangeable
+(franQ/common_utils.py:59-67)."""
 from dataclasses import dataclass
 from enum import Enum
 from pathlib import Path
@@ -29,55 +30,36 @@ class EncoderConf:
     burn_in_portion = 0.2
 
 
+# field -> default, grouped the way the update path consumes them
+_REPLAY = dict(batch_size=256, replay_size=int(5e4), temporal_len=50, use_squashed_rewards=False,
+               use_nStep_lowerbounds=True, nStep_return_steps=1000, use_HER=False, her_mode="final")
+_ALGORITHM = dict(use_distributional_sac=True, use_max_entropy_q=True, use_hard_updates=False, hard_update_interval=200,
+                  use_bootstrap_minibatch_nstep=False, init_log_alpha=-2, gamma=0.99, learning_rate=3e-4, tau=5e-2,
+                  clip_grad_norm=5e-3, top_quantiles_to_drop=0.2)
+_NETWORKS = dict(num_critics=2, num_q_predictions=10, latent_state_dim=256, use_decoder=False,
+                 use_hsv_data_augmentation=False)
+_RUNTIME = dict(algorithm="deep_q_learning", log_extra_debug_info=False, enable_timers=False, log_interval=50,
+                param_update_interval=50, use_async_train=True,
+                inference_input_keys=("obs_1d", "obs_2d", "idx", "achieved_goal", "desired_goal", "agent_state"))
+# additions of this implementation: ring shards per process (the reference's launcher sets it) and data-parallel ranks
+_ADDED = dict(num_instances=1, world_size=1)
+
+
 class AgentConf(AttrDict):
     def __init__(self):
         AttrDict.__init__(self)
         import torch
         from torch import multiprocessing as mp
-        self.algorithm = "deep_q_learning"
-        self.obs_space = None
-        self.action_space = None
-        self.discrete = None
+        for group in (_RUNTIME, _REPLAY, _ALGORITHM, _NETWORKS, _ADDED):
+            for name, default in group.items():
+                self[name] = default
+        # live objects and mutable defaults are made per instance
+        self.obs_space = self.action_space = self.discrete = None     # filled in by the env / launcher
         self.train_step = mp.Value("i", 0)
-        self.inference_input_keys = "obs_1d", "obs_2d", "idx", "achieved_goal", "desired_goal", "agent_state"
-        dev = torch.device("cuda:0" if torch.cuda.is_available() else "cpu:0")
-        self.training_device = dev
-        self.inference_device = dev
+        self.training_device = self.inference_device = torch.device("cuda:0" if torch.cuda.is_available() else "cpu:0")
         self.dtype = torch.float32
         self.eval_envs = [0]
         self.log_dir = Path("logs")
-        self.log_extra_debug_info = False
-        self.enable_timers = False
-        self.log_interval = 50
-        self.param_update_interval = 50
-        self.batch_size = 256
-        self.replay_size = int(5e4)
-        self.temporal_len = 50
-        self.clip_grad_norm = 5e-3
-        self.use_squashed_rewards = False
-        self.use_hard_updates = False
-        self.use_nStep_lowerbounds = True
-        self.nStep_return_steps = 1000
-        self.use_max_entropy_q = True
-        self.use_HER = False
-        self.her_mode = "final"
-        self.use_distributional_sac = True
-        self.init_log_alpha = -2
-        self.gamma = 0.99
-        self.learning_rate = 3e-4
-        self.tau = 5e-2
-        self.hard_update_interval = 200
         self.encoder_conf = EncoderConf()
         self.pi_hidden_dims = [256]
         self.critic_hidden_dims = [256, 256]
-        self.num_critics = 2
-        self.num_q_predictions = 10
-        self.latent_state_dim = 256
-        self.top_quantiles_to_drop = 0.2
-        self.use_bootstrap_minibatch_nstep = False
-        self.use_async_train = True
-        self.use_decoder = False
-        self.use_hsv_data_augmentation = False
-        # additions of this implementation
-        self.num_instances = 1
-        self.world_size = 1

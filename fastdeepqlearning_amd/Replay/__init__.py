@@ -3,25 +3,35 @@ from .replay_memory import ReplayMemory, AsyncReplayMemory, OversampleError
 from . import wrappers
 
 
+def _write_stack(conf, shard, compute_reward):
+    """Write-side wrappers of one shard, innermost first, chosen by the same conf flags as the reference:
+    n-step return (vmap variant under her_mode == "vmap"), reward squash (never together with HER),
+    hindsight relabel outermost."""
+    vmap = conf.use_HER and conf.her_mode == "vmap"
+    head = shard
+    if conf.use_nStep_lowerbounds:
+        cls = wrappers.NStepReturnVmap if conf.her_mode == "vmap" else wrappers.NStepReturn
+        head = cls(head, conf.nStep_return_steps, conf.gamma)
+    if conf.use_squashed_rewards and not conf.use_HER:
+        head = wrappers.SquashRewards(head)
+    if conf.use_HER:
+        if vmap:        # parity unpinned (the reference needs jax); see wrappers/her_vmap.py
+            head = wrappers.HindsightVmapWrite(head, compute_reward)
+        else:
+            head = wrappers.HindsightNStepReplay(head, compute_reward, mode=conf.her_mode)
+    return head
+
+
 def make(conf, **kwargs):
-    """Build one ring shard per env instance plus the write/read wrapper stacks selected by the
-    conf flags; returns ``(read_heads, write_heads)`` exactly like the reference."""
+    """One ring shard per env instance; returns ``(read_heads, write_heads)`` like the reference.  The read
+    heads are the shards themselves (the gather kernel already returns float32 device tensors), wrapped only
+    for the read-time goal selection of HER-vmap."""
     device = getattr(conf, "training_device", "cuda:0")
     shards = [AsyncReplayMemory(int(conf.replay_size), conf.batch_size, conf.temporal_len, device=device, seed=i)
               for i in range(conf.num_instances)]
-    write_heads = read_heads = shards
-    if conf.use_nStep_lowerbounds:
-        if conf.her_mode == "vmap":
-            write_heads = [wrappers.NStepReturnVmap(r, conf.nStep_return_steps, conf.gamma) for r in write_heads]
-        else:
-            write_heads = [wrappers.NStepReturn(r, conf.nStep_return_steps, conf.gamma) for r in write_heads]
-    if conf.use_squashed_rewards and not conf.use_HER:
-        write_heads = [wrappers.SquashRewards(r) for r in write_heads]
-    if conf.use_HER:
-        if conf.her_mode == "vmap":   # parity unpinned (reference needs jax); see wrappers/her_vmap.py
-            write_heads = [wrappers.HindsightVmapWrite(r, kwargs["compute_reward"]) for r in write_heads]
-            read_heads = [wrappers.HindsightVmapRead(r) for r in read_heads]
-        else:
-            write_heads = [wrappers.HindsightNStepReplay(r, kwargs["compute_reward"], mode=conf.her_mode)
-                           for r in write_heads]
+    reward_fn = kwargs.get("compute_reward") if conf.use_HER else None
+    if conf.use_HER and reward_fn is None:
+        raise KeyError("compute_reward")        # the reference indexes kwargs["compute_reward"]
+    write_heads = [_write_stack(conf, s, reward_fn) for s in shards]
+    read_heads = [wrappers.HindsightVmapRead(s) for s in shards] if conf.use_HER and conf.her_mode == "vmap" else shards
     return read_heads, write_heads

@@ -89,6 +89,60 @@ def test_conf_translation_matches_reference_defaults():
         native_config_from_conf(conf)
 
 
+def test_replay_make_selects_the_reference_wrapper_stacks():
+    """franQ/Replay/__init__.py:20-36: which write / read wrappers the conf flags select (no ring is touched:
+    shards allocate lazily)."""
+    from fastdeepqlearning_amd import Replay
+    from fastdeepqlearning_amd.Agent import AgentConf
+    from fastdeepqlearning_amd.Replay import wrappers as W
+
+    def chain(head):
+        names = []
+        while hasattr(head, "replay_buffer"):
+            names.append(type(head).__name__)
+            head = head.replay_buffer
+        return names + [type(head).__name__]
+
+    conf = AgentConf()
+    conf.training_device = "cuda:0"
+    conf.num_instances = 2
+    r, w = Replay.make(conf)
+    assert len(r) == len(w) == 2 and chain(w[0]) == ["NStepReturn", "AsyncReplayMemory"] and r[0] is w[0].replay_buffer
+    conf.use_squashed_rewards = True
+    assert chain(Replay.make(conf)[1][0]) == ["SquashRewards", "NStepReturn", "AsyncReplayMemory"]
+    conf.use_HER = True                       # squash is dropped under HER (:28)
+    with pytest.raises(KeyError):
+        Replay.make(conf)
+    fn = W.SparseL2Reward(0.05)
+    assert chain(Replay.make(conf, compute_reward=fn)[1][0]) == ["HindsightNStepReplay", "NStepReturn", "AsyncReplayMemory"]
+    conf.her_mode = "vmap"
+    r, w = Replay.make(conf, compute_reward=fn)
+    assert chain(w[0]) == ["HindsightVmapWrite", "NStepReturnVmap", "AsyncReplayMemory"] and chain(r[0])[0] == "HindsightVmapRead"
+    conf.use_nStep_lowerbounds = False
+    assert chain(Replay.make(conf, compute_reward=fn)[1][0]) == ["HindsightVmapWrite", "AsyncReplayMemory"]
+
+
+def test_squash_rewards_known_answers():
+    """squash_rewards.py:5-8: h(x) = sign(x)(sqrt(|x|+1)-1) + 0.01 x, applied to the record's reward only."""
+    from fastdeepqlearning_amd.Replay.wrappers import SquashRewards
+
+    class Sink:
+        def __init__(self):
+            self.rows = []
+
+        def add(self, d):
+            self.rows.append(d)
+
+    sink = Sink()
+    w = SquashRewards(sink)
+    xs = [0.0, 3.0, -3.0, 8.0, -0.44, 1e4]
+    for x in xs:
+        w.add({"reward": x, "obs_1d": np.ones(2)})
+    want = [0.0, 1.03, -1.03, 2.08, -(np.sqrt(1.44) - 1) - 0.0044, np.sqrt(10001.0) - 1 + 100.0]
+    np.testing.assert_allclose([r["reward"] for r in sink.rows], want, rtol=1e-12, atol=1e-15)
+    assert all(np.array_equal(r["obs_1d"], np.ones(2)) for r in sink.rows)
+
+
 def test_her_host_relabel_matches_golden_with_callable_reward():
     """A plain Python compute_reward (env code) takes the host branch of the HER wrapper; its
     relabel arithmetic is checked against the reference's emitted sequence."""
