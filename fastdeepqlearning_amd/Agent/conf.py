@@ -28,6 +28,8 @@ class EncoderConf:
     rnn_latent_state_training_mode = RnnLatentStateTrainMode.zero
     use_burn_in = False
     burn_in_portion = 0.2
+    # addition of this implementation: the pixel encoder the reference never had (obs_2d in the obs space)
+    conv_layers = ((32, 8, 4), (64, 4, 2), (64, 3, 1))     # (out_channels, kernel, stride) per layer
 
 
 # field -> default, grouped the way the update path consumes them

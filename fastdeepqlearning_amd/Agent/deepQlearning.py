@@ -31,9 +31,13 @@ def _space_dim(space):
 def native_config_from_conf(conf):
     """Translate a franQ conf (conf.py:8-98, encoder.py:16-33) into the C-ABI config."""
     spaces = conf.obs_space.spaces
-    if "obs_2d" in spaces:
-        raise NotImplementedError("obs_2d: the reference's pixel encoder is dead code (encoder.py:16-23)")
     ec = conf.encoder_conf
+    img, conv = (), ()
+    if "obs_2d" in spaces:
+        # the reference's pixel encoder is dead code (encoder.py:16-23); this build's own conv stack takes its place:
+        # EncoderConf.conv_layers = ((out_channels, kernel, stride), ...), default the 3-layer Atari stack
+        img = tuple(int(v) for v in spaces["obs_2d"].shape)
+        conv = tuple(getattr(ec, "conv_layers", ((32, 8, 4), (64, 4, 2), (64, 3, 1))))
     gru = getattr(getattr(ec, "joiner_mode", None), "name", "feedforward") == "gru"
     gru_mode = getattr(getattr(ec, "rnn_latent_state_training_mode", None), "name", "zero")
     obs = _space_dim(spaces["obs_1d"]) if "obs_1d" in spaces else 0
@@ -53,7 +57,7 @@ def native_config_from_conf(conf):
                        enc_hidden=tuple(ec.obs_1d_hidden_dims), joint_hidden=tuple(ec.joint_hidden_dims),
                        pi_hidden=tuple(conf.pi_hidden_dims), critic_hidden=tuple(conf.critic_hidden_dims),
                        distributional=bool(conf.use_distributional_sac), use_lowerbound=bool(conf.use_nStep_lowerbounds),
-                       use_max_entropy=bool(conf.use_max_entropy_q), bootstrap_nstep=boot, joiner_gru=gru, gru_state_mode=gru_mode,
+                       use_max_entropy=bool(conf.use_max_entropy_q), bootstrap_nstep=boot, joiner_gru=gru, gru_state_mode=gru_mode, img=img, conv=conv,
                        burn_in_steps=int(conf.temporal_len * ec.burn_in_portion) if getattr(ec, "use_burn_in", False) else 0, hard_updates=bool(conf.use_hard_updates),
                        keep_frozen_copy=True, world_size=int(getattr(conf, "world_size", 1) or 1),
                        gamma=float(conf.gamma), tau=float(conf.tau), lr=float(conf.learning_rate),
@@ -215,9 +219,9 @@ class DeepQLearning:
         log_now = (conf.train_step.value % conf.log_interval) == 0
         self._act_calls = getattr(self, "_act_calls", 0) + 1
         res = self.native.act(
-            experiences["obs_1d"], experiences.get("achieved_goal"), experiences.get("desired_goal"),
+            experiences.get("obs_1d"), experiences.get("achieved_goal"), experiences.get("desired_goal"),
             experiences.get("exploit_mask"), noise=noise, seed=self._seed ^ 0xAC7, counter=self._act_calls,
-            want_info=log_now, agent_state=experiences.get("agent_state"))
+            want_info=log_now, agent_state=experiences.get("agent_state"), obs_2d=experiences.get("obs_2d"))
         action, log_prob, explore, exploit = res[:4]
         hidden = res[4] if len(res) > 4 else None   # GRU joiner: the state the runner feeds back (runner.py:157)
         info = {}

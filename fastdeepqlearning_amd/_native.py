@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("FDQL_LIB_PATH") or os.path.join(_HERE, "libfdql_hip.s
 FDQL_OK, FDQL_EINVAL, FDQL_EHIP, FDQL_EOVERSAMPLE, FDQL_ESTATE, FDQL_ENOMEM = 0, -1, -2, -3, -4, -5
 PHASE_ALL, PHASE_GRAD, PHASE_APPLY = 0, 1, 2
 MAX_HIDDEN = 4
+MAX_CONV = 3
 
 
 class NativeLibraryMissing(ImportError):
@@ -41,6 +42,8 @@ class AgentConfig(C.Structure):
         ("n_joint_hidden", C.c_int32), ("joint_hidden", C.c_int32 * MAX_HIDDEN),
         ("n_pi_hidden", C.c_int32), ("pi_hidden", C.c_int32 * MAX_HIDDEN),
         ("n_critic_hidden", C.c_int32), ("critic_hidden", C.c_int32 * MAX_HIDDEN),
+        ("img_c", C.c_int32), ("img_h", C.c_int32), ("img_w", C.c_int32), ("n_conv", C.c_int32),
+        ("conv_out", C.c_int32 * MAX_CONV), ("conv_k", C.c_int32 * MAX_CONV), ("conv_s", C.c_int32 * MAX_CONV),
         ("joiner_gru", C.c_int32), ("gru_state_mode", C.c_int32),
         ("distributional", C.c_int32), ("use_lowerbound", C.c_int32), ("use_max_entropy", C.c_int32),
         ("hard_updates", C.c_int32), ("keep_frozen_copy", C.c_int32), ("bootstrap_nstep", C.c_int32), ("burn_in_steps", C.c_int32),
@@ -52,7 +55,7 @@ class AgentConfig(C.Structure):
 
 class Batch(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("obs_1d", "achieved_goal", "desired_goal", "action", "reward", "mc_return",
-                                          "task_done", "episode_step", "agent_state")]
+                                          "task_done", "episode_step", "obs_2d", "agent_state")]
 
 
 class AgentStats(C.Structure):
@@ -114,7 +117,7 @@ SIGNATURES = {
     "fdql_agent_set_step": (C.c_int, [_vp, _i32, _vp]),
     "fdql_agent_debug_ptr": (C.c_int, [_vp, C.c_char_p, C.POINTER(_vp), C.POINTER(_i64)]),
     "fdql_agent_act_workspace_bytes": (_i64, [_vp, _i32]),
-    "fdql_agent_act": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
+    "fdql_agent_act": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
                                  _vp]),
     "fdql_agent_stats": (C.c_int, [_vp, C.POINTER(AgentStats)]),
     "fdql_agent_profile_update": (_i32, [_vp, C.POINTER(Batch), _vp, _vp, _u64, C.POINTER(KernelTime), _i32, _vp]),

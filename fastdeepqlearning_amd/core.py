@@ -161,7 +161,7 @@ def make_config(obs_dim, act_dim, T, B, goal_dim=0, discrete=False, n_critics=2,
                 distributional=True, use_lowerbound=True, use_max_entropy=True, hard_updates=False,
                 keep_frozen_copy=True, world_size=1, gamma=0.99, tau=5e-2, lr=3e-4, beta1=0.9, beta2=0.999,
                 adam_eps=1e-8, init_log_alpha=-2.0, drop_frac=0.2, bootstrap_nstep=False, burn_in_steps=0, joiner_gru=False,
-                gru_state_mode=0):
+                gru_state_mode=0, img=(), conv=()):
     c = N.AgentConfig()
     c.obs_dim, c.goal_dim, c.act_dim, c.discrete = obs_dim, goal_dim, act_dim, int(discrete)
     c.n_critics, c.n_quantiles, c.latent, c.enc_features = n_critics, n_quantiles, latent, enc_features
@@ -178,6 +178,13 @@ def make_config(obs_dim, act_dim, T, B, goal_dim=0, discrete=False, n_critics=2,
     c.hard_updates, c.keep_frozen_copy = int(hard_updates), int(keep_frozen_copy)
     c.bootstrap_nstep = int(bootstrap_nstep)
     c.burn_in_steps = int(burn_in_steps)
+    if img:      # pixel encoder (a design of this build: the reference has none)
+        c.img_c, c.img_h, c.img_w = (int(v) for v in img)
+        if not 1 <= len(conv) <= N.MAX_CONV:
+            raise ValueError(f"pixel input needs 1..{N.MAX_CONV} conv layers (out_channels, kernel, stride)")
+        c.n_conv = len(conv)
+        for i, (co, k, st) in enumerate(conv):
+            c.conv_out[i], c.conv_k[i], c.conv_s[i] = int(co), int(k), int(st)
     c.joiner_gru = int(bool(joiner_gru))
     c.gru_state_mode = {"zero": 0, "store": 1, "learned": 2}.get(gru_state_mode, gru_state_mode) if joiner_gru else 0
     c.T, c.B, c.world_size = T, B, world_size
@@ -187,7 +194,7 @@ def make_config(obs_dim, act_dim, T, B, goal_dim=0, discrete=False, n_critics=2,
 
 
 BATCH_KEYS = ("obs_1d", "achieved_goal", "desired_goal", "action", "reward", "mc_return", "task_done", "episode_step",
-              "agent_state")
+              "obs_2d", "agent_state")
 
 
 class NativeAgent:
@@ -277,16 +284,22 @@ class NativeAgent:
         return [(arr[i].name.decode(), float(arr[i].ms), float(arr[i].flops), float(arr[i].bytes)) for i in range(n)]
 
     def act(self, obs_1d, achieved_goal=None, desired_goal=None, exploit_mask=None, noise=None, seed=0, counter=0,
-            want_info=True, agent_state=None):
+            want_info=True, agent_state=None, obs_2d=None):
         """deepQlearning.py:155-187 on `rows` observations: encoder -> actor on the online weights in the
         shared arena.  Returns (action, log_prob, explore_action, exploit_action); the last three are None
         unless want_info.  Asynchronous on the current torch stream."""
         dev, cfg = self.device, self.cfg
         f32 = lambda x: torch.as_tensor(x, dtype=torch.float32, device=dev).contiguous()
-        obs = f32(obs_1d)
-        rows = obs.shape[0]
-        if obs.dim() != 2 or obs.shape[1] != cfg.obs_dim:
-            raise ValueError(f"act(): obs_1d must be [rows, {cfg.obs_dim}], got {tuple(obs.shape)}")
+        obs = img = None
+        if cfg.obs_dim:
+            obs = f32(obs_1d)
+            if obs.dim() != 2 or obs.shape[1] != cfg.obs_dim:
+                raise ValueError(f"act(): obs_1d must be [rows, {cfg.obs_dim}], got {tuple(obs.shape)}")
+        if cfg.img_c:
+            img = f32(obs_2d)
+            if img.dim() != 4 or tuple(img.shape[1:]) != (cfg.img_c, cfg.img_h, cfg.img_w):
+                raise ValueError(f"act(): obs_2d must be [rows, {cfg.img_c}, {cfg.img_h}, {cfg.img_w}]")
+        rows = (obs if obs is not None else img).shape[0]
         ag = dg = None
         if cfg.goal_dim:
             ag, dg = f32(achieved_goal), f32(desired_goal)
@@ -316,9 +329,9 @@ class NativeAgent:
                 hs_in = f32(agent_state)
                 if tuple(hs_in.shape) != (rows, cfg.latent):
                     raise ValueError(f"act(): agent_state must be [rows, {cfg.latent}]")
-        self._act_keep = (obs, ag, dg, mask, noise, hs_in)
+        self._act_keep = (obs, ag, dg, mask, noise, hs_in, img)
         with torch.cuda.device(dev):
-            N.check(self.lib.fdql_agent_act(self.handle, N.ptr(obs), N.ptr(ag), N.ptr(dg), N.ptr(hs_in),
+            N.check(self.lib.fdql_agent_act(self.handle, N.ptr(obs), N.ptr(ag), N.ptr(dg), N.ptr(img), N.ptr(hs_in),
                                             C.c_void_p(mask.data_ptr()) if mask is not None else None, N.ptr(noise),
                                             int(seed), int(counter), rows, N.ptr(action), N.ptr(logp), N.ptr(explore),
                                             N.ptr(exploit), N.ptr(hs_out), C.c_void_p(self._act_ws.data_ptr()),

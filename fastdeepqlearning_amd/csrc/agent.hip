@@ -109,6 +109,10 @@ struct fdql_agent {
   MlpDesc enc_obs, joiner, actor;
   std::vector<MlpDesc> critic;
   int64_t log_alpha_off = 0;
+  // pixel encoder (cfg.img_c > 0): geometry and arena offsets of each conv layer; conv_feat = flattened output width
+  struct ConvLayer { ConvGeom g; int cout; int64_t w_off, b_off; };
+  std::vector<ConvLayer> conv;
+  int conv_feat = 0;
   // GRU joiner (cfg.joiner_gru): offsets of weight_ih_l0 [3L,F], weight_hh_l0 [3L,L], bias_ih_l0, bias_hh_l0 [3L],
   // encoder.hidden_state [L] in the trainable arena
   int64_t gru_wih = 0, gru_whh = 0, gru_bih = 0, gru_bhh = 0, gru_h0 = 0;
@@ -173,7 +177,27 @@ void add_mlp(fdql_agent *a, MlpDesc &m, const std::string &prefix, int din, cons
 int layout(fdql_agent *a) {
   const fdql_agent_config_t &c = a->cfg;
   int64_t top = 0;
-  add_mlp(a, a->enc_obs, "encoder.visible_layer_encoders.obs_1d", c.obs_dim + 2 * c.goal_dim, c.enc_hidden,
+  a->conv.clear();
+  a->conv_feat = 0;
+  if (c.img_c > 0) {
+    int ci = c.img_c, h = c.img_h, w = c.img_w;
+    for (int i = 0; i < c.n_conv; ++i) {
+      fdql_agent::ConvLayer L;
+      L.g.C = ci; L.g.H = h; L.g.W = w; L.g.k = c.conv_k[i]; L.g.s = c.conv_s[i];
+      L.g.OH = (h - L.g.k) / L.g.s + 1; L.g.OW = (w - L.g.k) / L.g.s + 1;
+      L.cout = c.conv_out[i];
+      const int K = ci * L.g.k * L.g.k;
+      const std::string pre = "encoder.visible_layer_encoders.obs_2d.conv." + std::to_string(i);
+      a->tensors.push_back({pre + ".weight", 0, top, L.cout, K});
+      L.w_off = top; top += pad4((int64_t)L.cout * K);
+      a->tensors.push_back({pre + ".bias", 0, top, L.cout, 0});
+      L.b_off = top; top += pad4(L.cout);
+      a->conv.push_back(L);
+      ci = L.cout; h = L.g.OH; w = L.g.OW;
+    }
+    a->conv_feat = ci * h * w;
+  }
+  add_mlp(a, a->enc_obs, "encoder.visible_layer_encoders.obs_1d", c.obs_dim + 2 * c.goal_dim + a->conv_feat, c.enc_hidden,
           c.n_enc_hidden, c.enc_features, top);
   if (c.joiner_gru) {   // nn.GRU(hidden_features, latent, 1) + learnable start state (encoder.py:41-42)
     const int L3 = 3 * c.latent;
@@ -254,6 +278,15 @@ void carve(fdql_agent *a) {
     }
     if (out) a->alloc(p + ".out", rows * d.dout);
   };
+  for (size_t i = 0; i < a->conv.size(); ++i) {   // im2col matrix, NHWC output, and their gradients over the M images
+    const fdql_agent::ConvLayer &L = a->conv[i];
+    const int64_t pos = (int64_t)L.g.OH * L.g.OW, K = (int64_t)L.g.C * L.g.k * L.g.k;
+    const std::string p = "conv" + std::to_string(i);
+    a->alloc(p + ".col", N * pos * K);
+    a->alloc(p + ".out", N * pos * L.cout);
+    a->alloc(p + ".dpre", M * pos * L.cout);
+    if (i > 0) a->alloc(p + ".dcol", M * pos * K);
+  }
   mlp_bufs("enc_obs", a->enc_obs, N, true, true);
   if (c.joiner_gru) {
     const int64_t L3 = 3 * c.latent, Bw = a->B;
@@ -543,10 +576,16 @@ int build_plan(fdql_agent *a) {
 
   // ---- instances
   MlpInst eo = make_inst(a, a->enc_obs, "enc_obs", params, 0, N, true);
-  eo.in.push_back({x.obs_1d, c.obs_dim, c.obs_dim});
+  if (c.obs_dim) eo.in.push_back({x.obs_1d, c.obs_dim, c.obs_dim});
   if (c.goal_dim) {
     eo.in.push_back({x.achieved_goal, c.goal_dim, c.goal_dim});
     eo.in.push_back({x.desired_goal, c.goal_dim, c.goal_dim});
+  }
+  const int nconv = (int)a->conv.size();
+  const int conv_col0 = c.obs_dim + 2 * c.goal_dim;   // first column of the conv features in the obs MLP's input
+  if (nconv) {
+    const float *feat = a->buf("conv" + std::to_string(nconv - 1) + ".out");
+    eo.in.push_back({feat, a->conv_feat, a->conv_feat});
   }
   eo.out = a->buf("enc_obs.out"); eo.ldout = c.enc_features;
   const bool gru = c.joiner_gru != 0;
@@ -615,6 +654,25 @@ int build_plan(fdql_agent *a) {
     Stage &hs = b.gemm_stage(name + ".head");
     for (MlpInst *m : group) hs.gemm.push_back(b.fwd_head(*m));
   };
+  for (int i = 0; i < nconv; ++i) {   // pixel encoder forward: im2col + GEMM (bias, LeakyReLU) per layer, all N images
+    const fdql_agent::ConvLayer &Lc = a->conv[i];
+    const ConvGeom g = Lc.g;
+    const int K = g.C * g.k * g.k;
+    const long long rows = (long long)N * g.OH * g.OW;
+    FDQL_REQUIRE(rows < (1LL << 31), "conv layer %d: %lld im2col rows exceed the GEMM's 32-bit row index", i, rows);
+    float *col = a->buf("conv" + std::to_string(i) + ".col"), *out = a->buf("conv" + std::to_string(i) + ".out");
+    const float *in = i == 0 ? x.obs_2d : a->buf("conv" + std::to_string(i - 1) + ".out");
+    const int nhwc = i > 0;
+    const float scale = i == 0 ? 1.0f / 255.0f : 1.0f;
+    const long long nimg = N;
+    b.func_stage("conv.im2col", [=](hipStream_t s) { return im2col_launch(in, nhwc, scale, nimg, g, col, s); });
+    Stage &gs = b.gemm_stage("conv.fwd" + std::to_string(i));
+    GemmProblem p = Builder::new_gemm((int)rows, Lc.cout, out, Lc.cout);
+    Builder::add_seg(p, col, K, 1, params + Lc.w_off, K, 1, K);
+    p.bias = params + Lc.b_off;
+    p.epi = EPI_LRELU;
+    gs.gemm.push_back(p);
+  }
   fwd_chain({&eo}, "enc_obs");
   if (!gru) {
     fwd_chain({&jo}, "joiner");
@@ -847,6 +905,34 @@ int build_plan(fdql_agent *a) {
     gs.gemm.push_back(b.bwd_dpre(eb, i, a->buf("denc"), c.enc_features));
     hosts.push_back(a->stages.size() - 1);
   }
+  // ---- pixel encoder backward (M images): d features -> per layer [dW, db], d col -> col2im -> previous layer
+  if (nconv) {
+    const int last = nconv - 1, F2 = a->conv_feat;
+    {
+      Stage &gs = b.gemm_stage("conv.dfeat");
+      GemmProblem p = Builder::new_gemm(M, F2, a->buf("conv" + std::to_string(last) + ".dpre"), F2);
+      b.input_grad_segs(eb, a->buf("denc"), c.enc_features, conv_col0, p);
+      p.epi = EPI_LRELU_GRAD;
+      p.ref = a->buf("conv" + std::to_string(last) + ".out");
+      p.ldref = F2;
+      gs.gemm.push_back(p);
+    }
+    for (int i = last; i > 0; --i) {
+      const fdql_agent::ConvLayer &Lc = a->conv[i];
+      const ConvGeom g = Lc.g;
+      const int K = g.C * g.k * g.k;
+      const long long rows = (long long)M * g.OH * g.OW;
+      float *dcol = a->buf("conv" + std::to_string(i) + ".dcol");
+      Stage &gs = b.gemm_stage("conv.dcol" + std::to_string(i));
+      GemmProblem p = Builder::new_gemm((int)rows, K, dcol, K);
+      Builder::add_seg(p, a->buf("conv" + std::to_string(i) + ".dpre"), Lc.cout, 1, params + Lc.w_off, K, 0, Lc.cout);
+      gs.gemm.push_back(p);
+      const float *act_prev = a->buf("conv" + std::to_string(i - 1) + ".out");
+      float *dprev = a->buf("conv" + std::to_string(i - 1) + ".dpre");
+      const long long nimg = M;
+      b.func_stage("conv.col2im", [=](hipStream_t s) { return col2im_mask_launch(dcol, act_prev, nimg, g, dprev, s); });
+    }
+  }
   // ---- weight gradients (K-split slabs) + column sums
   {
     Stage tail, ws;
@@ -869,6 +955,15 @@ int build_plan(fdql_agent *a) {
       b.wgrad_bias(M, a->buf("gru.dgi"), L3, L3, nullptr, slab + a->gru_bih, ws);
     }
     b.wgrads(eb, a->buf("denc"), c.enc_features, a->buf("cs.denc"), tail, tail, ws);
+    for (int i = 0; i < nconv; ++i) {   // conv weights: dW = d pre^T col over the M*OH*OW rows, bias = column sums
+      const fdql_agent::ConvLayer &Lc = a->conv[i];
+      const int K = Lc.g.C * Lc.g.k * Lc.g.k;
+      const int R = (int)((long long)M * Lc.g.OH * Lc.g.OW);
+      float *slab = a->buf("slabs");
+      const float *dpre = a->buf("conv" + std::to_string(i) + ".dpre");
+      b.wgrad_gemm(R, dpre, Lc.cout, Lc.cout, a->buf("conv" + std::to_string(i) + ".col"), K, K, slab + Lc.w_off, K, tail, tail);
+      b.wgrad_bias(R, dpre, Lc.cout, Lc.cout, nullptr, slab + Lc.b_off, ws);
+    }
     a->stages.push_back(tail);
     a->stages.push_back(ws);
   }
@@ -919,8 +1014,10 @@ hipError_t run_stage(fdql_agent *a, Stage &s, hipStream_t stream) {
 int prepare_update(fdql_agent *a, const fdql_batch_t *batch, const float *noise_target, const float *noise_actor,
                    uint64_t seed) {
   if (!a || !a->bound) { set_error("fdql_agent_update: agent not bound"); return FDQL_ESTATE; }
-  FDQL_REQUIRE(batch && batch->obs_1d && batch->action && batch->reward && batch->task_done && batch->episode_step,
-               "fdql_agent_update: batch needs obs_1d, action, reward, task_done, episode_step");
+  FDQL_REQUIRE(batch && batch->action && batch->reward && batch->task_done && batch->episode_step,
+               "fdql_agent_update: batch needs action, reward, task_done, episode_step");
+  FDQL_REQUIRE(!a->cfg.obs_dim || batch->obs_1d, "obs_dim > 0 needs obs_1d");
+  FDQL_REQUIRE(!a->cfg.img_c || batch->obs_2d, "img_c > 0 needs obs_2d");
   FDQL_REQUIRE(!a->cfg.goal_dim || (batch->achieved_goal && batch->desired_goal), "goal_dim > 0 needs achieved/desired goal");
   FDQL_REQUIRE(!a->cfg.use_lowerbound || batch->mc_return, "use_lowerbound needs mc_return");
   FDQL_REQUIRE(!(a->cfg.joiner_gru && a->cfg.gru_state_mode == 1) || batch->agent_state,
@@ -955,7 +1052,17 @@ void fdql_abi_sizes(int32_t *out6) {
 int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {
   FDQL_REQUIRE(out && cfg, "null argument");
   const fdql_agent_config_t &c = *cfg;
-  FDQL_REQUIRE(c.obs_dim > 0 && c.act_dim > 0 && c.goal_dim >= 0, "bad obs/act/goal dims");
+  FDQL_REQUIRE(c.obs_dim >= 0 && c.act_dim > 0 && c.goal_dim >= 0 && c.img_c >= 0 && (c.obs_dim > 0 || c.img_c > 0),
+               "bad obs/act/goal dims");
+  if (c.img_c > 0) {
+    FDQL_REQUIRE(c.n_conv >= 1 && c.n_conv <= FDQL_MAX_CONV && c.img_h > 0 && c.img_w > 0, "pixel input needs 1..%d conv layers", FDQL_MAX_CONV);
+    int h = c.img_h, w = c.img_w;
+    for (int i = 0; i < c.n_conv; ++i) {
+      FDQL_REQUIRE(c.conv_out[i] > 0 && c.conv_k[i] > 0 && c.conv_s[i] > 0 && c.conv_k[i] <= h && c.conv_k[i] <= w,
+                   "conv layer %d: bad channels / kernel / stride for a %dx%d map", i, h, w);
+      h = (h - c.conv_k[i]) / c.conv_s[i] + 1; w = (w - c.conv_k[i]) / c.conv_s[i] + 1;
+    }
+  }
   FDQL_REQUIRE(!c.discrete || c.act_dim <= 32, "discrete actor: at most 32 actions");
   FDQL_REQUIRE(c.n_critics > 0 && c.n_quantiles > 0 && c.n_critics * c.n_quantiles <= 256, "need 0 < C*Q <= 256");
   FDQL_REQUIRE(2 * c.n_critics + 2 <= GEMM_MAX_SEG, "too many critics for one d(state) GEMM");
@@ -1140,7 +1247,12 @@ int64_t fdql_agent_act_workspace_bytes(const fdql_agent_t *a, int32_t rows) {
   int64_t joiner = act_mlp_floats(a->joiner, rows);
   if (a->cfg.joiner_gru)   // gi, gh [rows, 3L], zero start state and the new state [rows, L]
     joiner = 2 * pad4((int64_t)rows * 3 * a->cfg.latent) + 2 * pad4((int64_t)rows * a->cfg.latent);
-  return 4 * (act_mlp_floats(a->enc_obs, rows) + joiner + act_mlp_floats(a->actor, rows));
+  int64_t conv = 0;   // im2col matrix + NHWC output of every conv layer
+  for (const auto &Lc : a->conv) {
+    const int64_t pos = (int64_t)rows * Lc.g.OH * Lc.g.OW;
+    conv += pad4(pos * Lc.g.C * Lc.g.k * Lc.g.k) + pad4(pos * Lc.cout);
+  }
+  return 4 * (conv + act_mlp_floats(a->enc_obs, rows) + joiner + act_mlp_floats(a->actor, rows));
 }
 
 namespace {
@@ -1175,14 +1287,14 @@ hipError_t act_mlp(const fdql_agent *a, const MlpDesc &d, const ActSeg *in, int 
 }  // namespace
 
 int fdql_agent_act(fdql_agent_t *a, const float *obs_1d, const float *achieved_goal, const float *desired_goal,
-                   const float *agent_state, const uint8_t *exploit_mask, const float *noise, uint64_t seed,
-                   uint64_t counter, int32_t rows, float *action, float *log_prob, float *explore_action,
+                   const float *obs_2d, const float *agent_state, const uint8_t *exploit_mask, const float *noise,
+                   uint64_t seed, uint64_t counter, int32_t rows, float *action, float *log_prob, float *explore_action,
                    float *exploit_action, float *hidden_state, void *workspace, int64_t workspace_bytes, void *stream) {
   if (!a || !a->bound) { set_error("fdql_agent_act: agent not bound"); return FDQL_ESTATE; }
   FDQL_REQUIRE(rows >= 0, "fdql_agent_act: rows < 0");
   if (rows == 0) return 0;
   const fdql_agent_config_t &c = a->cfg;
-  FDQL_REQUIRE(obs_1d && action, "fdql_agent_act: obs_1d and action are required");
+  FDQL_REQUIRE(action && (obs_1d || !c.obs_dim) && (obs_2d || !c.img_c), "fdql_agent_act: action and the observation inputs are required");
   FDQL_REQUIRE(!c.goal_dim || (achieved_goal && desired_goal), "goal_dim > 0 needs achieved/desired goal");
   FDQL_REQUIRE(workspace && workspace_bytes >= fdql_agent_act_workspace_bytes(a, rows) &&
                    (reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
@@ -1191,15 +1303,34 @@ int fdql_agent_act(fdql_agent_t *a, const float *obs_1d, const float *achieved_g
   FDQL_REQUIRE((int)a->enc_obs.hid.size() + 3 <= ACT_MAX_SEG, "too many hidden layers for act()");
   hipStream_t s = (hipStream_t)stream;
   float *top = (float *)workspace;
-  ActSeg in[3];
+  ActSeg in[4];
   int nin = 0;
-  in[nin++] = {obs_1d, c.obs_dim, c.obs_dim};
+  if (c.obs_dim) in[nin++] = {obs_1d, c.obs_dim, c.obs_dim};
   if (c.goal_dim) {  // encoder.py:54-58: cat(obs_1d, achieved_goal, desired_goal) as K-segments
     in[nin++] = {achieved_goal, c.goal_dim, c.goal_dim};
     in[nin++] = {desired_goal, c.goal_dim, c.goal_dim};
   }
   float *enc = nullptr, *state = nullptr, *logits = nullptr;
-  hipError_t e = act_mlp(a, a->enc_obs, in, nin, rows, top, &enc, s);
+  hipError_t e = hipSuccess;
+  {   // pixel encoder: im2col + one skinny layer launch per conv layer (rows * OH * OW "batch rows")
+    const float *cin = obs_2d;
+    for (size_t i = 0; i < a->conv.size() && e == hipSuccess; ++i) {
+      const fdql_agent::ConvLayer &Lc = a->conv[i];
+      const int K = Lc.g.C * Lc.g.k * Lc.g.k;
+      const int64_t pos = (int64_t)rows * Lc.g.OH * Lc.g.OW;
+      float *col = top; top += pad4(pos * K);
+      float *out = top; top += pad4(pos * Lc.cout);
+      e = im2col_launch(cin, i > 0, i == 0 ? 1.0f / 255.0f : 1.0f, rows, Lc.g, col, s);
+      ActLayerArgs l;
+      memset(&l, 0, sizeof(l));
+      l.in[0] = {col, K, K}; l.nseg = 1; l.W = a->params + Lc.w_off; l.ldw = K; l.bias = a->params + Lc.b_off;
+      l.out = out; l.ldo = Lc.cout; l.N = Lc.cout; l.rows = (int)pos; l.leaky = 1;
+      if (e == hipSuccess) e = act_layer_launch(l, s);
+      cin = out;
+    }
+    if (!a->conv.empty()) in[nin++] = {cin, a->conv_feat, a->conv_feat};
+  }
+  if (e == hipSuccess) e = act_mlp(a, a->enc_obs, in, nin, rows, top, &enc, s);
   if (e == hipSuccess && !c.joiner_gru) {
     ActSeg x = {enc, a->enc_obs.dout, a->enc_obs.dout};
     e = act_mlp(a, a->joiner, &x, 1, rows, top, &state, s);

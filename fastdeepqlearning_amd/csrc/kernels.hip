@@ -2,6 +2,7 @@
 // loss with its analytic gradient, slab reduction, Adam + polyak.  gfx950, wave64.
 #include "common.h"
 #include "update_kernels.h"
+#include <algorithm>
 
 namespace fdql {
 
@@ -760,6 +761,66 @@ hipError_t policy_bwd_launch(const float *logits, const float *noise, const floa
   else
     hipLaunchKernelGGL(k_policy_bwd, dim3((M + 255) / 256), dim3(256), 0, s, logits, noise, action, dpi_parts, nparts,
                        dpi_sum, w, st, M, A, dlogits);
+  return hipGetLastError();
+}
+
+// ======================================================================================
+// Pixel encoder: im2col / col2im around the grouped GEMM (no reference; see include/fdql.h)
+// ======================================================================================
+__global__ void k_im2col(const float *__restrict__ in, int nhwc, float scale, long long n_img, ConvGeom g,
+                         float *__restrict__ col) {
+  const int K = g.C * g.k * g.k;
+  const long long total = n_img * g.OH * g.OW * K;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long row = e / K;
+    const int kk = (int)(e - row * K);
+    const int c = kk / (g.k * g.k), r2 = kk - c * g.k * g.k, ky = r2 / g.k, kx = r2 - ky * g.k;
+    const long long img = row / (g.OH * g.OW);
+    const int pos = (int)(row - img * g.OH * g.OW), oy = pos / g.OW, ox = pos - oy * g.OW;
+    const int y = oy * g.s + ky, x = ox * g.s + kx;
+    const long long src = nhwc ? ((img * g.H + y) * g.W + x) * g.C + c : ((img * g.C + c) * g.H + y) * g.W + x;
+    col[e] = in[src] * scale;
+  }
+}
+
+__global__ void k_col2im_mask(const float *__restrict__ dcol, const float *__restrict__ act_prev, long long n_img, ConvGeom g,
+                              float *__restrict__ dpre_prev) {
+  const int K = g.C * g.k * g.k;
+  const long long total = n_img * g.H * g.W * g.C;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % g.C);
+    const long long p = e / g.C;
+    const int x = (int)(p % g.W);
+    const long long q = p / g.W;
+    const int y = (int)(q % g.H);
+    const long long img = q / g.H;
+    float acc = 0.f;
+    for (int ky = y % g.s; ky < g.k; ky += g.s) {       // windows with oy*s + ky == y
+      const int oy = (y - ky) / g.s;
+      if (y < ky || oy >= g.OH) continue;
+      for (int kx = x % g.s; kx < g.k; kx += g.s) {
+        const int ox = (x - kx) / g.s;
+        if (x < kx || ox >= g.OW) continue;
+        acc += dcol[((img * g.OH + oy) * g.OW + ox) * K + (c * g.k + ky) * g.k + kx];
+      }
+    }
+    dpre_prev[e] = act_prev[e] > 0.f ? acc : 0.01f * acc;
+  }
+}
+
+hipError_t im2col_launch(const float *in, int nhwc, float scale, long long n_img, const ConvGeom &g, float *col, hipStream_t s) {
+  const long long total = n_img * g.OH * g.OW * g.C * g.k * g.k;
+  if (total <= 0) return hipSuccess;
+  const int blocks = (int)std::min<long long>((total + 255) / 256, 1 << 20);
+  hipLaunchKernelGGL(k_im2col, dim3(blocks), dim3(256), 0, s, in, nhwc, scale, n_img, g, col);
+  return hipGetLastError();
+}
+hipError_t col2im_mask_launch(const float *dcol, const float *act_prev, long long n_img, const ConvGeom &g, float *dpre_prev,
+                              hipStream_t s) {
+  const long long total = n_img * g.H * g.W * g.C;
+  if (total <= 0) return hipSuccess;
+  const int blocks = (int)std::min<long long>((total + 255) / 256, 1 << 20);
+  hipLaunchKernelGGL(k_col2im_mask, dim3(blocks), dim3(256), 0, s, dcol, act_prev, n_img, g, dpre_prev);
   return hipGetLastError();
 }
 

@@ -109,6 +109,19 @@ hipError_t reduce_slabs_launch(const float *slabs, int nslab, long long n, float
 hipError_t adam_launch(const AdamArgs &a, hipStream_t s);
 hipError_t prep_launch(const float *task_done, const float *episode_step, int T, int B, int burn_in, int cumprod,
                        float inv_gb, float *w, float *contig, hipStream_t s);
+// ---- pixel encoder (design of this build; no reference): convolutions as im2col + the grouped GEMM
+struct ConvGeom {
+  int C, H, W;      // input feature map
+  int k, s;         // square kernel, stride (no padding)
+  int OH, OW;       // output positions
+};
+// col[(img*OH + oy)*OW + ox][c*k*k + ky*k + kx] = scale * in(img, c, oy*s + ky, ox*s + kx);
+// in is NCHW (the batch's frames) or NHWC (a previous layer's output [img*H*W, C])
+hipError_t im2col_launch(const float *in, int nhwc, float scale, long long n_img, const ConvGeom &g, float *col, hipStream_t s);
+// d(pre-activation of the previous layer) = col2im(dcol) * LeakyReLU'(act_prev), NHWC [n_img*H*W, C]:
+// a gather over the <= ceil(k/s)^2 windows that cover a pixel (fixed order, no atomics)
+hipError_t col2im_mask_launch(const float *dcol, const float *act_prev, long long n_img, const ConvGeom &g, float *dpre_prev,
+                              hipStream_t s);
 // ---- GRU joiner (torch.nn.GRU cell, gate order r, z, n; encoder.py:40-42)
 // start state of the scan: mode 0 zeros, 1 rows copied from src [B, L], 2 src [L] repeated over the batch
 hipError_t gru_h0_launch(int mode, const float *src, float *h0, int B, int L, hipStream_t s);

@@ -189,6 +189,7 @@ int fdql_episode_mc_return_vmap(const float *rewards, const float *dones, float 
 typedef struct fdql_agent fdql_agent_t;
 
 #define FDQL_MAX_HIDDEN 4
+#define FDQL_MAX_CONV 3
 
 typedef struct {
   /* shapes — franQ/Agent/conf.py:8-98, encoder.py:26-32 */
@@ -200,6 +201,13 @@ typedef struct {
   int32_t n_joint_hidden, joint_hidden[FDQL_MAX_HIDDEN];
   int32_t n_pi_hidden, pi_hidden[FDQL_MAX_HIDDEN];
   int32_t n_critic_hidden, critic_hidden[FDQL_MAX_HIDDEN];
+  /* Pixel observations (BASELINE config 5).  THE REFERENCE HAS NO SUCH ENCODER (encoder.py:16-23 is dead code): this is
+   * a design of this build - batch.obs_2d [T,B,img_c,img_h,img_w] (values 0..255) is scaled by 1/255 and run through
+   * n_conv strided convolutions (conv_out channels, conv_k x conv_k kernels, stride conv_s, no padding) with
+   * LeakyReLU(0.01); the last feature map, flattened in (y, x, channel) order, is fed to the obs MLP next to obs_1d /
+   * the goals.  img_c == 0: no pixel input.  obs_dim may then be 0.                                                 */
+  int32_t img_c, img_h, img_w, n_conv;
+  int32_t conv_out[FDQL_MAX_CONV], conv_k[FDQL_MAX_CONV], conv_s[FDQL_MAX_CONV];
   /* encoder joiner: 0 = SkipHeadMLP (EncoderConf.JoinerModeEnum.feedforward), 1 = one nn.GRU layer scanned
    * over the T axis (JoinerModeEnum.gru; encoder.py:40-42, 78-94).  gru_state_mode = where the scan starts
    * (EncoderConf.RnnLatentStateTrainMode): 0 zero, 1 store (batch.agent_state[0]), 2 learned
@@ -248,6 +256,7 @@ int fdql_agent_bind(fdql_agent_t *agent, float *params, float *grads, float *ada
 typedef struct {
   const float *obs_1d, *achieved_goal, *desired_goal, *action;
   const float *reward, *mc_return, *task_done, *episode_step;
+  const float *obs_2d;        /* [T,B,img_c,img_h,img_w] pixel frames as float32 (0..255), iff img_c > 0                        */
   const float *agent_state;   /* [T,B,latent]: hidden state the actor had at each step (runner.py:157); read iff
                                  joiner_gru && gru_state_mode == 1, row block t = 0 only (encoder.py:83-84)     */
 } fdql_batch_t;
@@ -282,7 +291,8 @@ int fdql_agent_debug_ptr(fdql_agent_t *agent, const char *name, const float **de
  * instance), reading the ONLINE weights straight from the bound parameter arena - the actors see
  * the trainer's current weights with no state_dict hop (the reference ships a full state_dict
  * through a queue every 50 steps, deepQlearning.py:136-148).
- *   obs_1d [rows, obs_dim]; achieved_goal / desired_goal [rows, goal_dim] iff goal_dim > 0;
+ *   obs_1d [rows, obs_dim] iff obs_dim > 0; achieved_goal / desired_goal [rows, goal_dim] iff goal_dim > 0;
+ *   obs_2d [rows, img_c, img_h, img_w] iff img_c > 0;
  *   exploit_mask [rows] bytes (1 = return the greedy action; Runner/runner.py:120-123) or NULL;
  *   noise [rows, act_dim]: N(0,1) draws (continuous) / U(0,1) draws (discrete) or NULL -> Philox4x32
  *   keyed by (seed, counter);
@@ -296,8 +306,8 @@ int fdql_agent_debug_ptr(fdql_agent_t *agent, const char *name, const float **de
  *   pre/post-step weights is in the arena, like any lock-free actor).  No host sync.          */
 int64_t fdql_agent_act_workspace_bytes(const fdql_agent_t *agent, int32_t rows);
 int fdql_agent_act(fdql_agent_t *agent, const float *obs_1d, const float *achieved_goal, const float *desired_goal,
-                   const float *agent_state, const uint8_t *exploit_mask, const float *noise, uint64_t seed,
-                   uint64_t counter, int32_t rows, float *action, float *log_prob, float *explore_action,
+                   const float *obs_2d, const float *agent_state, const uint8_t *exploit_mask, const float *noise,
+                   uint64_t seed, uint64_t counter, int32_t rows, float *action, float *log_prob, float *explore_action,
                    float *exploit_action, float *hidden_state, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* Algorithmic work of one update, for roofline accounting: dense GEMM flops

@@ -57,12 +57,33 @@ class Spec:
     world_size: int = 1           # data-parallel ranks: loss is normalised by B * world_size
     bootstrap: bool = False       # use_bootstrap_minibatch_nstep (SAC-min with lower bounds only)
     burn_in: int = 0              # int(T * burn_in_portion) when EncoderConf.use_burn_in, else 0
+    # Pixel observations (BASELINE config 5).  NO REFERENCE EXISTS for this encoder (encoder.py:16-23 is dead code):
+    # a small strided conv stack of this build's own design, LeakyReLU(0.01) like every other hidden layer (quirk q8),
+    # input scaled by 1/255, output flattened in (y, x, channel) order and fed to the obs MLP next to obs_1d.
+    img: Tuple[int, ...] = ()     # (C, H, W) of xp["obs_2d"], or () = none
+    conv: Tuple[Tuple[int, int, int], ...] = ()   # per layer (out_channels, kernel, stride)
     gru: str = ""                 # "" = feed-forward joiner; else EncoderConf.JoinerModeEnum.gru with the latent-state
                                   # training mode "zero" | "learned" | "store" (encoder.py:40-42, 78-94)
 
     @property
-    def enc_in(self):             # encoder.py:26-32
-        return self.obs + 2 * self.goal
+    def conv_shapes(self):        # per layer (Cin, H_in, W_in, Cout, k, s, H_out, W_out)
+        out, (c, h, w) = [], self.img if self.img else (0, 0, 0)
+        for co, k, st in self.conv:
+            ho, wo = (h - k) // st + 1, (w - k) // st + 1
+            out.append((c, h, w, co, k, st, ho, wo))
+            c, h, w = co, ho, wo
+        return out
+
+    @property
+    def conv_features(self):
+        if not self.img:
+            return 0
+        cs = self.conv_shapes
+        return cs[-1][3] * cs[-1][6] * cs[-1][7] if cs else self.img[0] * self.img[1] * self.img[2]
+
+    @property
+    def enc_in(self):             # encoder.py:26-32 (+ the flattened conv features)
+        return self.obs + 2 * self.goal + self.conv_features
 
     @property
     def act_feat(self):           # width of the action block fed to the critic
@@ -103,7 +124,11 @@ def mlp_shapes(prefix, din, hidden, dout):
 
 def net_shapes(spec: Spec, which: str):
     if which == "encoder.obs":
-        return mlp_shapes("encoder.visible_layer_encoders.obs_1d", spec.enc_in, spec.enc_hidden, spec.enc_features)
+        conv = []
+        for i, (ci, _, _, co, k, _, _, _) in enumerate(spec.conv_shapes):
+            conv += [(f"encoder.visible_layer_encoders.obs_2d.conv.{i}.weight", (co, ci * k * k)),
+                     (f"encoder.visible_layer_encoders.obs_2d.conv.{i}.bias", (co,))]
+        return conv + mlp_shapes("encoder.visible_layer_encoders.obs_1d", spec.enc_in, spec.enc_hidden, spec.enc_features)
     if which == "encoder.joiner":
         if spec.gru:    # nn.GRU(hidden_features, latent, num_layers=1) + the learnable initial state (encoder.py:41-42)
             L, F_ = spec.latent, spec.enc_features
@@ -180,6 +205,18 @@ def skip_head_mlp(p, prefix, x, n_hidden):
     return F.linear(torch.cat(feats, dim=-1), p[f"{prefix}.head.weight"], p[f"{prefix}.head.bias"])
 
 
+def conv_features(p, spec: Spec, frames):
+    """Pixel encoder of this build (no reference): frames [..., C, H, W] with values 0..255 -> x/255 ->
+    conv(k, stride) + LeakyReLU(0.01) per layer (weights kept as [Cout, Cin*k*k], torch's own flattening of a conv
+    weight) -> flattened in (y, x, channel) order [..., Ho*Wo*Cout]."""
+    lead = frames.shape[:-3]
+    x = frames.reshape((-1,) + tuple(spec.img)) * (1.0 / 255.0)
+    for i, (ci, _, _, co, k, st, _, _) in enumerate(spec.conv_shapes):
+        w = p[f"encoder.visible_layer_encoders.obs_2d.conv.{i}.weight"].view(co, ci, k, k)
+        x = F.leaky_relu(F.conv2d(x, w, p[f"encoder.visible_layer_encoders.obs_2d.conv.{i}.bias"], stride=st), 0.01)
+    return x.permute(0, 2, 3, 1).reshape(lead + (-1,))
+
+
 def gru_cell(p, x_t, h):
     """One step of torch.nn.GRU (gate order r, z, n):
     r = s(W_ir x + b_ir + W_hr h + b_hr); z = s(W_iz x + b_iz + W_hz h + b_hz);
@@ -197,9 +234,12 @@ def gru_cell(p, x_t, h):
 def encoder(p, spec: Spec, xp, h0=None, return_hidden=False):
     """encoder.py:52-67: obs MLP, then the feed-forward joiner or (spec.gru) one GRU layer scanned over the
     leading (time) axis from ``h0`` [B, L] (zeros when None)."""
-    x = xp["obs_1d"]
+    parts = [xp["obs_1d"]] if spec.obs else []
     if spec.goal:
-        x = torch.cat((x, xp["achieved_goal"], xp["desired_goal"]), dim=-1)
+        parts += [xp["achieved_goal"], xp["desired_goal"]]
+    if spec.img:
+        parts.append(conv_features(p, spec, xp["obs_2d"]))
+    x = torch.cat(parts, dim=-1)
     e = skip_head_mlp(p, "encoder.visible_layer_encoders.obs_1d", x, len(spec.enc_hidden))
     if not spec.gru:
         return skip_head_mlp(p, "encoder.joiner", e, len(spec.joint_hidden))

@@ -283,7 +283,8 @@ def _agent_for(spec, dev, **kw):
                       use_lowerbound=spec.lowerbound, use_max_entropy=spec.max_entropy,
                       hard_updates=spec.hard_updates, gamma=spec.gamma, tau=spec.tau, lr=spec.lr,
                       init_log_alpha=spec.init_log_alpha, drop_frac=spec.drop, bootstrap_nstep=spec.bootstrap,
-                      burn_in_steps=spec.burn_in, joiner_gru=bool(spec.gru), gru_state_mode=spec.gru or 0, **kw)
+                      burn_in_steps=spec.burn_in, joiner_gru=bool(spec.gru), gru_state_mode=spec.gru or 0,
+                      img=spec.img, conv=spec.conv, **kw)
     return NativeAgent(cfg, dev)
 
 
@@ -424,6 +425,11 @@ def test_update_matches_oracle_config2(dev, T, B, hid):
     ("GRU joiner, stored start state + burn-in rows", dict(obs=9, act=3, C=2, Q=3, T=12, B=40, gru="store", burn_in=2,
                                                           latent=64, enc_features=48, enc_hidden=(64,), joint_hidden=(64,),
                                                           pi_hidden=(64,), critic_hidden=(64, 64))),
+    ("pixel encoder, 2 conv layers on 2x12x12 frames + obs_1d, discrete head (no reference: vs torch conv2d)",
+     dict(obs=4, act=5, discrete=True, C=2, Q=3, T=3, B=20, img=(2, 12, 12), conv=((8, 4, 2), (16, 3, 1)), latent=32,
+          enc_features=32, enc_hidden=(48,), joint_hidden=(32,), pi_hidden=(32,), critic_hidden=(32, 32))),
+    ("pixel encoder alone (obs_dim 0), Atari stack on 4x84x84, config-5 shapes at a small batch",
+     dict(obs=0, act=6, discrete=True, C=2, Q=5, T=2, B=6, img=(4, 84, 84), conv=((32, 8, 4), (64, 4, 2), (64, 3, 1)))),
     ("config5 head (discrete SAC, 6 actions, Gumbel-softmax)", dict(obs=64, act=6, discrete=True, C=2, Q=5, T=4, B=128)),
     ("ragged sizes (B=7, odd widths 18/33/21: unaligned rows, partial tiles, M < one tile)",
      dict(obs=3, act=2, C=2, Q=3, T=3, B=7, critic_hidden=(33, 18), pi_hidden=(21,), enc_hidden=(18,), joint_hidden=(33,),
@@ -453,7 +459,7 @@ def test_update_matches_oracle_other_configs(dev, name, kw):
     ag.load_tensors(params)
     g = torch.Generator().manual_seed(9)
     A = spec.act
-    xp = {"obs_1d": torch.randn(T, B, spec.obs, generator=g), "action": torch.rand(T, B, A, generator=g) * 2 - 1,
+    xp = {"obs_1d": torch.randn(T, B, max(spec.obs, 1), generator=g), "action": torch.rand(T, B, A, generator=g) * 2 - 1,
           "reward": torch.randn(T, B, 1, generator=g), "mc_return": torch.randn(T, B, 1, generator=g) * 2,
           "task_done": (torch.rand(T, B, 1, generator=g) < (0.002 if spec.bootstrap else 0.1)).float(),
           "episode_step": (torch.arange(T).view(T, 1, 1) + torch.randint(0, 50, (1, B, 1), generator=g)).float()}
@@ -465,6 +471,10 @@ def test_update_matches_oracle_other_configs(dev, name, kw):
     xp["episode_step"][T // 2:, ::5] = 0.0
     if spec.gru == "store":
         xp["agent_state"] = torch.rand(T, B, spec.latent, generator=g)
+    if spec.img:
+        xp["obs_2d"] = torch.randint(0, 256, (T, B) + tuple(spec.img), generator=g).float()
+    if not spec.obs:
+        del xp["obs_1d"]
     nt, na = torch.randn(T - 1, B, A, generator=g), torch.randn(T - 1, B, A, generator=g)
     if spec.discrete:
         nt, na = torch.rand(T - 1, B, A, generator=g), torch.rand(T - 1, B, A, generator=g)
