@@ -77,6 +77,8 @@ struct MlpInst {
 // K-split of the per-step recurrent GEMMs of the GRU scan ([B, L] x [L, 3L] forward, [B, 3L] x [3L, L] backward):
 // at B = 256 they are 16-48 workgroups walking K serially; the splits trade that for a partial sum in the gate kernel
 constexpr int GRU_KSPLIT_FWD = 4, GRU_KSPLIT_BWD = 8;
+// K-split of a conv weight gradient over its R = images * positions rows: ~4096 rows per workgroup, at most 1024 parts
+inline int conv_wsplit(long long R) { return (int)std::max<long long>(1, std::min<long long>(1024, (R + 4095) / 4096)); }
 
 enum StageKind { ST_GEMM, ST_SKINNY_WGRAD, ST_FUNC, ST_HEAD_DGRAD };
 
@@ -286,6 +288,10 @@ void carve(fdql_agent *a) {
     a->alloc(p + ".out", N * pos * L.cout);
     a->alloc(p + ".dpre", M * pos * L.cout);
     if (i > 0) a->alloc(p + ".dcol", M * pos * K);
+    // weight gradient: K-split of its own over the M*pos rows (far more rows than the slab count serves), then a
+    // reduction of the partials into slab 0; bias gradient: two-level column sum
+    a->alloc(p + ".wpart", (int64_t)conv_wsplit(M * pos) * L.cout * K);
+    a->alloc(p + ".bpart", (int64_t)(colsum_tall_blocks(M * pos) + colsum_tall_blocks(colsum_tall_blocks(M * pos))) * L.cout);
   }
   mlp_bufs("enc_obs", a->enc_obs, N, true, true);
   if (c.joiner_gru) {
@@ -936,6 +942,7 @@ int build_plan(fdql_agent *a) {
   // ---- weight gradients (K-split slabs) + column sums
   {
     Stage tail, ws;
+    std::vector<std::function<hipError_t(hipStream_t)>> conv_post;   // conv weight / bias partials -> slab 0
     tail.kind = ST_GEMM; tail.name = "wgrad.enc";
     ws.kind = ST_SKINNY_WGRAD; ws.name = "colsums";
     // critics: spread over the dgrad launches that follow their backward (they are ready by then)
@@ -961,11 +968,35 @@ int build_plan(fdql_agent *a) {
       const int R = (int)((long long)M * Lc.g.OH * Lc.g.OW);
       float *slab = a->buf("slabs");
       const float *dpre = a->buf("conv" + std::to_string(i) + ".dpre");
-      b.wgrad_gemm(R, dpre, Lc.cout, Lc.cout, a->buf("conv" + std::to_string(i) + ".col"), K, K, slab + Lc.w_off, K, tail, tail);
-      b.wgrad_bias(R, dpre, Lc.cout, Lc.cout, nullptr, slab + Lc.b_off, ws);
+      float *wpart = a->buf("conv" + std::to_string(i) + ".wpart"), *bpart = a->buf("conv" + std::to_string(i) + ".bpart");
+      const int S2 = conv_wsplit(R);
+      {
+        GemmProblem p = Builder::new_gemm(Lc.cout, K, wpart, K);
+        Builder::add_seg(p, dpre, Lc.cout, 0, a->buf("conv" + std::to_string(i) + ".col"), K, 0, R);
+        p.ksplit = S2;
+        p.split_stride = (long long)Lc.cout * K;
+        tail.gemm.push_back(p);
+      }
+      float *wdst = slab + Lc.w_off, *bdst = slab + Lc.b_off;
+      const long long nw = (long long)Lc.cout * K;
+      const int cout = Lc.cout, nblk = colsum_tall_blocks(R);
+      conv_post.push_back([=](hipStream_t s) {
+        hipError_t e = reduce_partials_launch(wpart, S2, nw, wdst, s);
+        if (e == hipSuccess) e = colsum_tall_launch(dpre, R, cout, cout, bpart, s);
+        const int nblk2 = colsum_tall_blocks(nblk);     // second level: the [nblk, cout] partials are tall again
+        float *bpart2 = bpart + (long long)nblk * cout;
+        if (e == hipSuccess) e = colsum_tall_launch(bpart, nblk, cout, cout, bpart2, s);
+        if (e == hipSuccess) e = reduce_partials_launch(bpart2, nblk2, cout, bdst, s);
+        return e;
+      });
     }
     a->stages.push_back(tail);
     a->stages.push_back(ws);
+    if (!conv_post.empty())
+      b.func_stage("conv.wgrad_reduce", [=](hipStream_t s) {
+        for (const auto &f : conv_post) { hipError_t e = f(s); if (e != hipSuccess) return e; }
+        return hipSuccess;
+      });
   }
   {
     const float *slabs = a->buf("slabs");
@@ -1060,6 +1091,7 @@ int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {
     for (int i = 0; i < c.n_conv; ++i) {
       FDQL_REQUIRE(c.conv_out[i] > 0 && c.conv_k[i] > 0 && c.conv_s[i] > 0 && c.conv_k[i] <= h && c.conv_k[i] <= w,
                    "conv layer %d: bad channels / kernel / stride for a %dx%d map", i, h, w);
+      FDQL_REQUIRE(i + 1 == c.n_conv || c.conv_out[i] % 4 == 0, "conv layer %d: out_channels must be a multiple of 4", i);
       h = (h - c.conv_k[i]) / c.conv_s[i] + 1; w = (w - c.conv_k[i]) / c.conv_s[i] + 1;
     }
   }

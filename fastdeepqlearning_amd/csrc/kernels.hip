@@ -767,22 +767,35 @@ hipError_t policy_bwd_launch(const float *logits, const float *noise, const floa
 // ======================================================================================
 // Pixel encoder: im2col / col2im around the grouped GEMM (no reference; see include/fdql.h)
 // ======================================================================================
-__global__ void k_im2col(const float *__restrict__ in, int nhwc, float scale, long long n_img, ConvGeom g,
-                         float *__restrict__ col) {
-  const int K = g.C * g.k * g.k;
-  const long long total = n_img * g.OH * g.OW * K;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-    const long long row = e / K;
-    const int kk = (int)(e - row * K);
-    const int c = kk / (g.k * g.k), r2 = kk - c * g.k * g.k, ky = r2 / g.k, kx = r2 - ky * g.k;
+// layer 0: NCHW frames, K ordered (c, ky, kx); one thread copies the k contiguous pixels of one (row, c, ky)
+__global__ void k_im2col_nchw(const float *__restrict__ in, float scale, long long n_img, ConvGeom g, float *__restrict__ col) {
+  const int K = g.C * g.k * g.k, per_row = g.C * g.k;
+  const long long total = n_img * g.OH * g.OW * per_row;
+  for (long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x; u < total; u += (long long)gridDim.x * blockDim.x) {
+    const long long row = u / per_row;
+    const int ck = (int)(u - row * per_row), c = ck / g.k, ky = ck - c * g.k;
     const long long img = row / (g.OH * g.OW);
     const int pos = (int)(row - img * g.OH * g.OW), oy = pos / g.OW, ox = pos - oy * g.OW;
-    const int y = oy * g.s + ky, x = ox * g.s + kx;
-    const long long src = nhwc ? ((img * g.H + y) * g.W + x) * g.C + c : ((img * g.C + c) * g.H + y) * g.W + x;
-    col[e] = in[src] * scale;
+    const float *src = in + ((img * g.C + c) * g.H + (oy * g.s + ky)) * g.W + ox * g.s;
+    float *dst = col + row * K + ck * g.k;
+    for (int kx = 0; kx < g.k; ++kx) dst[kx] = src[kx] * scale;
+  }
+}
+// later layers: NHWC feature maps, K ordered (ky, kx, c); one thread copies 4 channels of one (row, ky, kx)
+__global__ void k_im2col_nhwc(const float *__restrict__ in, long long n_img, ConvGeom g, float *__restrict__ col) {
+  const int K = g.C * g.k * g.k, c4n = g.C >> 2, per_row = g.k * g.k * c4n;
+  const long long total = n_img * g.OH * g.OW * per_row;
+  for (long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x; u < total; u += (long long)gridDim.x * blockDim.x) {
+    const long long row = u / per_row;
+    const int r = (int)(u - row * per_row), kk = r / c4n, c4 = r - kk * c4n, ky = kk / g.k, kx = kk - ky * g.k;
+    const long long img = row / (g.OH * g.OW);
+    const int pos = (int)(row - img * g.OH * g.OW), oy = pos / g.OW, ox = pos - oy * g.OW;
+    const float4 v = *reinterpret_cast<const float4 *>(in + ((img * g.H + oy * g.s + ky) * g.W + ox * g.s + kx) * g.C + 4 * c4);
+    *reinterpret_cast<float4 *>(col + row * K + kk * g.C + 4 * c4) = v;
   }
 }
 
+// d(pre-activation of the previous layer), NHWC: gather over the windows covering a pixel; K ordered (ky, kx, c)
 __global__ void k_col2im_mask(const float *__restrict__ dcol, const float *__restrict__ act_prev, long long n_img, ConvGeom g,
                               float *__restrict__ dpre_prev) {
   const int K = g.C * g.k * g.k;
@@ -801,7 +814,7 @@ __global__ void k_col2im_mask(const float *__restrict__ dcol, const float *__res
       for (int kx = x % g.s; kx < g.k; kx += g.s) {
         const int ox = (x - kx) / g.s;
         if (x < kx || ox >= g.OW) continue;
-        acc += dcol[((img * g.OH + oy) * g.OW + ox) * K + (c * g.k + ky) * g.k + kx];
+        acc += dcol[((img * g.OH + oy) * g.OW + ox) * K + (ky * g.k + kx) * g.C + c];
       }
     }
     dpre_prev[e] = act_prev[e] > 0.f ? acc : 0.01f * acc;
@@ -809,10 +822,11 @@ __global__ void k_col2im_mask(const float *__restrict__ dcol, const float *__res
 }
 
 hipError_t im2col_launch(const float *in, int nhwc, float scale, long long n_img, const ConvGeom &g, float *col, hipStream_t s) {
-  const long long total = n_img * g.OH * g.OW * g.C * g.k * g.k;
-  if (total <= 0) return hipSuccess;
-  const int blocks = (int)std::min<long long>((total + 255) / 256, 1 << 20);
-  hipLaunchKernelGGL(k_im2col, dim3(blocks), dim3(256), 0, s, in, nhwc, scale, n_img, g, col);
+  const long long units = n_img * g.OH * g.OW * (nhwc ? g.k * g.k * (g.C >> 2) : g.C * g.k);
+  if (units <= 0) return hipSuccess;
+  const int blocks = (int)std::min<long long>((units + 255) / 256, 1 << 20);
+  if (nhwc) hipLaunchKernelGGL(k_im2col_nhwc, dim3(blocks), dim3(256), 0, s, in, n_img, g, col);
+  else hipLaunchKernelGGL(k_im2col_nchw, dim3(blocks), dim3(256), 0, s, in, scale, n_img, g, col);
   return hipGetLastError();
 }
 hipError_t col2im_mask_launch(const float *dcol, const float *act_prev, long long n_img, const ConvGeom &g, float *dpre_prev,
@@ -821,6 +835,57 @@ hipError_t col2im_mask_launch(const float *dcol, const float *act_prev, long lon
   if (total <= 0) return hipSuccess;
   const int blocks = (int)std::min<long long>((total + 255) / 256, 1 << 20);
   hipLaunchKernelGGL(k_col2im_mask, dim3(blocks), dim3(256), 0, s, dcol, act_prev, n_img, g, dpre_prev);
+  return hipGetLastError();
+}
+
+// tall-matrix column sums (conv bias gradients: millions of rows, a few dozen columns)
+__global__ __launch_bounds__(256) void k_colsum_tall(const float *__restrict__ X, long long R, int C, int ld,
+                                                     float *__restrict__ partial) {
+  __shared__ float red[256];
+  const int col = threadIdx.x % C, sub = threadIdx.x / C, nsub = 256 / C;   // C <= 256
+  const long long r0 = (long long)blockIdx.x * COLSUM_TALL_ROWS, r1 = min(R, r0 + COLSUM_TALL_ROWS);
+  float acc = 0.f;
+  if (sub < nsub)
+  {
+    float acc2 = 0.f;
+    long long r = r0 + sub;
+    for (; r + nsub < r1; r += 2 * nsub) { acc += X[r * ld + col]; acc2 += X[(r + nsub) * ld + col]; }
+    if (r < r1) acc += X[r * ld + col];
+    acc += acc2;
+  }
+  red[threadIdx.x] = sub < nsub ? acc : 0.f;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    float t = 0.f;
+    for (int j = 0; j < nsub; ++j) t += red[j * C + threadIdx.x];
+    partial[(long long)blockIdx.x * C + threadIdx.x] = t;
+  }
+}
+
+// block = 64 elements x 4 part lanes; each lane sums every 4th partial, LDS folds the 4 lanes (fixed order)
+__global__ __launch_bounds__(256) void k_reduce_partials(const float *__restrict__ part, int nparts, long long n,
+                                                         float *__restrict__ dst) {
+  __shared__ float red[4][64];
+  const int el = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const long long e = (long long)blockIdx.x * 64 + el;
+  float s0 = 0.f, s1 = 0.f;
+  if (e < n) {
+    int p = pl;
+    for (; p + 4 < nparts; p += 8) { s0 += part[(long long)p * n + e]; s1 += part[(long long)(p + 4) * n + e]; }
+    if (p < nparts) s0 += part[(long long)p * n + e];
+  }
+  red[pl][el] = s0 + s1;
+  __syncthreads();
+  if (pl == 0 && e < n) dst[e] = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+}
+
+hipError_t colsum_tall_launch(const float *X, long long R, int C, int ld, float *partial, hipStream_t s) {
+  if (R <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_colsum_tall, dim3(colsum_tall_blocks(R)), dim3(256), 0, s, X, R, C, ld, partial);
+  return hipGetLastError();
+}
+hipError_t reduce_partials_launch(const float *part, int nparts, long long n, float *dst, hipStream_t s) {
+  hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, part, nparts, n, dst);
   return hipGetLastError();
 }
 

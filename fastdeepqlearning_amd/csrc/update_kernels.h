@@ -115,13 +115,20 @@ struct ConvGeom {
   int k, s;         // square kernel, stride (no padding)
   int OH, OW;       // output positions
 };
-// col[(img*OH + oy)*OW + ox][c*k*k + ky*k + kx] = scale * in(img, c, oy*s + ky, ox*s + kx);
-// in is NCHW (the batch's frames) or NHWC (a previous layer's output [img*H*W, C])
+// row (img, oy, ox) of col = the k x k x C window at (oy*s, ox*s).  Layer 0 reads the batch's NCHW frames (times
+// `scale`) and orders K as (c, ky, kx); later layers read the previous layer's NHWC output [img*H*W, C] (C % 4 == 0)
+// and order K as (ky, kx, c), so both sides move contiguous runs.  The weights [Cout, K] use the same K order.
 hipError_t im2col_launch(const float *in, int nhwc, float scale, long long n_img, const ConvGeom &g, float *col, hipStream_t s);
 // d(pre-activation of the previous layer) = col2im(dcol) * LeakyReLU'(act_prev), NHWC [n_img*H*W, C]:
 // a gather over the <= ceil(k/s)^2 windows that cover a pixel (fixed order, no atomics)
 hipError_t col2im_mask_launch(const float *dcol, const float *act_prev, long long n_img, const ConvGeom &g, float *dpre_prev,
                               hipStream_t s);
+// column sums of a tall matrix X [R, C] (C <= 256) in two levels: partial[blk][c] over COLSUM_TALL_ROWS rows per block
+constexpr int COLSUM_TALL_ROWS = 1024;
+inline int colsum_tall_blocks(long long R) { return (int)((R + COLSUM_TALL_ROWS - 1) / COLSUM_TALL_ROWS); }
+hipError_t colsum_tall_launch(const float *X, long long R, int C, int ld, float *partial, hipStream_t s);
+// dst[e] = sum_p part[p][e] for e < n (fixed order)
+hipError_t reduce_partials_launch(const float *part, int nparts, long long n, float *dst, hipStream_t s);
 // ---- GRU joiner (torch.nn.GRU cell, gate order r, z, n; encoder.py:40-42)
 // start state of the scan: mode 0 zeros, 1 rows copied from src [B, L], 2 src [L] repeated over the batch
 hipError_t gru_h0_launch(int mode, const float *src, float *h0, int B, int L, hipStream_t s);

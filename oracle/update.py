@@ -207,12 +207,14 @@ def skip_head_mlp(p, prefix, x, n_hidden):
 
 def conv_features(p, spec: Spec, frames):
     """Pixel encoder of this build (no reference): frames [..., C, H, W] with values 0..255 -> x/255 ->
-    conv(k, stride) + LeakyReLU(0.01) per layer (weights kept as [Cout, Cin*k*k], torch's own flattening of a conv
-    weight) -> flattened in (y, x, channel) order [..., Ho*Wo*Cout]."""
+    conv(k, stride) + LeakyReLU(0.01) per layer (weights kept as [Cout, Cin*k*k]) -> flattened in (y, x, channel) order [..., Ho*Wo*Cout]."""
     lead = frames.shape[:-3]
     x = frames.reshape((-1,) + tuple(spec.img)) * (1.0 / 255.0)
     for i, (ci, _, _, co, k, st, _, _) in enumerate(spec.conv_shapes):
-        w = p[f"encoder.visible_layer_encoders.obs_2d.conv.{i}.weight"].view(co, ci, k, k)
+        w = p[f"encoder.visible_layer_encoders.obs_2d.conv.{i}.weight"]
+        # K of the stored [Cout, K] weight runs (c, ky, kx) for the first layer (NCHW frames) and (ky, kx, c) after it
+        # (NHWC feature maps): the order in which the device's im2col lays a window out
+        w = w.view(co, ci, k, k) if i == 0 else w.view(co, k, k, ci).permute(0, 3, 1, 2)
         x = F.leaky_relu(F.conv2d(x, w, p[f"encoder.visible_layer_encoders.obs_2d.conv.{i}.bias"], stride=st), 0.01)
     return x.permute(0, 2, 3, 1).reshape(lead + (-1,))
 

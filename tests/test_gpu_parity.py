@@ -608,6 +608,9 @@ def test_act_matches_reference_golden(dev, case):
 
 @pytest.mark.parametrize("rows,kw", [
     (1, {}), (8, {}), (9, {}), (33, dict(goal=3)), (300, {}),
+    (3, dict(img=(2, 12, 12), conv=((8, 4, 2), (16, 3, 1)), obs=4)),                                   # pixels + obs_1d
+    (2, dict(img=(4, 84, 84), conv=((32, 8, 4), (64, 4, 2), (64, 3, 1)), obs=0, discrete=True, act=6)),  # config-5 frames
+    (5, dict(gru="zero")),
     (5, dict(enc_hidden=(), joint_hidden=(), pi_hidden=())),            # head-only MLPs
     (12, dict(enc_hidden=(40, 24), joint_hidden=(24, 24, 16), pi_hidden=(48, 40))),
     (17, dict(discrete=True, act=5)),
@@ -626,15 +629,23 @@ def test_act_matches_oracle(dev, rows, kw):
         params[k] = params[k] + 0.05 * torch.randn(params[k].shape, generator=gen)
     ag = _agent_for(spec, dev)
     ag.load_tensors(params)
-    xp = {"obs_1d": torch.randn(rows, spec.obs, generator=gen)}
+    xp = {"obs_1d": torch.randn(rows, spec.obs, generator=gen)} if spec.obs else {}
+    if spec.img:
+        xp["obs_2d"] = torch.randint(0, 256, (rows,) + tuple(spec.img), generator=gen).float()
+    if spec.gru:
+        xp["agent_state"] = torch.rand(rows, spec.latent, generator=gen)
     if spec.goal:
         xp["achieved_goal"] = torch.randn(rows, spec.goal, generator=gen)
         xp["desired_goal"] = torch.randn(rows, spec.goal, generator=gen)
     xp["exploit_mask"] = (torch.rand(rows, 1, generator=gen) < 0.4)
     noise = torch.rand(rows, spec.act, generator=gen) if spec.discrete else torch.randn(rows, spec.act, generator=gen)
     want = oup.act(params, spec, xp, noise)
-    got = ag.act(xp["obs_1d"], xp.get("achieved_goal"), xp.get("desired_goal"), xp["exploit_mask"], noise=noise)
+    got = ag.act(xp.get("obs_1d"), xp.get("achieved_goal"), xp.get("desired_goal"), xp["exploit_mask"], noise=noise,
+                 obs_2d=xp.get("obs_2d"), agent_state=xp.get("agent_state"))
     rep = Report(f"act oracle rows={rows} {kw}")
+    if spec.gru:
+        rep.check("hidden_state", got[4], want[4])
+        got, want = got[:4], want[:4]
     if spec.discrete:
         for gt, wt, key in zip(got[:1] + got[2:], want[:1] + want[2:], ("action", "explore", "exploit")):
             assert np.array_equal(gt.cpu().numpy().astype(np.int64), wt.numpy()), key
