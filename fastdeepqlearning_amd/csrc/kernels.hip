@@ -778,7 +778,40 @@ __global__ void k_im2col_nchw(const float *__restrict__ in, float scale, long lo
     const int pos = (int)(row - img * g.OH * g.OW), oy = pos / g.OW, ox = pos - oy * g.OW;
     const float *src = in + ((img * g.C + c) * g.H + (oy * g.s + ky)) * g.W + ox * g.s;
     float *dst = col + row * K + ck * g.k;
-    for (int kx = 0; kx < g.k; ++kx) dst[kx] = src[kx] * scale;
+    if ((g.k & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) {
+      for (int kx = 0; kx < g.k; kx += 4) {   // e.g. the 8-pixel runs of an 8x8 stride-4 first layer
+        float4 v = *reinterpret_cast<const float4 *>(src + kx);
+        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        *reinterpret_cast<float4 *>(dst + kx) = v;
+      }
+    } else {
+      for (int kx = 0; kx < g.k; ++kx) dst[kx] = src[kx] * scale;
+    }
+  }
+}
+// layer 0, staged: a block owns one output row (img, oy): the C*k input rows it touches are read once,
+// coalesced, into LDS and the OW x K block of col - contiguous in memory - is written coalesced from there
+constexpr int IM2COL_LDS_FLOATS = 12288;
+__global__ __launch_bounds__(256) void k_im2col_nchw_rows(const float *__restrict__ in, float scale, long long n_img,
+                                                          ConvGeom g, float *__restrict__ col) {
+  extern __shared__ float tile[];   // C * k * W floats
+  const int K = g.C * g.k * g.k, kk2 = g.k * g.k, nin = g.C * g.k * g.W;
+  const long long total = n_img * g.OH;
+  for (long long blk = blockIdx.x; blk < total; blk += gridDim.x) {
+    const long long img = blk / g.OH;
+    const int oy = (int)(blk - img * g.OH);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nin; i += 256) {
+      const int cr = i / g.W, x = i - cr * g.W, c = cr / g.k, r = cr - c * g.k;
+      tile[i] = in[((img * g.C + c) * g.H + oy * g.s + r) * g.W + x] * scale;
+    }
+    __syncthreads();
+    float *dst = col + (blk * g.OW) * K;
+    for (int kk = threadIdx.x; kk < K; kk += 256) {   // a thread keeps its (c, ky, kx) and walks the output positions
+      const int c = kk / kk2, r2 = kk - c * kk2, ky = r2 / g.k, kx = r2 - ky * g.k;
+      const float *src = tile + (c * g.k + ky) * g.W + kx;
+      for (int ox = 0; ox < g.OW; ++ox) dst[(long long)ox * K + kk] = src[ox * g.s];
+    }
   }
 }
 // later layers: NHWC feature maps, K ordered (ky, kx, c); one thread copies 4 channels of one (row, ky, kx)
@@ -825,8 +858,14 @@ hipError_t im2col_launch(const float *in, int nhwc, float scale, long long n_img
   const long long units = n_img * g.OH * g.OW * (nhwc ? g.k * g.k * (g.C >> 2) : g.C * g.k);
   if (units <= 0) return hipSuccess;
   const int blocks = (int)std::min<long long>((units + 255) / 256, 1 << 20);
-  if (nhwc) hipLaunchKernelGGL(k_im2col_nhwc, dim3(blocks), dim3(256), 0, s, in, n_img, g, col);
-  else hipLaunchKernelGGL(k_im2col_nchw, dim3(blocks), dim3(256), 0, s, in, scale, n_img, g, col);
+  if (nhwc) {
+    hipLaunchKernelGGL(k_im2col_nhwc, dim3(blocks), dim3(256), 0, s, in, n_img, g, col);
+  } else if (g.C * g.k * g.W <= IM2COL_LDS_FLOATS) {
+    const int rb = (int)std::min<long long>(n_img * g.OH, 1 << 20);
+    hipLaunchKernelGGL(k_im2col_nchw_rows, dim3(rb), dim3(256), (size_t)g.C * g.k * g.W * sizeof(float), s, in, scale, n_img, g, col);
+  } else {
+    hipLaunchKernelGGL(k_im2col_nchw, dim3(blocks), dim3(256), 0, s, in, scale, n_img, g, col);
+  }
   return hipGetLastError();
 }
 hipError_t col2im_mask_launch(const float *dcol, const float *act_prev, long long n_img, const ConvGeom &g, float *dpre_prev,
