@@ -511,3 +511,43 @@ def test_gru_agent_life_cycle(dev):
     finally:
         ec.joiner_mode = ec.JoinerModeEnum.feedforward      # EncoderConf attributes are class-level defaults
         ec.rnn_latent_state_training_mode = ec.RnnLatentStateTrainMode.zero
+
+
+def test_pixel_agent_life_cycle(dev):
+    """obs_2d observation space (BASELINE config 5 shape of problem, small): frames enter the replay as uint8 arrays and
+    stay one byte per pixel in HBM, act() runs the conv encoder on the current frames, train_step trains it."""
+    from fastdeepqlearning_amd import Agent, Replay
+    conf = _conf(dev, T=3, B=8)
+    conf.num_instances = 1
+    conf.obs_space = _Space(spaces={"obs_2d": _Space(shape=(2, 12, 12))})
+    conf.action_space = _Space(n=4)
+    conf.discrete = True
+    conf.encoder_conf.conv_layers = ((8, 4, 2), (8, 3, 1))
+    read_heads, write_heads = Replay.make(conf)
+    agent = Agent.make(conf)
+    sd = agent.state_dict()
+    assert tuple(sd["encoder.visible_layer_encoders.obs_2d.conv.0.weight"].shape) == (8, 2 * 4 * 4)
+    assert tuple(sd["encoder.visible_layer_encoders.obs_2d.conv.1.weight"].shape) == (8, 8 * 3 * 3)
+    assert tuple(sd["encoder.visible_layer_encoders.obs_1d.feature_extractor.0.0.weight"].shape) == (32, 8 * 3 * 3)
+    rng = np.random.RandomState(2)
+    for ep in range(3):
+        for i in range(40):
+            frame = rng.randint(0, 256, (2, 12, 12)).astype(np.uint8)
+            action, hidden, info = agent.act({"obs_2d": torch.tensor(frame).unsqueeze(0),
+                                              "exploit_mask": torch.zeros(1, 1, dtype=torch.bool)})
+            assert hidden is None and action.dtype == torch.int64 and 0 <= int(action) < 4
+            write_heads[0].add({"obs_2d": frame, "action": np.asarray([int(action)]), "reward": float(rng.standard_normal()),
+                                "task_done": False, "episode_done": i == 39, "episode_step": i, "idx": 0})
+    ring = read_heads[0]
+    assert ring._dtypes[ring._keys.index("obs_2d")] == "u8"
+    batch = ring.temporal_sample()
+    assert tuple(batch["obs_2d"].shape) == (3, 8, 2, 12, 12) and batch["obs_2d"].dtype == torch.float32
+    assert float(batch["obs_2d"].max()) > 1.0 and torch.equal(batch["obs_2d"], batch["obs_2d"].round())
+    agent.enable_training(read_heads)
+    before = {k: v.clone() for k, v in agent.state_dict().items()}
+    for _ in range(2):
+        agent.train_step()
+    sc = agent.native.scalars()
+    assert np.isfinite(sc["loss"]) and sc["step"] == 2
+    assert not torch.equal(before["encoder.visible_layer_encoders.obs_2d.conv.0.weight"],
+                           agent.state_dict()["encoder.visible_layer_encoders.obs_2d.conv.0.weight"])
