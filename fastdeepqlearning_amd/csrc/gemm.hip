@@ -8,12 +8,13 @@
 // both operands in wgrad).  fp32 in / fp32 accumulate: the MFMA result is bitwise a
 // k-ordered fmaf chain, which is what keeps the 1e-5 parity budget against the CPU path.
 //
-// Tile: 128x128 per 256-thread workgroup, 4 waves as 2x2, each wave 2x2 MFMA tiles of
-// 32x32 (64 accumulator VGPRs).  K advances in chunks of 16 through a double-buffered LDS
-// image laid out [k][row] with pitch 132 floats, so every fragment read is a
-// conflict-free ds_read_b32 of 32 consecutive rows for one k.  Global loads of chunk c+1
-// are issued before the MFMAs of chunk c and written to the other LDS buffer after them
-// (one barrier per chunk).
+// Tile (default, dense problems): 64x64 per 256-thread workgroup, 4 waves as 2x2, each wave ONE 32x32 MFMA tile
+// (16 accumulator VGPRs, 63 VGPR in all -> 8 waves per SIMD; the larger 64x128 / 128x128 tiles stay selectable and
+// measured slower: occupancy, not operand reuse, is what this kernel is short of).  K advances in chunks of 16
+// through a double-buffered LDS image laid out [k][row] with pitch rows+4 floats, so every fragment read is a
+// conflict-free ds_read_b32 of 32 consecutive rows for one k.  Global loads of chunk c+1 are issued before the
+// MFMAs of chunk c (interior chunks: all addresses first, then the loads back to back) and written to the other
+// LDS buffer after them (one barrier per chunk).
 #include "common.h"
 
 #include <cstdarg>
@@ -26,7 +27,8 @@ constexpr int GEMM_THREADS = 256;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Tile shapes (rows x cols per workgroup; 4 waves, each TM x TN MFMA tiles of 32x32):
-//   GEMM_128x128: waves 2x2, wave tile 2x2  — the dense layers
+//   GEMM_64x64  : waves 2x2, wave tile 1x1  — the dense layers (default)
+//   GEMM_128x128: waves 2x2, wave tile 2x2  — selectable (FDQL_GEMM_DENSE_SHAPE)
 //   GEMM_128x32 : waves 4x1, wave tile 1x1  — narrow outputs (heads with N<=32, d pi, few-column wgrads)
 //   GEMM_32x128 : waves 1x4, wave tile 1x1  — few-row outputs (head weight gradients, K-split)
 //   GEMM_64x128 : waves 2x2, wave tile 1x2  — dense layers of a single network (M x 256 gives only
@@ -66,17 +68,12 @@ typedef const __attribute__((address_space(1))) v2f *gcf2;
 // Values read from the problem table are wave-uniform, but the table lives in memory the kernel may
 // also write (hipcc cannot prove otherwise), so they arrive through vector loads.  Pinning them into
 // SGPRs makes every branch on them a scalar branch and lets base pointers stay in scalar registers.
-#ifdef FDQL_DBG_NO_UNI
-__device__ __forceinline__ int uni(int v) { return v; }
-__device__ __forceinline__ const float *uni(const float *p) { return p; }
-#else
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ const float *uni(const float *p) {
   const uintptr_t u = reinterpret_cast<uintptr_t>(p);
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
   return reinterpret_cast<const float *>(((uintptr_t)hi << 32) | lo);
 }
-#endif
 
 __device__ __forceinline__ bool aligned16(gcf p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 __device__ __forceinline__ bool aligned8(gcf p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
@@ -356,13 +353,6 @@ __global__ __launch_bounds__(GEMM_THREADS, TileCfg<SHAPE>::MINB) void k_gemm_gro
     if (sbkc) store_chunk_kc<BN, NVB, BK>(lds[0] + BK * PA, tid, vb); else store_chunk_ks<BN, NVB, BK>(lds[0] + BK * PA, tid, vb);
   }
   __syncthreads();
-#ifdef FDQL_GEMM_DEBUG
-  if (P.ref && P.epi == 99) {  // debug: dump the first staged chunk
-    float *dbg = const_cast<float *>(P.ref);
-    for (int e = tid; e < BK * (PA + PB); e += GEMM_THREADS) dbg[e] = lds[0][e];
-    __syncthreads();
-  }
-#endif
 
   int cur = 0;
   // MFMAs of the chunk staged in lds[cur] (k, ke: its position in the current segment)

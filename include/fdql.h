@@ -340,7 +340,8 @@ int fdql_test_gemm(const float *A, int32_t lda, int32_t a_kc, const float *B, in
                    const float *bias, float *C, int32_t ldc, int32_t M, int32_t N, int32_t K,
                    int32_t epilogue, const float *ref, int32_t ldref, int32_t ksplit, void *stream);
 
-/* Tuning hook: select the K-chunk / pipelining build of the GEMM kernel (0..3); affects speed only. */
+/* Tuning hook: build of the GEMM main loop: 1 (default) = K-chunk 16 with next-step fragment prefetch, 0 = K-chunk 16
+ * without it, 4 = K-chunk 8; 2 and 3 alias 0.  Affects speed only. */
 int fdql_debug_set_gemm_variant(int32_t variant);
 /* Tuning / test hook: tile shape of the dense problems: 5 = 64x64 (default), 3 = 64x128, 0 = 128x128.
  * Applies to plans built afterwards and to fdql_test_gemm. */
