@@ -296,8 +296,24 @@ __global__ __launch_bounds__(GEMM_THREADS, TileCfg<SHAPE>::MINB) void k_gemm_gro
   const int tiles_mn = uni(P.tiles_m) * tiles_n;
   const int split = local / tiles_mn;
   const int rem = local - split * tiles_mn;
-  const int tile_m = rem / tiles_n;
-  const int tile_n = rem - tile_m * tiles_n;
+  // Tile order inside a problem.  Workgroup ids go round-robin over the 8 XCDs (each with its own L2), so with the
+  // plain order the tiles_n column tiles of one row tile sit on different XCDs and every one of them pulls the same
+  // A rows through the fabric.  Rows are therefore taken in groups of 8: ids g*8*tiles_n + [0, 8) are the 8 row tiles
+  // of column 0, the next 8 ids column 1, ... - the column tiles of a row tile are 8 ids apart = on ONE XCD, a few
+  // dispatch slots from each other, and share the A tile in that L2.  The XCD load stays what it was.
+  int tile_m, tile_n;
+  {
+    const int tiles_m = uni(P.tiles_m), full = (tiles_m >> 3) << 3;
+    if (rem < full * tiles_n) {
+      const int grp = rem / (8 * tiles_n), r = rem - grp * 8 * tiles_n;
+      tile_n = r >> 3;
+      tile_m = grp * 8 + (r & 7);
+    } else {
+      const int r = rem - full * tiles_n;
+      tile_m = full + r / tiles_n;
+      tile_n = r - (r / tiles_n) * tiles_n;
+    }
+  }
   const int r0 = tile_m * BM, c0 = tile_n * BN;
 
   // K range of segment 0 when the problem is K-split (wgrad); whole segments otherwise.
