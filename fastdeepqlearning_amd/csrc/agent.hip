@@ -77,6 +77,9 @@ struct MlpInst {
 // K-split of the per-step recurrent GEMMs of the GRU scan ([B, L] x [L, 3L] forward, [B, 3L] x [3L, L] backward):
 // at B = 256 they are 16-48 workgroups walking K serially; the splits trade that for a partial sum in the gate kernel
 constexpr int GRU_KSPLIT_FWD = 4, GRU_KSPLIT_BWD = 8;
+// Few rows (temporal_len 2, small batches): d state as one problem is a handful of workgroups walking all 2(C+1)
+// K-segments serially; below this row count each network's contribution is its own problem and a reduction sums them
+constexpr int DSTATE_SPLIT_MAX_ROWS = 1024;
 // K-split of a conv weight gradient over its R = images * positions rows: ~4096 rows per workgroup, at most 1024 parts
 inline int conv_wsplit(long long R) { return (int)std::max<long long>(1, std::min<long long>(1024, (R + 4095) / 4096)); }
 
@@ -337,6 +340,7 @@ void carve(fdql_agent *a) {
   a->alloc("dpi", M * c.act_dim);
   a->alloc("dlogits", M * a->actor.dout);
   a->alloc("dstate", M * c.latent);
+  if (M <= DSTATE_SPLIT_MAX_ROWS) a->alloc("dstate.parts", (int64_t)(c.n_critics + 1) * M * c.latent);
   a->alloc("denc", M * c.enc_features);
   a->alloc("cs.dstate", ((M + 63) / 64) * c.latent);
   a->alloc("cs.denc", ((M + 63) / 64) * c.enc_features);
@@ -850,14 +854,33 @@ int build_plan(fdql_agent *a) {
   // ---- d state = sum over online critics and the actor
   {
     Stage &gs = b.gemm_stage("dstate");
-    GemmProblem p = Builder::new_gemm(M, L, a->buf("dstate"), L);
-    for (int k = 0; k < C; ++k) b.input_grad_segs(co[k], a->buf("dz") + k * Q, Nq, 0, p);
-    b.input_grad_segs(ao, a->buf("dlogits"), a->actor.dout, 0, p);
-    p.colsum = a->buf("cs.dstate");
-    gs.gemm.push_back(p);
+    if (M <= DSTATE_SPLIT_MAX_ROWS) {
+      float *parts = a->buf("dstate.parts");
+      const long long ML = (long long)M * L;
+      for (int k = 0; k <= C; ++k) {
+        GemmProblem p = Builder::new_gemm(M, L, parts + k * ML, L);
+        if (k < C) b.input_grad_segs(co[k], a->buf("dz") + k * Q, Nq, 0, p);
+        else b.input_grad_segs(ao, a->buf("dlogits"), a->actor.dout, 0, p);
+        gs.gemm.push_back(p);
+      }
+    } else {
+      GemmProblem p = Builder::new_gemm(M, L, a->buf("dstate"), L);
+      for (int k = 0; k < C; ++k) b.input_grad_segs(co[k], a->buf("dz") + k * Q, Nq, 0, p);
+      b.input_grad_segs(ao, a->buf("dlogits"), a->actor.dout, 0, p);
+      p.colsum = a->buf("cs.dstate");
+      gs.gemm.push_back(p);
+    }
     hosts.push_back(a->stages.size() - 1);
   }
   const size_t idx_dstate = a->stages.size() - 1;
+  if (M <= DSTATE_SPLIT_MAX_ROWS) {
+    const float *parts = a->buf("dstate.parts");
+    float *dsum = a->buf("dstate");
+    const long long ML = (long long)M * L;
+    const int np = C + 1;
+    b.func_stage("dstate.sum", [=](hipStream_t s) { return reduce_partials_launch(parts, np, ML, dsum, s); });
+  }
+  const float *cs_dstate = M <= DSTATE_SPLIT_MAX_ROWS ? nullptr : a->buf("cs.dstate");   // bias sums straight from d state
   // ---- encoder backward over the M rows that carry gradient (next-only rows get none)
   MlpInst jb = jo, eb = eo;
   jb.rows = M; eb.rows = M;
@@ -951,7 +974,7 @@ int build_plan(fdql_agent *a) {
     b.wgrads(ao, a->buf("dlogits"), a->actor.dout, nullptr, a->stages[idx_dstate], tail, ws);
     // joiner: needs d state and its dpre -> the d enc launch; encoder MLP: needs d enc and its dpre -> the tail
     if (!gru) {
-      b.wgrads(jb, a->buf("dstate"), L, a->buf("cs.dstate"), a->stages[idx_denc], tail, ws);
+      b.wgrads(jb, a->buf("dstate"), L, cs_dstate, a->stages[idx_denc], tail, ws);
     } else {   // GRU weights: dW_hh = d gh^T h_prev, dW_ih = d gi^T e, biases = column sums (all over the M rows)
       const int L3 = 3 * L, F = c.enc_features;
       float *slab = a->buf("slabs");
