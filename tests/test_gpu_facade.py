@@ -284,6 +284,50 @@ def test_phase_split_equals_single_call(dev):
         assert torch.equal(a1.tensors[k], a2.tensors[k]), k
 
 
+def test_data_parallel_sharding_on_device(dev):
+    """The multi-GPU sequence on one card: two agents configured as ranks of a world of 2 take half the windows each
+    (FDQL_PHASE_GRAD), their gradient arenas are summed (what the RCCL all-reduce does) and applied
+    (FDQL_PHASE_APPLY); the result matches one agent stepping on the whole batch (weights within fp32 summation
+    order, every replica identical bit for bit)."""
+    import dataclasses
+    from fastdeepqlearning_amd import _native as nat
+    from oracle import update as oup
+    from test_gpu_parity import _agent_for
+    spec = oup.Spec(obs=9, act=3, C=3, Q=4, latent=64, enc_features=48, enc_hidden=(64,), joint_hidden=(48,), pi_hidden=(64,),
+                    critic_hidden=(64, 64), T=6, B=32)
+    half = dataclasses.replace(spec, B=16, world_size=2)
+    params = oup.init_params(spec, seed=4)
+    g = torch.Generator().manual_seed(4)
+    T, B, A = spec.T, spec.B, spec.act
+    xp = {"obs_1d": torch.randn(T, B, spec.obs, generator=g), "action": torch.rand(T, B, A, generator=g) * 2 - 1,
+          "reward": torch.randn(T, B, 1, generator=g), "mc_return": torch.randn(T, B, 1, generator=g),
+          "task_done": (torch.rand(T, B, 1, generator=g) < 0.1).float(),
+          "episode_step": (torch.arange(T).view(T, 1, 1) + torch.randint(0, 30, (1, B, 1), generator=g)).float()}
+    nt, na = torch.randn(T - 1, B, A, generator=g), torch.randn(T - 1, B, A, generator=g)
+    whole = _agent_for(spec, dev)
+    ranks = [_agent_for(half, dev, world_size=2), _agent_for(half, dev, world_size=2)]
+    for ag in [whole] + ranks:
+        ag.load_tensors(params)
+    whole.update({k: v.to(dev) for k, v in xp.items()}, nt.to(dev), na.to(dev))
+    for r, ag in enumerate(ranks):
+        sl = slice(16 * r, 16 * (r + 1))
+        ag.update({k: v[:, sl].contiguous().to(dev) for k, v in xp.items()}, nt[:, sl].contiguous().to(dev),
+                  na[:, sl].contiguous().to(dev), phase=nat.PHASE_GRAD)
+    total = ranks[0].grads + ranks[1].grads            # all_reduce(sum)
+    ref = whole.grads
+    assert float((total - ref).abs().max() / ref.abs().max()) < 2e-5
+    for ag in ranks:
+        ag.grads.copy_(total)
+        ag.update(None, phase=nat.PHASE_APPLY)
+    lr = spec.lr
+    for k in whole.tensors:
+        assert torch.equal(ranks[0].tensors[k], ranks[1].tensors[k]), k          # replicas stay identical
+        d = float((ranks[0].tensors[k] - whole.tensors[k]).abs().max())
+        assert d <= 2.1 * lr, (k, d)                                            # Adam's step is sign-like where g ~ 0
+    close = [float((ranks[0].tensors[k] - whole.tensors[k]).abs().max()) < 1e-6 for k in whole.tensors]
+    assert sum(close) >= 0.9 * len(close)
+
+
 def test_device_noise_statistics_and_determinism(dev):
     """Philox path (perf runs): same seed/step -> same result; actions inside (-1, 1); noise ~ N(0,1)."""
     from test_gpu_parity import _agent_for
