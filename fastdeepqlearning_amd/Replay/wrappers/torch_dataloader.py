@@ -1,39 +1,49 @@
-"""TorchDataLoader: the trainer-side read head (reference:
-franQ/Replay/wrappers/torch_dataloader.py:11-50).  Over the HBM ring there is nothing to
-prefetch or copy — ``temporal_sample`` launches the gather kernel on the current stream and
-returns float32 device tensors — so no thread or queue is started.  A foreign replay object
-that yields numpy arrays is still converted per key like the reference does."""
+"""TorchDataLoader: the trainer-side read head (reference: franQ/Replay/wrappers/torch_dataloader.py:11-50).
+
+The reference starts a thread that keeps one sampled batch converted to float32 on the GPU in a queue.  Over the HBM
+ring there is nothing to prefetch or copy: a sample IS a kernel launch on the current stream that returns float32
+device tensors, so this class only keeps the reference's interface (``ready``, ``temporal_sample``, ``sample`` and the
+``use_temporal`` switch that selects which of the two is legal) and converts per key when it wraps a foreign replay
+object that still yields numpy arrays."""
 import torch
 
 from .wrapper_base_class import ReplayMemoryWrapper
 
 
 class ConfigurationError(Exception):
-    ...
+    """Asked for the kind of sample the loader was not configured for (same rule as the reference)."""
 
 
 class TorchDataLoader(ReplayMemoryWrapper):
     def __init__(self, replay_buffer, device="cuda:0", precision=torch.float32, use_temporal=True, vectorized=True):
         ReplayMemoryWrapper.__init__(self, replay_buffer)
-        self.device, self.precision, self._use_temporal, self.vectorized = device, precision, use_temporal, vectorized
-        if not use_temporal:
-            raise NotImplementedError("TODO: Add support for pre-fetching and batching non-temporal samples")
+        self.device = torch.device(device)
+        self.precision = precision
+        self.vectorized = vectorized
+        self._use_temporal = bool(use_temporal)    # False: plain [B, *] minibatches (the reference never built this mode)
 
     def ready(self):
-        r = getattr(self.replay_buffer, "ready", None)
-        return bool(r()) if r is not None else True
+        probe = getattr(self.replay_buffer, "ready", None)
+        return True if probe is None else bool(probe())
 
-    def _convert(self, experience):
-        return {k: (v if isinstance(v, torch.Tensor) and v.device == torch.device(self.device) and v.dtype == self.precision
-                    else torch.as_tensor(v).to(device=self.device, dtype=self.precision))
-                for k, v in experience.items()}
+    def _on_device(self, batch):
+        out = {}
+        for key, value in batch.items():
+            if isinstance(value, torch.Tensor) and value.device == self.device and value.dtype == self.precision:
+                out[key] = value
+            else:
+                out[key] = torch.as_tensor(value).to(device=self.device, dtype=self.precision)
+        return out
+
+    def _require(self, temporal):
+        if self._use_temporal != temporal:
+            want = "use_temporal=True" if temporal else "use_temporal=False"
+            raise ConfigurationError(f"this loader was built for the other sample kind; construct it with {want}")
 
     def sample(self):
-        if self._use_temporal:
-            raise ConfigurationError("Incorrect Config! Unset `use_temporal` in init to support this feature")
-        return self._convert(self.replay_buffer.sample())
+        self._require(temporal=False)
+        return self._on_device(self.replay_buffer.sample())
 
     def temporal_sample(self, *args, **kwargs):
-        if not self._use_temporal:
-            raise ConfigurationError("Incorrect config! Set `use_temporal` in init to support this feature")
-        return self._convert(self.replay_buffer.temporal_sample())
+        self._require(temporal=True)
+        return self._on_device(self.replay_buffer.temporal_sample())
