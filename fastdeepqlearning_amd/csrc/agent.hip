@@ -118,6 +118,7 @@ struct fdql_agent {
   struct ConvLayer { ConvGeom g; int cout; int64_t w_off, b_off; };
   std::vector<ConvLayer> conv;
   int conv_feat = 0;
+  int hf_planes = 0;   // partial-sum planes per critic instance (head fusion)
   // GRU joiner (cfg.joiner_gru): offsets of weight_ih_l0 [3L,F], weight_hh_l0 [3L,L], bias_ih_l0, bias_hh_l0 [3L],
   // encoder.hidden_state [L] in the trainable arena
   int64_t gru_wih = 0, gru_whh = 0, gru_bih = 0, gru_bhh = 0, gru_h0 = 0;
@@ -328,6 +329,13 @@ void carve(fdql_agent *a) {
     mlp_bufs("crit" + s, a->critic[k], M, true, false);
     mlp_bufs("crit_f" + s, a->critic[k], M, true, false);
   }
+  {   // head fusion: per critic instance (3C of them) the partial head sums of every hidden layer, then their total
+    int planes = 0;
+    for (int h : a->critic[0].hid) planes += ((h + 63) / 64) * 2;
+    a->hf_planes = planes;
+    a->alloc("hf.parts", (int64_t)3 * c.n_critics * planes * M * c.n_quantiles);
+    a->alloc("hf.sum", (int64_t)3 * c.n_critics * M * c.n_quantiles);
+  }
   a->alloc("next_z", M * Nq);
   a->alloc("q_pred", M * Nq);
   a->alloc("q_frozen", M * Nq);
@@ -407,6 +415,16 @@ struct Builder {
     int col = 0;
     for (const SegIn &s : m.in) { add_seg(p, s.ptr, s.ld, 1, m.HW() + col, ld, 1, s.width); col += s.width; }
     for (size_t i = 0; i < d.hid.size(); ++i) { add_seg(p, m.h[i], d.hid[i], 1, m.HW() + col, ld, 1, d.hid[i]); col += d.hid[i]; }
+    p.bias = m.HB();
+    return p;
+  }
+  // the head restricted to the MLP's inputs (the hidden activations' part comes from the fused partial sums)
+  GemmProblem fwd_head_inputs_only(const MlpInst &m) {
+    const MlpDesc &d = *m.d;
+    const int ld = d.head_ld();
+    GemmProblem p = new_gemm(m.rows, d.dout, m.out, m.ldout);
+    int col = 0;
+    for (const SegIn &s : m.in) { add_seg(p, s.ptr, s.ld, 1, m.HW() + col, ld, 1, s.width); col += s.width; }
     p.bias = m.HB();
     return p;
   }
@@ -741,27 +759,63 @@ int build_plan(fdql_agent *a) {
     // critic accumulates cat(s, a), stores h0 of the online pass, continues with (pi - a).Wa and stores
     // h0 of the frozen pass (GemmProblem::emit_seg) - 10 layer-0 problems instead of 15.
     const size_t nh = a->critic[0].hid.size();
+    // Head fusion: each hidden layer's launch also forms its part of the skip head's dot product (GemmProblem::hf_*),
+    // so the head streams only cat(s, a) instead of every hidden activation again (584 -> 197 MB at config 2).
+    // Needs the Q outputs of a critic to be 1, 2, 4 or 8 (the butterfly's group size).
+    bool fuse = nh > 0 && getenv("FDQL_NO_HEAD_FUSE") == nullptr && (Q == 1 || Q == 2 || Q == 4 || Q == 8);
+    float *hf_parts = a->buf("hf.parts"), *hf_sum = a->buf("hf.sum");
+    const long long MQ = (long long)M * Q;
+    auto inst_id = [&](int k, int which) { return 3 * k + which; };   // which: 0 target, 1 online, 2 frozen
+    auto plane0 = [&](int layer) { int p = 0; for (int i = 0; i < layer; ++i) p += ((a->critic[0].hid[i] + 63) / 64) * 2; return p; };
+    auto set_hf = [&](GemmProblem &p, const MlpInst &m, int layer, int inst, bool second) {
+      if (!fuse) return;
+      p.hf_w = m.HW() + b.head_col_of_hidden(*m.d, layer);
+      p.hf_ldw = m.d->head_ld();
+      p.hf_q = Q;
+      float *out = hf_parts + ((long long)inst * a->hf_planes + plane0(layer)) * MQ;
+      if (second) p.hf_out2 = out; else p.hf_out = out;
+    };
     if (nh > 0 && getenv("FDQL_NO_DUAL") == nullptr) {
       Stage &gs = b.gemm_stage("critics.fwd0");
       for (int k = 0; k < C; ++k) {
         GemmProblem pt = b.fwd_layer(ct[k], 0);
         pt.emit_seg = pt.nseg - 1;   // no tail: rides in the same launch as the dual problems
+        set_hf(pt, ct[k], 0, inst_id(k, 0), false);
         gs.gemm.push_back(pt);
         GemmProblem p = b.fwd_layer(co[k], 0);
         Builder::add_seg(p, a->buf("pi_diff"), A, 1, co[k].W(0) + L, a->critic[k].din, 1, A);
         p.emit_seg = p.nseg - 2;
         p.C2 = cf[k].h[0];
         p.ldc2 = a->critic[k].hid[0];
+        set_hf(p, co[k], 0, inst_id(k, 1), false);
+        set_hf(p, cf[k], 0, inst_id(k, 2), true);
         gs.gemm.push_back(p);
       }
       for (size_t i = 1; i < nh; ++i) {
         Stage &ls = b.gemm_stage("critics.fwd" + std::to_string(i));
-        for (int k = 0; k < C; ++k)
-          for (MlpInst *m : {&ct[k], &co[k], &cf[k]}) ls.gemm.push_back(b.fwd_layer(*m, (int)i));
+        for (int k = 0; k < C; ++k) {
+          int which = 0;
+          for (MlpInst *m : {&ct[k], &co[k], &cf[k]}) {
+            GemmProblem p = b.fwd_layer(*m, (int)i);
+            set_hf(p, *m, (int)i, inst_id(k, which++), false);
+            ls.gemm.push_back(p);
+          }
+        }
+      }
+      if (fuse) {
+        const int ninst = 3 * C, planes = a->hf_planes;
+        b.func_stage("critics.head_sum", [=](hipStream_t s) { return reduce_partials_batched_launch(hf_parts, ninst, planes, MQ, hf_sum, s); });
       }
       Stage &hs = b.gemm_stage("critics.head");
-      for (int k = 0; k < C; ++k)
-        for (MlpInst *m : {&ct[k], &co[k], &cf[k]}) hs.gemm.push_back(b.fwd_head(*m));
+      for (int k = 0; k < C; ++k) {
+        int which = 0;
+        for (MlpInst *m : {&ct[k], &co[k], &cf[k]}) {
+          GemmProblem p = fuse ? b.fwd_head_inputs_only(*m) : b.fwd_head(*m);
+          if (fuse) { p.epi = EPI_ADD_REF; p.ref = hf_sum + (long long)inst_id(k, which) * MQ; p.ldref = Q; }
+          ++which;
+          hs.gemm.push_back(p);
+        }
+      }
     } else {
       std::vector<MlpInst *> g;
       for (int k = 0; k < C; ++k) { g.push_back(&ct[k]); g.push_back(&co[k]); g.push_back(&cf[k]); }
@@ -1268,7 +1322,7 @@ int32_t fdql_agent_profile_update(fdql_agent_t *a, const fdql_batch_t *batch, co
     FDQL_HIP(hipEventRecord(ev[i + 1], s));
   }
   FDQL_HIP(hipStreamSynchronize(s));
-  static const char *shape_names[GEMM_NSHAPES] = {"128x128", "128x32", "32x128", "64x128", "64x128dual", "64x64"};
+  static const char *shape_names[GEMM_NSHAPES] = {"128x128", "128x32", "32x128", "64x128", "64x128dual", "64x64", "64x64hf"};
   int32_t cnt = 0;
   for (size_t i = 0; i < n && cnt < cap; ++i, ++cnt) {
     float ms = 0;

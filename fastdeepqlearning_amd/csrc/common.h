@@ -43,8 +43,8 @@ struct GemmSeg {
   int a_kc, b_kc;
 };
 
-enum GemmEpilogue { EPI_NONE = 0, EPI_LRELU = 1, EPI_LRELU_GRAD = 2 };
-enum GemmShape { GEMM_128x128 = 0, GEMM_128x32 = 1, GEMM_32x128 = 2, GEMM_64x128 = 3, GEMM_64x128_DUAL = 4, GEMM_64x64 = 5, GEMM_NSHAPES = 6 };
+enum GemmEpilogue { EPI_NONE = 0, EPI_LRELU = 1, EPI_LRELU_GRAD = 2, EPI_ADD_REF = 3 /* x += ref[row][col] */ };
+enum GemmShape { GEMM_128x128 = 0, GEMM_128x32 = 1, GEMM_32x128 = 2, GEMM_64x128 = 3, GEMM_64x128_DUAL = 4, GEMM_64x64 = 5, GEMM_64x64_HF = 6, GEMM_NSHAPES = 7 };
 
 struct GemmProblem {
   int M, N;
@@ -61,6 +61,13 @@ struct GemmProblem {
   int emit_seg;            // -1, or a DUAL problem (64x128 tiles): C = f(sum over segments <= emit_seg),
   float *C2;               //   C2 = f(sum over ALL segments), same bias / activation: two outputs that share
   int ldc2;                //   their leading K-segments in one pass (ksplit == 1, no colsum)
+  // Head fusion (shapes GEMM_64x64_HF and the dual one): besides storing the activation tile, its part of the skip
+  // head's dot product is formed in the epilogue - hf_out[(plane*M + row)*hf_q + q] = sum over the wave's 32 columns
+  // of x[row][col] * hf_w[q*hf_ldw + col], plane = tile_n*2 + (wave column) - so the head no longer re-reads the
+  // hidden activations.  hf_q in {1, 2, 4, 8}; hf_w == null: off.  hf_out2: same for the second output of a dual problem.
+  const float *hf_w;
+  int hf_ldw, hf_q;
+  float *hf_out, *hf_out2;
   int tiles_m, tiles_n;    // filled by gemm_finalize
   int tile_start;          // first block id of this problem in its launch
   GemmSeg seg[GEMM_MAX_SEG];

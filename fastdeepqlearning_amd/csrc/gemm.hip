@@ -42,17 +42,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define FDQL_DUAL_TN 1   // dual-output tiles: 64 x (64 * FDQL_DUAL_TN)
 #endif
 template <int SHAPE> struct TileCfg;
-template <> struct TileCfg<GEMM_128x128> { static constexpr int WM = 2, WN = 2, TM = 2, TN = 2; static constexpr bool DUAL = false; static constexpr int MINB = 2; };
-template <> struct TileCfg<GEMM_128x32> { static constexpr int WM = 4, WN = 1, TM = 1, TN = 1; static constexpr bool DUAL = false; static constexpr int MINB = FDQL_NARROW_MINB; };
-template <> struct TileCfg<GEMM_32x128> { static constexpr int WM = 1, WN = 4, TM = 1, TN = 1; static constexpr bool DUAL = false; static constexpr int MINB = FDQL_NARROW_MINB; };
-template <> struct TileCfg<GEMM_64x128> { static constexpr int WM = 2, WN = 2, TM = 1, TN = 2; static constexpr bool DUAL = false; static constexpr int MINB = 2; };
+template <> struct TileCfg<GEMM_128x128> { static constexpr int WM = 2, WN = 2, TM = 2, TN = 2; static constexpr bool DUAL = false; static constexpr int MINB = 2; static constexpr bool HF = false; };
+template <> struct TileCfg<GEMM_128x32> { static constexpr int WM = 4, WN = 1, TM = 1, TN = 1; static constexpr bool DUAL = false; static constexpr int MINB = FDQL_NARROW_MINB; static constexpr bool HF = false; };
+template <> struct TileCfg<GEMM_32x128> { static constexpr int WM = 1, WN = 4, TM = 1, TN = 1; static constexpr bool DUAL = false; static constexpr int MINB = FDQL_NARROW_MINB; static constexpr bool HF = false; };
+template <> struct TileCfg<GEMM_64x128> { static constexpr int WM = 2, WN = 2, TM = 1, TN = 2; static constexpr bool DUAL = false; static constexpr int MINB = 2; static constexpr bool HF = false; };
 // 64x128 tiles, two outputs: C = f(sum over segments <= emit_seg), C2 = f(sum over all segments) -
 // critic layer 0 of q(s, a) and q(s, pi) in one pass over s.Ws
 //   (no second accumulator: the tile is stored, the tail segments are added, the tile is stored again)
 // 64x64: for launches with too few 64x128 tiles to give every SIMD more than one wave (a single network's
 // layer at 12.5 k rows is 392 tiles on 256 CUs): twice the workgroups, one 32x32 MFMA tile per wave
-template <> struct TileCfg<GEMM_64x64> { static constexpr int WM = 2, WN = 2, TM = 1, TN = 1; static constexpr bool DUAL = false; static constexpr int MINB = 2; };
-template <> struct TileCfg<GEMM_64x128_DUAL> { static constexpr int WM = 2, WN = 2, TM = 1, TN = FDQL_DUAL_TN; static constexpr bool DUAL = true; static constexpr int MINB = 2; };
+template <> struct TileCfg<GEMM_64x64> { static constexpr int WM = 2, WN = 2, TM = 1, TN = 1; static constexpr bool DUAL = false; static constexpr int MINB = 2; static constexpr bool HF = false; };
+// 64x64 with the head-fusion epilogue (GemmProblem::hf_*): the hidden layers >= 1 of the critics
+template <> struct TileCfg<GEMM_64x64_HF> { static constexpr int WM = 2, WN = 2, TM = 1, TN = 1; static constexpr bool DUAL = false; static constexpr int MINB = 2; static constexpr bool HF = true; };
+template <> struct TileCfg<GEMM_64x128_DUAL> { static constexpr int WM = 2, WN = 2, TM = 1, TN = FDQL_DUAL_TN; static constexpr bool DUAL = true; static constexpr int MINB = 8; static constexpr bool HF = true; };
 
 // Pointers that come out of the problem tables are generic to the compiler, which would emit
 // FLAT loads: those also count on lgkmcnt, so the `s_waitcnt lgkmcnt(0)` in front of the MFMAs
@@ -274,6 +276,39 @@ __device__ __forceinline__ void frag_ready(float (&f)[T]) {
   for (int t = 0; t < T; ++t) asm volatile("" : "+v"(f[t]));
 }
 
+// Head fusion (GemmProblem::hf_*): a wave holds 32 rows x 32 columns of an activation tile - 16 rows per lane half,
+// one column per lane (D layout of the 32x32 MFMA tile).  Per group of 8/Q rows the 8 products x * w[q] are summed
+// over the 32 column lanes by a halving butterfly (4 + 2 + 1 exchanges, then 2 full steps): lane bits (4,3,2) pick
+// which of the 8 sums a lane ends up with, lanes with (lane & 3) == 0 store it.  x is recomputed from the accumulator.
+template <int Q>
+__device__ __forceinline__ void hf_partial(const f32x16 &acc, float bv, int epi, const float (&wq)[8], bool cok, int lane,
+                                           int M, int rbase, gf out, int plane) {
+  constexpr int GROWS = 8 / Q;
+  const int b4 = (lane >> 4) & 1, b3 = (lane >> 3) & 1, b2 = (lane >> 2) & 1;
+  const int jmine = 4 * b4 + 2 * b3 + b2, rr_mine = jmine / Q, q_mine = jmine - rr_mine * Q;
+#pragma unroll
+  for (int g0 = 0; g0 < 16; g0 += GROWS) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float x = acc[g0 + j / Q] + bv;
+      if (epi == EPI_LRELU) x = x > 0.f ? x : 0.01f * x;
+      v[j] = cok ? x * wq[j % Q] : 0.f;
+    }
+    float h4[4], h2[2], h1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h4[j] = (b4 ? v[4 + j] : v[j]) + __shfl_xor(b4 ? v[j] : v[4 + j], 16);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) h2[j] = (b3 ? h4[2 + j] : h4[j]) + __shfl_xor(b3 ? h4[j] : h4[2 + j], 8);
+    h1 = (b2 ? h2[1] : h2[0]) + __shfl_xor(b2 ? h2[0] : h2[1], 4);
+    h1 += __shfl_xor(h1, 2);
+    h1 += __shfl_xor(h1, 1);
+    const int r = g0 + rr_mine;
+    const int row = rbase + (r & 3) + 8 * (r >> 2);
+    if ((lane & 3) == 0 && row < M) out[((long long)plane * M + row) * Q + q_mine] = h1;
+  }
+}
+
 template <int SHAPE, int BK, int PIPE>
 __global__ __launch_bounds__(GEMM_THREADS, TileCfg<SHAPE>::MINB) void k_gemm_grouped(const GemmProblem *__restrict__ probs, int nprob) {
   using Cfg = TileCfg<SHAPE>;
@@ -476,9 +511,28 @@ __global__ __launch_bounds__(GEMM_THREADS, TileCfg<SHAPE>::MINB) void k_gemm_gro
             const float a = ref[(long long)row * ldref + col];
             x = a > 0.f ? x : 0.01f * x;
           }
+          else if (epi == EPI_ADD_REF) x += ref[(long long)row * ldref + col];
           C[(long long)row * ldc + col] = x;
           if (!second) csum[tn] += x;
         }
+      }
+    }
+    if constexpr (Cfg::HF && TM == 1 && TN == 1) {
+      gcf hw = (gcf)P.hf_w;
+      if (hw) {
+        const int Q = P.hf_q, ldw = P.hf_ldw;
+        gf out = (gf)(second ? P.hf_out2 : P.hf_out);
+        const int col = c0 + wn * 32 + li;
+        const bool cok = col < N;
+        const float bv = (bias && cok) ? bias[col] : 0.f;
+        float wq[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) wq[q] = (q < Q && cok) ? hw[(long long)q * ldw + col] : 0.f;
+        const int plane = (c0 / 64) * 2 + wn, rbase = r0 + wm * 32 + 4 * lh;
+        if (Q == 2) hf_partial<2>(acc[0][0], bv, epi, wq, cok, lane, M, rbase, out, plane);
+        else if (Q == 1) hf_partial<1>(acc[0][0], bv, epi, wq, cok, lane, M, rbase, out, plane);
+        else if (Q == 4) hf_partial<4>(acc[0][0], bv, epi, wq, cok, lane, M, rbase, out, plane);
+        else hf_partial<8>(acc[0][0], bv, epi, wq, cok, lane, M, rbase, out, plane);
       }
     }
   };
@@ -524,8 +578,8 @@ __global__ __launch_bounds__(GEMM_THREADS, TileCfg<SHAPE>::MINB) void k_gemm_gro
 }
 
 static void shape_dims(int shape, int &bm, int &bn) {
-  bm = shape == GEMM_32x128 ? 32 : ((shape == GEMM_64x128 || shape == GEMM_64x128_DUAL || shape == GEMM_64x64) ? 64 : 128);
-  bn = shape == GEMM_128x32 ? 32 : (shape == GEMM_64x64 ? 64 : (shape == GEMM_64x128_DUAL ? 64 * FDQL_DUAL_TN : 128));
+  bm = shape == GEMM_32x128 ? 32 : ((shape == GEMM_64x128 || shape == GEMM_64x128_DUAL || shape == GEMM_64x64 || shape == GEMM_64x64_HF) ? 64 : 128);
+  bn = shape == GEMM_128x32 ? 32 : ((shape == GEMM_64x64 || shape == GEMM_64x64_HF) ? 64 : (shape == GEMM_64x128_DUAL ? 64 * FDQL_DUAL_TN : 128));
 }
 
 int gemm_finalize(GemmProblem *probs, int nprob, int shape) {
@@ -561,6 +615,7 @@ int gemm_dense_shape() {
 
 int gemm_pick_shape(const GemmProblem &p, int dense_shape) {
   if (p.emit_seg >= 0) return GEMM_64x128_DUAL;
+  if (p.hf_w) return GEMM_64x64_HF;
   if (p.N <= 32) return GEMM_128x32;
   if (p.M <= 32 && !p.colsum) return GEMM_32x128;
   return dense_shape;
@@ -609,6 +664,7 @@ hipError_t gemm_launch(const GemmProblem *probs_dev, int nprob, int total_blocks
   else if (shape == GEMM_64x128) launch_shape<GEMM_64x128>(probs_dev, nprob, total_blocks, v, stream);
   else if (shape == GEMM_64x128_DUAL) launch_shape<GEMM_64x128_DUAL>(probs_dev, nprob, total_blocks, v, stream);
   else if (shape == GEMM_64x64) launch_shape<GEMM_64x64>(probs_dev, nprob, total_blocks, v, stream);
+  else if (shape == GEMM_64x64_HF) launch_shape<GEMM_64x64_HF>(probs_dev, nprob, total_blocks, v, stream);
   else launch_shape<GEMM_32x128>(probs_dev, nprob, total_blocks, v, stream);
   return hipGetLastError();
 }

@@ -907,6 +907,8 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const float *__restrict
   __shared__ float red[4][64];
   const int el = threadIdx.x & 63, pl = threadIdx.x >> 6;
   const long long e = (long long)blockIdx.x * 64 + el;
+  part += (long long)blockIdx.y * nparts * n;   // gridDim.y independent instances, back to back
+  dst += (long long)blockIdx.y * n;
   float s0 = 0.f, s1 = 0.f;
   if (e < n) {
     int p = pl;
@@ -921,6 +923,10 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const float *__restrict
 hipError_t colsum_tall_launch(const float *X, long long R, int C, int ld, float *partial, hipStream_t s) {
   if (R <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_colsum_tall, dim3(colsum_tall_blocks(R)), dim3(256), 0, s, X, R, C, ld, partial);
+  return hipGetLastError();
+}
+hipError_t reduce_partials_batched_launch(const float *part, int ninst, int nparts, long long n, float *dst, hipStream_t s) {
+  hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n + 63) / 64), ninst), dim3(256), 0, s, part, nparts, n, dst);
   return hipGetLastError();
 }
 hipError_t reduce_partials_launch(const float *part, int nparts, long long n, float *dst, hipStream_t s) {

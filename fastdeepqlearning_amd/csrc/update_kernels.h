@@ -129,6 +129,8 @@ inline int colsum_tall_blocks(long long R) { return (int)((R + COLSUM_TALL_ROWS 
 hipError_t colsum_tall_launch(const float *X, long long R, int C, int ld, float *partial, hipStream_t s);
 // dst[e] = sum_p part[p][e] for e < n (fixed order)
 hipError_t reduce_partials_launch(const float *part, int nparts, long long n, float *dst, hipStream_t s);
+// the same for `ninst` independent instances laid out back to back: part [ninst][nparts][n] -> dst [ninst][n]
+hipError_t reduce_partials_batched_launch(const float *part, int ninst, int nparts, long long n, float *dst, hipStream_t s);
 // ---- GRU joiner (torch.nn.GRU cell, gate order r, z, n; encoder.py:40-42)
 // start state of the scan: mode 0 zeros, 1 rows copied from src [B, L], 2 src [L] repeated over the batch
 hipError_t gru_h0_launch(int mode, const float *src, float *h0, int B, int L, hipStream_t s);

@@ -444,11 +444,23 @@ def test_update_matches_oracle_config2(dev, T, B, hid):
     ("deep nets (3-layer critic, 2-layer actor/encoder)", dict(obs=9, act=4, C=3, Q=5, T=4, B=40, critic_hidden=(64, 96, 64),
                                                                pi_hidden=(64, 48), enc_hidden=(80, 64), joint_hidden=(64, 64),
                                                                latent=64, enc_features=48)),
+    ("fused skip-head partials, 4 quantiles, ragged critic widths 96/40 (partial column tiles, 3-layer head sum)",
+     dict(obs=7, act=3, C=3, Q=4, T=5, B=52, critic_hidden=(96, 40, 70), pi_hidden=(64,), enc_hidden=(64,), joint_hidden=(64,),
+          latent=64, enc_features=48)),
+    ("fused skip-head partials, 8 quantiles (one row per butterfly group)",
+     dict(obs=7, act=3, C=2, Q=8, T=4, B=33, critic_hidden=(128, 64), pi_hidden=(64,), enc_hidden=(64,), joint_hidden=(64,),
+          latent=64, enc_features=48)),
+    ("config 2 dims with the head fusion switched off (FDQL_NO_HEAD_FUSE: the head streams every activation)",
+     dict(obs=17, act=6, C=5, Q=2, T=4, B=64, env={"FDQL_NO_HEAD_FUSE": "1"})),
+    ("config 2 dims without the dual-output first layer (FDQL_NO_DUAL)",
+     dict(obs=17, act=6, C=5, Q=2, T=4, B=64, env={"FDQL_NO_DUAL": "1"})),
 ])
-def test_update_matches_oracle_other_configs(dev, name, kw):
+def test_update_matches_oracle_other_configs(dev, name, kw, monkeypatch):
     """The remaining BASELINE configs' shapes (and non-default depths) against the CPU oracle, one step."""
     from oracle import update as oup
     kw = dict(kw)
+    for k, v in kw.pop("env", {}).items():      # plan switches are read when the agent is created
+        monkeypatch.setenv(k, v)
     T, B = kw.pop("T"), kw.pop("B")
     base = dict(latent=256, enc_features=256, enc_hidden=(256,), joint_hidden=(256,), pi_hidden=(256,), critic_hidden=(256, 256))
     base.update(kw)

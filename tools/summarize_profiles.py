@@ -44,7 +44,7 @@ for key in fetch:
     t[2] += fetch[key][1]
 open(os.path.join(out, "hbm_traffic_pmc.txt"), "w").write("\n".join(lines) + "\n")
 # dominant kernel = the tile-shape instantiation bench.py names in its roofline object
-shape_id = {"128x128": 0, "128x32": 1, "32x128": 2, "64x128": 3, "64x128dual": 4, "64x64": 5}
+shape_id = {"128x128": 0, "128x32": 1, "32x128": 2, "64x128": 3, "64x128dual": 4, "64x64": 5, "64x64hf": 6}
 dom_shape = "64x64"
 try:
     for line in open(os.path.join(out, "bench_n1.json")):
