@@ -1322,7 +1322,7 @@ int32_t fdql_agent_profile_update(fdql_agent_t *a, const fdql_batch_t *batch, co
     FDQL_HIP(hipEventRecord(ev[i + 1], s));
   }
   FDQL_HIP(hipStreamSynchronize(s));
-  static const char *shape_names[GEMM_NSHAPES] = {"128x128", "128x32", "32x128", "64x128", "64x128dual", "64x64", "64x64hf"};
+  static const char *shape_names[GEMM_NSHAPES] = {"128x128", "128x32", "32x128", "64x128", "64x128dual", "64x64", "64x64hf", "dma128x128", "dma128x64", "dma64x64"};
   int32_t cnt = 0;
   for (size_t i = 0; i < n && cnt < cap; ++i, ++cnt) {
     float ms = 0;
@@ -1538,7 +1538,7 @@ int fdql_debug_set_gemm_variant(int32_t variant) {
 }
 
 int fdql_debug_set_gemm_dense_shape(int32_t shape) {
-  FDQL_REQUIRE(gemm_shape_is_dense(shape), "dense shape must be 0 (128x128), 3 (64x128) or 5 (64x64)");
+  FDQL_REQUIRE(gemm_shape_is_dense(shape), "dense shape must be 0 (128x128), 3 (64x128), 5 (64x64) or an LDS-DMA shape 7 (128x128), 8 (128x64), 9 (64x64)");
   gemm_set_dense_shape(shape);
   return 0;
 }

@@ -44,7 +44,8 @@ struct GemmSeg {
 };
 
 enum GemmEpilogue { EPI_NONE = 0, EPI_LRELU = 1, EPI_LRELU_GRAD = 2, EPI_ADD_REF = 3 /* x += ref[row][col] */ };
-enum GemmShape { GEMM_128x128 = 0, GEMM_128x32 = 1, GEMM_32x128 = 2, GEMM_64x128 = 3, GEMM_64x128_DUAL = 4, GEMM_64x64 = 5, GEMM_64x64_HF = 6, GEMM_NSHAPES = 7 };
+enum GemmShape { GEMM_128x128 = 0, GEMM_128x32 = 1, GEMM_32x128 = 2, GEMM_64x128 = 3, GEMM_64x128_DUAL = 4, GEMM_64x64 = 5, GEMM_64x64_HF = 6,
+                 GEMM_DMA_128x128 = 7, GEMM_DMA_128x64 = 8, GEMM_DMA_64x64 = 9 /* LDS-DMA staged dense shapes */, GEMM_NSHAPES = 10 };
 
 struct GemmProblem {
   int M, N;

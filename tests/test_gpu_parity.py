@@ -36,9 +36,9 @@ def dev():
 
 # --------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("M,N,K", [(128, 128, 16), (256, 256, 256), (200, 70, 33), (1000, 262, 258), (64, 6, 300),
-                                   (513, 129, 17)])
+                                   (513, 129, 17), (1024, 384, 272)])
 @pytest.mark.parametrize("form", ["nt", "nn", "tn"])
-@pytest.mark.parametrize("dense", [5, 3, 0])     # 64x64 (default), 64x128, 128x128 tiles
+@pytest.mark.parametrize("dense", [7, 8, 9, 5, 3, 0])     # LDS-DMA 128x128 / 128x64 / 64x64; register-staged 64x64, 64x128, 128x128
 def test_gemm_forms(dev, M, N, K, form, dense):
     from fastdeepqlearning_amd import _native as nat
     lib = nat.load()
@@ -65,9 +65,11 @@ def test_gemm_forms(dev, M, N, K, form, dense):
     assert rel_err(c_d, ref) < 2e-6
 
 
-def test_gemm_epilogues_and_ksplit(dev):
+@pytest.mark.parametrize("dense", [7, 8, 9, 5])
+def test_gemm_epilogues_and_ksplit(dev, dense):
     from fastdeepqlearning_amd import _native as nat
     lib = nat.load()
+    nat.check(lib.fdql_debug_set_gemm_dense_shape(dense))
     g = torch.Generator().manual_seed(5)
     M, N, K = 300, 140, 1000
     A, Bm = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g)
@@ -85,6 +87,7 @@ def test_gemm_epilogues_and_ksplit(dev):
     slabs = torch.full((S, M, N), float("nan"), device=dev)
     nat.check(lib.fdql_test_gemm(nat.ptr(a_d), K, 1, nat.ptr(b_d), N, 0, None, nat.ptr(slabs), N, M, N, K, 0, None, 0,
                                  S, nat.current_stream()))
+    nat.check(lib.fdql_debug_set_gemm_dense_shape(5))
     assert rel_err(slabs.sum(0), base.float()) < 2e-6
 
 
