@@ -200,14 +200,6 @@ __device__ __forceinline__ void load_operands(const float *A, int lda, int akc, 
   if (bkc) load_chunk_kc<BNT, NVB, BKT>(B, ldb, N, kend, c0, k0, tid, vb); else load_chunk_ks<BNT, NVB, BKT>(B, ldb, N, kend, c0, k0, tid, vb);
 }
 
-// LDS image [k][row], pitch rows + 4.  A K-contiguous operand is written transposed - a lane holds 4 k's of one row, the
-// 32 lanes of a store group cover 8 rows x 4 k-quads - and with the plain layout k-quads 0 and 2 (and 1 and 3) land on the
-// same banks (4 * pitch = 16 banks mod 32): every such ds_write_b32 is a 2-way conflict.  Rows of the k's >= 8 are
-// therefore stored at row ^ 8; the fragment reads of k-steps >= 4 apply the same flip (still 32 consecutive banks).
-#ifndef FDQL_LDS_SWIZZLE
-#define FDQL_LDS_SWIZZLE 0   // measured: no gain (1.77 vs 1.78 ms/step); the 2-way conflict hides behind the 4-cycle store issue
-#endif
-#define FDQL_SWZ(k) (FDQL_LDS_SWIZZLE ? ((((k) >> 3) & 1) << 3) : 0)
 template <int R, int NV, int BKT>
 __device__ __forceinline__ void store_chunk_kc(float *__restrict__ lds, int tid, const float (&v)[4 * NV]) {
   constexpr int PITCH = R + 4, KQ = BKT / 4;
@@ -217,7 +209,7 @@ __device__ __forceinline__ void store_chunk_kc(float *__restrict__ lds, int tid,
     const int kq = (slot % KQ) * 4, r = slot / KQ;
     if (r < R) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) lds[(kq + j) * PITCH + (r ^ FDQL_SWZ(kq))] = v[4 * h + j];
+      for (int j = 0; j < 4; ++j) lds[(kq + j) * PITCH + r] = v[4 * h + j];
     }
   }
 }
@@ -230,7 +222,7 @@ __device__ __forceinline__ void store_chunk_ks(float *__restrict__ lds, int tid,
     const int slot = tid + GEMM_THREADS * h;
     const int kl = slot / RQ, rq = (slot - kl * RQ) * 4;
     if (kl < BKT)
-      *reinterpret_cast<float4 *>(&lds[kl * PITCH + (rq ^ FDQL_SWZ(kl))]) = make_float4(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
+      *reinterpret_cast<float4 *>(&lds[kl * PITCH + rq]) = make_float4(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
   }
 }
 
@@ -425,7 +417,6 @@ __global__ __launch_bounds__(GEMM_THREADS, TileCfg<SHAPE>::MINB) void k_gemm_gro
     // immediates (<= 64 KB) address the whole staged tile from two base registers.
     const unsigned la = lds_addr(lds[cur] + wm * (TM * 32) + li + lh * PA);
     const unsigned lb = lds_addr(lds[cur] + BK * PA + wn * (TN * 32) + li + lh * PB);
-    const int flip = FDQL_LDS_SWIZZLE ? ((li & 8) ? -32 : 32) : 0;   // bytes from row li to row li ^ 8
     constexpr int NS = BK / 2;
     // k-steps that hold data: a ragged last chunk (or a narrow segment such as the Q columns of dz or
     // the 6 action columns) stops early instead of multiplying staged zeros
@@ -444,8 +435,8 @@ __global__ __launch_bounds__(GEMM_THREADS, TileCfg<SHAPE>::MINB) void k_gemm_gro
       if (PIPE && kk + 1 < NS) {
         // next k-step's fragments are requested before this step's MFMAs issue; LDS returns in order,
         // so "at most TM+TN reads outstanding" means this step's fragments have landed
-        frag_read_dyn<TM, PA>(a[(kk + 1) & 1], kk + 1 >= 4 ? la + flip : la, kk + 1);
-        frag_read_dyn<TN, PB>(b[(kk + 1) & 1], kk + 1 >= 4 ? lb + flip : lb, kk + 1);
+        frag_read_dyn<TM, PA>(a[(kk + 1) & 1], la, kk + 1);
+        frag_read_dyn<TN, PB>(b[(kk + 1) & 1], lb, kk + 1);
         lds_wait<TM + TN>();
       } else {
         lds_wait<0>();
@@ -458,8 +449,8 @@ __global__ __launch_bounds__(GEMM_THREADS, TileCfg<SHAPE>::MINB) void k_gemm_gro
         for (int tn = 0; tn < TN; ++tn)
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[tm], bc[tn], acc[tm][tn], 0, 0, 0);
       if (!PIPE && kk + 1 < NS) {
-        frag_read_dyn<TM, PA>(a[(kk + 1) & 1], kk + 1 >= 4 ? la + flip : la, kk + 1);
-        frag_read_dyn<TN, PB>(b[(kk + 1) & 1], kk + 1 >= 4 ? lb + flip : lb, kk + 1);
+        frag_read_dyn<TM, PA>(a[(kk + 1) & 1], la, kk + 1);
+        frag_read_dyn<TN, PB>(b[(kk + 1) & 1], lb, kk + 1);
       }
     }
     // the two base registers stay reserved until every read of the chunk has returned, so no
@@ -619,7 +610,7 @@ typedef const __attribute__((address_space(1))) void *glb_vp;
 
 template <int SHAPE> struct DmaCfg;
 #ifndef FDQL_DMA_NBUF_128
-#define FDQL_DMA_NBUF_128 4
+#define FDQL_DMA_NBUF_128 3   // 48 KB -> 3 workgroups per CU: 88.9 TF vs 81.4 with 4 images (2 per CU) at 192000x256x256
 #endif
 template <> struct DmaCfg<GEMM_DMA_128x128> { static constexpr int TM = 2, TN = 2, NBUF = FDQL_DMA_NBUF_128, MINB = FDQL_DMA_NBUF_128 == 3 ? 3 : 2; };
 template <> struct DmaCfg<GEMM_DMA_128x64> { static constexpr int TM = 2, TN = 1, NBUF = 4, MINB = 3; };
@@ -764,10 +755,7 @@ __global__ __launch_bounds__(GEMM_THREADS, DmaCfg<SHAPE>::MINB) void k_gemm_dma(
     float *img = lds[buf];
     gcf baseA = pA, baseB = pB;
     pA += incA; pB += incB;
-#ifndef FDQL_DMA_EXPERIMENT
-#define FDQL_DMA_EXPERIMENT 0   // 1: timing-only build that assumes interior tiles, full chunks, kc operands (wrong otherwise)
-#endif
-    if (FDQL_DMA_EXPERIMENT || (interior && kl >= BK)) {
+    if (interior && kl >= BK) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
         __builtin_amdgcn_global_load_lds((glb_vp)(baseA + i * stA + voa), (lds_vp)(img + (wave + 4 * i) * 256), 16, 0, 0);
@@ -834,7 +822,6 @@ __global__ __launch_bounds__(GEMM_THREADS, DmaCfg<SHAPE>::MINB) void k_gemm_dma(
     const unsigned lb = lds_addr(lds[buf]);
     const unsigned a0 = lb + fa_kc0, a1 = lb + fa_kc1, as = lb + fa_ks;
     const unsigned b0 = lb + fb_kc0, b1 = lb + fb_kc1, bs = lb + fb_ks;
-    if (FDQL_DMA_EXPERIMENT) { akc = 1; bkc = 1; }
     if (akc) { dma_frag_kc<TM, BM, 0>(fa, a0, a1); dma_frag_kc<TM, BM, 1>(ga, a0, a1); }
     else { dma_frag_ks<TM, BM, 0>(fa, as); dma_frag_ks<TM, BM, 1>(ga, as); }
     if (bkc) { dma_frag_kc<TN, BN, 0>(fb, b0, b1); dma_frag_kc<TN, BN, 1>(gb, b0, b1); }

@@ -17,4 +17,6 @@ python3 $R/tools/profile_stages.py > $OUT/stage_times.txt 2>&1 || exit 1
 # 3. HBM traffic of every kernel of one update: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (TCC slots)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/tools/profile_stages.py --reps 1 > $OUT/pmc_fetch.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/tools/profile_stages.py --reps 1 > $OUT/pmc_write.log 2>&1 || exit 1
+# 4. matrix-pipe utilisation of every GEMM launch of one update (SQ counters, their own pass)
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $OUT/pmc_sq -- python3 $R/tools/profile_stages.py --reps 1 > $OUT/pmc_sq.log 2>&1 || exit 1
 python3 $R/tools/summarize_profiles.py $OUT

@@ -59,6 +59,43 @@ if dom:
                "hbm_write_MB_per_launch": t[1] / t[2], "hbm_bytes_per_launch": (t[0] + t[1]) / t[2] * 1e6,
                "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE doubled (gfx950)",
                "workload": "config 2, T=50, B=256"}, open(os.path.join(out, "dominant_kernel_traffic.json"), "w"), indent=1)
+# matrix-pipe utilisation per GEMM kernel: SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of the 1024 SIMDs' MFMA pipes,
+# SQ_BUSY_CYCLES the cycles the 32 shader engines (8 XCD x 4) had work: utilisation = (MFMA/1024) / (BUSY/32); the
+# kernel trace of the same pass gives the duration, hence the shader clock the kernel actually ran at.
+sq_rows = counter_rows("pmc_sq")
+if sq_rows:
+    per = collections.OrderedDict()
+    for r in sq_rows:
+        if "k_gemm" not in r["Kernel_Name"]:
+            continue
+        key = (r["Kernel_Name"].split("(")[0], int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0))
+        d = per.setdefault(key, collections.defaultdict(float))
+        d[r["Counter_Name"]] += float(r["Counter_Value"])
+        d["n_" + r["Counter_Name"]] += 1
+    dur = collections.defaultdict(lambda: [0.0, 0])
+    kt = sorted(glob.glob(os.path.join(out, "pmc_sq", "**", "*_kernel_trace.csv"), recursive=True), key=os.path.getmtime)
+    if kt:
+        for r in csv.DictReader(open(kt[-1])):
+            if "k_gemm" in r["Kernel_Name"]:
+                key = (r["Kernel_Name"].split("(")[0], int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0))
+                dur[key][0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
+                dur[key][1] += 1
+    sq_lines = ["# rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY over",
+                "# tools/profile_stages.py --reps 1 (config 2, T=50, B=256); per dispatch means.",
+                "# mfma_util = (MFMA_BUSY / 1024 SIMDs) / (BUSY_CYCLES / 32 shader engines); clock = (BUSY_CYCLES / 32) / duration;",
+                "# waves = SQ_WAVE_CYCLES x 4 / 1024 / (BUSY_CYCLES / 32) = resident waves per SIMD; parked = SQ_WAIT_ANY / SQ_WAVE_CYCLES",
+                "# (waves sitting at s_waitcnt / s_barrier)."]
+    for key, d in per.items():
+        n = max(d["n_SQ_BUSY_CYCLES"], 1.0)
+        busy = d["SQ_BUSY_CYCLES"] / n / 32.0
+        mf = d["SQ_VALU_MFMA_BUSY_CYCLES"] / max(d["n_SQ_VALU_MFMA_BUSY_CYCLES"], 1.0) / 1024.0
+        wc = d["SQ_WAVE_CYCLES"] / max(d["n_SQ_WAVE_CYCLES"], 1.0)
+        wa = d["SQ_WAIT_ANY"] / max(d["n_SQ_WAIT_ANY"], 1.0)
+        us = dur[key][0] / dur[key][1] if dur[key][1] else float("nan")
+        sq_lines.append(f"{key[0]:58s} grid={key[1]:8d} n={int(n):3d} dur_us={us:8.1f} mfma_util={mf / busy if busy else 0:5.3f} "
+                        f"clock_GHz={busy / us / 1e3 if us == us and us > 0 else float('nan'):5.2f} waves_per_simd={wc * 4 / 1024 / busy if busy else 0:4.1f} "
+                        f"parked={wa / wc if wc else 0:4.2f}")
+    open(os.path.join(out, "mfma_utilisation_pmc.txt"), "w").write("\n".join(sq_lines) + "\n")
 # kernel stats csv of the bench run
 st = sorted(glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
 if st:
