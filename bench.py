@@ -20,6 +20,7 @@ and `cpu_baseline` (the CPU oracle = port of the reference path, timed on this h
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -242,6 +243,22 @@ def main():
             roofline["traffic_unit"] = "bytes/launch (HBM read+write, PMC FETCH_SIZE x2 + WRITE_SIZE)"
             roofline["traffic_source"] = "profiles/r01_hbm_traffic_pmc.txt (" + tr["source"] + ")"
             roofline["algorithmic_bytes_per_launch"] = sum(v[2] * v[3] for v in dom.values()) / reps / max(n_gemm, 1)
+        # matrix-pipe utilisation and shader clock of the same kernel, from the committed SQ-counter pass
+        uj = os.path.join(ROOT, "profiles", "r01_mfma_utilisation_pmc.txt")
+        if os.path.exists(uj) and T == 50 and B == 256:
+            shape_id = {"128x128": 0, "128x32": 1, "32x128": 2, "64x128": 3, "64x128dual": 4, "64x64": 5, "64x64hf": 6}
+            tag = f"k_gemm_grouped<{shape_id.get(dom_name[4:], -1)},"
+            wsum = usum = csum = 0.0
+            for line in open(uj):
+                if tag in line:
+                    f = dict(re.findall(r"(\w+)=\s*([\d.]+)", line))
+                    w = float(f["dur_us"]) * float(f["n"])      # time-weighted over that kernel's launches
+                    wsum += w; usum += w * float(f["mfma_util"]); csum += w * float(f["clock_GHz"])
+            if wsum > 0:
+                roofline["mfma_pipe_busy_frac"] = round(usum / wsum, 3)
+                roofline["shader_clock_ghz_under_load"] = round(csum / wsum, 2)
+                roofline["pmc_source"] = ("profiles/r01_mfma_utilisation_pmc.txt (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES "
+                                          "SQ_BUSY_CYCLES; peak 157.3 TFLOP/s assumes 2.4 GHz)")
         breakdown = {k: round(v[0] / reps, 4) for k, v in sorted(acc.items(), key=lambda kv: -kv[1][0])[:12]}
         # sampler on its own: HBM-bound gather, algorithmic bytes = 2*T*B*rowbytes + 8*B
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
