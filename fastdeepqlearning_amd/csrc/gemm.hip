@@ -35,6 +35,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //                 196 tiles of 128x128 on 256 CUs; halving the tile doubles the workgroups)
 // The narrow shapes waste MFMA lanes on padding but those problems are bandwidth-bound: what
 // matters is that they stream their big operand through the same coalesced LDS staging.
+#ifndef FDQL_MFMA_PRIO
+#define FDQL_MFMA_PRIO 1   // s_setprio around a chunk's MFMA k-steps: waves that have their operands go before waves still
+#endif                   // forming addresses (1.770 -> 1.729 ms/update; priority on the operand requests instead: 1.82)
 #ifndef FDQL_NARROW_MINB
 #define FDQL_NARROW_MINB 6   // occupancy target of the narrow (bandwidth-bound) shapes: 72 VGPR, 7 waves/SIMD (92 / 5 without)
 #endif
@@ -424,6 +427,9 @@ __global__ __launch_bounds__(GEMM_THREADS, TileCfg<SHAPE>::MINB) void k_gemm_gro
     float a[2][TM], b[2][TN];
     frag_read<TM, 0, PA>(a[0], la);
     frag_read<TN, 0, PB>(b[0], lb);
+#if FDQL_MFMA_PRIO
+    __builtin_amdgcn_s_setprio(FDQL_MFMA_PRIO);
+#endif
 #pragma unroll
     for (int kk = 0; kk < NS; ++kk) {
       if (kk >= ksteps) {   // wave-uniform
@@ -456,6 +462,9 @@ __global__ __launch_bounds__(GEMM_THREADS, TileCfg<SHAPE>::MINB) void k_gemm_gro
     // the two base registers stay reserved until every read of the chunk has returned, so no
     // fragment destination is ever allocated on top of an address still in use by an in-flight read
     asm volatile("" ::"v"(la), "v"(lb));
+#if FDQL_MFMA_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
   };
   while (have) {
     // locate the next chunk
@@ -809,6 +818,9 @@ __global__ __launch_bounds__(GEMM_THREADS, DmaCfg<SHAPE>::MINB) void k_gemm_dma(
     for (int t = 0; t < TM; ++t) asm volatile("" : "+v"(a[t]));   // orders the MFMAs behind the lgkmcnt wait
 #pragma unroll
     for (int t = 0; t < TN; ++t) asm volatile("" : "+v"(b[t]));
+#if FDQL_MFMA_PRIO
+    __builtin_amdgcn_s_setprio(FDQL_MFMA_PRIO);
+#endif
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -816,6 +828,9 @@ __global__ __launch_bounds__(GEMM_THREADS, DmaCfg<SHAPE>::MINB) void k_gemm_dma(
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][c], b[tn][c], acc[tm][tn], 0, 0, 0);
+#if FDQL_MFMA_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
   };
   v4f fa[TM], fb[TN], ga[TM], gb[TN];   // fragments of the chunk being multiplied (read groups 0 and 1)
   auto read_frags = [&](int buf, int akc, int bkc) __attribute__((always_inline)) {
