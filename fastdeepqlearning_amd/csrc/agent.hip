@@ -333,8 +333,10 @@ void carve(fdql_agent *a) {
     int planes = 0;
     for (int h : a->critic[0].hid) planes += ((h + 63) / 64) * 2;
     a->hf_planes = planes;
-    a->alloc("hf.parts", (int64_t)3 * c.n_critics * planes * M * c.n_quantiles);
-    a->alloc("hf.sum", (int64_t)3 * c.n_critics * M * c.n_quantiles);
+    const int q = c.n_quantiles;
+    const bool can_fuse = planes > 0 && (q == 1 || q == 2 || q == 4 || q == 8);   // same rule as the plan below
+    a->alloc("hf.parts", can_fuse ? (int64_t)3 * c.n_critics * planes * M * q : 1);
+    a->alloc("hf.sum", can_fuse ? (int64_t)3 * c.n_critics * M * q : 1);
   }
   a->alloc("next_z", M * Nq);
   a->alloc("q_pred", M * Nq);
