@@ -66,9 +66,7 @@ template <> struct TileCfg<GEMM_64x128_DUAL> { static constexpr int WM = 2, WN =
 typedef const __attribute__((address_space(1))) float *gcf;
 typedef __attribute__((address_space(1))) float *gf;
 typedef float v4f __attribute__((ext_vector_type(4)));
-typedef float v2f __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) v4f *gcf4;
-typedef const __attribute__((address_space(1))) v2f *gcf2;
 
 // Values read from the problem table are wave-uniform, but the table lives in memory the kernel may
 // also write (hipcc cannot prove otherwise), so they arrive through vector loads.  Pinning them into
@@ -80,8 +78,6 @@ __device__ __forceinline__ const float *uni(const float *p) {
   return reinterpret_cast<const float *>(((uintptr_t)hi << 32) | lo);
 }
 
-__device__ __forceinline__ bool aligned16(gcf p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-__device__ __forceinline__ bool aligned8(gcf p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
 
 // Load this thread's share of a [R rows x BKT k] operand chunk: NV float4 slots per thread
 // (NV = ceil(R*BKT/4/256)).  kc: element (r,k) at P[r*ld + k]; slot -> row = slot / (BKT/4),
@@ -98,17 +94,8 @@ __device__ __forceinline__ void load_chunk_kc(const float *__restrict__ P, int l
     const bool in_tile = (slot / KQ) < R;
     gcf p = (gcf)(P + (long long)r * ld + kq);
     if (in_tile && r < Rmax && kq + 3 < kend) {
-      if (aligned16(p)) {
-        const v4f x = *(gcf4)p;
-        v[4 * h + 0] = x.x; v[4 * h + 1] = x.y; v[4 * h + 2] = x.z; v[4 * h + 3] = x.w;
-      } else if (aligned8(p)) {
-        const v2f x = *(gcf2)p;
-        const v2f y = *(gcf2)(p + 2);
-        v[4 * h + 0] = x.x; v[4 * h + 1] = x.y; v[4 * h + 2] = y.x; v[4 * h + 3] = y.y;
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[4 * h + j] = p[j];
-      }
+      const v4f x = *(gcf4)p;   // any 4-byte aligned address (see operand_fast)
+      v[4 * h + 0] = x.x; v[4 * h + 1] = x.y; v[4 * h + 2] = x.z; v[4 * h + 3] = x.w;
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[4 * h + j] = (in_tile && r < Rmax && kq + j < kend) ? p[j] : 0.f;
@@ -130,17 +117,8 @@ __device__ __forceinline__ void load_chunk_ks(const float *__restrict__ P, int l
     const bool in_tile = kl < BKT;
     gcf p = (gcf)(P + (long long)k * ld + rq);
     if (in_tile && k < kend && rq + 3 < Rmax) {
-      if (aligned16(p)) {
-        const v4f x = *(gcf4)p;
-        v[4 * h + 0] = x.x; v[4 * h + 1] = x.y; v[4 * h + 2] = x.z; v[4 * h + 3] = x.w;
-      } else if (aligned8(p)) {
-        const v2f x = *(gcf2)p;
-        const v2f y = *(gcf2)(p + 2);
-        v[4 * h + 0] = x.x; v[4 * h + 1] = x.y; v[4 * h + 2] = y.x; v[4 * h + 3] = y.y;
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[4 * h + j] = p[j];
-      }
+      const v4f x = *(gcf4)p;   // any 4-byte aligned address (see operand_fast)
+      v[4 * h + 0] = x.x; v[4 * h + 1] = x.y; v[4 * h + 2] = x.z; v[4 * h + 3] = x.w;
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[4 * h + j] = (in_tile && k < kend && rq + j < Rmax) ? p[j] : 0.f;
@@ -158,7 +136,10 @@ __device__ __forceinline__ void load_chunk_ks(const float *__restrict__ P, int l
 template <int R, int BKT>
 __device__ __forceinline__ bool operand_fast(const float *P, int ld, int Rmax, int kend, int r0, int k0) {
   constexpr bool EXACT = (R * BKT / 4) % GEMM_THREADS == 0;
-  return EXACT && (r0 + R <= Rmax) && (k0 + BKT <= kend) && ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(P) & 15) == 0);
+  // gfx950 serves a dwordx4 load from any 4-byte aligned address (HSA runs with unaligned access enabled), so row pitches
+  // such as 262 or 273 floats need no special case: requiring ld % 4 == 0 and a 16-byte base here sent every chunk of the
+  // [256][262] critic layer-0 weights through the guarded loader and cost layer 0 and d state 12-14 % each
+  return EXACT && (r0 + R <= Rmax) && (k0 + BKT <= kend);
 }
 // per-lane element offset of slot 0 of an operand chunk (constant for a segment) and the uniform
 // distance between a thread's slots
