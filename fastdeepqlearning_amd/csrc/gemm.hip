@@ -39,7 +39,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define FDQL_MFMA_PRIO 1   // s_setprio around a chunk's MFMA k-steps: waves that have their operands go before waves still
 #endif                   // forming addresses (1.770 -> 1.729 ms/update; priority on the operand requests instead: 1.82)
 #ifndef FDQL_NARROW_MINB
-#define FDQL_NARROW_MINB 6   // occupancy target of the narrow (bandwidth-bound) shapes: 72 VGPR, 7 waves/SIMD (92 / 5 without)
+#define FDQL_NARROW_MINB 7   // occupancy target of the narrow (bandwidth-bound) shapes: 72 VGPR, 7 waves/SIMD (92 / 5 without)
 #endif
 #ifndef FDQL_DUAL_TN
 #define FDQL_DUAL_TN 1   // dual-output tiles: 64 x (64 * FDQL_DUAL_TN)
@@ -180,8 +180,45 @@ __device__ __forceinline__ void load_operands(const float *A, int lda, int akc, 
     for (int h = 0; h < NVB; ++h) { vb[4 * h] = xb[h].x; vb[4 * h + 1] = xb[h].y; vb[4 * h + 2] = xb[h].z; vb[4 * h + 3] = xb[h].w; }
     return;
   }
-  if (akc) load_chunk_kc<BMT, NVA, BKT>(A, lda, M, kend, r0, k0, tid, va); else load_chunk_ks<BMT, NVA, BKT>(A, lda, M, kend, r0, k0, tid, va);
-  if (bkc) load_chunk_kc<BNT, NVB, BKT>(B, ldb, N, kend, c0, k0, tid, vb); else load_chunk_ks<BNT, NVB, BKT>(B, ldb, N, kend, c0, k0, tid, vb);
+  // Mixed case (the narrow shapes: a 32-row operand is never a whole number of slots per thread; an edge tile in one
+  // dimension only): the guarded operand first - its loads wait on each other - then the interior one straight-line, so
+  // that its loads are the ones left in flight under the MFMAs.
+  if constexpr (BMT != 32 && BNT != 32) {   // dense shapes: both guarded (keeps them at 64 VGPRs)
+    if (akc) load_chunk_kc<BMT, NVA, BKT>(A, lda, M, kend, r0, k0, tid, va); else load_chunk_ks<BMT, NVA, BKT>(A, lda, M, kend, r0, k0, tid, va);
+    if (bkc) load_chunk_kc<BNT, NVB, BKT>(B, ldb, N, kend, c0, k0, tid, vb); else load_chunk_ks<BNT, NVB, BKT>(B, ldb, N, kend, c0, k0, tid, vb);
+    return;
+  }
+  const bool fa = operand_fast<BMT, BKT>(A, lda, M, kend, r0, k0), fb = operand_fast<BNT, BKT>(B, ldb, N, kend, c0, k0);
+  if (!fa) { if (akc) load_chunk_kc<BMT, NVA, BKT>(A, lda, M, kend, r0, k0, tid, va); else load_chunk_ks<BMT, NVA, BKT>(A, lda, M, kend, r0, k0, tid, va); }
+  if (!fb) { if (bkc) load_chunk_kc<BNT, NVB, BKT>(B, ldb, N, kend, c0, k0, tid, vb); else load_chunk_ks<BNT, NVB, BKT>(B, ldb, N, kend, c0, k0, tid, vb); }
+  if (fa) {
+    gcf baseA = (gcf)(akc ? A + (long long)r0 * lda + k0 : A + (long long)k0 * lda + r0);
+    const long long hsa = operand_slot_stride<BMT, BKT>(lda, akc);
+    gcf4 pa[NVA];
+#pragma unroll
+    for (int h = 0; h < NVA; ++h) pa[h] = (gcf4)(baseA + h * hsa + voa);
+    __builtin_amdgcn_sched_barrier(0);
+    v4f xa[NVA];
+#pragma unroll
+    for (int h = 0; h < NVA; ++h) xa[h] = *pa[h];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int h = 0; h < NVA; ++h) { va[4 * h] = xa[h].x; va[4 * h + 1] = xa[h].y; va[4 * h + 2] = xa[h].z; va[4 * h + 3] = xa[h].w; }
+  }
+  if (fb) {
+    gcf baseB = (gcf)(bkc ? B + (long long)c0 * ldb + k0 : B + (long long)k0 * ldb + c0);
+    const long long hsb = operand_slot_stride<BNT, BKT>(ldb, bkc);
+    gcf4 pb[NVB];
+#pragma unroll
+    for (int h = 0; h < NVB; ++h) pb[h] = (gcf4)(baseB + h * hsb + vob);
+    __builtin_amdgcn_sched_barrier(0);
+    v4f xb[NVB];
+#pragma unroll
+    for (int h = 0; h < NVB; ++h) xb[h] = *pb[h];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int h = 0; h < NVB; ++h) { vb[4 * h] = xb[h].x; vb[4 * h + 1] = xb[h].y; vb[4 * h + 2] = xb[h].z; vb[4 * h + 3] = xb[h].w; }
+  }
 }
 
 template <int R, int NV, int BKT>
