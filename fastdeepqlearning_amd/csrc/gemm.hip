@@ -127,7 +127,7 @@ __device__ __forceinline__ void load_chunk_ks(const float *__restrict__ P, int l
 }
 
 // Both operand chunks -> registers.  Interior, aligned chunks (the common case: the tile inside the
-// matrix, a whole K-chunk, ld % 4 == 0, 16-byte bases) take a straight-line path: every address is
+// matrix, a whole K-chunk; any row pitch) take a straight-line path: every address is
 // formed FIRST, then the loads issue back to back.  The order matters: hipcc reuses the (dead)
 // destination registers of the staging loads as address temporaries, and a temporary written while
 // an earlier load of this chunk is in flight costs an `s_waitcnt vmcnt(0)` - one exposed global-load
