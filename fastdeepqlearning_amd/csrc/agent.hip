@@ -660,14 +660,13 @@ int build_plan(fdql_agent *a) {
 
   // ---- stage 0: tick + prep
   {
-    b.func_stage("tick_alpha", [=](hipStream_t s) { return tick_alpha_launch(dst, log_alpha, s); });
     const float inv_gb = 1.0f / (float)(B * (c.world_size > 0 ? c.world_size : 1));
     float *w = a->buf("w"), *ic = a->buf("is_contiguous");
     const float *td = x.task_done, *es = x.episode_step;
     const int T = a->T;
     const int burn = c.burn_in_steps;
     const int cumprod = gru ? 1 : 0;   // encoder.py:80
-    b.func_stage("prep", [=](hipStream_t s) { return prep_launch(td, es, T, B, burn, cumprod, inv_gb, w, ic, s); });
+    b.func_stage("prep", [=](hipStream_t s) { return prep_launch(td, es, T, B, burn, cumprod, inv_gb, w, ic, dst, log_alpha, s); });
     if (c.discrete) {   // stored action index -> one-hot critic input (deepQlearning.py:206-210)
       const float *act = x.action;
       float *oh = a->buf("action_onehot");

@@ -211,7 +211,14 @@ __device__ __forceinline__ float device_noise(uint64_t seed, uint32_t step, uint
 // block = 16 windows x 16 time lanes; consecutive threads -> consecutive b (coalesced rows)
 __global__ __launch_bounds__(256) void k_prep(const float *__restrict__ task_done, const float *__restrict__ episode_step,
                                               int T, int B, int burn_in, int cumprod, float inv_global_batch,
-                                              float *__restrict__ w, float *__restrict__ contig) {
+                                              float *__restrict__ w, float *__restrict__ contig, DevState *st,
+                                              const float *log_alpha) {
+  // get_losses() side effect in the reference: curr_alpha <- exp(log_alpha) AFTER it was used (soft_actor_critic.py:152);
+  // rides in this launch (nothing here reads alpha) instead of a one-thread kernel of its own
+  if (st && blockIdx.x == 0 && threadIdx.x == 0) {
+    st->alpha_cur = st->alpha_next;
+    st->alpha_next = expf(*log_alpha);
+  }
   __shared__ float cnt[16][17];
   const int bl = threadIdx.x & 15, tl = threadIdx.x >> 4;
   const int b = blockIdx.x * 16 + bl;
@@ -259,12 +266,6 @@ __global__ __launch_bounds__(256) void k_prep(const float *__restrict__ task_don
 // tick: optimiser step counter, Adam bias corrections (double, like the Python floats in
 // torch.optim.Adam), and the one-step-lagged alpha (soft_actor_critic.py:41,152)
 // ======================================================================================
-__global__ void k_tick_alpha(DevState *st, const float *log_alpha) {
-  // get_losses() side effect in the reference: curr_alpha <- exp(log_alpha) AFTER it was used
-  st->alpha_cur = st->alpha_next;
-  st->alpha_next = expf(*log_alpha);
-}
-
 __global__ void k_tick_adam(DevState *st, double lr, double b1, double b2) {
   st->step += 1;
   const double bc1 = 1.0 - pow(b1, (double)st->step);
@@ -721,14 +722,9 @@ hipError_t adam_launch(const AdamArgs &a, hipStream_t s) {
 }
 
 hipError_t prep_launch(const float *task_done, const float *episode_step, int T, int B, int burn_in, int cumprod,
-                       float inv_gb, float *w, float *contig, hipStream_t s) {
+                       float inv_gb, float *w, float *contig, DevState *st, const float *log_alpha, hipStream_t s) {
   hipLaunchKernelGGL(k_prep, dim3((B + 15) / 16), dim3(256), 0, s, task_done, episode_step, T, B, burn_in, cumprod, inv_gb, w,
-                     contig);
-  return hipGetLastError();
-}
-
-hipError_t tick_alpha_launch(DevState *st, const float *log_alpha, hipStream_t s) {
-  hipLaunchKernelGGL(k_tick_alpha, dim3(1), dim3(1), 0, s, st, log_alpha);
+                     contig, st, log_alpha);
   return hipGetLastError();
 }
 

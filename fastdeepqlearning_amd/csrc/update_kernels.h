@@ -108,7 +108,7 @@ hipError_t loss_finish_launch(const float *partials, int nblocks, int M, int Nq,
 hipError_t reduce_slabs_launch(const float *slabs, int nslab, long long n, float *grads, hipStream_t s);
 hipError_t adam_launch(const AdamArgs &a, hipStream_t s);
 hipError_t prep_launch(const float *task_done, const float *episode_step, int T, int B, int burn_in, int cumprod,
-                       float inv_gb, float *w, float *contig, hipStream_t s);
+                       float inv_gb, float *w, float *contig, DevState *st, const float *log_alpha, hipStream_t s);
 // ---- pixel encoder (design of this build; no reference): convolutions as im2col + the grouped GEMM
 struct ConvGeom {
   int C, H, W;      // input feature map
@@ -148,7 +148,6 @@ hipError_t gru_cell_bwd_launch(const float *dstate, const float *carry_a, const 
                                float *dh_direct, int rows, int L, hipStream_t s);
 // d encoder.hidden_state[l] = sum_b (a[b][l] + b[b][l])  (learned start state), fixed order
 hipError_t gru_dh0_launch(const float *a, const float *b, int nparts_b, int B, int L, float *out, hipStream_t s);
-hipError_t tick_alpha_launch(DevState *st, const float *log_alpha, hipStream_t s);
 hipError_t tick_adam_launch(DevState *st, double lr, double b1, double b2, hipStream_t s);
 hipError_t policy_fwd_launch(const PolicyFwdArgs &a0, const PolicyFwdArgs &a1, int nprob, int M, int A,
                              const DevState *st, uint64_t seed, int discrete, hipStream_t s);
