@@ -457,6 +457,11 @@ def test_update_matches_oracle_config2(dev, T, B, hid):
      dict(obs=17, act=6, C=5, Q=2, T=4, B=64, env={"FDQL_NO_HEAD_FUSE": "1"})),
     ("config 2 dims without the dual-output first layer (FDQL_NO_DUAL)",
      dict(obs=17, act=6, C=5, Q=2, T=4, B=64, env={"FDQL_NO_DUAL": "1"})),
+    ("config 2 dims on the LDS-DMA GEMM, 128x128 tiles (dense shape 7: dual outputs + head fusion in that kernel)",
+     dict(obs=17, act=6, C=5, Q=2, T=6, B=64, dense_shape=7)),
+    ("ragged sizes on the LDS-DMA GEMM, 64x64 tiles (edge tiles and ragged chunks through its guarded path)",
+     dict(obs=3, act=2, C=2, Q=4, T=3, B=7, critic_hidden=(33, 18), pi_hidden=(21,), enc_hidden=(18,), joint_hidden=(33,),
+          latent=21, enc_features=18, dense_shape=9)),
 ])
 def test_update_matches_oracle_other_configs(dev, name, kw, monkeypatch):
     """The remaining BASELINE configs' shapes (and non-default depths) against the CPU oracle, one step."""
@@ -464,6 +469,19 @@ def test_update_matches_oracle_other_configs(dev, name, kw, monkeypatch):
     kw = dict(kw)
     for k, v in kw.pop("env", {}).items():      # plan switches are read when the agent is created
         monkeypatch.setenv(k, v)
+    dense_shape = kw.pop("dense_shape", None)   # tile shape of the dense GEMMs (process-wide setting: restored below)
+    if dense_shape is not None:
+        from fastdeepqlearning_amd import _native as nat
+        nat.check(nat.load().fdql_debug_set_gemm_dense_shape(dense_shape))
+    try:
+        _run_other_config(dev, name, kw)
+    finally:
+        if dense_shape is not None:
+            nat.check(nat.load().fdql_debug_set_gemm_dense_shape(5))
+
+
+def _run_other_config(dev, name, kw):
+    from oracle import update as oup
     T, B = kw.pop("T"), kw.pop("B")
     base = dict(latent=256, enc_features=256, enc_hidden=(256,), joint_hidden=(256,), pi_hidden=(256,), critic_hidden=(256, 256))
     base.update(kw)
