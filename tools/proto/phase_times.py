@@ -1,4 +1,4 @@
-"""Per-phase cycle split of the register-staged GEMM main loop (instrumented build build_ab/libfdql_timing.so:
+"""Per-phase cycle split of the register-staged GEMM main loop (instrumented build from make_timing_build.py:
 s_memtime at loop top / after the operand requests / after the MFMA k-steps / after the LDS stores / after the barrier)."""
 import ctypes, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
