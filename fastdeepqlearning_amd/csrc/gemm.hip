@@ -14,7 +14,10 @@
 // through a double-buffered LDS image laid out [k][row] with pitch rows+4 floats, so every fragment read is a
 // conflict-free ds_read_b32 of 32 consecutive rows for one k.  Global loads of chunk c+1 are issued before the
 // MFMAs of chunk c (interior chunks: all addresses first, then the loads back to back) and written to the other
-// LDS buffer after them (one barrier per chunk).
+// LDS buffer after them (one barrier per chunk); a chunk's MFMA k-steps run at raised wave priority.
+//
+// Two kernels live here: k_gemm_grouped (register-staged, described above: the default for every shape) and, further
+// down, k_gemm_dma (operands by LDS-DMA into a ring of chunk images; dense shapes 7/8/9, selectable, see its header).
 #include "common.h"
 
 #include <cstdarg>
