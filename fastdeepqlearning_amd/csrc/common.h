@@ -88,6 +88,23 @@ constexpr int GEMM_DEFAULT_VARIANT = 1;
 int gemm_variant();
 void gemm_set_variant(int v);
 
+// Which problem of a launch group a workgroup belongs to (problems sorted by their first block id): ONE vector load round -
+// lane i looks at problem i, ballot, highest set bit - instead of a chain of up to nprob dependent loads; with a handful
+// of workgroups per launch (temporal_len 2) that chain was a visible part of every multi-problem launch.
+#if defined(__HIPCC__)
+template <typename P, int P::*START>
+__device__ __forceinline__ int find_problem(const P *probs, int nprob, int bid, int lane) {
+  int pi = 0;
+  for (int base = 0; base < nprob; base += 64) {
+    const int i = base + lane;
+    const bool ge = i < nprob && bid >= (((const __attribute__((address_space(1))) P *)probs)[i].*START);
+    const unsigned long long m = __ballot(ge);
+    if (m) pi = base + 63 - __builtin_clzll(m);
+  }
+  return __builtin_amdgcn_readfirstlane(pi);
+}
+#endif
+
 // ---------------------------------------------------------------------------------------
 // Column-sum / narrow reductions (kernels.hip): bias gradients
 // ---------------------------------------------------------------------------------------

@@ -344,9 +344,7 @@ __global__ __launch_bounds__(GEMM_THREADS, TileCfg<SHAPE>::MINB) void k_gemm_gro
 
   const int tid = threadIdx.x;
   const int bid = blockIdx.x;
-  int pi = 0;
-  for (int i = 1; i < nprob; ++i)
-    if (bid >= probs[i].tile_start) pi = i;
+  const int pi = find_problem<GemmProblem, &GemmProblem::tile_start>(probs, nprob, bid, tid & 63);
   const GemmProblem &P = probs[pi];
 
   const int M = uni(P.M), N = uni(P.N), nseg = uni(P.nseg), ksplit = uni(P.ksplit);
@@ -690,20 +688,7 @@ __global__ __launch_bounds__(GEMM_THREADS, DmaCfg<SHAPE>::MINB) void k_gemm_dma(
 
   const int tid = threadIdx.x;
   const int bid = blockIdx.x;
-  // Which problem: one vector load round (lane i looks at problem i) instead of a chain of dependent scalar loads - at
-  // 2-3 workgroups per CU nothing hides a tile's start-up latency, so the table reads are kept to two rounds in all:
-  // this one, then header + segment 0 together.
-  int pi = 0;
-  {
-    const int l = tid & 63;
-    for (int base = 0; base < nprob; base += 64) {   // nprob <= 64 in practice: one trip
-      const int i = base + l;
-      const bool ge = i < nprob && bid >= ((const __attribute__((address_space(1))) GemmProblem *)probs)[i].tile_start;
-      const unsigned long long m = __ballot(ge);
-      if (m) pi = base + 63 - __builtin_clzll(m);
-    }
-    pi = uni(pi);
-  }
+  const int pi = find_problem<GemmProblem, &GemmProblem::tile_start>(probs, nprob, bid, tid & 63);   // one load round
   const GemmProblem &P = probs[pi];
 
   const int M = uni(P.M), N = uni(P.N), nseg = uni(P.nseg), ksplit = uni(P.ksplit);

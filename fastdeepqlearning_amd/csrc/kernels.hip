@@ -18,9 +18,7 @@ template <int NOUT_MAX>
 __global__ __launch_bounds__(SW_THREADS) void k_skinny_wgrad(const SkinnyWgradProblem *__restrict__ probs, int nprob) {
   __shared__ float red[3][NOUT_MAX][SW_COLS];
   const int bid = blockIdx.x;
-  int pi = 0;
-  for (int i = 1; i < nprob; ++i)
-    if (bid >= probs[i].block_start) pi = i;
+  const int pi = find_problem<SkinnyWgradProblem, &SkinnyWgradProblem::block_start>(probs, nprob, bid, threadIdx.x & 63);
   const SkinnyWgradProblem &P = probs[pi];
   const int local = bid - P.block_start;
   const int split = local / P.col_blocks;
@@ -128,9 +126,7 @@ int head_dgrad_finalize(HeadDgradProblem *p, int n) {
 
 __global__ __launch_bounds__(256) void k_head_dgrad(const HeadDgradProblem *__restrict__ probs, int nprob) {
   __shared__ float dys[64 * HEAD_DGRAD_MAXQ];
-  int pi = 0;
-  for (int i = 1; i < nprob; ++i)
-    if ((int)blockIdx.x >= probs[i].block_start) pi = i;
+  const int pi = find_problem<HeadDgradProblem, &HeadDgradProblem::block_start>(probs, nprob, (int)blockIdx.x, threadIdx.x & 63);
   const HeadDgradProblem P = probs[pi];
   const int local = blockIdx.x - P.block_start;
   const int rb = local / P.col_blocks, cb = local - rb * P.col_blocks;
