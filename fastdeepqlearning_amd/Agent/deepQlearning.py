@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 from .. import _native as N
+from .._native import OversampleError
 from ..common_utils import AttrDict
 from ..core import NativeAgent, make_config
 from ..Replay.wrappers import TorchDataLoader
@@ -80,6 +81,8 @@ class DeepQLearning:
         self._seed = int(kwargs.get("seed", 0))
         self._last_xp = None
         self._trainer = None
+        self._stop_training = False
+        self.trainer_error = None
         if kwargs.get("train_process", False):   # reference signature: run the trainer loop in place
             self._initialize_trainer_members(kwargs["replays"])
             self._infinite_loop_for_async_training_process()
@@ -87,6 +90,7 @@ class DeepQLearning:
     # ------------------------------------------------------------------ training
     def enable_training(self, replays):
         self._initialize_trainer_members(replays)
+        self._stop_training = False
         if self.conf.use_async_train:
             # the reference forks a trainer process; the GPU is asynchronous already, so a host
             # thread that enqueues kernels is enough and the weights stay shared (no state_dict pickling)
@@ -97,17 +101,41 @@ class DeepQLearning:
         self.replays = [TorchDataLoader(r, self.device, torch.float32) for r in replays]
 
     def _infinite_loop_for_async_training_process(self):
+        """deepQlearning.py:83-94 (+ the crash report of :37-43: traceback, "[Trainer Crashed]" warning).  The failure
+        is also kept in ``trainer_error`` and re-raised by the next ``act()``: acting on frozen weights for the
+        rest of a run is the silent failure mode the reference's warning is there to prevent."""
         import time
-        for step_train in itertools.count():
-            if not all(r.ready() for r in self.replays):
-                time.sleep(0.05)
-                continue
-            self.train_step()
-            if (step_train % self.conf.param_update_interval) == 0 and not self.param_queue.full():
+        import traceback
+        import warnings
+        try:
+            for step_train in itertools.count():
+                if self._stop_training:
+                    return
+                if not all(r.ready() for r in self.replays):
+                    time.sleep(0.05)
+                    continue
                 try:
-                    self.param_queue.put_nowait(OrderedDict((k, v.to("cpu")) for k, v in self.state_dict().items()))
-                except Exception:
-                    pass
+                    self.train_step()
+                except OversampleError:      # a shard shrank below a window between ready() and the sample
+                    time.sleep(0.05)         # (async_replay_memory.py:57-61 sleeps and retries)
+                    continue
+                if (step_train % self.conf.param_update_interval) == 0 and not self.param_queue.full():
+                    try:
+                        self.param_queue.put_nowait(OrderedDict((k, v.to("cpu")) for k, v in self.state_dict().items()))
+                    except Exception:
+                        pass
+        except Exception as e:   # noqa: BLE001 - report like the reference, then stop training
+            traceback.print_exc()
+            warnings.warn("[Trainer Crashed]")
+            self.trainer_error = e
+
+    def disable_training(self, timeout=10.0):
+        """Stop the trainer thread started by enable_training (not in the reference, whose trainer is a daemon
+        process killed with its parent)."""
+        self._stop_training = True
+        t, self._trainer = self._trainer, None
+        if t is not None:
+            t.join(timeout)
 
     def _distributed(self):
         return int(getattr(self.conf, "world_size", 1) or 1) > 1
@@ -214,6 +242,9 @@ class DeepQLearning:
         (encoder.py:63-65).  `noise` ([rows, A] N(0,1) / U(0,1) draws) replays a fixed sample
         (parity tests); by default the device draws Philox noise keyed by (seed, call count)."""
         conf = self.conf
+        if self.trainer_error is not None:
+            err, self.trainer_error = self.trainer_error, None
+            raise RuntimeError("the trainer thread crashed; act() would run on frozen weights") from err
         if not conf.use_async_train and self.replays and all(r.ready() for r in self.replays):
             self.train_step()
         log_now = (conf.train_step.value % conf.log_interval) == 0

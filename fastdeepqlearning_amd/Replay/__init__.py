@@ -15,7 +15,7 @@ def _write_stack(conf, shard, compute_reward):
     if conf.use_squashed_rewards and not conf.use_HER:
         head = wrappers.SquashRewards(head)
     if conf.use_HER:
-        if vmap:        # parity unpinned (the reference needs jax); see wrappers/her_vmap.py
+        if vmap:        # shim-pinned (the reference needs jax); see wrappers/her_vmap.py
             head = wrappers.HindsightVmapWrite(head, compute_reward)
         else:
             head = wrappers.HindsightNStepReplay(head, compute_reward, mode=conf.her_mode)

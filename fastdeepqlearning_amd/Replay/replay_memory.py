@@ -5,6 +5,8 @@ wrappers/torch_dataloader.py:11-50 (host->device, f32 cast).  Here the ring live
 one object plays all three roles: ``add`` stages rows host-side (pinned) and the gather kernel
 returns float32 device tensors directly — no child process, no queues, no per-key H2D copy.
 """
+import threading
+
 import numpy as np
 import torch
 
@@ -22,8 +24,14 @@ class ReplayMemory:
     """Same constructor and methods as the reference; returns torch device tensors (float32),
     i.e. what ``TorchDataLoader(ReplayMemory(...))`` returns in the reference."""
 
-    def __init__(self, maxlen, batch_size, temporal_len, device=None, seed=0, **kwargs):
+    def __init__(self, maxlen, batch_size, temporal_len, device=None, seed=0, sample_buffers=3, **kwargs):
+        """sample_buffers: temporal_sample() writes into a rotating pool of this many persistent output sets, so a
+        returned batch stays valid until `sample_buffers` further samples have been drawn (the reference's loader
+        hands out one prefetched batch at a time, torch_dataloader.py:22,47-50) and the agent sees a small, recurring
+        set of batch addresses - its launch plans are cached per address set.  0: fresh tensors on every call."""
         self._batch_size, self._temporal_len, self._maxlen = int(batch_size), int(temporal_len), int(maxlen)
+        self._pool, self._pool_i, self._pool_n = [], 0, max(0, int(sample_buffers))
+        self._init_lock = threading.Lock()     # first add() from two writer threads: one of them lays the ring out
         self.batch_size, self.temporal_len = self._batch_size, self._temporal_len
         self.device = torch.device(device if device is not None else "cuda:0")
         self._seed, self._counter = int(seed), 0
@@ -54,9 +62,14 @@ class ReplayMemory:
                 v = v.detach().cpu().numpy()
             out[self._offsets[j]:self._offsets[j + 1]] = np.asarray(v, dtype=np.float32).reshape(-1)
 
-    def add(self, experience_dict):
+    def _ensure_ring(self, template):
         if self._ring is None:
-            self._jit_initialize(experience_dict)
+            with self._init_lock:
+                if self._ring is None:
+                    self._jit_initialize(template)
+
+    def add(self, experience_dict):
+        self._ensure_ring(experience_dict)
         row = np.empty(self._offsets[-1], np.float32)
         self._pack(experience_dict, row)
         self._ring.add_rows(row[None])
@@ -76,7 +89,7 @@ class ReplayMemory:
             template = dict(records[0])
             if return_name is not None:
                 template[return_name] = 0.0     # NStepReturn adds the key last (nstep_return.py:44-46)
-            self._jit_initialize(template)
+            self._ensure_ring(template)
         rows = np.zeros((len(records), int(self._offsets[-1])), np.float32)
         for j, k in enumerate(self._keys):
             if k == return_name:
@@ -116,8 +129,16 @@ class ReplayMemory:
         len < 2T or len < B."""
         self._check_init()
         self._counter += 1
+        outs = None
+        if self._pool_n:
+            if len(self._pool) < self._pool_n:
+                self._pool.append([torch.empty((self._temporal_len, self._batch_size, d), dtype=torch.float32,
+                                               device=self.device) for d in self._dims])
+            outs = self._pool[self._pool_i % len(self._pool)]
         outs = self._ring.sample_windows(self._temporal_len, self._batch_size, starts=starts, seed=self._seed,
-                                         counter=self._counter)
+                                         counter=self._counter, outs=outs)
+        if self._pool_n:
+            self._pool_i = (self._pool_i + 1) % self._pool_n   # advanced only after a successful sample
         return self._named(outs, (self._temporal_len, self._batch_size))
 
     def temporal_sample_select(self, select, starts=None):
@@ -138,10 +159,19 @@ class ReplayMemory:
     def __getitem__(self, idxes):
         """replay_memory.py:67-70: gather arbitrary index arrays (any shape)."""
         self._check_init()
-        idx = torch.as_tensor(np.asarray(idxes), dtype=torch.int64)
-        flat = idx.reshape(-1)
-        saveB = self._batch_size
-        outs = self._ring.sample_rows(int(flat.numel()), idx=flat)
+        if isinstance(idxes, torch.Tensor):
+            idxes = idxes.detach().cpu().numpy()
+        idx = np.asarray(idxes)
+        if idx.dtype == np.bool_ or not np.issubdtype(idx.dtype, np.integer):
+            raise IndexError("ReplayMemory.__getitem__ takes integer slot indices")
+        idx = idx.astype(np.int64)
+        # numpy semantics on the reference's [maxlen, ...] arrays: negatives count from maxlen, anything else
+        # outside [0, maxlen) is an IndexError; slots in [len, maxlen) hold their (possibly zero) contents
+        bad = (idx < -self._maxlen) | (idx >= self._maxlen)
+        if bad.any():
+            raise IndexError(f"index {int(idx[bad].flat[0])} is out of bounds for axis 0 with size {self._maxlen}")
+        idx = np.where(idx < 0, idx + self._maxlen, idx)
+        outs = self._ring.gather_rows(torch.from_numpy(idx.reshape(-1)))
         return {k: o.view(tuple(idx.shape) + s) for k, s, o in zip(self._keys, self._shapes, outs)}
 
     def __len__(self):
@@ -179,14 +209,17 @@ class ReplayMemory:
         sd = self.state_dict()
         np.savez(path, rows=sd["rows"], keys=np.asarray(sd["keys"]), top=sd["top"], len=sd["len"], counter=sd["counter"],
                  maxlen=sd["maxlen"], shapes=np.asarray([",".join(str(int(x)) for x in s) for s in sd["shapes"]]),
-                 dtypes=np.asarray(sd.get("dtypes", [])))
+                 dtypes=np.asarray(sd.get("dtypes", [])), proxy_len=int(sd.get("proxy_len", -1)))
 
     def load(self, path):
         z = np.load(path if str(path).endswith(".npz") else str(path) + ".npz", allow_pickle=False)
-        self.load_state_dict({"rows": z["rows"], "keys": [str(k) for k in z["keys"]], "top": int(z["top"]),
-                              "len": int(z["len"]), "counter": int(z["counter"]), "maxlen": int(z["maxlen"]),
-                              "shapes": [tuple(int(x) for x in s.split(",") if x) for s in z["shapes"]],
-                              "dtypes": [str(t) for t in z["dtypes"]] if "dtypes" in z.files else None})
+        sd = {"rows": z["rows"], "keys": [str(k) for k in z["keys"]], "top": int(z["top"]),
+              "len": int(z["len"]), "counter": int(z["counter"]), "maxlen": int(z["maxlen"]),
+              "shapes": [tuple(int(x) for x in s.split(",") if x) for s in z["shapes"]],
+              "dtypes": [str(t) for t in z["dtypes"]] if "dtypes" in z.files else None}
+        if "proxy_len" in z.files and int(z["proxy_len"]) >= 0:
+            sd["proxy_len"] = int(z["proxy_len"])
+        self.load_state_dict(sd)
 
 
 class AsyncReplayMemory(ReplayMemory):

@@ -1,7 +1,8 @@
 """HER with K virtual goals stored per step and ONE picked at read time ("vmap" mode).
 
-Reference: franQ/Replay/wrappers/her_vmap.py:10-123.  PARITY UNPINNED — the reference file needs jax and
-cannot be executed in the build image; semantics restated from its text (see oracle/replay.py):
+Reference: franQ/Replay/wrappers/her_vmap.py:10-123.  SHIM-PINNED: the reference file needs jax, which the build
+image lacks; it was run on a numpy-backed jax stand-in (tests/golden/_refimport.py) and this path is checked against the
+vectors it produced (tests/golden/her_vmap.npz):
 write: K goals ``achieved_goal[randint(0, n, K)]`` per finished episode; per step the K relabelled rewards /
 dones plus the real ones as column K; read: one column for the WHOLE batch (quirk q11) replaces
 desired_goal / reward / task_done / mc_return.  The relabel runs on the device (fdql_episode_her_vmap); the
@@ -20,9 +21,8 @@ from .episode_ops import SparseL2Reward, _dev
 class HindsightVmapWrite(ReplayMemoryWrapper):
     def __init__(self, replay_buffer, compute_reward, ignore_keys=("info",), num_virtual_goals=32, device=None):
         super().__init__(replay_buffer)
-        if not isinstance(compute_reward, SparseL2Reward):
-            raise NotImplementedError("her_mode='vmap' evaluates K x n rewards per episode on the device and needs a "
-                                      "SparseL2Reward; arbitrary Python callables are only supported by 'final'/'random'")
+        # a SparseL2Reward is evaluated K x n times on the device; any other callable (the reference takes any
+        # ``compute_reward(achieved_goal, goal) -> (reward, done)``, her_vmap.py:18-28) on the host like 'final'/'random' do
         self.compute_reward = compute_reward
         self._ignored_keys = ignore_keys
         self.num_virtual_goals = num_virtual_goals
@@ -50,16 +50,20 @@ class HindsightVmapWrite(ReplayMemoryWrapper):
         col = lambda k: np.asarray([np.asarray(x[k], np.float32).reshape(-1) for x in self.buffer], np.float32)
         ag, dg = col("achieved_goal"), col("desired_goal")
         g = ag.shape[1]
-        r, td = _dev(col("reward")[:, 0], dev), _dev(col("task_done")[:, 0], dev)
-        idx = torch.as_tensor(self._draw_goal_indices(n), dtype=torch.int32, device=dev)
-        agd, dgd = _dev(ag, dev), _dev(dg, dev)
-        vg = torch.empty(n, (K + 1) * g, device=dev)
-        vr, vd = torch.empty(n, K + 1, device=dev), torch.empty(n, K + 1, device=dev)
-        fn = self.compute_reward.native()
-        with torch.cuda.device(dev):
-            N.check(lib.fdql_episode_her_vmap(N.ptr(r), N.ptr(td), N.ptr(agd), N.ptr(dgd), C.c_void_p(idx.data_ptr()), n, g,
-                                              K, C.byref(fn), N.ptr(vg), N.ptr(vr), N.ptr(vd), N.current_stream(dev)))
-        vg, vr, vd = vg.cpu().numpy().reshape(n, K + 1, g), vr.cpu().numpy(), vd.cpu().numpy()
+        goal_idx = self._draw_goal_indices(n)
+        if isinstance(self.compute_reward, SparseL2Reward):
+            r, td = _dev(col("reward")[:, 0], dev), _dev(col("task_done")[:, 0], dev)
+            idx = torch.as_tensor(goal_idx, dtype=torch.int32, device=dev)
+            agd, dgd = _dev(ag, dev), _dev(dg, dev)
+            vg = torch.empty(n, (K + 1) * g, device=dev)
+            vr, vd = torch.empty(n, K + 1, device=dev), torch.empty(n, K + 1, device=dev)
+            fn = self.compute_reward.native()
+            with torch.cuda.device(dev):
+                N.check(lib.fdql_episode_her_vmap(N.ptr(r), N.ptr(td), N.ptr(agd), N.ptr(dgd), C.c_void_p(idx.data_ptr()), n,
+                                                  g, K, C.byref(fn), N.ptr(vg), N.ptr(vr), N.ptr(vd), N.current_stream(dev)))
+            vg, vr, vd = vg.cpu().numpy().reshape(n, K + 1, g), vr.cpu().numpy(), vd.cpu().numpy()
+        else:
+            vg, vr, vd = self._host_relabel(ag, dg, col("reward")[:, 0], col("task_done")[:, 0] != 0, goal_idx)
         for i, row in enumerate(self.buffer):
             out = {k: v for k, v in row.items() if k not in self._ignored_keys}
             out["virtual_goals"] = vg[i]
@@ -68,13 +72,35 @@ class HindsightVmapWrite(ReplayMemoryWrapper):
             self.replay_buffer.add(out)
 
 
+    def _host_relabel(self, ag, dg, reward, done, goal_idx):
+        """her_vmap.py:30-45 with a Python reward callable: float32 like jax (x64 off), (reward - R(ag, dg)) + R(ag, g_k),
+        done_k = (done and not D(ag, dg)) or D(ag, g_k); column K keeps the real goal / reward / done."""
+        n, K, g = len(reward), self.num_virtual_goals, ag.shape[1]
+        vg = np.empty((n, K + 1, g), np.float32)
+        vr, vd = np.empty((n, K + 1), np.float32), np.empty((n, K + 1), np.float32)
+        goals = ag[goal_idx]
+        for i in range(n):
+            dr, dd = self.compute_reward(ag[i], dg[i])
+            agnostic_r = np.float32(reward[i]) - np.float32(dr)
+            agnostic_d = bool(done[i]) and not bool(dd)
+            for k in range(K):
+                r, d = self.compute_reward(ag[i], goals[k])
+                vr[i, k] = agnostic_r + np.float32(r)
+                vd[i, k] = float(agnostic_d or bool(d))
+            vg[i, :K], vg[i, K] = goals, dg[i]
+            vr[i, K], vd[i, K] = reward[i], float(done[i])
+        return vg, vr, vd
+
+
 class HindsightVmapRead(ReplayMemoryWrapper):
     """her_vmap.py:93-123: replaces goal / reward / done (/ mc_return) by ONE virtual column per batch."""
 
     VIRTUAL = {"virtual_goals": "desired_goal", "virtual_rewards": "reward", "virtual_dones": "task_done",
                "virtual_mc_return": "mc_return"}
 
-    def temporal_sample(self):
+    def temporal_sample(self, starts=None):
+        """``starts``: optional window starts (parity runs); the virtual column comes from Python's ``random`` like
+        the reference."""
         rb = self.replay_buffer
         keys, shapes = rb._keys, dict(zip(rb._keys, rb._shapes))
         k1 = shapes["virtual_rewards"][0]                      # K + 1 stored columns
@@ -85,7 +111,7 @@ class HindsightVmapRead(ReplayMemoryWrapper):
         if "virtual_mc_return" in keys:
             select["virtual_mc_return"] = (idx, 1)
             select["mc_return"] = None
-        xp = rb.temporal_sample_select(select)
+        xp = rb.temporal_sample_select(select, starts=starts)
         for src, dst in self.VIRTUAL.items():
             if src in xp:
                 xp[dst] = xp.pop(src)

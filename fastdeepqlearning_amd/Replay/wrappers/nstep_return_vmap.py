@@ -1,8 +1,8 @@
 """NStepReturnVmap: per-virtual-goal Monte-Carlo return attached at write time.
 
 Reference: franQ/Replay/wrappers/nstep_return_vmap.py:8-74 (control flow as NStepReturn, incl. the one-shot
-``_pop``); the recurrence multiplies by ``dones[i]`` (quirk q10).  PARITY UNPINNED (the reference file uses the
-removed ``np.bool`` and only ever runs together with the jax-based her_vmap.py).  The K+1 column scans run on the
+``_pop``); the recurrence multiplies by ``dones[i]`` (quirk q10).  SHIM-PINNED together with her_vmap.py (it only ever
+runs behind the jax-based HindsightVmapWrite; vectors in tests/golden/her_vmap.npz).  The K+1 column scans run on the
 device (fdql_episode_mc_return_vmap)."""
 import numpy as np
 import torch

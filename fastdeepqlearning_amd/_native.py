@@ -60,7 +60,7 @@ class Batch(C.Structure):
 
 class AgentStats(C.Structure):
     _fields_ = [("gemm_flops", C.c_double), ("skinny_flops", C.c_double), ("n_launches", C.c_int32),
-                ("n_gemm_launches", C.c_int32), ("params", C.c_int64)]
+                ("n_gemm_launches", C.c_int32), ("params", C.c_int64), ("plans_built", C.c_int64)]
 
 
 class KernelTime(C.Structure):
@@ -101,6 +101,7 @@ SIGNATURES = {
     "fdql_ring_sample_windows_sel": (C.c_int, [_vp, _i32, _i32, _vp, _u64, _u64, C.POINTER(_vp), C.POINTER(_i32),
                                                C.POINTER(_i32), _vp, _vp]),
     "fdql_ring_sample_rows": (C.c_int, [_vp, _i32, _vp, _u64, _u64, C.POINTER(_vp), _vp, _vp]),
+    "fdql_ring_gather_rows": (C.c_int, [_vp, _i64, _vp, C.POINTER(_vp), _vp]),
     "fdql_episode_mc_return": (C.c_int, [_vp, _vp, _i32, _f32, _vp]),
     "fdql_episode_her_vmap": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, C.POINTER(RewardFn), _vp, _vp, _vp, _vp]),
     "fdql_episode_mc_return_vmap": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f32, _vp]),

@@ -144,6 +144,16 @@ class NativeRing:
                                                           N.current_stream(self.device)))
         return (outs, so) if return_starts else outs
 
+    def gather_rows(self, idx):
+        """ring[k][idx] for explicit slot indices in [0, maxlen) (reference __getitem__, replay_memory.py:67-70)."""
+        idx = torch.as_tensor(idx, dtype=torch.int64, device=self.device).contiguous().reshape(-1)
+        outs, arr = self._outs((int(idx.numel()),))
+        if idx.numel():
+            with torch.cuda.device(self.device):
+                N.check(self.lib.fdql_ring_gather_rows(self.handle, int(idx.numel()), C.c_void_p(idx.data_ptr()), arr,
+                                                       N.current_stream(self.device)))
+        return outs
+
     def sample_rows(self, B, idx=None, seed=0, counter=0):
         outs, arr = self._outs((B,))
         ip = None
@@ -352,7 +362,7 @@ class NativeAgent:
         s = N.AgentStats()
         N.check(self.lib.fdql_agent_stats(self.handle, C.byref(s)))
         return {"gemm_flops": s.gemm_flops, "skinny_flops": s.skinny_flops, "n_launches": s.n_launches,
-                "n_gemm_launches": s.n_gemm_launches, "params": s.params}
+                "n_gemm_launches": s.n_gemm_launches, "params": s.params, "plans_built": s.plans_built}
 
     def set_alpha(self, alpha):
         N.check(self.lib.fdql_agent_set_alpha(self.handle, float(alpha), N.current_stream(self.device)))

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -80,6 +81,7 @@ constexpr int GRU_KSPLIT_FWD = 4, GRU_KSPLIT_BWD = 8;
 // Few rows (temporal_len 2, small batches): d state as one problem is a handful of workgroups walking all 2(C+1)
 // K-segments serially; below this row count each network's contribution is its own problem and a reduction sums them
 constexpr int DSTATE_SPLIT_MAX_ROWS = 1024;
+constexpr size_t PLAN_CACHE_MAX = 4;   // finished plans kept besides the current one
 // K-split of a conv weight gradient over its R = images * positions rows: ~4096 rows per workgroup, at most 1024 parts
 inline int conv_wsplit(long long R) { return (int)std::max<long long>(1, std::min<long long>(1024, (R + 4095) / 4096)); }
 
@@ -138,11 +140,18 @@ struct fdql_agent {
   int64_t carve_top = 0;
   std::map<std::string, std::pair<int64_t, int64_t>> named;  // name -> (byte offset, float count)
 
-  // plan
+  // update / act / set_* / scalars on one handle are serialised (the facade's trainer thread runs train_step while the
+  // Runner's agent thread calls act(): franQ/Agent/deepQlearning.py:83-94 vs :155-187)
+  std::mutex mu;
+  // plan: the launch list for one set of batch pointers.  A few finished plans are kept (keyed by their batch pointers)
+  // so that a caller who alternates between two or three sample buffers does not rebuild and re-upload tables every step.
   fdql_batch_t batch = {};
   bool plan_ready = false;
   std::vector<Stage> stages;
   void *tables_dev = nullptr;
+  struct CachedPlan { fdql_batch_t batch; std::vector<Stage> stages; void *tables_dev; };
+  std::vector<CachedPlan> plan_cache;   // most recently stashed last
+  long long plans_built = 0;
   const float *noise_t = nullptr, *noise_a = nullptr;  // per-call (read by the policy stage lambdas)
   uint64_t seed = 0;
 
@@ -1132,9 +1141,31 @@ int prepare_update(fdql_agent *a, const fdql_batch_t *batch, const float *noise_
   FDQL_REQUIRE(!(a->cfg.joiner_gru && a->cfg.gru_state_mode == 1) || batch->agent_state,
                "GRU joiner in store mode needs batch.agent_state");
   if (!a->plan_ready || memcmp(&a->batch, batch, sizeof(*batch)) != 0) {
-    a->batch = *batch;
-    int rc = build_plan(a);
-    if (rc) return rc;
+    if (a->plan_ready) {   // keep the plan being replaced
+      a->plan_cache.push_back({a->batch, std::move(a->stages), a->tables_dev});
+      a->tables_dev = nullptr;
+      a->plan_ready = false;
+      if (a->plan_cache.size() > PLAN_CACHE_MAX) {
+        (void)hipFree(a->plan_cache.front().tables_dev);   // synchronises: nothing still reads the evicted tables
+        a->plan_cache.erase(a->plan_cache.begin());
+      }
+    }
+    a->stages.clear();
+    for (size_t i = 0; i < a->plan_cache.size(); ++i) {
+      if (memcmp(&a->plan_cache[i].batch, batch, sizeof(*batch)) != 0) continue;
+      a->batch = *batch;
+      a->stages = std::move(a->plan_cache[i].stages);
+      a->tables_dev = a->plan_cache[i].tables_dev;
+      a->plan_cache.erase(a->plan_cache.begin() + i);
+      a->plan_ready = true;
+      break;
+    }
+    if (!a->plan_ready) {
+      a->batch = *batch;
+      int rc = build_plan(a);
+      if (rc) return rc;
+      ++a->plans_built;
+    }
   }
   a->noise_t = noise_target;
   a->noise_a = noise_actor;
@@ -1218,6 +1249,7 @@ int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {
 int fdql_agent_destroy(fdql_agent_t *a) {
   if (!a) return 0;
   if (a->tables_dev) (void)hipFree(a->tables_dev);
+  for (auto &c : a->plan_cache) (void)hipFree(c.tables_dev);
   delete a;
   return 0;
 }
@@ -1247,7 +1279,9 @@ int64_t fdql_agent_workspace_bytes(const fdql_agent_t *a) { return a ? a->ws_nee
 
 int fdql_agent_bind(fdql_agent_t *a, float *params, float *grads, float *adam_m, float *adam_v, float *targets,
                     float *frozen, void *workspace, int64_t workspace_bytes) {
-  FDQL_REQUIRE(a && params && grads && adam_m && adam_v && targets && workspace, "null pointer in bind");
+  FDQL_REQUIRE(a, "null agent");
+  std::lock_guard<std::mutex> lk(a->mu);
+  FDQL_REQUIRE(params && grads && adam_m && adam_v && targets && workspace, "null pointer in bind");
   FDQL_REQUIRE(workspace_bytes >= a->ws_need, "workspace too small: %lld < %lld", (long long)workspace_bytes, (long long)a->ws_need);
   FDQL_REQUIRE(!a->cfg.keep_frozen_copy || frozen, "keep_frozen_copy needs a frozen arena");
   FDQL_REQUIRE((reinterpret_cast<uintptr_t>(params) & 15) == 0 && (reinterpret_cast<uintptr_t>(grads) & 15) == 0 &&
@@ -1269,15 +1303,19 @@ int fdql_agent_bind(fdql_agent_t *a, float *params, float *grads, float *adam_m,
   FDQL_HIP(hipDeviceSynchronize());
   a->bound = true;
   a->plan_ready = false;
+  for (auto &c : a->plan_cache) (void)hipFree(c.tables_dev);
+  a->plan_cache.clear();
   return 0;
 }
 
 int fdql_agent_update(fdql_agent_t *a, const fdql_batch_t *batch, const float *noise_target, const float *noise_actor,
                       uint64_t seed, int32_t phase, void *stream) {
+  if (!a) { set_error("null agent"); return FDQL_EINVAL; }
+  std::lock_guard<std::mutex> lk(a->mu);
   if (phase != FDQL_PHASE_APPLY) {
     int rc = prepare_update(a, batch, noise_target, noise_actor, seed);
     if (rc) return rc;
-  } else if (!a || !a->plan_ready) {
+  } else if (!a->plan_ready) {
     set_error("FDQL_PHASE_APPLY before any FDQL_PHASE_GRAD");
     return FDQL_ESTATE;
   }
@@ -1293,6 +1331,8 @@ int fdql_agent_update(fdql_agent_t *a, const fdql_batch_t *batch, const float *n
 int32_t fdql_agent_profile_update(fdql_agent_t *a, const fdql_batch_t *batch, const float *noise_target,
                                   const float *noise_actor, uint64_t seed, fdql_kernel_time_t *out, int32_t cap,
                                   void *stream) {
+  if (!a) { set_error("null agent"); return FDQL_EINVAL; }
+  std::lock_guard<std::mutex> lk(a->mu);
   int rc = prepare_update(a, batch, noise_target, noise_actor, seed);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
@@ -1400,7 +1440,9 @@ int fdql_agent_act(fdql_agent_t *a, const float *obs_1d, const float *achieved_g
                    const float *obs_2d, const float *agent_state, const uint8_t *exploit_mask, const float *noise,
                    uint64_t seed, uint64_t counter, int32_t rows, float *action, float *log_prob, float *explore_action,
                    float *exploit_action, float *hidden_state, void *workspace, int64_t workspace_bytes, void *stream) {
-  if (!a || !a->bound) { set_error("fdql_agent_act: agent not bound"); return FDQL_ESTATE; }
+  if (!a) { set_error("null agent"); return FDQL_EINVAL; }
+  std::lock_guard<std::mutex> lk(a->mu);
+  if (!a->bound) { set_error("fdql_agent_act: agent not bound"); return FDQL_ESTATE; }
   FDQL_REQUIRE(rows >= 0, "fdql_agent_act: rows < 0");
   if (rows == 0) return 0;
   const fdql_agent_config_t &c = a->cfg;
@@ -1478,7 +1520,9 @@ int fdql_agent_act(fdql_agent_t *a, const float *obs_1d, const float *achieved_g
 }
 
 int fdql_agent_scalars(fdql_agent_t *a, float *host_out8, void *stream) {
-  if (!a || !a->bound) { set_error("agent not bound"); return FDQL_ESTATE; }
+  if (!a) { set_error("null agent"); return FDQL_EINVAL; }
+  std::lock_guard<std::mutex> lk(a->mu);
+  if (!a->bound) { set_error("agent not bound"); return FDQL_ESTATE; }
   DevState st;
   FDQL_HIP(hipMemcpyAsync(host_out8, a->buf("scalars"), 8 * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
   FDQL_HIP(hipMemcpyAsync(&st, a->st(), sizeof(st), hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -1488,7 +1532,9 @@ int fdql_agent_scalars(fdql_agent_t *a, float *host_out8, void *stream) {
 }
 
 int fdql_agent_set_alpha(fdql_agent_t *a, float alpha, void *stream) {
-  if (!a || !a->bound) { set_error("agent not bound"); return FDQL_ESTATE; }
+  if (!a) { set_error("null agent"); return FDQL_EINVAL; }
+  std::lock_guard<std::mutex> lk(a->mu);
+  if (!a->bound) { set_error("agent not bound"); return FDQL_ESTATE; }
   DevState st;
   FDQL_HIP(hipStreamSynchronize((hipStream_t)stream));
   FDQL_HIP(hipMemcpy(&st, a->st(), sizeof(st), hipMemcpyDeviceToHost));
@@ -1499,7 +1545,9 @@ int fdql_agent_set_alpha(fdql_agent_t *a, float alpha, void *stream) {
 }
 
 int fdql_agent_set_step(fdql_agent_t *a, int32_t step, void *stream) {
-  if (!a || !a->bound) { set_error("agent not bound"); return FDQL_ESTATE; }
+  if (!a) { set_error("null agent"); return FDQL_EINVAL; }
+  std::lock_guard<std::mutex> lk(a->mu);
+  if (!a->bound) { set_error("agent not bound"); return FDQL_ESTATE; }
   DevState st;
   FDQL_HIP(hipStreamSynchronize((hipStream_t)stream));
   FDQL_HIP(hipMemcpy(&st, a->st(), sizeof(st), hipMemcpyDeviceToHost));
@@ -1521,6 +1569,7 @@ int fdql_agent_stats(const fdql_agent_t *a, fdql_agent_stats_t *out) {
   FDQL_REQUIRE(a && out, "null argument");
   memset(out, 0, sizeof(*out));
   out->params = a->n_train;
+  out->plans_built = a->plans_built;
   for (const Stage &s : a->stages) {
     out->n_launches++;
     if (s.kind == ST_GEMM) {

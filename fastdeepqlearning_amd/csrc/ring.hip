@@ -7,6 +7,7 @@
 // (franQ/Replay/replay_memory.py:62-70).
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -31,8 +32,11 @@ struct GatherKey {
 };
 struct GatherArgs {
   int nkeys, T, B;
-  long long len;
-  const long long *starts;  // [B]
+  long long len;            // modulus of the window rows (the ring's len; maxlen for explicit index gathers)
+  const long long *starts;  // [B] supplied by the caller, or null: drawn in the kernel (Philox, below)
+  long long range;          // starts == null: start[b] uniform in [0, range)
+  uint64_t seed, counter;
+  long long *starts_out;    // optional [B]: the starts used (written by the blocks of key 0)
   GatherKey key[RING_MAX_KEYS];
 };
 
@@ -54,13 +58,18 @@ __device__ __forceinline__ void philox4(uint32_t c0, uint32_t c1, uint32_t c2, u
 }
 
 // start[b] uniform in [0, range)  (replay_memory.py:59 draws numpy randint(0, len - T, B))
-__global__ void k_draw_starts(long long *starts, int B, long long range, uint64_t seed, uint64_t counter) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+__device__ __forceinline__ long long draw_start(int b, long long range, uint64_t seed, uint64_t counter) {
   uint32_t r[4];
   philox4((uint32_t)b, (uint32_t)counter, (uint32_t)(counter >> 32), 0x72696e67u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
   const uint64_t x = ((uint64_t)r[0] << 32) | r[1];
-  starts[b] = (long long)(((unsigned __int128)x * (unsigned __int128)(uint64_t)range) >> 64);
+  return (long long)(((unsigned __int128)x * (unsigned __int128)(uint64_t)range) >> 64);
+}
+// Window start of batch element b: drawn here (no separate launch) or read from the caller's array, where any int64 is
+// accepted and reduced into [0, len) the way numpy's `%` does (replay_memory.py:64)
+__device__ __forceinline__ long long window_start(const GatherArgs &a, int b) {
+  if (!a.starts) return draw_start(b, a.range, a.seed, a.counter);
+  long long s = a.starts[b] % a.len;
+  return s < 0 ? s + a.len : s;
 }
 
 // One launch gathers every key.  Narrow keys (dim*4 < 256 B): a block takes 16 windows x
@@ -84,7 +93,11 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather_windows(GatherArgs a)
     const int bb = local % K.blocks_b, tb = local / K.blocks_b;
     const int b0 = bb * STAGE_WINDOWS, t0 = tb * K.tchunk;
     const int nw = min(STAGE_WINDOWS, B - b0), nt = min(K.tchunk, T - t0);
-    if (tid < nw) sstart[tid] = (a.starts[b0 + tid] + t0) % len;   // index block staged in LDS
+    if (tid < nw) {   // index block staged in LDS
+      const long long st = window_start(a, b0 + tid);
+      sstart[tid] = (st + t0) % len;
+      if (a.starts_out && ki == 0 && tb == 0) a.starts_out[b0 + tid] = st;
+    }
     __syncthreads();
     const int run = nt * dim;  // floats per window in this chunk: ONE contiguous source run
     for (int w = wave; w < nw; w += GATHER_THREADS / 64) {
@@ -123,8 +136,10 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather_windows(GatherArgs a)
     const int waves_total = K.blocks_b * (GATHER_THREADS / 64);
     for (int row = local * (GATHER_THREADS / 64) + wave; row < rows; row += waves_total) {
       const int t = row / B, b = row - t * B;
-      long long srow = a.starts[b] + t;
+      const long long st = window_start(a, b);
+      long long srow = st + t;
       if (srow >= len) srow %= len;
+      if (a.starts_out && ki == 0 && t == 0 && lane == 0) a.starts_out[b] = st;
       float *dst = K.dst + (long long)row * dim;
       if (K.u8) {   // widen bytes to float32 (torch_dataloader.py:36), 4 elements per lane step when aligned
         const uint8_t *sb = reinterpret_cast<const uint8_t *>(K.src) + srow * K.pitch;
@@ -331,6 +346,11 @@ __global__ void k_mc_return_vmap(const float *__restrict__ r, const float *__res
 using namespace fdql;
 
 struct fdql_ring {
+  // Every entry point that takes a ring locks `mu`: the Runner's pattern is one writer thread per shard calling add()
+  // while the trainer thread samples the same shard (franQ/Replay/async_replay_memory.py:55-70, runner.py:177-191);
+  // ctypes drops the GIL around each call.  The mutex covers host bookkeeping and launch order only - nothing waits
+  // for the GPU under it except where an entry point's comment says it synchronises.
+  std::mutex mu;
   int64_t maxlen = 0;
   int nkeys = 0;
   int dims[RING_MAX_KEYS] = {};
@@ -340,14 +360,20 @@ struct fdql_ring {
   int u8[RING_MAX_KEYS] = {};
   // bookkeeping (replay_memory.py:45-46)
   int64_t top = 0, len = 0;
-  // staging
-  float *pinned = nullptr;
-  float *dev_stage = nullptr;
+  // staging of add(): two pinned / device buffer pairs, so that filling one never waits for the H2D copy of the other
+  float *pinned[2] = {nullptr, nullptr};
+  float *dev_stage[2] = {nullptr, nullptr};
+  hipEvent_t stage_done[2] = {nullptr, nullptr};
+  bool stage_inflight[2] = {false, false};
+  int cur = 0;
   int64_t stage_cap = 0, staged = 0, stage_top = 0;
-  hipEvent_t stage_done = nullptr;
-  bool stage_inflight = false;
-  long long *starts = nullptr;
-  int starts_cap = 0;
+  // Device-side order between writers and readers on DIFFERENT streams (same stream: the stream is the order).
+  // Used only once a second stream has been seen on this handle.
+  hipStream_t first_stream = nullptr;
+  bool have_stream = false, multi_stream = false;
+  hipEvent_t wr_done = nullptr, rd_done = nullptr;
+  hipStream_t wr_stream = nullptr, rd_stream = nullptr;
+  bool has_wr = false, has_rd = false;
   // episode append staging (fdql_ring_append_episode)
   float *ep_pinned = nullptr, *ep_in = nullptr, *ep_out = nullptr;
   int64_t ep_in_cap = 0, ep_out_cap = 0;   // rows
@@ -370,6 +396,41 @@ void advance(fdql_ring *r, int64_t n) {
   }
 }
 
+void see_stream(fdql_ring *r, hipStream_t s) {
+  if (!r->have_stream) { r->first_stream = s; r->have_stream = true; }
+  else if (s != r->first_stream) r->multi_stream = true;
+}
+// a launch on `s` that WRITES ring slots: after every read issued on another stream, and after writes elsewhere
+int begin_write(fdql_ring *r, hipStream_t s) {
+  see_stream(r, s);
+  if (!r->multi_stream) return 0;
+  if (r->has_rd && r->rd_stream != s) FDQL_HIP(hipStreamWaitEvent(s, r->rd_done, 0));
+  if (r->has_wr && r->wr_stream != s) FDQL_HIP(hipStreamWaitEvent(s, r->wr_done, 0));
+  return 0;
+}
+int end_write(fdql_ring *r, hipStream_t s) {
+  r->wr_stream = s; r->has_wr = true;   // remembered even while single-stream: a later second stream waits for it
+  if (!r->multi_stream) return 0;
+  FDQL_HIP(hipEventRecord(r->wr_done, s));
+  return 0;
+}
+int begin_read(fdql_ring *r, hipStream_t s) {
+  see_stream(r, s);
+  if (!r->multi_stream) return 0;
+  if (r->has_wr && r->wr_stream != s) {
+    // a write issued before the second stream appeared has no recorded event yet: record it now on its own stream
+    FDQL_HIP(hipEventRecord(r->wr_done, r->wr_stream));
+    FDQL_HIP(hipStreamWaitEvent(s, r->wr_done, 0));
+  }
+  return 0;
+}
+int end_read(fdql_ring *r, hipStream_t s) {
+  r->rd_stream = s; r->has_rd = true;
+  if (!r->multi_stream) return 0;
+  FDQL_HIP(hipEventRecord(r->rd_done, s));
+  return 0;
+}
+
 int scatter(fdql_ring *r, const float *dev_rows, int64_t n, int64_t top, hipStream_t s) {
   ScatterArgs a;
   memset(&a, 0, sizeof(a));
@@ -377,35 +438,39 @@ int scatter(fdql_ring *r, const float *dev_rows, int64_t n, int64_t top, hipStre
   for (int k = 0; k < r->nkeys; ++k) { a.dst[k] = r->data[k]; a.dim[k] = r->dims[k]; a.off[k] = r->offs[k]; a.u8[k] = r->u8[k]; }
   const long long total = n * r->rowfloats;
   const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+  int rc = begin_write(r, s);
+  if (rc) return rc;
   hipLaunchKernelGGL(k_scatter_rows, dim3(blocks), dim3(256), 0, s, a);
   FDQL_HIP(hipGetLastError());
+  return end_write(r, s);
+}
+
+int wait_stage(fdql_ring *r, int i) {
+  if (r->stage_inflight[i]) { FDQL_HIP(hipEventSynchronize(r->stage_done[i])); r->stage_inflight[i] = false; }
   return 0;
 }
 
+// staged rows -> HBM: one H2D copy + one scatter launch on `s`; the other buffer pair takes the next adds
 int flush(fdql_ring *r, hipStream_t s) {
   if (r->staged == 0) return 0;
-  FDQL_HIP(hipMemcpyAsync(r->dev_stage, r->pinned, r->staged * r->rowfloats * sizeof(float), hipMemcpyHostToDevice, s));
-  int rc = scatter(r, r->dev_stage, r->staged, r->stage_top, s);
+  const int i = r->cur;
+  FDQL_HIP(hipMemcpyAsync(r->dev_stage[i], r->pinned[i], r->staged * r->rowfloats * sizeof(float), hipMemcpyHostToDevice, s));
+  int rc = scatter(r, r->dev_stage[i], r->staged, r->stage_top, s);
   if (rc) return rc;
-  FDQL_HIP(hipEventRecord(r->stage_done, s));
-  r->stage_inflight = true;
+  FDQL_HIP(hipEventRecord(r->stage_done[i], s));
+  r->stage_inflight[i] = true;
   r->staged = 0;
+  r->cur = i ^ 1;
   return 0;
 }
 
-int ensure_starts(fdql_ring *r, int B) {
-  if (B <= r->starts_cap) return 0;
-  if (r->starts) FDQL_HIP(hipFree(r->starts));
-  FDQL_HIP(hipMalloc(&r->starts, sizeof(long long) * B));
-  r->starts_cap = B;
-  return 0;
-}
-
-int gather(fdql_ring *r, int T, int B, const long long *starts, float *const *out, const int32_t *sel_off,
-           const int32_t *sel_dim, hipStream_t s) {
+int gather(fdql_ring *r, int T, int B, long long modulus, const long long *starts, long long range, uint64_t seed,
+           uint64_t counter, long long *starts_out, float *const *out, const int32_t *sel_off, const int32_t *sel_dim,
+           hipStream_t s) {
   GatherArgs a;
   memset(&a, 0, sizeof(a));
-  a.T = T; a.B = B; a.len = r->len; a.starts = starts;
+  a.T = T; a.B = B; a.len = modulus; a.starts = starts; a.range = range; a.seed = seed; a.counter = counter;
+  a.starts_out = starts_out;
   int total = 0;
   for (int k = 0; k < r->nkeys; ++k) {
     if (!out[k]) {
@@ -436,10 +501,14 @@ int gather(fdql_ring *r, int T, int B, const long long *starts, float *const *ou
     }
   }
   if (total == 0) return 0;
+  int rc = begin_read(r, s);
+  if (rc) return rc;
   hipLaunchKernelGGL(k_gather_windows, dim3(total), dim3(GATHER_THREADS), 0, s, a);
   FDQL_HIP(hipGetLastError());
-  return 0;
+  return end_read(r, s);
 }
+
+typedef std::lock_guard<std::mutex> Lock;
 
 }  // namespace
 
@@ -470,9 +539,15 @@ int fdql_ring_create_typed(fdql_ring_t **out, int64_t maxlen, int32_t n_keys, co
     if (e != hipSuccess) { set_error("ring alloc of key %d (%zu bytes): %s", k, bytes, hipGetErrorString(e)); fdql_ring_destroy(r); return FDQL_ENOMEM; }
   }
   r->stage_cap = std::max<int64_t>(1, std::min<int64_t>(maxlen, (int64_t)(8 << 20) / (r->rowfloats * 4)));
-  FDQL_HIP(hipHostMalloc(&r->pinned, r->stage_cap * r->rowfloats * sizeof(float)));
-  FDQL_HIP(hipMalloc(&r->dev_stage, r->stage_cap * r->rowfloats * sizeof(float)));
-  FDQL_HIP(hipEventCreateWithFlags(&r->stage_done, hipEventDisableTiming));
+  for (int i = 0; i < 2; ++i) {
+    hipError_t e = hipHostMalloc(&r->pinned[i], r->stage_cap * r->rowfloats * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&r->dev_stage[i], r->stage_cap * r->rowfloats * sizeof(float));
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&r->stage_done[i], hipEventDisableTiming);
+    if (e != hipSuccess) { set_error("ring staging buffers: %s", hipGetErrorString(e)); fdql_ring_destroy(r); return FDQL_ENOMEM; }
+  }
+  hipError_t e = hipEventCreateWithFlags(&r->wr_done, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&r->rd_done, hipEventDisableTiming);
+  if (e != hipSuccess) { set_error("ring events: %s", hipGetErrorString(e)); fdql_ring_destroy(r); return FDQL_EHIP; }
   *out = r;
   return 0;
 }
@@ -481,10 +556,14 @@ int fdql_ring_destroy(fdql_ring_t *r) {
   if (!r) return 0;
   for (int k = 0; k < r->nkeys; ++k)
     if (r->data[k]) (void)hipFree(r->data[k]);
-  if (r->pinned) (void)hipHostFree(r->pinned);
-  if (r->dev_stage) (void)hipFree(r->dev_stage);
-  if (r->starts) (void)hipFree(r->starts);
-  if (r->stage_done) (void)hipEventDestroy(r->stage_done);
+  for (int i = 0; i < 2; ++i) {
+    if (r->stage_inflight[i]) (void)hipEventSynchronize(r->stage_done[i]);
+    if (r->pinned[i]) (void)hipHostFree(r->pinned[i]);
+    if (r->dev_stage[i]) (void)hipFree(r->dev_stage[i]);
+    if (r->stage_done[i]) (void)hipEventDestroy(r->stage_done[i]);
+  }
+  if (r->wr_done) (void)hipEventDestroy(r->wr_done);
+  if (r->rd_done) (void)hipEventDestroy(r->rd_done);
   if (r->ep_pinned) (void)hipHostFree(r->ep_pinned);
   if (r->ep_in) (void)hipFree(r->ep_in);
   if (r->ep_out) (void)hipFree(r->ep_out);
@@ -495,14 +574,17 @@ int fdql_ring_destroy(fdql_ring_t *r) {
 
 int fdql_ring_add(fdql_ring_t *r, const float *host_rows, int64_t n, void *stream) {
   FDQL_REQUIRE(r && host_rows && n >= 0, "bad arguments");
+  Lock lk(r->mu);
   hipStream_t s = (hipStream_t)stream;
   while (n > 0) {
     if (r->staged == 0) {
-      if (r->stage_inflight) { FDQL_HIP(hipEventSynchronize(r->stage_done)); r->stage_inflight = false; }
+      // this buffer pair was flushed two batches ago: its copy has normally long retired
+      int rc = wait_stage(r, r->cur);
+      if (rc) return rc;
       r->stage_top = r->top;
     }
     const int64_t take = std::min(n, r->stage_cap - r->staged);
-    memcpy(r->pinned + r->staged * r->rowfloats, host_rows, take * r->rowfloats * sizeof(float));
+    memcpy(r->pinned[r->cur] + r->staged * r->rowfloats, host_rows, take * r->rowfloats * sizeof(float));
     r->staged += take;
     advance(r, take);
     host_rows += take * r->rowfloats;
@@ -514,6 +596,7 @@ int fdql_ring_add(fdql_ring_t *r, const float *host_rows, int64_t n, void *strea
 
 int fdql_ring_add_device(fdql_ring_t *r, const float *dev_rows, int64_t n, void *stream) {
   FDQL_REQUIRE(r && dev_rows && n >= 0, "bad arguments");
+  Lock lk(r->mu);
   hipStream_t s = (hipStream_t)stream;
   int rc = flush(r, s);
   if (rc) return rc;
@@ -526,6 +609,7 @@ int fdql_ring_add_device(fdql_ring_t *r, const float *dev_rows, int64_t n, void 
 
 int fdql_ring_flush(fdql_ring_t *r, void *stream) {
   FDQL_REQUIRE(r, "null ring");
+  Lock lk(r->mu);
   return flush(r, (hipStream_t)stream);
 }
 
@@ -534,6 +618,7 @@ int fdql_ring_append_episode(fdql_ring_t *r, const float *host_rows, int64_t n, 
   FDQL_REQUIRE(r && host_rows && sp && n >= 0, "bad arguments");
   if (appended) *appended = 0;
   if (n == 0) return 0;
+  Lock lk(r->mu);
   auto scalar_key = [&](int k) { return k >= 0 && k < r->nkeys && r->dims[k] == 1; };
   FDQL_REQUIRE(sp->return_key < 0 || (scalar_key(sp->return_key) && scalar_key(sp->reward_key)),
                "append_episode: reward / mc_return must be keys of width 1");
@@ -620,23 +705,26 @@ int fdql_ring_append_episode(fdql_ring_t *r, const float *host_rows, int64_t n, 
 
 int fdql_ring_snapshot(fdql_ring_t *r, float *host_rows_out, int64_t n_slots, void *stream) {
   FDQL_REQUIRE(r && host_rows_out && n_slots >= 0 && n_slots <= r->maxlen, "bad arguments");
+  Lock lk(r->mu);
   hipStream_t s = (hipStream_t)stream;
   int rc = flush(r, s);
   if (rc) return rc;
-  if (r->stage_inflight) { FDQL_HIP(hipEventSynchronize(r->stage_done)); r->stage_inflight = false; }
+  for (int i = 0; i < 2; ++i) { rc = wait_stage(r, i); if (rc) return rc; }
+  rc = begin_read(r, s);
+  if (rc) return rc;
   const int F = r->rowfloats;
-  for (int64_t done = 0; done < n_slots;) {   // through the staging buffers, stage_cap slots at a time
+  for (int64_t done = 0; done < n_slots;) {   // through staging pair 0, stage_cap slots at a time
     const int64_t n = std::min<int64_t>(r->stage_cap, n_slots - done);
     ScatterArgs a;
     memset(&a, 0, sizeof(a));
-    a.nkeys = r->nkeys; a.n = n; a.top = done; a.maxlen = r->maxlen; a.rowfloats = F; a.rows = r->dev_stage;
+    a.nkeys = r->nkeys; a.n = n; a.top = done; a.maxlen = r->maxlen; a.rowfloats = F; a.rows = r->dev_stage[0];
     for (int k = 0; k < r->nkeys; ++k) { a.dst[k] = r->data[k]; a.dim[k] = r->dims[k]; a.off[k] = r->offs[k]; a.u8[k] = r->u8[k]; }
     const long long total = n * F;
     hipLaunchKernelGGL(k_pack_slots, dim3((int)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, s, a);
     FDQL_HIP(hipGetLastError());
-    FDQL_HIP(hipMemcpyAsync(r->pinned, r->dev_stage, total * sizeof(float), hipMemcpyDeviceToHost, s));
+    FDQL_HIP(hipMemcpyAsync(r->pinned[0], r->dev_stage[0], total * sizeof(float), hipMemcpyDeviceToHost, s));
     FDQL_HIP(hipStreamSynchronize(s));
-    memcpy(host_rows_out + done * F, r->pinned, total * sizeof(float));
+    memcpy(host_rows_out + done * F, r->pinned[0], total * sizeof(float));
     done += n;
   }
   return 0;
@@ -647,19 +735,22 @@ int fdql_ring_restore(fdql_ring_t *r, const float *host_rows, int64_t n_slots, i
   FDQL_REQUIRE(top >= 0 && top < r->maxlen && len >= 0 && len < r->maxlen && len <= n_slots,
                "restore: (top=%lld, len=%lld) inconsistent with %lld slots of a ring of %lld", (long long)top,
                (long long)len, (long long)n_slots, (long long)r->maxlen);
+  Lock lk(r->mu);
   hipStream_t s = (hipStream_t)stream;
   int rc = flush(r, s);
   if (rc) return rc;
   const int F = r->rowfloats;
-  for (int64_t done = 0; done < n_slots;) {
-    if (r->stage_inflight) { FDQL_HIP(hipEventSynchronize(r->stage_done)); r->stage_inflight = false; }
-    const int64_t n = std::min<int64_t>(r->stage_cap, n_slots - done);
-    memcpy(r->pinned, host_rows + done * F, n * F * sizeof(float));
-    FDQL_HIP(hipMemcpyAsync(r->dev_stage, r->pinned, n * F * sizeof(float), hipMemcpyHostToDevice, s));
-    rc = scatter(r, r->dev_stage, n, done, s);
+  int i = r->cur;
+  for (int64_t done = 0; done < n_slots; i ^= 1) {
+    rc = wait_stage(r, i);
     if (rc) return rc;
-    FDQL_HIP(hipEventRecord(r->stage_done, s));
-    r->stage_inflight = true;
+    const int64_t n = std::min<int64_t>(r->stage_cap, n_slots - done);
+    memcpy(r->pinned[i], host_rows + done * F, n * F * sizeof(float));
+    FDQL_HIP(hipMemcpyAsync(r->dev_stage[i], r->pinned[i], n * F * sizeof(float), hipMemcpyHostToDevice, s));
+    rc = scatter(r, r->dev_stage[i], n, done, s);
+    if (rc) return rc;
+    FDQL_HIP(hipEventRecord(r->stage_done[i], s));
+    r->stage_inflight[i] = true;
     done += n;
   }
   r->top = top;
@@ -667,8 +758,16 @@ int fdql_ring_restore(fdql_ring_t *r, const float *host_rows, int64_t n_slots, i
   return 0;
 }
 
-int64_t fdql_ring_len(const fdql_ring_t *r) { return r ? r->len : -1; }
-int64_t fdql_ring_top(const fdql_ring_t *r) { return r ? r->top : -1; }
+int64_t fdql_ring_len(const fdql_ring_t *r) {
+  if (!r) return -1;
+  Lock lk(const_cast<fdql_ring_t *>(r)->mu);
+  return r->len;
+}
+int64_t fdql_ring_top(const fdql_ring_t *r) {
+  if (!r) return -1;
+  Lock lk(const_cast<fdql_ring_t *>(r)->mu);
+  return r->top;
+}
 int64_t fdql_ring_row_floats(const fdql_ring_t *r) { return r ? r->rowfloats : -1; }
 
 int fdql_ring_key_ptr(fdql_ring_t *r, int32_t key, float **dev_ptr) {
@@ -687,6 +786,7 @@ int fdql_ring_sample_windows_sel(fdql_ring_t *r, int32_t T, int32_t B, const int
                                  uint64_t counter, float *const *out, const int32_t *sel_off, const int32_t *sel_dim,
                                  int64_t *starts_out_dev, void *stream) {
   FDQL_REQUIRE(r && out && T >= 1 && B >= 1, "bad arguments");
+  Lock lk(r->mu);
   if (r->len < 2 * (int64_t)T || r->len < B) {  // replay_memory.py:57-58
     set_error("Trying to sample more memories than available! (len=%lld, T=%d, B=%d)", (long long)r->len, T, B);
     return FDQL_EOVERSAMPLE;
@@ -694,22 +794,15 @@ int fdql_ring_sample_windows_sel(fdql_ring_t *r, int32_t T, int32_t B, const int
   hipStream_t s = (hipStream_t)stream;
   int rc = flush(r, s);
   if (rc) return rc;
-  const long long *starts = reinterpret_cast<const long long *>(starts_dev);
-  if (!starts) {
-    rc = ensure_starts(r, B);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_draw_starts, dim3((B + 255) / 256), dim3(256), 0, s, r->starts, B, (long long)(r->len - T), seed, counter);
-    FDQL_HIP(hipGetLastError());
-    starts = r->starts;
-  }
-  if (starts_out_dev && (const void *)starts_out_dev != (const void *)starts)
-    FDQL_HIP(hipMemcpyAsync(starts_out_dev, starts, sizeof(long long) * B, hipMemcpyDeviceToDevice, s));
-  return gather(r, T, B, starts, out, sel_off, sel_dim, s);
+  // starts drawn inside the gather (one launch); caller-supplied starts are reduced mod len there
+  return gather(r, T, B, r->len, reinterpret_cast<const long long *>(starts_dev), (long long)(r->len - T), seed, counter,
+                reinterpret_cast<long long *>(starts_out_dev), out, sel_off, sel_dim, s);
 }
 
 int fdql_ring_sample_rows(fdql_ring_t *r, int32_t B, const int64_t *idx_dev, uint64_t seed, uint64_t counter,
                           float *const *out, int64_t *idx_out_dev, void *stream) {
   FDQL_REQUIRE(r && out && B >= 1, "bad arguments");
+  Lock lk(r->mu);
   if (r->len < B) {  // replay_memory.py:50
     set_error("Trying to sample more memories than available! (len=%lld, B=%d)", (long long)r->len, B);
     return FDQL_EOVERSAMPLE;
@@ -717,17 +810,19 @@ int fdql_ring_sample_rows(fdql_ring_t *r, int32_t B, const int64_t *idx_dev, uin
   hipStream_t s = (hipStream_t)stream;
   int rc = flush(r, s);
   if (rc) return rc;
-  const long long *idx = reinterpret_cast<const long long *>(idx_dev);
-  if (!idx) {
-    rc = ensure_starts(r, B);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_draw_starts, dim3((B + 255) / 256), dim3(256), 0, s, r->starts, B, (long long)r->len, seed, counter);
-    FDQL_HIP(hipGetLastError());
-    idx = r->starts;
-  }
-  if (idx_out_dev && (const void *)idx_out_dev != (const void *)idx)
-    FDQL_HIP(hipMemcpyAsync(idx_out_dev, idx, sizeof(long long) * B, hipMemcpyDeviceToDevice, s));
-  return gather(r, 1, B, idx, out, nullptr, nullptr, s);
+  return gather(r, 1, B, r->len, reinterpret_cast<const long long *>(idx_dev), (long long)r->len, seed, counter,
+                reinterpret_cast<long long *>(idx_out_dev), out, nullptr, nullptr, s);
+}
+
+int fdql_ring_gather_rows(fdql_ring_t *r, int64_t n, const int64_t *idx_dev, float *const *out, void *stream) {
+  FDQL_REQUIRE(r && out && idx_dev && n >= 0 && n < (1LL << 31), "bad arguments");
+  if (n == 0) return 0;
+  Lock lk(r->mu);
+  hipStream_t s = (hipStream_t)stream;
+  int rc = flush(r, s);
+  if (rc) return rc;
+  // slots are addressed up to maxlen whatever `len` is, like numpy indexing of the [maxlen, ...] arrays
+  return gather(r, 1, (int)n, r->maxlen, reinterpret_cast<const long long *>(idx_dev), 0, 0, 0, nullptr, out, nullptr, nullptr, s);
 }
 
 int fdql_episode_mc_return(const float *reward_dev, float *ret_dev, int32_t n, float gamma, void *stream) {

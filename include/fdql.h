@@ -15,9 +15,15 @@
  *     library synchronises the host unless its comment says so;
  *   - device pointers handed in stay owned by the caller (torch tensors); a ring owns its
  *     own HBM;
- *   - handles are not re-entrant: one thread per handle at a time
- *     (reference: franQ/Replay/async_replay_memory.py:55-70 relies on the GIL; here the
- *     HIP stream order is the lock).
+ *   - threads: every fdql_ring_* call on one ring handle is serialised by a mutex inside the
+ *     handle (host bookkeeping + launch order; it never waits for the GPU unless the entry
+ *     point's comment says it synchronises), so one writer thread per shard may add() while
+ *     the trainer thread samples the same shard - the reference's pattern
+ *     (franQ/Replay/async_replay_memory.py:55-70, franQ/Runner/runner.py:177-191), which
+ *     there relies on the GIL.  On the device, calls on ONE stream are ordered by the
+ *     stream; once a handle has seen two different streams, its writes wait for earlier
+ *     reads issued elsewhere and its reads for earlier writes (events).  fdql_agent_* calls
+ *     on one agent handle are serialised the same way (update / act / set_* / scalars).
  */
 #ifndef FDQL_H
 #define FDQL_H
@@ -111,6 +117,15 @@ int fdql_ring_sample_rows(fdql_ring_t *ring, int32_t B, const int64_t *idx_dev, 
                           uint64_t counter, float *const *out_dev_ptrs, int64_t *idx_out_dev,
                           void *stream);
 
+/* replay_memory.py:67-70 __getitem__(): out[k] is [n, dims[k]] = ring[k][idx[i], :] for explicit
+ * slot indices (int64, device), each in [0, maxlen): slots are addressed up to maxlen whatever
+ * len() is, like numpy indexing of the reference's [maxlen, ...] arrays, and there is no
+ * OversampleError.  The caller normalises negative indices and rejects idx >= maxlen
+ * (IndexError in the reference); the kernel itself reduces mod maxlen, so no index can read
+ * outside the ring. */
+int fdql_ring_gather_rows(fdql_ring_t *ring, int64_t n, const int64_t *idx_dev, float *const *out_dev_ptrs,
+                          void *stream);
+
 /* ------------------------------------------------------------------------------------ */
 /* Write-time episode transforms, on device                                              */
 /* replaces franQ/Replay/wrappers/nstep_return.py:60-72 (calculate_montecarlo_return)    */
@@ -168,8 +183,9 @@ int fdql_ring_append_episode(fdql_ring_t *ring, const float *host_rows, int64_t 
  *   r'[i,k] = (reward[i] - R(ag_i, dg_i)) + R(ag_i, g_k),
  *   d'[i,k] = (task_done[i] && !done(ag_i, dg_i)) || done(ag_i, g_k),
  * plus the real column last.  Outputs (f32): virtual_goals[n, (K+1)*g] (the K goals then the step's own
- * desired goal), virtual_rewards[n, K+1], virtual_dones[n, K+1].  PARITY UNPINNED: the reference file needs
- * jax and cannot be executed; restated from its text (oracle/replay.py).                              */
+ * desired goal), virtual_rewards[n, K+1], virtual_dones[n, K+1].  Shim-pinned: the reference file needs jax,
+ * which the build image lacks; it ran on a numpy-backed jax stand-in and the kernel is checked against the
+ * vectors it produced (tests/golden/her_vmap.npz).                                                      */
 int fdql_episode_her_vmap(const float *reward, const float *task_done, const float *achieved_goal,
                           const float *desired_goal, const int32_t *goal_idx, int32_t n, int32_t goal_dim,
                           int32_t K, const fdql_reward_fn_t *fn, float *virtual_goals, float *virtual_rewards,
@@ -318,6 +334,7 @@ typedef struct {
   int32_t n_launches;
   int32_t n_gemm_launches;
   int64_t params;
+  int64_t plans_built;     /* launch plans built so far (one per new set of batch pointers; a handful are cached) */
 } fdql_agent_stats_t;
 int fdql_agent_stats(const fdql_agent_t *agent, fdql_agent_stats_t *out);
 

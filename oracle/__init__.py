@@ -11,7 +11,7 @@ It is the *checker*, never the product:
 Parity pin: every function here is checked against golden vectors produced by running the
 reference itself in the build container (tests/golden/make_golden.py ->
 tests/golden/*.npz; see tests/test_oracle_vs_golden.py).  HER-vmap (her_vmap.py /
-nstep_return_vmap.py) could not be executed (needs jax; uses the removed ``np.bool``):
-that restatement is pinned by hand-derived known answers only ("parity unpinned" by the
-reference).
+nstep_return_vmap.py) is "shim-pinned": those files need jax, which the image lacks, so
+they ran on a numpy-backed stand-in of the few jax entry points they use
+(tests/golden/_refimport.py); see DESIGN.md.
 """

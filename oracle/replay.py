@@ -6,7 +6,7 @@ Restates, from the reference's text (citations are path:line under /root/referen
   cast_like_loader      franQ/Replay/wrappers/torch_dataloader.py:36
   nstep_episode / NStepOracle   franQ/Replay/wrappers/nstep_return.py:8-72
   her_relabel / HerOracle       franQ/Replay/wrappers/her.py:7-95
-  vmap_* (parity unpinned)      franQ/Replay/wrappers/her_vmap.py:26-123,
+  vmap_* (shim-pinned)          franQ/Replay/wrappers/her_vmap.py:26-123,
                                 franQ/Replay/wrappers/nstep_return_vmap.py:61-74
 """
 import numpy as np
@@ -213,8 +213,9 @@ class HerOracle:
 
 
 # ---------------------------------------------------------------------------------------
-# HER-vmap ("sample-time" relabel).  PARITY UNPINNED: the reference file needs jax and a
-# removed numpy alias, so it could not be run; restated from text only.
+# HER-vmap ("sample-time" relabel).  SHIM-PINNED: the reference files need jax, which the image lacks; they were run
+# on the numpy-backed jax stand-in of tests/golden/_refimport.py and this restatement is checked against the vectors
+# they produced (tests/golden/her_vmap.npz).
 # ---------------------------------------------------------------------------------------
 def vmap_virtual_episode(virtual_goals, achieved_goal, desired_goal, reward, task_done, compute_reward):
     """her_vmap.py:30-45.  Inputs are per-episode arrays [n, ...]; virtual_goals [K, goal].
@@ -253,3 +254,57 @@ def vmap_read_select(sample, idx):
     for k in ("virtual_goals", "virtual_rewards", "virtual_dones", "virtual_mc_return"):
         out.pop(k, None)
     return out
+
+
+class VmapWriteOracle:
+    """HindsightVmapWrite stacked on NStepReturnVmap as franQ/Replay/__init__.py:20-36 builds them:
+    her_vmap.py:56-90 buffers an episode, draws K goal indices into the NEWEST-first buffer (``draw(n, K)``; the
+    reference calls ``np.random.randint(0, n, size=K)``, her_vmap.py:75), relabels, and hands the records oldest first
+    to nstep_return_vmap.py:26-59, which emits its one-shot ``_pop`` duplicate (quirk q3) and, at the episode end, every
+    record with the per-column return (quirk q10).  ``sink.add(dict)`` receives what the ring would."""
+
+    def __init__(self, sink, compute_reward, num_virtual_goals, n_step, gamma, draw=None, ignore_keys=("info",)):
+        self.sink, self.compute_reward, self.K = sink, compute_reward, int(num_virtual_goals)
+        self.n_step, self.gamma, self.ignore = int(n_step), gamma, ignore_keys
+        self.draw = draw if draw is not None else (lambda n, K: np.random.randint(0, n, size=K))
+        self.episode, self.pending = [], []
+
+    def add(self, row):
+        self.episode.append(row)
+        if row["episode_done"]:
+            self._hindsight_flush()
+            self.episode = []
+
+    def _hindsight_flush(self):
+        ep, n = self.episode, len(self.episode)
+        f32 = lambda key: np.asarray([np.asarray(x[key], np.float32).reshape(-1) for x in ep], np.float32)
+        ag, dg = f32("achieved_goal"), f32("desired_goal")
+        reward, done = f32("reward")[:, 0], np.asarray([bool(x["task_done"]) for x in ep])
+        newest_first = np.asarray(self.draw(n, self.K))
+        goals = ag[::-1][newest_first]                                  # her_vmap.py:75
+        vr, vd = vmap_virtual_episode(goals, ag, dg, reward, done, self.compute_reward)
+        for i, row in enumerate(ep):                                    # her_vmap.py:80-90, oldest first
+            out = {k: v for k, v in row.items() if k not in self.ignore}
+            out["virtual_goals"] = np.concatenate([goals, dg[i][None]])
+            out["virtual_rewards"] = np.concatenate([vr[:, i], [np.float32(reward[i])]]).astype(np.float32)
+            out["virtual_dones"] = np.concatenate([vd[:, i], [done[i]]])
+            self._nstep_add(out)
+
+    def _returns(self):   # nstep_return_vmap.py:61-74 on the newest-first buffers
+        r = np.asarray([x["virtual_rewards"] for x in reversed(self.pending)], np.float32)
+        d = np.asarray([x["virtual_dones"] for x in reversed(self.pending)], bool)
+        return vmap_return_newest_first(r, d, self.gamma)
+
+    def _nstep_add(self, row):   # nstep_return_vmap.py:26-59
+        self.pending.append(row)
+        if row["episode_done"]:
+            ret = self._returns()[::-1]
+            for x, g in zip(self.pending, ret):
+                out = dict(x)
+                out["virtual_mc_return"] = g
+                self.sink.add(out)
+            self.pending = []
+        elif len(self.pending) == self.n_step:
+            out = dict(self.pending[0])
+            out["virtual_mc_return"] = self._returns()[-1]
+            self.sink.add(out)

@@ -194,13 +194,39 @@ def init_params(spec: Spec, seed=0) -> Dict[str, Tensor]:
 # ---------------------------------------------------------------------------------------
 # networks
 # ---------------------------------------------------------------------------------------
+# Kink bookkeeping for the fp64 three-way gradient comparison (tests/test_gpu_parity.py): LeakyReLU and relu(mc - q)
+# make the gradient discontinuous in the activations, so two evaluations that agree to 1e-7 in the forward pass can
+# pick different branches for a unit that sits on its kink.  KINKS["record"] (a dict, when set) receives every
+# pre-activation under "<prefix>.<layer>"; KINKS["force"] (a dict of bool tensors, when set) replaces the branch
+# choice x > 0 of the units it names by the given pattern (e.g. the one the GPU took).
+KINKS = {"record": None, "force": None}
+
+
+def _leaky(pre, key):
+    if KINKS["record"] is not None:
+        KINKS["record"][key] = pre.detach()
+    force = KINKS["force"]
+    if force is not None and key in force:
+        return torch.where(force[key], pre, 0.01 * pre)
+    return F.leaky_relu(pre, 0.01)
+
+
+def _relu_kink(x, key):
+    if KINKS["record"] is not None:
+        KINKS["record"][key] = x.detach()
+    force = KINKS["force"]
+    if force is not None and key in force:
+        return torch.where(force[key], x, torch.zeros_like(x))
+    return x.relu()
+
+
 def skip_head_mlp(p, prefix, x, n_hidden):
     """mlp.py:88-94: h_i = LeakyReLU_0.01(W_i h_{i-1} + b_i); out = W_head cat(x, h_1..h_n) + b."""
     feats = [x]
     h = x
     for i in range(n_hidden):
-        h = F.leaky_relu(F.linear(h, p[f"{prefix}.feature_extractor.{i}.0.weight"],
-                                  p[f"{prefix}.feature_extractor.{i}.0.bias"]), 0.01)
+        h = _leaky(F.linear(h, p[f"{prefix}.feature_extractor.{i}.0.weight"],
+                            p[f"{prefix}.feature_extractor.{i}.0.bias"]), f"{prefix}.{i}")
         feats.append(h)
     return F.linear(torch.cat(feats, dim=-1), p[f"{prefix}.head.weight"], p[f"{prefix}.head.bias"])
 
@@ -281,12 +307,12 @@ def gumbel_policy(p, spec: Spec, which, s, u):
     temperature 1, with the U(0,1) draw ``u`` supplied by the caller."""
     logits = skip_head_mlp(p, f"actor_critic.{which}", s, len(spec.pi_hidden))
     norm = logits - logits.logsumexp(dim=-1, keepdim=True)      # Categorical normalisation
-    tiny = torch.finfo(torch.float32).eps
-    uc = u.clamp(min=tiny, max=1 - tiny)                        # clamp_probs
+    tiny = torch.finfo(torch.float32).eps                       # clamp_probs of the reference's float32 draw
+    uc = u.clamp(min=tiny, max=1 - tiny)
     gumbels = -((-(uc.log())).log())
     scores = (norm + gumbels) / 1.0
     relaxed = (scores - scores.logsumexp(dim=-1, keepdim=True)).exp()
-    hard = F.one_hot(torch.argmax(relaxed, dim=-1), logits.shape[-1]).float()
+    hard = F.one_hot(torch.argmax(relaxed, dim=-1), logits.shape[-1]).to(relaxed.dtype)
     st = (hard - relaxed).detach() + relaxed                    # straight-through
     logp = -torch.sum(-st * F.log_softmax(norm, -1), -1, keepdim=True)
     return st, logp
@@ -331,7 +357,7 @@ def quantile_huber(q, y):
     n = q.shape[-1]
     tau = torch.arange(n, dtype=q.dtype) / n + 1 / 2 / n
     tau = tau.view(*([1] * (q.dim() - 1)), n, 1)
-    return (torch.abs(tau - (delta < 0).float()) * huber).mean((-1, -2))
+    return (torch.abs(tau - (delta < 0).to(q.dtype)) * huber).mean((-1, -2))
 
 
 def losses(p, spec: Spec, xp, noise_target, noise_actor, alpha):
@@ -342,7 +368,7 @@ def losses(p, spec: Spec, xp, noise_target, noise_actor, alpha):
     contig = (xp["episode_step"][1:] == xp["episode_step"][:-1] + 1) & mask[:-1]   # :202-203
     action = xp["action"]
     if spec.discrete:                                                      # :206-210
-        action = torch.eye(spec.act)[action.view(action.shape[:-1]).long()]
+        action = torch.eye(spec.act, dtype=xp["reward"].dtype)[action.view(action.shape[:-1]).long()]
     h0 = None
     if spec.gru:                                                           # encoder.py:78-94 (forward_train)
         contig = torch.cumprod(contig.to(torch.int64), dim=0).bool()       # a window is valid up to its first break
@@ -369,7 +395,7 @@ def losses(p, spec: Spec, xp, noise_target, noise_actor, alpha):
     if spec.distributional:
         q_loss = quantile_huber(q, td).unsqueeze(-1)                       # distributional…:70
         if spec.lowerbound:
-            q_loss = q_loss + (mc - q).relu().mean(-1, keepdim=True)       # :76-79
+            q_loss = q_loss + _relu_kink(mc - q, "lowerbound").mean(-1, keepdim=True)       # :76-79
     else:
         ql = F.smooth_l1_loss(q, td.expand_as(q), reduction="none")       # soft_actor_critic.py:88
         if spec.lowerbound:                                                # :93-97
@@ -382,7 +408,7 @@ def losses(p, spec: Spec, xp, noise_target, noise_actor, alpha):
     qpi = ensemble(frozen, spec, "critic_frozen", torch.cat((s_cur.detach(), pi), -1)).mean(-1, keepdim=True)
     pi_loss = -(alpha * (-logp)) - qpi
     alpha_loss = -(p["actor_critic.log_alpha"] * (spec.target_entropy - (-logp)).detach())
-    w = contig.float()
+    w = contig.to(state.dtype)
     if spec.burn_in:                                                       # deepQlearning.py:219-220
         w = w.clone()
         w[:spec.burn_in] = 0
@@ -467,3 +493,22 @@ def train_step(st: TrainState, spec: Spec, xp, noise_target, noise_actor):
                     st.params[kt] = st.params[kt] * (1.0 - spec.tau) + st.params[k] * spec.tau
     aux["grad"] = grads
     return loss.detach(), aux
+
+
+def grads_in(dtype, spec: Spec, params, xp, noise_target, noise_actor, alpha, force=None):
+    """loss, d loss / d theta, d loss / d q_pred and every pre-activation of ONE evaluation of ``losses`` in ``dtype``
+    (torch.float64: the arbiter of the three-way comparison oracle-f32 / GPU / f64).  ``force``: optional
+    {"<prefix>.<layer>" | "lowerbound": bool tensor} branch pattern to impose on the kinks (see KINKS)."""
+    names = trainable_names(spec)
+    cast = lambda v: v.detach().to(dtype) if v.is_floating_point() else v.detach()
+    leaves = {k: cast(v).clone().requires_grad_(k in names) for k, v in params.items()}
+    xpd = {k: cast(v) for k, v in xp.items()}
+    rec = {}
+    KINKS["record"], KINKS["force"] = rec, force
+    try:
+        loss, aux = losses(leaves, spec, xpd, cast(noise_target), cast(noise_actor), torch.tensor(float(alpha), dtype=dtype))
+        g = torch.autograd.grad(loss, [leaves[n] for n in names] + [aux["q_pred"]], allow_unused=True)
+    finally:
+        KINKS["record"], KINKS["force"] = None, None
+    grads = {n: (x if x is not None else torch.zeros_like(leaves[n])) for n, x in zip(names, g[:-1])}
+    return loss.detach(), grads, g[-1], rec, aux

@@ -2,9 +2,16 @@
 
 It makes the read-only reference at /root/reference importable in this image by
 putting permissive stand-in modules into ``sys.modules`` for third-party packages the
-image lacks (gym, numba, jax, autoslot, tensorboard, torchvision, cv2, py_ics).  None of
-the stand-ins touches hot-path arithmetic; ``numba.njit`` becomes the identity decorator,
-so the reference's own 3-line Python loops run as plain Python.
+image lacks (gym, numba, jax, autoslot, tensorboard, torchvision, cv2, py_ics).  Two of the
+stand-ins sit under hot-path arithmetic and are therefore written out rather than stubbed:
+``numba.njit`` becomes the identity decorator, so the reference's own 3-line Python loops
+run as plain Python (pure float32 under numpy 2; real numba forms the product in double),
+and ``jax`` / ``jax.numpy`` become a numpy-backed stand-in (`_install_jax`) with exactly
+what franQ/Replay/wrappers/her_vmap.py uses: ``vmap`` (loop over the mapped axis + stack,
+honouring ``in_axes``), ``logical_and/or/not``, ``devices`` and ``device_put`` (which, like
+jax with x64 disabled, demotes float64 -> float32 and int64 -> int32).  Fixtures produced
+through it (tests/golden/her_vmap.npz) are "shim-pinned": the reference's own file ran,
+on a stand-in for a library the image lacks.
 
 Nothing in tests/, bench.py or the package imports this file at run time on the GPU box:
 the reference cannot travel, only the vectors generated from it (tests/golden/*.npz).
@@ -58,11 +65,12 @@ def install():
 
     for name in ["gym", "gym.spaces", "gym.wrappers", "gym.envs", "gym.envs.classic_control",
                  "gym.utils", "gym.error",
-                 "jax", "jax.numpy", "autoslot", "torchvision", "torchvision.transforms",
+                 "autoslot", "torchvision", "torchvision.transforms",
                  "cv2", "py_ics", "py_ics.gym_env", "py_ics.gym_env.envs",
                  "zarr", "caterva", "highway_env"]:
         if name not in sys.modules:
             _stub(name)
+    _install_jax()
     # numba: njit must be a real identity decorator (with and without arguments)
     nb = _stub("numba")
 
@@ -91,6 +99,50 @@ def install():
 
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
+
+
+def _install_jax():
+    """numpy-backed jax / jax.numpy with the handful of entry points her_vmap.py:26-45,66-78 calls."""
+    import numpy as np
+
+    def demote(x):     # jax with x64 disabled (the default): 64-bit inputs become 32-bit on device_put / asarray
+        a = np.asarray(x)
+        if a.dtype == np.float64:
+            return a.astype(np.float32)
+        if a.dtype == np.int64:
+            return a.astype(np.int32)
+        return a
+
+    def vmap(fn, in_axes=0, out_axes=0):
+        assert out_axes == 0
+
+        def mapped(*args):
+            axes = tuple(in_axes) if isinstance(in_axes, (tuple, list)) else (in_axes,) * len(args)
+            assert len(axes) == len(args)
+            sizes = {np.shape(a)[ax] for a, ax in zip(args, axes) if ax is not None}
+            assert len(sizes) == 1, f"vmap: mapped axes disagree: {sizes}"
+            outs = []
+            for i in range(sizes.pop()):
+                call = [a if ax is None else np.take(demote(a), i, axis=ax) for a, ax in zip(args, axes)]
+                outs.append(fn(*call))
+            if isinstance(outs[0], (tuple, list)):
+                return tuple(np.stack([np.asarray(o[j]) for o in outs]) for j in range(len(outs[0])))
+            return np.stack([np.asarray(o) for o in outs])
+
+        return mapped
+
+    jax = types.ModuleType("jax")
+    jnp = types.ModuleType("jax.numpy")
+    jax.__path__ = []
+    jax.vmap = vmap
+    jax.devices = lambda kind=None: ["cpu:0"]
+    jax.device_put = lambda x, device=None: demote(x)
+    for name in ("logical_and", "logical_or", "logical_not", "sqrt", "sum", "abs", "square", "where", "linalg",
+                 "float32", "asarray", "array", "all", "any", "equal", "less", "greater", "mean"):
+        setattr(jnp, name, getattr(np, name))
+    jax.numpy = jnp
+    sys.modules["jax"] = jax
+    sys.modules["jax.numpy"] = jnp
 
 
 class Space:

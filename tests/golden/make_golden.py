@@ -12,6 +12,9 @@ calling the reference's own classes:
   * franQ.Replay.replay_memory.ReplayMemory               (ring add / wrap / windows)
   * franQ.Replay.wrappers.nstep_return.NStepReturn        (discounted return at write)
   * franQ.Replay.wrappers.her.HindsightNStepReplay        (write-time hindsight relabel)
+  * franQ.Replay.wrappers.her_vmap.HindsightVmapWrite/Read + nstep_return_vmap.NStepReturnVmap
+    (K virtual goals per step, one picked at read time) - "shim-pinned": these files need jax, which the
+    image lacks; they run on the numpy-backed stand-in of tests/golden/_refimport.py
   * franQ.Agent.deepQlearning.DeepQLearning.train_step    (loss, backward, Adam, polyak)
 
 Noise is captured by wrapping the torch RNG entry points the reference's distributions
@@ -37,6 +40,8 @@ import franQ  # noqa: E402,F401
 from franQ.Replay.replay_memory import ReplayMemory  # noqa: E402
 from franQ.Replay.wrappers.nstep_return import NStepReturn  # noqa: E402
 from franQ.Replay.wrappers.her import HindsightNStepReplay  # noqa: E402
+from franQ.Replay.wrappers.her_vmap import HindsightVmapWrite, HindsightVmapRead  # noqa: E402  (on the jax stand-in)
+from franQ.Replay.wrappers.nstep_return_vmap import NStepReturnVmap  # noqa: E402
 from franQ.Agent.deepQlearning import DeepQLearning  # noqa: E402
 from franQ.Agent.conf import AgentConf  # noqa: E402
 
@@ -203,6 +208,76 @@ def golden_her():
             "out": sink.stacked(),
         }
     save("her", out)
+
+
+class TeeMemory(ReplayMemory):
+    """The reference ring that also records every record it is handed (what the write wrappers emitted)."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.rows = []
+
+    def add(self, d):
+        self.rows.append({k: np.array(v) for k, v in d.items()})
+        super().add(d)
+
+
+def golden_her_vmap():
+    """her_vmap.py:10-123 + nstep_return_vmap.py:8-74 as the reference stacks them
+    (franQ/Replay/__init__.py:20-36): HindsightVmapWrite -> NStepReturnVmap -> ReplayMemory on the write side,
+    HindsightVmapRead -> ReplayMemory on the read side."""
+    out = {}
+    for name, (K, ep_lens, n_step, gamma, T, B) in {
+        "k4": (4, [6, 5, 3], 1000, 0.97, 3, 4),
+        "k32_pop": (32, [9, 4], 4, 0.9, 2, 6),      # n_step 4: NStepReturnVmap._pop fires once per episode (q3)
+    }.items():
+        rng = np.random.RandomState(21 + K)
+        ring = TeeMemory(64, B, T)
+        inner = NStepReturnVmap(ring, n_step, gamma)
+        w = HindsightVmapWrite(inner, l2_sparse_reward, num_virtual_goals=K)
+        inputs, goal_idx = [], []
+        np.random.seed(100 + K)
+        for L in ep_lens:
+            dg = rng.uniform(-1, 1, 2).astype(np.float32)
+            pos = rng.uniform(-1, 1, 2).astype(np.float32)
+            for i in range(L):
+                pos = (pos + rng.uniform(-0.3, 0.3, 2)).astype(np.float32)
+                if i in (1, 3):     # the same place twice: a virtual goal drawn from it is reached mid-episode
+                    pos = np.asarray([0.4, -0.2], np.float32) + np.float32(0.01 * i)
+                rew, td = l2_sparse_reward(pos, dg)
+                row = {"obs_1d": rng.standard_normal(3).astype(np.float32),
+                       "achieved_goal": pos.copy(), "desired_goal": dg.copy(),
+                       "action": rng.uniform(-1, 1, 2).astype(np.float32),
+                       "reward": float(np.float32(float(rew) + 0.125 * i)),
+                       "task_done": bool(td) or (i == L - 2 and L > 3),   # a real done besides the hindsight ones
+                       "episode_done": i == L - 1, "episode_step": i, "info": {}}
+                inputs.append(row)
+                if row["episode_done"]:
+                    # the draw her_vmap.py:75 is about to make (indices into the NEWEST-first episode buffer)
+                    st = np.random.get_state()
+                    goal_idx.append(np.random.randint(0, L, size=K))
+                    np.random.set_state(st)
+                w.add(dict(row))
+        keys = [k for k in inputs[0] if k != "info"]
+        emitted = {k: np.stack([np.asarray(r[k], np.float32).reshape(-1) for r in ring.rows]) for k in sorted(ring.rows[0])}
+        # read side: one virtual column for the whole batch (q11); starts and column re-derived from the seeds
+        r = HindsightVmapRead(ring)
+        np.random.seed(7)
+        random.seed(7)
+        sample = r.temporal_sample()
+        np.random.seed(7)
+        random.seed(7)
+        starts = np.random.randint(0, len(ring) - T, B)
+        col = random.randint(0, K)
+        out[name] = {
+            "K": K, "ep_lens": np.asarray(ep_lens), "n_step": n_step, "gamma": gamma, "thr": 0.25, "T": T, "B": B,
+            "in": {k: np.stack([np.asarray(x[k], np.float32).reshape(-1) for x in inputs]) for k in keys},
+            "goal_idx_newest_first": np.stack(goal_idx),
+            "out": emitted, "ring_len": len(ring),
+            "read": {"starts": starts, "column": col,
+                     "sample": {k: np.asarray(v, np.float32) for k, v in sample.items()}},
+        }
+    save("her_vmap", out)
 
 
 # --------------------------------------------------------------------------------------
@@ -513,6 +588,8 @@ def main():
         golden_nstep()
     if not only or "her" in only:
         golden_her()
+    if not only or "her_vmap" in only:
+        golden_her_vmap()
     picked = {a.split(":", 1)[1] for a in only if a.startswith("update:")}   # e.g. `update:sac_boot`
     if not only or "update" in only or picked:
         for name, case in UPDATE_CASES.items():

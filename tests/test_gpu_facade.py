@@ -356,7 +356,48 @@ def test_device_noise_statistics_and_determinism(dev):
     assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1.0) < 0.02
 
 
-# --------------------------------------------------------------------------- HER-vmap (parity unpinned: vs the text restatement)
+# --------------------------------------------------------------------------- HER-vmap (shim-pinned: the reference files ran on a jax stand-in)
+def _l2_callable(ag, dg, thr=0.25):
+    d = np.linalg.norm(np.asarray(ag, np.float32) - np.asarray(dg, np.float32))
+    reward = np.float32(-1.0) if d > thr else np.float32(0.0)
+    return reward, bool(reward == 0)
+
+
+@pytest.mark.parametrize("case", ["k4", "k32_pop"])
+@pytest.mark.parametrize("reward_kind", ["device", "host_callable"])
+def test_her_vmap_stack_matches_reference(dev, case, reward_kind):
+    """HindsightVmapWrite -> NStepReturnVmap -> HBM ring -> HindsightVmapRead against what the reference's own
+    her_vmap.py / nstep_return_vmap.py emitted and sampled (tests/golden/her_vmap.npz): fdql_episode_her_vmap (or the
+    host loop for an arbitrary reward callable), fdql_episode_mc_return_vmap (q10, and the _pop duplicate q3) and the
+    column select inside the gather, fdql_ring_sample_windows_sel (q11) - bit for bit."""
+    from fastdeepqlearning_amd.Replay import ReplayMemory
+    from fastdeepqlearning_amd.Replay.wrappers import HindsightVmapRead, HindsightVmapWrite, NStepReturnVmap, SparseL2Reward
+    g = load("her_vmap")[case]
+    K, T, B = int(g["K"]), int(g["T"]), int(g["B"])
+    ring = ReplayMemory(64, B, T, device=dev)
+    inner = NStepReturnVmap(ring, int(g["n_step"]), float(g["gamma"]))
+    fn = SparseL2Reward(float(g["thr"]), -1.0) if reward_kind == "device" else _l2_callable
+    w = HindsightVmapWrite(inner, fn, num_virtual_goals=K)
+    inp = g["in"]
+    np.random.seed(100 + K)                 # the generator's seed: her_vmap.py:75 draws from numpy's global state
+    for i in range(inp["reward"].shape[0]):
+        w.add({"obs_1d": inp["obs_1d"][i], "achieved_goal": inp["achieved_goal"][i], "desired_goal": inp["desired_goal"][i],
+               "action": inp["action"][i], "reward": float(inp["reward"][i, 0]), "task_done": bool(inp["task_done"][i, 0]),
+               "episode_done": bool(inp["episode_done"][i, 0]), "episode_step": int(inp["episode_step"][i, 0]), "info": {}})
+    n = int(g["ring_len"])
+    assert len(ring) == n
+    got = ring[np.arange(n)]
+    assert set(got) == set(g["out"])
+    for k, v in g["out"].items():
+        np.testing.assert_array_equal(got[k].cpu().numpy().reshape(v.shape), v, err_msg=k)
+    random.seed(7)                          # the generator's seed for the read-time column (her_vmap.py:107-108)
+    xp = HindsightVmapRead(ring).temporal_sample(starts=torch.as_tensor(g["read"]["starts"]))
+    assert set(xp) == set(g["read"]["sample"])
+    for k, v in g["read"]["sample"].items():
+        np.testing.assert_array_equal(xp[k].cpu().numpy().reshape(v.shape), v, err_msg=k)
+
+
+
 def test_her_vmap_kernels_match_restatement(dev):
     """fdql_episode_her_vmap / fdql_episode_mc_return_vmap against oracle.replay.vmap_* (her_vmap.py:30-45,
     nstep_return_vmap.py:61-74 restated from text; the reference file itself cannot run without jax)."""

@@ -723,3 +723,104 @@ def test_act_device_noise_and_live_weights(dev):
     ag.tensors["actor_critic.actor.head.bias"].add_(0.25)
     _, _, _, gr4 = ag.act(obs, exploit_mask=mask, seed=5, counter=1)
     assert not torch.equal(gr1, gr4)
+
+
+# --------------------------------------------------------------------------- gradients: GPU vs oracle-f32 vs an fp64 evaluation
+def _gpu_branch_pattern(ag, spec, xp_cpu):
+    """Which side of every kink the GPU took: sign of each stored hidden activation (LeakyReLU keeps the sign of its
+    input) and of mc - q for the lower-bound term.  Keys are oracle.update's "<prefix>.<layer>" names."""
+    T, B = spec.T, spec.B
+    pat = {}
+
+    def grab(key, name, lead, width):
+        pat[key] = (ag.debug(name, lead + (width,)) > 0).cpu()
+
+    for i, w in enumerate(spec.enc_hidden):
+        grab(f"encoder.visible_layer_encoders.obs_1d.{i}", f"enc_obs.h{i}", (T, B), w)
+    if not spec.gru:
+        for i, w in enumerate(spec.joint_hidden):
+            grab(f"encoder.joiner.{i}", f"joiner.h{i}", (T, B), w)
+    for i, w in enumerate(spec.pi_hidden):
+        grab(f"actor_critic.actor.{i}", f"actor.h{i}", (T - 1, B), w)
+    for k in range(spec.C):
+        for i, w in enumerate(spec.critic_hidden):
+            grab(f"actor_critic.critic.nets.{k}.{i}", f"crit{k}.h{i}", (T - 1, B), w)
+            grab(f"actor_critic.critic_frozen.nets.{k}.{i}", f"crit_f{k}.h{i}", (T - 1, B), w)
+    if spec.lowerbound and spec.distributional:
+        pat["lowerbound"] = (xp_cpu["mc_return"][1:] - ag.debug("q_pred", (T - 1, B, spec.Nq)).cpu()) > 0
+    return pat
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("config 2 full size (T=50, B=256)", dict(obs=17, act=6, C=5, Q=2, T=50, B=256)),
+    ("config 4 dims (obs 376, act 17, 5x25 quantiles, T=3, B=96)", dict(obs=376, act=17, C=5, Q=25, T=3, B=96)),
+])
+def test_gradient_parity_three_way_fp64(dev, name, kw):
+    """north_star: gradients within 1e-5 rel fp32 of the reference CPU path.  Two fp32 evaluations of this loss cannot
+    agree to 1e-5 element by element: LeakyReLU and relu(mc - q) make the gradient discontinuous in the activations, and
+    a unit whose pre-activation is ~1e-7 from its kink picks its branch by rounding.  An fp64 evaluation of the oracle
+    is the arbiter:
+      (a) every unit where the GPU's branch differs from the fp64 one has an fp64 pre-activation within KINK of zero
+          (relative to the largest pre-activation of its layer): the GPU picked the other side of a kink it sits on;
+      (b) with exactly those branch choices imposed on the fp64 evaluation, EVERY element of every gradient tensor
+          and of d loss / d q_pred agrees with the GPU within 1e-5 * max|tensor| (max-norm-relative, like every bound
+          of this file);
+      (c) the GPU is no farther from the unforced fp64 gradient than the CPU oracle (fp32) is, up to a factor 2 + 1e-5.
+    The table goes to gpurun_out/parity_three_way.txt (committed as profiles/r02_parity_report.txt)."""
+    import os
+    from oracle import update as oup
+    spec = oup.Spec(**kw)
+    T, B = spec.T, spec.B
+    params = oup.init_params(spec, seed=3)
+    st = oup.new_state(spec, params)
+    g = torch.Generator().manual_seed(1)
+    xp = {"obs_1d": torch.randn(T, B, spec.obs, generator=g), "action": torch.rand(T, B, spec.act, generator=g) * 2 - 1,
+          "reward": torch.randn(T, B, 1, generator=g), "mc_return": torch.randn(T, B, 1, generator=g) * 2,
+          "task_done": (torch.rand(T, B, 1, generator=g) < 0.05).float(),
+          "episode_step": (torch.arange(T).view(T, 1, 1) + torch.randint(0, 900, (1, B, 1), generator=g)).float()}
+    xp["episode_step"][T // 2:, ::7] = torch.arange(T - T // 2).view(-1, 1, 1).float()
+    nt, na = torch.randn(T - 1, B, spec.act, generator=g), torch.randn(T - 1, B, spec.act, generator=g)
+    ag = _agent_for(spec, dev)
+    ag.load_tensors(params)
+    ag.update({k: v.to(dev) for k, v in xp.items()}, nt.to(dev), na.to(dev), phase=1)     # FDQL_PHASE_GRAD: weights untouched
+    pat = _gpu_branch_pattern(ag, spec, xp)
+    g_gpu = {n: ag.grad_views[n].cpu().double() for n in ag.trainable}
+    g_gpu["d loss / d q_pred"] = ag.debug("dz", (T - 1, B, spec.Nq)).cpu().double()
+    _, g32, dq32, rec32, _ = oup.grads_in(torch.float32, spec, params, xp, nt, na, st.alpha)
+    _, g64, dq64, rec64, _ = oup.grads_in(torch.float64, spec, params, xp, nt, na, st.alpha)
+    _, g64f, dq64f, _, _ = oup.grads_in(torch.float64, spec, params, xp, nt, na, st.alpha, force=pat)
+    for d, dq in ((g32, dq32), (g64, dq64), (g64f, dq64f)):
+        d["d loss / d q_pred"] = dq
+    KINK, TOL_G = 2e-6, 1e-5
+    lines = [f"== {name}: gradients, GPU vs CPU oracle (fp32) vs fp64 evaluation of the oracle",
+             "branch flips (units whose LeakyReLU / relu(mc-q) branch differs from the fp64 evaluation):",
+             f"{'kink set':58s} {'units':>10s} {'gpu flips':>9s} {'max |pre64|/max|pre|':>21s} {'oracle-f32 flips':>16s}"]
+    bad = []
+    for key, p64 in rec64.items():
+        if key not in pat:
+            continue
+        b64 = p64 > 0
+        flips = pat[key].reshape(b64.shape) != b64
+        f32 = (rec32[key] > 0) != b64
+        scale = float(p64.abs().max())
+        dist = float(p64[flips].abs().max() / scale) if bool(flips.any()) else 0.0
+        lines.append(f"{key:58s} {b64.numel():10d} {int(flips.sum()):9d} {dist:21.3e} {int(f32.sum()):16d}")
+        if dist > KINK:
+            bad.append(("kink distance", key, dist))
+    lines.append(f"{'tensor':58s} {'oracle32-f64':>12s} {'gpu-f64':>12s} {'gpu-f64forced':>13s} {'elems>1e-5':>10s} {'viol.(c)':>8s}")
+    for n in g_gpu:
+        ref, reff = g64[n].double(), g64f[n].double()
+        sc = float(ref.abs().max()) + 1e-300
+        e_or = (g32[n].double() - ref).abs()
+        e_gpu = (g_gpu[n].reshape(ref.shape) - ref).abs()
+        e_f = (g_gpu[n].reshape(ref.shape) - reff).abs()
+        n_out = int((e_f > TOL_G * sc).sum())
+        viol_c = int((e_gpu > 2 * e_or + TOL_G * sc).sum())
+        lines.append(f"{n:58s} {float(e_or.max()) / sc:12.3e} {float(e_gpu.max()) / sc:12.3e} {float(e_f.max()) / sc:13.3e} "
+                     f"{n_out:10d} {viol_c:8d}")
+        if n_out:
+            bad.append(("beyond 1e-5 with the GPU's branches imposed", n, float(e_f.max()) / sc))
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity_three_way.txt", "a") as f:
+        f.write("\n".join(lines) + "\n")
+    assert not bad, bad[:8]

@@ -125,6 +125,41 @@ def test_her_matches_reference(case):
                                    err_msg=k)
 
 
+def _vmap_records(inp):
+    return [{"obs_1d": inp["obs_1d"][i], "achieved_goal": inp["achieved_goal"][i], "desired_goal": inp["desired_goal"][i],
+             "action": inp["action"][i], "reward": float(inp["reward"][i, 0]), "task_done": bool(inp["task_done"][i, 0]),
+             "episode_done": bool(inp["episode_done"][i, 0]), "episode_step": int(inp["episode_step"][i, 0]), "info": {}}
+            for i in range(inp["reward"].shape[0])]
+
+
+@pytest.mark.parametrize("case", ["k4", "k32_pop"])
+def test_her_vmap_matches_reference(case):
+    """her_vmap.py + nstep_return_vmap.py ran on the jax stand-in (shim-pinned): K relabelled columns + the real
+    one, per-column returns (q10), the one-shot _pop duplicate (q3), and the read-time single column (q11)."""
+    g = load("her_vmap")[case]
+    K, T, B = int(g["K"]), int(g["T"]), int(g["B"])
+    draws = iter(g["goal_idx_newest_first"])
+    sink = Sink()
+    w = orp.VmapWriteOracle(sink, l2_sparse_reward, K, int(g["n_step"]), float(g["gamma"]), draw=lambda n, k: next(draws))
+    for row in _vmap_records(g["in"]):
+        w.add(row)
+    out = sink.stacked()
+    assert set(out) == set(g["out"])
+    for k, v in g["out"].items():
+        np.testing.assert_array_equal(np.asarray(out[k], np.float32).reshape(v.shape), v, err_msg=k)
+    # read side through the numpy ring
+    ring = orp.RingOracle(64, B, T)
+    for r in sink.rows:
+        ring.add({k: (np.asarray(v) if np.asarray(v).ndim else v) for k, v in r.items()})
+    assert len(ring) == int(g["ring_len"])
+    sample = orp.vmap_read_select({k: v.reshape(v.shape[:2] + ((K + 1, -1) if k == "virtual_goals" else v.shape[2:]))
+                                   for k, v in ring.temporal_sample(starts=g["read"]["starts"]).items()},
+                                  int(g["read"]["column"]))
+    assert set(sample) == set(g["read"]["sample"])
+    for k, v in g["read"]["sample"].items():
+        np.testing.assert_array_equal(np.asarray(sample[k], np.float32).reshape(v.shape), v, err_msg=k)
+
+
 # --------------------------------------------------------------------------- update
 TOL = 2e-5  # tensor-normalised max error; both sides are fp32 CPU with different op order
 
