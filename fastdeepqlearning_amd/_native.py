@@ -101,6 +101,8 @@ SIGNATURES = {
     "fdql_ring_sample_windows_sel": (C.c_int, [_vp, _i32, _i32, _vp, _u64, _u64, C.POINTER(_vp), C.POINTER(_i32),
                                                C.POINTER(_i32), _vp, _vp]),
     "fdql_ring_sample_rows": (C.c_int, [_vp, _i32, _vp, _u64, _u64, C.POINTER(_vp), _vp, _vp]),
+    "fdql_debug_chain_stamps": (C.c_int, [_vp, _i32]),
+    "fdql_test_chain_mlp": (C.c_int, [_vp, _i32, _i32, C.POINTER(_i32), _i32, _i32, _vp, C.POINTER(_vp), _vp, _vp]),
     "fdql_ring_gather_rows": (C.c_int, [_vp, _i64, _vp, C.POINTER(_vp), _vp]),
     "fdql_episode_mc_return": (C.c_int, [_vp, _vp, _i32, _f32, _vp]),
     "fdql_episode_her_vmap": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, C.POINTER(RewardFn), _vp, _vp, _vp, _vp]),

@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -17,6 +18,7 @@
 #include <string>
 #include <vector>
 
+#include "chain.h"
 #include "common.h"
 #include "update_kernels.h"
 
@@ -85,7 +87,7 @@ constexpr size_t PLAN_CACHE_MAX = 4;   // finished plans kept besides the curren
 // K-split of a conv weight gradient over its R = images * positions rows: ~4096 rows per workgroup, at most 1024 parts
 inline int conv_wsplit(long long R) { return (int)std::max<long long>(1, std::min<long long>(1024, (R + 4095) / 4096)); }
 
-enum StageKind { ST_GEMM, ST_SKINNY_WGRAD, ST_FUNC, ST_HEAD_DGRAD };
+enum StageKind { ST_GEMM, ST_SKINNY_WGRAD, ST_FUNC, ST_HEAD_DGRAD, ST_CHAIN };
 
 struct GemmSub {
   std::vector<GemmProblem> probs;
@@ -100,6 +102,10 @@ struct Stage {
   GemmSub sub[GEMM_NSHAPES];  // the problems of `gemm`, grouped by tile shape (one launch each)
   std::vector<SkinnyWgradProblem> swg;
   std::vector<HeadDgradProblem> hdg;
+  std::vector<ChainProblem> cprobs;   // ST_CHAIN: programs (chain.h) and their operations
+  std::vector<ChainOp> cops;
+  void *cops_dev = nullptr;
+  int lds_floats = 0;
   void *dev = nullptr;  // device copy of the table
   int blocks = 0;
   double flops = 0, bytes = 0;
@@ -531,6 +537,179 @@ struct Builder {
   }
 };
 
+// ------------------------------------------------------------------------ chain programs (chain.h)
+// Emits the operations of MLP forward passes for the row-block chain kernel.  `ok` turns false as soon as something
+// does not fit the kernel (a layer wider than 256 columns, more K-segments than an operation holds, LDS exhausted,
+// too many operations): the caller then drops the stage and keeps the per-layer GEMM launches.
+struct ChainImg { int slot = -1, pitch = 0, K = 0, size = 0; };
+struct RowWin { int lo, hi, shift; };
+
+struct ChainBuilder {
+  Stage &st;
+  bool ok = true;
+  int op_start = 0, rows = 0, peak = 0;
+  int wstage = -1, wstage_size = 0;   // head-weight staging area of the program's CH_NARROW operations
+  std::vector<std::pair<int, int>> used;   // live LDS ranges (offset, size) of the program being built
+  explicit ChainBuilder(Stage &s) : st(s) {}
+
+  void begin(int nrows) { rows = nrows; op_start = (int)st.cops.size(); used.clear(); peak = 0; wstage = -1; wstage_size = 0; }
+  // reserved up front (lives for the whole program): N rows of the widest K-segment a narrow head of this program reads
+  void reserve_head_stage(int N, int maxK) {
+    const int need = N * (((maxK + 15) & ~15) + 4);
+    if (need > wstage_size) {
+      if (wstage >= 0) { ok = false; return; }   // must be sized before the first allocation that follows it
+      wstage = alloc(need);
+      wstage_size = need;
+    }
+  }
+  void end() {
+    ChainOp e;
+    memset(&e, 0, sizeof(e));
+    e.kind = CH_END;
+    st.cops.push_back(e);
+    if ((int)st.cops.size() - op_start > CH_MAX_OPS) ok = false;
+    ChainProblem p;
+    memset(&p, 0, sizeof(p));
+    p.rows = rows; p.op_start = op_start; p.nops = (int)st.cops.size() - op_start; p.lds_floats = peak;
+    st.cprobs.push_back(p);
+    st.lds_floats = std::max(st.lds_floats, peak);
+  }
+  int alloc(int size) {   // first fit; sizes are multiples of 4 floats (16-byte aligned images)
+    size = (size + 3) & ~3;
+    std::sort(used.begin(), used.end());
+    int at = 0;
+    for (auto &u : used) {
+      if (u.first - at >= size) break;
+      at = u.first + u.second;
+    }
+    if (at + size > CH_LDS_FLOATS) { ok = false; return 0; }
+    used.push_back({at, size});
+    peak = std::max(peak, at + size);
+    return at;
+  }
+  void release(const ChainImg &im) {
+    for (size_t i = 0; i < used.size(); ++i)
+      if (used[i].first == im.slot) { used.erase(used.begin() + i); return; }
+  }
+  ChainImg image(int K, int min_size = 0) {
+    ChainImg im;
+    im.K = K; im.pitch = chain_pitch(K); im.size = std::max(CH_BM * im.pitch, min_size);
+    im.slot = alloc(im.size);
+    return im;
+  }
+  static ChainOp new_op(int kind) {
+    ChainOp o;
+    memset(&o, 0, sizeof(o));
+    o.kind = kind; o.out_slot = -1;
+    return o;
+  }
+  ChainImg load(const std::vector<SegIn> &segs, int min_size = 0) {
+    int K = 0;
+    for (auto &s : segs) K += s.width;
+    ChainImg im = image(K, min_size);
+    ChainOp o = new_op(CH_LOAD);
+    if ((int)segs.size() > CH_MAX_SEG) { ok = false; return im; }
+    o.slot = im.slot; o.pitch = im.pitch; o.kpad = chain_kpad(K); o.nseg = (int)segs.size();
+    int col = 0;
+    for (size_t i = 0; i < segs.size(); ++i) {
+      o.ld[i].src = segs[i].ptr; o.ld[i].ld = segs[i].ld; o.ld[i].width = segs[i].width; o.ld[i].col = col;
+      col += segs[i].width;
+    }
+    st.cops.push_back(o);
+    return im;
+  }
+  // one Linear layer over cat(ins): W rows of pitch ldw, the k-th input image reads columns starting at its offset
+  // in the concatenation.  dst: the LDS image that receives the result (may alias a dying input; slot -1: none)
+  void gemm(const std::vector<ChainImg> &ins, const float *W, int ldw, int N, const float *bias, int act, const ChainImg &dst,
+            float *out, int ldo, RowWin win) {
+    if (N > 256 || (int)ins.size() > CH_MAX_SEG) { ok = false; return; }
+    ChainOp o = new_op(CH_GEMM);
+    o.N = N; o.flags = CHF_ZERO | CHF_EMIT; o.act = act; o.bias = bias; o.nseg = (int)ins.size();
+    int col = 0;
+    for (size_t i = 0; i < ins.size(); ++i) {
+      o.seg[i].W = W + col; o.seg[i].ldw = ldw; o.seg[i].slot = ins[i].slot; o.seg[i].pitch = ins[i].pitch; o.seg[i].K = ins[i].K;
+      col += ins[i].K;
+    }
+    o.out_slot = dst.slot; o.out_pitch = dst.pitch;
+    o.out = out; o.ldo = ldo; o.row_lo = win.lo; o.row_hi = win.hi; o.row_shift = win.shift;
+    st.cops.push_back(o);
+    st.flops += chain_op_flops(o, std::min(rows, win.hi) - win.lo);
+  }
+  // part of a narrow head (N <= 32) over cat(ins) starting at column `col0` of the head weight
+  void narrow(const std::vector<ChainImg> &ins, const float *W, int ldw, int col0, int N, bool begin, bool finish,
+              const float *bias, float *out, int ldo, RowWin win, int scratch_slot) {
+    if (N > 32 || (int)ins.size() > CH_MAX_SEG) { ok = false; return; }
+    ChainOp o = new_op(CH_NARROW);
+    o.N = N; o.flags = (begin ? CHF_BEGIN : 0) | (finish ? CHF_FINISH : 0); o.nseg = (int)ins.size();
+    int col = col0;
+    for (size_t i = 0; i < ins.size(); ++i) {
+      o.seg[i].W = W + col; o.seg[i].ldw = ldw; o.seg[i].slot = ins[i].slot; o.seg[i].pitch = ins[i].pitch; o.seg[i].K = ins[i].K;
+      col += ins[i].K;
+    }
+    for (auto &im : ins)
+      if (wstage < 0 || N * (((im.K + 15) & ~15) + 4) > wstage_size) ok = false;   // reserve_head_stage() sizes it
+    (void)scratch_slot;
+    o.slot = wstage; o.bias = bias; o.out = out; o.ldo = ldo;
+    o.row_lo = win.lo; o.row_hi = win.hi; o.row_shift = win.shift;
+    st.cops.push_back(o);
+    st.flops += chain_op_flops(o, std::min(rows, win.hi) - win.lo);
+  }
+
+  // SkipHeadMLP forward (mlp.py:88-94) on images already in LDS.
+  //   in_dies: the input images are not needed after this MLP (their LDS may be reused).
+  //   hidden activations go to m.h[i] (global, rows of `win`) when store_h; the head output to m.out (global) and,
+  //   for a wide head, to the returned LDS image.
+  // Narrow head (dout <= 32): the head's dot product is accumulated piecewise (CH_NARROW, per-wave 16-row tiles) as soon as
+  // each block of its input exists, so a layer's input image can be overwritten in place by its output: one image per MLP.
+  ChainImg mlp(const MlpInst &m, std::vector<ChainImg> ins, bool in_dies, bool store_h, RowWin win, bool want_out_image) {
+    const MlpDesc &d = *m.d;
+    const int nh = (int)d.hid.size(), ld_head = d.head_ld();
+    ChainImg none;
+    if (d.dout <= 32 && !want_out_image) {   // (an output that feeds the next MLP from LDS takes the GEMM path)
+      narrow(ins, m.HW(), ld_head, 0, d.dout, true, nh == 0, m.HB(), m.out, m.ldout, win, 0);
+      int col = d.din;
+      std::vector<ChainImg> cur = ins;
+      bool cur_dies = in_dies;
+      for (int i = 0; i < nh; ++i) {
+        // the layer's output image: in place of its (single, dying) input when possible, else a new one
+        int need = CH_BM * chain_pitch(d.hid[i]);
+        ChainImg dst;
+        if (cur_dies && cur.size() == 1 && cur[0].size >= need) {
+          dst = cur[0];
+          dst.K = d.hid[i]; dst.pitch = chain_pitch(d.hid[i]);
+        } else {
+          if (cur_dies) for (auto &c : cur) release(c);
+          dst = image(d.hid[i], need);
+          if (cur_dies) for (auto &c : cur) { (void)c; }
+        }
+        gemm(cur, m.W(i), d.in_of(i), d.hid[i], m.Bv(i), CHA_LRELU, dst, store_h ? m.h[i] : nullptr, d.hid[i], win);
+        const bool last = i + 1 == nh;
+        narrow({dst}, m.HW(), ld_head, col, d.dout, false, last, m.HB(), m.out, m.ldout, win, 0);
+        col += d.hid[i];
+        cur = {dst};
+        cur_dies = true;
+      }
+      if (nh > 0) release(cur[0]);
+      else if (in_dies) for (auto &c : ins) release(c);
+      return none;
+    }
+    // wide head: every feature block stays in LDS until the head GEMM has read it
+    std::vector<ChainImg> feats = ins, cur = ins;
+    for (int i = 0; i < nh; ++i) {
+      ChainImg dst = image(d.hid[i]);
+      gemm(cur, m.W(i), d.in_of(i), d.hid[i], m.Bv(i), CHA_LRELU, dst, store_h ? m.h[i] : nullptr, d.hid[i], win);
+      feats.push_back(dst);
+      cur = {dst};
+    }
+    // the head's output image may reuse what dies here: the epilogue writes only after every wave has finished reading
+    for (size_t i = in_dies ? 0 : ins.size(); i < feats.size(); ++i) release(feats[i]);
+    ChainImg dst;
+    if (want_out_image) dst = image(d.dout);
+    gemm(feats, m.HW(), ld_head, d.dout, m.HB(), CHA_NONE, dst, m.out, m.ldout, win);
+    return dst;
+  }
+};
+
 MlpInst make_inst(fdql_agent *a, const MlpDesc &d, const std::string &p, const float *wbase, int64_t worigin, int rows,
                   bool bwd) {
   MlpInst m;
@@ -559,6 +738,7 @@ int upload_tables(fdql_agent *a) {
     }
     if (s.kind == ST_SKINNY_WGRAD) total += pad(s.swg.size() * sizeof(SkinnyWgradProblem));
     if (s.kind == ST_HEAD_DGRAD) total += pad(s.hdg.size() * sizeof(HeadDgradProblem));
+    if (s.kind == ST_CHAIN) total += pad(s.cprobs.size() * sizeof(ChainProblem)) + pad(s.cops.size() * sizeof(ChainOp));
   }
   if (a->tables_dev) { FDQL_HIP(hipFree(a->tables_dev)); a->tables_dev = nullptr; }
   FDQL_HIP(hipMalloc(&a->tables_dev, total ? total : 256));
@@ -598,6 +778,16 @@ int upload_tables(fdql_agent *a) {
       const size_t bytes = s.hdg.size() * sizeof(HeadDgradProblem);
       memcpy(host.data() + off, s.hdg.data(), bytes);
       s.dev = (char *)a->tables_dev + off;
+      off += pad(bytes);
+    } else if (s.kind == ST_CHAIN) {
+      s.blocks = chain_finalize(s.cprobs.data(), (int)s.cprobs.size());
+      size_t bytes = s.cprobs.size() * sizeof(ChainProblem);
+      memcpy(host.data() + off, s.cprobs.data(), bytes);
+      s.dev = (char *)a->tables_dev + off;
+      off += pad(bytes);
+      bytes = s.cops.size() * sizeof(ChainOp);
+      memcpy(host.data() + off, s.cops.data(), bytes);
+      s.cops_dev = (char *)a->tables_dev + off;
       off += pad(bytes);
     }
   }
@@ -711,6 +901,39 @@ int build_plan(fdql_agent *a) {
     p.epi = EPI_LRELU;
     gs.gemm.push_back(p);
   }
+  // Row-block chain (chain.hip): encoder MLP -> joiner MLP -> online actor and target actor in ONE launch, the
+  // activations of a 64-row block resident in LDS from the observation to the policy logits.  Falls back to the
+  // per-layer launches when a layer does not fit the kernel (see ChainBuilder).
+  // FDQL_CHAIN: "0" never, "1" (default) the encoder/actor chain when the batch fills at least half the chip with
+  // 64-row blocks (fewer blocks leave most CUs idle for the length of a whole chain: the per-layer launches with their
+  // K-splits are faster there), "all" every eligible program incl. the critics' (measured slower than the grouped
+  // launches at config 2 so far: DESIGN.md section 5), regardless of size - the parity tests run all three.
+  const char *chain_env = getenv("FDQL_CHAIN");
+  const std::string chain_mode = chain_env ? chain_env : "1";
+  const bool chain_all = chain_mode == "all";
+  const bool want_chain = chain_all || (chain_mode != "0" && getenv("FDQL_NO_CHAIN") == nullptr && N >= 128 * CH_BM);
+  bool enc_chained = false;
+  if (want_chain && !gru) {
+    Stage cs;
+    cs.kind = ST_CHAIN; cs.name = "enc_joiner_actors";
+    ChainBuilder cb(cs);
+    cb.begin(N);
+    {
+      int mk = L;
+      for (int h : a->actor.hid) mk = std::max(mk, h);
+      cb.reserve_head_stage(a->actor.dout, mk);
+    }
+    ChainImg xi = cb.load(eo.in);
+    ChainImg ei = cb.mlp(eo, {xi}, true, true, {0, N, 0}, true);
+    ChainImg si = cb.mlp(jo, {ei}, true, true, {0, N, 0}, true);
+    cb.mlp(ao, {si}, false, true, {0, M, 0}, false);
+    cb.mlp(at, {si}, true, false, {B, N, B}, false);
+    cb.end();
+    if (cb.ok) { a->stages.push_back(cs); enc_chained = true; }
+  }
+  if (enc_chained) {
+    // nothing left to launch for these three networks
+  } else {
   fwd_chain({&eo}, "enc_obs");
   if (!gru) {
     fwd_chain({&jo}, "joiner");
@@ -749,6 +972,7 @@ int build_plan(fdql_agent *a) {
     }
   }
   fwd_chain({&at, &ao}, "actors");
+  }
   // ---- policy sampling (gaussian_mlp.py:15-39)
   {
     PolicyFwdArgs p0{at.out, nullptr, nullptr, a->buf("next_action"), a->buf("next_log_pi"), 0u, nullptr, nullptr};
@@ -785,7 +1009,31 @@ int build_plan(fdql_agent *a) {
       float *out = hf_parts + ((long long)inst * a->hf_planes + plane0(layer)) * MQ;
       if (second) p.hf_out2 = out; else p.hf_out = out;
     };
-    if (nh > 0 && getenv("FDQL_NO_DUAL") == nullptr) {
+    bool crit_chained = false;
+    if (chain_all) {   // every critic instance as one chain program: cat(s, a) -> hidden layers -> skip head
+      Stage cs;
+      cs.kind = ST_CHAIN; cs.name = "critics.fwd";
+      ChainBuilder cb(cs);
+      for (int k = 0; k < C && cb.ok; ++k) {
+        int which = 0;
+        for (MlpInst *m : {&ct[k], &co[k], &cf[k]}) {
+          cb.begin(M);
+          {
+            int mk = m->d->din;
+            for (int h : m->d->hid) mk = std::max(mk, h);
+            cb.reserve_head_stage(m->d->dout, mk);
+          }
+          ChainImg xi = cb.load(m->in);
+          cb.mlp(*m, {xi}, true, which != 0, {0, M, 0}, false);   // target activations are never needed again
+          cb.end();
+          ++which;
+        }
+      }
+      if (cb.ok) { a->stages.push_back(cs); crit_chained = true; }
+    }
+    if (crit_chained) {
+      // done
+    } else if (nh > 0 && getenv("FDQL_NO_DUAL") == nullptr) {
       Stage &gs = b.gemm_stage("critics.fwd0");
       for (int k = 0; k < C; ++k) {
         GemmProblem pt = b.fwd_layer(ct[k], 0);
@@ -1125,6 +1373,8 @@ hipError_t run_stage(fdql_agent *a, Stage &s, hipStream_t stream) {
     case ST_SKINNY_WGRAD: return skinny_wgrad_launch_host(s.swg.data(), (const SkinnyWgradProblem *)s.dev, (int)s.swg.size(), s.blocks, stream);
     case ST_FUNC: return s.fn(stream);
     case ST_HEAD_DGRAD: return head_dgrad_launch((const HeadDgradProblem *)s.dev, (int)s.hdg.size(), s.blocks, stream);
+    case ST_CHAIN:
+      return chain_launch((const ChainProblem *)s.dev, (int)s.cprobs.size(), (const ChainOp *)s.cops_dev, s.blocks, s.lds_floats, stream);
   }
   return hipSuccess;
 }
@@ -1375,7 +1625,8 @@ int32_t fdql_agent_profile_update(fdql_agent_t *a, const fdql_batch_t *batch, co
       for (const auto &p : st.sub[parts[i].shape].probs) { flops += gemm_flops(p); bytes += gemm_bytes(p); }
       snprintf(out[cnt].name, sizeof(out[cnt].name), "gemm%s:%s", shape_names[parts[i].shape], st.name.c_str());
     } else {
-      snprintf(out[cnt].name, sizeof(out[cnt].name), "%s%s", st.kind == ST_SKINNY_WGRAD ? "colsum:" : "k:", st.name.c_str());
+      snprintf(out[cnt].name, sizeof(out[cnt].name), "%s%s", st.kind == ST_SKINNY_WGRAD ? "colsum:" : (st.kind == ST_CHAIN ? "chain:" : "k:"),
+               st.name.c_str());
     }
     out[cnt].ms = ms;
     out[cnt].flops = flops;
@@ -1577,6 +1828,7 @@ int fdql_agent_stats(const fdql_agent_t *a, fdql_agent_stats_t *out) {
       for (const auto &sub : s.sub) if (sub.blocks > 0) out->n_gemm_launches++;
     }
     if (s.kind == ST_SKINNY_WGRAD) out->skinny_flops += s.flops;
+    if (s.kind == ST_CHAIN) { out->gemm_flops += s.flops; out->n_gemm_launches++; }
   }
   return 0;
 }
@@ -1590,6 +1842,49 @@ int fdql_debug_set_gemm_variant(int32_t variant) {
 int fdql_debug_set_gemm_dense_shape(int32_t shape) {
   FDQL_REQUIRE(gemm_shape_is_dense(shape), "dense shape must be 0 (128x128), 3 (64x128), 5 (64x64) or an LDS-DMA shape 7 (128x128), 8 (128x64), 9 (64x64)");
   gemm_set_dense_shape(shape);
+  return 0;
+}
+
+int fdql_debug_chain_stamps(uint64_t *out, int32_t cap) {
+  return chain_read_stamps(reinterpret_cast<unsigned long long *>(out), cap);
+}
+
+int fdql_test_chain_mlp(const float *x, int32_t rows, int32_t din, const int32_t *hid, int32_t nh, int32_t dout,
+                        const float *weights, float *const *h_out, float *out, void *stream) {
+  FDQL_REQUIRE(x && hid && weights && out && rows > 0 && din > 0 && dout > 0 && nh >= 0 && nh <= FDQL_MAX_HIDDEN, "bad arguments");
+  fdql_agent tmp;
+  MlpDesc d;
+  int64_t top = 0;
+  add_mlp(&tmp, d, "test", din, hid, nh, dout, top);
+  MlpInst m;
+  m.d = &d; m.wbase = weights; m.worigin = 0; m.rows = rows;
+  m.in.push_back({x, din, din});
+  for (int i = 0; i < nh; ++i) m.h.push_back(h_out ? h_out[i] : nullptr);
+  m.out = out; m.ldout = dout;
+  Stage cs;
+  cs.kind = ST_CHAIN; cs.name = "test";
+  ChainBuilder cb(cs);
+  cb.begin(rows);
+  if (dout <= 32) {
+    int mk = din;
+    for (int i = 0; i < nh; ++i) mk = std::max(mk, (int)hid[i]);
+    cb.reserve_head_stage(dout, mk);
+  }
+  ChainImg xi = cb.load(m.in);
+  cb.mlp(m, {xi}, true, h_out != nullptr, {0, rows, 0}, false);
+  cb.end();
+  FDQL_REQUIRE(cb.ok, "this MLP does not fit the chain kernel");
+  const int blocks = chain_finalize(cs.cprobs.data(), (int)cs.cprobs.size());
+  void *dev = nullptr;
+  const size_t pb = cs.cprobs.size() * sizeof(ChainProblem), ob = cs.cops.size() * sizeof(ChainOp);
+  FDQL_HIP(hipMalloc(&dev, pb + ob + 256));
+  FDQL_HIP(hipMemcpy(dev, cs.cprobs.data(), pb, hipMemcpyHostToDevice));
+  void *odev = (char *)dev + (pb + 255) / 256 * 256;
+  FDQL_HIP(hipMemcpy(odev, cs.cops.data(), ob, hipMemcpyHostToDevice));
+  hipError_t e = chain_launch((const ChainProblem *)dev, (int)cs.cprobs.size(), (const ChainOp *)odev, blocks, cs.lds_floats, (hipStream_t)stream);
+  if (e != hipSuccess) { set_error("chain launch: %s", hipGetErrorString(e)); (void)hipFree(dev); return FDQL_EHIP; }
+  FDQL_HIP(hipStreamSynchronize((hipStream_t)stream));
+  FDQL_HIP(hipFree(dev));
   return 0;
 }
 

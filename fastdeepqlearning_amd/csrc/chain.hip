@@ -1,0 +1,559 @@
+// Row-block chain kernel: several Linear layers per launch with the activations resident in LDS.
+//
+// Why (measured on MI355X, tools/proto/rowblock.hip, profiles/r02_*): the grouped GEMM of gemm.hip runs one layer per
+// launch and sends every activation through HBM/L2 between layers; at the update's sizes (12.5 k rows, K = N = 256) a
+// third of each launch is tile start-up, operand staging and the epilogue's round trip.  Here a 256-thread workgroup
+// (one wave per SIMD, one workgroup per CU) owns 64 rows of the batch and interprets a short program of operations
+// (chain.h) on them:
+//   CH_LOAD    global rows (the K-segments of a torch.cat) -> an LDS image [64][pitch]
+//   CH_GEMM    acc[64 x N<=256] (+)= sum over K-segments of image x W^T; wave w owns columns [64w, 64w+64) as 2x2 MFMA
+//              tiles (v_mfma_f32_32x32x2_f32); epilogue: bias, LeakyReLU / LeakyReLU' mask, store to an LDS image (the
+//              next layer's input) and / or to global memory, per-block column sums (bias gradients)
+//   CH_NARROW  skip heads and other N <= 32 outputs: the K range is dealt round-robin to the four waves, partial
+//              32-column tiles are summed through LDS in wave order
+// The A operand is read from LDS by ds_read_b128 ((pitch / 4) odd: the 32 rows of a fragment hit distinct banks); the B
+// operand (weights) goes global -> registers directly as MFMA fragments: lane (li, lh) of a column tile holds, for a
+// 32-k group, the 16 k's 32g + 16 lh + 0..15 of ITS column - K-contiguous weights: 64 contiguous bytes per lane
+// (4 x dwordx4), K-strided weights (dgrad): column pairs (dwordx2) of 16 rows.  A and B pair the same k's in every MFMA
+// step, so the fp32 sum runs over a fixed permutation of k (bitwise a k-ordered fma chain, like gemm.hip).  No LDS
+// staging of B, no barrier inside a K loop; the next group's fragments are requested before the current group's 64 MFMAs.
+#include "chain.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+namespace fdql {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) float *gcf;
+typedef __attribute__((address_space(1))) float *gf;
+typedef const __attribute__((address_space(1))) v4f *gcf4;
+typedef const __attribute__((address_space(1))) v2f *gcf2;
+
+static_assert(CH_LDS_FLOATS * 4 + CH_MAX_OPS * sizeof(ChainOp) + 256 <= 163840, "LDS budget of the chain kernel");
+
+__device__ __forceinline__ unsigned ch_lds_addr(const float *p) {
+  return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)p;
+}
+// early-clobber destination: a fragment can never be allocated on top of its own address register (gemm.hip, finding 2)
+__device__ __forceinline__ void ch_rd128(v4f &d, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=&v"(d) : "v"(addr)); }
+template <int N>
+__device__ __forceinline__ void ch_lgkm_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ int ch_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ const float *ch_uni(const float *p) {
+  const uintptr_t u = reinterpret_cast<uintptr_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+  return reinterpret_cast<const float *>(((uintptr_t)hi << 32) | lo);
+}
+
+// Diagnostic stamps (FDQL_CHAIN_STAMPS=1 -> chain_read_stamps): the workgroup in the middle of a launch records
+// s_memtime at its entry, after the program fetch and after every operation.
+__device__ unsigned long long g_ch_stamps[2 * CH_MAX_OPS + 4];
+__device__ int g_ch_stamps_on = 0;
+
+// MINB = workgroups per CU the register budget is cut for (1: 512 registers per lane; 2: 256 - two workgroups per CU
+// overlap each other's load / epilogue phases when the program's LDS allows)
+template <int MINB>
+__global__ __launch_bounds__(CH_THREADS, MINB) void k_chain(const ChainProblem *__restrict__ probs, int nprob,
+                                                             const ChainOp *__restrict__ ops_all) {
+  __shared__ ChainOp s_ops[CH_MAX_OPS];
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = ch_uni(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int bid = blockIdx.x;
+  // which program, which rows: ONE load round - lane i reads problem i's header, ballot, the owning lane's fields are
+  // broadcast (every dependent global access before the first MFMA is a memory round trip this workgroup sits out)
+  const bool stamp = g_ch_stamps_on && bid == (int)(gridDim.x / 2) && tid == 0;
+  int nstamp = 0;
+  if (stamp) g_ch_stamps[nstamp++] = __builtin_amdgcn_s_memtime();
+  int rows = 0, blk = 0, op_start = 0, nops = 0;
+  for (int base = 0; base < nprob; base += 64) {
+    const int i = base + lane;
+    int bs = 0x7fffffff, rw = 0, os = 0, no = 0;
+    if (i < nprob) {
+      const __attribute__((address_space(1))) ChainProblem *pp = (const __attribute__((address_space(1))) ChainProblem *)probs + i;
+      bs = pp->block_start; rw = pp->rows; os = pp->op_start; no = pp->nops;
+    }
+    const unsigned long long m = __ballot(bid >= bs);
+    if (m) {
+      const int src = 63 - __builtin_clzll(m);
+      rows = __builtin_amdgcn_readlane(rw, src);
+      op_start = __builtin_amdgcn_readlane(os, src);
+      nops = __builtin_amdgcn_readlane(no, src);
+      blk = bid - __builtin_amdgcn_readlane(bs, src);
+    }
+  }
+  const int r0 = blk * CH_BM;
+  {   // the program -> LDS in one coalesced round (fields are then read from LDS, not through L2)
+    const int *src = reinterpret_cast<const int *>(ops_all + op_start);
+    int *dst = reinterpret_cast<int *>(s_ops);
+    constexpr int WORDS = (int)(sizeof(ChainOp) / 4);
+    const int total = min(nops, CH_MAX_OPS) * WORDS;
+    for (int e = tid; e < total; e += CH_THREADS) dst[e] = ((const __attribute__((address_space(1))) int *)src)[e];
+    __syncthreads();
+  }
+  const unsigned lds0 = ch_lds_addr(lds);
+  if (stamp) g_ch_stamps[nstamp++] = __builtin_amdgcn_s_memtime();
+
+  f32x16 acc[2][2];   // [tm][tn]: rows 32 tm + ..., columns of column tile tn
+  v4f hacc[2];        // CH_NARROW accumulators: this wave's 16 rows x 16 columns per tile (v_mfma_f32_16x16x4_f32)
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[a][0][r] = 0.f; acc[a][1][r] = 0.f; }
+    hacc[a] = v4f{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // ---------------------------------------------------------------- 32-k group of MFMAs: A from LDS, B in registers
+  // a0 / a1: byte addresses of this lane's row in row tile 0 / 1 at the group's first k (+ 16 lh floats)
+  auto mfma_group_kc = [&](unsigned a0, unsigned a1, const v4f (&b)[2][4]) __attribute__((always_inline)) {
+    v4f a[2][2];   // [parity of j][tm]
+    ch_rd128(a[0][0], a0);
+    ch_rd128(a[0][1], a1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < 3) {
+        ch_rd128(a[(j + 1) & 1][0], a0 + 16 * (j + 1));
+        ch_rd128(a[(j + 1) & 1][1], a1 + 16 * (j + 1));
+        ch_lgkm_wait<2>();
+      } else {
+        ch_lgkm_wait<0>();
+      }
+      asm volatile("" : "+v"(a[j & 1][0]), "+v"(a[j & 1][1]));
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j & 1][tm][c], b[tn][j][c], acc[tm][tn], 0, 0, 0);
+    }
+    asm volatile("" ::"v"(a0), "v"(a1));
+  };
+  auto mfma_group_ks = [&](unsigned a0, unsigned a1, const v2f (&b)[4][4]) __attribute__((always_inline)) {
+    v4f a[2][2];
+    ch_rd128(a[0][0], a0);
+    ch_rd128(a[0][1], a1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < 3) {
+        ch_rd128(a[(j + 1) & 1][0], a0 + 16 * (j + 1));
+        ch_rd128(a[(j + 1) & 1][1], a1 + 16 * (j + 1));
+        ch_lgkm_wait<2>();
+      } else {
+        ch_lgkm_wait<0>();
+      }
+      asm volatile("" : "+v"(a[j & 1][0]), "+v"(a[j & 1][1]));
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j & 1][tm][c], b[j][c][tn], acc[tm][tn], 0, 0, 0);
+    }
+    asm volatile("" ::"v"(a0), "v"(a1));
+  };
+  // 8-k tail group: lanes lh = 0 / 1 hold k = kb + 0..3 / kb + 4..7 (component c -> MFMA step c)
+  auto mfma_tail = [&](unsigned a0, unsigned a1, const v4f &b0, const v4f &b1) __attribute__((always_inline)) {
+    v4f a[2];
+    ch_rd128(a[0], a0);
+    ch_rd128(a[1], a1);
+    ch_lgkm_wait<0>();
+    asm volatile("" : "+v"(a[0]), "+v"(a[1]));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][c], b0[c], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][c], b1[c], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][c], b0[c], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][c], b1[c], acc[1][1], 0, 0, 0);
+    }
+    asm volatile("" ::"v"(a0), "v"(a1));
+  };
+
+  // ---------------------------------------------------------------- one K-segment of a GEMM, K-contiguous weights
+  auto gemm_seg_kc = [&](const ChainSeg &S, int N, int n0) __attribute__((always_inline)) {
+    const float *W = ch_uni(S.W);
+    const int ldw = ch_uni(S.ldw), K = ch_uni(S.K), pitch = ch_uni(S.pitch), slot = ch_uni(S.slot);
+    const int na = min(n0 + li, N - 1), nb = min(n0 + 32 + li, N - 1);   // clamped: rows beyond N repeat row N-1, never stored
+    gcf wpa = (gcf)(W + (long long)na * ldw + 16 * lh), wpb = (gcf)(W + (long long)nb * ldw + 16 * lh);
+    const unsigned a0 = lds0 + (unsigned)(slot + li * pitch + 16 * lh) * 4u, a1 = a0 + (unsigned)(32 * pitch) * 4u;
+    const int G = K >> 5, ntail = ((K & 31) + 7) >> 3;
+    // first tail group's fragments are requested before the full groups (their latency hides behind them)
+    v4f tb0 = {0.f, 0.f, 0.f, 0.f}, tb1 = {0.f, 0.f, 0.f, 0.f};
+    auto load_tail = [&](int t) __attribute__((always_inline)) {
+      const int kb = 32 * G + 8 * t + 4 * lh;     // this lane's 4 k's
+      gcf pa = (gcf)(W + (long long)na * ldw + kb), pb = (gcf)(W + (long long)nb * ldw + kb);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        tb0[c] = kb + c < K ? pa[c] : 0.f;
+        tb1[c] = kb + c < K ? pb[c] : 0.f;
+      }
+    };
+    if (ntail > 0) load_tail(0);
+    if (G > 0) {
+      v4f b[2][2][4];   // [buffer][tn][j]
+      auto load_b = [&](int buf, int g) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[buf][0][j] = *(gcf4)(wpa + 32 * g + 4 * j);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[buf][1][j] = *(gcf4)(wpb + 32 * g + 4 * j);
+      };
+      load_b(0, 0);
+      int g = 0;
+      for (; g + 2 <= G; g += 2) {   // branch-free pairs: the last pair re-requests group G-1 (harmless)
+        load_b(1, g + 1);
+        mfma_group_kc(a0 + 128u * g, a1 + 128u * g, b[0]);
+        load_b(0, min(g + 2, G - 1));
+        mfma_group_kc(a0 + 128u * (g + 1), a1 + 128u * (g + 1), b[1]);
+      }
+      if (g < G) mfma_group_kc(a0 + 128u * g, a1 + 128u * g, b[0]);
+    }
+    for (int t = 0; t < ntail; ++t) {
+      if (t > 0) load_tail(t);
+      // tail A fragment: k = 32 G + 8 t + 4 lh + c: the lane-half offset inside a tail group is 4 floats, not 16
+      const unsigned off = (unsigned)(32 * G + 8 * t) * 4u - (unsigned)(12 * lh) * 4u;
+      mfma_tail(a0 + off, a1 + off, tb0, tb1);
+    }
+  };
+  // ---------------------------------------------------------------- K-strided weights (dgrad): columns n0 + 2 li + tn
+  auto gemm_seg_ks = [&](const ChainSeg &S, int N, int n0) __attribute__((always_inline)) {
+    const float *W = ch_uni(S.W);
+    const int ldw = ch_uni(S.ldw), K = ch_uni(S.K), pitch = ch_uni(S.pitch), slot = ch_uni(S.slot);
+    const int nc = max(0, min(n0 + 2 * li, N - 2));   // column pair this lane reads (clamped; never stored when shifted)
+    gcf wp = (gcf)(W + nc + (long long)(16 * lh) * ldw);
+    const unsigned a0 = lds0 + (unsigned)(slot + li * pitch + 16 * lh) * 4u, a1 = a0 + (unsigned)(32 * pitch) * 4u;
+    const int G = K >> 5, ntail = ((K & 31) + 7) >> 3;
+    if (G > 0) {
+      v2f b[2][4][4];   // [buffer][j][c]
+      auto load_b = [&](int buf, int g) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) b[buf][j][c] = *(gcf2)(wp + (long long)(32 * g + 4 * j + c) * ldw);
+      };
+      load_b(0, 0);
+      int g = 0;
+      for (; g + 2 <= G; g += 2) {
+        load_b(1, g + 1);
+        mfma_group_ks(a0 + 128u * g, a1 + 128u * g, b[0]);
+        load_b(0, min(g + 2, G - 1));
+        mfma_group_ks(a0 + 128u * (g + 1), a1 + 128u * (g + 1), b[1]);
+      }
+      if (g < G) mfma_group_ks(a0 + 128u * g, a1 + 128u * g, b[0]);
+    }
+    for (int t = 0; t < ntail; ++t) {
+      const int kb = 32 * G + 8 * t + 4 * lh;
+      v4f tb0, tb1;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        v2f x = {0.f, 0.f};
+        if (kb + c < K) x = *(gcf2)((gcf)(W + nc) + (long long)(kb + c) * ldw);
+        tb0[c] = x.x;
+        tb1[c] = x.y;
+      }
+      const unsigned off = (unsigned)(32 * G + 8 * t) * 4u - (unsigned)(12 * lh) * 4u;
+      mfma_tail(a0 + off, a1 + off, tb0, tb1);
+    }
+  };
+
+  // ---------------------------------------------------------------- epilogue of a GEMM
+  auto epilogue = [&](const ChainOp &op) __attribute__((always_inline)) {
+    const int N = ch_uni(op.N), flags = ch_uni(op.flags), act = ch_uni(op.act);
+    const int out_slot = ch_uni(op.out_slot), out_pitch = ch_uni(op.out_pitch);
+    const int row_lo = ch_uni(op.row_lo), row_hi = ch_uni(op.row_hi), shift = ch_uni(op.row_shift);
+    const int ldo = ch_uni(op.ldo), ldref = ch_uni(op.ldref);
+    gcf bias = (gcf)ch_uni(op.bias);
+    gf out = (gf)ch_uni(op.out);
+    gcf ref = (gcf)ch_uni(op.ref);
+    gf colsum = (gf)ch_uni(op.colsum);
+    const bool ks = (flags & CHF_KS) != 0;
+    const int n0 = wave * 64;
+    // global stores: one dword per lane and accumulator register is store-issue bound (64 of them per lane and layer);
+    // when the tile also goes to an LDS image, memory is written FROM the image instead, 16 bytes per lane
+    const bool wide = out && out_slot >= 0 && ((N | ldo) & 3) == 0 && (reinterpret_cast<uintptr_t>(op.out) & 15) == 0;
+    if (out_slot >= 0) __syncthreads();   // every wave has finished reading the images this op may overwrite
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int col = ks ? n0 + 2 * li + tn : n0 + 32 * tn + li;
+      const bool cok = col < N;
+      const float bv = (bias && cok) ? bias[col] : 0.f;
+      float csum = 0.f;
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) {
+        float rv[16];
+        if (act == CHA_LRELU_GRAD) {   // reference values first, then the stores (gemm.hip: loads behind stores would wait)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int grow = r0 + 32 * tm + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            rv[r] = (cok && grow >= row_lo && grow < row_hi) ? ref[(long long)(grow - shift) * ldref + col] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rl = 32 * tm + (r & 3) + 8 * (r >> 2) + 4 * lh, grow = r0 + rl;
+          float x = acc[tm][tn][r] + bv;
+          if (act == CHA_LRELU) x = x > 0.f ? x : 0.01f * x;
+          else if (act == CHA_LRELU_GRAD) x = rv[r] > 0.f ? x : 0.01f * x;
+          const bool rok = grow >= row_lo && grow < row_hi;
+          if (out_slot >= 0 && cok) lds[out_slot + rl * out_pitch + col] = x;
+          if (out && !wide && cok && rok) out[(long long)(grow - shift) * ldo + col] = x;
+          if (rok) csum += x;
+        }
+      }
+      if (colsum) {   // fixed order: the 32 rows of lane half 0, then those of lane half 1
+        const float other = __shfl_xor(csum, 32);
+        if (lh == 0 && cok) colsum[(long long)blk * N + col] = csum + other;
+      }
+    }
+    if (out_slot >= 0) {
+      // columns [N, next multiple of 8) of the image stay zero: the next layer's last k-group reads them
+      const int npad = ((N + 7) & ~7) - N;
+      for (int e = tid; e < CH_BM * npad; e += CH_THREADS) {
+        const int r = e / npad, c = e - r * npad;
+        lds[out_slot + r * out_pitch + N + c] = 0.f;
+      }
+      __syncthreads();
+      if (wide) {
+        const int nq = N >> 2, total = CH_BM * nq;
+        for (int base = 0; base < total; base += 8 * CH_THREADS) {
+          v4f v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int e = min(base + tid + u * CH_THREADS, total - 1);
+            const int r = e / nq, c = (e - r * nq) * 4;
+            v[u] = *reinterpret_cast<const v4f *>(&lds[out_slot + r * out_pitch + c]);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int e = base + tid + u * CH_THREADS;
+            const int r = e / nq, c = (e - r * nq) * 4, grow = r0 + r;
+            if (e < total && grow >= row_lo && grow < row_hi)
+              *reinterpret_cast<__attribute__((address_space(1))) v4f *>(out + (long long)(grow - shift) * ldo + c) = v[u];
+          }
+        }
+      }
+    }
+  };
+
+  // ---------------------------------------------------------------- the program
+  for (int ip = 0; ip < CH_MAX_OPS; ++ip) {
+    const ChainOp &op = s_ops[ip];
+    const int kind = ch_uni(op.kind);
+    if (kind == CH_END) break;
+    if (kind == CH_LOAD) {
+      const int slot = ch_uni(op.slot), pitch = ch_uni(op.pitch), kpad = ch_uni(op.kpad), nseg = ch_uni(op.nseg);
+      __syncthreads();   // readers of the image being replaced are done
+      int ktot = 0;
+      for (int s = 0; s < nseg; ++s) {
+        gcf src = (gcf)ch_uni(op.ld[s].src);
+        const int ld = ch_uni(op.ld[s].ld), width = ch_uni(op.ld[s].width), col = ch_uni(op.ld[s].col);
+        const bool vec = ((width | ld | col) & 3) == 0 && (reinterpret_cast<uintptr_t>(op.ld[s].src) & 15) == 0;
+        // eight loads in flight per thread, then the eight LDS stores (a load -> store loop would expose one memory
+        // round trip per iteration: 16 of them for a 256-wide block)
+        if (vec) {
+          const int wq = width >> 2, total = CH_BM * wq;
+          for (int base = 0; base < total; base += 16 * CH_THREADS) {
+            v4f v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+              const int e = base + tid + u * CH_THREADS;
+              const int r = e / wq, c = (e - r * wq) * 4;
+              const int grow = min(r0 + min(r, CH_BM - 1), rows - 1);   // rows beyond the batch repeat its last row (never stored)
+              v[u] = *(gcf4)(src + (long long)grow * ld + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+              const int e = base + tid + u * CH_THREADS;
+              const int r = e / wq, c = (e - r * wq) * 4;
+              if (e < total) *reinterpret_cast<v4f *>(&lds[slot + r * pitch + col + c]) = v[u];
+            }
+          }
+        } else {
+          const int total = CH_BM * width;
+          for (int base = 0; base < total; base += 8 * CH_THREADS) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int e = base + tid + u * CH_THREADS;
+              const int r = e / width, c = e - r * width;
+              const int grow = min(r0 + min(r, CH_BM - 1), rows - 1);
+              v[u] = src[(long long)grow * ld + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int e = base + tid + u * CH_THREADS;
+              const int r = e / width, c = e - r * width;
+              if (e < total) lds[slot + r * pitch + col + c] = v[u];
+            }
+          }
+        }
+        ktot = max(ktot, col + width);
+      }
+      const int npad = kpad - ktot;
+      for (int e = tid; e < CH_BM * npad; e += CH_THREADS) {
+        const int r = e / npad, c = e - r * npad;
+        lds[slot + r * pitch + ktot + c] = 0.f;
+      }
+      __syncthreads();
+    } else if (kind == CH_GEMM) {
+      const int N = ch_uni(op.N), flags = ch_uni(op.flags), nseg = ch_uni(op.nseg);
+      const int n0 = wave * 64;
+      if (flags & CHF_ZERO) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { acc[a][0][r] = 0.f; acc[a][1][r] = 0.f; }
+      }
+      if (n0 < N) {   // wave-uniform: a wave whose 64 columns lie beyond N has no tile
+        if (flags & CHF_KS) {
+          for (int s = 0; s < nseg; ++s) gemm_seg_ks(op.seg[s], N, n0);
+        } else {
+          for (int s = 0; s < nseg; ++s) gemm_seg_kc(op.seg[s], N, n0);
+        }
+      }
+      if (stamp) g_ch_stamps[nstamp++] = __builtin_amdgcn_s_memtime();
+      if (flags & CHF_EMIT) epilogue(op);
+    } else if (kind == CH_NARROW) {
+      // Narrow outputs (skip heads, N <= 32): every wave computes the COMPLETE K sum for its own 16 rows with
+      // v_mfma_f32_16x16x4_f32 - lane (i = l & 15, kq = l >> 4) holds A[row 16 w + i][16 h + 4 kq + c] and
+      // B[..][col l & 15] for MFMA step c of 16-k half group h - so there is no cross-wave reduction, no scratch and
+      // no barrier, and the accumulators are 4 registers per 16 columns.
+      const int N = ch_uni(op.N), flags = ch_uni(op.flags), nseg = ch_uni(op.nseg);
+      const bool ks = (flags & CHF_KS) != 0;
+      const int lj = lane & 15, kq = lane >> 4;
+      if (flags & CHF_BEGIN) { hacc[0] = v4f{0.f, 0.f, 0.f, 0.f}; hacc[1] = v4f{0.f, 0.f, 0.f, 0.f}; }
+      const int n0c = min(lj, N - 1), n1c = min(16 + lj, N - 1);   // clamped columns (never stored when shifted)
+      const bool two = N > 16;
+      const int wslot = ch_uni(op.slot);   // staging area for the head weights of one segment: [N][wp]
+      for (int s = 0; s < nseg; ++s) {
+        gcf W = (gcf)ch_uni(op.seg[s].W);
+        const int ldw = ch_uni(op.seg[s].ldw), K = ch_uni(op.seg[s].K), pitch = ch_uni(op.seg[s].pitch), slot = ch_uni(op.seg[s].slot);
+        const int k16 = (K + 15) & ~15, wp = k16 + 4;   // (wp / 4) odd: the 16 rows of a B fragment hit distinct banks
+        // The segment's weight slice -> LDS (one coalesced round, shared by the four waves): read straight from global
+        // memory the fragments of a 16-k step would need a memory round trip per 128 cycles of MFMA.
+        __syncthreads();
+        {
+          const int total = N * k16;
+          for (int base = 0; base < total; base += 8 * CH_THREADS) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int e = base + tid + u * CH_THREADS;
+              int n, k;
+              if (!ks) { n = e / k16; k = e - n * k16; } else { k = e / N; n = e - k * N; }
+              v[u] = (e < total && k < K) ? (ks ? W[(long long)k * ldw + n] : W[(long long)n * ldw + k]) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int e = base + tid + u * CH_THREADS;
+              int n, k;
+              if (!ks) { n = e / k16; k = e - n * k16; } else { k = e / N; n = e - k * N; }
+              if (e < total) lds[wslot + n * wp + k] = v[u];
+            }
+          }
+        }
+        __syncthreads();
+        const unsigned a0 = lds0 + (unsigned)(slot + (16 * wave + lj) * pitch + 4 * kq) * 4u;
+        const unsigned w0 = lds0 + (unsigned)(wslot + n0c * wp + 4 * kq) * 4u, w1 = lds0 + (unsigned)(wslot + n1c * wp + 4 * kq) * 4u;
+        const int nh = k16 >> 4;
+        v4f a, b0, b1 = {0.f, 0.f, 0.f, 0.f};
+        ch_rd128(a, a0);
+        ch_rd128(b0, w0);
+        if (two) ch_rd128(b1, w1);
+        for (int h = 0; h < nh; ++h) {
+          const int hn = min(h + 1, nh - 1);
+          v4f na, nb0, nb1 = b1;
+          ch_lgkm_wait<0>();
+          asm volatile("" : "+v"(a), "+v"(b0), "+v"(b1));
+          ch_rd128(na, a0 + (unsigned)hn * 64u);     // next half group's fragments fly under this one's MFMAs
+          ch_rd128(nb0, w0 + (unsigned)hn * 64u);
+          if (two) ch_rd128(nb1, w1 + (unsigned)hn * 64u);
+          if (16 * h + 16 > K) {   // last, partial half group: image columns beyond K's 8-padding are not defined
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[c] = 16 * h + 4 * kq + c < K ? a[c] : 0.f;
+          }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            hacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], b0[c], hacc[0], 0, 0, 0);
+            if (two) hacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], b1[c], hacc[1], 0, 0, 0);
+          }
+          a = na; b0 = nb0; b1 = nb1;
+        }
+        ch_lgkm_wait<0>();
+        asm volatile("" ::"v"(a0), "v"(w0), "v"(w1));
+      }
+      if (flags & CHF_FINISH) {   // D: column l & 15, rows 4 (l >> 4) + reg of the wave's 16
+        const int row_lo = ch_uni(op.row_lo), row_hi = ch_uni(op.row_hi), shift = ch_uni(op.row_shift), ldo = ch_uni(op.ldo);
+        gcf bias = (gcf)ch_uni(op.bias);
+        gf out = (gf)ch_uni(op.out);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int col = 16 * t + lj;
+          if (col < N) {
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int grow = r0 + 16 * wave + 4 * kq + r;
+              if (grow >= row_lo && grow < row_hi) out[(long long)(grow - shift) * ldo + col] = hacc[t][r] + bv;
+            }
+          }
+        }
+      }
+    }
+    if (stamp) g_ch_stamps[nstamp++] = __builtin_amdgcn_s_memtime();
+  }
+  if (stamp) g_ch_stamps[2 * CH_MAX_OPS + 3] = nstamp;
+}
+
+int chain_read_stamps(unsigned long long *out, int cap) {
+  unsigned long long h[2 * CH_MAX_OPS + 4];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ch_stamps), sizeof(h)) != hipSuccess) return -1;
+  const int n = (int)h[2 * CH_MAX_OPS + 3];
+  for (int i = 0; i < n && i < cap; ++i) out[i] = h[i];
+  return n < cap ? n : cap;
+}
+void chain_enable_stamps(int on) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ch_stamps_on), &on, sizeof(on)); }
+
+int chain_finalize(ChainProblem *probs, int nprob) {
+  int total = 0;
+  for (int i = 0; i < nprob; ++i) {
+    probs[i].block_start = total;
+    total += (probs[i].rows + CH_BM - 1) / CH_BM;
+  }
+  return total;
+}
+
+hipError_t chain_launch(const ChainProblem *probs_dev, int nprob, const ChainOp *ops_dev, int total_blocks, int lds_floats,
+                        hipStream_t stream) {
+  if (total_blocks <= 0) return hipSuccess;
+  static bool attr_set = false;
+  static int minb_pref = 1;
+  if (!attr_set) {   // dynamic LDS beyond 64 KiB has to be allowed once per process
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       CH_LDS_FLOATS * 4);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<2>), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_FLOATS * 4);
+    if (e != hipSuccess) return e;
+    if (const char *v = getenv("FDQL_CHAIN_MINB")) minb_pref = atoi(v) == 2 ? 2 : 1;   // tuning hook
+    if (getenv("FDQL_CHAIN_STAMPS")) chain_enable_stamps(1);
+    attr_set = true;
+  }
+  const size_t lds_bytes = (size_t)lds_floats * 4;
+  const bool two = minb_pref == 2 && lds_bytes + CH_MAX_OPS * sizeof(ChainOp) + 512 <= 81920;
+  if (two) hipLaunchKernelGGL(k_chain<2>, dim3(total_blocks), dim3(CH_THREADS), lds_bytes, stream, probs_dev, nprob, ops_dev);
+  else hipLaunchKernelGGL(k_chain<1>, dim3(total_blocks), dim3(CH_THREADS), lds_bytes, stream, probs_dev, nprob, ops_dev);
+  return hipGetLastError();
+}
+
+double chain_op_flops(const ChainOp &op, int rows) {
+  if (op.kind != CH_GEMM && op.kind != CH_NARROW) return 0.0;
+  double k = 0;
+  for (int s = 0; s < op.nseg; ++s) k += op.seg[s].K;
+  return 2.0 * rows * (double)op.N * k;
+}
+
+}  // namespace fdql
