@@ -1,23 +1,30 @@
 #!/usr/bin/env python3
 """Headline benchmark: gradient-steps/sec of the SAC/TQC hot path (BASELINE.json).
 
-One "step" = one full train_step of the reference (franQ/Agent/deepQlearning.py:105-127) on
-one shard: windowed minibatch sample from the 1M-transition HBM ring + TQC loss + backward +
-Adam + polyak.  Workload at every N: BASELINE config 2 — obs 17, act 6, TQC 5 critics x 2
-quantiles, MLPs of 256, ring 1,000,000, batch B=256 windows PER GPU of temporal_len T=50
-(the reference default, conf.py:38), synthetic data resident in HBM, random-init weights.
-N>1: one process per GPU (torchrun), each rank its own ring shard and B windows, gradient
-arena all-reduced with RCCL, identical Adam on every rank ("weak" scaling: global batch = N*B).
+One "step" = one full train_step of the reference (franQ/Agent/deepQlearning.py:105-127) on one shard: windowed
+minibatch sample from the HBM ring + loss + backward + Adam + polyak.  Synthetic data resident in HBM, random-init
+weights; nothing here reads /root/reference.
+
+N = 1 (the driver's BENCH line): BASELINE config 2 - obs 17, act 6, TQC 5 critics x 2 quantiles, MLPs of 256, ring
+  1,000,000, B = 256 windows of temporal_len T = 50 (the reference default, conf.py:38).  `value` = steps/s over
+  exactly --steps steps; extra keys: `sustained` (>= 2 s of back-to-back steps), `roofline` (dominant kernel, HIP
+  events on the launch stream), `cpu_baseline` (the CPU oracle timed on this host), `sampler_roofline`,
+  `other_configs` (configs 3, 4 at B=1024 on one GPU, 5), `facade_path` (the franQ-shaped objects end to end).
+N > 1 (launched by torch.distributed.run, one process per GPU): BASELINE config 4 - obs 376, act 17,
+  TQC 5 x 25 quantiles, GLOBAL batch B = 1024 windows split B/N per GPU, a 2M-slot ring shard per rank; each rank
+  runs FDQL_PHASE_GRAD on its windows, the 5.27 MB gradient arena is summed by ONE RCCL all-reduce (the row weights
+  already carry 1/(B_global), so the sum is the global-batch gradient), then FDQL_PHASE_APPLY: identical Adam on every
+  rank.  `value` = GLOBAL optimiser steps/s (one step of the whole job, not multiplied by N): "scaling": "strong".
+  The line also carries `same_workload_1gpu` (rank 0 running the whole B = 1024 batch alone, measured in the same
+  process before the distributed phase) so that speed-up is computable from the line itself.
 
     python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
-
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the
-dominant kernel (the grouped fp32-MFMA GEMM, timed with HIP events on the launch stream)
-and `cpu_baseline` (the CPU oracle = port of the reference path, timed on this host).
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import re
@@ -30,22 +37,50 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-OBS, ACT, C, Q, HID = 17, 6, 5, 2, 256
-RING = 1_000_000
-KEYS = ["obs_1d", "action", "reward", "mc_return", "task_done", "episode_done", "episode_step", "idx"]
-DIMS = [OBS, ACT, 1, 1, 1, 1, 1, 1]          # 29 f32 = 116 B per transition
-MFMA_F32_PEAK_TFLOPS = 157.3                   # MI355X_MICROARCH.md: dense fp32 matrix peak
+HID = 256
+MFMA_F32_PEAK_TFLOPS = 157.3                   # MI355X_MICROARCH.md: dense fp32 matrix peak (2.4 GHz)
 HBM_PEAK_GBS = 8000.0
 
+# name -> workload.  dims/keys: ring layout; rowbytes follow from it.
+WORKLOADS = {
+    "config2": dict(obs=17, act=6, goal=0, C=5, Q=2, ring=1_000_000, B=256, T=50, ep_len=1000,
+                    text="BASELINE config 2: TQC 5x2 quantile critics, obs=17 act=6, MLP(256), 1M-transition HBM ring"),
+    "config3": dict(obs=28, act=6, goal=10, C=5, Q=2, ring=1_000_000, B=256, T=50, ep_len=50,
+                    text="BASELINE config 3: config 2 + goal-conditioned rows (obs 28, achieved/desired goal 10), HER-relabelled "
+                         "episodes of 50 in a 1M ring"),
+    "config4": dict(obs=376, act=17, goal=0, C=5, Q=25, ring=2_000_000, B=1024, T=50, ep_len=1000,
+                    text="BASELINE config 4: TQC 5x25 quantile critics, obs=376 act=17 (Humanoid dims), MLP(256), 2M-slot ring"),
+}
 
-def synth_rows(n, seed, device, ep_len=1000, gamma=0.99):
-    """Synthetic transitions: obs~N(0,1), action~U(-1,1), reward~N(0,1),
-    episodes of 1000 steps, task_done~Bernoulli(1e-3), mc_return = discounted reward-to-go."""
+
+def csrc_hash():
+    """sha256 over the HIP sources: profiles collected on another revision are not quoted as this one's."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "fastdeepqlearning_amd", "csrc", "*.h*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def layout(w):
+    keys = ["obs_1d"] + (["achieved_goal", "desired_goal"] if w["goal"] else []) + \
+           ["action", "reward", "mc_return", "task_done", "episode_done", "episode_step", "idx"]
+    dims = [w["obs"]] + ([w["goal"], w["goal"]] if w["goal"] else []) + [w["act"], 1, 1, 1, 1, 1, 1]
+    return keys, dims
+
+
+def synth_rows(w, n, seed, device, gamma=0.99):
+    """Synthetic transitions: obs~N(0,1), goals~U(-1,1), action~U(-1,1), reward~N(0,1), fixed-length episodes,
+    task_done~Bernoulli(1e-3), mc_return = discounted reward-to-go (what NStepReturn attaches at write time)."""
     g = torch.Generator(device=device).manual_seed(seed)
+    ep_len = w["ep_len"]
     n_ep = (n + ep_len - 1) // ep_len
     tot = n_ep * ep_len
-    obs = torch.randn(tot, OBS, generator=g, device=device)
-    act = torch.rand(tot, ACT, generator=g, device=device) * 2 - 1
+    cols = [torch.randn(tot, w["obs"], generator=g, device=device)]
+    if w["goal"]:
+        cols.append(torch.rand(tot, w["goal"], generator=g, device=device) * 2 - 1)
+        cols.append((torch.rand(n_ep, 1, w["goal"], generator=g, device=device) * 2 - 1).expand(n_ep, ep_len, w["goal"]).reshape(tot, -1))
+    cols.append(torch.rand(tot, w["act"], generator=g, device=device) * 2 - 1)
     rew = torch.randn(n_ep, ep_len, generator=g, device=device)
     ret = torch.empty_like(rew)
     acc = torch.zeros(n_ep, device=device)
@@ -54,26 +89,140 @@ def synth_rows(n, seed, device, ep_len=1000, gamma=0.99):
         ret[:, t] = acc
     td = (torch.rand(tot, 1, generator=g, device=device) < 1e-3).float()
     step = torch.arange(ep_len, device=device, dtype=torch.float32).repeat(n_ep).view(-1, 1)
-    edone = (step == ep_len - 1).float()
-    idx = torch.zeros(tot, 1, device=device)
-    rows = torch.cat([obs, act, rew.reshape(-1, 1), ret.reshape(-1, 1), td, edone, step, idx], dim=1)
-    return rows[:n].contiguous()
+    cols += [rew.reshape(-1, 1), ret.reshape(-1, 1), td, (step == ep_len - 1).float(), step, torch.zeros(tot, 1, device=device)]
+    return torch.cat(cols, dim=1)[:n].contiguous()
 
 
-def cpu_baseline(T, B, seconds_budget=25.0):
-    """The CPU oracle (oracle/: numpy ring + eager-torch update, a port of the reference path)
-    timed on this host: sample + update, steady state, bounded sample of the same workload."""
+class Job:
+    """Ring + agent + persistent sample buffers of one workload on one device."""
+
+    def __init__(self, w, dev, B, T, world=1, rank=0, ring_slots=None, fill_chunk=250_000):
+        from fastdeepqlearning_amd.core import NativeAgent, NativeRing, make_config
+        self.w, self.dev, self.B, self.T = w, dev, B, T
+        self.keys, self.dims = layout(w)
+        slots = ring_slots or w["ring"]
+        self.ring = NativeRing(slots, self.dims, dev)
+        for c0 in range(0, slots + 1000, fill_chunk):          # wraps once: len = slots - 1 (quirk q1)
+            n = min(fill_chunk, slots + 1000 - c0)
+            self.ring.add_rows(synth_rows(w, n, 1000 * rank + c0 // fill_chunk, dev))
+        assert len(self.ring) == slots - 1
+        cfg = make_config(w["obs"], w["act"], T, B, goal_dim=w["goal"], n_critics=w["C"], n_quantiles=w["Q"], latent=HID,
+                          enc_features=HID, enc_hidden=(HID,), joint_hidden=(HID,), pi_hidden=(HID,), critic_hidden=(HID, HID),
+                          world_size=world, keep_frozen_copy=True)
+        self.agent = NativeAgent(cfg, dev)
+        self.agent.init_weights(seed=0)                        # same weights on every rank
+        self.outs = [torch.empty(T, B, d, device=dev) for d in self.dims]
+        self.xp = dict(zip(self.keys, self.outs))
+        self.seed = 1234 + rank
+        self.rowbytes = 4 * sum(self.dims)
+
+    def step(self, i):
+        self.ring.sample_windows(self.T, self.B, seed=self.seed, counter=i, outs=self.outs)
+        self.agent.update(self.xp, seed=self.seed)
+
+    def timed(self, steps, warmup, first=0):
+        for i in range(warmup):
+            self.step(first + i)
+        torch.cuda.synchronize(self.dev)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            self.step(first + warmup + i)
+        torch.cuda.synchronize(self.dev)
+        return time.perf_counter() - t0
+
+    def kernel_profile(self, reps=3):
+        """name -> (ms, flops, bytes, launches) per step, HIP events on the launch stream."""
+        acc = {}
+        for _ in range(reps):
+            for name, ms, fl, by in self.agent.profile_update(self.xp, seed=self.seed):
+                a = acc.setdefault(name, [0.0, fl, by, 0])
+                a[0] += ms
+                a[3] += 1
+        return {k: (v[0] / reps, v[1], v[2], v[3] // reps) for k, v in acc.items()}
+
+
+def dominant(prof):
+    """The kernel instantiation with the largest total time among the MFMA kernels (tile shapes of the grouped GEMM,
+    the row-block chain kernel): name, ms/step, flops/step, launches/step, and the all-MFMA-kernel totals."""
+    groups = {}
+    for k, v in prof.items():
+        if k.startswith("gemm") or k.startswith("chain"):
+            groups.setdefault(k.split(":")[0], []).append(v)
+    name, rows = max(groups.items(), key=lambda kv: sum(r[0] for r in kv[1]))
+    ms, fl, n = sum(r[0] for r in rows), sum(r[1] * r[3] for r in rows), sum(r[3] for r in rows)
+    all_ms = sum(r[0] for g in groups.values() for r in g)
+    all_fl = sum(r[1] * r[3] for g in groups.values() for r in g)
+    total_ms = sum(v[0] for v in prof.values())
+    return name, ms, fl, n, all_ms, all_fl, total_ms, sum(r[2] * r[3] for r in rows)
+
+
+def kernel_label(name):
+    if name.startswith("chain"):
+        return "k_chain (row-block MLP chain, fp32 v_mfma_f32_32x32x2_f32)"
+    return f"k_gemm_grouped<{name[4:]} tile> (fp32 v_mfma_f32_32x32x2_f32)"
+
+
+def roofline_of(job, committed_pmc=True):
+    prof = job.kernel_profile()
+    name, ms, fl, n, all_ms, all_fl, total_ms, by = dominant(prof)
+    tf = fl / max(ms * 1e-3, 1e-12) / 1e12
+    r = {"bound": "mfma", "kernel": kernel_label(name), "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+         "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+         "launches_per_step": int(n), "flops_per_launch": fl / max(n, 1), "avg_launch_ms": round(ms / max(n, 1), 4),
+         "share_of_step": round(ms / total_ms, 3),
+         "all_mfma_kernels": {"flops_per_step": all_fl, "ms_per_step": round(all_ms, 4),
+                              "achieved": round(all_fl / (all_ms * 1e-3) / 1e12, 2), "share_of_step": round(all_ms / total_ms, 3)}}
+    top = {k: round(v[0], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]}
+    if not committed_pmc:
+        return r, top
+    # PMC figures (HBM traffic, MFMA pipe utilisation, clock) cannot be measured from inside this process: they come from
+    # the committed rocprofv3 --pmc passes of the SAME workload, and only if those were collected on THIS csrc revision
+    tj = os.path.join(ROOT, "profiles", "r02_dominant_kernel_traffic.json")
+    if os.path.exists(tj):
+        tr = json.load(open(tj))
+        if tr.get("csrc_sha") == csrc_hash():
+            r["traffic"] = tr["hbm_bytes_per_launch"]
+            r["traffic_unit"] = "bytes/launch (L2<->fabric read+write, PMC FETCH_SIZE x2 + WRITE_SIZE)"
+            r["traffic_source"] = "profiles/r02_hbm_traffic_pmc.txt (" + tr["source"] + ")"
+            r["algorithmic_bytes_per_launch"] = by / max(n, 1)
+            for k in ("mfma_pipe_busy_frac", "shader_clock_ghz_under_load"):
+                if k in tr:
+                    r[k] = tr[k]
+        else:
+            r["stale_profile"] = True      # profiles/ were collected on another revision of csrc/: not quoted
+    return r, top
+
+
+def sampler_roofline(job, reps=50):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(job.dev)
+    e0.record()
+    for i in range(reps):
+        job.ring.sample_windows(job.T, job.B, seed=job.seed, counter=10_000 + i, outs=job.outs)
+    e1.record()
+    torch.cuda.synchronize(job.dev)
+    ms = e0.elapsed_time(e1) / reps
+    nbytes = 2.0 * job.T * job.B * job.rowbytes + 8 * job.B
+    return {"bound": "hbm", "kernel": "k_gather_windows (window starts drawn in-kernel)", "ms": round(ms, 4),
+            "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes": nbytes}
+
+
+def cpu_baseline(w, T, B, seconds_budget=25.0):
+    """The CPU oracle (oracle/: numpy ring + eager-torch update, a port of the reference path) timed on this host:
+    sample + update, steady state, bounded sample of the same workload."""
     from oracle import update as oup
     from oracle.replay import RingOracle, cast_like_loader
+    keys, dims = layout(w)
     threads = torch.get_num_threads()
-    spec = oup.Spec(obs=OBS, act=ACT, C=C, Q=Q, latent=HID, enc_features=HID, enc_hidden=(HID,), joint_hidden=(HID,),
-                    pi_hidden=(HID,), critic_hidden=(HID, HID), T=T, B=B)
+    spec = oup.Spec(obs=w["obs"], act=w["act"], C=w["C"], Q=w["Q"], latent=HID, enc_features=HID, enc_hidden=(HID,),
+                    joint_hidden=(HID,), pi_hidden=(HID,), critic_hidden=(HID, HID), T=T, B=B)
     st = oup.new_state(spec, oup.init_params(spec, seed=0))
-    ring = RingOracle(RING, B, T)
-    rows = synth_rows(200_000, 0, "cpu").numpy()          # a 200k-row slice of the ring is enough for timing
-    off = np.cumsum([0] + DIMS)
-    ring.memory = {k: np.zeros((RING, d), np.float32) for k, d in zip(KEYS, DIMS)}
-    for j, k in enumerate(KEYS):
+    ring = RingOracle(w["ring"], B, T)
+    rows = synth_rows(w, 200_000, 0, "cpu").numpy()          # a 200k-row slice of the ring is enough for timing
+    off = np.cumsum([0] + dims)
+    ring.memory = {k: np.zeros((w["ring"], d), np.float32) for k, d in zip(keys, dims)}
+    for j, k in enumerate(keys):
         ring.memory[k][:rows.shape[0]] = rows[:, off[j]:off[j + 1]]
     ring.top, ring.len = rows.shape[0], rows.shape[0]
     rng = np.random.RandomState(0)
@@ -85,7 +234,7 @@ def cpu_baseline(T, B, seconds_budget=25.0):
 
     def one():
         xp = sample_only()
-        nt, na = torch.randn(T - 1, B, ACT, generator=g), torch.randn(T - 1, B, ACT, generator=g)
+        nt, na = torch.randn(T - 1, B, w["act"], generator=g), torch.randn(T - 1, B, w["act"], generator=g)
         oup.train_step(st, spec, xp, nt, na)
 
     def timed(nthreads, budget):
@@ -118,28 +267,161 @@ def cpu_baseline(T, B, seconds_budget=25.0):
                       f"{el:.1f} s [{detail}]"}
 
 
+def secondary(name, dev, steps=12, warmup=3, **kw):
+    """steps/s of another BASELINE config on this one GPU + its dominant kernel's fraction (never `value`)."""
+    w = WORKLOADS[name]
+    job = Job(w, dev, kw.pop("B", w["B"]), kw.pop("T", w["T"]), **kw)
+    el = job.timed(steps, warmup)
+    r, _ = roofline_of(job, committed_pmc=False)
+    out = {"workload": w["text"] + f", B={job.B} x T={job.T}", "value": round(steps / el, 2), "unit": "steps/s",
+           "ms_per_step": round(1e3 * el / steps, 4), "steps": steps,
+           "dominant_kernel": r["kernel"], "dominant_kernel_tflops": r["achieved"], "dominant_kernel_frac": r["frac"],
+           "all_mfma_kernels_tflops": r["all_mfma_kernels"]["achieved"],
+           "sampler_gbs": sampler_roofline(job, 20)["achieved"]}
+    del job
+    torch.cuda.empty_cache()
+    return out
+
+
+def config3_her_ingest(dev, episodes=400):
+    """Config 3's write path: episodes of 50 through fdql_ring_append_episode with the hindsight copy and the n-step
+    return computed on the device (her.py:55-95, nstep_return.py:36-72); records/s including the host packing."""
+    from fastdeepqlearning_amd.Replay import ReplayMemory
+    from fastdeepqlearning_amd.Replay.wrappers import SparseL2Reward
+    w = WORKLOADS["config3"]
+    shard = ReplayMemory(200_000, 256, 50, device=dev)
+    rng = np.random.RandomState(0)
+    fn = SparseL2Reward(0.05, -1.0)
+    eps = []
+    for e in range(episodes):
+        dg = rng.uniform(-1, 1, w["goal"]).astype(np.float32)
+        eps.append([{"obs_1d": rng.standard_normal(w["obs"]).astype(np.float32),
+                     "achieved_goal": rng.uniform(-1, 1, w["goal"]).astype(np.float32), "desired_goal": dg,
+                     "action": rng.uniform(-1, 1, w["act"]).astype(np.float32), "reward": -1.0, "task_done": False,
+                     "episode_done": i == 49, "episode_step": i} for i in range(50)])
+    shard.append_episode(eps[0], return_name="mc_return", n_step=1000, discount=0.99, her=(49, fn))
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    n = 0
+    for ep in eps[1:]:
+        n += shard.append_episode(ep, return_name="mc_return", n_step=1000, discount=0.99, her=(49, fn))
+    torch.cuda.synchronize(dev)
+    return round(n / (time.perf_counter() - t0), 0)
+
+
+def config5_secondary(dev, ring=200_000, B=512, T=50, steps=6):
+    """BASELINE config 5 (discrete SAC on 4x84x84 uint8 frame stacks, conv encoder of this build - no reference exists,
+    SURVEY 8d) at the full batch on a 200k-frame uint8 ring (5.6 GB; the step does not depend on the ring's length)."""
+    from fastdeepqlearning_amd.core import NativeAgent, NativeRing, make_config
+    IMG, ACT = (4, 84, 84), 6
+    dims = [IMG[0] * IMG[1] * IMG[2], 1, 1, 1, 1, 1]
+    keys = ["obs_2d", "action", "reward", "mc_return", "task_done", "episode_step"]
+    r = NativeRing(ring, dims, dev, dtypes=["u8", "f32", "f32", "f32", "f32", "f32"])
+    g = torch.Generator(device=dev).manual_seed(0)
+    done = 0
+    while done < ring:
+        n = min(4096, ring - done)
+        rows = torch.empty(n, sum(dims), device=dev)
+        rows[:, :dims[0]] = torch.randint(0, 256, (n, dims[0]), device=dev, generator=g).float()
+        rows[:, dims[0]] = torch.randint(0, ACT, (n,), device=dev, generator=g).float()
+        rows[:, dims[0] + 1:dims[0] + 3] = torch.randn(n, 2, device=dev, generator=g)
+        rows[:, dims[0] + 3] = (torch.rand(n, device=dev, generator=g) < 0.001).float()
+        rows[:, dims[0] + 4] = ((torch.arange(n, device=dev) + done) % 1000).float()
+        r.add_rows(rows)
+        done += n
+    cfg = make_config(0, ACT, T, B, discrete=True, n_critics=5, n_quantiles=2, img=IMG, conv=((32, 8, 4), (64, 4, 2), (64, 3, 1)))
+    agent = NativeAgent(cfg, dev)
+    agent.init_weights(0)
+    outs = [torch.empty((T, B) + (IMG if k == "obs_2d" else (1,)), device=dev) for k in keys]
+    xp = dict(zip(keys, outs))
+    flat = [o.view(T, B, -1) for o in outs]
+
+    def step(i):
+        r.sample_windows(T, B, seed=7, counter=i, outs=flat)
+        agent.update(xp, seed=7)
+
+    for i in range(2):
+        step(i)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(10 + i)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    fl = agent.stats()["gemm_flops"]
+    out = {"workload": f"BASELINE config 5: discrete SAC (6 actions), 4x84x84 uint8 frame stacks, conv 32x8/4-64x4/2-64x3/1, "
+                       f"B={B} x T={T}, {ring}-frame uint8 ring (conv encoder: no reference exists, throughput only)",
+           "value": round(1 / dt, 2), "unit": "steps/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+           "frames_per_s": round(T * B / dt, 0), "all_mfma_kernels_tflops_over_step": round(fl / dt / 1e12, 1),
+           "workspace_GiB": round(agent.workspace.numel() / 2 ** 30, 1)}
+    del agent, r, outs, xp, flat
+    torch.cuda.empty_cache()
+    return out
+
+
+class _Space:
+    def __init__(self, shape=None, spaces=None):
+        if shape is not None:
+            self.shape = tuple(shape)
+        if spaces is not None:
+            self.spaces = spaces
+
+
+def facade_path(dev, steps=100):
+    """Config 2 through the franQ-shaped objects a Runner would hold (Replay.make + Agent.make + train_step()): what the
+    drop-in user gets, Python wrapper and per-step buffer bookkeeping included."""
+    from fastdeepqlearning_amd import Agent, Replay
+    from fastdeepqlearning_amd.Agent import AgentConf
+    w = WORKLOADS["config2"]
+    conf = AgentConf()
+    conf.obs_space = _Space(spaces={"obs_1d": _Space(shape=(w["obs"],))})
+    conf.action_space = _Space(shape=(w["act"],))
+    conf.discrete = False
+    conf.training_device = conf.inference_device = dev
+    conf.batch_size, conf.temporal_len, conf.replay_size = w["B"], w["T"], 200_000
+    conf.num_critics, conf.num_q_predictions = w["C"], w["Q"]
+    conf.use_async_train, conf.num_instances = False, 1
+    read_heads, _ = Replay.make(conf)
+    keys, dims = layout(w)
+    rows = synth_rows(w, 150_000, 5, dev)
+    template = {k: (np.zeros(d, np.float32) if d > 1 else 0.0) for k, d in zip(keys, dims)}
+    read_heads[0]._ensure_ring(template)
+    read_heads[0].add_rows(rows)
+    read_heads[0]._len = 150_000
+    agent = Agent.make(conf)
+    agent.enable_training(read_heads)
+    for _ in range(10):
+        agent.train_step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        agent.train_step()
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    return {"value": round(steps / el, 2), "unit": "steps/s", "ms_per_step": round(1e3 * el / steps, 4),
+            "plans_built": agent.native.stats()["plans_built"],
+            "what": "DeepQLearning.train_step() on Replay.make()'s shard, config 2 dims, T=50, B=256, 200k-slot ring"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--temporal-len", type=int, default=50)
-    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=0, help="windows per step (default: the workload's; N>1: the GLOBAL batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--also-t2", action="store_true",
-                    help="add the temporal_len=2 figure (off by default so that a rocprofv3 summary of the "
-                         "default command holds launches of ONE workload only)")
+    ap.add_argument("--no-extras", action="store_true", help="skip other_configs / facade_path / temporal_len 2 (profiling runs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
     import torch.distributed as dist
-    # FDQL_BENCH_BACKEND=gloo: rehearsal of the N>1 code path on a box with fewer GPUs than ranks
-    # (ranks share devices, the gradient all-reduce goes through the host); the driver uses nccl (= RCCL)
+    # FDQL_BENCH_BACKEND=gloo: rehearsal of the N>1 code path on a box with fewer GPUs than ranks (ranks share devices,
+    # the gradient all-reduce goes through the host); the driver uses nccl (= RCCL)
     backend = os.environ.get("FDQL_BENCH_BACKEND", "nccl")
     dev = torch.device(f"cuda:{local_rank % max(torch.cuda.device_count(), 1)}")
     torch.cuda.set_device(dev)
@@ -149,42 +431,107 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-
-    from fastdeepqlearning_amd.core import NativeAgent, NativeRing, make_config
     from fastdeepqlearning_amd import _native as nat
+    T = args.temporal_len
 
-    T, B = args.temporal_len, args.batch
-    ring = NativeRing(RING, DIMS, dev)
-    for c0 in range(0, RING + 1000, 250_000):               # wraps once: len = RING - 1 (quirk q1)
-        n = min(250_000, RING + 1000 - c0)
-        ring.add_rows(synth_rows(n, 1000 * rank + c0 // 250_000, dev))
-    assert len(ring) == RING - 1
-    cfg = make_config(OBS, ACT, T, B, n_critics=C, n_quantiles=Q, latent=HID, enc_features=HID, enc_hidden=(HID,),
-                      joint_hidden=(HID,), pi_hidden=(HID,), critic_hidden=(HID, HID), world_size=world,
-                      keep_frozen_copy=True)
-    agent = NativeAgent(cfg, dev)
-    agent.init_weights(seed=0)                               # same weights on every rank
-    outs = [torch.empty(T, B, d, device=dev) for d in DIMS]
-    xp = dict(zip(KEYS, outs))
-    seed = 1234 + rank
+    if world == 1:
+        out = bench_single(args, dev, T)
+    else:
+        out = bench_distributed(args, dev, T, rank, world, backend, dist, nat)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def bench_single(args, dev, T):
+    w = WORKLOADS["config2"]
+    B = args.batch or w["B"]
+    job = Job(w, dev, B, T)
+    el = job.timed(args.steps, args.warmup)
+    ms_per_step = 1e3 * el / max(args.steps, 1)
+    # sustained: >= 2 s of back-to-back steps (DVFS: short dispatch trains clock higher than sustained ones)
+    n_sus = max(200, int(2.2 / max(el / max(args.steps, 1), 1e-6)))
+    el_sus = job.timed(n_sus, 0, first=100_000)
+    roofline, top = roofline_of(job)
+    sampler = sampler_roofline(job)
+    extras, t2, facade = None, None, None
+    if not args.no_extras:
+        t2job = Job(w, dev, B, 2, ring_slots=200_000)
+        e2 = t2job.timed(300, 30)
+        t2 = {"temporal_len": 2, "value": round(300 / e2, 1), "unit": "steps/s", "ms_per_step": round(1e3 * e2 / 300, 4),
+              "transitions_per_step": 2 * B, "note": "the plain 1-step-minibatch reading of batch=256: launch/latency-bound, 2.6 GFLOP per step"}
+        del t2job
+        torch.cuda.empty_cache()
+        facade = facade_path(dev)
+        extras = {}
+        for name, fn in (("config3_her", lambda: dict(secondary("config3", dev), her_ingest_records_per_s=config3_her_ingest(dev))),
+                         ("config4_1gpu_B1024", lambda: secondary("config4", dev, steps=8, warmup=2)),
+                         ("config5_B512", lambda: config5_secondary(dev))):
+            try:
+                extras[name] = fn()
+            except Exception as e:   # noqa: BLE001 - a secondary figure must never take the headline line down
+                extras[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            torch.cuda.empty_cache()
+    cpu = None if args.no_cpu_baseline else cpu_baseline(w, T, B)
+    return {
+        "metric": "gradient-steps/sec", "value": round(args.steps / el, 2), "unit": "steps/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{w['text']}, B={B} windows x temporal_len T={T} (reference default), "
+                               f"sample+loss+backward+Adam+polyak per step",
+                   "global_batch_windows": B, "temporal_len": T, "transitions_per_step": B * T, "ring": w["ring"],
+                   "parallelism": "dp1"},
+        "roofline": roofline, "cpu_baseline": cpu,
+        "sustained": {"value": round(n_sus / el_sus, 2), "unit": "steps/s", "steps": n_sus, "seconds": round(el_sus, 2)},
+        "sampler_roofline": sampler, "kernel_ms_top": top, "also_temporal_len_2": t2, "facade_path": facade,
+        "other_configs": extras, "csrc_sha": csrc_hash(),
+    }
+
+
+def bench_distributed(args, dev, T, rank, world, backend, dist, nat):
+    """BASELINE config 4, strong scaling: the global batch of 1024 windows is split over the ranks."""
+    w = WORKLOADS["config4"]
+    Bg = args.batch or w["B"]
+    assert Bg % world == 0, "the global batch must divide by the number of GPUs"
+    ring_slots = int(os.environ.get("FDQL_BENCH_RING", w["ring"]))      # rehearsal knob (ranks sharing one card)
+    # the same workload on ONE GPU, measured by rank 0 before the distributed phase (never `value`)
+    single = None
+    if rank == 0 and os.environ.get("FDQL_BENCH_SKIP_1GPU") is None:
+        j1 = Job(w, dev, Bg, T, ring_slots=ring_slots)
+        e1 = j1.timed(max(4, args.steps // 4), 2)
+        single = {"value": round(max(4, args.steps // 4) / e1, 2), "unit": "steps/s", "global_batch_windows": Bg,
+                  "what": "rank 0 alone on the whole batch, same process, before the distributed phase"}
+        del j1
+        torch.cuda.empty_cache()
+    dist.barrier()
+    job = Job(w, dev, Bg // world, T, world=world, rank=rank, ring_slots=ring_slots)
+    agent, grads = job.agent, job.agent.grads
+    side = torch.cuda.Stream(dev)
+    main_stream = torch.cuda.current_stream(dev)
+    ev_grad, ev_red = torch.cuda.Event(), torch.cuda.Event()
 
     def step(i):
-        ring.sample_windows(T, B, seed=seed, counter=i, outs=outs)
-        if world == 1:
-            agent.update(xp, seed=seed)
-        else:
-            agent.update(xp, seed=seed, phase=nat.PHASE_GRAD)
+        job.ring.sample_windows(T, job.B, seed=job.seed, counter=i, outs=job.outs)
+        agent.update(job.xp, seed=job.seed, phase=nat.PHASE_GRAD)
+        # the all-reduce runs on its own stream: the arena is complete only when the slab reduction at the end of
+        # PHASE_GRAD has run, so what it can overlap with is host-side launch work of the apply phase, not the backward
+        ev_grad.record(main_stream)
+        with torch.cuda.stream(side):
+            side.wait_event(ev_grad)
             if backend == "nccl":
-                dist.all_reduce(agent.grads)                 # RCCL sum over xGMI; loss already carries 1/(B*world)
+                dist.all_reduce(grads)                   # RCCL sum over xGMI; the row weights already carry 1/B_global
             else:
-                g = agent.grads.cpu()
+                g = grads.cpu()
                 dist.all_reduce(g)
-                agent.grads.copy_(g)
-            agent.update(None, phase=nat.PHASE_APPLY)
+                grads.copy_(g)
+            ev_red.record(side)
+        main_stream.wait_event(ev_red)
+        agent.update(None, phase=nat.PHASE_APPLY)
 
     def sync():
-        if world > 1:
-            dist.barrier()
+        dist.barrier()
         torch.cuda.synchronize(dev)
 
     for i in range(args.warmup):
@@ -195,132 +542,24 @@ def main():
         step(args.warmup + i)
     sync()
     el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-    ms_per_step = 1e3 * el / max(args.steps, 1)
-    value = world * args.steps / el                          # every rank completes one train_step per step
-
-    # ---- per-kernel timing with HIP events on the launch stream (rank 0), after the timed region
-    roofline, breakdown, sampler = None, None, None
-    if rank == 0:
-        acc = {}
-        reps = 5
-        for r in range(reps):
-            for name, ms, fl, by in agent.profile_update(xp, seed=seed):
-                a = acc.setdefault(name, [0.0, fl, by, 0])
-                a[0] += ms
-                a[3] += 1
-        # dominant kernel = the tile-shape instantiation of the grouped fp32-MFMA GEMM with the largest total
-        # time (rocprofv3 agrees: profiles/*kernel_stats*.csv); the narrow shapes run bandwidth-bound problems
-        allg = {k: v for k, v in acc.items() if k.startswith("gemm")}
-        by_shape = {}
-        for k, v in allg.items():
-            by_shape.setdefault(k.split(":")[0], {})[k] = v
-        dom_name, dom = max(by_shape.items(), key=lambda kv: sum(v[0] for v in kv[1].values()))
-        gemm_ms = sum(v[0] for v in dom.values()) / reps
-        gemm_fl = sum(v[1] * v[3] for v in dom.values()) / reps
-        n_gemm = sum(v[3] for v in dom.values()) // reps
-        all_ms = sum(v[0] for v in allg.values()) / reps
-        all_fl = sum(v[1] * v[3] for v in allg.values()) / reps
-        total_ms = sum(v[0] for v in acc.values()) / reps
-        tf = gemm_fl / max(gemm_ms * 1e-3, 1e-12) / 1e12
-        roofline = {"bound": "mfma", "kernel": f"k_gemm_grouped<{dom_name[4:]} tile> (fp32 v_mfma_f32_32x32x2_f32)",
-                    "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
-                    "launches_per_step": int(n_gemm), "flops_per_launch": gemm_fl / max(n_gemm, 1),
-                    "avg_launch_ms": round(gemm_ms / max(n_gemm, 1), 4), "share_of_step": round(gemm_ms / total_ms, 3),
-                    "all_gemm_tile_shapes": {"flops_per_step": all_fl, "ms_per_step": round(all_ms, 4),
-                                             "achieved": round(all_fl / (all_ms * 1e-3) / 1e12, 2),
-                                             "share_of_step": round(all_ms / total_ms, 3)}}
-        # HBM traffic of the dominant kernel cannot be measured from inside this process (PMC needs rocprofv3):
-        # it is taken from the committed rocprofv3 --pmc summary of the SAME workload when one is present
-        tj = os.path.join(ROOT, "profiles", "r01_dominant_kernel_traffic.json")
-        if os.path.exists(tj) and T == 50 and B == 256:
-            tr = json.load(open(tj))
-            roofline["traffic"] = tr["hbm_bytes_per_launch"]
-            roofline["traffic_unit"] = "bytes/launch (HBM read+write, PMC FETCH_SIZE x2 + WRITE_SIZE)"
-            roofline["traffic_source"] = "profiles/r01_hbm_traffic_pmc.txt (" + tr["source"] + ")"
-            roofline["algorithmic_bytes_per_launch"] = sum(v[2] * v[3] for v in dom.values()) / reps / max(n_gemm, 1)
-        # matrix-pipe utilisation and shader clock of the same kernel, from the committed SQ-counter pass
-        uj = os.path.join(ROOT, "profiles", "r01_mfma_utilisation_pmc.txt")
-        if os.path.exists(uj) and T == 50 and B == 256:
-            shape_id = {"128x128": 0, "128x32": 1, "32x128": 2, "64x128": 3, "64x128dual": 4, "64x64": 5, "64x64hf": 6}
-            tag = f"k_gemm_grouped<{shape_id.get(dom_name[4:], -1)},"
-            wsum = usum = csum = 0.0
-            for line in open(uj):
-                if tag in line:
-                    f = dict(re.findall(r"(\w+)=\s*([\d.]+)", line))
-                    w = float(f["dur_us"]) * float(f["n"])      # time-weighted over that kernel's launches
-                    wsum += w; usum += w * float(f["mfma_util"]); csum += w * float(f["clock_GHz"])
-            if wsum > 0:
-                roofline["mfma_pipe_busy_frac"] = round(usum / wsum, 3)
-                roofline["shader_clock_ghz_under_load"] = round(csum / wsum, 2)
-                roofline["pmc_source"] = ("profiles/r01_mfma_utilisation_pmc.txt (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES "
-                                          "SQ_BUSY_CYCLES; peak 157.3 TFLOP/s assumes 2.4 GHz)")
-        breakdown = {k: round(v[0] / reps, 4) for k, v in sorted(acc.items(), key=lambda kv: -kv[1][0])[:12]}
-        # sampler on its own: HBM-bound gather, algorithmic bytes = 2*T*B*rowbytes + 8*B
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize(dev)
-        e0.record()
-        for i in range(50):
-            ring.sample_windows(T, B, seed=seed, counter=10_000 + i, outs=outs)
-        e1.record()
-        torch.cuda.synchronize(dev)
-        s_ms = e0.elapsed_time(e1) / 50
-        s_bytes = 2.0 * T * B * sum(DIMS) * 4 + 8 * B
-        sampler = {"bound": "hbm", "kernel": "k_draw_starts + k_gather_windows", "ms": round(s_ms, 4),
-                   "achieved": round(s_bytes / (s_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": round(s_bytes / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes": s_bytes}
-
-    # ---- secondary figure ("reports both T=50 and T=2"): the same workload as plain 1-step
-    # minibatches (temporal_len 2 = one TD pair per window), rank 0 at N=1 only; never `value`
-    t2 = None
-    if rank == 0 and world == 1 and T != 2 and args.also_t2:
-        cfg2 = make_config(OBS, ACT, 2, B, n_critics=C, n_quantiles=Q, latent=HID, enc_features=HID, enc_hidden=(HID,),
-                           joint_hidden=(HID,), pi_hidden=(HID,), critic_hidden=(HID, HID), world_size=1,
-                           keep_frozen_copy=True)
-        ag2 = NativeAgent(cfg2, dev)
-        ag2.init_weights(seed=0)
-        outs2 = [torch.empty(2, B, d, device=dev) for d in DIMS]
-        xp2 = dict(zip(KEYS, outs2))
-        for i in range(20):
-            ring.sample_windows(2, B, seed=seed, counter=20_000 + i, outs=outs2)
-            ag2.update(xp2, seed=seed)
-        torch.cuda.synchronize(dev)
-        n2 = 200
-        t0 = time.perf_counter()
-        for i in range(n2):
-            ring.sample_windows(2, B, seed=seed, counter=30_000 + i, outs=outs2)
-            ag2.update(xp2, seed=seed)
-        torch.cuda.synchronize(dev)
-        e2 = time.perf_counter() - t0
-        t2 = {"temporal_len": 2, "value": round(n2 / e2, 1), "unit": "steps/s", "ms_per_step": round(1e3 * e2 / n2, 4),
-              "transitions_per_step": 2 * B, "note": "launch/latency-bound: 2.6 GFLOP per step"}
-        del ag2
-
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(T, B)
-
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        out = {
-            "metric": "gradient-steps/sec", "value": round(value, 2), "unit": "steps/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE config 2: TQC 5x2 quantile critics, obs=17 act=6, MLP(256), "
-                                   f"1M-transition HBM ring, B={B} windows/GPU x temporal_len T={T} "
-                                   f"(reference default), sample+loss+backward+Adam+polyak per step",
-                       "global_batch_windows": B * world, "temporal_len": T, "transitions_per_step": B * world * T,
-                       "ring": RING, "parallelism": f"dp{world}"},
-            "roofline": roofline, "cpu_baseline": cpu,
-            "sampler_roofline": sampler, "kernel_ms_top": breakdown, "also_temporal_len_2": t2,
-        }
-        print(json.dumps(out))
+    t = torch.tensor([el], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+    roofline, top = (roofline_of(job, committed_pmc=False) if rank == 0 else (None, None))
+    value = args.steps / el                                  # ONE optimiser step of the whole job per step
+    return {
+        "metric": "gradient-steps/sec", "value": round(value, 2), "unit": "steps/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / max(args.steps, 1), 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{w['text']} per rank, GLOBAL batch {Bg} windows split {Bg // world} per GPU x temporal_len "
+                               f"T={T}, sample+loss+backward, all-reduce of the {agent.grads.numel() * 4 / 1e6:.2f} MB gradient "
+                               f"arena ({backend}), Adam+polyak on every rank",
+                   "global_batch_windows": Bg, "temporal_len": T, "transitions_per_step": Bg * T, "ring": ring_slots,
+                   "parallelism": f"dp{world}", "collective_ranks": dist.get_world_size(), "backend": backend},
+        "transitions_per_s": round(value * Bg * T, 0),
+        "same_workload_1gpu": single, "roofline": roofline, "cpu_baseline": None, "kernel_ms_top": top,
+        "csrc_sha": csrc_hash(),
+    }
 
 
 if __name__ == "__main__":

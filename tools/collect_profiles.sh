@@ -10,8 +10,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # 1. bench line (N=1) and its rocprofv3 kernel stats (same command)
 python3 $R/bench.py --steps 50 --warmup 10 > $OUT/bench_n1.json 2> $OUT/bench_n1.err || exit 1
-python3 $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline --also-t2 > $OUT/bench_n1_with_t2.json 2>> $OUT/bench_n1.err || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-extras > $OUT/bench_under_rocprof.json 2> $OUT/stats.err || exit 1
 # 2. per-stage times (HIP events inside the library)
 python3 $R/tools/profile_stages.py > $OUT/stage_times.txt 2>&1 || exit 1
 # 3. HBM traffic of every kernel of one update: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (TCC slots)

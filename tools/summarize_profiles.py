@@ -43,22 +43,37 @@ for key in fetch:
     t[1] += wr * fetch[key][1]
     t[2] += fetch[key][1]
 open(os.path.join(out, "hbm_traffic_pmc.txt"), "w").write("\n".join(lines) + "\n")
-# dominant kernel = the tile-shape instantiation bench.py names in its roofline object
-shape_id = {"128x128": 0, "128x32": 1, "32x128": 2, "64x128": 3, "64x128dual": 4, "64x64": 5, "64x64hf": 6}
+# dominant kernel = the kernel instantiation bench.py names in its roofline object
+shape_id = {"128x128": 0, "128x32": 1, "32x128": 2, "64x128": 3, "64x64dual": 4, "64x64": 5, "64x64hf": 6}
 dom_shape = "64x64"
 try:
     for line in open(os.path.join(out, "bench_n1.json")):
         if line.startswith("{"):
-            dom_shape = json.loads(line)["roofline"]["kernel"].split("<")[1].split(" ")[0]
+            kn = json.loads(line)["roofline"]["kernel"]
+            dom_shape = kn.split("<")[1].split(" ")[0] if "<" in kn else "chain"
 except (OSError, KeyError, IndexError, ValueError):
     pass
-dom = [k for k in tot if f"k_gemm_grouped<{shape_id[dom_shape]}," in k]
+dom_tag = f"k_gemm_grouped<{shape_id[dom_shape]}," if dom_shape in shape_id else "k_chain"
+dom = [k for k in tot if dom_tag in k]
+
+
+def csrc_hash():
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "fastdeepqlearning_amd", "csrc", "*.h*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+traffic = None
 if dom:
     t = tot[dom[0]]
-    json.dump({"kernel": dom[0], "dispatches_measured": t[2], "hbm_read_MB_per_launch": t[0] / t[2],
+    traffic = {"kernel": dom[0], "dispatches_measured": t[2], "hbm_read_MB_per_launch": t[0] / t[2],
                "hbm_write_MB_per_launch": t[1] / t[2], "hbm_bytes_per_launch": (t[0] + t[1]) / t[2] * 1e6,
                "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE doubled (gfx950)",
-               "workload": "config 2, T=50, B=256"}, open(os.path.join(out, "dominant_kernel_traffic.json"), "w"), indent=1)
+               "workload": "config 2, T=50, B=256", "csrc_sha": csrc_hash()}
 # matrix-pipe utilisation per GEMM kernel: SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of the 1024 SIMDs' MFMA pipes,
 # SQ_BUSY_CYCLES the cycles the 32 shader engines (8 XCD x 4) had work: utilisation = (MFMA/1024) / (BUSY/32); the
 # kernel trace of the same pass gives the duration, hence the shader clock the kernel actually ran at.
@@ -66,7 +81,7 @@ sq_rows = counter_rows("pmc_sq")
 if sq_rows:
     per = collections.OrderedDict()
     for r in sq_rows:
-        if "k_gemm" not in r["Kernel_Name"]:
+        if "k_gemm" not in r["Kernel_Name"] and "k_chain" not in r["Kernel_Name"]:
             continue
         key = (r["Kernel_Name"].split("(")[0], int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0))
         d = per.setdefault(key, collections.defaultdict(float))
@@ -76,7 +91,7 @@ if sq_rows:
     kt = sorted(glob.glob(os.path.join(out, "pmc_sq", "**", "*_kernel_trace.csv"), recursive=True), key=os.path.getmtime)
     if kt:
         for r in csv.DictReader(open(kt[-1])):
-            if "k_gemm" in r["Kernel_Name"]:
+            if "k_gemm" in r["Kernel_Name"] or "k_chain" in r["Kernel_Name"]:
                 key = (r["Kernel_Name"].split("(")[0], int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0))
                 dur[key][0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
                 dur[key][1] += 1
@@ -96,6 +111,24 @@ if sq_rows:
                         f"clock_GHz={busy / us / 1e3 if us == us and us > 0 else float('nan'):5.2f} waves_per_simd={wc * 4 / 1024 / busy if busy else 0:4.1f} "
                         f"parked={wa / wc if wc else 0:4.2f}")
     open(os.path.join(out, "mfma_utilisation_pmc.txt"), "w").write("\n".join(sq_lines) + "\n")
+    if traffic is not None:
+        wsum = usum = csum = 0.0
+        for key, d in per.items():
+            if dom_tag not in key[0] or not dur[key][1]:
+                continue
+            n = max(d["n_SQ_BUSY_CYCLES"], 1.0)
+            busy = d["SQ_BUSY_CYCLES"] / n / 32.0
+            mf = d["SQ_VALU_MFMA_BUSY_CYCLES"] / max(d["n_SQ_VALU_MFMA_BUSY_CYCLES"], 1.0) / 1024.0
+            us = dur[key][0] / dur[key][1]
+            wgt = us * dur[key][1]
+            wsum += wgt; usum += wgt * (mf / busy if busy else 0.0); csum += wgt * (busy / us / 1e3)
+        if wsum > 0:
+            traffic["mfma_pipe_busy_frac"] = round(usum / wsum, 3)
+            traffic["shader_clock_ghz_under_load"] = round(csum / wsum, 2)
+            traffic["pmc_source"] = ("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES, time-weighted over the "
+                                     "kernel's launches; the 157.3 TFLOP/s peak assumes 2.4 GHz")
+if traffic is not None:
+    json.dump(traffic, open(os.path.join(out, "dominant_kernel_traffic.json"), "w"), indent=1)
 # kernel stats csv of the bench run
 st = sorted(glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
 if st:
