@@ -140,18 +140,33 @@ class DeepQLearning:
     def _distributed(self):
         return int(getattr(self.conf, "world_size", 1) or 1) > 1
 
-    def train_step(self):
-        """deepQlearning.py:105-127: for every shard: sample -> loss -> backward -> Adam -> polyak."""
+    def _all_reduce_gradients(self):
+        """One all-reduce(sum) of the contiguous gradient arena: RCCL over xGMI when the process group is
+        nccl; with gloo (CPU rehearsals, tests) the arena is staged through the host.  The row weights of every rank's
+        loss already carry 1 / (B_local * world_size), so the sum IS the global-batch gradient."""
+        import torch.distributed as dist
+        g = self.native.grads
+        if dist.get_backend() == "nccl":
+            dist.all_reduce(g)
+        else:
+            h = g.cpu()
+            dist.all_reduce(h)
+            g.copy_(h)
+
+    def train_step(self, noise=None):
+        """deepQlearning.py:105-127: for every shard: sample -> loss -> backward -> Adam -> polyak.
+        noise: optional (noise_target, noise_actor) device tensors replayed by the policy kernels instead of the
+        device's Philox draws (parity runs; the reference draws from torch's global generator)."""
+        nt, na = noise if noise is not None else (None, None)
         for replay in self.replays:
             xp = replay.temporal_sample()
             self._last_xp = xp
             if self._distributed():
-                import torch.distributed as dist
-                self.native.update(xp, seed=self._seed, phase=N.PHASE_GRAD)
-                dist.all_reduce(self.native.grads)
+                self.native.update(xp, nt, na, seed=self._seed, phase=N.PHASE_GRAD)
+                self._all_reduce_gradients()
                 self.native.update(None, phase=N.PHASE_APPLY)
             else:
-                self.native.update(xp, seed=self._seed, phase=N.PHASE_ALL)
+                self.native.update(xp, nt, na, seed=self._seed, phase=N.PHASE_ALL)
             self.conf.train_step.value += 1
 
     def get_losses(self, xp, noise_target=None, noise_actor=None):

@@ -803,10 +803,11 @@ int fdql_ring_sample_rows(fdql_ring_t *r, int32_t B, const int64_t *idx_dev, uin
                           float *const *out, int64_t *idx_out_dev, void *stream) {
   FDQL_REQUIRE(r && out && B >= 1, "bad arguments");
   Lock lk(r->mu);
-  if (r->len < B) {  // replay_memory.py:50
+  if (r->len < B && !idx_dev) {  // replay_memory.py:50 guards the random draw only; explicit indices are the caller's
     set_error("Trying to sample more memories than available! (len=%lld, B=%d)", (long long)r->len, B);
     return FDQL_EOVERSAMPLE;
   }
+  FDQL_REQUIRE(r->len > 0, "the ring is empty");
   hipStream_t s = (hipStream_t)stream;
   int rc = flush(r, s);
   if (rc) return rc;
