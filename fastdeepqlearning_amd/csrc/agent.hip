@@ -548,20 +548,13 @@ struct ChainBuilder {
   Stage &st;
   bool ok = true;
   int op_start = 0, rows = 0, peak = 0;
-  int wstage = -1, wstage_size = 0;   // head-weight staging area of the program's CH_NARROW operations
+  int stage_top = CH_LDS_FLOATS;      // weight staging areas of the CH_NARROW operations: carved downwards from the top of
+                                      // LDS, alive for the whole program (they are filled before its first operation)
   std::vector<std::pair<int, int>> used;   // live LDS ranges (offset, size) of the program being built
   explicit ChainBuilder(Stage &s) : st(s) {}
 
-  void begin(int nrows) { rows = nrows; op_start = (int)st.cops.size(); used.clear(); peak = 0; wstage = -1; wstage_size = 0; }
-  // reserved up front (lives for the whole program): N rows of the widest K-segment a narrow head of this program reads
-  void reserve_head_stage(int N, int maxK) {
-    const int need = N * (((maxK + 15) & ~15) + 4);
-    if (need > wstage_size) {
-      if (wstage >= 0) { ok = false; return; }   // must be sized before the first allocation that follows it
-      wstage = alloc(need);
-      wstage_size = need;
-    }
-  }
+  void begin(int nrows) { rows = nrows; op_start = (int)st.cops.size(); used.clear(); peak = 0; stage_top = CH_LDS_FLOATS; }
+  void reserve_head_stage(int, int) {}
   void end() {
     ChainOp e;
     memset(&e, 0, sizeof(e));
@@ -570,9 +563,10 @@ struct ChainBuilder {
     if ((int)st.cops.size() - op_start > CH_MAX_OPS) ok = false;
     ChainProblem p;
     memset(&p, 0, sizeof(p));
-    p.rows = rows; p.op_start = op_start; p.nops = (int)st.cops.size() - op_start; p.lds_floats = peak;
+    const int need = stage_top < CH_LDS_FLOATS ? CH_LDS_FLOATS : peak;   // staging areas sit at the top of the budget
+    p.rows = rows; p.op_start = op_start; p.nops = (int)st.cops.size() - op_start; p.lds_floats = need;
     st.cprobs.push_back(p);
-    st.lds_floats = std::max(st.lds_floats, peak);
+    st.lds_floats = std::max(st.lds_floats, need);
   }
   int alloc(int size) {   // first fit; sizes are multiples of 4 floats (16-byte aligned images)
     size = (size + 3) & ~3;
@@ -582,7 +576,7 @@ struct ChainBuilder {
       if (u.first - at >= size) break;
       at = u.first + u.second;
     }
-    if (at + size > CH_LDS_FLOATS) { ok = false; return 0; }
+    if (at + size > stage_top) { ok = false; return 0; }
     used.push_back({at, size});
     peak = std::max(peak, at + size);
     return at;
@@ -621,10 +615,12 @@ struct ChainBuilder {
   // one Linear layer over cat(ins): W rows of pitch ldw, the k-th input image reads columns starting at its offset
   // in the concatenation.  dst: the LDS image that receives the result (may alias a dying input; slot -1: none)
   void gemm(const std::vector<ChainImg> &ins, const float *W, int ldw, int N, const float *bias, int act, const ChainImg &dst,
-            float *out, int ldo, RowWin win) {
+            float *out, int ldo, RowWin win, const float *rider_w = nullptr, int rider_ld = 0, int rider_n = 0, bool rider_begin = false) {
     if (N > 256 || (int)ins.size() > CH_MAX_SEG) { ok = false; return; }
     ChainOp o = new_op(CH_GEMM);
-    o.N = N; o.flags = CHF_ZERO | CHF_EMIT; o.act = act; o.bias = bias; o.nseg = (int)ins.size();
+    o.N = N; o.flags = CHF_ZERO | CHF_EMIT | (rider_w && rider_begin ? CHF_HBEGIN : 0); o.act = act; o.bias = bias; o.nseg = (int)ins.size();
+    o.hw = rider_w; o.hldw = rider_ld; o.hN = rider_n;
+    if (rider_w) st.flops += 2.0 * (std::min(rows, win.hi) - win.lo) * (double)rider_n * [&] { int k = 0; for (auto &im : ins) k += im.K; return k; }();
     int col = 0;
     for (size_t i = 0; i < ins.size(); ++i) {
       o.seg[i].W = W + col; o.seg[i].ldw = ldw; o.seg[i].slot = ins[i].slot; o.seg[i].pitch = ins[i].pitch; o.seg[i].K = ins[i].K;
@@ -646,10 +642,14 @@ struct ChainBuilder {
       o.seg[i].W = W + col; o.seg[i].ldw = ldw; o.seg[i].slot = ins[i].slot; o.seg[i].pitch = ins[i].pitch; o.seg[i].K = ins[i].K;
       col += ins[i].K;
     }
-    for (auto &im : ins)
-      if (wstage < 0 || N * (((im.K + 15) & ~15) + 4) > wstage_size) ok = false;   // reserve_head_stage() sizes it
+    int need = 0;
+    for (auto &im : ins) need += N * (((im.K + 15) & ~15) + 4);
+    need = (need + 3) & ~3;
+    stage_top -= need;
+    if (stage_top < peak) ok = false;   // (images allocated later are checked against stage_top in alloc())
+    for (auto &u : used) if (u.first + u.second > stage_top) ok = false;
     (void)scratch_slot;
-    o.slot = wstage; o.bias = bias; o.out = out; o.ldo = ldo;
+    o.slot = stage_top; o.bias = bias; o.out = out; o.ldo = ldo;
     o.row_lo = win.lo; o.row_hi = win.hi; o.row_shift = win.shift;
     st.cops.push_back(o);
     st.flops += chain_op_flops(o, std::min(rows, win.hi) - win.lo);
@@ -666,13 +666,18 @@ struct ChainBuilder {
     const int nh = (int)d.hid.size(), ld_head = d.head_ld();
     ChainImg none;
     if (d.dout <= 32 && !want_out_image) {   // (an output that feeds the next MLP from LDS takes the GEMM path)
-      narrow(ins, m.HW(), ld_head, 0, d.dout, true, nh == 0, m.HB(), m.out, m.ldout, win, 0);
-      int col = d.din;
+      // The head's block over a layer's INPUT rides in that layer's K loop when the layer is wide enough for every wave to
+      // own a column tile (chain.hip, RIDER); otherwise it is a CH_NARROW pass of its own.  The block over the last
+      // hidden activation always is one (nothing follows it to ride in).
+      auto rides = [&](int i) { return i < nh && d.hid[i] > 192; };
+      bool begun = false;
+      if (!rides(0)) { narrow(ins, m.HW(), ld_head, 0, d.dout, true, nh == 0, m.HB(), m.out, m.ldout, win, 0); begun = true; }
+      int col = 0;
       std::vector<ChainImg> cur = ins;
       bool cur_dies = in_dies;
       for (int i = 0; i < nh; ++i) {
         // the layer's output image: in place of its (single, dying) input when possible, else a new one
-        int need = CH_BM * chain_pitch(d.hid[i]);
+        const int need = CH_BM * chain_pitch(d.hid[i]);
         ChainImg dst;
         if (cur_dies && cur.size() == 1 && cur[0].size >= need) {
           dst = cur[0];
@@ -680,12 +685,15 @@ struct ChainBuilder {
         } else {
           if (cur_dies) for (auto &c : cur) release(c);
           dst = image(d.hid[i], need);
-          if (cur_dies) for (auto &c : cur) { (void)c; }
         }
-        gemm(cur, m.W(i), d.in_of(i), d.hid[i], m.Bv(i), CHA_LRELU, dst, store_h ? m.h[i] : nullptr, d.hid[i], win);
+        const bool ride = rides(i);
+        gemm(cur, m.W(i), d.in_of(i), d.hid[i], m.Bv(i), CHA_LRELU, dst, store_h ? m.h[i] : nullptr, d.hid[i], win,
+             ride ? m.HW() + col : nullptr, ld_head, d.dout, ride && !begun);
+        if (ride) begun = true;
+        col += d.in_of(i);
         const bool last = i + 1 == nh;
-        narrow({dst}, m.HW(), ld_head, col, d.dout, false, last, m.HB(), m.out, m.ldout, win, 0);
-        col += d.hid[i];
+        if (last || !rides(i + 1)) narrow({dst}, m.HW(), ld_head, col, d.dout, !begun, last, m.HB(), m.out, m.ldout, win, 0);
+        begun = true;
         cur = {dst};
         cur_dies = true;
       }

@@ -9,8 +9,8 @@ namespace fdql {
 constexpr int CH_BM = 64;          // rows per workgroup
 constexpr int CH_THREADS = 256;    // 4 waves, one per SIMD
 constexpr int CH_MAX_SEG = 4;      // K-segments of one operation (torch.cat of up to 4 row blocks)
-constexpr int CH_MAX_OPS = 24;      // operations per program (the program is copied to LDS)
-constexpr int CH_LDS_FLOATS = 39040;   // dynamic LDS available to the images: 160 KiB minus the program copy and a reserve
+constexpr int CH_MAX_OPS = 16;      // operations per program (the program is copied to LDS)
+constexpr int CH_LDS_FLOATS = 39616;   // dynamic LDS available to the images: 160 KiB minus the program copy and a reserve
 
 enum ChainOpKind { CH_END = 0, CH_LOAD = 1, CH_GEMM = 2, CH_NARROW = 3 };
 enum ChainFlags {
@@ -19,6 +19,7 @@ enum ChainFlags {
   CHF_KS = 4,        // weights are K-strided: element (k, n) at W[k*ldw + n] (dgrad); default K-contiguous W[n*ldw + k]
   CHF_BEGIN = 8,     // NARROW: clear the head accumulators first
   CHF_FINISH = 16,   // NARROW: add the bias and store the wave's 16 rows
+  CHF_HBEGIN = 32,   // GEMM with a head rider: clear the head accumulators first
 };
 enum ChainAct { CHA_NONE = 0, CHA_LRELU = 1, CHA_LRELU_GRAD = 2 };
 
@@ -46,6 +47,9 @@ struct ChainOp {
   float *out;                   // global output [*, ldo] or null
   const float *ref;             // CHA_LRELU_GRAD: activation output whose sign gates the gradient, [*, ldref]
   float *colsum;                // optional [blocks, N]: column sums of the emitted tile over this block's valid rows
+  const float *hw;              // GEMM (K-contiguous weights, N > 192): a narrow skip head's weight block over this op's
+  int hldw, hN;                 // input columns rides in the K loop: head row n at hw[n*hldw + k], hN <= 32 outputs (CH_NARROW
+                                // + CHF_FINISH later stores them); null: none
   ChainSeg seg[CH_MAX_SEG];
   ChainLoadSeg ld[CH_MAX_SEG];
 };

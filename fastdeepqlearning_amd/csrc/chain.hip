@@ -21,6 +21,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 namespace fdql {
 
@@ -50,7 +51,7 @@ __device__ __forceinline__ const float *ch_uni(const float *p) {
 
 // Diagnostic stamps (FDQL_CHAIN_STAMPS=1 -> chain_read_stamps): the workgroup in the middle of a launch records
 // s_memtime at its entry, after the program fetch and after every operation.
-__device__ unsigned long long g_ch_stamps[2 * CH_MAX_OPS + 4];
+__device__ unsigned long long g_ch_stamps[8 * CH_MAX_OPS + 4];
 __device__ int g_ch_stamps_on = 0;
 
 // MINB = workgroups per CU the register budget is cut for (1: 512 registers per lane; 2: 256 - two workgroups per CU
@@ -68,6 +69,7 @@ __global__ __launch_bounds__(CH_THREADS, MINB) void k_chain(const ChainProblem *
   // broadcast (every dependent global access before the first MFMA is a memory round trip this workgroup sits out)
   const bool stamp = g_ch_stamps_on && bid == (int)(gridDim.x / 2) && tid == 0;
   int nstamp = 0;
+#define CH_STAMP() do { if (stamp) g_ch_stamps[nstamp++] = __builtin_amdgcn_s_memtime(); } while (0)
   if (stamp) g_ch_stamps[nstamp++] = __builtin_amdgcn_s_memtime();
   int rows = 0, blk = 0, op_start = 0, nops = 0;
   for (int base = 0; base < nprob; base += 64) {
@@ -96,23 +98,75 @@ __global__ __launch_bounds__(CH_THREADS, MINB) void k_chain(const ChainProblem *
     __syncthreads();
   }
   const unsigned lds0 = ch_lds_addr(lds);
+  // The weight slices of every CH_NARROW operation -> their staging areas, once, before anything else is in flight:
+  // fetched inside the operation they would cost a memory round trip (behind the layer's own stores) per operation.
+  {
+    bool any = false;
+    for (int ip = 0; ip < nops; ++ip) {
+      const ChainOp &op = s_ops[ip];
+      if (ch_uni(op.kind) != CH_NARROW) continue;
+      any = true;
+      const int N = ch_uni(op.N), nseg = ch_uni(op.nseg);
+      const bool ks = (ch_uni(op.flags) & CHF_KS) != 0;
+      int wslot = ch_uni(op.slot);
+      for (int s = 0; s < nseg; ++s) {
+        gcf W = (gcf)ch_uni(op.seg[s].W);
+        const int ldw = ch_uni(op.seg[s].ldw), K = ch_uni(op.seg[s].K);
+        const int k16 = (K + 15) & ~15, wp = k16 + 4, total = N * k16;   // (wp / 4) odd: conflict-free B fragments
+        for (int base = 0; base < total; base += 8 * CH_THREADS) {
+          float v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int e = base + tid + u * CH_THREADS;
+            int n, k;
+            if (!ks) { n = e / k16; k = e - n * k16; } else { k = e / N; n = e - k * N; }
+            v[u] = (e < total && k < K) ? (ks ? W[(long long)k * ldw + n] : W[(long long)n * ldw + k]) : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int e = base + tid + u * CH_THREADS;
+            int n, k;
+            if (!ks) { n = e / k16; k = e - n * k16; } else { k = e / N; n = e - k * N; }
+            if (e < total) lds[wslot + n * wp + k] = v[u];
+          }
+        }
+        wslot += N * wp;
+      }
+    }
+    if (any) __syncthreads();
+  }
   if (stamp) g_ch_stamps[nstamp++] = __builtin_amdgcn_s_memtime();
 
   f32x16 acc[2][2];   // [tm][tn]: rows 32 tm + ..., columns of column tile tn
-  v4f hacc[2];        // CH_NARROW accumulators: this wave's 16 rows x 16 columns per tile (v_mfma_f32_16x16x4_f32)
+  v4f hacc[2];        // narrow-head accumulators: this wave's 16 rows x 16 columns per tile (v_mfma_f32_16x16x4_f32)
+  v4f hodd[2];        // CH_NARROW: the odd 16-k steps' sums (two independent MFMA chains; added at CHF_FINISH)
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[a][0][r] = 0.f; acc[a][1][r] = 0.f; }
     hacc[a] = v4f{0.f, 0.f, 0.f, 0.f};
+    hodd[a] = v4f{0.f, 0.f, 0.f, 0.f};
   }
 
   // ---------------------------------------------------------------- 32-k group of MFMAs: A from LDS, B in registers
   // a0 / a1: byte addresses of this lane's row in row tile 0 / 1 at the group's first k (+ 16 lh floats)
-  auto mfma_group_kc = [&](unsigned a0, unsigned a1, const v4f (&b)[2][4]) __attribute__((always_inline)) {
+  // af: the group's first fragments (j = 0), already requested by the previous group (or the segment prologue); the
+  // group requests the NEXT group's first fragments (na0 / na1) under its last MFMA step, so no LDS latency is exposed
+  // at a group boundary.  RIDER: the rider's two A fragments are requested first and consumed after the 64 main MFMAs.
+  // The NEXT group's weight fragments (pa / pb / ph0 / ph1 -> bn / rbn) are requested two or three at a time under each
+  // MFMA step, not in one burst at the group boundary: a wave issues in order, and a burst of 12 cache-line-scattered
+  // loads holds the instruction stream (and with it the matrix pipe) for ~1 k cycles while the texture path takes them in.
+  auto mfma_group_kc = [&](unsigned a0, unsigned a1, unsigned na0, unsigned na1, v4f (&af)[2], const v4f (&b)[2][4], unsigned a16g,
+                           const v4f (&rb)[2][2], gcf pa, gcf pb, gcf ph0, gcf ph1, v4f (&bn)[2][4], v4f (&rbn)[2][2],
+                           auto rider_tag) __attribute__((always_inline)) {
+    constexpr int NTH = decltype(rider_tag)::value;   // head tiles riding: 0, 1 or 2
+    constexpr bool RIDER = NTH > 0;
     v4f a[2][2];   // [parity of j][tm]
-    ch_rd128(a[0][0], a0);
-    ch_rd128(a[0][1], a1);
+    v4f ra[2], an[2];
+    if constexpr (RIDER) {
+      ch_rd128(ra[0], a16g);
+      ch_rd128(ra[1], a16g + 64u);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (j < 3) {
@@ -121,17 +175,41 @@ __global__ __launch_bounds__(CH_THREADS, MINB) void k_chain(const ChainProblem *
         ch_lgkm_wait<2>();
       } else {
         ch_lgkm_wait<0>();
+        ch_rd128(an[0], na0);
+        ch_rd128(an[1], na1);
       }
-      asm volatile("" : "+v"(a[j & 1][0]), "+v"(a[j & 1][1]));
+      if (j == 0) {
+        asm volatile("" : "+v"(af[0]), "+v"(af[1]));
+        if constexpr (RIDER) asm volatile("" : "+v"(ra[0]), "+v"(ra[1]));
+      } else {
+        asm volatile("" : "+v"(a[j & 1][0]), "+v"(a[j & 1][1]));
+      }
+      bn[0][j] = *(gcf4)(pa + 4 * j);
+      bn[1][j] = *(gcf4)(pb + 4 * j);
+      if constexpr (RIDER) {
+        if (j < 2) rbn[j][0] = *(gcf4)(ph0 + 16 * j);
+        if constexpr (NTH > 1) { if (j >= 2) rbn[j - 2][1] = *(gcf4)(ph1 + 16 * (j - 2)); }
+      }
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
           for (int tn = 0; tn < 2; ++tn)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j & 1][tm][c], b[tn][j][c], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(j == 0 ? af[tm][c] : a[j & 1][tm][c], b[tn][j][c], acc[tm][tn], 0, 0, 0);
     }
-    asm volatile("" ::"v"(a0), "v"(a1));
+    if constexpr (RIDER) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          hacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[hh][c], rb[hh][0][c], hacc[0], 0, 0, 0);
+          if constexpr (NTH > 1) hacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[hh][c], rb[hh][1][c], hacc[1], 0, 0, 0);
+        }
+    }
+    af[0] = an[0];
+    af[1] = an[1];
+    asm volatile("" ::"v"(a0), "v"(a1), "v"(na0), "v"(na1), "v"(a16g));
   };
   auto mfma_group_ks = [&](unsigned a0, unsigned a1, const v2f (&b)[4][4]) __attribute__((always_inline)) {
     v4f a[2][2];
@@ -175,13 +253,29 @@ __global__ __launch_bounds__(CH_THREADS, MINB) void k_chain(const ChainProblem *
   };
 
   // ---------------------------------------------------------------- one K-segment of a GEMM, K-contiguous weights
-  auto gemm_seg_kc = [&](const ChainSeg &S, int N, int n0) __attribute__((always_inline)) {
+  // RIDER (hw != null): the segment's block of a narrow skip head rides in the same K loop - per 32-k group each wave
+  // also multiplies ITS 16 rows of the image by the head's columns (8 v_mfma_f32_16x16x4_f32 per 16 head columns beside
+  // the 64 v_mfma_f32_32x32x2_f32), operands requested a group ahead like the main ones: the head costs ~6 % of the
+  // layer instead of a latency-bound pass of its own.
+  auto gemm_seg_kc = [&](const ChainSeg &S, int N, int n0, const float *hw, int hldw, int hN, auto rider_tag) __attribute__((always_inline)) {
+    constexpr int NTH = decltype(rider_tag)::value;
+    constexpr bool RIDER = NTH > 0;
     const float *W = ch_uni(S.W);
     const int ldw = ch_uni(S.ldw), K = ch_uni(S.K), pitch = ch_uni(S.pitch), slot = ch_uni(S.slot);
     const int na = min(n0 + li, N - 1), nb = min(n0 + 32 + li, N - 1);   // clamped: rows beyond N repeat row N-1, never stored
     gcf wpa = (gcf)(W + (long long)na * ldw + 16 * lh), wpb = (gcf)(W + (long long)nb * ldw + 16 * lh);
     const unsigned a0 = lds0 + (unsigned)(slot + li * pitch + 16 * lh) * 4u, a1 = a0 + (unsigned)(32 * pitch) * 4u;
     const int G = K >> 5, ntail = ((K & 31) + 7) >> 3;
+    // rider operands: lane (lj, kq) of head tile t reads head row min(16 t + lj, hN - 1), k's 16 h + 4 kq + 0..3
+    const int lj = lane & 15, kq = lane >> 4;
+    constexpr bool two = NTH > 1;
+    gcf hp0 = nullptr, hp1 = nullptr;
+    unsigned a16 = 0;
+    if constexpr (RIDER) {
+      hp0 = (gcf)(hw + (long long)min(lj, hN - 1) * hldw + 4 * kq);
+      hp1 = (gcf)(hw + (long long)min(16 + lj, hN - 1) * hldw + 4 * kq);
+      a16 = lds0 + (unsigned)(slot + (16 * wave + lj) * pitch + 4 * kq) * 4u;
+    }
     // first tail group's fragments are requested before the full groups (their latency hides behind them)
     v4f tb0 = {0.f, 0.f, 0.f, 0.f}, tb1 = {0.f, 0.f, 0.f, 0.f};
     auto load_tail = [&](int t) __attribute__((always_inline)) {
@@ -196,27 +290,67 @@ __global__ __launch_bounds__(CH_THREADS, MINB) void k_chain(const ChainProblem *
     if (ntail > 0) load_tail(0);
     if (G > 0) {
       v4f b[2][2][4];   // [buffer][tn][j]
+      v4f rb[2][2][2];  // rider: [buffer][half group][head tile]
       auto load_b = [&](int buf, int g) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) b[buf][0][j] = *(gcf4)(wpa + 32 * g + 4 * j);
 #pragma unroll
         for (int j = 0; j < 4; ++j) b[buf][1][j] = *(gcf4)(wpb + 32 * g + 4 * j);
+        if constexpr (RIDER) {
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            rb[buf][hh][0] = *(gcf4)(hp0 + 32 * g + 16 * hh);
+            if constexpr (two) rb[buf][hh][1] = *(gcf4)(hp1 + 32 * g + 16 * hh);
+          }
+        }
       };
       load_b(0, 0);
+      v4f af[2];
+      ch_rd128(af[0], a0);
+      ch_rd128(af[1], a1);
       int g = 0;
       for (; g + 2 <= G; g += 2) {   // branch-free pairs: the last pair re-requests group G-1 (harmless)
-        load_b(1, g + 1);
-        mfma_group_kc(a0 + 128u * g, a1 + 128u * g, b[0]);
-        load_b(0, min(g + 2, G - 1));
-        mfma_group_kc(a0 + 128u * (g + 1), a1 + 128u * (g + 1), b[1]);
+        mfma_group_kc(a0 + 128u * g, a1 + 128u * g, a0 + 128u * (g + 1), a1 + 128u * (g + 1), af, b[0], a16 + 128u * g, rb[0],
+                      wpa + 32 * (g + 1), wpb + 32 * (g + 1), hp0 + 32 * (g + 1), hp1 + 32 * (g + 1), b[1], rb[1], rider_tag);
+        const int g2 = min(g + 2, G - 1);
+        mfma_group_kc(a0 + 128u * (g + 1), a1 + 128u * (g + 1), a0 + 128u * g2, a1 + 128u * g2, af, b[1], a16 + 128u * (g + 1), rb[1],
+                      wpa + 32 * g2, wpb + 32 * g2, hp0 + 32 * g2, hp1 + 32 * g2, b[0], rb[0], rider_tag);
       }
-      if (g < G) mfma_group_kc(a0 + 128u * g, a1 + 128u * g, b[0]);
+      if (g < G) {   // odd count: the last group (its fragments were requested by the pair before it, or by the prologue)
+        v4f bd[2][4], rbd[2][2];
+        mfma_group_kc(a0 + 128u * g, a1 + 128u * g, a0 + 128u * g, a1 + 128u * g, af, b[0], a16 + 128u * g, rb[0],
+                      wpa + 32 * g, wpb + 32 * g, hp0 + 32 * g, hp1 + 32 * g, bd, rbd, rider_tag);
+        asm volatile("" ::"v"(bd[0][0]), "v"(bd[1][3]));
+      }
+      ch_lgkm_wait<0>();   // the last group's look-ahead reads
+      asm volatile("" : "+v"(af[0]), "+v"(af[1]));
     }
     for (int t = 0; t < ntail; ++t) {
       if (t > 0) load_tail(t);
       // tail A fragment: k = 32 G + 8 t + 4 lh + c: the lane-half offset inside a tail group is 4 floats, not 16
       const unsigned off = (unsigned)(32 * G + 8 * t) * 4u - (unsigned)(12 * lh) * 4u;
       mfma_tail(a0 + off, a1 + off, tb0, tb1);
+    }
+    if constexpr (RIDER) {   // the rider's own tail: the k's past the last full group, in guarded 16-k steps
+      for (int kb0 = 32 * G; kb0 < K; kb0 += 16) {
+        const int kb = kb0 + 4 * kq;
+        v4f ra, r0v, r1v = {0.f, 0.f, 0.f, 0.f};
+        ch_rd128(ra, a16 + (unsigned)kb0 * 4u);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          r0v[c] = kb + c < K ? hp0[kb0 + c] : 0.f;
+          if constexpr (two) r1v[c] = kb + c < K ? hp1[kb0 + c] : 0.f;
+        }
+        ch_lgkm_wait<0>();
+        asm volatile("" : "+v"(ra));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float av = kb + c < K ? ra[c] : 0.f;   // image columns past K's 8-padding are not defined
+          hacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, r0v[c], hacc[0], 0, 0, 0);
+          if constexpr (two) hacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, r1v[c], hacc[1], 0, 0, 0);
+        }
+      }
+      asm volatile("" ::"v"(a16));
     }
   };
   // ---------------------------------------------------------------- K-strided weights (dgrad): columns n0 + 2 li + tn
@@ -276,6 +410,28 @@ __global__ __launch_bounds__(CH_THREADS, MINB) void k_chain(const ChainProblem *
     // when the tile also goes to an LDS image, memory is written FROM the image instead, 16 bytes per lane
     const bool wide = out && out_slot >= 0 && ((N | ldo) & 3) == 0 && (reinterpret_cast<uintptr_t>(op.out) & 15) == 0;
     if (out_slot >= 0) __syncthreads();   // every wave has finished reading the images this op may overwrite
+    CH_STAMP();
+    // Fast path (the common case: forward layer, tile inside the matrix and inside the row window, tile goes to an LDS
+    // image and memory is written from there): straight-line, no per-element predicates.  Everything else - partial
+    // tiles, LeakyReLU' masks from memory, column sums, direct global stores - takes the general loop below.
+    const bool fast = !ks && act != CHA_LRELU_GRAD && !colsum && out_slot >= 0 && (!out || wide) && n0 + 64 <= N;
+    if (fast) {
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const int col = n0 + 32 * tn + li;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+          float *dst = &lds[out_slot + (32 * tm + 4 * lh) * out_pitch + col];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float x = acc[tm][tn][r] + bv;
+            if (act == CHA_LRELU) x = fmaxf(x, 0.01f * x);   // == x > 0 ? x : 0.01 x
+            dst[((r & 3) + 8 * (r >> 2)) * out_pitch] = x;
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
       const int col = ks ? n0 + 2 * li + tn : n0 + 32 * tn + li;
@@ -309,6 +465,8 @@ __global__ __launch_bounds__(CH_THREADS, MINB) void k_chain(const ChainProblem *
         if (lh == 0 && cok) colsum[(long long)blk * N + col] = csum + other;
       }
     }
+    }
+    CH_STAMP();
     if (out_slot >= 0) {
       // columns [N, next multiple of 8) of the image stay zero: the next layer's last k-group reads them
       const int npad = ((N + 7) & ~7) - N;
@@ -317,7 +475,12 @@ __global__ __launch_bounds__(CH_THREADS, MINB) void k_chain(const ChainProblem *
         lds[out_slot + r * out_pitch + N + c] = 0.f;
       }
       __syncthreads();
+      CH_STAMP();
       if (wide) {
+        // memory is written from the image, 16 bytes per lane.  (Tried and not kept: trickling this copy out under the
+        // next layer's MFMA steps - the stores cost the K loop what they cost here: a wave's vector-memory operations
+        // retire in order, so the loop's weight loads wait for the stores ahead of them, and with every CU writing its
+        // 64 KB tile at the same moment the burst runs at the chip's HBM write rate either way.)
         const int nq = N >> 2, total = CH_BM * nq;
         for (int base = 0; base < total; base += 8 * CH_THREADS) {
           v4f v[8];
@@ -408,11 +571,21 @@ __global__ __launch_bounds__(CH_THREADS, MINB) void k_chain(const ChainProblem *
 #pragma unroll
           for (int r = 0; r < 16; ++r) { acc[a][0][r] = 0.f; acc[a][1][r] = 0.f; }
       }
+      const float *hw = ch_uni(op.hw);
+      if (hw && (flags & CHF_HBEGIN)) { hacc[0] = v4f{0.f, 0.f, 0.f, 0.f}; hacc[1] = v4f{0.f, 0.f, 0.f, 0.f}; }
       if (n0 < N) {   // wave-uniform: a wave whose 64 columns lie beyond N has no tile
         if (flags & CHF_KS) {
           for (int s = 0; s < nseg; ++s) gemm_seg_ks(op.seg[s], N, n0);
+        } else if (hw) {   // (the builder attaches a rider only when every wave has a tile: N > 192)
+          const int hldw = ch_uni(op.hldw), hN = ch_uni(op.hN);
+          int kcol = 0;
+          for (int s = 0; s < nseg; ++s) {
+            if (hN > 16) gemm_seg_kc(op.seg[s], N, n0, hw + kcol, hldw, hN, std::integral_constant<int, 2>{});
+            else gemm_seg_kc(op.seg[s], N, n0, hw + kcol, hldw, hN, std::integral_constant<int, 1>{});
+            kcol += ch_uni(op.seg[s].K);
+          }
         } else {
-          for (int s = 0; s < nseg; ++s) gemm_seg_kc(op.seg[s], N, n0);
+          for (int s = 0; s < nseg; ++s) gemm_seg_kc(op.seg[s], N, n0, nullptr, 0, 0, std::integral_constant<int, 0>{});
         }
       }
       if (stamp) g_ch_stamps[nstamp++] = __builtin_amdgcn_s_memtime();
@@ -428,62 +601,48 @@ __global__ __launch_bounds__(CH_THREADS, MINB) void k_chain(const ChainProblem *
       if (flags & CHF_BEGIN) { hacc[0] = v4f{0.f, 0.f, 0.f, 0.f}; hacc[1] = v4f{0.f, 0.f, 0.f, 0.f}; }
       const int n0c = min(lj, N - 1), n1c = min(16 + lj, N - 1);   // clamped columns (never stored when shifted)
       const bool two = N > 16;
-      const int wslot = ch_uni(op.slot);   // staging area for the head weights of one segment: [N][wp]
+      int wslot = ch_uni(op.slot);   // this op's weight slices, staged at program start: per segment [N][wp]
       for (int s = 0; s < nseg; ++s) {
-        gcf W = (gcf)ch_uni(op.seg[s].W);
-        const int ldw = ch_uni(op.seg[s].ldw), K = ch_uni(op.seg[s].K), pitch = ch_uni(op.seg[s].pitch), slot = ch_uni(op.seg[s].slot);
-        const int k16 = (K + 15) & ~15, wp = k16 + 4;   // (wp / 4) odd: the 16 rows of a B fragment hit distinct banks
-        // The segment's weight slice -> LDS (one coalesced round, shared by the four waves): read straight from global
-        // memory the fragments of a 16-k step would need a memory round trip per 128 cycles of MFMA.
-        __syncthreads();
-        {
-          const int total = N * k16;
-          for (int base = 0; base < total; base += 8 * CH_THREADS) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              const int e = base + tid + u * CH_THREADS;
-              int n, k;
-              if (!ks) { n = e / k16; k = e - n * k16; } else { k = e / N; n = e - k * N; }
-              v[u] = (e < total && k < K) ? (ks ? W[(long long)k * ldw + n] : W[(long long)n * ldw + k]) : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              const int e = base + tid + u * CH_THREADS;
-              int n, k;
-              if (!ks) { n = e / k16; k = e - n * k16; } else { k = e / N; n = e - k * N; }
-              if (e < total) lds[wslot + n * wp + k] = v[u];
-            }
-          }
-        }
-        __syncthreads();
+        const int K = ch_uni(op.seg[s].K), pitch = ch_uni(op.seg[s].pitch), slot = ch_uni(op.seg[s].slot);
+        const int k16 = (K + 15) & ~15, wp = k16 + 4;
         const unsigned a0 = lds0 + (unsigned)(slot + (16 * wave + lj) * pitch + 4 * kq) * 4u;
         const unsigned w0 = lds0 + (unsigned)(wslot + n0c * wp + 4 * kq) * 4u, w1 = lds0 + (unsigned)(wslot + n1c * wp + 4 * kq) * 4u;
+        wslot += N * wp;
         const int nh = k16 >> 4;
-        v4f a, b0, b1 = {0.f, 0.f, 0.f, 0.f};
-        ch_rd128(a, a0);
-        ch_rd128(b0, w0);
-        if (two) ch_rd128(b1, w1);
-        for (int h = 0; h < nh; ++h) {
-          const int hn = min(h + 1, nh - 1);
-          v4f na, nb0, nb1 = b1;
+        for (int h0 = 0; h0 < nh; h0 += 4) {   // four 16-k steps per pass: 8 or 12 fragment reads in flight, then their MFMAs
+          v4f a[4], b0[4], b1[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const unsigned off = (unsigned)min(h0 + u, nh - 1) * 64u;
+            ch_rd128(a[u], a0 + off);
+            ch_rd128(b0[u], w0 + off);
+            if (two) ch_rd128(b1[u], w1 + off);
+          }
           ch_lgkm_wait<0>();
-          asm volatile("" : "+v"(a), "+v"(b0), "+v"(b1));
-          ch_rd128(na, a0 + (unsigned)hn * 64u);     // next half group's fragments fly under this one's MFMAs
-          ch_rd128(nb0, w0 + (unsigned)hn * 64u);
-          if (two) ch_rd128(nb1, w1 + (unsigned)hn * 64u);
-          if (16 * h + 16 > K) {   // last, partial half group: image columns beyond K's 8-padding are not defined
 #pragma unroll
-            for (int c = 0; c < 4; ++c) a[c] = 16 * h + 4 * kq + c < K ? a[c] : 0.f;
+          for (int u = 0; u < 4; ++u) {
+            asm volatile("" : "+v"(a[u]), "+v"(b0[u]));
+            if (two) asm volatile("" : "+v"(b1[u]));
+            // steps past the end contribute nothing; image columns beyond K's 8-padding are not defined
+            const int kb = 16 * (h0 + u) + 4 * kq;
+            if (16 * (h0 + u) + 16 > K) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) a[u][c] = (h0 + u < nh && kb + c < K) ? a[u][c] : 0.f;
+            }
           }
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            hacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], b0[c], hacc[0], 0, 0, 0);
-            if (two) hacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], b1[c], hacc[1], 0, 0, 0);
-          }
-          a = na; b0 = nb0; b1 = nb1;
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              if (u & 1) {
+                hodd[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][c], b0[u][c], hodd[0], 0, 0, 0);
+                if (two) hodd[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][c], b1[u][c], hodd[1], 0, 0, 0);
+              } else {
+                hacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][c], b0[u][c], hacc[0], 0, 0, 0);
+                if (two) hacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][c], b1[u][c], hacc[1], 0, 0, 0);
+              }
+            }
         }
-        ch_lgkm_wait<0>();
         asm volatile("" ::"v"(a0), "v"(w0), "v"(w1));
       }
       if (flags & CHF_FINISH) {   // D: column l & 15, rows 4 (l >> 4) + reg of the wave's 16
@@ -498,21 +657,23 @@ __global__ __launch_bounds__(CH_THREADS, MINB) void k_chain(const ChainProblem *
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int grow = r0 + 16 * wave + 4 * kq + r;
-              if (grow >= row_lo && grow < row_hi) out[(long long)(grow - shift) * ldo + col] = hacc[t][r] + bv;
+              if (grow >= row_lo && grow < row_hi) out[(long long)(grow - shift) * ldo + col] = (hacc[t][r] + hodd[t][r]) + bv;
             }
           }
         }
+        hodd[0] = v4f{0.f, 0.f, 0.f, 0.f};
+        hodd[1] = v4f{0.f, 0.f, 0.f, 0.f};
       }
     }
     if (stamp) g_ch_stamps[nstamp++] = __builtin_amdgcn_s_memtime();
   }
-  if (stamp) g_ch_stamps[2 * CH_MAX_OPS + 3] = nstamp;
+  if (stamp) g_ch_stamps[8 * CH_MAX_OPS + 3] = nstamp;
 }
 
 int chain_read_stamps(unsigned long long *out, int cap) {
-  unsigned long long h[2 * CH_MAX_OPS + 4];
+  unsigned long long h[8 * CH_MAX_OPS + 4];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ch_stamps), sizeof(h)) != hipSuccess) return -1;
-  const int n = (int)h[2 * CH_MAX_OPS + 3];
+  const int n = (int)h[8 * CH_MAX_OPS + 3];
   for (int i = 0; i < n && i < cap; ++i) out[i] = h[i];
   return n < cap ? n : cap;
 }

@@ -1,6 +1,7 @@
 """Diagnostic: per-operation shader-clock stamps of the middle workgroup of the critic chain launch (config 2)."""
 import ctypes as C, os, sys
 os.environ["FDQL_CHAIN_STAMPS"] = "1"
+os.environ.setdefault("FDQL_CHAIN", "all")
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fastdeepqlearning_amd.core import NativeAgent, make_config
@@ -17,9 +18,9 @@ for _ in range(3): ag.update(xp, seed=1)
 torch.cuda.synchronize()
 names = [n for n, *_ in ag.profile_update(xp, seed=1)]
 lib = nat.load()
-buf = (C.c_uint64 * 64)()
+buf = (C.c_uint64 * 256)()
 # stamps of the LAST chain launch of the update = critics.fwd
 ag.update(xp, seed=1); torch.cuda.synchronize()
-n = lib.fdql_debug_chain_stamps(buf, 64)
+n = lib.fdql_debug_chain_stamps(buf, 256)
 st = [buf[i] for i in range(n)]
 print("stamps:", n, "deltas (cycles):", [st[i + 1] - st[i] for i in range(n - 1)], "total", st[-1] - st[0])
