@@ -1068,6 +1068,41 @@ int build_plan(fdql_agent *a) {
           }
         }
       }
+      // The head's finish.  With the hidden layers' parts already formed (head fusion), what is left per instance is
+      // cat(s, a) . Wh[:, inputs] + the parts + the bias: a row-per-wave kernel for all instances (k_head_finish)
+      // instead of a partial-sum reduction launch plus a head GEMM streaming cat(s, a) through padded tiles.
+      bool finished = false;
+      if (fuse && C * Q <= 16 && A <= 16 && C <= HEAD_FINISH_MAX_SETS && getenv("FDQL_NO_HEAD_FINISH") == nullptr) {
+        HeadFinishArgs ha;
+        memset(&ha, 0, sizeof(ha));
+        ha.M = M; ha.L = L; ha.A = A; ha.Q = Q; ha.planes = a->hf_planes; ha.ngroups = 2;
+        bool okf = true;
+        for (int k = 0; k < C; ++k)
+          for (MlpInst *m : {&ct[k], &co[k], &cf[k]}) okf = okf && m->in.size() == 2 && m->in[0].width == L && m->in[1].width == A;
+        if (okf) {
+          HeadFinishGroup &gc = ha.g[0], &gn = ha.g[1];   // group 0: s_cur (online + frozen, one weight set per critic); 1: s_next (targets)
+          gc.s = co[0].in[0].ptr; gc.lds = co[0].in[0].ld; gc.nsets = C; gc.nvar = 2; gc.ldw = a->critic[0].head_ld();
+          gc.a[0] = co[0].in[1].ptr; gc.lda[0] = co[0].in[1].ld; gc.out[0] = a->buf("q_pred"); gc.ldo[0] = Nq;
+          gc.a[1] = cf[0].in[1].ptr; gc.lda[1] = cf[0].in[1].ld; gc.out[1] = a->buf("q_frozen"); gc.ldo[1] = Nq;
+          gn.s = ct[0].in[0].ptr; gn.lds = ct[0].in[0].ld; gn.nsets = C; gn.nvar = 1; gn.ldw = a->critic[0].head_ld();
+          gn.a[0] = ct[0].in[1].ptr; gn.lda[0] = ct[0].in[1].ld; gn.out[0] = a->buf("next_z"); gn.ldo[0] = Nq;
+          for (int k = 0; k < C; ++k) {
+            okf = okf && co[k].HW() == cf[k].HW() && a->critic[k].head_ld() == gc.ldw;   // frozen reads the online weights
+            gc.Wh[k] = co[k].HW(); gc.bias[k] = co[k].HB();
+            gn.Wh[k] = ct[k].HW(); gn.bias[k] = ct[k].HB();
+            gc.parts[k][0] = hf_sum + (long long)inst_id(k, 1) * MQ;
+            gc.parts[k][1] = hf_sum + (long long)inst_id(k, 2) * MQ;
+            gn.parts[k][0] = hf_sum + (long long)inst_id(k, 0) * MQ;
+          }
+        }
+        if (okf) {
+          const int ninst = 3 * C, planes = a->hf_planes;
+          b.func_stage("critics.head_sum", [=](hipStream_t s) { return reduce_partials_batched_launch(hf_parts, ninst, planes, MQ, hf_sum, s); });
+          b.func_stage("critics.head", [=](hipStream_t s) { return head_finish_launch(ha, s); });
+          finished = true;
+        }
+      }
+      if (!finished) {
       if (fuse) {
         const int ninst = 3 * C, planes = a->hf_planes;
         b.func_stage("critics.head_sum", [=](hipStream_t s) { return reduce_partials_batched_launch(hf_parts, ninst, planes, MQ, hf_sum, s); });
@@ -1081,6 +1116,7 @@ int build_plan(fdql_agent *a) {
           ++which;
           hs.gemm.push_back(p);
         }
+      }
       }
     } else {
       std::vector<MlpInst *> g;

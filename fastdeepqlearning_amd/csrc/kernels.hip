@@ -912,6 +912,106 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const float *__restrict
   if (pl == 0 && e < n) dst[e] = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
 }
 
+// see update_kernels.h: the critics' head finish.  grid (ceil(M / 16), groups), one wave = 16 rows per workgroup.
+// v_mfma_f32_16x16x4_f32: lane l holds A[row l & 15][k = 4 (l >> 4) + c] and B[k][column l & 15] for step c of a 16-k
+// block; D: column l & 15, rows 4 (l >> 4) + reg.
+typedef float hf_v4f __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(64) void k_head_finish(HeadFinishArgs a) {
+  const HeadFinishGroup &G = a.g[blockIdx.y];
+  const int lane = threadIdx.x & 63;
+  const int L = a.L, A = a.A, Q = a.Q, M = a.M;
+  const int i = lane & 15, kq = lane >> 4;
+  const int row0 = blockIdx.x * 16;
+  if (row0 >= M) return;
+  const int set = i / Q, q = i - set * Q;
+  const bool nok = set < G.nsets;                      // this lane's head column exists
+  // per-lane table entries picked by compares from wave-uniform (scalar) loads of the whole table: indexing the kernel
+  // argument with a per-lane index is a vector load from memory - a dependent round trip before the first real load
+  const float *wsel = G.Wh[0], *bsel = G.bias[0], *psel0 = G.parts[0][0], *psel1 = G.parts[0][1];
+#pragma unroll
+  for (int k = 1; k < HEAD_FINISH_MAX_SETS; ++k) {
+    const bool m = set == k;
+    wsel = m ? G.Wh[k] : wsel; bsel = m ? G.bias[k] : bsel; psel0 = m ? G.parts[k][0] : psel0; psel1 = m ? G.parts[k][1] : psel1;
+  }
+  const float *wrow = wsel + (long long)q * G.ldw;
+  const float *srow = G.s + (long long)min(row0 + i, M - 1) * G.lds;
+  // everything the wave needs from memory is requested before the first MFMA: the action blocks, the summed parts and
+  // the bias here, the state / weight rows below (a wave is 16 rows: its time is memory round trips, not arithmetic)
+  float aval[2][4], wact[4], pval[2][4], bq = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) wact[c] = (nok && 4 * kq + c < A) ? wrow[L + 4 * kq + c] : 0.f;   // (A <= 16 on this path)
+#pragma unroll
+  for (int v = 0; v < 2; ++v) {
+    const bool vok = v < G.nvar;
+    const float *arow = vok ? G.a[v] + (long long)min(row0 + i, M - 1) * G.lda[v] : nullptr;
+    const float *pp = (vok && nok) ? (v == 0 ? psel0 : psel1) : nullptr;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) aval[v][c] = (vok && 4 * kq + c < A) ? arow[4 * kq + c] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + 4 * kq + r;
+      pval[v][r] = (pp && row < M) ? pp[(long long)row * Q + q] : 0.f;
+    }
+  }
+  if (nok) bq = bsel[q];
+  hf_v4f acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // even / odd 16-k blocks: two independent MFMA chains
+  const bool vec = (L & 15) == 0 && ((G.lds | G.ldw) & 3) == 0 && ((reinterpret_cast<uintptr_t>(G.s) | reinterpret_cast<uintptr_t>(wrow)) & 15) == 0;
+  if (vec) {   // whole 16-k blocks, 16-byte aligned rows: one dwordx4 per operand and block, sixteen blocks in flight
+    const hf_v4f *sp = reinterpret_cast<const hf_v4f *>(srow) + kq, *wp = reinterpret_cast<const hf_v4f *>(wrow) + kq;
+    for (int k0 = 0; k0 < L; k0 += 256) {
+      hf_v4f av[16], bv[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int blk = min((k0 >> 4) + u, (L >> 4) - 1);
+        av[u] = sp[4 * blk];
+        bv[u] = nok ? wp[4 * blk] : hf_v4f{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 16; u += 2) {
+        if (k0 + 16 * u < L) {   // uniform
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][c], bv[u][c], acc, 0, 0, 0);
+        }
+        if (k0 + 16 * (u + 1) < L) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u + 1][c], bv[u + 1][c], acc2, 0, 0, 0);
+        }
+      }
+    }
+  } else {
+    for (int k0 = 0; k0 < L; k0 += 16) {
+      const int kb = k0 + 4 * kq;
+      float av[4], bv[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        av[c] = kb + c < L ? srow[kb + c] : 0.f;
+        bv[c] = (nok && kb + c < L) ? wrow[kb + c] : 0.f;
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], bv[c], acc, 0, 0, 0);
+    }
+  }
+  acc += acc2;
+  for (int v = 0; v < G.nvar; ++v) {
+    hf_v4f accv = acc;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) accv = __builtin_amdgcn_mfma_f32_16x16x4f32(v == 0 ? aval[0][c] : aval[1][c], wact[c], accv, 0, 0, 0);
+    if (nok) {
+      float *out = G.out[v];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + 4 * kq + r;
+        if (row < M) out[(long long)row * G.ldo[v] + set * Q + q] = (accv[r] + (v == 0 ? pval[0][r] : pval[1][r])) + bq;
+      }
+    }
+  }
+}
+hipError_t head_finish_launch(const HeadFinishArgs &a, hipStream_t s) {
+  if (a.M <= 0 || a.ngroups <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_head_finish, dim3((unsigned)((a.M + 15) / 16), (unsigned)a.ngroups), dim3(64), 0, s, a);
+  return hipGetLastError();
+}
+
 hipError_t colsum_tall_launch(const float *X, long long R, int C, int ld, float *partial, hipStream_t s) {
   if (R <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_colsum_tall, dim3(colsum_tall_blocks(R)), dim3(256), 0, s, X, R, C, ld, partial);

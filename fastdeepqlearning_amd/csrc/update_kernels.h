@@ -131,6 +131,32 @@ hipError_t colsum_tall_launch(const float *X, long long R, int C, int ld, float 
 hipError_t reduce_partials_launch(const float *part, int nparts, long long n, float *dst, hipStream_t s);
 // the same for `ninst` independent instances laid out back to back: part [ninst][nparts][n] -> dst [ninst][n]
 hipError_t reduce_partials_batched_launch(const float *part, int ninst, int nparts, long long n, float *dst, hipStream_t s);
+
+// Finish of the critics' skip heads when the hidden layers' parts were formed in the producing GEMMs' epilogues
+// (head fusion): out[row, k*Q + q] = bias_k[q] + cat(s, a)[row] . Wh_k[q, 0 : L + A] + sum over planes of parts[plane][row][q].
+// ONE launch for all 3C instances instead of a partial-sum reduction launch plus a head GEMM that streams cat(s, a)
+// once per instance (198 MB at config 2): instances that share their state rows form a group - online and frozen
+// critics read s_cur with the SAME weights (critic_frozen is the copy taken when the actor loss is formed), the targets
+// read s_next - and a wave multiplies 16 state rows by all C*Q <= 16 head columns of the group at once
+// (v_mfma_f32_16x16x4_f32, operands straight from global memory), so every state row is read once per group.
+constexpr int HEAD_FINISH_MAX_SETS = 16;
+struct HeadFinishGroup {
+  const float *s;                            // state rows [M, lds], L columns
+  int lds, nsets, nvar;                      // nsets weight sets (critics), nvar instances per set that differ in the action block
+  const float *Wh[HEAD_FINISH_MAX_SETS];     // head weight of set k: row q at Wh[k][q*ldw + col], input columns first (L state, A action)
+  const float *bias[HEAD_FINISH_MAX_SETS];
+  int ldw;
+  const float *a[2];                         // per variant: action rows [M, lda[v]], A columns
+  int lda[2];
+  float *out[2];                             // per variant: [M, ldo[v]], set k writes columns k*Q .. k*Q+Q-1
+  int ldo[2];
+  const float *parts[HEAD_FINISH_MAX_SETS][2];   // per (set, variant): [M][Q], the hidden layers' parts with the planes summed
+};
+struct HeadFinishArgs {
+  int M, L, A, Q, planes, ngroups;
+  HeadFinishGroup g[2];
+};
+hipError_t head_finish_launch(const HeadFinishArgs &a, hipStream_t s);
 // ---- GRU joiner (torch.nn.GRU cell, gate order r, z, n; encoder.py:40-42)
 // start state of the scan: mode 0 zeros, 1 rows copied from src [B, L], 2 src [L] repeated over the batch
 hipError_t gru_h0_launch(int mode, const float *src, float *h0, int B, int L, hipStream_t s);
