@@ -60,7 +60,8 @@ class Batch(C.Structure):
 
 class AgentStats(C.Structure):
     _fields_ = [("gemm_flops", C.c_double), ("skinny_flops", C.c_double), ("n_launches", C.c_int32),
-                ("n_gemm_launches", C.c_int32), ("params", C.c_int64), ("plans_built", C.c_int64)]
+                ("n_gemm_launches", C.c_int32), ("params", C.c_int64), ("plans_built", C.c_int64),
+                ("graph_launches", C.c_int64)]
 
 
 class KernelTime(C.Structure):

@@ -362,7 +362,8 @@ class NativeAgent:
         s = N.AgentStats()
         N.check(self.lib.fdql_agent_stats(self.handle, C.byref(s)))
         return {"gemm_flops": s.gemm_flops, "skinny_flops": s.skinny_flops, "n_launches": s.n_launches,
-                "n_gemm_launches": s.n_gemm_launches, "params": s.params, "plans_built": s.plans_built}
+                "n_gemm_launches": s.n_gemm_launches, "params": s.params, "plans_built": s.plans_built,
+                "graph_launches": s.graph_launches}
 
     def set_alpha(self, alpha):
         N.check(self.lib.fdql_agent_set_alpha(self.handle, float(alpha), N.current_stream(self.device)))

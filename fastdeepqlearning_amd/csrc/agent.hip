@@ -110,7 +110,12 @@ struct Stage {
   int blocks = 0;
   double flops = 0, bytes = 0;
   int phase = FDQL_PHASE_GRAD;
+  int when = 0;   // 0: whenever its phase runs; 1: only in a split (GRAD / APPLY) call; 2: only in a FDQL_PHASE_ALL call
   std::function<hipError_t(hipStream_t)> fn;
+  bool runs_in(int call_phase) const {
+    if (call_phase == FDQL_PHASE_ALL) return when != 1;
+    return phase == call_phase && when != 2;
+  }
 };
 
 }  // namespace fdql
@@ -155,7 +160,26 @@ struct fdql_agent {
   bool plan_ready = false;
   std::vector<Stage> stages;
   void *tables_dev = nullptr;
-  struct CachedPlan { fdql_batch_t batch; std::vector<Stage> stages; void *tables_dev; };
+  // hipGraph of one FDQL_PHASE_ALL update of a plan: captured on `cap_stream` the second time the plan runs with the
+  // same per-call values (seed, noise pointers), replayed on the caller's stream from then on.  Everything that changes
+  // from step to step (optimiser step, Philox counter, lagged alpha) lives in device memory, so the node parameters
+  // never change; other per-call values fall back to the eager launch list.
+  struct PlanGraph {
+    hipGraphExec_t exec = nullptr;
+    uint64_t seed = 0;
+    const float *noise_t = nullptr, *noise_a = nullptr;
+    int eager_runs = 0;   // eager FDQL_PHASE_ALL runs of this plan with the key above
+    void reset() {
+      if (exec) (void)hipGraphExecDestroy(exec);
+      exec = nullptr;
+      eager_runs = 0;
+    }
+  };
+  PlanGraph graph;
+  hipStream_t cap_stream = nullptr;
+  int use_graph = 0;    // FDQL_GRAPH (read at create): "1" replay, default eager launches
+  long long graph_launches = 0;
+  struct CachedPlan { fdql_batch_t batch; std::vector<Stage> stages; void *tables_dev; PlanGraph graph; };
   std::vector<CachedPlan> plan_cache;   // most recently stashed last
   long long plans_built = 0;
   const float *noise_t = nullptr, *noise_a = nullptr;  // per-call (read by the policy stage lambdas)
@@ -1157,7 +1181,9 @@ int build_plan(fdql_agent *a) {
     float *scal = a->buf("scalars");
     float *dla = a->buf("slabs") + a->log_alpha_off;
     const float *parts = la.partials;
-    b.func_stage("loss_finish", [=](hipStream_t s) { return loss_finish_launch(parts, nblocks, M, Nq, dst, scal, dla, s); });
+    // also the Adam bias corrections of the step about to be applied (torch.optim.Adam's Python floats)
+    const double lr = c.lr, b1 = c.beta1, b2 = c.beta2;
+    b.func_stage("loss_finish", [=](hipStream_t s) { return loss_finish_launch(parts, nblocks, M, Nq, dst, scal, dla, lr, b1, b2, s); });
   }
   // ---- critic backward (online: wgrad + d state; frozen: d pi only)
   {
@@ -1382,7 +1408,9 @@ int build_plan(fdql_agent *a) {
     float *grads = a->grads;
     const int S = a->nsplit;
     const long long P = a->n_train;
-    b.func_stage("reduce_slabs", [=](hipStream_t s) { return reduce_slabs_launch(slabs, S, P, grads, s); });
+    // a split call (data-parallel: the all-reduce sits between the phases) sums the slabs into grads here; the
+    // single-process step forms the sum inside k_adam_polyak
+    b.func_stage("reduce_slabs", [=](hipStream_t s) { return reduce_slabs_launch(slabs, S, P, grads, s); }).when = 1;
   }
   // ---- Adam + polyak (+ frozen copy)
   {
@@ -1394,9 +1422,10 @@ int build_plan(fdql_agent *a) {
     ad.eps = (float)c.adam_eps; ad.st = dst; ad.targets = a->targets; ad.tgt_begin = a->tgt_begin; ad.tgt_end = a->tgt_end;
     ad.tau = (float)c.tau; ad.one_minus_tau = (float)(1.0 - c.tau); ad.hard = c.hard_updates;
     ad.frozen = c.keep_frozen_copy ? a->frozen : nullptr; ad.frozen_begin = a->crit_begin; ad.frozen_end = a->crit_end;
-    const double lr = c.lr, b1 = c.beta1, b2 = c.beta2;
-    b.func_stage("tick_adam", [=](hipStream_t s) { return tick_adam_launch(dst, lr, b1, b2, s); }, FDQL_PHASE_APPLY);
-    b.func_stage("adam_polyak", [=](hipStream_t s) { return adam_launch(ad, s); }, FDQL_PHASE_APPLY);
+    b.func_stage("adam_polyak", [=](hipStream_t s) { return adam_launch(ad, s); }, FDQL_PHASE_APPLY).when = 1;
+    AdamArgs af = ad;
+    af.slabs = a->buf("slabs"); af.nslab = a->nsplit; af.grads_out = a->grads;
+    b.func_stage("adam_polyak", [=](hipStream_t s) { return adam_launch(af, s); }, FDQL_PHASE_APPLY).when = 2;
   }
   int rc = upload_tables(a);
   if (rc) return rc;
@@ -1423,6 +1452,30 @@ hipError_t run_stage(fdql_agent *a, Stage &s, hipStream_t stream) {
   return hipSuccess;
 }
 
+// Records the FDQL_PHASE_ALL launch list of the current plan into a graph (nothing executes during the capture).
+int capture_update(fdql_agent *a) {
+  if (!a->cap_stream) FDQL_HIP(hipStreamCreateWithFlags(&a->cap_stream, hipStreamNonBlocking));
+  FDQL_HIP(hipStreamBeginCapture(a->cap_stream, hipStreamCaptureModeThreadLocal));
+  hipError_t bad = hipSuccess;
+  const char *where = "";
+  for (Stage &st : a->stages) {
+    if (!st.runs_in(FDQL_PHASE_ALL)) continue;
+    bad = run_stage(a, st, a->cap_stream);
+    if (bad != hipSuccess) { where = st.name.c_str(); break; }
+  }
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamEndCapture(a->cap_stream, &graph);
+  if (bad != hipSuccess || e != hipSuccess) {
+    if (graph) (void)hipGraphDestroy(graph);
+    set_error("graph capture%s%s: %s", where[0] ? " at stage " : "", where, hipGetErrorString(bad != hipSuccess ? bad : e));
+    return FDQL_EHIP;
+  }
+  e = hipGraphInstantiate(&a->graph.exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) { a->graph.exec = nullptr; set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return FDQL_EHIP; }
+  return 0;
+}
+
 int prepare_update(fdql_agent *a, const fdql_batch_t *batch, const float *noise_target, const float *noise_actor,
                    uint64_t seed) {
   if (!a || !a->bound) { set_error("fdql_agent_update: agent not bound"); return FDQL_ESTATE; }
@@ -1436,11 +1489,13 @@ int prepare_update(fdql_agent *a, const fdql_batch_t *batch, const float *noise_
                "GRU joiner in store mode needs batch.agent_state");
   if (!a->plan_ready || memcmp(&a->batch, batch, sizeof(*batch)) != 0) {
     if (a->plan_ready) {   // keep the plan being replaced
-      a->plan_cache.push_back({a->batch, std::move(a->stages), a->tables_dev});
+      a->plan_cache.push_back({a->batch, std::move(a->stages), a->tables_dev, a->graph});
+      a->graph = fdql_agent::PlanGraph();
       a->tables_dev = nullptr;
       a->plan_ready = false;
       if (a->plan_cache.size() > PLAN_CACHE_MAX) {
         (void)hipFree(a->plan_cache.front().tables_dev);   // synchronises: nothing still reads the evicted tables
+        a->plan_cache.front().graph.reset();
         a->plan_cache.erase(a->plan_cache.begin());
       }
     }
@@ -1450,12 +1505,14 @@ int prepare_update(fdql_agent *a, const fdql_batch_t *batch, const float *noise_
       a->batch = *batch;
       a->stages = std::move(a->plan_cache[i].stages);
       a->tables_dev = a->plan_cache[i].tables_dev;
+      a->graph = a->plan_cache[i].graph;
       a->plan_cache.erase(a->plan_cache.begin() + i);
       a->plan_ready = true;
       break;
     }
     if (!a->plan_ready) {
       a->batch = *batch;
+      a->graph = fdql_agent::PlanGraph();
       int rc = build_plan(a);
       if (rc) return rc;
       ++a->plans_built;
@@ -1516,6 +1573,12 @@ int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {
                "SoftActorCritic.q_loss under use_nStep_lowerbounds)");
   fdql_agent *a = new fdql_agent();
   a->cfg = c;
+  {
+    // measured on ROCm 7.2 / MI355X: the replay is 0.5-1.5 % SLOWER than the eager launch list at
+    // T=50 and at T=2 - the step is bound by its kernels' own latency, the host stays ahead of the queue - so it is opt-in
+    const char *e = getenv("FDQL_GRAPH");
+    a->use_graph = e && e[0] == '1';
+  }
   a->T = c.T; a->B = c.B; a->N = c.T * c.B; a->M = (c.T - 1) * c.B; a->A = c.act_dim; a->L = c.latent;
   a->Nq = c.n_critics * c.n_quantiles;
   if (c.distributional) {
@@ -1543,7 +1606,9 @@ int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {
 int fdql_agent_destroy(fdql_agent_t *a) {
   if (!a) return 0;
   if (a->tables_dev) (void)hipFree(a->tables_dev);
-  for (auto &c : a->plan_cache) (void)hipFree(c.tables_dev);
+  a->graph.reset();
+  for (auto &c : a->plan_cache) { (void)hipFree(c.tables_dev); c.graph.reset(); }
+  if (a->cap_stream) (void)hipStreamDestroy(a->cap_stream);
   delete a;
   return 0;
 }
@@ -1597,7 +1662,8 @@ int fdql_agent_bind(fdql_agent_t *a, float *params, float *grads, float *adam_m,
   FDQL_HIP(hipDeviceSynchronize());
   a->bound = true;
   a->plan_ready = false;
-  for (auto &c : a->plan_cache) (void)hipFree(c.tables_dev);
+  a->graph.reset();
+  for (auto &c : a->plan_cache) { (void)hipFree(c.tables_dev); c.graph.reset(); }
   a->plan_cache.clear();
   return 0;
 }
@@ -1614,8 +1680,25 @@ int fdql_agent_update(fdql_agent_t *a, const fdql_batch_t *batch, const float *n
     return FDQL_ESTATE;
   }
   hipStream_t s = (hipStream_t)stream;
+  if (phase == FDQL_PHASE_ALL && a->use_graph) {
+    fdql_agent::PlanGraph &g = a->graph;
+    if (g.seed != a->seed || g.noise_t != a->noise_t || g.noise_a != a->noise_a) {
+      g.reset();
+      g.seed = a->seed; g.noise_t = a->noise_t; g.noise_a = a->noise_a;
+    }
+    if (!g.exec && g.eager_runs >= 1) {   // the first run stays eager: one-time set-up inside the launchers happens there
+      int rc = capture_update(a);
+      if (rc) return rc;
+    }
+    if (g.exec) {
+      FDQL_HIP(hipGraphLaunch(g.exec, s));
+      ++a->graph_launches;
+      return 0;
+    }
+    ++g.eager_runs;
+  }
   for (Stage &st : a->stages) {
-    if (phase != FDQL_PHASE_ALL && st.phase != phase) continue;
+    if (!st.runs_in(phase)) continue;
     hipError_t e = run_stage(a, st, s);
     if (e != hipSuccess) { set_error("stage %s: %s", st.name.c_str(), hipGetErrorString(e)); return FDQL_EHIP; }
   }
@@ -1634,6 +1717,7 @@ int32_t fdql_agent_profile_update(fdql_agent_t *a, const fdql_batch_t *batch, co
   struct Part { Stage *st; int shape; };
   std::vector<Part> parts;
   for (Stage &st : a->stages) {
+    if (!st.runs_in(FDQL_PHASE_ALL)) continue;
     if (st.kind == ST_GEMM) {
       for (int sh = 0; sh < GEMM_NSHAPES; ++sh)
         if (st.sub[sh].blocks > 0) parts.push_back({&st, sh});
@@ -1865,7 +1949,9 @@ int fdql_agent_stats(const fdql_agent_t *a, fdql_agent_stats_t *out) {
   memset(out, 0, sizeof(*out));
   out->params = a->n_train;
   out->plans_built = a->plans_built;
+  out->graph_launches = a->graph_launches;
   for (const Stage &s : a->stages) {
+    if (!s.runs_in(FDQL_PHASE_ALL)) continue;
     out->n_launches++;
     if (s.kind == ST_GEMM) {
       out->gemm_flops += s.flops;

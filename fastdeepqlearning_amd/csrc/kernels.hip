@@ -262,10 +262,12 @@ __global__ __launch_bounds__(256) void k_prep(const float *__restrict__ task_don
 // tick: optimiser step counter, Adam bias corrections (double, like the Python floats in
 // torch.optim.Adam), and the one-step-lagged alpha (soft_actor_critic.py:41,152)
 // ======================================================================================
-__global__ void k_tick_adam(DevState *st, double lr, double b1, double b2) {
-  st->step += 1;
-  const double bc1 = 1.0 - pow(b1, (double)st->step);
-  const double bc2 = 1.0 - pow(b2, (double)st->step);
+// Runs on one thread of k_loss_finish (the step's one single-block kernel): corrections of the step ABOUT to be
+// applied, step + 1; the counter itself is advanced by k_adam_polyak.
+__device__ void tick_adam(DevState *st, double lr, double b1, double b2) {
+  const double step = (double)(st->step + 1);
+  const double bc1 = 1.0 - pow(b1, step);
+  const double bc2 = 1.0 - pow(b2, step);
   st->neg_step_size = (float)(-(lr / bc1));
   st->bc2_sqrt = (float)sqrt(bc2);
 }
@@ -591,9 +593,10 @@ hipError_t loss_launch(const LossArgs &a, hipStream_t s) {
 
 // Sums the per-block partials in a fixed order; publishes the scalars and d log_alpha.
 __global__ __launch_bounds__(256) void k_loss_finish(const float *__restrict__ partials, int nblocks, int M, int Nq,
-                                                     const DevState *st, float *__restrict__ scalars,
-                                                     float *__restrict__ dlog_alpha) {
+                                                     DevState *st, float *__restrict__ scalars,
+                                                     float *__restrict__ dlog_alpha, double lr, double b1, double b2) {
   __shared__ float red[256][LOSS_NPART];
+  if (threadIdx.x == 255) tick_adam(st, lr, b1, b2);
   const int tid = threadIdx.x;
   float acc[LOSS_NPART];
 #pragma unroll
@@ -663,9 +666,9 @@ hipError_t boot_lowerbound_launch(const BootArgs &a, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t loss_finish_launch(const float *partials, int nblocks, int M, int Nq, const DevState *st, float *scalars,
-                              float *dlog_alpha, hipStream_t s) {
-  hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(256), 0, s, partials, nblocks, M, Nq, st, scalars, dlog_alpha);
+hipError_t loss_finish_launch(const float *partials, int nblocks, int M, int Nq, DevState *st, float *scalars,
+                              float *dlog_alpha, double lr, double b1, double b2, hipStream_t s) {
+  hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(256), 0, s, partials, nblocks, M, Nq, st, scalars, dlog_alpha, lr, b1, b2);
   return hipGetLastError();
 }
 
@@ -691,28 +694,78 @@ hipError_t reduce_slabs_launch(const float *slabs, int nslab, long long n, float
   return hipGetLastError();
 }
 
-__global__ void k_adam_polyak(AdamArgs a) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.n) return;
-  const float g = a.grads[i] * a.grad_scale;
-  const float p = a.params[i];
-  float m = a.m[i], v = a.v[i];
-  m = m + a.one_minus_b1 * (g - m);                 // exp_avg.lerp_(grad, 1 - beta1)
-  v = v * a.b2 + (a.one_minus_b2 * g) * g;          // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
-  const float denom = sqrtf(v) / a.st->bc2_sqrt + a.eps;
-  const float pn = p + (a.st->neg_step_size * m) / denom;   // param.addcdiv_(m, denom, -step_size)
-  a.m[i] = m;
-  a.v[i] = v;
-  a.params[i] = pn;
-  if (i >= a.tgt_begin && i < a.tgt_end) {          // common.py:10-19
-    const long long j = i - a.tgt_begin;
-    a.targets[j] = a.hard ? pn : a.targets[j] * a.one_minus_tau + pn * a.tau;
+// One thread per 4 parameters (the arena length is a multiple of 4).  a.slabs != null (single-process step): the
+// K-split slab sum (k_reduce_slabs' order) is formed here and written to grads on the way.  Thread 0 advances the optimiser step.
+__global__ __launch_bounds__(256) void k_adam_polyak(AdamArgs a) {
+  const long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long n4 = a.n / 4;
+  const float bc2_sqrt = a.st->bc2_sqrt, neg_step_size = a.st->neg_step_size;
+  if (i4 < n4) {
+    float4 gv;
+    if (a.slabs) {
+      const float4 *sl = reinterpret_cast<const float4 *>(a.slabs) + i4;
+      gv = sl[0];
+      int k = 1;
+      for (; k + 4 <= a.nslab; k += 4) {   // four loads in flight, added in slab order
+        const float4 v0 = sl[(long long)k * n4], v1 = sl[(long long)(k + 1) * n4], v2 = sl[(long long)(k + 2) * n4],
+                     v3 = sl[(long long)(k + 3) * n4];
+        gv.x += v0.x; gv.y += v0.y; gv.z += v0.z; gv.w += v0.w;
+        gv.x += v1.x; gv.y += v1.y; gv.z += v1.z; gv.w += v1.w;
+        gv.x += v2.x; gv.y += v2.y; gv.z += v2.z; gv.w += v2.w;
+        gv.x += v3.x; gv.y += v3.y; gv.z += v3.z; gv.w += v3.w;
+      }
+      for (; k < a.nslab; ++k) {
+        const float4 v = sl[(long long)k * n4];
+        gv.x += v.x; gv.y += v.y; gv.z += v.z; gv.w += v.w;
+      }
+      reinterpret_cast<float4 *>(a.grads_out)[i4] = gv;
+    } else {
+      gv = reinterpret_cast<const float4 *>(a.grads)[i4];
+    }
+    const float4 pv = reinterpret_cast<const float4 *>(a.params)[i4];
+    float4 mv = reinterpret_cast<const float4 *>(a.m)[i4], vv = reinterpret_cast<const float4 *>(a.v)[i4], pnv;
+    const float gs[4] = {gv.x, gv.y, gv.z, gv.w}, ps[4] = {pv.x, pv.y, pv.z, pv.w};
+    float ms[4] = {mv.x, mv.y, mv.z, mv.w}, vs[4] = {vv.x, vv.y, vv.z, vv.w}, pn[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float g = gs[c] * a.grad_scale;
+      ms[c] = ms[c] + a.one_minus_b1 * (g - ms[c]);           // exp_avg.lerp_(grad, 1 - beta1)
+      vs[c] = vs[c] * a.b2 + (a.one_minus_b2 * g) * g;        // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+      const float denom = sqrtf(vs[c]) / bc2_sqrt + a.eps;
+      pn[c] = ps[c] + (neg_step_size * ms[c]) / denom;        // param.addcdiv_(m, denom, -step_size)
+    }
+    mv = make_float4(ms[0], ms[1], ms[2], ms[3]);
+    vv = make_float4(vs[0], vs[1], vs[2], vs[3]);
+    pnv = make_float4(pn[0], pn[1], pn[2], pn[3]);
+    reinterpret_cast<float4 *>(a.m)[i4] = mv;
+    reinterpret_cast<float4 *>(a.v)[i4] = vv;
+    reinterpret_cast<float4 *>(a.params)[i4] = pnv;
+    const long long i0 = i4 * 4;
+    if (i0 + 3 >= a.tgt_begin && i0 < a.tgt_end) {            // common.py:10-19
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const long long i = i0 + c;
+        if (i >= a.tgt_begin && i < a.tgt_end) {
+          const long long j = i - a.tgt_begin;
+          a.targets[j] = a.hard ? pn[c] : a.targets[j] * a.one_minus_tau + pn[c] * a.tau;
+        }
+      }
+    }
+    if (a.frozen && i0 + 3 >= a.frozen_begin && i0 < a.frozen_end) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const long long i = i0 + c;
+        if (i >= a.frozen_begin && i < a.frozen_end) a.frozen[i - a.frozen_begin] = ps[c];
+      }
+    }
   }
-  if (a.frozen && i >= a.frozen_begin && i < a.frozen_end) a.frozen[i - a.frozen_begin] = p;
+  // the step counter: nothing in this kernel reads it (the corrections above were derived from step + 1 by
+  // k_loss_finish), so one thread can advance it without ordering against the other workgroups
+  if (i4 == 0) a.st->step += 1;
 }
 
 hipError_t adam_launch(const AdamArgs &a, hipStream_t s) {
-  const int blocks = (int)((a.n + 255) / 256);
+  const int blocks = (int)((a.n / 4 + 255) / 256);
   hipLaunchKernelGGL(k_adam_polyak, dim3(blocks), dim3(256), 0, s, a);
   return hipGetLastError();
 }
@@ -721,11 +774,6 @@ hipError_t prep_launch(const float *task_done, const float *episode_step, int T,
                        float inv_gb, float *w, float *contig, DevState *st, const float *log_alpha, hipStream_t s) {
   hipLaunchKernelGGL(k_prep, dim3((B + 15) / 16), dim3(256), 0, s, task_done, episode_step, T, B, burn_in, cumprod, inv_gb, w,
                      contig, st, log_alpha);
-  return hipGetLastError();
-}
-
-hipError_t tick_adam_launch(DevState *st, double lr, double b1, double b2, hipStream_t s) {
-  hipLaunchKernelGGL(k_tick_adam, dim3(1), dim3(1), 0, s, st, lr, b1, b2);
   return hipGetLastError();
 }
 

@@ -9,8 +9,8 @@ struct DevState {
   int step;             // optimiser step (torch.optim.Adam state['step'])
   float alpha_cur;      // exp(log_alpha) as of the previous step (soft_actor_critic.py:41,152)
   float alpha_next;
-  float neg_step_size;  // -lr / (1 - beta1^step)
-  float bc2_sqrt;       // sqrt(1 - beta2^step)
+  float neg_step_size;  // -lr / (1 - beta1^(step+1)): of the step about to be applied (k_loss_finish)
+  float bc2_sqrt;       // sqrt(1 - beta2^(step+1))
   float pad[3];
 };
 
@@ -50,8 +50,11 @@ struct AdamArgs {
   long long n;
   float *params, *m, *v;
   const float *grads;
+  const float *slabs;   // optional [nslab][n]: gradient = sum of the slabs (written to grads_out), else read from grads
+  float *grads_out;
+  int nslab;
   float grad_scale, one_minus_b1, b2, one_minus_b2, eps;
-  const DevState *st;
+  DevState *st;
   float *targets;
   long long tgt_begin, tgt_end;
   float tau, one_minus_tau;
@@ -103,8 +106,8 @@ struct BootArgs {
   float *partial_row;           // [LOSS_NPART]
 };
 hipError_t boot_lowerbound_launch(const BootArgs &a, hipStream_t s);
-hipError_t loss_finish_launch(const float *partials, int nblocks, int M, int Nq, const DevState *st, float *scalars,
-                              float *dlog_alpha, hipStream_t s);
+hipError_t loss_finish_launch(const float *partials, int nblocks, int M, int Nq, DevState *st, float *scalars,
+                              float *dlog_alpha, double lr, double b1, double b2, hipStream_t s);
 hipError_t reduce_slabs_launch(const float *slabs, int nslab, long long n, float *grads, hipStream_t s);
 hipError_t adam_launch(const AdamArgs &a, hipStream_t s);
 hipError_t prep_launch(const float *task_done, const float *episode_step, int T, int B, int burn_in, int cumprod,
@@ -174,7 +177,6 @@ hipError_t gru_cell_bwd_launch(const float *dstate, const float *carry_a, const 
                                float *dh_direct, int rows, int L, hipStream_t s);
 // d encoder.hidden_state[l] = sum_b (a[b][l] + b[b][l])  (learned start state), fixed order
 hipError_t gru_dh0_launch(const float *a, const float *b, int nparts_b, int B, int L, float *out, hipStream_t s);
-hipError_t tick_adam_launch(DevState *st, double lr, double b1, double b2, hipStream_t s);
 hipError_t policy_fwd_launch(const PolicyFwdArgs &a0, const PolicyFwdArgs &a1, int nprob, int M, int A,
                              const DevState *st, uint64_t seed, int discrete, hipStream_t s);
 hipError_t onehot_launch(const float *action, int rows, int n, float *out, hipStream_t s);

@@ -335,6 +335,7 @@ typedef struct {
   int32_t n_gemm_launches;
   int64_t params;
   int64_t plans_built;     /* launch plans built so far (one per new set of batch pointers; a handful are cached) */
+  int64_t graph_launches;  /* updates replayed as one hipGraph launch (opt-in: FDQL_GRAPH=1 at create) */
 } fdql_agent_stats_t;
 int fdql_agent_stats(const fdql_agent_t *agent, fdql_agent_stats_t *out);
 

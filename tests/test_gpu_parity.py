@@ -859,3 +859,45 @@ def test_gradient_parity_three_way_fp64(dev, name, kw, monkeypatch):
     with open("gpurun_out/parity_three_way.txt", "a") as f:
         f.write("\n".join(lines) + "\n")
     assert not bad, bad[:8]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,B", [(2, 256), (6, 64)])
+def test_graph_replay_matches_eager_launches(dev, T, B, monkeypatch):
+    """With FDQL_GRAPH=1 (read at create; the default is the eager launch list) fdql_agent_update replays one hipGraph
+    per launch plan from its second use on (agent.hip capture_update).  Same weights, same persistent batch tensors,
+    device-drawn noise: the two must stay bit-identical over several steps, the replayed one through different batches refilled in place and
+    through a second plan (another set of batch pointers) and back."""
+    from oracle import update as oup
+    spec = oup.Spec(obs=17, act=6, C=5, Q=2, latent=64, enc_features=64, enc_hidden=(64,), joint_hidden=(64,),
+                    pi_hidden=(64,), critic_hidden=(64, 64), T=T, B=B)
+    params = oup.init_params(spec, seed=5)
+    agents = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("FDQL_GRAPH", mode)
+        ag = _agent_for(spec, dev)
+        ag.load_tensors(params)
+        agents.append(ag)
+    g = torch.Generator().manual_seed(2)
+
+    def batch():
+        return {"obs_1d": torch.randn(T, B, 17, generator=g), "action": torch.rand(T, B, 6, generator=g) * 2 - 1,
+                "reward": torch.randn(T, B, 1, generator=g), "mc_return": torch.randn(T, B, 1, generator=g) * 2,
+                "task_done": (torch.rand(T, B, 1, generator=g) < 0.05).float(),
+                "episode_step": (torch.arange(T).view(T, 1, 1) + torch.randint(0, 900, (1, B, 1), generator=g)).float()}
+    pools = [[{k: v.to(dev) for k, v in batch().items()} for _ in range(2)] for _ in agents]   # two pointer sets each
+    order = [0, 0, 0, 1, 1, 0, 1, 0]
+    for step, which in enumerate(order):
+        fresh = batch()
+        for ag, pool in zip(agents, pools):
+            for k, v in fresh.items():
+                pool[which][k].copy_(v)
+            ag.update(pool[which], seed=11)
+        torch.cuda.synchronize()
+        for k in agents[0].tensors:
+            assert torch.equal(agents[0].tensors[k], agents[1].tensors[k]), (step, k)
+    s0, s1 = agents[0].stats(), agents[1].stats()
+    assert s0["graph_launches"] == 0 and s0["plans_built"] == 2
+    assert s1["plans_built"] == 2 and s1["graph_launches"] == len(order) - 2      # first use of each plan is eager
+    sc0, sc1 = agents[0].scalars(), agents[1].scalars()
+    assert sc0 == sc1 and sc0["step"] == len(order)
