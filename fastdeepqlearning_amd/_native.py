@@ -129,6 +129,9 @@ SIGNATURES = {
     "fdql_debug_set_gemm_dense_shape": (C.c_int, [_i32]),
     "fdql_test_gemm": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32,
                                  _i32, _vp]),
+    "fdql_debug_rowgemm_life": (C.c_int, [_vp, _i32]),
+    "fdql_test_rowgemm": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32,
+                                    _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
 }
 
 _lib = None

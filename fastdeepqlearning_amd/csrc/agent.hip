@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "chain.h"
+#include "rowgemm.h"
 #include "common.h"
 #include "update_kernels.h"
 
@@ -100,6 +101,8 @@ struct Stage {
   std::string name;
   std::vector<GemmProblem> gemm;
   GemmSub sub[GEMM_NSHAPES];  // the problems of `gemm`, grouped by tile shape (one launch each)
+  bool try_rows = false;      // ST_GEMM: groups of like problems may run on the persistent row-block kernel (rowgemm.hip)
+  std::vector<RowGemmArgs> rows;   // the groups that do (one launch each); their problems are not in `sub`
   std::vector<SkinnyWgradProblem> swg;
   std::vector<HeadDgradProblem> hdg;
   std::vector<ChainProblem> cprobs;   // ST_CHAIN: programs (chain.h) and their operations
@@ -182,6 +185,7 @@ struct fdql_agent {
   struct CachedPlan { fdql_batch_t batch; std::vector<Stage> stages; void *tables_dev; PlanGraph graph; };
   std::vector<CachedPlan> plan_cache;   // most recently stashed last
   long long plans_built = 0;
+  long long rows_min_tiles = 512;   // FDQL_ROWGEMM: "0" never; default: groups with at least two tiles per CU
   const float *noise_t = nullptr, *noise_a = nullptr;  // per-call (read by the policy stage lambdas)
   uint64_t seed = 0;
 
@@ -765,7 +769,32 @@ int upload_tables(fdql_agent *a) {
   for (Stage &s : a->stages) {
     if (s.kind == ST_GEMM) {
       for (auto &sub : s.sub) sub.probs.clear();
-      for (auto &p : s.gemm) s.sub[gemm_pick_shape(p, gemm_dense_shape())].probs.push_back(p);
+      s.rows.clear();
+      std::vector<char> taken(s.gemm.size(), 0);
+      if (s.try_rows) {   // like problems (same segment list shape and epilogue) -> one row-block launch per group
+        for (size_t i = 0; i < s.gemm.size(); ++i) {
+          if (taken[i]) continue;
+          std::vector<GemmProblem> grp;
+          std::vector<size_t> idx;
+          for (size_t j = i; j < s.gemm.size(); ++j) {
+            const GemmProblem &p = s.gemm[j], &q = s.gemm[i];
+            if (!taken[j] && p.nseg == q.nseg && p.emit_seg == q.emit_seg && p.epi == q.epi && (p.C2 != nullptr) == (q.C2 != nullptr)) {
+              grp.push_back(p);
+              idx.push_back(j);
+            }
+          }
+          RowGemmArgs ra;
+          const long long tiles = (long long)grp.size() * (grp[0].M / RG_BM);
+          if (tiles >= a->rows_min_tiles && rowgemm_from_problems(grp.data(), (int)grp.size(), ra)) {
+            s.rows.push_back(ra);
+            for (size_t j : idx) taken[j] = 1;
+          } else {
+            for (size_t j : idx) taken[j] = 2;   // looked at, stays on the tile kernels
+          }
+        }
+      }
+      for (size_t i = 0; i < s.gemm.size(); ++i)
+        if (taken[i] != 1) s.sub[gemm_pick_shape(s.gemm[i], gemm_dense_shape())].probs.push_back(s.gemm[i]);
       for (auto &sub : s.sub) total += pad(sub.probs.size() * sizeof(GemmProblem));
     }
     if (s.kind == ST_SKINNY_WGRAD) total += pad(s.swg.size() * sizeof(SkinnyWgradProblem));
@@ -1067,6 +1096,7 @@ int build_plan(fdql_agent *a) {
       // done
     } else if (nh > 0 && getenv("FDQL_NO_DUAL") == nullptr) {
       Stage &gs = b.gemm_stage("critics.fwd0");
+      gs.try_rows = true;
       for (int k = 0; k < C; ++k) {
         GemmProblem pt = b.fwd_layer(ct[k], 0);
         pt.emit_seg = pt.nseg - 1;   // no tail: rides in the same launch as the dual problems
@@ -1083,6 +1113,7 @@ int build_plan(fdql_agent *a) {
       }
       for (size_t i = 1; i < nh; ++i) {
         Stage &ls = b.gemm_stage("critics.fwd" + std::to_string(i));
+        ls.try_rows = true;
         for (int k = 0; k < C; ++k) {
           int which = 0;
           for (MlpInst *m : {&ct[k], &co[k], &cf[k]}) {
@@ -1200,6 +1231,7 @@ int build_plan(fdql_agent *a) {
         continue;
       }
       Stage &gs = b.gemm_stage("critics.dpre" + std::to_string(i));
+      gs.try_rows = true;
       for (int k = 0; k < C; ++k) {
         gs.gemm.push_back(b.bwd_dpre(co[k], i, a->buf("dz") + k * Q, Nq));
         gs.gemm.push_back(b.bwd_dpre(cf[k], i, a->buf("dzf") + k * Q, Nq));
@@ -1436,6 +1468,10 @@ int build_plan(fdql_agent *a) {
 hipError_t run_stage(fdql_agent *a, Stage &s, hipStream_t stream) {
   switch (s.kind) {
     case ST_GEMM:
+      for (const RowGemmArgs &ra : s.rows) {
+        hipError_t e = rowgemm_launch(ra, stream);
+        if (e != hipSuccess) return e;
+      }
       for (int sh = 0; sh < GEMM_NSHAPES; ++sh) {
         const GemmSub &sub = s.sub[sh];
         if (sub.blocks <= 0) continue;
@@ -1578,6 +1614,9 @@ int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {
     // T=50 and at T=2 - the step is bound by its kernels' own latency, the host stays ahead of the queue - so it is opt-in
     const char *e = getenv("FDQL_GRAPH");
     a->use_graph = e && e[0] == '1';
+    const char *r = getenv("FDQL_ROWGEMM");   // "0": off; "all": every eligible group whatever its size (tests)
+    if (r && r[0] == '0') a->rows_min_tiles = 1LL << 60;
+    else if (r && !strcmp(r, "all")) a->rows_min_tiles = 1;
   }
   a->T = c.T; a->B = c.B; a->N = c.T * c.B; a->M = (c.T - 1) * c.B; a->A = c.act_dim; a->L = c.latent;
   a->Nq = c.n_critics * c.n_quantiles;
@@ -1714,11 +1753,12 @@ int32_t fdql_agent_profile_update(fdql_agent_t *a, const fdql_batch_t *batch, co
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   // one entry per kernel launch: GEMM stages launch one kernel per tile shape
-  struct Part { Stage *st; int shape; };
+  struct Part { Stage *st; int shape; };   // shape < -1: row-block group -(shape + 2)
   std::vector<Part> parts;
   for (Stage &st : a->stages) {
     if (!st.runs_in(FDQL_PHASE_ALL)) continue;
     if (st.kind == ST_GEMM) {
+      for (size_t r = 0; r < st.rows.size(); ++r) parts.push_back({&st, -2 - (int)r});
       for (int sh = 0; sh < GEMM_NSHAPES; ++sh)
         if (st.sub[sh].blocks > 0) parts.push_back({&st, sh});
     } else {
@@ -1734,6 +1774,8 @@ int32_t fdql_agent_profile_update(fdql_agent_t *a, const fdql_batch_t *batch, co
     if (parts[i].shape >= 0) {
       const GemmSub &sub = parts[i].st->sub[parts[i].shape];
       e = gemm_launch((const GemmProblem *)sub.dev, (int)sub.probs.size(), sub.blocks, parts[i].shape, s);
+    } else if (parts[i].shape < -1) {
+      e = rowgemm_launch(parts[i].st->rows[-2 - parts[i].shape], s);
     } else {
       e = run_stage(a, *parts[i].st, s);
     }
@@ -1752,6 +1794,11 @@ int32_t fdql_agent_profile_update(fdql_agent_t *a, const fdql_batch_t *batch, co
       flops = 0; bytes = 0;
       for (const auto &p : st.sub[parts[i].shape].probs) { flops += gemm_flops(p); bytes += gemm_bytes(p); }
       snprintf(out[cnt].name, sizeof(out[cnt].name), "gemm%s:%s", shape_names[parts[i].shape], st.name.c_str());
+    } else if (parts[i].shape < -1) {
+      const RowGemmArgs &ra = st.rows[-2 - parts[i].shape];
+      flops = rowgemm_flops(ra);
+      bytes = 4.0 * ra.M * ra.ninst * (double)(RG_KMAIN + RG_N * (ra.dual ? 2 : 1) + (ra.grad ? RG_N : 0));
+      snprintf(out[cnt].name, sizeof(out[cnt].name), "rows%s%s:%s", ra.grad ? "KS" : "", ra.dual ? "dual" : "", st.name.c_str());
     } else {
       snprintf(out[cnt].name, sizeof(out[cnt].name), "%s%s", st.kind == ST_SKINNY_WGRAD ? "colsum:" : (st.kind == ST_CHAIN ? "chain:" : "k:"),
                st.name.c_str());
@@ -1956,6 +2003,7 @@ int fdql_agent_stats(const fdql_agent_t *a, fdql_agent_stats_t *out) {
     if (s.kind == ST_GEMM) {
       out->gemm_flops += s.flops;
       for (const auto &sub : s.sub) if (sub.blocks > 0) out->n_gemm_launches++;
+      out->n_gemm_launches += (int)s.rows.size();
     }
     if (s.kind == ST_SKINNY_WGRAD) out->skinny_flops += s.flops;
     if (s.kind == ST_CHAIN) { out->gemm_flops += s.flops; out->n_gemm_launches++; }
@@ -2037,6 +2085,51 @@ int fdql_test_gemm(const float *A, int32_t lda, int32_t a_kc, const float *B, in
   if (e != hipSuccess) { set_error("gemm launch: %s", hipGetErrorString(e)); (void)hipFree(dev); return FDQL_EHIP; }
   FDQL_HIP(hipStreamSynchronize((hipStream_t)stream));
   FDQL_HIP(hipFree(dev));
+  return 0;
+}
+
+int fdql_debug_rowgemm_life(uint64_t *out, int32_t cap) { return rowgemm_read_life((unsigned long long *)out, cap); }
+
+/* Test hook for the persistent row-block kernel (rowgemm.hip): `ninst` instances of one layer, instance i using rows
+ * [i*M, (i+1)*M) of every activation / output array and its own weights W0[i] [256 x 256] (ks: [k][n], else [n][k] with
+ * row stride ldw0), W1[i] / W2[i] ([256 x k1] rows of stride k1, or K-strided [k1 x 256]).  Returns FDQL_EINVAL when the
+ * kernel does not take the form (the caller's fallback is the tile kernels). */
+int fdql_test_rowgemm(const float *A0, const float *A1, int32_t k1, const float *A2, int32_t k2, const float *W0, int32_t ldw0,
+                      const float *W1, const float *W2, const float *bias, float *C, float *C2, const float *ref, float *colsum,
+                      const float *hf_w, int32_t hf_ldw, int32_t hf_q, float *hf_out, float *hf_out2, int32_t M, int32_t ninst,
+                      int32_t ks, int32_t grad, int32_t dual, int32_t planes, void *stream) {
+  std::vector<GemmProblem> probs;
+  for (int i = 0; i < ninst; ++i) {
+    GemmProblem p;
+    memset(&p, 0, sizeof(p));
+    p.M = M; p.N = RG_N; p.ksplit = 1; p.emit_seg = -1;
+    const long long r0 = (long long)i * M;
+    p.C = C + r0 * RG_N; p.ldc = RG_N;
+    auto seg = [&](const float *Aptr, int lda, const float *W, int ldw, int K) {
+      GemmSeg &sg = p.seg[p.nseg++];
+      sg.A = Aptr; sg.lda = lda; sg.a_kc = 1; sg.B = W; sg.ldb = ldw; sg.b_kc = ks ? 0 : 1; sg.K = K;
+    };
+    seg(A0 + r0 * RG_KMAIN, RG_KMAIN, W0 + (long long)i * RG_KMAIN * ldw0 * (ks ? 1 : 1), ks ? RG_N : ldw0, RG_KMAIN);
+    if (A1) seg(A1 + r0 * k1, k1, W1 + (long long)i * RG_N * k1, ks ? RG_N : k1, k1);
+    if (A2) seg(A2 + r0 * k2, k2, W2 + (long long)i * RG_N * k2, ks ? RG_N : k2, k2);
+    if (grad) {
+      p.epi = EPI_LRELU_GRAD; p.ref = ref + r0 * RG_N; p.ldref = RG_N;
+      p.colsum = colsum + (long long)i * (M / 64) * RG_N;
+    } else {
+      p.epi = EPI_LRELU; p.bias = bias + (long long)i * RG_N;
+    }
+    if (dual) { p.emit_seg = p.nseg - 2; p.C2 = C2 + r0 * RG_N; p.ldc2 = RG_N; }
+    if (hf_w) {
+      p.hf_w = hf_w + (long long)i * hf_q * hf_ldw; p.hf_ldw = hf_ldw; p.hf_q = hf_q;
+      p.hf_out = hf_out + (long long)i * planes * M * hf_q;
+      if (dual) p.hf_out2 = hf_out2 + (long long)i * planes * M * hf_q;
+    }
+    probs.push_back(p);
+  }
+  RowGemmArgs ra;
+  FDQL_REQUIRE(rowgemm_from_problems(probs.data(), (int)probs.size(), ra), "the row-block kernel does not take this form");
+  hipError_t e = rowgemm_launch(ra, (hipStream_t)stream);
+  if (e != hipSuccess) { set_error("rowgemm launch: %s", hipGetErrorString(e)); return FDQL_EHIP; }
   return 0;
 }
 

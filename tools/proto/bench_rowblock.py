@@ -22,13 +22,21 @@ runs = {}
 def prod():
     nat.check(lib.fdql_test_gemm(nat.ptr(A), K, 1, nat.ptr(W), K, 1, nat.ptr(b), nat.ptr(C0), N, M, N, K, 1, None, 0, 1, st))
 runs["product 64x64"] = (prod, C0)
+C2 = torch.zeros(M, N, device=dev)
+def rows():
+    nat.check(lib.fdql_test_rowgemm(nat.ptr(A), None, 0, None, 0, nat.ptr(W), K, None, None, nat.ptr(b), nat.ptr(C2), None, None, None,
+                                    None, 0, 0, None, None, M, 1, 0, 0, 0, 0, st))
+if K == 256: runs["product rows"] = (rows, C2)
 for name in names:
     pl = ctypes.CDLL(os.path.join(ROOT, "build_ab", f"libproto_{name}.so"))
     pl.proto_rowblock.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 2 + [ctypes.c_void_p]
     C1 = torch.zeros(M, N, device=dev)
-    def mk(pl, C1):
+    Wk = W
+    if "pk" in name:   # weights pre-packed in MFMA-fragment order [wave][tn][g][j][lh][li][c] (K = 256)
+        Wk = W.view(4, 2, 32, K // 32, 2, 4, 4).permute(0, 1, 3, 5, 4, 2, 6).contiguous()
+    def mk(pl, C1, Wk=Wk):
         def f():
-            rc = pl.proto_rowblock(A.data_ptr(), W.data_ptr(), b.data_ptr(), C1.data_ptr(), M, K, st)
+            rc = pl.proto_rowblock(A.data_ptr(), Wk.data_ptr(), b.data_ptr(), C1.data_ptr(), M, K, st)
             assert rc == 0, rc
         return f
     runs[f"proto {name}"] = (mk(pl, C1), C1)

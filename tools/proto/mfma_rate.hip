@@ -32,11 +32,11 @@ __global__ __launch_bounds__(256, 1) void k_rate(const float *g, float *out, uns
   out[blockIdx.x * 256 + tid] = s;
   if (tid == 0) cyc[blockIdx.x] = t1 - t0;
 }
-int main() {
+int main(int argc, char **argv) {
   float *g, *out; unsigned long long *cyc;
   hipMalloc(&g, 65536 * 16 * 2); hipMemset(g, 0, 65536 * 16 * 2);
   hipMalloc(&out, 256 * 256 * 4); hipMalloc(&cyc, 256 * 8);
-  const int iters = 200;
+  const int iters = argc > 1 ? atoi(argv[1]) : 200;
   for (int mode = 0; mode < 3; ++mode) {
     for (int rep = 0; rep < 2; ++rep) {
       hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
