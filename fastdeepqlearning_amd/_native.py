@@ -131,7 +131,7 @@ SIGNATURES = {
                                  _i32, _vp]),
     "fdql_debug_rowgemm_life": (C.c_int, [_vp, _i32]),
     "fdql_test_rowgemm": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32,
-                                    _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+                                    _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
 }
 
 _lib = None

@@ -793,8 +793,11 @@ int upload_tables(fdql_agent *a) {
           }
         }
       }
-      for (size_t i = 0; i < s.gemm.size(); ++i)
-        if (taken[i] != 1) s.sub[gemm_pick_shape(s.gemm[i], gemm_dense_shape())].probs.push_back(s.gemm[i]);
+      for (size_t i = 0; i < s.gemm.size(); ++i) {
+        if (taken[i] == 1) continue;
+        if (s.gemm[i].fz_h) { set_error("stage %s: a fused head-dgrad problem was not taken by the row-block kernel", s.name.c_str()); return FDQL_ESTATE; }
+        s.sub[gemm_pick_shape(s.gemm[i], gemm_dense_shape())].probs.push_back(s.gemm[i]);
+      }
       for (auto &sub : s.sub) total += pad(sub.probs.size() * sizeof(GemmProblem));
     }
     if (s.kind == ST_SKINNY_WGRAD) total += pad(s.swg.size() * sizeof(SkinnyWgradProblem));
@@ -1219,7 +1222,35 @@ int build_plan(fdql_agent *a) {
   // ---- critic backward (online: wgrad + d state; frozen: d pi only)
   {
     const size_t nh = a->critic[0].hid.size();
-    for (int i = (int)nh - 1; i >= 0; --i) {
+    // Two hidden layers under a narrow head: the last layer's gradient (k_head_dgrad: a rank-Q outer product gated by
+    // LeakyReLU') can be formed inside the loader of the row-block launch that consumes it (rowgemm.hip, FUSE) instead of
+    // making a 2 x 131 MB round trip through HBM in a launch of its own.  Only when that launch takes the problems.
+    bool fused1 = false;
+    if (nh == 2 && Builder::narrow_head_last(a->critic[0], 1) && getenv("FDQL_NO_FUSE_DPRE1") == nullptr) {
+      std::vector<GemmProblem> cand;
+      for (int k = 0; k < C; ++k) {
+        int which = 0;
+        for (MlpInst *m : {&co[k], &cf[k]}) {
+          GemmProblem p = b.bwd_dpre(*m, 0, a->buf(which == 0 ? "dz" : "dzf") + k * Q, Nq);
+          p.fz_h = m->h[1];
+          p.fz_w = m->HW() + b.head_col_of_hidden(*m->d, 1);
+          p.fz_ldw = m->d->head_ld();
+          p.fz_out = m->dpre[1];
+          p.fz_colsum = m->dpre_cs[1];
+          cand.push_back(p);
+          ++which;
+        }
+      }
+      RowGemmArgs ra;
+      const long long tiles = (long long)cand.size() * (M / RG_BM);
+      if (M % RG_BM == 0 && tiles >= a->rows_min_tiles && rowgemm_from_problems(cand.data(), (int)cand.size(), ra)) {
+        Stage &gs = b.gemm_stage("critics.dpre1+0");
+        gs.try_rows = true;
+        gs.gemm = cand;
+        fused1 = true;
+      }
+    }
+    for (int i = (int)nh - 1; i >= 0 && !fused1; --i) {
       if (Builder::narrow_head_last(a->critic[0], i)) {
         Stage st;
         st.kind = ST_HEAD_DGRAD; st.name = "critics.dpre" + std::to_string(i);
@@ -2092,12 +2123,14 @@ int fdql_debug_rowgemm_life(uint64_t *out, int32_t cap) { return rowgemm_read_li
 
 /* Test hook for the persistent row-block kernel (rowgemm.hip): `ninst` instances of one layer, instance i using rows
  * [i*M, (i+1)*M) of every activation / output array and its own weights W0[i] [256 x 256] (ks: [k][n], else [n][k] with
- * row stride ldw0), W1[i] / W2[i] ([256 x k1] rows of stride k1, or K-strided [k1 x 256]).  Returns FDQL_EINVAL when the
- * kernel does not take the form (the caller's fallback is the tile kernels). */
+ * row stride ldw0), W1[i] / W2[i] ([256 x k1] rows of stride k1, or K-strided [k1 x 256]).  fz_h: fused head dgrad
+ * (GemmProblem::fz_*): A0's rows are OUTPUT, formed from fz_h, A1 (= dY, k1 = 2) and fz_w[i] [2 x fz_ldw].  Returns
+ * FDQL_EINVAL when the kernel does not take the form (the caller's fallback is the tile kernels). */
 int fdql_test_rowgemm(const float *A0, const float *A1, int32_t k1, const float *A2, int32_t k2, const float *W0, int32_t ldw0,
                       const float *W1, const float *W2, const float *bias, float *C, float *C2, const float *ref, float *colsum,
                       const float *hf_w, int32_t hf_ldw, int32_t hf_q, float *hf_out, float *hf_out2, int32_t M, int32_t ninst,
-                      int32_t ks, int32_t grad, int32_t dual, int32_t planes, void *stream) {
+                      int32_t ks, int32_t grad, int32_t dual, int32_t planes, const float *fz_h, const float *fz_w, int32_t fz_ldw,
+                      float *fz_colsum, void *stream) {
   std::vector<GemmProblem> probs;
   for (int i = 0; i < ninst; ++i) {
     GemmProblem p;
@@ -2119,6 +2152,10 @@ int fdql_test_rowgemm(const float *A0, const float *A1, int32_t k1, const float 
       p.epi = EPI_LRELU; p.bias = bias + (long long)i * RG_N;
     }
     if (dual) { p.emit_seg = p.nseg - 2; p.C2 = C2 + r0 * RG_N; p.ldc2 = RG_N; }
+    if (fz_h) {   // the main segment's A block is formed from (fz_h, A1 = dY, fz_w) and lands in A0's rows
+      p.fz_h = fz_h + r0 * RG_N; p.fz_w = fz_w + (long long)i * 2 * fz_ldw; p.fz_ldw = fz_ldw;
+      p.fz_out = const_cast<float *>(A0) + r0 * RG_KMAIN; p.fz_colsum = fz_colsum + (long long)i * (M / 64) * RG_N;
+    }
     if (hf_w) {
       p.hf_w = hf_w + (long long)i * hf_q * hf_ldw; p.hf_ldw = hf_ldw; p.hf_q = hf_q;
       p.hf_out = hf_out + (long long)i * planes * M * hf_q;

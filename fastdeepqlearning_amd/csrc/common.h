@@ -69,6 +69,13 @@ struct GemmProblem {
   const float *hf_w;
   int hf_ldw, hf_q;
   float *hf_out, *hf_out2;
+  // Fused head dgrad (row-block kernel, rowgemm.hip, only): the 256-wide segment's A operand is not read from memory
+  // but formed while the tile is staged,  A[m][k] = LeakyReLU'(fz_h[m][k]) * sum_q dY[m][q] * fz_w[q*fz_ldw + k]  with dY
+  // the problem's narrow segment (that is k_head_dgrad's formula: the gradient of the last hidden layer under a narrow
+  // head), written to fz_out [M, 256] for the weight gradients, its per-64-row column sums to fz_colsum.
+  const float *fz_h, *fz_w;
+  int fz_ldw;
+  float *fz_out, *fz_colsum;
   int tiles_m, tiles_n;    // filled by gemm_finalize
   int tile_start;          // first block id of this problem in its launch
   GemmSeg seg[GEMM_MAX_SEG];

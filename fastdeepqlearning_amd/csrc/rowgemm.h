@@ -10,7 +10,7 @@ constexpr int RG_BM = 64;          // rows per tile
 constexpr int RG_N = 256;          // output columns (4 waves x 64)
 constexpr int RG_KMAIN = 256;      // K of the main segment
 constexpr int RG_MAX_MINOR = 2;    // narrow K-segments beside it, one 8-k MFMA step each
-constexpr int RG_MAX_INST = 30;     // the table travels in the kernel arguments (scalar loads): 30 x 112 B < 4 KiB
+constexpr int RG_MAX_INST = 24;    // the table travels in the kernel arguments (scalar loads): 24 x 144 B < 4 KiB
 
 struct RowGemmInst {
   const float *A[1 + RG_MAX_MINOR];   // activations of the segments, [0] = main; row-major, K contiguous
@@ -21,6 +21,8 @@ struct RowGemmInst {
   float *colsum;                      // GRAD: optional [M / 64, 256] column sums of the stored tile
   const float *hf_w;                  // head fusion (common.h, GemmProblem::hf_*): head weight rows over this layer's columns
   float *hf_out, *hf_out2;
+  const float *fz_h, *fz_w;           // fused head dgrad (GemmProblem::fz_*)
+  float *fz_out, *fz_colsum;
 };
 
 struct RowGemmArgs {
@@ -32,6 +34,7 @@ struct RowGemmArgs {
   int grad;                  // 1: x *= LeakyReLU'(ref) (no bias), column sums; 0: x = LeakyReLU(x + bias)
   int dual;                  // 1: C = f(all segments but the last), C2 = f(all)
   int hf_q, hf_ldw;          // head fusion: outputs per row (1, 2, 4, 8), 0 = off
+  int fz, fz_ldw;            // fused head dgrad: A of the main segment formed from (fz_h, dY, fz_w)
   int ldc, ldc2, ldref;
   RowGemmInst inst[RG_MAX_INST];
 };

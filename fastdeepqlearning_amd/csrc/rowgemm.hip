@@ -62,8 +62,8 @@ __device__ __forceinline__ T *rg_uni(T *p) {   // a pointer read from the instan
 // The fields of an instance a tile needs, read ONCE per tile: the asm statements of the K loop clobber "memory", so a
 // field left in the table would be re-read (by a vector load followed by s_waitcnt vmcnt(0)) at every use.
 struct RgPtrs {
-  const float *A[1 + RG_MAX_MINOR], *W[1 + RG_MAX_MINOR], *bias, *ref, *hf_w;
-  float *C, *C2, *colsum, *hf_out, *hf_out2;
+  const float *A[1 + RG_MAX_MINOR], *W[1 + RG_MAX_MINOR], *bias, *ref, *hf_w, *fz_h, *fz_w;
+  float *C, *C2, *colsum, *hf_out, *hf_out2, *fz_out, *fz_colsum;
 };
 __device__ __forceinline__ RgPtrs rg_read(const RowGemmArgs &a, int i) {
   const RowGemmInst &I = a.inst[i];   // kernel-argument segment: scalar loads
@@ -72,6 +72,7 @@ __device__ __forceinline__ RgPtrs rg_read(const RowGemmArgs &a, int i) {
   for (int s = 0; s < 1 + RG_MAX_MINOR; ++s) { r.A[s] = rg_uni(I.A[s]); r.W[s] = rg_uni(I.W[s]); }
   r.bias = rg_uni(I.bias); r.ref = rg_uni(I.ref); r.hf_w = rg_uni(I.hf_w);
   r.C = rg_uni(I.C); r.C2 = rg_uni(I.C2); r.colsum = rg_uni(I.colsum); r.hf_out = rg_uni(I.hf_out); r.hf_out2 = rg_uni(I.hf_out2);
+  r.fz_h = rg_uni(I.fz_h); r.fz_w = rg_uni(I.fz_w); r.fz_out = rg_uni(I.fz_out); r.fz_colsum = rg_uni(I.fz_colsum);
   return r;
 }
 
@@ -119,8 +120,11 @@ __device__ __forceinline__ void rg_hf_partial(const f32x16 &acc, float bv, const
 // KS: weights K-strided (dgrad), output column of (tile tn, lane li) = n0 + 2 li + tn; else K-contiguous, n0 + 32 tn + li.
 // NMINOR: narrow segments (K <= 8) beside the 256-wide one.  DUAL: two outputs (see rowgemm.h).  HFQ: head-fusion
 // outputs per row (0 = off).  GRAD: dgrad epilogue (LeakyReLU' gate from `ref`, column sums) instead of bias + LeakyReLU.
-template <bool KS, int NMINOR, bool DUAL, int HFQ, bool GRAD>
+// FUSE (dgrad form, one narrow segment of K = 2 = dY): the main segment's A is formed from (fz_h, dY, fz_w) while it is
+// staged (GemmProblem::fz_* in common.h) - the head dgrad of the layer above runs inside this launch's loader.
+template <bool KS, int NMINOR, bool DUAL, int HFQ, bool GRAD, bool FUSE = false>
 __global__ __launch_bounds__(256, 1) void k_rowgemm(const RowGemmArgs a) {
+  static_assert(!FUSE || (GRAD && NMINOR == 1), "the fused head dgrad belongs to the dgrad form with its dY segment");
   static_assert(!DUAL || NMINOR >= 1, "a dual launch emits before its last narrow segment");
   static_assert(!(KS && HFQ), "head fusion belongs to the forward layers");
   static_assert(!(GRAD && DUAL), "one output in the dgrad form");
@@ -141,6 +145,7 @@ __global__ __launch_bounds__(256, 1) void k_rowgemm(const RowGemmArgs a) {
     __syncthreads();
   }
 
+  float *fzred = lds + 2 * img_floats;   // FUSE: [2][4 waves][256] column-sum partials of the staged tiles
   // narrow segments: which elements of the [64, K] block this thread moves (two per segment at most: 64 * 8 / 256)
   int m_src[NMINOR > 0 ? NMINOR : 1][2], m_dst[NMINOR > 0 ? NMINOR : 1][2];
   bool m_ok[NMINOR > 0 ? NMINOR : 1][2];
@@ -342,6 +347,22 @@ __global__ __launch_bounds__(256, 1) void k_rowgemm(const RowGemmArgs a) {
     }
   };
 
+  // ---- FUSE: one staged row slice (this lane's 4 columns of one row): h -> LeakyReLU'(h) * (dY . Wh)
+  v4f fw[2];          // head weight rows q = 0, 1 over this lane's 4 columns, of the instance being staged
+  v2f dzr[3][3];      // dY of the rows in flight (same ring as stg)
+  float fcs[4] = {0.f, 0.f, 0.f, 0.f};   // column sums of the tile being staged (this wave's 16 rows)
+  auto fuse_row = [&](v4f h, v2f dz) __attribute__((always_inline)) {
+    v4f t;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float x = dz.x * fw[0][c];
+      x = fmaf(dz.y, fw[1][c], x);        // k_head_dgrad's order and rounding (fma chain over q)
+      x = h[c] > 0.f ? x : 0.01f * x;
+      t[c] = x;
+      fcs[c] += x;
+    }
+    return t;
+  };
   // ---- next tile's rows: global -> registers, 3 of a wave's 16 rows per k-group (groups 0..5); registers -> the other
   // image two groups later (groups 2..7).  Nothing of it is left after the loop: a wait there would sit behind the
   // stores of the last slices (vmcnt completes in order).
@@ -387,16 +408,44 @@ __global__ __launch_bounds__(256, 1) void k_rowgemm(const RowGemmArgs a) {
         }
       }
     }
-    const float *nsrc = IN.A[0] + (long long)nblk * RG_BM * LD;   // uniform; the lane adds its 16 bytes of the row
+    const float *nsrc = (FUSE ? IN.fz_h : IN.A[0]) + (long long)nblk * RG_BM * LD;   // uniform; the lane adds its 16 bytes of the row
+    if constexpr (FUSE) {
+      // this tile was staged during the previous one: the column sums of its formed A block (4 partials per column)
+      const float *red = fzred + img * (4 * RG_N);
+      const float t = (red[tid] + red[RG_N + tid]) + (red[2 * RG_N + tid] + red[3 * RG_N + tid]);
+      rg_uni((gf)IC.fz_colsum + (long long)cblk * RG_N)[(unsigned)tid] = t;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) fw[q][c] = ((gcf)(IN.fz_w + (long long)q * a.fz_ldw))[(unsigned)(lane * 4 + c)];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) fcs[c] = 0.f;
+    }
     float *ndst = lds + (img ^ 1) * img_floats + lane * 4;
     // side work of k-group g, quarter j (runs under the 16 MFMAs of that step)
     auto piece = [&](int g, int j, int lbuf, int lg, const gcf4 (&lp)[2], gcf lk) __attribute__((always_inline)) {
       load_b_part(lbuf, lg, j, lp, lk);                 // B fragments of the next k-group
       // next tile's rows: row 3 g + j of the wave's 16 (groups 0..5), written to the other image two groups later
-      if (j < 3 && g < 6 && 3 * g + j < RG_BM / 4)
-        stg[g % 3][j] = rg_uni((gcf4)(nsrc + (wave + 4 * (3 * g + j)) * LD))[(unsigned)lane];
-      if (j < 3 && g >= 2 && 3 * (g - 2) + j < RG_BM / 4)
-        *reinterpret_cast<v4f *>(ndst + (wave + 4 * (3 * (g - 2) + j)) * pitch) = stg[(g - 2) % 3][j];
+      if (j < 3 && g < 6 && 3 * g + j < RG_BM / 4) {
+        const int row = wave + 4 * (3 * g + j);
+        stg[g % 3][j] = rg_uni((gcf4)(nsrc + row * LD))[(unsigned)lane];
+        if constexpr (FUSE) dzr[g % 3][j] = *(gcf2)rg_uni(IN.A[1] + ((long long)nblk * RG_BM + row) * a.lda[1]);
+      }
+      if (j < 3 && g >= 2 && 3 * (g - 2) + j < RG_BM / 4) {
+        const int row = wave + 4 * (3 * (g - 2) + j);
+        v4f val = stg[(g - 2) % 3][j];
+        if constexpr (FUSE) {
+          val = fuse_row(val, dzr[(g - 2) % 3][j]);
+          rg_uni((__attribute__((address_space(1))) v4f *)(IN.fz_out + ((long long)nblk * RG_BM + row) * LD))[(unsigned)lane] = val;
+        }
+        *reinterpret_cast<v4f *>(ndst + row * pitch) = val;
+      }
+      if constexpr (FUSE) {
+        if (g == 7 && j == 2) {   // all 16 rows of this wave are in: its column-sum partials for the next tile's start
+          float *red = fzred + (img ^ 1) * (4 * RG_N) + wave * RG_N + lane * 4;
+          *reinterpret_cast<v4f *>(red) = v4f{fcs[0], fcs[1], fcs[2], fcs[3]};
+        }
+      }
       if (j == 3 && g == 0) {
 #pragma unroll
         for (int s = 0; s < NMINOR; ++s)
@@ -485,12 +534,24 @@ __global__ __launch_bounds__(256, 1) void k_rowgemm(const RowGemmArgs a) {
     const RgPtrs IC = rg_read(a, cinst);
     w_pointers(IC, wp, wk);
     load_b(0, 0, wp, wk);
-    const float *src = IC.A[0] + (long long)cblk * RG_BM * LD;
+    const float *src = (FUSE ? IC.fz_h : IC.A[0]) + (long long)cblk * RG_BM * LD;
+    if constexpr (FUSE) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) fw[q][c] = ((gcf)(IC.fz_w + (long long)q * a.fz_ldw))[(unsigned)(lane * 4 + c)];
+    }
 #pragma unroll
     for (int i = 0; i < RG_BM / 4; ++i) {
       const int r = wave + 4 * i;
-      *reinterpret_cast<v4f *>(lds + r * pitch + lane * 4) = ((gcf4)(src + r * LD))[(unsigned)lane];
+      v4f val = ((gcf4)(src + r * LD))[(unsigned)lane];
+      if constexpr (FUSE) {
+        val = fuse_row(val, *(gcf2)(IC.A[1] + ((long long)cblk * RG_BM + r) * a.lda[1]));
+        ((__attribute__((address_space(1))) v4f *)(IC.fz_out + ((long long)cblk * RG_BM + r) * LD))[(unsigned)lane] = val;
+      }
+      *reinterpret_cast<v4f *>(lds + r * pitch + lane * 4) = val;
     }
+    if constexpr (FUSE) *reinterpret_cast<v4f *>(fzred + wave * RG_N + lane * 4) = v4f{fcs[0], fcs[1], fcs[2], fcs[3]};
 #pragma unroll
     for (int s = 0; s < NMINOR; ++s)
 #pragma unroll
@@ -586,6 +647,9 @@ bool rowgemm_from_problems(const GemmProblem *probs, int nprob, RowGemmArgs &arg
   args.M = p0.M; args.ninst = nprob; args.blocks_per_inst = p0.M / RG_BM;
   args.nminor = nminor; args.ks = ks; args.grad = grad; args.dual = dual;
   args.hf_q = p0.hf_w ? p0.hf_q : 0; args.hf_ldw = p0.hf_ldw;
+  const bool fz = p0.fz_h != nullptr;
+  if (fz && (!grad || nminor != 1 || !p0.fz_w || !p0.fz_out || !p0.fz_colsum)) return false;
+  args.fz = fz; args.fz_ldw = p0.fz_ldw;
   args.ldc = p0.ldc; args.ldc2 = p0.ldc2; args.ldref = p0.ldref;
   for (int i = 0; i < nprob; ++i) {
     const GemmProblem &p = probs[i];
@@ -595,6 +659,9 @@ bool rowgemm_from_problems(const GemmProblem *probs, int nprob, RowGemmArgs &arg
         (p.ref != nullptr) != (p0.ref != nullptr) || (p.colsum != nullptr) != (p0.colsum != nullptr))
       return false;
     if (dual && (!p.C2 || (p.hf_w && !p.hf_out2))) return false;
+    if ((p.fz_h != nullptr) != fz || p.fz_ldw != p0.fz_ldw) return false;
+    if (fz && (!p.fz_w || !p.fz_out || !p.fz_colsum || (reinterpret_cast<uintptr_t>(p.fz_h) & 15) || (reinterpret_cast<uintptr_t>(p.fz_out) & 15)))
+      return false;
     RowGemmInst I;
     memset(&I, 0, sizeof(I));
     int m = 0;
@@ -603,6 +670,7 @@ bool rowgemm_from_problems(const GemmProblem *probs, int nprob, RowGemmArgs &arg
       if (!sg.a_kc || sg.b_kc != (ks ? 0 : 1) || sg.K != s0.K || sg.lda != s0.lda || sg.ldb != s0.ldb) return false;
       const int slot = s == main0 ? 0 : 1 + m++;
       if (slot > 0 && (sg.K < 1 || sg.K > 8)) return false;
+      if (fz && slot > 0 && (sg.K != 2 || sg.lda % 2 || (reinterpret_cast<uintptr_t>(sg.A) & 7))) return false;   // dY rows read as float2
       if (slot == 0 && (sg.lda % 4 || (reinterpret_cast<uintptr_t>(sg.A) & 15))) return false;
       if (!ks && slot == 0 && (sg.ldb % 4 || (reinterpret_cast<uintptr_t>(sg.B) & 15))) return false;
       if (ks && (sg.ldb % 2 || (reinterpret_cast<uintptr_t>(sg.B) & 7))) return false;
@@ -616,14 +684,12 @@ bool rowgemm_from_problems(const GemmProblem *probs, int nprob, RowGemmArgs &arg
       return false;
     I.bias = p.bias; I.C = p.C; I.C2 = p.C2; I.ref = p.ref; I.colsum = p.colsum;
     I.hf_w = p.hf_w; I.hf_out = p.hf_out; I.hf_out2 = p.hf_out2;
+    I.fz_h = p.fz_h; I.fz_w = p.fz_w; I.fz_out = p.fz_out; I.fz_colsum = p.fz_colsum;
     args.inst[i] = I;
   }
   // instantiated forms; FDQL_ROWGEMM_FORMS (bit mask, tuning hook): 1 forward, 2 dgrad, 4 dual forward
-  static int forms = -1;
-  if (forms < 0) {
-    const char *e = getenv("FDQL_ROWGEMM_FORMS");
-    forms = e ? atoi(e) : 3;
-  }
+  const char *fe = getenv("FDQL_ROWGEMM_FORMS");   // (read per plan build / test call)
+  const int forms = fe ? atoi(fe) : 2;   // the forward form with head fusion is slower than the tile kernel in the update so far
   if (grad) return (forms & 2) && nminor == 1;
   if (dual) return (forms & 4) && nminor == 2 && args.hf_q == 2;   // (spills registers so far: off by default)
   if (!(forms & 1)) return false;
@@ -655,10 +721,10 @@ double rowgemm_flops(const RowGemmArgs &a) {
   return f;
 }
 
-template <bool KS, int NMINOR, bool DUAL, int HFQ, bool GRAD>
+template <bool KS, int NMINOR, bool DUAL, int HFQ, bool GRAD, bool FUSE = false>
 static hipError_t rg_launch(const RowGemmArgs &a, int grid, int lds_bytes, hipStream_t s) {
   static bool attr = false;
-  auto kern = &k_rowgemm<KS, NMINOR, DUAL, HFQ, GRAD>;
+  auto kern = &k_rowgemm<KS, NMINOR, DUAL, HFQ, GRAD, FUSE>;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     if (e != hipSuccess) return e;
@@ -678,7 +744,8 @@ hipError_t rowgemm_launch(const RowGemmArgs &a, hipStream_t s) {
   }
   const int ntiles = a.ninst * a.blocks_per_inst;
   const int grid = ntiles < ncu ? ntiles : ncu;
-  const int lds_bytes = 2 * RG_BM * (RG_KMAIN + 8 * a.nminor + 4) * 4;
+  const int lds_bytes = 2 * RG_BM * (RG_KMAIN + 8 * a.nminor + 4) * 4 + (a.fz ? 2 * 4 * RG_N * 4 : 0);
+  if (a.grad && a.fz) return rg_launch<true, 1, false, 0, true, true>(a, grid, lds_bytes, s);
   if (a.grad) return rg_launch<true, 1, false, 0, true>(a, grid, lds_bytes, s);
   if (a.dual) return rg_launch<false, 2, true, 2, false>(a, grid, lds_bytes, s);
   if (a.nminor == 0) return a.hf_q ? rg_launch<false, 0, false, 2, false>(a, grid, lds_bytes, s) : rg_launch<false, 0, false, 0, false>(a, grid, lds_bytes, s);

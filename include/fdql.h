@@ -375,11 +375,14 @@ int fdql_debug_rowgemm_life(uint64_t *out, int32_t cap);
  * with 256 inputs (+ up to two narrow input blocks of k1, k2 <= 8 columns) and 256 outputs; instance i owns rows
  * [i*M, (i+1)*M) of every array.  ks: weights stored [k][n] (dgrad) else [n][k]; grad: LeakyReLU' gate from `ref` and
  * column sums instead of bias + LeakyReLU; dual: C = f(all but the last narrow block), C2 = f(all); hf_*: head fusion
- * (GemmProblem::hf_* in csrc/common.h).  Asynchronous on `stream`.  FDQL_EINVAL: the kernel does not take the form. */
+ * (GemmProblem::hf_* in csrc/common.h); fz_h != null: the head dgrad of the layer above fused into the loader - A0's rows
+ * are then OUTPUT, LeakyReLU'(fz_h) * (A1 . fz_w[i]) with A1 = dY (k1 = 2), their per-64-row column sums in fz_colsum.
+ * Asynchronous on `stream`.  FDQL_EINVAL: the kernel does not take the form. */
 int fdql_test_rowgemm(const float *A0, const float *A1, int32_t k1, const float *A2, int32_t k2, const float *W0, int32_t ldw0,
                       const float *W1, const float *W2, const float *bias, float *C, float *C2, const float *ref, float *colsum,
                       const float *hf_w, int32_t hf_ldw, int32_t hf_q, float *hf_out, float *hf_out2, int32_t M, int32_t ninst,
-                      int32_t ks, int32_t grad, int32_t dual, int32_t planes, void *stream);
+                      int32_t ks, int32_t grad, int32_t dual, int32_t planes, const float *fz_h, const float *fz_w, int32_t fz_ldw,
+                      float *fz_colsum, void *stream);
 
 /* Tuning hook: build of the GEMM main loop: 1 (default) = K-chunk 16 with next-step fragment prefetch, 0 = K-chunk 16
  * without it, 4 = K-chunk 8; 2 and 3 alias 0.  Affects speed only. */

@@ -901,3 +901,76 @@ def test_graph_replay_matches_eager_launches(dev, T, B, monkeypatch):
     assert s1["plans_built"] == 2 and s1["graph_launches"] == len(order) - 2      # first use of each plan is eager
     sc0, sc1 = agents[0].scalars(), agents[1].scalars()
     assert sc0 == sc1 and sc0["step"] == len(order)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["fwd", "fwd_hf", "fwd_minor_hf", "dgrad", "dgrad_fused", "dual_hf"])
+@pytest.mark.parametrize("M,ninst", [(64, 1), (192, 3), (1280, 15)])
+def test_rowgemm_forms(dev, form, M, ninst, monkeypatch):
+    """The persistent row-block kernel (csrc/rowgemm.hip) through fdql_test_rowgemm against fp64 torch: every form
+    (forward with / without head fusion and a narrow extra input block, two-output forward, dgrad with the LeakyReLU'
+    gate and column sums, dgrad with the head dgrad of the layer above fused into its loader), for one tile per
+    workgroup, a few, and more tiles than CUs (the software-pipelined path)."""
+    from fastdeepqlearning_amd import _native as nat
+    monkeypatch.setenv("FDQL_ROWGEMM_FORMS", "7")
+    lib = nat.load(); st = nat.current_stream(dev)
+    g = torch.Generator().manual_seed(7 + M + ninst)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    R, Q, k1 = M * ninst, 2, 6
+    ks = form.startswith("dgrad")
+    dual, fused = form == "dual_hf", form == "dgrad_fused"
+    bmm = lambda x, w, k: torch.bmm(x.double().view(ninst, M, k), w.double())
+    A0, A1, A2, W1, W2, bias, ref, hfw, fzh, fzw = (None,) * 10
+    if ks:
+        W0 = rnd(ninst, 256, 256) / 16                       # [k][n]
+        A1, W1, ref = rnd(R, Q), rnd(ninst, Q, 256), rnd(R, 256)     # dY and the head's rows over this layer's columns
+        if fused:
+            fzh, fzw = rnd(R, 256), rnd(ninst, Q, 300)
+            pre1 = bmm(A1, fzw[:, :, :256], Q)
+            a0 = torch.where(fzh.double().view(ninst, M, 256) > 0, pre1, 0.01 * pre1)
+            A0 = torch.full((R, 256), float("nan"))
+        else:
+            A0 = rnd(R, 256)
+            a0 = A0.double().view(ninst, M, 256)
+        pre = torch.bmm(a0, W0.double()) + bmm(A1, W1, Q)
+        want = torch.where(ref.double().view(ninst, M, 256) > 0, pre, 0.01 * pre)
+    else:
+        A0, W0, bias = rnd(R, 256), rnd(ninst, 256, 256) / 16, rnd(ninst, 256)      # W0 [n][k]
+        pre = bmm(A0, W0.transpose(1, 2), 256) + bias.double()[:, None, :]
+        if form in ("fwd_minor_hf", "dual_hf"):
+            A1, W1 = rnd(R, k1), rnd(ninst, 256, k1)
+            pre = pre + bmm(A1, W1.transpose(1, 2), k1)
+        want = torch.nn.functional.leaky_relu(pre, 0.01)
+        if dual:
+            A2, W2 = rnd(R, k1), rnd(ninst, 256, k1)
+            want2 = torch.nn.functional.leaky_relu(pre + bmm(A2, W2.transpose(1, 2), k1), 0.01)
+        if form != "fwd":
+            hfw = rnd(ninst, Q, 300)
+    d = lambda t: None if t is None else t.to(dev).contiguous()
+    A0_d, A1_d, A2_d, W0_d, W1_d, W2_d, bias_d, ref_d, hfw_d, fzh_d, fzw_d = map(d, (A0, A1, A2, W0, W1, W2, bias, ref, hfw, fzh, fzw))
+    C = torch.full((R, 256), float("nan"), device=dev)
+    C2 = torch.full((R, 256), float("nan"), device=dev) if dual else None
+    cs = torch.full((ninst, M // 64, 256), float("nan"), device=dev) if ks else None
+    fcs = torch.full((ninst, M // 64, 256), float("nan"), device=dev) if fused else None
+    hfo = torch.full((ninst, 8, M, Q), float("nan"), device=dev) if hfw is not None else None
+    hfo2 = torch.full((ninst, 8, M, Q), float("nan"), device=dev) if dual else None
+    rc = lib.fdql_test_rowgemm(nat.ptr(A0_d), nat.ptr(A1_d), 0 if A1 is None else A1.shape[1], nat.ptr(A2_d), 0 if A2 is None else k1,
+                               nat.ptr(W0_d), 256, nat.ptr(W1_d), nat.ptr(W2_d), nat.ptr(bias_d), nat.ptr(C), nat.ptr(C2), nat.ptr(ref_d),
+                               nat.ptr(cs), nat.ptr(hfw_d), 300, Q if hfw is not None else 0, nat.ptr(hfo), nat.ptr(hfo2), M, ninst,
+                               int(ks), int(ks), int(dual), 8, nat.ptr(fzh_d), nat.ptr(fzw_d), 300, nat.ptr(fcs), st)
+    assert rc == 0, lib.fdql_last_error().decode()
+    torch.cuda.synchronize()
+    close = lambda got, ref_, tol: float((got.double().cpu().reshape(ref_.shape) - ref_).abs().max()) <= tol * float(ref_.abs().max())
+    assert close(C, want, 2e-5)
+    if dual:
+        assert close(C2, want2, 2e-5)
+    if ks:
+        assert close(cs, want.view(ninst, M // 64, 64, 256).sum(2), 1e-4)
+    if fused:
+        assert close(A0_d, a0, 2e-5)
+        assert close(fcs, a0.view(ninst, M // 64, 64, 256).sum(2), 1e-4)
+    if hfw is not None:
+        w = hfw[:, :, :256].double().view(ninst, Q, 8, 32)
+        assert close(hfo, torch.einsum("impc,iqpc->ipmq", want.view(ninst, M, 8, 32), w), 1e-4)
+        if dual:
+            assert close(hfo2, torch.einsum("impc,iqpc->ipmq", want2.view(ninst, M, 8, 32), w), 1e-4)

@@ -25,7 +25,7 @@ runs["product 64x64"] = (prod, C0)
 C2 = torch.zeros(M, N, device=dev)
 def rows():
     nat.check(lib.fdql_test_rowgemm(nat.ptr(A), None, 0, None, 0, nat.ptr(W), K, None, None, nat.ptr(b), nat.ptr(C2), None, None, None,
-                                    None, 0, 0, None, None, M, 1, 0, 0, 0, 0, st))
+                                    None, 0, 0, None, None, M, 1, 0, 0, 0, 0, None, None, 0, None, st))
 if K == 256: runs["product rows"] = (rows, C2)
 for name in names:
     pl = ctypes.CDLL(os.path.join(ROOT, "build_ab", f"libproto_{name}.so"))

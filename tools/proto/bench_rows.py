@@ -14,7 +14,7 @@ C = torch.zeros(ninst * M, N, device=dev); C0 = torch.zeros(ninst * M, N, device
 hw = torch.randn(ninst, 2, 774, device=dev); hout = torch.zeros(ninst, 8, M, 2, device=dev)
 def rows():
     nat.check(lib.fdql_test_rowgemm(nat.ptr(A), None, 0, None, 0, nat.ptr(W), K, None, None, nat.ptr(b), nat.ptr(C), None, None, None,
-                                    nat.ptr(hw) if hf else None, 774, 2 if hf else 0, nat.ptr(hout) if hf else None, None, M, ninst, 0, 0, 0, 8, st))
+                                    nat.ptr(hw) if hf else None, 774, 2 if hf else 0, nat.ptr(hout) if hf else None, None, M, ninst, 0, 0, 0, 8, None, None, 0, None, st))
 def tiles():
     for i in range(ninst):
         nat.check(lib.fdql_test_gemm(A[i * M:].data_ptr(), K, 1, W[i].data_ptr(), K, 1, b[i].data_ptr(), C0[i * M:].data_ptr(), N, M, N, K, 1, None, 0, 1, st))
