@@ -20,7 +20,7 @@ def per_kernel(rows, counter):
     for r in rows:
         if r["Counter_Name"] != counter or "fdql::" not in r["Kernel_Name"]:
             continue
-        key = (r["Kernel_Name"].split("(")[0], int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0))
+        key = (r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0], int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0))
         a = acc.setdefault(key, [0.0, 0])
         a[0] += float(r["Counter_Value"])
         a[1] += 1
@@ -50,10 +50,10 @@ try:
     for line in open(os.path.join(out, "bench_n1.json")):
         if line.startswith("{"):
             kn = json.loads(line)["roofline"]["kernel"]
-            dom_shape = kn.split("<")[1].split(" ")[0] if "<" in kn else "chain"
+            dom_shape = kn.split("<")[1].split(" ")[0] if "<" in kn else ("rows" if "k_rowgemm" in kn else "chain")
 except (OSError, KeyError, IndexError, ValueError):
     pass
-dom_tag = f"k_gemm_grouped<{shape_id[dom_shape]}," if dom_shape in shape_id else "k_chain"
+dom_tag = f"k_gemm_grouped<{shape_id[dom_shape]}," if dom_shape in shape_id else ("k_rowgemm" if dom_shape == "rows" else "k_chain")
 dom = [k for k in tot if dom_tag in k]
 
 
@@ -81,9 +81,9 @@ sq_rows = counter_rows("pmc_sq")
 if sq_rows:
     per = collections.OrderedDict()
     for r in sq_rows:
-        if "k_gemm" not in r["Kernel_Name"] and "k_chain" not in r["Kernel_Name"]:
+        if "k_gemm" not in r["Kernel_Name"] and "k_chain" not in r["Kernel_Name"] and "k_rowgemm" not in r["Kernel_Name"]:
             continue
-        key = (r["Kernel_Name"].split("(")[0], int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0))
+        key = (r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0], int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0))
         d = per.setdefault(key, collections.defaultdict(float))
         d[r["Counter_Name"]] += float(r["Counter_Value"])
         d["n_" + r["Counter_Name"]] += 1
@@ -91,8 +91,8 @@ if sq_rows:
     kt = sorted(glob.glob(os.path.join(out, "pmc_sq", "**", "*_kernel_trace.csv"), recursive=True), key=os.path.getmtime)
     if kt:
         for r in csv.DictReader(open(kt[-1])):
-            if "k_gemm" in r["Kernel_Name"] or "k_chain" in r["Kernel_Name"]:
-                key = (r["Kernel_Name"].split("(")[0], int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0))
+            if "k_gemm" in r["Kernel_Name"] or "k_chain" in r["Kernel_Name"] or "k_rowgemm" in r["Kernel_Name"]:
+                key = (r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0], int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0))
                 dur[key][0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
                 dur[key][1] += 1
     sq_lines = ["# rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY over",
