@@ -238,6 +238,22 @@ __device__ __forceinline__ void store_chunk_kc(float *__restrict__ lds, int tid,
   }
 }
 
+// K-contiguous operand kept K-contiguous in LDS (variant 5): [row][16 k] with the four 16-byte slots of a row permuted
+// by (row >> 2) & 3, ONE ds_write_b128 per thread instead of a transposing set of ds_write_b32; the fragment reads are
+// then two conflict-free ds_read_b128 per operand and chunk instead of eight ds_read_b32 (every LDS instruction costs
+// MFMA issue time: profiles/r02_rowgemm_notes.txt).
+template <int R, int NV, int BKT>
+__device__ __forceinline__ void store_chunk_kc128(float *__restrict__ lds, int tid, const float (&v)[4 * NV]) {
+  static_assert(BKT == 16, "four float4 slots per row");
+#pragma unroll
+  for (int h = 0; h < NV; ++h) {
+    const int slot = tid + GEMM_THREADS * h;
+    const int kq = slot & 3, r = slot >> 2;
+    if (r < R)
+      *reinterpret_cast<float4 *>(&lds[r * 16 + ((kq ^ ((r >> 2) & 3)) << 2)]) = make_float4(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
+  }
+}
+
 template <int R, int NV, int BKT>
 __device__ __forceinline__ void store_chunk_ks(float *__restrict__ lds, int tid, const float (&v)[4 * NV]) {
   constexpr int PITCH = R + 4, RQ = R / 4;
@@ -288,6 +304,10 @@ __device__ __forceinline__ void frag_read_dyn(float (&f)[T], unsigned addr, int 
     case 15: frag_read<T, 15, PITCH>(f, addr); break;
     default: frag_read<T, 0, PITCH>(f, addr); break;
   }
+}
+template <int OFF_BYTES>
+__device__ __forceinline__ void frag_read_b128(v4f &d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(d) : "v"(addr), "n"(OFF_BYTES));
 }
 template <int N>
 __device__ __forceinline__ void lds_wait() {
@@ -419,17 +439,102 @@ __global__ __launch_bounds__(GEMM_THREADS, TileCfg<SHAPE>::MINB) void k_gemm_gro
     vob = operand_lane_off<BN, BK>(sldb, sbkc, tid);
   };
   float va[4 * NVA], vb[4 * NVB];
+  constexpr bool F128 = PIPE == 2;
+  auto stage = [&](int buf, int akc, int bkc) {
+    if (akc) { if constexpr (F128) store_chunk_kc128<BM, NVA, BK>(lds[buf], tid, va); else store_chunk_kc<BM, NVA, BK>(lds[buf], tid, va); }
+    else store_chunk_ks<BM, NVA, BK>(lds[buf], tid, va);
+    if (bkc) { if constexpr (F128) store_chunk_kc128<BN, NVB, BK>(lds[buf] + BK * PA, tid, vb); else store_chunk_kc<BN, NVB, BK>(lds[buf] + BK * PA, tid, vb); }
+    else store_chunk_ks<BN, NVB, BK>(lds[buf] + BK * PA, tid, vb);
+  };
   if (have) {
     fetch_seg(s);
     load_operands<BM, BN, NVA, NVB, BK>(sA, slda, sakc, M, sB, sldb, sbkc, N, ke, r0, c0, k, tid, voa, vob, va, vb);
-    if (sakc) store_chunk_kc<BM, NVA, BK>(lds[0], tid, va); else store_chunk_ks<BM, NVA, BK>(lds[0], tid, va);
-    if (sbkc) store_chunk_kc<BN, NVB, BK>(lds[0] + BK * PA, tid, vb); else store_chunk_ks<BN, NVB, BK>(lds[0] + BK * PA, tid, vb);
+    stage(0, sakc, sbkc);
   }
   __syncthreads();
 
   int cur = 0;
+  int c_akc = sakc, c_bkc = sbkc;   // operand forms of the chunk staged in lds[cur] (F128 picks its fragment reads by them)
   // MFMAs of the chunk staged in lds[cur] (k, ke: its position in the current segment)
   auto run_chunk = [&]() {
+    if constexpr (F128) {
+      // k-pairing of an MFMA step: lanes lh = 0 supply k = kk, lanes lh = 1 k = 8 + kk (kk = 0..7; both operands agree).
+      // K-contiguous operand: the lane's 8 k's are two float4 slots of its row; K-strided operand: [k][row] as before.
+      const int ksteps = min(8, ke - k);
+      v4f fa[TM][2], fb[TN][2];
+      float sa[TM][8], sb[TN][8];
+      if (c_akc) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          const int row = wm * (TM * 32) + tm * 32 + li, sw = (row >> 2) & 3;
+          const unsigned base = lds_addr(lds[cur] + row * 16);
+          frag_read_b128<0>(fa[tm][0], base + ((unsigned)((2 * lh) ^ sw) << 4));
+          frag_read_b128<0>(fa[tm][1], base + ((unsigned)((2 * lh + 1) ^ sw) << 4));
+        }
+      } else {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          const unsigned base = lds_addr(lds[cur] + wm * (TM * 32) + tm * 32 + li + lh * 8 * PA);
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=&v"(sa[tm][kk]) : "v"(base), "n"(kk * PA * 4));
+        }
+      }
+      if (c_bkc) {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const int row = wn * (TN * 32) + tn * 32 + li, sw = (row >> 2) & 3;
+          const unsigned base = lds_addr(lds[cur] + BK * PA + row * 16);
+          frag_read_b128<0>(fb[tn][0], base + ((unsigned)((2 * lh) ^ sw) << 4));
+          frag_read_b128<0>(fb[tn][1], base + ((unsigned)((2 * lh + 1) ^ sw) << 4));
+        }
+      } else {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const unsigned base = lds_addr(lds[cur] + BK * PA + wn * (TN * 32) + tn * 32 + li + lh * 8 * PB);
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=&v"(sb[tn][kk]) : "v"(base), "n"(kk * PB * 4));
+        }
+      }
+      lds_wait<0>();
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        if (c_akc) {
+          asm volatile("" : "+v"(fa[tm][0]), "+v"(fa[tm][1]));
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) sa[tm][kk] = fa[tm][kk >> 2][kk & 3];
+        } else {
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) asm volatile("" : "+v"(sa[tm][kk]));
+        }
+      }
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        if (c_bkc) {
+          asm volatile("" : "+v"(fb[tn][0]), "+v"(fb[tn][1]));
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) sb[tn][kk] = fb[tn][kk >> 2][kk & 3];
+        } else {
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) asm volatile("" : "+v"(sb[tn][kk]));
+        }
+      }
+#if FDQL_MFMA_PRIO
+      __builtin_amdgcn_s_setprio(FDQL_MFMA_PRIO);
+#endif
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        if (kk >= ksteps) break;   // wave-uniform
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[tm][kk], sb[tn][kk], acc[tm][tn], 0, 0, 0);
+      }
+#if FDQL_MFMA_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
+      return;
+    }
     // Fragment reads are written as inline `ds_read_b32` with EARLY-CLOBBER destinations and explicit
     // lgkmcnt waits.  Reason (observed twice on gfx950, reproducible, LDS contents verified by a dump):
     // when hipcc allocates a fragment's destination VGPR on top of that read's own address VGPR
@@ -504,10 +609,10 @@ __global__ __launch_bounds__(GEMM_THREADS, TileCfg<SHAPE>::MINB) void k_gemm_gro
     run_chunk();
 
     if (!has_next) break;
-    if (n_akc) store_chunk_kc<BM, NVA, BK>(lds[cur ^ 1], tid, va); else store_chunk_ks<BM, NVA, BK>(lds[cur ^ 1], tid, va);
-    if (n_bkc) store_chunk_kc<BN, NVB, BK>(lds[cur ^ 1] + BK * PA, tid, vb); else store_chunk_ks<BN, NVB, BK>(lds[cur ^ 1] + BK * PA, tid, vb);
+    stage(cur ^ 1, n_akc, n_bkc);
     __syncthreads();
     cur ^= 1;
+    c_akc = n_akc; c_bkc = n_bkc;
     s = ns; k = nk; ke = nke;
   }
 
@@ -579,8 +684,8 @@ __global__ __launch_bounds__(GEMM_THREADS, TileCfg<SHAPE>::MINB) void k_gemm_gro
       for (k = 0; k < ke; k += BK) {
         __syncthreads();   // every wave is done reading the staging buffer
         load_operands<BM, BN, NVA, NVB, BK>(sA, slda, sakc, M, sB, sldb, sbkc, N, ke, r0, c0, k, tid, voa, vob, va, vb);
-        if (sakc) store_chunk_kc<BM, NVA, BK>(lds[0], tid, va); else store_chunk_ks<BM, NVA, BK>(lds[0], tid, va);
-        if (sbkc) store_chunk_kc<BN, NVB, BK>(lds[0] + BK * PA, tid, vb); else store_chunk_ks<BN, NVB, BK>(lds[0] + BK * PA, tid, vb);
+        stage(0, sakc, sbkc);
+        c_akc = sakc; c_bkc = sbkc;
         __syncthreads();
         cur = 0;
         run_chunk();
@@ -1109,6 +1214,10 @@ static void launch_shape(const GemmProblem *probs_dev, int nprob, int total_bloc
   switch (variant) {
     case 1: hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 16, 1>), g, b, 0, stream, probs_dev, nprob); break;
     case 4: hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 8, 1>), g, b, 0, stream, probs_dev, nprob); break;
+    case 5:   // b128 fragments of K-contiguous operands: the 64x64 shapes only (the others spill at their register caps)
+      if constexpr (SHAPE == GEMM_64x64 || SHAPE == GEMM_64x64_HF) hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 16, 2>), g, b, 0, stream, probs_dev, nprob);
+      else hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 16, 1>), g, b, 0, stream, probs_dev, nprob);
+      break;
     default: hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 16, 0>), g, b, 0, stream, probs_dev, nprob); break;
   }
 }
