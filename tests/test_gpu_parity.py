@@ -774,6 +774,13 @@ def _gpu_branch_pattern(ag, spec, xp_cpu):
     ("config 4 dims (obs 376, act 17, 5x25 quantiles, T=3, B=96)", dict(obs=376, act=17, C=5, Q=25, T=3, B=96)),
     ("config 2 full size, every forward pass through the row-block chain kernel (FDQL_CHAIN=all)",
      dict(obs=17, act=6, C=5, Q=2, T=50, B=256, env={"FDQL_CHAIN": "all"})),
+    ("config 2 full size, every critic layer through the persistent row-block kernel (forward forms with head fusion, "
+     "two-output layer 0, dgrad with the fused head dgrad: FDQL_ROWGEMM_FORMS=7)",
+     dict(obs=17, act=6, C=5, Q=2, T=50, B=256, env={"FDQL_ROWGEMM_FORMS": "7"})),
+    ("config 2 dims at T=4, B=64 with the row-block launches forced (one tile per workgroup: prologue + flush paths)",
+     dict(obs=17, act=6, C=5, Q=2, T=4, B=64, env={"FDQL_ROWGEMM": "all", "FDQL_ROWGEMM_FORMS": "7"})),
+    ("config 2 full size without the row-block kernel (FDQL_ROWGEMM=0: k_head_dgrad + tile kernels)",
+     dict(obs=17, act=6, C=5, Q=2, T=50, B=256, env={"FDQL_ROWGEMM": "0"})),
 ])
 def test_gradient_parity_three_way_fp64(dev, name, kw, monkeypatch):
     """north_star: gradients within 1e-5 rel fp32 of the reference CPU path.  Two fp32 evaluations of this loss cannot
