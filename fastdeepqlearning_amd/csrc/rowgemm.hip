@@ -672,7 +672,8 @@ bool rowgemm_from_problems(const GemmProblem *probs, int nprob, RowGemmArgs &arg
       if (slot > 0 && (sg.K < 1 || sg.K > 8)) return false;
       if (fz && slot > 0 && (sg.K != 2 || sg.lda % 2 || (reinterpret_cast<uintptr_t>(sg.A) & 7))) return false;   // dY rows read as float2
       if (slot == 0 && (sg.lda % 4 || (reinterpret_cast<uintptr_t>(sg.A) & 15))) return false;
-      if (!ks && slot == 0 && (sg.ldb % 4 || (reinterpret_cast<uintptr_t>(sg.B) & 15))) return false;
+      // (K-contiguous weights: any row pitch - gfx950 serves dwordx4 loads from 4-byte aligned addresses, and the critics'
+      // layer-0 weights have rows of 256 + act_dim floats)
       if (ks && (sg.ldb % 2 || (reinterpret_cast<uintptr_t>(sg.B) & 7))) return false;
       I.A[slot] = sg.A; I.W[slot] = sg.B;
       if (i == 0) {
