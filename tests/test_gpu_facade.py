@@ -328,6 +328,71 @@ def test_data_parallel_sharding_on_device(dev):
     assert sum(close) >= 0.9 * len(close)
 
 
+def test_config4_full_size_two_rank_split_on_device(dev):
+    """BASELINE config 4 at its full size - TQC 5 x 25 quantiles, obs 376, act 17, MLP 256, T = 50, GLOBAL batch of 1024
+    windows from 2 M-slot ring shards - as bench.py --gpus 2 runs it, but with both ranks on this card: each rank samples
+    512 windows from its own shard (fdql_ring_sample_windows, Philox starts), FDQL_PHASE_GRAD, gradient arenas summed,
+    FDQL_PHASE_APPLY.  Size-independent properties (the CPU oracle would need minutes here): the summed arena equals the
+    gradient of ONE agent stepping on the concatenated 1024 windows (fp32 summation order), both replicas end bit-identical,
+    and the sampled windows are bit-exact gathers of the ring rows they name."""
+    from fastdeepqlearning_amd import _native as nat
+    from fastdeepqlearning_amd.core import NativeAgent, NativeRing, make_config
+    T, Bg, obs, act = 50, 1024, 376, 17
+    keys = ["obs_1d", "action", "reward", "mc_return", "task_done", "episode_done", "episode_step", "idx"]
+    dims = [obs, act, 1, 1, 1, 1, 1, 1]
+    slots = 2_000_000
+    mk = lambda B, world: NativeAgent(make_config(obs, act, T, B, n_critics=5, n_quantiles=25, latent=256, enc_features=256,
+                                                  enc_hidden=(256,), joint_hidden=(256,), pi_hidden=(256,), critic_hidden=(256, 256),
+                                                  world_size=world), dev)
+    whole, ranks = mk(Bg, 1), [mk(Bg // 2, 2), mk(Bg // 2, 2)]
+    whole.init_weights(3)
+    for ag in ranks:
+        ag.load_tensors({k: v.clone() for k, v in whole.tensors.items()})
+    g = torch.Generator(device=dev).manual_seed(5)
+    batches = []
+    for r in range(2):
+        ring = NativeRing(slots, dims, dev)
+        n = 600_000   # rows written to this 2 M-slot shard (3.8 GB of f32 rows)
+        rows = torch.randn(n, sum(dims), device=dev, generator=g)
+        ep = torch.arange(n, device=dev) % 1000
+        rows[:, obs + act + 2] = (torch.rand(n, device=dev, generator=g) < 0.001).float()     # task_done
+        rows[:, obs + act + 3] = (ep == 999).float()                                            # episode_done
+        rows[:, obs + act + 4] = ep.float()                                                     # episode_step
+        rows[:, obs + act + 5] = torch.arange(n, device=dev).float()                            # idx
+        rows[:, obs:obs + act].clamp_(-0.999, 0.999)
+        ring.add_rows(rows)
+        outs = [torch.empty(T, Bg // 2, d, device=dev) for d in dims]
+        _, starts = ring.sample_windows(T, Bg // 2, seed=11 + r, counter=0, outs=outs, return_starts=True)
+        xp = dict(zip(keys, outs))
+        # the gather is exact: window b at time t is ring row starts[b] + t
+        sel = torch.randint(0, Bg // 2, (16,), device=dev, generator=g)
+        for b in sel.tolist():
+            want = rows[int(starts[b]):int(starts[b]) + T]
+            got = torch.cat([o[:, b] for o in outs], dim=1)
+            assert torch.equal(got, want)
+        batches.append(xp)
+        del ring, rows
+    use = ["obs_1d", "action", "reward", "mc_return", "task_done", "episode_step"]
+    nz = [torch.randn(T - 1, Bg, act, device=dev, generator=g) for _ in range(2)]
+    cat = {k: torch.cat([batches[0][k], batches[1][k]], dim=1).contiguous() for k in use}
+    whole.update(cat, nz[0], nz[1], phase=nat.PHASE_GRAD)
+    for r, ag in enumerate(ranks):
+        sl = slice(512 * r, 512 * (r + 1))
+        ag.update({k: batches[r][k] for k in use}, nz[0][:, sl].contiguous(), nz[1][:, sl].contiguous(), phase=nat.PHASE_GRAD)
+    total = ranks[0].grads + ranks[1].grads
+    ref = whole.grads
+    torch.cuda.synchronize()
+    assert float((total - ref).abs().max() / ref.abs().max()) < 2e-5
+    for ag in ranks:
+        ag.grads.copy_(total)
+        ag.update(None, phase=nat.PHASE_APPLY)
+    whole.update(None, phase=nat.PHASE_APPLY)
+    torch.cuda.synchronize()
+    for k in whole.tensors:
+        assert torch.equal(ranks[0].tensors[k], ranks[1].tensors[k]), k
+    assert ranks[0].scalars()["step"] == 1
+
+
 def test_device_noise_statistics_and_determinism(dev):
     """Philox path (perf runs): same seed/step -> same result; actions inside (-1, 1); noise ~ N(0,1)."""
     from test_gpu_parity import _agent_for
