@@ -1,6 +1,7 @@
 """Prototype check: row-block stationary layer (tools/proto/rowblock.hip) vs the product grouped GEMM on
 C = lrelu(A W^T + b), N = 256.  Interleaved rounds in one process (box clocks drift between invocations)."""
 import ctypes, os, sys, torch
+os.environ.setdefault("FDQL_ROWGEMM_FORMS", "7")   # the forward form is off by default in the update
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from fastdeepqlearning_amd import _native as nat

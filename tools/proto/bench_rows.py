@@ -1,6 +1,7 @@
 """Row-block kernel (fdql_test_rowgemm) on `ninst` instances of one layer, against the 64x64-tile grouped kernel on the
 same work: bench_rows.py [M_per_instance] [ninst] [hf]"""
 import os, sys, torch
+os.environ.setdefault("FDQL_ROWGEMM_FORMS", "7")
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from fastdeepqlearning_amd import _native as nat
