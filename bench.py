@@ -56,7 +56,8 @@ WORKLOADS = {
 def csrc_hash():
     """sha256 over the HIP sources: profiles collected on another revision are not quoted as this one's."""
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "fastdeepqlearning_amd", "csrc", "*.h*"))):
+    d = os.path.join(ROOT, "fastdeepqlearning_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
@@ -129,6 +130,28 @@ class Job:
             self.step(first + warmup + i)
         torch.cuda.synchronize(self.dev)
         return time.perf_counter() - t0
+
+    def timed_windows(self, steps, warmup, windows=3):
+        """`windows` back-to-back timed windows of `steps` steps after `warmup`: per-window steps/s (wall clock around a
+        synchronised window) and the longest single step of all windows (HIP events between steps): one stalled step
+        in a window shows up as max_step_ms instead of silently halving the figure."""
+        for i in range(warmup):
+            self.step(i)
+        torch.cuda.synchronize(self.dev)
+        rates, max_ms, first = [], 0.0, warmup
+        for _ in range(windows):
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+            t0 = time.perf_counter()
+            evs[0].record()
+            for i in range(steps):
+                self.step(first + i)
+                evs[i + 1].record()
+            torch.cuda.synchronize(self.dev)
+            rates.append(steps / (time.perf_counter() - t0))
+            max_ms = max(max_ms, max(evs[i].elapsed_time(evs[i + 1]) for i in range(steps)))
+            first += steps
+        rates.sort()
+        return rates[len(rates) // 2], rates, max_ms
 
     def kernel_profile(self, reps=3):
         """name -> (ms, flops, bytes, launches) per step, HIP events on the launch stream."""
@@ -269,14 +292,17 @@ def cpu_baseline(w, T, B, seconds_budget=25.0):
                       f"{el:.1f} s [{detail}]"}
 
 
-def secondary(name, dev, steps=12, warmup=3, **kw):
-    """steps/s of another BASELINE config on this one GPU + its dominant kernel's fraction (never `value`)."""
+def secondary(name, dev, steps=200, warmup=10, **kw):
+    """steps/s of another BASELINE config on this one GPU + its dominant kernel's fraction (never `value`): the median of
+    three windows of `steps` steps each, every window's figure and the longest single step listed beside it."""
     w = WORKLOADS[name]
     job = Job(w, dev, kw.pop("B", w["B"]), kw.pop("T", w["T"]), **kw)
-    el = job.timed(steps, warmup)
+    plans0 = job.agent.stats()["plans_built"]
+    med, rates, max_ms = job.timed_windows(steps, warmup)
     r, _ = roofline_of(job, committed_pmc=False)
-    out = {"workload": w["text"] + f", B={job.B} x T={job.T}", "value": round(steps / el, 2), "unit": "steps/s",
-           "ms_per_step": round(1e3 * el / steps, 4), "steps": steps,
+    out = {"workload": w["text"] + f", B={job.B} x T={job.T}", "value": round(med, 2), "unit": "steps/s",
+           "ms_per_step": round(1e3 / med, 4), "steps": steps, "windows": [round(x, 2) for x in rates],
+           "max_step_ms": round(max_ms, 4), "plans_built_in_windows": job.agent.stats()["plans_built"] - plans0,
            "dominant_kernel": r["kernel"], "dominant_kernel_tflops": r["achieved"], "dominant_kernel_frac": r["frac"],
            "all_mfma_kernels_tflops": r["all_mfma_kernels"]["achieved"],
            "sampler_gbs": sampler_roofline(job, 20)["achieved"]}
@@ -311,7 +337,7 @@ def config3_her_ingest(dev, episodes=400):
     return round(n / (time.perf_counter() - t0), 0)
 
 
-def config5_secondary(dev, ring=200_000, B=512, T=50, steps=6):
+def config5_secondary(dev, ring=200_000, B=512, T=50, steps=20):
     """BASELINE config 5 (discrete SAC on 4x84x84 uint8 frame stacks, conv encoder of this build - no reference exists,
     SURVEY 8d) at the full batch on a 200k-frame uint8 ring (5.6 GB; the step does not depend on the ring's length)."""
     from fastdeepqlearning_amd.core import NativeAgent, NativeRing, make_config
@@ -345,15 +371,19 @@ def config5_secondary(dev, ring=200_000, B=512, T=50, steps=6):
     for i in range(2):
         step(i)
     torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for i in range(steps):
-        step(10 + i)
-    torch.cuda.synchronize(dev)
-    dt = (time.perf_counter() - t0) / steps
+    dts = []
+    for wnd in range(3):                      # median of three windows (>= 2 s in all)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(10 + wnd * steps + i)
+        torch.cuda.synchronize(dev)
+        dts.append((time.perf_counter() - t0) / steps)
+    dt = sorted(dts)[1]
     fl = agent.stats()["gemm_flops"]
     out = {"workload": f"BASELINE config 5: discrete SAC (6 actions), 4x84x84 uint8 frame stacks, conv 32x8/4-64x4/2-64x3/1, "
                        f"B={B} x T={T}, {ring}-frame uint8 ring (conv encoder: no reference exists, throughput only)",
            "value": round(1 / dt, 2), "unit": "steps/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+           "windows": [round(1 / d, 2) for d in dts],
            "frames_per_s": round(T * B / dt, 0), "all_mfma_kernels_tflops_over_step": round(fl / dt / 1e12, 1),
            "workspace_GiB": round(agent.workspace.numel() / 2 ** 30, 1)}
     del agent, r, outs, xp, flat
@@ -469,7 +499,7 @@ def bench_single(args, dev, T):
         facade = facade_path(dev)
         extras = {}
         for name, fn in (("config3_her", lambda: dict(secondary("config3", dev), her_ingest_records_per_s=config3_her_ingest(dev))),
-                         ("config4_1gpu_B1024", lambda: secondary("config4", dev, steps=8, warmup=2)),
+                         ("config4_1gpu_B1024", lambda: secondary("config4", dev, steps=100, warmup=5)),
                          ("config5_B512", lambda: config5_secondary(dev))):
             try:
                 extras[name] = fn()
@@ -480,7 +510,7 @@ def bench_single(args, dev, T):
     return {
         "metric": "gradient-steps/sec", "value": round(args.steps / el, 2), "unit": "steps/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "none", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{w['text']}, B={B} windows x temporal_len T={T} (reference default), "
                                f"sample+loss+backward+Adam+polyak per step",
                    "global_batch_windows": B, "temporal_len": T, "transitions_per_step": B * T, "ring": w["ring"],

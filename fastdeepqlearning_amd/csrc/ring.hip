@@ -371,9 +371,18 @@ struct fdql_ring {
   // Used only once a second stream has been seen on this handle.
   hipStream_t first_stream = nullptr;
   bool have_stream = false, multi_stream = false;
-  hipEvent_t wr_done = nullptr, rd_done = nullptr;
-  hipStream_t wr_stream = nullptr, rd_stream = nullptr;
-  bool has_wr = false, has_rd = false;
+  // One event for the last writer; one per distinct reader stream (RING_RD_SLOTS of them; when they run out a new
+  // reader first waits for the slot it takes over, so its own event stands for both).  While the handle has seen one
+  // stream the events are not recorded; the moment a second stream shows up every pending one is recorded on its own
+  // stream (conservative: after everything issued there so far) before anybody waits on it.
+  static constexpr int RING_RD_SLOTS = 4;
+  hipEvent_t wr_done = nullptr;
+  hipStream_t wr_stream = nullptr;
+  bool has_wr = false;
+  hipEvent_t rd_done[RING_RD_SLOTS] = {};
+  hipStream_t rd_stream[RING_RD_SLOTS] = {};
+  bool has_rd[RING_RD_SLOTS] = {};
+  int rd_next = 0;
   // episode append staging (fdql_ring_append_episode)
   float *ep_pinned = nullptr, *ep_in = nullptr, *ep_out = nullptr;
   int64_t ep_in_cap = 0, ep_out_cap = 0;   // rows
@@ -396,38 +405,53 @@ void advance(fdql_ring *r, int64_t n) {
   }
 }
 
-void see_stream(fdql_ring *r, hipStream_t s) {
-  if (!r->have_stream) { r->first_stream = s; r->have_stream = true; }
-  else if (s != r->first_stream) r->multi_stream = true;
+int see_stream(fdql_ring *r, hipStream_t s) {
+  if (!r->have_stream) { r->first_stream = s; r->have_stream = true; return 0; }
+  if (s == r->first_stream || r->multi_stream) return 0;
+  // second stream: whatever was issued while single-stream has no recorded event yet - record it now, on its stream
+  r->multi_stream = true;
+  if (r->has_wr) FDQL_HIP(hipEventRecord(r->wr_done, r->wr_stream));
+  for (int i = 0; i < fdql_ring::RING_RD_SLOTS; ++i)
+    if (r->has_rd[i]) FDQL_HIP(hipEventRecord(r->rd_done[i], r->rd_stream[i]));
+  return 0;
 }
 // a launch on `s` that WRITES ring slots: after every read issued on another stream, and after writes elsewhere
 int begin_write(fdql_ring *r, hipStream_t s) {
-  see_stream(r, s);
-  if (!r->multi_stream) return 0;
-  if (r->has_rd && r->rd_stream != s) FDQL_HIP(hipStreamWaitEvent(s, r->rd_done, 0));
+  int rc = see_stream(r, s);
+  if (rc || !r->multi_stream) return rc;
+  for (int i = 0; i < fdql_ring::RING_RD_SLOTS; ++i)
+    if (r->has_rd[i] && r->rd_stream[i] != s) FDQL_HIP(hipStreamWaitEvent(s, r->rd_done[i], 0));
   if (r->has_wr && r->wr_stream != s) FDQL_HIP(hipStreamWaitEvent(s, r->wr_done, 0));
   return 0;
 }
 int end_write(fdql_ring *r, hipStream_t s) {
-  r->wr_stream = s; r->has_wr = true;   // remembered even while single-stream: a later second stream waits for it
+  r->wr_stream = s; r->has_wr = true;   // remembered even while single-stream: see_stream() records it later
   if (!r->multi_stream) return 0;
   FDQL_HIP(hipEventRecord(r->wr_done, s));
   return 0;
 }
 int begin_read(fdql_ring *r, hipStream_t s) {
-  see_stream(r, s);
-  if (!r->multi_stream) return 0;
-  if (r->has_wr && r->wr_stream != s) {
-    // a write issued before the second stream appeared has no recorded event yet: record it now on its own stream
-    FDQL_HIP(hipEventRecord(r->wr_done, r->wr_stream));
-    FDQL_HIP(hipStreamWaitEvent(s, r->wr_done, 0));
-  }
+  int rc = see_stream(r, s);
+  if (rc || !r->multi_stream) return rc;
+  if (r->has_wr && r->wr_stream != s) FDQL_HIP(hipStreamWaitEvent(s, r->wr_done, 0));
   return 0;
 }
 int end_read(fdql_ring *r, hipStream_t s) {
-  r->rd_stream = s; r->has_rd = true;
+  int slot = -1;
+  for (int i = 0; i < fdql_ring::RING_RD_SLOTS; ++i)
+    if (r->has_rd[i] && r->rd_stream[i] == s) { slot = i; break; }
+  if (slot < 0)
+    for (int i = 0; i < fdql_ring::RING_RD_SLOTS; ++i)
+      if (!r->has_rd[i]) { slot = i; break; }
+  if (slot < 0) {
+    // every slot tracks another stream: take one over; this stream waits for that reader first, so the event recorded
+    // below also covers it (multi_stream is necessarily true here, so its event is recorded)
+    slot = r->rd_next; r->rd_next = (r->rd_next + 1) % fdql_ring::RING_RD_SLOTS;
+    FDQL_HIP(hipStreamWaitEvent(s, r->rd_done[slot], 0));
+  }
+  r->rd_stream[slot] = s; r->has_rd[slot] = true;
   if (!r->multi_stream) return 0;
-  FDQL_HIP(hipEventRecord(r->rd_done, s));
+  FDQL_HIP(hipEventRecord(r->rd_done[slot], s));
   return 0;
 }
 
@@ -546,7 +570,8 @@ int fdql_ring_create_typed(fdql_ring_t **out, int64_t maxlen, int32_t n_keys, co
     if (e != hipSuccess) { set_error("ring staging buffers: %s", hipGetErrorString(e)); fdql_ring_destroy(r); return FDQL_ENOMEM; }
   }
   hipError_t e = hipEventCreateWithFlags(&r->wr_done, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&r->rd_done, hipEventDisableTiming);
+  for (int i = 0; i < fdql_ring::RING_RD_SLOTS && e == hipSuccess; ++i)
+    e = hipEventCreateWithFlags(&r->rd_done[i], hipEventDisableTiming);
   if (e != hipSuccess) { set_error("ring events: %s", hipGetErrorString(e)); fdql_ring_destroy(r); return FDQL_EHIP; }
   *out = r;
   return 0;
@@ -563,7 +588,8 @@ int fdql_ring_destroy(fdql_ring_t *r) {
     if (r->stage_done[i]) (void)hipEventDestroy(r->stage_done[i]);
   }
   if (r->wr_done) (void)hipEventDestroy(r->wr_done);
-  if (r->rd_done) (void)hipEventDestroy(r->rd_done);
+  for (int i = 0; i < fdql_ring::RING_RD_SLOTS; ++i)
+    if (r->rd_done[i]) (void)hipEventDestroy(r->rd_done[i]);
   if (r->ep_pinned) (void)hipHostFree(r->ep_pinned);
   if (r->ep_in) (void)hipFree(r->ep_in);
   if (r->ep_out) (void)hipFree(r->ep_out);

@@ -353,20 +353,19 @@ int32_t fdql_agent_profile_update(fdql_agent_t *agent, const fdql_batch_t *batch
 
 /* ------------------------------------------------------------------------------------ */
 /* Test hook: the grouped MFMA GEMM on its own (C = A * op(B) + bias, fp32)               */
+int fdql_test_gemm(const float *A, int32_t lda, int32_t a_kc, const float *B, int32_t ldb, int32_t b_kc,
+                   const float *bias, float *C, int32_t ldc, int32_t M, int32_t N, int32_t K,
+                   int32_t epilogue, const float *ref, int32_t ldref, int32_t ksplit, void *stream);
+
 /* Test hook: one SkipHeadMLP forward (franQ/Agent/models/mlp.py:88-94) through the row-block chain kernel
  * (csrc/chain.hip).  weights: the MLP's tensors packed as the agent's arena packs them (per hidden layer W [h, in]
  * then b [h], then head W [dout, din + sum(h)] and b [dout]; each padded to a multiple of 4 floats).
  * h_out: NULL or nh device pointers [rows, h_i].  Synchronises `stream`. */
+int fdql_test_chain_mlp(const float *x, int32_t rows, int32_t din, const int32_t *hid, int32_t nh, int32_t dout,
+                        const float *weights, float *const *h_out, float *out, void *stream);
 /* Diagnostic: with FDQL_CHAIN_STAMPS=1 in the environment the middle workgroup of every chain launch records the
  * shader clock at its entry, after its program fetch and after each operation; returns the count copied. */
 int fdql_debug_chain_stamps(uint64_t *out, int32_t cap);
-int fdql_test_chain_mlp(const float *x, int32_t rows, int32_t din, const int32_t *hid, int32_t nh, int32_t dout,
-                        const float *weights, float *const *h_out, float *out, void *stream);
-
-/* ------------------------------------------------------------------------------------ */
-int fdql_test_gemm(const float *A, int32_t lda, int32_t a_kc, const float *B, int32_t ldb, int32_t b_kc,
-                   const float *bias, float *C, int32_t ldc, int32_t M, int32_t N, int32_t K,
-                   int32_t epilogue, const float *ref, int32_t ldref, int32_t ksplit, void *stream);
 
 /* Diagnostic: (shader cycles, 100 MHz wall ticks) of every workgroup's life in the last row-block launch, interleaved;
  * cycles / ticks / 10 = shader clock in GHz under that launch's load.  Returns the count of values copied. */

@@ -219,3 +219,33 @@ def test_ring_orders_writes_and_reads_across_streams(dev):
         s_r.synchronize()
         assert bool((got == float(rnd)).all()), rnd
     torch.cuda.synchronize(dev)
+
+
+def test_ring_orders_a_writer_that_moves_to_a_new_stream(dev):
+    """Several rounds on ONE stream (no ordering events recorded yet), then the writer moves to a second stream while
+    a slow gather is still queued on the first: the scatter must wait for that read (write-after-read across the
+    single-stream -> multi-stream transition), and a reader on a third stream must still see it."""
+    from fastdeepqlearning_amd.core import NativeRing
+    n = 2048
+    ring = NativeRing(n, [4, 1], dev)
+    s_a, s_b, s_c = torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    idx = torch.arange(n, device=dev)
+    with torch.cuda.stream(s_a):
+        for rnd in range(5):
+            ring.add_rows(torch.full((n, 5), float(rnd), device=dev))
+            assert bool((ring.gather_rows(idx)[0] == float(rnd)).all())
+        # a long queue on stream A, then the gather of the rows of round 4
+        spin = torch.randn(4096, 4096, device=dev)
+        for _ in range(6):
+            spin = spin @ spin * 1e-4
+        got_a = ring.gather_rows(idx)[0]
+    with torch.cuda.stream(s_b):          # first time this handle sees a second stream: overwrite every slot
+        ring.add_rows(torch.full((n, 5), 99.0, device=dev))
+    with torch.cuda.stream(s_c):          # a second reader stream
+        got_c = ring.gather_rows(idx)[0]
+    with torch.cuda.stream(s_a):          # the writer comes back: must wait for BOTH readers
+        ring.add_rows(torch.full((n, 5), 7.0, device=dev))
+    torch.cuda.synchronize(dev)
+    assert bool((got_a == 4.0).all()), "scatter on the new stream overtook the gather queued on the old one"
+    assert bool((got_c == 99.0).all()), "reader on a third stream missed / was overwritten"
+    assert bool((ring.gather_rows(idx)[0] == 7.0).all())

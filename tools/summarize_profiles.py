@@ -61,7 +61,8 @@ def csrc_hash():
     import hashlib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(root, "fastdeepqlearning_amd", "csrc", "*.h*"))):
+    d = os.path.join(root, "fastdeepqlearning_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
