@@ -20,6 +20,7 @@
 
 #include "chain.h"
 #include "rowgemm.h"
+#include "wstat.h"
 #include "common.h"
 #include "update_kernels.h"
 
@@ -90,6 +91,14 @@ inline int conv_wsplit(long long R) { return (int)std::max<long long>(1, std::mi
 
 enum StageKind { ST_GEMM, ST_SKINNY_WGRAD, ST_FUNC, ST_HEAD_DGRAD, ST_CHAIN };
 
+// one launch of a row-block kernel: the weight-stationary one (wstat.hip, forward forms) or the streamed-weights one
+struct RowsLaunch {
+  bool ws = false;
+  RowGemmArgs rg;
+  WsArgs wa;
+  hipError_t launch(hipStream_t s) const { return ws ? wstat_launch(wa, s) : rowgemm_launch(rg, s); }
+};
+
 struct GemmSub {
   std::vector<GemmProblem> probs;
   void *dev = nullptr;
@@ -102,7 +111,7 @@ struct Stage {
   std::vector<GemmProblem> gemm;
   GemmSub sub[GEMM_NSHAPES];  // the problems of `gemm`, grouped by tile shape (one launch each)
   bool try_rows = false;      // ST_GEMM: groups of like problems may run on the persistent row-block kernel (rowgemm.hip)
-  std::vector<RowGemmArgs> rows;   // the groups that do (one launch each); their problems are not in `sub`
+  std::vector<RowsLaunch> rows;    // the groups that do (one launch each); their problems are not in `sub`
   std::vector<SkinnyWgradProblem> swg;
   std::vector<HeadDgradProblem> hdg;
   std::vector<ChainProblem> cprobs;   // ST_CHAIN: programs (chain.h) and their operations
@@ -783,10 +792,14 @@ int upload_tables(fdql_agent *a) {
               idx.push_back(j);
             }
           }
-          RowGemmArgs ra;
+          RowsLaunch rl;
           const long long tiles = (long long)grp.size() * (grp[0].M / RG_BM);
-          if (tiles >= a->rows_min_tiles && rowgemm_from_problems(grp.data(), (int)grp.size(), ra)) {
-            s.rows.push_back(ra);
+          if (tiles >= a->rows_min_tiles && wstat_from_problems(grp.data(), (int)grp.size(), rl.wa)) {
+            rl.ws = true;
+            s.rows.push_back(rl);
+            for (size_t j : idx) taken[j] = 1;
+          } else if (tiles >= a->rows_min_tiles && rowgemm_from_problems(grp.data(), (int)grp.size(), rl.rg)) {
+            s.rows.push_back(rl);
             for (size_t j : idx) taken[j] = 1;
           } else {
             for (size_t j : idx) taken[j] = 2;   // looked at, stays on the tile kernels
@@ -1499,8 +1512,8 @@ int build_plan(fdql_agent *a) {
 hipError_t run_stage(fdql_agent *a, Stage &s, hipStream_t stream) {
   switch (s.kind) {
     case ST_GEMM:
-      for (const RowGemmArgs &ra : s.rows) {
-        hipError_t e = rowgemm_launch(ra, stream);
+      for (const RowsLaunch &rl : s.rows) {
+        hipError_t e = rl.launch(stream);
         if (e != hipSuccess) return e;
       }
       for (int sh = 0; sh < GEMM_NSHAPES; ++sh) {
@@ -1806,7 +1819,7 @@ int32_t fdql_agent_profile_update(fdql_agent_t *a, const fdql_batch_t *batch, co
       const GemmSub &sub = parts[i].st->sub[parts[i].shape];
       e = gemm_launch((const GemmProblem *)sub.dev, (int)sub.probs.size(), sub.blocks, parts[i].shape, s);
     } else if (parts[i].shape < -1) {
-      e = rowgemm_launch(parts[i].st->rows[-2 - parts[i].shape], s);
+      e = parts[i].st->rows[-2 - parts[i].shape].launch(s);
     } else {
       e = run_stage(a, *parts[i].st, s);
     }
@@ -1826,10 +1839,17 @@ int32_t fdql_agent_profile_update(fdql_agent_t *a, const fdql_batch_t *batch, co
       for (const auto &p : st.sub[parts[i].shape].probs) { flops += gemm_flops(p); bytes += gemm_bytes(p); }
       snprintf(out[cnt].name, sizeof(out[cnt].name), "gemm%s:%s", shape_names[parts[i].shape], st.name.c_str());
     } else if (parts[i].shape < -1) {
-      const RowGemmArgs &ra = st.rows[-2 - parts[i].shape];
+      const RowsLaunch &rl = st.rows[-2 - parts[i].shape];
+      if (rl.ws) {
+        flops = wstat_flops(rl.wa);
+        bytes = 4.0 * rl.wa.M * rl.wa.ninst * (double)(WS_KMAIN + WS_N * (rl.wa.dual ? 2 : 1));
+        snprintf(out[cnt].name, sizeof(out[cnt].name), "wstat%s%s:%s", rl.wa.dual ? "dual" : "", rl.wa.hf_q ? "hf" : "", st.name.c_str());
+      } else {
+      const RowGemmArgs &ra = rl.rg;
       flops = rowgemm_flops(ra);
       bytes = 4.0 * ra.M * ra.ninst * (double)(RG_KMAIN + RG_N * (ra.dual ? 2 : 1) + (ra.grad ? RG_N : 0));
       snprintf(out[cnt].name, sizeof(out[cnt].name), "rows%s%s:%s", ra.grad ? "KS" : "", ra.dual ? "dual" : "", st.name.c_str());
+      }
     } else {
       snprintf(out[cnt].name, sizeof(out[cnt].name), "%s%s", st.kind == ST_SKINNY_WGRAD ? "colsum:" : (st.kind == ST_CHAIN ? "chain:" : "k:"),
                st.name.c_str());
@@ -2163,10 +2183,12 @@ int fdql_test_rowgemm(const float *A0, const float *A1, int32_t k1, const float 
     }
     probs.push_back(p);
   }
-  RowGemmArgs ra;
-  FDQL_REQUIRE(rowgemm_from_problems(probs.data(), (int)probs.size(), ra), "the row-block kernel does not take this form");
-  hipError_t e = rowgemm_launch(ra, (hipStream_t)stream);
-  if (e != hipSuccess) { set_error("rowgemm launch: %s", hipGetErrorString(e)); return FDQL_EHIP; }
+  // the forward forms go to the weight-stationary kernel (wstat.hip) unless FDQL_WSTAT=0, as in the update's plan
+  RowsLaunch rl;
+  if (wstat_from_problems(probs.data(), (int)probs.size(), rl.wa)) rl.ws = true;
+  else FDQL_REQUIRE(rowgemm_from_problems(probs.data(), (int)probs.size(), rl.rg), "the row-block kernels do not take this form");
+  hipError_t e = rl.launch((hipStream_t)stream);
+  if (e != hipSuccess) { set_error("row-block launch: %s", hipGetErrorString(e)); return FDQL_EHIP; }
   return 0;
 }
 

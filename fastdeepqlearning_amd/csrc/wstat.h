@@ -1,0 +1,42 @@
+// Weight-stationary persistent row-block GEMM (wstat.hip) for the forward layers of the critic ensemble: a launch is a set
+// of INSTANCES (critic k x {target, online, frozen}) of one Linear layer of 256 outputs,
+//   C[M, 256] = LeakyReLU( A0[M, 256] W0^T + A1[M, K1] W1^T (+ A2[M, K2] W2^T) + bias )      K1, K2 <= 8 (the action columns)
+// and every workgroup belongs to ONE instance for its whole life: the instance's 256 x 256 weights sit in the AccVGPRs
+// of its four waves (64 output columns x 256 k = 256 registers per lane), so the K loop issues no weight loads at all.
+#pragma once
+#include "common.h"
+
+namespace fdql {
+
+constexpr int WS_BM = 32;          // rows per tile
+constexpr int WS_N = 256;          // output columns (4 waves x 64)
+constexpr int WS_KMAIN = 256;      // K of the main segment
+constexpr int WS_MAX_MINOR = 2;    // narrow K-segments beside it, one 8-k MFMA step each
+constexpr int WS_MAX_INST = 16;    // the table travels in the kernel arguments (scalar loads)
+
+struct WsInst {
+  const float *A[1 + WS_MAX_MINOR];   // activations of the segments, [0] = main; row-major, K contiguous
+  const float *W[1 + WS_MAX_MINOR];   // weights of the segments, K contiguous: element (n, k) at W[n*ldw + k]
+  const float *bias;                  // [256]
+  float *C, *C2;                      // outputs [M, 256]; C2: second output of a dual launch
+  const float *hf_w;                  // head fusion (common.h, GemmProblem::hf_*): head weight rows over this layer's columns
+  float *hf_out, *hf_out2;
+};
+
+struct WsArgs {
+  int M;                     // rows per instance, multiple of 32
+  int ninst, blocks_per_inst;
+  int nminor, kminor[WS_MAX_MINOR];
+  int lda[1 + WS_MAX_MINOR], ldw[1 + WS_MAX_MINOR];
+  int dual;                  // 1: C = f(all segments but the last), C2 = f(all)
+  int hf_q, hf_ldw;          // head fusion: outputs per row (2), 0 = off
+  int wg_first[WS_MAX_INST + 1];   // workgroups [wg_first[i], wg_first[i+1]) serve instance i (block j, j + n, ... of it)
+  WsInst inst[WS_MAX_INST];
+};
+
+// Can these problems (one launch group) run as one weight-stationary launch?  Fills args when they can.
+bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args);
+hipError_t wstat_launch(const WsArgs &args, hipStream_t stream);
+double wstat_flops(const WsArgs &a);
+
+}  // namespace fdql

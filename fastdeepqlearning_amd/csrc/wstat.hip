@@ -1,0 +1,508 @@
+// Weight-stationary persistent row-block fp32 MFMA GEMM for the forward layers of the critic ensemble (wstat.h).
+//
+// One 256-thread workgroup per CU serves ONE instance for its whole life and walks that instance's 32-row tiles.  Each of
+// its 4 waves owns 64 of the 256 output columns and keeps the 64 x 256 weights of those columns in its 256 AccVGPRs (the
+// register file of a CU holds a whole 256 x 256 fp32 layer), so the K loop of a tile issues NO weight loads: 8 MFMAs
+// (v_mfma_f32_32x32x2_f32, 512 cycles) per ds_read_b128 of activations.  fp32 MFMA and the vector ALU share one issue
+// stream on gfx950 (profiles/r02_rowgemm_notes.txt), so what counts is the number of non-MFMA instructions per tile:
+//   * the MFMA computes the TRANSPOSED tile (weights as the A operand, activations as the B operand): a lane ends up with
+//     4 consecutive output columns of one row per register quad -> one global_store_dwordx4 per quad, the bias is the
+//     accumulators' start value, LeakyReLU is 2 VALU instructions per value;
+//   * the finished registers are directly the B operand of v_mfma_f32_4x4x1_16b_f32: the skip head's partial sums
+//     (GemmProblem::hf_*) ride as 32 two-pass MFMAs per tile instead of ~900 DPP adds;
+//   * the next tile's rows go global -> LDS by LDS-DMA (no staging registers, no ds_write), the previous tile's result
+//     (second accumulator set, architectural VGPRs: no v_accvgpr_read) is finished and stored between the MFMA steps.
+// Measured on the prototype (tools/proto/wstat.hip, M = 192000, K = N = 256): 131-135 TFLOP/s against 116 for the
+// software-pipelined row-block prototype with streamed weights, 110 for k_rowgemm and 92 for the 64x64-tile kernel.
+//
+// The MFMAs are inline asm: hipcc keeps MFMA sources in architectural VGPRs and would park the 256 stationary registers
+// in AccVGPRs behind a v_accvgpr_read per use.  The hazard recogniser does not look into asm, so the rules it would
+// enforce are kept by construction (ISA 4.5): a VALU / VMEM reader of an MFMA result sits behind an `anchor()` placed
+// after at least one further 8-MFMA step (>= 18 wait states), dependent 4x4x1 MFMAs are 2 wait states apart (s_nop 1),
+// back-to-back 32x32x2 MFMAs on one accumulator need none.
+#include "wstat.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <mutex>
+#include <type_traits>
+#include <utility>
+
+namespace fdql {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void *lds_vp;
+typedef const __attribute__((address_space(1))) void *glb_vp;
+typedef const __attribute__((address_space(1))) v4f *gcf4;
+typedef const __attribute__((address_space(1))) float *gcf;
+typedef __attribute__((address_space(1))) float *gf;
+typedef __attribute__((address_space(1))) v4f *gf4;
+typedef __attribute__((address_space(1))) v2f *gf2;
+
+constexpr int NSTEP = WS_KMAIN / 8;   // 32 steps of 8 k (4 k-pairs x both lane halves)
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void sfor(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    sfor<I + 1, N>(f);
+  }
+}
+__device__ __forceinline__ unsigned ws_lds_addr(const float *p) { return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)p; }
+template <int OFF>
+__device__ __forceinline__ void ws_rd128(v4f &d, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(d) : "v"(addr), "n"(OFF)); }
+template <int N>
+__device__ __forceinline__ void ws_lgkm_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ int ws_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T>
+__device__ __forceinline__ T *ws_uni(T *p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (T *)(((unsigned long long)hi << 32) | lo);
+}
+// One step (8 k) of a 32-row tile: 4 k-pairs x the wave's 2 column tiles in ONE asm statement (between separate asm
+// statements the compiler pads a def -> use pair with s_nop).  The weights are the A operand: D[i = column][j = row].
+__device__ __forceinline__ void ws_step_a(f32x16 &a0, f32x16 &a1, const v4f &w0, const v4f &w1, const v4f &x) {   // weights in AccVGPRs
+  asm volatile(
+      "v_mfma_f32_32x32x2_f32 %0, %2, %10, %0\n\tv_mfma_f32_32x32x2_f32 %1, %6, %10, %1\n\t"
+      "v_mfma_f32_32x32x2_f32 %0, %3, %11, %0\n\tv_mfma_f32_32x32x2_f32 %1, %7, %11, %1\n\t"
+      "v_mfma_f32_32x32x2_f32 %0, %4, %12, %0\n\tv_mfma_f32_32x32x2_f32 %1, %8, %12, %1\n\t"
+      "v_mfma_f32_32x32x2_f32 %0, %5, %13, %0\n\tv_mfma_f32_32x32x2_f32 %1, %9, %13, %1"
+      : "+v"(a0), "+v"(a1)
+      : "a"(w0.x), "a"(w0.y), "a"(w0.z), "a"(w0.w), "a"(w1.x), "a"(w1.y), "a"(w1.z), "a"(w1.w), "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w));
+}
+__device__ __forceinline__ void ws_step_a0(f32x16 &a0, f32x16 &a1, const v4f &w0, const v4f &w1, const v4f &x) {   // first step of a tile: C = 0
+  asm volatile(
+      "v_mfma_f32_32x32x2_f32 %0, %2, %10, 0\n\tv_mfma_f32_32x32x2_f32 %1, %6, %10, 0\n\t"
+      "v_mfma_f32_32x32x2_f32 %0, %3, %11, %0\n\tv_mfma_f32_32x32x2_f32 %1, %7, %11, %1\n\t"
+      "v_mfma_f32_32x32x2_f32 %0, %4, %12, %0\n\tv_mfma_f32_32x32x2_f32 %1, %8, %12, %1\n\t"
+      "v_mfma_f32_32x32x2_f32 %0, %5, %13, %0\n\tv_mfma_f32_32x32x2_f32 %1, %9, %13, %1"
+      : "=&v"(a0), "=&v"(a1)
+      : "a"(w0.x), "a"(w0.y), "a"(w0.z), "a"(w0.w), "a"(w1.x), "a"(w1.y), "a"(w1.z), "a"(w1.w), "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w));
+}
+__device__ __forceinline__ void ws_step_v(f32x16 &a0, f32x16 &a1, const v4f &w0, const v4f &w1, const v4f &x) {   // weights in VGPRs (narrow segments)
+  asm volatile(
+      "v_mfma_f32_32x32x2_f32 %0, %2, %10, %0\n\tv_mfma_f32_32x32x2_f32 %1, %6, %10, %1\n\t"
+      "v_mfma_f32_32x32x2_f32 %0, %3, %11, %0\n\tv_mfma_f32_32x32x2_f32 %1, %7, %11, %1\n\t"
+      "v_mfma_f32_32x32x2_f32 %0, %4, %12, %0\n\tv_mfma_f32_32x32x2_f32 %1, %8, %12, %1\n\t"
+      "v_mfma_f32_32x32x2_f32 %0, %5, %13, %0\n\tv_mfma_f32_32x32x2_f32 %1, %9, %13, %1"
+      : "+v"(a0), "+v"(a1)
+      : "v"(w0.x), "v"(w0.y), "v"(w0.z), "v"(w0.w), "v"(w1.x), "v"(w1.y), "v"(w1.z), "v"(w1.w), "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w));
+}
+// Skip-head rider of one register quad: h[q][lane] += sum_c w[c] (lane 4 b + i: head weight row i over the column of
+// register c in lane half b / 8) * x[c] (lane 4 b + j: row 4 (b % 8) + j).  Dependent 4x4x1 MFMAs: 2 wait states apart.
+__device__ __forceinline__ void ws_rider(v4f &h, const v4f &w, const v4f &x) {
+  asm volatile(
+      "v_mfma_f32_4x4x1_16b_f32 %0, %1, %5, %0\n\ts_nop 1\n\t"
+      "v_mfma_f32_4x4x1_16b_f32 %0, %2, %6, %0\n\ts_nop 1\n\t"
+      "v_mfma_f32_4x4x1_16b_f32 %0, %3, %7, %0\n\ts_nop 1\n\t"
+      "v_mfma_f32_4x4x1_16b_f32 %0, %4, %8, %0"
+      : "+v"(h)
+      : "v"(w.x), "v"(w.y), "v"(w.z), "v"(w.w), "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w));
+}
+// A reader of MFMA results written by the asm statements above must not be scheduled ahead of the steps that separate
+// it from them: volatile asm statements keep their order, and what consumes the "output" of this one follows it.
+__device__ __forceinline__ void ws_anchor(f32x16 &a, f32x16 &b) { asm volatile("" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void ws_anchor(v4f &a) { asm volatile("" : "+v"(a)); }
+__device__ __forceinline__ float ws_lrelu(float v) {   // max(v, 0.01 v); fmaxf would add a canonicalising v_max
+  float t = 0.01f * v, o;
+  asm("v_max_f32 %0, %1, %2" : "=v"(o) : "v"(v), "v"(t));
+  return o;
+}
+__device__ __forceinline__ float ws_sum_halves(float x) {   // x[l] + x[l ^ 32] in every lane
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+
+template <int NMINOR, bool DUAL, int HFQ>
+__global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
+  static_assert(!DUAL || NMINOR >= 1, "a dual launch emits before its last narrow segment");
+  static_assert(HFQ == 0 || HFQ == 2, "head-fusion riders: 2 outputs per row");
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // two images [32][P]
+  constexpr int P = WS_KMAIN + 8 * NMINOR + 4, IMG = WS_BM * P;   // (P / 4) odd: conflict-free ds_read_b128
+  constexpr int NM_LOOP = DUAL ? NMINOR - 1 : NMINOR;             // narrow steps inside a tile's K loop
+  constexpr int LD = WS_N;                                        // row pitch of the outputs (compile-time)
+  const int tid = threadIdx.x, lane = tid & 63, wave = ws_uni(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5, n0 = wave * 64;
+
+  // ---- this workgroup's instance and its share of the instance's tiles: j0, j0 + stride, ...
+  int inst = 0;
+  for (int i = 1; i < a.ninst; ++i)
+    if ((int)blockIdx.x >= a.wg_first[i]) inst = i;
+  inst = ws_uni(inst);
+  const int j0 = (int)blockIdx.x - a.wg_first[inst], stride = a.wg_first[inst + 1] - a.wg_first[inst];
+  const int nblk = a.blocks_per_inst, M = a.M;
+  if (j0 >= nblk) return;
+  const WsInst &I = a.inst[inst];   // kernel-argument segment: scalar loads, each field read once
+  const float *A0 = ws_uni(I.A[0]);
+  const float *An[WS_MAX_MINOR] = {ws_uni(I.A[1]), ws_uni(I.A[2])};
+  float *const C = ws_uni(I.C), *const C2 = ws_uni(I.C2);
+  float *const hf_out = ws_uni(I.hf_out), *const hf_out2 = ws_uni(I.hf_out2);
+  const int lda0 = a.lda[0];
+
+  // ---- stationary operands
+  // main weights: wb[tn][s] = W0[n0 + 32 tn + li][32 (s / 4) + 16 lh + 4 (s % 4) .. + 3]
+  v4f wb[2][NSTEP];
+  {
+    const float *W0 = ws_uni(I.W[0]);
+    const int ldw0 = a.ldw[0];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s)
+        wb[tn][s] = *(gcf4)(W0 + (long long)(n0 + 32 * tn + li) * ldw0 + 32 * (s >> 2) + 16 * lh + 4 * (s & 3));
+  }
+  // narrow segments: one step each, k = 4 lh + c (zero beyond the segment's K)
+  v4f wn[NMINOR > 0 ? NMINOR : 1][2];
+#pragma unroll
+  for (int s = 0; s < NMINOR; ++s) {
+    const float *Ws = ws_uni(I.W[1 + s]);
+    const int Ks = a.kminor[s], ldw = a.ldw[1 + s];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k = 4 * lh + c, kc = k < Ks ? k : Ks - 1;   // clamped, unconditional loads
+        const float x = ((gcf)Ws)[(long long)(n0 + 32 * tn + li) * ldw + kc];
+        wn[s][tn][c] = k < Ks ? x : 0.f;
+      }
+  }
+  // Per-wave constants in LDS (behind the images), read one register quad ahead of their use:
+  //   bias of the columns 8 q + 4 lh + c of each column tile                                        [wave][lh][tn][q][c]
+  //   head-fusion rider weights: lane 4 b + i holds row i (< HFQ) of the head over those columns    [wave][i][lh][tn][q][c]
+  float *const cbias = lds + 2 * IMG, *const cwh = cbias + 4 * 2 * 32;
+  {
+    const float *bias = ws_uni(I.bias);
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<v4f *>(cbias + (wave * 2 + lh) * 32 + (tn * 4 + q) * 4) = *(gcf4)(bias + n0 + 32 * tn + 8 * q + 4 * lh);
+    if constexpr (HFQ > 0) {
+      const float *hw = ws_uni(I.hf_w);
+      const int i = lane & 3, ic = i < HFQ ? i : 0;
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const v4f x = *(gcf4)(hw + (long long)ic * a.hf_ldw + n0 + 32 * tn + 8 * q + 4 * lh);
+          *reinterpret_cast<v4f *>(cwh + ((wave * 4 + i) * 2 + lh) * 32 + (tn * 4 + q) * 4) = i < HFQ ? x : v4f{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    // (lanes that share a slot write the same values; read back by this wave only, after its s_waitcnt below)
+  }
+  const unsigned cb_addr = ws_lds_addr(cbias) + (unsigned)((wave * 2 + lh) * 32) * 4u;
+  const unsigned cw_addr = ws_lds_addr(cwh) + (unsigned)(((wave * 4 + (lane & 3)) * 2 + lh) * 32) * 4u;
+
+  // ---- addresses
+  const unsigned abase = ws_lds_addr(lds) + (unsigned)(li * P + 16 * lh) * 4u;                 // main fragments: k = 16 lh + ...
+  const unsigned nbase = ws_lds_addr(lds) + (unsigned)(li * P + WS_KMAIN + 4 * lh) * 4u;       // narrow fragments: k = 4 lh + c
+  const unsigned vo_c = (unsigned)(li * LD + 4 * lh);   // lane offset of a row's quad in an output tile
+  // narrow staging: thread -> (row tid / 8, column tid % 8) of every segment's [32, 8] slot
+  const int m_r = tid >> 3, m_c = tid & 7;
+  int m_src[NMINOR > 0 ? NMINOR : 1];
+  bool m_ok[NMINOR > 0 ? NMINOR : 1];
+#pragma unroll
+  for (int s = 0; s < NMINOR; ++s) {
+    m_ok[s] = m_c < a.kminor[s];
+    m_src[s] = m_r * a.lda[1 + s] + (m_ok[s] ? m_c : 0);
+  }
+  float *const m_dst = lds + m_r * P + WS_KMAIN + m_c;
+  int m_tile[NMINOR > 0 ? NMINOR : 1];   // floats between consecutive tiles of a narrow input
+#pragma unroll
+  for (int s = 0; s < NMINOR; ++s) m_tile[s] = ws_uni(WS_BM * a.lda[1 + s]);
+
+  auto dma_row = [&](const float *src_tile, int img, int r) __attribute__((always_inline)) {   // one row: 1 KiB global -> LDS
+    __builtin_amdgcn_global_load_lds((glb_vp)(src_tile + (long long)r * lda0 + lane * 4), (lds_vp)(lds + img * IMG + r * P), 16, 0, 0);
+  };
+
+  f32x16 acc[2][2];   // [set][tn]: the tile being accumulated and the previous one (being finished)
+  v4f hacc[2], hacc2[2];   // rider sums per column tile (second output of a dual launch: hacc2)
+  v4f pa = {0.f, 0.f, 0.f, 0.f};   // DUAL: fragment of the last narrow segment of the previous tile
+  float stm[NMINOR > 0 ? NMINOR : 1];
+
+  // constants of register quad kq = 4 tn + q (bias, rider weights): requested one quad ahead of their use
+  v4f cb[2], cw[2];
+  auto read_consts = [&](auto kqc) __attribute__((always_inline)) {
+    constexpr int kq = decltype(kqc)::value & 7;
+    ws_rd128<kq * 16>(cb[kq & 1], cb_addr);
+    if constexpr (HFQ > 0) ws_rd128<kq * 16>(cw[kq & 1], cw_addr);
+  };
+  // finish + store one register quad of a finished set; the rider takes the finished values as its B operand
+  auto quad = [&](f32x16 (&pv)[2], float *Cout, v4f (&hs)[2], int pblk, int kq) __attribute__((always_inline)) {
+    const int tn = (kq >> 2) & 1, q = kq & 3;
+    v4f x;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) x[c] = ws_lrelu(pv[tn][4 * q + c] + cb[kq & 1][c]);
+    gf base = ws_uni((gf)Cout + (long long)pblk * WS_BM * LD + n0 + 32 * tn + 8 * q);
+    *(gf4)(&base[vo_c]) = x;
+    if constexpr (HFQ > 0) {
+      if (q == 0) hs[tn] = v4f{0.f, 0.f, 0.f, 0.f};
+      ws_rider(hs[tn], cw[kq & 1], x);
+    }
+  };
+  // the head partial sums of a finished tile: plane = wave * 2 + tn (its 32 columns), both lane halves summed
+  auto hf_store = [&](v4f (&hs)[2], float *hout, int pblk) __attribute__((always_inline)) {
+    if constexpr (HFQ > 0) {
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        ws_anchor(hs[tn]);
+        const v2f y = {ws_sum_halves(hs[tn][0]), ws_sum_halves(hs[tn][1])};
+        gf base = ws_uni((gf)hout + ((long long)(wave * 2 + tn) * M + (long long)pblk * WS_BM) * HFQ);
+        *(gf2)(&base[(unsigned)(li * HFQ)]) = y;   // (both lane halves hold and write the same sums)
+      }
+    }
+  };
+
+  // One tile: K loop into `ac` from image IM; the previous tile `pv` (block pblk) is finished and stored, the rows of the
+  // next tile (block nxt) are fetched into the other image.
+  auto block = [&](auto has_prev, auto imgc, f32x16 (&ac)[2], f32x16 (&pv)[2], int nxt, int pblk) __attribute__((always_inline)) {
+    constexpr bool HP = decltype(has_prev)::value;
+    constexpr int IM = decltype(imgc)::value;
+    constexpr int IOFF = IM * IMG * 4;   // < 64 KiB: fits the ds offset field
+    // every wave is done with the other image and this image has landed (each wave waited for its own DMA rows and
+    // narrow writes before it arrived here)
+    asm volatile("s_barrier" ::: "memory");
+    const float *nsrc = ws_uni(A0 + (long long)nxt * WS_BM * lda0);
+    const v4f pa_prev = pa;
+    v4f af[2], nf[NM_LOOP > 0 ? NM_LOOP : 1];
+    ws_rd128<IOFF>(af[0], abase);
+#pragma unroll
+    for (int s = 0; s < NM_LOOP; ++s) ws_rd128<IOFF>(nf[s], nbase + (unsigned)(8 * s) * 4u);
+    if constexpr (DUAL) ws_rd128<IOFF>(pa, nbase + (unsigned)(8 * (NMINOR - 1)) * 4u);
+    if constexpr (HP) read_consts(std::integral_constant<int, 0>{});
+    sfor<0, NSTEP>([&](auto sc) __attribute__((always_inline)) {
+      constexpr int s = decltype(sc)::value;
+      // fragment of the next step requested; everything older (this step's fragment, the constants requested during the
+      // previous step) has arrived: LDS operations complete in order
+      if constexpr (s + 1 < NSTEP) {
+        constexpr int s1 = s + 1;
+        ws_rd128<IOFF + (s1 >> 2) * 128 + (s1 & 3) * 16>(af[s1 & 1], abase);
+        ws_lgkm_wait<1>();
+      } else {
+        ws_lgkm_wait<0>();
+      }
+      asm volatile("" : "+v"(af[s & 1]));
+      if constexpr (s == 0) ws_step_a0(ac[0], ac[1], wb[0][s], wb[1][s], af[s & 1]);
+      else ws_step_a(ac[0], ac[1], wb[0][s], wb[1][s], af[s & 1]);
+      // ---- side work of step s
+      if constexpr (HP) {
+        // quad kq is finished at step s: first output kq = s (0..7); second output of a dual launch kq = s - 1 (8..15)
+        constexpr int kq = s < 8 ? s : s - 1;
+        constexpr bool has_quad = s < 8 || (DUAL && s >= 9 && s < 17);
+        if constexpr (has_quad) {
+          asm volatile("" : "+v"(cb[kq & 1]));
+          if constexpr (HFQ > 0) asm volatile("" : "+v"(cw[kq & 1]));
+          if constexpr (kq + 1 < (DUAL ? 16 : 8)) read_consts(std::integral_constant<int, kq + 1>{});
+        }
+        if constexpr (s == 0) ws_anchor(pv[0], pv[1]);
+        if constexpr (s < 8) quad(pv, C, hacc, pblk, kq);
+        if constexpr (!DUAL) {
+          if constexpr (s == 9) hf_store(hacc, hf_out, pblk);
+        } else {
+          if constexpr (s == 8) ws_step_v(pv[0], pv[1], wn[NMINOR - 1][0], wn[NMINOR - 1][1], pa_prev);   // the previous tile becomes its second output
+          if constexpr (s == 9) ws_anchor(pv[0], pv[1]);
+          if constexpr (s >= 9 && s < 17) quad(pv, C2, hacc2, pblk, kq);
+          if constexpr (s == 10) hf_store(hacc, hf_out, pblk);
+          if constexpr (s == 18) hf_store(hacc2, hf_out2, pblk);
+        }
+      }
+      if constexpr (s == 12) {
+#pragma unroll
+        for (int u = 0; u < NMINOR; ++u) stm[u] = ((gcf)(An[u] + (long long)nxt * m_tile[u]))[m_src[u]];
+      }
+      if constexpr (s >= 16 && s < 16 + WS_BM / 4) dma_row(nsrc, IM ^ 1, wave + 4 * (s - 16));
+      if constexpr (s == 27) {
+#pragma unroll
+        for (int u = 0; u < NMINOR; ++u) m_dst[(IM ^ 1) * IMG + 8 * u] = m_ok[u] ? stm[u] : 0.f;
+      }
+      asm volatile("" ::: "memory");   // the memory operations of a step stay in their step
+    });
+#pragma unroll
+    for (int s = 0; s < NM_LOOP; ++s) {
+      asm volatile("" : "+v"(nf[s]));
+      ws_step_v(ac[0], ac[1], wn[s][0], wn[s][1], nf[s]);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's part of the next image has landed
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  // ---- first image (once per workgroup)
+  int blk = j0;
+  {
+    const float *src = A0 + (long long)blk * WS_BM * lda0;
+#pragma unroll
+    for (int u = 0; u < WS_BM / 4; ++u) dma_row(src, 0, wave + 4 * u);
+#pragma unroll
+    for (int u = 0; u < NMINOR; ++u) {
+      const float x = ((gcf)(An[u] + (long long)blk * m_tile[u]))[m_src[u]];
+      m_dst[8 * u] = m_ok[u] ? x : 0.f;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  }
+  int nxt = blk + stride < nblk ? blk + stride : blk;   // a workgroup's last tile prefetches itself again (nobody reads it)
+  block(F(), I0(), acc[0], acc[1], nxt, 0);
+  int prv = blk, set = 1;
+  blk += stride;
+#pragma unroll 1
+  while (blk < nblk) {
+    nxt = blk + stride < nblk ? blk + stride : blk;
+    block(T(), I1(), acc[1], acc[0], nxt, prv);
+    prv = blk; blk += stride; set = 0;
+    if (blk >= nblk) break;
+    nxt = blk + stride < nblk ? blk + stride : blk;
+    block(T(), I0(), acc[0], acc[1], nxt, prv);
+    prv = blk; blk += stride; set = 1;
+  }
+  // ---- the last tile's result, not overlapped
+  auto flush = [&](f32x16 (&pv)[2]) __attribute__((always_inline)) {
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // MFMA results -> VALU readers
+    ws_anchor(pv[0], pv[1]);
+    sfor<0, 8>([&](auto kc) __attribute__((always_inline)) {
+      read_consts(kc);
+      ws_lgkm_wait<0>();
+      asm volatile("" : "+v"(cb[decltype(kc)::value & 1]), "+v"(cw[decltype(kc)::value & 1]));
+      quad(pv, C, hacc, prv, decltype(kc)::value);
+    });
+    if constexpr (DUAL) {
+      ws_step_v(pv[0], pv[1], wn[NMINOR - 1][0], wn[NMINOR - 1][1], pa);   // pa: read at the start of this tile's K loop
+      asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+      ws_anchor(pv[0], pv[1]);
+      sfor<0, 8>([&](auto kc) __attribute__((always_inline)) {
+        read_consts(kc);
+        ws_lgkm_wait<0>();
+        asm volatile("" : "+v"(cb[decltype(kc)::value & 1]), "+v"(cw[decltype(kc)::value & 1]));
+        quad(pv, C2, hacc2, prv, decltype(kc)::value);
+      });
+    }
+    asm volatile("s_nop 7" ::: "memory");   // rider results -> VALU readers
+    hf_store(hacc, hf_out, prv);
+    if constexpr (DUAL) hf_store(hacc2, hf_out2, prv);
+  };
+  if (set == 1) flush(acc[0]);
+  else flush(acc[1]);
+}
+
+}  // namespace
+
+bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
+  if (nprob < 1 || nprob > WS_MAX_INST) return false;
+  const char *env = getenv("FDQL_WSTAT");   // "0": never (tuning / test hook; read per plan build)
+  if (env && env[0] == '0') return false;
+  memset(&args, 0, sizeof(args));
+  const GemmProblem &p0 = probs[0];
+  auto main_of = [](const GemmProblem &p) {
+    int m = -1;
+    for (int s = 0; s < p.nseg; ++s)
+      if (p.seg[s].K == WS_KMAIN) { if (m >= 0) return -1; m = s; }
+    return m;
+  };
+  const int main0 = main_of(p0);
+  if (main0 < 0 || p0.N != WS_N || p0.M % WS_BM || p0.M < WS_BM || p0.ksplit != 1 || p0.epi != EPI_LRELU) return false;
+  if (!p0.bias || p0.colsum || p0.ref || p0.fz_h || p0.ldc != WS_N) return false;
+  const int nminor = p0.nseg - 1;
+  if (nminor > WS_MAX_MINOR) return false;
+  const bool dual = p0.emit_seg >= 0 && p0.emit_seg < p0.nseg - 1;
+  if (dual && (p0.emit_seg != p0.nseg - 2 || main0 == p0.nseg - 1 || !p0.C2 || p0.ldc2 != WS_N)) return false;
+  if (p0.hf_w && p0.hf_q != 2) return false;
+  // instantiated forms
+  if (dual && nminor != 2) return false;
+  args.M = p0.M; args.ninst = nprob; args.blocks_per_inst = p0.M / WS_BM;
+  args.nminor = nminor; args.dual = dual;
+  args.hf_q = p0.hf_w ? p0.hf_q : 0; args.hf_ldw = p0.hf_ldw;
+  for (int i = 0; i < nprob; ++i) {
+    const GemmProblem &p = probs[i];
+    if (p.M != p0.M || p.N != p0.N || p.nseg != p0.nseg || p.ksplit != 1 || p.epi != p0.epi || p.emit_seg != p0.emit_seg ||
+        main_of(p) != main0 || (p.hf_w != nullptr) != (p0.hf_w != nullptr) || p.hf_q != p0.hf_q || p.hf_ldw != p0.hf_ldw ||
+        p.ldc != p0.ldc || p.ldc2 != p0.ldc2 || !p.bias || p.ref || p.colsum || p.fz_h)
+      return false;
+    if (dual && (!p.C2 || (p.hf_w && !p.hf_out2))) return false;
+    if (p.hf_w && (!p.hf_out || (reinterpret_cast<uintptr_t>(p.hf_out) & 7))) return false;
+    if ((reinterpret_cast<uintptr_t>(p.C) & 15) || (p.C2 && (reinterpret_cast<uintptr_t>(p.C2) & 15)) || (reinterpret_cast<uintptr_t>(p.bias) & 15))
+      return false;
+    if (p.hf_w && ((reinterpret_cast<uintptr_t>(p.hf_w) & 3) != 0)) return false;
+    WsInst I;
+    memset(&I, 0, sizeof(I));
+    int m = 0;
+    for (int s = 0; s < p.nseg; ++s) {
+      const GemmSeg &sg = p.seg[s], &s0 = p0.seg[s];
+      if (!sg.a_kc || !sg.b_kc || sg.K != s0.K || sg.lda != s0.lda || sg.ldb != s0.ldb) return false;
+      const int slot = s == main0 ? 0 : 1 + m++;
+      if (slot > 0 && (sg.K < 1 || sg.K > 8)) return false;
+      if (slot == 0 && (sg.lda % 4 || (reinterpret_cast<uintptr_t>(sg.A) & 15))) return false;   // rows move as 16-byte pieces
+      I.A[slot] = sg.A; I.W[slot] = sg.B;
+      if (i == 0) {
+        args.lda[slot] = sg.lda; args.ldw[slot] = sg.ldb;
+        if (slot > 0) args.kminor[slot - 1] = sg.K;
+      }
+    }
+    I.bias = p.bias; I.C = p.C; I.C2 = p.C2;
+    I.hf_w = p.hf_w; I.hf_out = p.hf_out; I.hf_out2 = p.hf_out2;
+    args.inst[i] = I;
+  }
+  // workgroups per instance: an equal share of the CUs (at most one per tile)
+  int dev = 0;
+  static int ncu_of[64];
+  static std::mutex mu;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (!ncu_of[dev]) {
+      hipDeviceProp_t pr;
+      if (hipGetDeviceProperties(&pr, dev) != hipSuccess) return false;
+      ncu_of[dev] = pr.multiProcessorCount;
+    }
+  }
+  const int ncu = ncu_of[dev];
+  if (nprob > ncu) return false;
+  int per = ncu / nprob;
+  if (per > args.blocks_per_inst) per = args.blocks_per_inst;
+  for (int i = 0; i <= nprob; ++i) args.wg_first[i] = i * per;
+  return true;
+}
+
+double wstat_flops(const WsArgs &a) {
+  double k = WS_KMAIN;
+  for (int s = 0; s < a.nminor; ++s) k += a.kminor[s];
+  return 2.0 * a.M * (double)WS_N * k * a.ninst;
+}
+
+template <int NMINOR, bool DUAL, int HFQ>
+static hipError_t ws_launch(const WsArgs &a, hipStream_t s) {
+  // the opt-in to > 64 KiB of dynamic LDS belongs to the (device, function) pair
+  static bool attr[64];
+  static std::mutex mu;
+  auto kern = &k_wstat<NMINOR, DUAL, HFQ>;
+  constexpr int lds_bytes = (2 * WS_BM * (WS_KMAIN + 8 * NMINOR + 4) + 4 * 2 * 32 + 4 * 8 * 32) * 4;   // two images + per-wave constants
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (!attr[dev]) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+      if (e != hipSuccess) return e;
+      attr[dev] = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(a.wg_first[a.ninst]), dim3(256), lds_bytes, s, a);
+  return hipGetLastError();
+}
+
+hipError_t wstat_launch(const WsArgs &a, hipStream_t s) {
+  if (a.dual) return a.hf_q ? ws_launch<2, true, 2>(a, s) : ws_launch<2, true, 0>(a, s);
+  if (a.nminor == 0) return a.hf_q ? ws_launch<0, false, 2>(a, s) : ws_launch<0, false, 0>(a, s);
+  if (a.nminor == 1) return a.hf_q ? ws_launch<1, false, 2>(a, s) : ws_launch<1, false, 0>(a, s);
+  return a.hf_q ? ws_launch<2, false, 2>(a, s) : ws_launch<2, false, 0>(a, s);
+}
+
+}  // namespace fdql
