@@ -72,7 +72,9 @@ struct MlpInst {
   float *out = nullptr;
   int ldout = 0;
   std::vector<float *> dpre;
-  std::vector<float *> dpre_cs;  // per hidden layer: [ceil(rows/128), hid] column sums of dpre (bias gradients)
+  std::vector<float *> dpre_cs;  // per hidden layer: [ceil(rows/64), hid] column sums of dpre (bias gradients)
+  std::vector<int> dpre_cs_rows; // partial rows actually written there (0: one per 64 rows; the weight-stationary dgrad
+                                 // launch writes one per workgroup of the instance, wstat.h)
   const float *W(int i) const { return wbase + (d->w_off[i] - worigin); }
   const float *Bv(int i) const { return wbase + (d->b_off[i] - worigin); }
   const float *HW() const { return wbase + (d->hw_off - worigin); }
@@ -531,11 +533,11 @@ struct Builder {
     (gemm_shape_is_dense(gemm_pick_shape(p, gemm_dense_shape())) ? gs : narrow).gemm.push_back(p);
   }
   // bias gradient = column sums of dOut over R rows, from per-64-row partials `cs` when the dgrad GEMM left them
-  void wgrad_bias(int R, const float *dOut, int ldo, int nout, const float *cs, float *dst, Stage &ws) {
+  void wgrad_bias(int R, const float *dOut, int ldo, int nout, const float *cs, float *dst, Stage &ws, int cs_rows = 0) {
     SkinnyWgradProblem p;
     memset(&p, 0, sizeof(p));
     p.Nout = 1; p.K = nout; p.dY = nullptr;
-    if (cs) { p.M = (R + 63) / 64; p.X = cs; p.ldx = nout; }
+    if (cs) { p.M = cs_rows > 0 ? cs_rows : (R + 63) / 64; p.X = cs; p.ldx = nout; }
     else { p.M = R; p.X = dOut; p.ldx = ldo; }
     p.dW = dst; p.sq = 0; p.sk = 1; p.split_stride = a->n_train; p.nsplit = a->nsplit;
     ws.swg.push_back(p);
@@ -552,8 +554,8 @@ struct Builder {
     auto gemm_w = [&](const float *dOut, int ldo, int nout, const float *X, int ldx, int width, float *dst, int ldw) {
       wgrad_gemm(R, dOut, ldo, nout, X, ldx, width, dst, ldw, gs, narrow);
     };
-    auto bias_w = [&](const float *dOut, int ldo, int nout, const float *cs, float *dst) {
-      wgrad_bias(R, dOut, ldo, nout, cs, dst, ws);
+    auto bias_w = [&](const float *dOut, int ldo, int nout, const float *cs, float *dst, int cs_rows = 0) {
+      wgrad_bias(R, dOut, ldo, nout, cs, dst, ws, cs_rows);
     };
     for (size_t i = 0; i < d.hid.size(); ++i) {
       float *dst = slab + d.w_off[i];
@@ -563,7 +565,7 @@ struct Builder {
       } else {
         gemm_w(m.dpre[i], d.hid[i], d.hid[i], m.h[i - 1], d.hid[i - 1], d.hid[i - 1], dst, d.hid[i - 1]);
       }
-      bias_w(m.dpre[i], d.hid[i], d.hid[i], m.dpre_cs[i], slab + d.b_off[i]);
+      bias_w(m.dpre[i], d.hid[i], d.hid[i], m.dpre_cs[i], slab + d.b_off[i], i < m.dpre_cs_rows.size() ? m.dpre_cs_rows[i] : 0);
     }
     float *dst = slab + d.hw_off;
     const int ld = d.head_ld();
@@ -767,9 +769,21 @@ MlpInst make_inst(fdql_agent *a, const MlpDesc &d, const std::string &p, const f
     if (bwd) {
       m.dpre.push_back(a->buf(p + ".dpre" + std::to_string(i)));
       m.dpre_cs.push_back(a->buf(p + ".cs" + std::to_string(i)));
+      m.dpre_cs_rows.push_back(0);
     }
   }
   return m;
+}
+
+// Which row-block kernel takes a group of like problems (one launch): the weight-stationary one when it has the form,
+// else the streamed-weights one, else none (the tile kernels).  Deterministic in (problems, environment): the plan
+// builder asks the same question where the answer changes what other stages read (the dgrad form's column sums).
+bool rows_launch_of(const fdql_agent *a, const std::vector<GemmProblem> &grp, RowsLaunch &rl) {
+  const long long tiles = (long long)grp.size() * (grp[0].M / RG_BM);
+  if (tiles < a->rows_min_tiles) return false;
+  if (wstat_from_problems(grp.data(), (int)grp.size(), rl.wa)) { rl.ws = true; return true; }
+  rl.ws = false;
+  return rowgemm_from_problems(grp.data(), (int)grp.size(), rl.rg);
 }
 
 int upload_tables(fdql_agent *a) {
@@ -793,12 +807,7 @@ int upload_tables(fdql_agent *a) {
             }
           }
           RowsLaunch rl;
-          const long long tiles = (long long)grp.size() * (grp[0].M / RG_BM);
-          if (tiles >= a->rows_min_tiles && wstat_from_problems(grp.data(), (int)grp.size(), rl.wa)) {
-            rl.ws = true;
-            s.rows.push_back(rl);
-            for (size_t j : idx) taken[j] = 1;
-          } else if (tiles >= a->rows_min_tiles && rowgemm_from_problems(grp.data(), (int)grp.size(), rl.rg)) {
+          if (rows_launch_of(a, grp, rl)) {
             s.rows.push_back(rl);
             for (size_t j : idx) taken[j] = 1;
           } else {
@@ -1254,13 +1263,15 @@ int build_plan(fdql_agent *a) {
           ++which;
         }
       }
-      RowGemmArgs ra;
-      const long long tiles = (long long)cand.size() * (M / RG_BM);
-      if (M % RG_BM == 0 && tiles >= a->rows_min_tiles && rowgemm_from_problems(cand.data(), (int)cand.size(), ra)) {
+      RowsLaunch rl;
+      if (M % RG_BM == 0 && rows_launch_of(a, cand, rl)) {
         Stage &gs = b.gemm_stage("critics.dpre1+0");
         gs.try_rows = true;
         gs.gemm = cand;
         fused1 = true;
+        if (rl.ws)   // the weight-stationary launch leaves one partial row of column sums per workgroup
+          for (int k = 0; k < C; ++k)
+            for (MlpInst *m : {&co[k], &cf[k]}) m->dpre_cs_rows[0] = m->dpre_cs_rows[1] = wstat_colsum_rows(rl.wa);
       }
     }
     for (int i = (int)nh - 1; i >= 0 && !fused1; --i) {
@@ -1279,6 +1290,13 @@ int build_plan(fdql_agent *a) {
       for (int k = 0; k < C; ++k) {
         gs.gemm.push_back(b.bwd_dpre(co[k], i, a->buf("dz") + k * Q, Nq));
         gs.gemm.push_back(b.bwd_dpre(cf[k], i, a->buf("dzf") + k * Q, Nq));
+      }
+      {
+        RowsLaunch rl;
+        std::vector<GemmProblem> grp = gs.gemm;
+        if (rows_launch_of(a, grp, rl) && rl.ws)
+          for (int k = 0; k < C; ++k)
+            for (MlpInst *m : {&co[k], &cf[k]}) m->dpre_cs_rows[i] = wstat_colsum_rows(rl.wa);
       }
     }
     // d pi: input-grad of each frozen critic's action columns as its own narrow (128x32) problem
@@ -1843,7 +1861,9 @@ int32_t fdql_agent_profile_update(fdql_agent_t *a, const fdql_batch_t *batch, co
       if (rl.ws) {
         flops = wstat_flops(rl.wa);
         bytes = 4.0 * rl.wa.M * rl.wa.ninst * (double)(WS_KMAIN + WS_N * (rl.wa.dual ? 2 : 1));
-        snprintf(out[cnt].name, sizeof(out[cnt].name), "wstat%s%s:%s", rl.wa.dual ? "dual" : "", rl.wa.hf_q ? "hf" : "", st.name.c_str());
+        if (rl.wa.grad) bytes = 4.0 * rl.wa.M * rl.wa.ninst * (double)(WS_KMAIN * (rl.wa.fz ? 2 : 1) + 2 * WS_N);
+        snprintf(out[cnt].name, sizeof(out[cnt].name), "wstat%s%s%s:%s", rl.wa.grad ? (rl.wa.fz ? "KSfz" : "KS") : "", rl.wa.dual ? "dual" : "",
+                 rl.wa.hf_q ? "hf" : "", st.name.c_str());
       } else {
       const RowGemmArgs &ra = rl.rg;
       flops = rowgemm_flops(ra);
@@ -2187,6 +2207,13 @@ int fdql_test_rowgemm(const float *A0, const float *A1, int32_t k1, const float 
   RowsLaunch rl;
   if (wstat_from_problems(probs.data(), (int)probs.size(), rl.wa)) rl.ws = true;
   else FDQL_REQUIRE(rowgemm_from_problems(probs.data(), (int)probs.size(), rl.rg), "the row-block kernels do not take this form");
+  if (rl.ws && rl.wa.grad) {
+    // the weight-stationary dgrad form writes wstat_colsum_rows() partial rows per instance, not one per 64 rows: clear the
+    // caller's [ninst, M / 64, 256] buffers so that their sum over the row axis is the total either way
+    const size_t bytes = (size_t)ninst * (M / 64) * RG_N * sizeof(float);
+    FDQL_HIP(hipMemsetAsync(colsum, 0, bytes, (hipStream_t)stream));
+    if (fz_colsum) FDQL_HIP(hipMemsetAsync(fz_colsum, 0, bytes, (hipStream_t)stream));
+  }
   hipError_t e = rl.launch((hipStream_t)stream);
   if (e != hipSuccess) { set_error("row-block launch: %s", hipGetErrorString(e)); return FDQL_EHIP; }
   return 0;

@@ -12,7 +12,7 @@ constexpr int WS_BM = 32;          // rows per tile
 constexpr int WS_N = 256;          // output columns (4 waves x 64)
 constexpr int WS_KMAIN = 256;      // K of the main segment
 constexpr int WS_MAX_MINOR = 2;    // narrow K-segments beside it, one 8-k MFMA step each
-constexpr int WS_MAX_INST = 16;    // the table travels in the kernel arguments (scalar loads)
+constexpr int WS_MAX_INST = 16;    // the table travels in the kernel arguments (scalar loads): 16 x 144 B + header < 4 KiB
 
 struct WsInst {
   const float *A[1 + WS_MAX_MINOR];   // activations of the segments, [0] = main; row-major, K contiguous
@@ -21,6 +21,11 @@ struct WsInst {
   float *C, *C2;                      // outputs [M, 256]; C2: second output of a dual launch
   const float *hf_w;                  // head fusion (common.h, GemmProblem::hf_*): head weight rows over this layer's columns
   float *hf_out, *hf_out2;
+  // dgrad form
+  const float *ref;                   // activation output whose sign gates the gradient
+  float *colsum;                      // [workgroups of the instance, 256] column sums of C (one partial row per workgroup)
+  const float *fz_h, *fz_w;           // fused head dgrad (GemmProblem::fz_*)
+  float *fz_out, *fz_colsum;          // fz_colsum: [workgroups of the instance, 256]
 };
 
 struct WsArgs {
@@ -30,12 +35,18 @@ struct WsArgs {
   int lda[1 + WS_MAX_MINOR], ldw[1 + WS_MAX_MINOR];
   int dual;                  // 1: C = f(all segments but the last), C2 = f(all)
   int hf_q, hf_ldw;          // head fusion: outputs per row (2), 0 = off
+  int grad;                  // 1: dgrad form - weights K-strided (element (k, n) at W[k*ldw + n]), x *= LeakyReLU'(ref), column sums
+  int fz, fz_ldw;            // dgrad form: A0 formed from (fz_h, dY = A1, fz_w) while it is staged
   int wg_first[WS_MAX_INST + 1];   // workgroups [wg_first[i], wg_first[i+1]) serve instance i (block j, j + n, ... of it)
   WsInst inst[WS_MAX_INST];
 };
 
 // Can these problems (one launch group) run as one weight-stationary launch?  Fills args when they can.
+// Forward problems: EPI_LRELU with a bias.  dgrad problems (EPI_LRELU_GRAD, K-strided weights, one narrow segment = dY, ref
+// and colsum set; optionally the fused head dgrad): NOTE the column sums (colsum, fz_colsum) then hold
+// wstat_colsum_rows(args) partial rows per instance instead of one per 64 rows - the caller sizes its reduction by it.
 bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args);
+inline int wstat_colsum_rows(const WsArgs &a) { return a.wg_first[1] - a.wg_first[0]; }
 hipError_t wstat_launch(const WsArgs &args, hipStream_t stream);
 double wstat_flops(const WsArgs &a);
 

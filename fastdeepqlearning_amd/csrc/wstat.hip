@@ -391,14 +391,284 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
   else flush(acc[1]);
 }
 
+
+// ======================================================================================================================
+// dgrad form:  C[M, 256] = LeakyReLU'(ref) * ( A0[M, 256] W0 + dY[M, K1] W1 ),  weights K-strided (element (k, n) at W[k*ldw + n]),
+// column sums of C per workgroup.  FUSE: A0 is not read but formed while the next tile is staged - the head dgrad of the
+// layer above (GemmProblem::fz_*):  A0[m][k] = LeakyReLU'(fz_h[m][k]) * (dY[m][0] fz_w[0][k] + dY[m][1] fz_w[1][k]), written to
+// fz_out for the weight gradients, its column sums per workgroup to fz_colsum.
+// Same transposed tile as the forward form (a lane holds 4 consecutive columns of ONE row per register quad), so the sums
+// over ROWS that the bias gradients need run over lanes: each lane keeps its own running sums over all tiles of the
+// workgroup (one v_add per value, as an in-lane sum would cost) and the 32 lanes are added ONCE, when the workgroup ends;
+// colsum / fz_colsum therefore hold one partial row per WORKGROUP of the instance (WsArgs::wg_first), not per 64 rows.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float ws_dpp(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float ws_sum32(float x) {   // sum over the 32 lanes of a lane half: valid in lanes 31 and 63
+  x += ws_dpp<0x111, 0xf>(x);   // row_shr:1
+  x += ws_dpp<0x112, 0xf>(x);   // row_shr:2
+  x += ws_dpp<0x114, 0xf>(x);   // row_shr:4
+  x += ws_dpp<0x118, 0xf>(x);   // row_shr:8
+  x += ws_dpp<0x142, 0xa>(x);   // row_bcast:15 into rows 1 and 3
+  return x;
+}
+
+template <bool FUSE>
+__global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // two images [32][P]
+  constexpr int NMINOR = 1;
+  constexpr int P = WS_KMAIN + 8 * NMINOR + 4, IMG = WS_BM * P;
+  constexpr int LD = WS_N;
+  const int tid = threadIdx.x, lane = tid & 63, wave = ws_uni(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5, n0 = wave * 64;
+
+  int inst = 0;
+  for (int i = 1; i < a.ninst; ++i)
+    if ((int)blockIdx.x >= a.wg_first[i]) inst = i;
+  inst = ws_uni(inst);
+  const int j0 = (int)blockIdx.x - a.wg_first[inst], stride = a.wg_first[inst + 1] - a.wg_first[inst];
+  const int nblk = a.blocks_per_inst;
+  if (j0 >= nblk) return;
+  const WsInst &I = a.inst[inst];
+  const float *A0 = ws_uni(FUSE ? I.fz_h : I.A[0]);
+  const float *A1 = ws_uni(I.A[1]);
+  const float *ref = ws_uni(I.ref);
+  float *const C = ws_uni(I.C), *const fz_out = ws_uni(I.fz_out);
+  const int lda0 = FUSE ? LD : a.lda[0], lda1 = a.lda[1];
+
+  // ---- stationary weights, K-strided: wb[tn][s][c] = W0[32 (s / 4) + 16 lh + 4 (s % 4) + c][n0 + 32 tn + li]
+  v4f wb[2][NSTEP];
+  {
+    // (row pitch LD of the K-strided weights is compile-time: every load is base + lane offset + immediate)
+    gcf W0 = (gcf)ws_uni(I.W[0]) + (16 * lh * LD + n0 + li);
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) wb[tn][s][c] = W0[(32 * (s >> 2) + 4 * (s & 3) + c) * LD + 32 * tn];
+  }
+  v4f wn[2];
+  {
+    const float *W1 = ws_uni(I.W[1]);
+    const int Ks = a.kminor[0], ldw = a.ldw[1];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k = 4 * lh + c, kc = k < Ks ? k : Ks - 1;
+        const float x = ((gcf)W1)[(long long)kc * ldw + n0 + 32 * tn + li];
+        wn[tn][c] = k < Ks ? x : 0.f;
+      }
+  }
+  // FUSE: head weight rows q = 0, 1 over this lane's 4 columns of a staged row
+  v4f fw0 = {0.f, 0.f, 0.f, 0.f}, fw1 = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (FUSE) {
+    const float *fzw = ws_uni(I.fz_w);
+    fw0 = *(gcf4)(fzw + lane * 4);
+    fw1 = *(gcf4)(fzw + (long long)a.fz_ldw + lane * 4);
+  }
+
+  const unsigned abase = ws_lds_addr(lds) + (unsigned)(li * P + 16 * lh) * 4u;
+  const unsigned nbase = ws_lds_addr(lds) + (unsigned)(li * P + WS_KMAIN + 4 * lh) * 4u;
+  const unsigned vo_c = (unsigned)(li * LD + 4 * lh);
+  const int m_r = tid >> 3, m_c = tid & 7;
+  const bool m_ok = m_c < a.kminor[0];
+  const int m_src = m_r * lda1 + (m_ok ? m_c : 0);
+  float *const m_dst = lds + m_r * P + WS_KMAIN + m_c;
+  const int m_tile = ws_uni(WS_BM * lda1);
+
+  auto dma_row = [&](const float *src_tile, int img, int r) __attribute__((always_inline)) {
+    __builtin_amdgcn_global_load_lds((glb_vp)(src_tile + (long long)r * lda0 + lane * 4), (lds_vp)(lds + img * IMG + r * P), 16, 0, 0);
+  };
+
+  f32x16 acc[2][2];
+  float cs[2][16];                  // running column sums of C over this lane's rows (register r <-> column 8 (r/4) + 4 lh + r%4)
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cs[tn][r] = 0.f;
+  v4f fcs = {0.f, 0.f, 0.f, 0.f};   // FUSE: running column sums of the formed A0 over the rows this thread stages
+  v4f sh[8];                        // FUSE: rows in flight (fz_h pieces)
+  v2f sdz = {0.f, 0.f};             // FUSE: dY of this wave's 8 rows of the tile in flight, row u in lane u
+  float stm = 0.f;
+  v4f rq[2];                        // gate references of the quads in flight
+
+  // FUSE: one staged row piece: h -> LeakyReLU'(h) * (dY . Wh), k_head_dgrad's order and rounding (fma chain over q)
+  auto fuse_row = [&](v4f h, float dz0, float dz1, float live) __attribute__((always_inline)) {
+    v4f t;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float x = dz0 * fw0[c];
+      x = fmaf(dz1, fw1[c], x);
+      x = h[c] > 0.f ? x : 0.01f * x;
+      t[c] = x;
+      fcs[c] = fmaf(live, x, fcs[c]);   // live = 0 on the self-prefetch of a workgroup's last tile (counted once already)
+    }
+    return t;
+  };
+  auto ref_load = [&](v4f &dst, int blkid, int kq) __attribute__((always_inline)) {
+    const int tn = (kq >> 2) & 1, q = kq & 3;
+    gcf base = ws_uni((gcf)ref + (long long)blkid * WS_BM * LD + n0 + 32 * tn + 8 * q);
+    dst = *(gcf4)(&base[vo_c]);
+  };
+  auto quad = [&](f32x16 (&pv)[2], int pblk, int kq) __attribute__((always_inline)) {
+    const int tn = (kq >> 2) & 1, q = kq & 3;
+    v4f x;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float v = pv[tn][4 * q + c];
+      const float y = rq[kq & 1][c] > 0.f ? v : 0.01f * v;
+      cs[tn][4 * q + c] += y;
+      x[c] = y;
+    }
+    gf base = ws_uni((gf)C + (long long)pblk * WS_BM * LD + n0 + 32 * tn + 8 * q);
+    *(gf4)(&base[vo_c]) = x;
+  };
+
+  auto block = [&](auto has_prev, auto imgc, f32x16 (&ac)[2], f32x16 (&pv)[2], int nxt, int pblk, float live) __attribute__((always_inline)) {
+    constexpr bool HP = decltype(has_prev)::value;
+    constexpr int IM = decltype(imgc)::value;
+    constexpr int IOFF = IM * IMG * 4;
+    asm volatile("s_barrier" ::: "memory");
+    const float *nsrc = ws_uni(A0 + (long long)nxt * WS_BM * lda0);
+    const float *ndz = ws_uni(A1 + (long long)nxt * m_tile);
+    float *nout = ws_uni(fz_out + (long long)nxt * WS_BM * LD);
+    v4f af[2], nf;
+    ws_rd128<IOFF>(af[0], abase);
+    ws_rd128<IOFF>(nf, nbase);
+    if constexpr (HP) ref_load(rq[0], pblk, 0);
+    sfor<0, NSTEP>([&](auto sc) __attribute__((always_inline)) {
+      constexpr int s = decltype(sc)::value;
+      if constexpr (s + 1 < NSTEP) {
+        constexpr int s1 = s + 1;
+        ws_rd128<IOFF + (s1 >> 2) * 128 + (s1 & 3) * 16>(af[s1 & 1], abase);
+        ws_lgkm_wait<1>();
+      } else {
+        ws_lgkm_wait<0>();
+      }
+      asm volatile("" : "+v"(af[s & 1]));
+      if constexpr (s == 0) ws_step_a0(ac[0], ac[1], wb[0][s], wb[1][s], af[s & 1]);
+      else ws_step_a(ac[0], ac[1], wb[0][s], wb[1][s], af[s & 1]);
+      // ---- side work of step s
+      if constexpr (HP) {
+        if constexpr (s == 0) ws_anchor(pv[0], pv[1]);
+        if constexpr (s < 8) {
+          if constexpr (s + 1 < 8) ref_load(rq[(s + 1) & 1], pblk, s + 1);   // requested a step ahead, ahead of this quad's store
+          quad(pv, pblk, s);
+        }
+      }
+      if constexpr (FUSE) {
+        if constexpr (s >= 8 && s < 16) {   // request row s - 8 of this wave's 8
+          constexpr int u = s - 8;
+          const int row = wave + 4 * u;
+          sh[u] = ws_uni((gcf4)(nsrc + row * LD))[(unsigned)lane];
+          if constexpr (u == 0) sdz = *(const __attribute__((address_space(1))) v2f *)(ndz + (wave + 4 * (lane & 7)) * lda1);
+        }
+        if constexpr (s >= 22 && s < 30) {  // form it, keep it for the weight gradients, put it into the other image
+          constexpr int u = s - 22;
+          const int row = wave + 4 * u;
+          // (copies first: __builtin_bit_cast of a vector ELEMENT lvalue reads the vector's first element)
+          const float d0 = sdz.x, d1 = sdz.y;
+          const v4f t = fuse_row(sh[u], __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d0), u)),
+                                 __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d1), u)), live);
+          ws_uni((gf4)(nout + row * LD))[(unsigned)lane] = t;
+          *reinterpret_cast<v4f *>(lds + (IM ^ 1) * IMG + row * P + lane * 4) = t;
+        }
+      } else {
+        if constexpr (s >= 16 && s < 16 + WS_BM / 4) dma_row(nsrc, IM ^ 1, wave + 4 * (s - 16));
+      }
+      if constexpr (s == 12) stm = ((gcf)ndz)[m_src];
+      if constexpr (s == 30) m_dst[(IM ^ 1) * IMG] = m_ok ? stm : 0.f;
+      asm volatile("" ::: "memory");
+    });
+    asm volatile("" : "+v"(nf));
+    ws_step_v(ac[0], ac[1], wn[0], wn[1], nf);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  // ---- first image (once per workgroup)
+  int blk = j0;
+  {
+    const float *src = A0 + (long long)blk * WS_BM * lda0;
+    if constexpr (FUSE) {
+      const float *dzs = A1 + (long long)blk * m_tile;
+      float *out = fz_out + (long long)blk * WS_BM * LD;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int row = wave + 4 * u;
+        const v4f h = ((gcf4)(src + row * LD))[(unsigned)lane];
+        const v2f dz = *(const __attribute__((address_space(1))) v2f *)(dzs + row * lda1);
+        const v4f t = fuse_row(h, dz.x, dz.y, 1.f);
+        ((gf4)(out + row * LD))[(unsigned)lane] = t;
+        *reinterpret_cast<v4f *>(lds + row * P + lane * 4) = t;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < WS_BM / 4; ++u) dma_row(src, 0, wave + 4 * u);
+    }
+    const float x = ((gcf)(A1 + (long long)blk * m_tile))[m_src];
+    m_dst[0] = m_ok ? x : 0.f;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  }
+  int nxt = blk + stride < nblk ? blk + stride : blk;
+  block(F(), I0(), acc[0], acc[1], nxt, 0, nxt != blk ? 1.f : 0.f);
+  int prv = blk, set = 1;
+  blk += stride;
+#pragma unroll 1
+  while (blk < nblk) {
+    nxt = blk + stride < nblk ? blk + stride : blk;
+    block(T(), I1(), acc[1], acc[0], nxt, prv, nxt != blk ? 1.f : 0.f);
+    prv = blk; blk += stride; set = 0;
+    if (blk >= nblk) break;
+    nxt = blk + stride < nblk ? blk + stride : blk;
+    block(T(), I0(), acc[0], acc[1], nxt, prv, nxt != blk ? 1.f : 0.f);
+    prv = blk; blk += stride; set = 1;
+  }
+  auto flush = [&](f32x16 (&pv)[2]) __attribute__((always_inline)) {
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    ws_anchor(pv[0], pv[1]);
+#pragma unroll
+    for (int kq = 0; kq < 8; ++kq) {
+      ref_load(rq[kq & 1], prv, kq);
+      quad(pv, prv, kq);
+    }
+  };
+  if (set == 1) flush(acc[0]);
+  else flush(acc[1]);
+  // ---- the workgroup's partial rows of the column sums
+  {
+    gf colsum = (gf)ws_uni(I.colsum) + (long long)j0 * WS_N;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float t = ws_sum32(cs[tn][r]);
+        if (li == 31) colsum[n0 + 32 * tn + (r & 3) + 8 * (r >> 2) + 4 * lh] = t;
+      }
+    if constexpr (FUSE) {
+      __syncthreads();   // every wave is done with the images
+      *reinterpret_cast<v4f *>(lds + wave * WS_N + lane * 4) = fcs;
+      __syncthreads();
+      ((gf)ws_uni(I.fz_colsum) + (long long)j0 * WS_N)[tid] = (lds[tid] + lds[WS_N + tid]) + (lds[2 * WS_N + tid] + lds[3 * WS_N + tid]);
+    }
+  }
+}
+
 }  // namespace
 
 bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
   if (nprob < 1 || nprob > WS_MAX_INST) return false;
-  const char *env = getenv("FDQL_WSTAT");   // "0": never (tuning / test hook; read per plan build)
+  const char *env = getenv("FDQL_WSTAT");   // "0": never; "fwd": forward forms only (tuning / test hook; read per plan build)
   if (env && env[0] == '0') return false;
   memset(&args, 0, sizeof(args));
   const GemmProblem &p0 = probs[0];
+  auto aligned = [](const void *p, uintptr_t n) { return (reinterpret_cast<uintptr_t>(p) & (n - 1)) == 0; };
   auto main_of = [](const GemmProblem &p) {
     int m = -1;
     for (int s = 0; s < p.nseg; ++s)
@@ -406,38 +676,47 @@ bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
     return m;
   };
   const int main0 = main_of(p0);
-  if (main0 < 0 || p0.N != WS_N || p0.M % WS_BM || p0.M < WS_BM || p0.ksplit != 1 || p0.epi != EPI_LRELU) return false;
-  if (!p0.bias || p0.colsum || p0.ref || p0.fz_h || p0.ldc != WS_N) return false;
+  if (main0 < 0 || p0.N != WS_N || p0.M % WS_BM || p0.M < WS_BM || p0.ksplit != 1 || p0.ldc != WS_N) return false;
+  const bool grad = p0.epi == EPI_LRELU_GRAD;
+  if (!grad && p0.epi != EPI_LRELU) return false;
+  if (grad && env && !strcmp(env, "fwd")) return false;
   const int nminor = p0.nseg - 1;
   if (nminor > WS_MAX_MINOR) return false;
   const bool dual = p0.emit_seg >= 0 && p0.emit_seg < p0.nseg - 1;
-  if (dual && (p0.emit_seg != p0.nseg - 2 || main0 == p0.nseg - 1 || !p0.C2 || p0.ldc2 != WS_N)) return false;
-  if (p0.hf_w && p0.hf_q != 2) return false;
-  // instantiated forms
-  if (dual && nminor != 2) return false;
+  const bool fz = p0.fz_h != nullptr;
+  if (grad) {
+    if (p0.bias || !p0.ref || p0.ldref != WS_N || !p0.colsum || p0.hf_w || dual || nminor != 1) return false;
+    if (fz && (p0.seg[1 - main0].K != 2 || p0.seg[1 - main0].lda % 2)) return false;   // dY rows read as float2
+  } else {
+    if (!p0.bias || p0.colsum || p0.ref || fz) return false;
+    if (dual && (p0.emit_seg != p0.nseg - 2 || main0 == p0.nseg - 1 || !p0.C2 || p0.ldc2 != WS_N || nminor != 2)) return false;
+    if (p0.hf_w && p0.hf_q != 2) return false;
+  }
   args.M = p0.M; args.ninst = nprob; args.blocks_per_inst = p0.M / WS_BM;
-  args.nminor = nminor; args.dual = dual;
+  args.nminor = nminor; args.dual = dual; args.grad = grad; args.fz = fz; args.fz_ldw = p0.fz_ldw;
   args.hf_q = p0.hf_w ? p0.hf_q : 0; args.hf_ldw = p0.hf_ldw;
   for (int i = 0; i < nprob; ++i) {
     const GemmProblem &p = probs[i];
     if (p.M != p0.M || p.N != p0.N || p.nseg != p0.nseg || p.ksplit != 1 || p.epi != p0.epi || p.emit_seg != p0.emit_seg ||
         main_of(p) != main0 || (p.hf_w != nullptr) != (p0.hf_w != nullptr) || p.hf_q != p0.hf_q || p.hf_ldw != p0.hf_ldw ||
-        p.ldc != p0.ldc || p.ldc2 != p0.ldc2 || !p.bias || p.ref || p.colsum || p.fz_h)
+        p.ldc != p0.ldc || p.ldc2 != p0.ldc2 || (p.bias != nullptr) != (p0.bias != nullptr) || (p.ref != nullptr) != (p0.ref != nullptr) ||
+        p.ldref != p0.ldref || (p.colsum != nullptr) != (p0.colsum != nullptr) || (p.fz_h != nullptr) != fz || p.fz_ldw != p0.fz_ldw)
       return false;
     if (dual && (!p.C2 || (p.hf_w && !p.hf_out2))) return false;
-    if (p.hf_w && (!p.hf_out || (reinterpret_cast<uintptr_t>(p.hf_out) & 7))) return false;
-    if ((reinterpret_cast<uintptr_t>(p.C) & 15) || (p.C2 && (reinterpret_cast<uintptr_t>(p.C2) & 15)) || (reinterpret_cast<uintptr_t>(p.bias) & 15))
+    if (p.hf_w && (!p.hf_out || !aligned(p.hf_out, 8) || (p.hf_out2 && !aligned(p.hf_out2, 8)))) return false;
+    if (!aligned(p.C, 16) || (p.C2 && !aligned(p.C2, 16)) || (p.bias && !aligned(p.bias, 16)) || (p.ref && !aligned(p.ref, 16))) return false;
+    if (fz && (!p.fz_w || !p.fz_out || !p.fz_colsum || !aligned(p.fz_h, 16) || !aligned(p.fz_out, 16) || !aligned(p.fz_w, 4)))
       return false;
-    if (p.hf_w && ((reinterpret_cast<uintptr_t>(p.hf_w) & 3) != 0)) return false;
     WsInst I;
     memset(&I, 0, sizeof(I));
     int m = 0;
     for (int s = 0; s < p.nseg; ++s) {
       const GemmSeg &sg = p.seg[s], &s0 = p0.seg[s];
-      if (!sg.a_kc || !sg.b_kc || sg.K != s0.K || sg.lda != s0.lda || sg.ldb != s0.ldb) return false;
+      if (!sg.a_kc || sg.b_kc != (grad ? 0 : 1) || sg.K != s0.K || sg.lda != s0.lda || sg.ldb != s0.ldb) return false;
       const int slot = s == main0 ? 0 : 1 + m++;
       if (slot > 0 && (sg.K < 1 || sg.K > 8)) return false;
-      if (slot == 0 && (sg.lda % 4 || (reinterpret_cast<uintptr_t>(sg.A) & 15))) return false;   // rows move as 16-byte pieces
+      if (slot == 0 && !fz && (sg.lda % 4 || !aligned(sg.A, 16))) return false;   // rows move as 16-byte pieces
+      if (slot > 0 && fz && !aligned(sg.A, 8)) return false;
       I.A[slot] = sg.A; I.W[slot] = sg.B;
       if (i == 0) {
         args.lda[slot] = sg.lda; args.ldw[slot] = sg.ldb;
@@ -446,6 +725,8 @@ bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
     }
     I.bias = p.bias; I.C = p.C; I.C2 = p.C2;
     I.hf_w = p.hf_w; I.hf_out = p.hf_out; I.hf_out2 = p.hf_out2;
+    I.ref = p.ref; I.colsum = p.colsum;
+    I.fz_h = p.fz_h; I.fz_w = p.fz_w; I.fz_out = p.fz_out; I.fz_colsum = p.fz_colsum;
     args.inst[i] = I;
   }
   // workgroups per instance: an equal share of the CUs (at most one per tile)
@@ -465,6 +746,8 @@ bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
   if (nprob > ncu) return false;
   int per = ncu / nprob;
   if (per > args.blocks_per_inst) per = args.blocks_per_inst;
+  // the dgrad form's column sums: one partial row per workgroup in buffers sized for one per 64 rows
+  if (grad && per > (p0.M + 63) / 64) per = (p0.M + 63) / 64;
   for (int i = 0; i <= nprob; ++i) args.wg_first[i] = i * per;
   return true;
 }
@@ -475,13 +758,10 @@ double wstat_flops(const WsArgs &a) {
   return 2.0 * a.M * (double)WS_N * k * a.ninst;
 }
 
-template <int NMINOR, bool DUAL, int HFQ>
-static hipError_t ws_launch(const WsArgs &a, hipStream_t s) {
+template <typename K>
+static hipError_t ws_launch_kernel(K kern, int lds_bytes, bool (&attr)[64], const WsArgs &a, hipStream_t s) {
   // the opt-in to > 64 KiB of dynamic LDS belongs to the (device, function) pair
-  static bool attr[64];
   static std::mutex mu;
-  auto kern = &k_wstat<NMINOR, DUAL, HFQ>;
-  constexpr int lds_bytes = (2 * WS_BM * (WS_KMAIN + 8 * NMINOR + 4) + 4 * 2 * 32 + 4 * 8 * 32) * 4;   // two images + per-wave constants
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
@@ -497,8 +777,21 @@ static hipError_t ws_launch(const WsArgs &a, hipStream_t s) {
   hipLaunchKernelGGL(kern, dim3(a.wg_first[a.ninst]), dim3(256), lds_bytes, s, a);
   return hipGetLastError();
 }
+template <int NMINOR, bool DUAL, int HFQ>
+static hipError_t ws_launch(const WsArgs &a, hipStream_t s) {
+  static bool attr[64];
+  constexpr int lds_bytes = (2 * WS_BM * (WS_KMAIN + 8 * NMINOR + 4) + 4 * 2 * 32 + 4 * 8 * 32) * 4;   // two images + per-wave constants
+  return ws_launch_kernel(&k_wstat<NMINOR, DUAL, HFQ>, lds_bytes, attr, a, s);
+}
+template <bool FUSE>
+static hipError_t ws_launch_grad(const WsArgs &a, hipStream_t s) {
+  static bool attr[64];
+  constexpr int lds_bytes = 2 * WS_BM * (WS_KMAIN + 8 + 4) * 4;
+  return ws_launch_kernel(&k_wstat_grad<FUSE>, lds_bytes, attr, a, s);
+}
 
 hipError_t wstat_launch(const WsArgs &a, hipStream_t s) {
+  if (a.grad) return a.fz ? ws_launch_grad<true>(a, s) : ws_launch_grad<false>(a, s);
   if (a.dual) return a.hf_q ? ws_launch<2, true, 2>(a, s) : ws_launch<2, true, 0>(a, s);
   if (a.nminor == 0) return a.hf_q ? ws_launch<0, false, 2>(a, s) : ws_launch<0, false, 0>(a, s);
   if (a.nminor == 1) return a.hf_q ? ws_launch<1, false, 2>(a, s) : ws_launch<1, false, 0>(a, s);

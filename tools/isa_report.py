@@ -28,7 +28,7 @@ def kernels_of(path):
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
         subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", path, "-o", out,
-                        "-I", CSRC], check=True, capture_output=True)
+                        "-I", CSRC] + (["-fno-slp-vectorize"] if os.path.basename(path) == "wstat.hip" else []), check=True, capture_output=True)
         text = open(out).read()
     res = []
     for blk in re.split(r"\n  - \.agpr_count", text)[1:]:
