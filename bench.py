@@ -169,7 +169,7 @@ def dominant(prof):
     the row-block chain kernel): name, ms/step, flops/step, launches/step, and the all-MFMA-kernel totals."""
     groups = {}
     for k, v in prof.items():
-        if k.startswith("gemm") or k.startswith("chain") or k.startswith("rows"):
+        if k.startswith(("gemm", "chain", "rows", "wstat", "wgstat")):
             groups.setdefault(k.split(":")[0], []).append(v)
     name, rows = max(groups.items(), key=lambda kv: sum(r[0] for r in kv[1]))
     ms, fl, n = sum(r[0] for r in rows), sum(r[1] * r[3] for r in rows), sum(r[3] for r in rows)
@@ -182,6 +182,10 @@ def dominant(prof):
 def kernel_label(name):
     if name.startswith("chain"):
         return "k_chain (row-block MLP chain, fp32 v_mfma_f32_32x32x2_f32)"
+    if name.startswith("wstat"):
+        return "k_wstat (weight-stationary persistent row-block GEMM, " + ("dgrad" if "KS" in name else "forward") + " form, fp32 v_mfma_f32_32x32x2_f32)"
+    if name.startswith("wgstat"):
+        return "k_wgrad_stat (output-stationary weight-gradient blocks, fp32 v_mfma_f32_32x32x2_f32)"
     if name.startswith("rows"):
         return "k_rowgemm (persistent row-block GEMM, " + ("dgrad" if "KS" in name else "forward") + " form, fp32 v_mfma_f32_32x32x2_f32)"
     return f"k_gemm_grouped<{name[4:]} tile> (fp32 v_mfma_f32_32x32x2_f32)"

@@ -21,6 +21,7 @@
 #include "chain.h"
 #include "rowgemm.h"
 #include "wstat.h"
+#include "wgrad.h"
 #include "common.h"
 #include "update_kernels.h"
 
@@ -91,7 +92,7 @@ constexpr size_t PLAN_CACHE_MAX = 4;   // finished plans kept besides the curren
 // K-split of a conv weight gradient over its R = images * positions rows: ~4096 rows per workgroup, at most 1024 parts
 inline int conv_wsplit(long long R) { return (int)std::max<long long>(1, std::min<long long>(1024, (R + 4095) / 4096)); }
 
-enum StageKind { ST_GEMM, ST_SKINNY_WGRAD, ST_FUNC, ST_HEAD_DGRAD, ST_CHAIN };
+enum StageKind { ST_GEMM, ST_SKINNY_WGRAD, ST_FUNC, ST_HEAD_DGRAD, ST_CHAIN, ST_WGRAD_STAT };
 
 // one launch of a row-block kernel: the weight-stationary one (wstat.hip, forward forms) or the streamed-weights one
 struct RowsLaunch {
@@ -116,6 +117,7 @@ struct Stage {
   std::vector<RowsLaunch> rows;    // the groups that do (one launch each); their problems are not in `sub`
   std::vector<SkinnyWgradProblem> swg;
   std::vector<HeadDgradProblem> hdg;
+  WgArgs wga;                         // ST_WGRAD_STAT: the dense 256 x 256 weight-gradient blocks (wgrad.h), one launch
   std::vector<ChainProblem> cprobs;   // ST_CHAIN: programs (chain.h) and their operations
   std::vector<ChainOp> cops;
   void *cops_dev = nullptr;
@@ -418,6 +420,9 @@ struct Builder {
   fdql_agent *a;
   std::vector<Stage> &st;
   Builder(fdql_agent *ag) : a(ag), st(ag->stages) {}
+  // dense 256 x 256 weight-gradient blocks: candidates for the output-stationary launch (wgrad.h), each with the index of the
+  // stage it rides in otherwise (-1: the tail stage)
+  std::vector<std::pair<GemmProblem, int>> wg_cand;
 
   Stage &gemm_stage(const std::string &name) {
     st.emplace_back();
@@ -529,6 +534,13 @@ struct Builder {
     add_seg(p, dOut, ldo, 0, X, ldx, 0, R);
     p.ksplit = a->nsplit;
     p.split_stride = a->n_train;
+    if (wgrad_stat_takes(p)) {   // decided once every weight gradient of the plan is known (build_plan)
+      int host = -1;
+      for (size_t i = 0; i < st.size(); ++i)
+        if (&st[i] == &gs) host = (int)i;
+      wg_cand.push_back({p, host});
+      return;
+    }
     // narrow problems (other tile shapes = other launches) are pooled in one stage at the end
     (gemm_shape_is_dense(gemm_pick_shape(p, gemm_dense_shape())) ? gs : narrow).gemm.push_back(p);
   }
@@ -1489,6 +1501,22 @@ int build_plan(fdql_agent *a) {
         return e;
       });
     }
+    // The dense 256 x 256 blocks: one output-stationary launch (wgrad.hip) when there are enough row tiles for every
+    // workgroup to amortise its 256 KiB partial result; else they ride in the dgrad launches / the tail as before.
+    if (!b.wg_cand.empty()) {
+      std::vector<GemmProblem> probs;
+      for (auto &pc : b.wg_cand) probs.push_back(pc.first);
+      Stage wst;
+      wst.kind = ST_WGRAD_STAT; wst.name = "wgrad.dense";
+      const long long tiles = (long long)probs.size() * (probs[0].seg[0].K / WG_BM);
+      if (tiles >= 8 * a->rows_min_tiles && wgrad_stat_from_problems(probs.data(), (int)probs.size(), a->nsplit, a->n_train, wst.wga)) {
+        wst.flops = wgrad_stat_flops(wst.wga);
+        wst.bytes = 8.0 * wst.wga.M * WG_N * wst.wga.ninst;
+        a->stages.push_back(wst);
+      } else {
+        for (auto &pc : b.wg_cand) (pc.second >= 0 ? a->stages[pc.second] : tail).gemm.push_back(pc.first);
+      }
+    }
     a->stages.push_back(tail);
     a->stages.push_back(ws);
     if (!conv_post.empty())
@@ -1544,6 +1572,7 @@ hipError_t run_stage(fdql_agent *a, Stage &s, hipStream_t stream) {
     case ST_SKINNY_WGRAD: return skinny_wgrad_launch_host(s.swg.data(), (const SkinnyWgradProblem *)s.dev, (int)s.swg.size(), s.blocks, stream);
     case ST_FUNC: return s.fn(stream);
     case ST_HEAD_DGRAD: return head_dgrad_launch((const HeadDgradProblem *)s.dev, (int)s.hdg.size(), s.blocks, stream);
+    case ST_WGRAD_STAT: return wgrad_stat_launch(s.wga, stream);
     case ST_CHAIN:
       return chain_launch((const ChainProblem *)s.dev, (int)s.cprobs.size(), (const ChainOp *)s.cops_dev, s.blocks, s.lds_floats, stream);
   }
@@ -1871,7 +1900,8 @@ int32_t fdql_agent_profile_update(fdql_agent_t *a, const fdql_batch_t *batch, co
       snprintf(out[cnt].name, sizeof(out[cnt].name), "rows%s%s:%s", ra.grad ? "KS" : "", ra.dual ? "dual" : "", st.name.c_str());
       }
     } else {
-      snprintf(out[cnt].name, sizeof(out[cnt].name), "%s%s", st.kind == ST_SKINNY_WGRAD ? "colsum:" : (st.kind == ST_CHAIN ? "chain:" : "k:"),
+      snprintf(out[cnt].name, sizeof(out[cnt].name), "%s%s",
+               st.kind == ST_SKINNY_WGRAD ? "colsum:" : (st.kind == ST_CHAIN ? "chain:" : (st.kind == ST_WGRAD_STAT ? "wgstat:" : "k:")),
                st.name.c_str());
     }
     out[cnt].ms = ms;
@@ -2077,7 +2107,7 @@ int fdql_agent_stats(const fdql_agent_t *a, fdql_agent_stats_t *out) {
       out->n_gemm_launches += (int)s.rows.size();
     }
     if (s.kind == ST_SKINNY_WGRAD) out->skinny_flops += s.flops;
-    if (s.kind == ST_CHAIN) { out->gemm_flops += s.flops; out->n_gemm_launches++; }
+    if (s.kind == ST_CHAIN || s.kind == ST_WGRAD_STAT) { out->gemm_flops += s.flops; out->n_gemm_launches++; }
   }
   return 0;
 }

@@ -462,6 +462,13 @@ def test_update_matches_oracle_config2(dev, T, B, hid):
      dict(obs=17, act=6, C=5, Q=2, T=4, B=64, env={"FDQL_NO_HEAD_FUSE": "1"})),
     ("config 2 dims without the dual-output first layer (FDQL_NO_DUAL)",
      dict(obs=17, act=6, C=5, Q=2, T=4, B=64, env={"FDQL_NO_DUAL": "1"})),
+    ("config 2 dims, critic layers forced onto the weight-stationary row-block kernel at a small batch (FDQL_ROWGEMM=all: "
+     "8 tiles per instance, prologue + flush paths, per-workgroup column sums)",
+     dict(obs=17, act=6, C=5, Q=2, T=5, B=64, env={"FDQL_ROWGEMM": "all"})),
+    ("3-layer 256-wide critics on the weight-stationary kernel (non-fused dgrad form on the middle layer, fused on the last)",
+     dict(obs=17, act=6, C=3, Q=2, T=5, B=64, critic_hidden=(256, 256, 256), env={"FDQL_ROWGEMM": "all"})),
+    ("config 2 dims, same forced launches on the streamed-weights row-block kernel (FDQL_WSTAT=0)",
+     dict(obs=17, act=6, C=5, Q=2, T=5, B=64, env={"FDQL_ROWGEMM": "all", "FDQL_WSTAT": "0", "FDQL_ROWGEMM_FORMS": "7"})),
     ("config 2 dims, every MLP forward through the row-block chain kernel (FDQL_CHAIN=all: encoder/joiner/actors in one "
      "program, each critic instance in one)", dict(obs=17, act=6, C=5, Q=2, T=4, B=64, env={"FDQL_CHAIN": "all"})),
     ("config 2 dims on per-layer launches only (FDQL_CHAIN=0)", dict(obs=17, act=6, C=5, Q=2, T=6, B=192, env={"FDQL_CHAIN": "0"})),
@@ -774,11 +781,16 @@ def _gpu_branch_pattern(ag, spec, xp_cpu):
     ("config 4 dims (obs 376, act 17, 5x25 quantiles, T=3, B=96)", dict(obs=376, act=17, C=5, Q=25, T=3, B=96)),
     ("config 2 full size, every forward pass through the row-block chain kernel (FDQL_CHAIN=all)",
      dict(obs=17, act=6, C=5, Q=2, T=50, B=256, env={"FDQL_CHAIN": "all"})),
-    ("config 2 full size, every critic layer through the persistent row-block kernel (forward forms with head fusion, "
-     "two-output layer 0, dgrad with the fused head dgrad: FDQL_ROWGEMM_FORMS=7)",
-     dict(obs=17, act=6, C=5, Q=2, T=50, B=256, env={"FDQL_ROWGEMM_FORMS": "7"})),
-    ("config 2 dims at T=4, B=64 with the row-block launches forced (one tile per workgroup: prologue + flush paths)",
-     dict(obs=17, act=6, C=5, Q=2, T=4, B=64, env={"FDQL_ROWGEMM": "all", "FDQL_ROWGEMM_FORMS": "7"})),
+    ("config 2 full size, every critic layer through the streamed-weights row-block kernel instead of the weight-stationary "
+     "one (forward forms with head fusion, two-output layer 0, dgrad with the fused head dgrad: FDQL_WSTAT=0 "
+     "FDQL_ROWGEMM_FORMS=7)",
+     dict(obs=17, act=6, C=5, Q=2, T=50, B=256, env={"FDQL_WSTAT": "0", "FDQL_ROWGEMM_FORMS": "7"})),
+    ("config 2 full size, weight-stationary kernel for the forward layers only (FDQL_WSTAT=fwd: dgrad on k_rowgemm)",
+     dict(obs=17, act=6, C=5, Q=2, T=50, B=256, env={"FDQL_WSTAT": "fwd"})),
+    ("config 2 dims at T=4, B=64 with the weight-stationary launches forced (few tiles per workgroup: prologue + flush paths)",
+     dict(obs=17, act=6, C=5, Q=2, T=4, B=64, env={"FDQL_ROWGEMM": "all"})),
+    ("config 2 dims at T=4, B=64 with the streamed-weights row-block launches forced (one tile per workgroup)",
+     dict(obs=17, act=6, C=5, Q=2, T=4, B=64, env={"FDQL_ROWGEMM": "all", "FDQL_WSTAT": "0", "FDQL_ROWGEMM_FORMS": "7"})),
     ("config 2 full size without the row-block kernel (FDQL_ROWGEMM=0: k_head_dgrad + tile kernels)",
      dict(obs=17, act=6, C=5, Q=2, T=50, B=256, env={"FDQL_ROWGEMM": "0"})),
 ])
