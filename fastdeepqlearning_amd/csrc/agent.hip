@@ -807,6 +807,13 @@ int upload_tables(fdql_agent *a) {
       s.rows.clear();
       std::vector<char> taken(s.gemm.size(), 0);
       if (s.try_rows) {   // like problems (same segment list shape and epilogue) -> one row-block launch per group
+        {   // ... or the whole stage as ONE weight-stationary launch (critic layer 0: two-output and plain instances mixed)
+          RowsLaunch rl;
+          if (s.gemm.size() > 1 && rows_launch_of(a, s.gemm, rl) && rl.ws) {
+            s.rows.push_back(rl);
+            std::fill(taken.begin(), taken.end(), 1);
+          }
+        }
         for (size_t i = 0; i < s.gemm.size(); ++i) {
           if (taken[i]) continue;
           std::vector<GemmProblem> grp;
@@ -1727,6 +1734,9 @@ int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {
     if (v >= 1 && v <= 64) a->nsplit = v;
   }
   layout(a);
+  // (The output-stationary weight-gradient launch (wgrad.h) writes ncu / blocks slabs per block - 17 at config 2 - and clears
+  // the others.  Sizing the K-split to that count was measured: the slab sum drops 0.037 -> 0.024 ms, but the narrow
+  // HBM-bound weight gradients, which share the split, lose their parallelism: 0.106 -> 0.142 ms.  The split stays.)
   carve(a);
   a->ws_need = a->carve_top;
   *out = a;

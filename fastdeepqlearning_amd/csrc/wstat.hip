@@ -140,8 +140,11 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
   if (j0 >= nblk) return;
   const WsInst &I = a.inst[inst];   // kernel-argument segment: scalar loads, each field read once
   const float *A0 = ws_uni(I.A[0]);
-  const float *An[WS_MAX_MINOR] = {ws_uni(I.A[1]), ws_uni(I.A[2])};
   float *const C = ws_uni(I.C), *const C2 = ws_uni(I.C2);
+  // DUAL launches may mix two-output instances with plain ones (critic layer 0: online + frozen pass / target pass): a plain
+  // instance has no second output and no last narrow segment - its slot is staged from the first one's memory and never used
+  const bool has2 = DUAL && C2 != nullptr;
+  const float *An[WS_MAX_MINOR] = {ws_uni(I.A[1]), (DUAL && !has2) ? ws_uni(I.A[1]) : ws_uni(I.A[2])};
   float *const hf_out = ws_uni(I.hf_out), *const hf_out2 = ws_uni(I.hf_out2);
   const int lda0 = a.lda[0];
 
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
   v4f wn[NMINOR > 0 ? NMINOR : 1][2];
 #pragma unroll
   for (int s = 0; s < NMINOR; ++s) {
-    const float *Ws = ws_uni(I.W[1 + s]);
+    const float *Ws = ws_uni((DUAL && !has2 && s == NMINOR - 1) ? I.W[1] : I.W[1 + s]);
     const int Ks = a.kminor[s], ldw = a.ldw[1 + s];
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn)
@@ -294,22 +297,33 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
       if constexpr (HP) {
         // quad kq is finished at step s: first output kq = s (0..7); second output of a dual launch kq = s - 1 (8..15)
         constexpr int kq = s < 8 ? s : s - 1;
-        constexpr bool has_quad = s < 8 || (DUAL && s >= 9 && s < 17);
-        if constexpr (has_quad) {
+        if constexpr (s < 8) {
           asm volatile("" : "+v"(cb[kq & 1]));
           if constexpr (HFQ > 0) asm volatile("" : "+v"(cw[kq & 1]));
-          if constexpr (kq + 1 < (DUAL ? 16 : 8)) read_consts(std::integral_constant<int, kq + 1>{});
+          if constexpr (kq + 1 < 8) read_consts(std::integral_constant<int, kq + 1>{});
         }
         if constexpr (s == 0) ws_anchor(pv[0], pv[1]);
         if constexpr (s < 8) quad(pv, C, hacc, pblk, kq);
         if constexpr (!DUAL) {
           if constexpr (s == 9) hf_store(hacc, hf_out, pblk);
         } else {
-          if constexpr (s == 8) ws_step_v(pv[0], pv[1], wn[NMINOR - 1][0], wn[NMINOR - 1][1], pa_prev);   // the previous tile becomes its second output
-          if constexpr (s == 9) ws_anchor(pv[0], pv[1]);
-          if constexpr (s >= 9 && s < 17) quad(pv, C2, hacc2, pblk, kq);
           if constexpr (s == 10) hf_store(hacc, hf_out, pblk);
-          if constexpr (s == 18) hf_store(hacc2, hf_out2, pblk);
+          if constexpr (s >= 8 && s <= 18) {
+            if (has2) {   // (uniform: the instance's second output)
+              if constexpr (s == 8) {
+                ws_step_v(pv[0], pv[1], wn[NMINOR - 1][0], wn[NMINOR - 1][1], pa_prev);   // the previous tile becomes its second output
+                read_consts(std::integral_constant<int, 8>{});
+              }
+              if constexpr (s >= 9 && s < 17) {
+                asm volatile("" : "+v"(cb[kq & 1]));
+                if constexpr (HFQ > 0) asm volatile("" : "+v"(cw[kq & 1]));
+                if constexpr (kq + 1 < 16) read_consts(std::integral_constant<int, kq + 1>{});
+                if constexpr (s == 9) ws_anchor(pv[0], pv[1]);
+                quad(pv, C2, hacc2, pblk, kq);
+              }
+              if constexpr (s == 18) hf_store(hacc2, hf_out2, pblk);
+            }
+          }
         }
       }
       if constexpr (s == 12) {
@@ -372,7 +386,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
       asm volatile("" : "+v"(cb[decltype(kc)::value & 1]), "+v"(cw[decltype(kc)::value & 1]));
       quad(pv, C, hacc, prv, decltype(kc)::value);
     });
-    if constexpr (DUAL) {
+    if (DUAL && has2) {
       ws_step_v(pv[0], pv[1], wn[NMINOR - 1][0], wn[NMINOR - 1][1], pa);   // pa: read at the start of this tile's K loop
       asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
       ws_anchor(pv[0], pv[1]);
@@ -385,7 +399,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
     }
     asm volatile("s_nop 7" ::: "memory");   // rider results -> VALU readers
     hf_store(hacc, hf_out, prv);
-    if constexpr (DUAL) hf_store(hacc2, hf_out2, prv);
+    if (DUAL && has2) hf_store(hacc2, hf_out2, prv);
   };
   if (set == 1) flush(acc[0]);
   else flush(acc[1]);
@@ -667,7 +681,6 @@ bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
   const char *env = getenv("FDQL_WSTAT");   // "0": never; "fwd": forward forms only (tuning / test hook; read per plan build)
   if (env && env[0] == '0') return false;
   memset(&args, 0, sizeof(args));
-  const GemmProblem &p0 = probs[0];
   auto aligned = [](const void *p, uintptr_t n) { return (reinterpret_cast<uintptr_t>(p) & (n - 1)) == 0; };
   auto main_of = [](const GemmProblem &p) {
     int m = -1;
@@ -675,6 +688,14 @@ bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
       if (p.seg[s].K == WS_KMAIN) { if (m >= 0) return -1; m = s; }
     return m;
   };
+  auto is_dual = [](const GemmProblem &p) { return p.emit_seg >= 0 && p.emit_seg < p.nseg - 1; };
+  // the launch's shape: that of its two-output problems if it has any (plain problems may ride along: a critic's target
+  // pass beside the online + frozen pass of layer 0), else that of the first problem
+  int ref_i = 0;
+  bool dual = false;
+  for (int i = 0; i < nprob; ++i)
+    if (is_dual(probs[i])) { ref_i = i; dual = true; break; }
+  const GemmProblem &p0 = probs[ref_i];
   const int main0 = main_of(p0);
   if (main0 < 0 || p0.N != WS_N || p0.M % WS_BM || p0.M < WS_BM || p0.ksplit != 1 || p0.ldc != WS_N) return false;
   const bool grad = p0.epi == EPI_LRELU_GRAD;
@@ -682,10 +703,10 @@ bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
   if (grad && env && !strcmp(env, "fwd")) return false;
   const int nminor = p0.nseg - 1;
   if (nminor > WS_MAX_MINOR) return false;
-  const bool dual = p0.emit_seg >= 0 && p0.emit_seg < p0.nseg - 1;
   const bool fz = p0.fz_h != nullptr;
   if (grad) {
     if (p0.bias || !p0.ref || p0.ldref != WS_N || !p0.colsum || p0.hf_w || dual || nminor != 1) return false;
+    if (p0.seg[main0].ldb != WS_N) return false;   // K-strided weights: compile-time row pitch
     if (fz && (p0.seg[1 - main0].K != 2 || p0.seg[1 - main0].lda % 2)) return false;   // dY rows read as float2
   } else {
     if (!p0.bias || p0.colsum || p0.ref || fz) return false;
@@ -695,14 +716,19 @@ bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
   args.M = p0.M; args.ninst = nprob; args.blocks_per_inst = p0.M / WS_BM;
   args.nminor = nminor; args.dual = dual; args.grad = grad; args.fz = fz; args.fz_ldw = p0.fz_ldw;
   args.hf_q = p0.hf_w ? p0.hf_q : 0; args.hf_ldw = p0.hf_ldw;
+  int cost[WS_MAX_INST], cost_sum = 0;
   for (int i = 0; i < nprob; ++i) {
     const GemmProblem &p = probs[i];
-    if (p.M != p0.M || p.N != p0.N || p.nseg != p0.nseg || p.ksplit != 1 || p.epi != p0.epi || p.emit_seg != p0.emit_seg ||
-        main_of(p) != main0 || (p.hf_w != nullptr) != (p0.hf_w != nullptr) || p.hf_q != p0.hf_q || p.hf_ldw != p0.hf_ldw ||
-        p.ldc != p0.ldc || p.ldc2 != p0.ldc2 || (p.bias != nullptr) != (p0.bias != nullptr) || (p.ref != nullptr) != (p0.ref != nullptr) ||
+    const bool pd = is_dual(p);
+    const bool plain_in_dual = dual && !pd;   // one narrow segment and one output fewer than the launch's shape
+    if (plain_in_dual && (p.nseg != p0.nseg - 1 || (p.emit_seg >= 0 && p.emit_seg != p.nseg - 1) || p.C2)) return false;
+    if (!plain_in_dual && (p.nseg != p0.nseg || p.emit_seg != p0.emit_seg)) return false;
+    if (p.M != p0.M || p.N != p0.N || p.ksplit != 1 || p.epi != p0.epi || main_of(p) != main0 ||
+        (p.hf_w != nullptr) != (p0.hf_w != nullptr) || p.hf_q != p0.hf_q || p.hf_ldw != p0.hf_ldw || p.ldc != p0.ldc ||
+        (pd && p.ldc2 != p0.ldc2) || (p.bias != nullptr) != (p0.bias != nullptr) || (p.ref != nullptr) != (p0.ref != nullptr) ||
         p.ldref != p0.ldref || (p.colsum != nullptr) != (p0.colsum != nullptr) || (p.fz_h != nullptr) != fz || p.fz_ldw != p0.fz_ldw)
       return false;
-    if (dual && (!p.C2 || (p.hf_w && !p.hf_out2))) return false;
+    if (pd && (!p.C2 || (p.hf_w && !p.hf_out2))) return false;
     if (p.hf_w && (!p.hf_out || !aligned(p.hf_out, 8) || (p.hf_out2 && !aligned(p.hf_out2, 8)))) return false;
     if (!aligned(p.C, 16) || (p.C2 && !aligned(p.C2, 16)) || (p.bias && !aligned(p.bias, 16)) || (p.ref && !aligned(p.ref, 16))) return false;
     if (fz && (!p.fz_w || !p.fz_out || !p.fz_colsum || !aligned(p.fz_h, 16) || !aligned(p.fz_out, 16) || !aligned(p.fz_w, 4)))
@@ -718,18 +744,24 @@ bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
       if (slot == 0 && !fz && (sg.lda % 4 || !aligned(sg.A, 16))) return false;   // rows move as 16-byte pieces
       if (slot > 0 && fz && !aligned(sg.A, 8)) return false;
       I.A[slot] = sg.A; I.W[slot] = sg.B;
-      if (i == 0) {
-        args.lda[slot] = sg.lda; args.ldw[slot] = sg.ldb;
-        if (slot > 0) args.kminor[slot - 1] = sg.K;
-      }
     }
     I.bias = p.bias; I.C = p.C; I.C2 = p.C2;
     I.hf_w = p.hf_w; I.hf_out = p.hf_out; I.hf_out2 = p.hf_out2;
     I.ref = p.ref; I.colsum = p.colsum;
     I.fz_h = p.fz_h; I.fz_w = p.fz_w; I.fz_out = p.fz_out; I.fz_colsum = p.fz_colsum;
     args.inst[i] = I;
+    cost[i] = pd ? 12 : 11;   // a two-output instance finishes twice as many register quads per tile
+    cost_sum += cost[i];
   }
-  // workgroups per instance: an equal share of the CUs (at most one per tile)
+  {
+    int m = 0;
+    for (int s = 0; s < p0.nseg; ++s) {
+      const int slot = s == main0 ? 0 : 1 + m++;
+      args.lda[slot] = p0.seg[s].lda; args.ldw[slot] = p0.seg[s].ldb;
+      if (slot > 0) args.kminor[slot - 1] = p0.seg[s].K;
+    }
+  }
+  // workgroups per instance: a share of the CUs in proportion to the instance's work (at most one per tile)
   int dev = 0;
   static int ncu_of[64];
   static std::mutex mu;
@@ -744,11 +776,15 @@ bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
   }
   const int ncu = ncu_of[dev];
   if (nprob > ncu) return false;
-  int per = ncu / nprob;
-  if (per > args.blocks_per_inst) per = args.blocks_per_inst;
-  // the dgrad form's column sums: one partial row per workgroup in buffers sized for one per 64 rows
-  if (grad && per > (p0.M + 63) / 64) per = (p0.M + 63) / 64;
-  for (int i = 0; i <= nprob; ++i) args.wg_first[i] = i * per;
+  args.wg_first[0] = 0;
+  for (int i = 0; i < nprob; ++i) {
+    int per = (int)((long long)ncu * cost[i] / cost_sum);
+    if (per < 1) per = 1;
+    if (per > args.blocks_per_inst) per = args.blocks_per_inst;
+    // the dgrad form's column sums: one partial row per workgroup in buffers sized for one per 64 rows
+    if (grad && per > (p0.M + 63) / 64) per = (p0.M + 63) / 64;
+    args.wg_first[i + 1] = args.wg_first[i] + per;
+  }
   return true;
 }
 
