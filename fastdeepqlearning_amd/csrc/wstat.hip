@@ -45,6 +45,23 @@ typedef __attribute__((address_space(1))) v2f *gf2;
 
 constexpr int NSTEP = WS_KMAIN / 8;   // 32 steps of 8 k (4 k-pairs x both lane halves)
 
+#ifdef WS_STAMPS   // diagnostic build (tools/ws_stamps.py): shader clock at the seams of a workgroup's life, never inside a K loop
+__device__ unsigned long long g_ws_stamps[1024 * 8];
+#define WS_STAMP(i) st_[i] = __builtin_amdgcn_s_memtime()
+#define WS_STAMP_DECL unsigned long long st_[6] = {0, 0, 0, 0, 0, 0}; int st_tiles = 0
+#define WS_STAMP_TILE ++st_tiles
+#define WS_STAMP_OUT                                                                    \
+  if (threadIdx.x == 0 && blockIdx.x < 1024) {                                          \
+    for (int i_ = 0; i_ < 6; ++i_) g_ws_stamps[8 * blockIdx.x + i_] = st_[i_];          \
+    g_ws_stamps[8 * blockIdx.x + 6] = (unsigned long long)st_tiles;                     \
+  }
+#else
+#define WS_STAMP(i)
+#define WS_STAMP_DECL
+#define WS_STAMP_TILE
+#define WS_STAMP_OUT
+#endif
+
 template <int I, int N, typename F>
 __device__ __forceinline__ void sfor(F &&f) {
   if constexpr (I < N) {
@@ -124,6 +141,8 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
   static_assert(!DUAL || NMINOR >= 1, "a dual launch emits before its last narrow segment");
   static_assert(HFQ == 0 || HFQ == 2, "head-fusion riders: 2 outputs per row");
   extern __shared__ __attribute__((aligned(16))) float lds[];   // two images [32][P]
+  WS_STAMP_DECL;
+  WS_STAMP(0);
   constexpr int P = WS_KMAIN + 8 * NMINOR + 4, IMG = WS_BM * P;   // (P / 4) odd: conflict-free ds_read_b128
   constexpr int NM_LOOP = DUAL ? NMINOR - 1 : NMINOR;             // narrow steps inside a tile's K loop
   constexpr int LD = WS_N;                                        // row pitch of the outputs (compile-time)
@@ -362,20 +381,26 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   }
+  WS_STAMP(1);
   int nxt = blk + stride < nblk ? blk + stride : blk;   // a workgroup's last tile prefetches itself again (nobody reads it)
   block(F(), I0(), acc[0], acc[1], nxt, 0);
+  WS_STAMP(2);
+  WS_STAMP_TILE;
   int prv = blk, set = 1;
   blk += stride;
 #pragma unroll 1
   while (blk < nblk) {
     nxt = blk + stride < nblk ? blk + stride : blk;
     block(T(), I1(), acc[1], acc[0], nxt, prv);
+    WS_STAMP_TILE;
     prv = blk; blk += stride; set = 0;
     if (blk >= nblk) break;
     nxt = blk + stride < nblk ? blk + stride : blk;
     block(T(), I0(), acc[0], acc[1], nxt, prv);
+    WS_STAMP_TILE;
     prv = blk; blk += stride; set = 1;
   }
+  WS_STAMP(3);
   // ---- the last tile's result, not overlapped
   auto flush = [&](f32x16 (&pv)[2]) __attribute__((always_inline)) {
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // MFMA results -> VALU readers
@@ -403,6 +428,8 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
   };
   if (set == 1) flush(acc[0]);
   else flush(acc[1]);
+  WS_STAMP(4);
+  WS_STAMP_OUT;
 }
 
 
@@ -787,6 +814,16 @@ bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
   }
   return true;
 }
+
+#ifdef WS_STAMPS
+extern "C" int wstat_debug_stamps(unsigned long long *out, int cap) {
+  static unsigned long long h[1024 * 8];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ws_stamps), sizeof(h)) != hipSuccess) return -1;
+  const int n = cap < 1024 * 8 ? cap : 1024 * 8;
+  for (int i = 0; i < n; ++i) out[i] = h[i];
+  return n;
+}
+#endif
 
 double wstat_flops(const WsArgs &a) {
   double k = WS_KMAIN;
