@@ -102,16 +102,18 @@ class Job:
         self.w, self.dev, self.B, self.T = w, dev, B, T
         self.keys, self.dims = layout(w)
         slots = ring_slots or w["ring"]
-        self.ring = NativeRing(slots, self.dims, dev)
-        for c0 in range(0, slots + 1000, fill_chunk):          # wraps once: len = slots - 1 (quirk q1)
-            n = min(fill_chunk, slots + 1000 - c0)
-            self.ring.add_rows(synth_rows(w, n, 1000 * rank + c0 // fill_chunk, dev))
-        assert len(self.ring) == slots - 1
         cfg = make_config(w["obs"], w["act"], T, B, goal_dim=w["goal"], n_critics=w["C"], n_quantiles=w["Q"], latent=HID,
                           enc_features=HID, enc_hidden=(HID,), joint_hidden=(HID,), pi_hidden=(HID,), critic_hidden=(HID, HID),
                           world_size=world, keep_frozen_copy=True)
         self.agent = NativeAgent(cfg, dev)
         self.agent.init_weights(seed=0)                        # same weights on every rank
+        # the ring is filled last: the step that follows finds the device as a running job would (busy, not idling
+        # behind host-side set-up)
+        self.ring = NativeRing(slots, self.dims, dev)
+        for c0 in range(0, slots + 1000, fill_chunk):          # wraps once: len = slots - 1 (quirk q1)
+            n = min(fill_chunk, slots + 1000 - c0)
+            self.ring.add_rows(synth_rows(w, n, 1000 * rank + c0 // fill_chunk, dev))
+        assert len(self.ring) == slots - 1
         self.outs = [torch.empty(T, B, d, device=dev) for d in self.dims]
         self.xp = dict(zip(self.keys, self.outs))
         self.seed = 1234 + rank

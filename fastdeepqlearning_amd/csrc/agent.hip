@@ -199,6 +199,10 @@ struct fdql_agent {
   std::vector<CachedPlan> plan_cache;   // most recently stashed last
   long long plans_built = 0;
   long long rows_min_tiles = 512;   // FDQL_ROWGEMM: "0" never; default: groups with at least two tiles per CU
+  // d state = sum over the online critics and the actor: one problem accumulating every network's K-segments, or - few rows
+  // (a handful of workgroups would walk all segments serially), or many rows with critics the weight-stationary kernel
+  // takes (wstat.h, plain dgrad form) - one problem per network into partials + a reduction
+  bool dstate_split = false;
   const float *noise_t = nullptr, *noise_a = nullptr;  // per-call (read by the policy stage lambdas)
   uint64_t seed = 0;
 
@@ -406,9 +410,9 @@ void carve(fdql_agent *a) {
   a->alloc("dpi", M * c.act_dim);
   a->alloc("dlogits", M * a->actor.dout);
   a->alloc("dstate", M * c.latent);
-  if (M <= DSTATE_SPLIT_MAX_ROWS) a->alloc("dstate.parts", (int64_t)(c.n_critics + 1) * M * c.latent);
+  if (a->dstate_split) a->alloc("dstate.parts", (int64_t)(c.n_critics + 1) * M * c.latent);
   a->alloc("denc", M * c.enc_features);
-  a->alloc("cs.dstate", ((M + 63) / 64) * c.latent);
+  a->alloc("cs.dstate", ((M + 31) / 32) * c.latent);   // per 64 rows (one-problem d state) or per 32 rows (sum of shares)
   a->alloc("cs.denc", ((M + 63) / 64) * c.enc_features);
   a->alloc("dpi_part", (int64_t)c.n_critics * M * c.act_dim);
   a->alloc("loss_partials", (int64_t)loss_blocks((int)M, 256) * LOSS_NPART + (int64_t)M * LOSS_NPART + LOSS_NPART);
@@ -558,7 +562,7 @@ struct Builder {
   // gradient is a K-split GEMM (the narrow ones on the 128x32 / 32x128 tiles); bias gradients
   // come from the per-tile column sums the dgrad GEMMs leave behind (dy_cs / dpre_cs), or
   // directly from dY when dY is narrow (dz, d logits).
-  void wgrads(const MlpInst &m, const float *dY, int lddy, const float *dy_cs, Stage &gs, Stage &narrow, Stage &ws) {
+  void wgrads(const MlpInst &m, const float *dY, int lddy, const float *dy_cs, Stage &gs, Stage &narrow, Stage &ws, int dy_cs_rows = 0) {
     const MlpDesc &d = *m.d;
     float *slab = a->buf("slabs");
     const long long P = a->n_train;
@@ -584,7 +588,7 @@ struct Builder {
     int col = 0;
     for (const SegIn &s : m.in) { gemm_w(dY, lddy, d.dout, s.ptr, s.ld, s.width, dst + col, ld); col += s.width; }
     for (size_t i = 0; i < d.hid.size(); ++i) { gemm_w(dY, lddy, d.dout, m.h[i], d.hid[i], d.hid[i], dst + col, ld); col += d.hid[i]; }
-    bias_w(dY, lddy, d.dout, dy_cs, slab + d.hb_off);
+    bias_w(dY, lddy, d.dout, dy_cs, slab + d.hb_off, dy_cs_rows);
   }
 };
 
@@ -820,7 +824,11 @@ int upload_tables(fdql_agent *a) {
           std::vector<size_t> idx;
           for (size_t j = i; j < s.gemm.size(); ++j) {
             const GemmProblem &p = s.gemm[j], &q = s.gemm[i];
-            if (!taken[j] && p.nseg == q.nseg && p.emit_seg == q.emit_seg && p.epi == q.epi && (p.C2 != nullptr) == (q.C2 != nullptr)) {
+            bool like = !taken[j] && p.nseg == q.nseg && p.emit_seg == q.emit_seg && p.epi == q.epi && (p.C2 != nullptr) == (q.C2 != nullptr);
+            for (int sg = 0; like && sg < p.nseg; ++sg)
+              like = p.seg[sg].K == q.seg[sg].K && p.seg[sg].lda == q.seg[sg].lda && p.seg[sg].ldb == q.seg[sg].ldb &&
+                     p.seg[sg].a_kc == q.seg[sg].a_kc && p.seg[sg].b_kc == q.seg[sg].b_kc;
+            if (like) {
               grp.push_back(p);
               idx.push_back(j);
             }
@@ -1349,9 +1357,10 @@ int build_plan(fdql_agent *a) {
   // ---- d state = sum over online critics and the actor
   {
     Stage &gs = b.gemm_stage("dstate");
-    if (M <= DSTATE_SPLIT_MAX_ROWS) {
+    if (a->dstate_split) {
       float *parts = a->buf("dstate.parts");
       const long long ML = (long long)M * L;
+      gs.try_rows = true;   // the critics' shares: weight-stationary plain dgrad form when there are enough rows
       for (int k = 0; k <= C; ++k) {
         GemmProblem p = Builder::new_gemm(M, L, parts + k * ML, L);
         if (k < C) b.input_grad_segs(co[k], a->buf("dz") + k * Q, Nq, 0, p);
@@ -1368,14 +1377,21 @@ int build_plan(fdql_agent *a) {
     hosts.push_back(a->stages.size() - 1);
   }
   const size_t idx_dstate = a->stages.size() - 1;
-  if (M <= DSTATE_SPLIT_MAX_ROWS) {
+  if (a->dstate_split) {
     const float *parts = a->buf("dstate.parts");
     float *dsum = a->buf("dstate");
     const long long ML = (long long)M * L;
     const int np = C + 1;
-    b.func_stage("dstate.sum", [=](hipStream_t s) { return reduce_partials_launch(parts, np, ML, dsum, s); });
+    if (L % 4 == 0) {   // the sum also leaves the column sums the joiner head's bias gradient is reduced from
+      float *csd = a->buf("cs.dstate");
+      b.func_stage("dstate.sum", [=](hipStream_t s) { return sum_parts_colsum_launch(parts, np, M, L, dsum, csd, s); });
+    } else {
+      b.func_stage("dstate.sum", [=](hipStream_t s) { return reduce_partials_launch(parts, np, ML, dsum, s); });
+    }
   }
-  const float *cs_dstate = M <= DSTATE_SPLIT_MAX_ROWS ? nullptr : a->buf("cs.dstate");   // bias sums straight from d state
+  // column sums of d state: per 64 rows from the one-problem GEMM, per 32 rows from the sum of shares, else straight from d state
+  const float *cs_dstate = (a->dstate_split && L % 4) ? nullptr : a->buf("cs.dstate");
+  const int cs_dstate_rows = a->dstate_split ? (M + 31) / 32 : 0;
   // ---- encoder backward over the M rows that carry gradient (next-only rows get none)
   MlpInst jb = jo, eb = eo;
   jb.rows = M; eb.rows = M;
@@ -1469,7 +1485,7 @@ int build_plan(fdql_agent *a) {
     b.wgrads(ao, a->buf("dlogits"), a->actor.dout, nullptr, a->stages[idx_dstate], tail, ws);
     // joiner: needs d state and its dpre -> the d enc launch; encoder MLP: needs d enc and its dpre -> the tail
     if (!gru) {
-      b.wgrads(jb, a->buf("dstate"), L, cs_dstate, a->stages[idx_denc], tail, ws);
+      b.wgrads(jb, a->buf("dstate"), L, cs_dstate, a->stages[idx_denc], tail, ws, cs_dstate_rows);
     } else {   // GRU weights: dW_hh = d gh^T h_prev, dW_ih = d gi^T e, biases = column sums (all over the M rows)
       const int L3 = 3 * L, F = c.enc_features;
       float *slab = a->buf("slabs");
@@ -1734,6 +1750,14 @@ int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {
     if (v >= 1 && v <= 64) a->nsplit = v;
   }
   layout(a);
+  {
+    const char *we = getenv("FDQL_WSTAT");
+    bool ws_ok = !(we && (we[0] == '0' || !strcmp(we, "fwd"))) && getenv("FDQL_NO_DSTATE_SPLIT") == nullptr;
+    for (const MlpDesc &d : a->critic) ws_ok = ws_ok && !d.hid.empty() && d.hid[0] == WS_N;
+    ws_ok = ws_ok && c.latent == WS_N && a->M % WS_BM == 0 && c.n_critics <= WS_MAX_INST && c.n_quantiles <= 8 &&
+            (long long)c.n_critics * (a->M / RG_BM) >= a->rows_min_tiles;
+    a->dstate_split = a->M <= DSTATE_SPLIT_MAX_ROWS || ws_ok;
+  }
   // (The output-stationary weight-gradient launch (wgrad.h) writes ncu / blocks slabs per block - 17 at config 2 - and clears
   // the others.  Sizing the K-split to that count was measured: the slab sum drops 0.037 -> 0.024 ms, but the narrow
   // HBM-bound weight gradients, which share the split, lose their parallelism: 0.106 -> 0.142 ms.  The split stays.)

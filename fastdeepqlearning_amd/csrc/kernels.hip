@@ -1069,6 +1069,39 @@ hipError_t reduce_partials_batched_launch(const float *part, int ninst, int npar
   hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n + 63) / 64), ninst), dim3(256), 0, s, part, nparts, n, dst);
   return hipGetLastError();
 }
+// dst[rows, cols] = sum over nparts partials of the same shape, + column sums of dst per 32-row block (cs [ceil(rows/32), cols]):
+// the sum of the per-network shares of an input gradient, and the bias-gradient partials of the layer that produced its input.
+// One workgroup per 32-row block: thread -> (row phase t / 64, float4 column group t % 64 + 64 j).  cols % 4 == 0.
+typedef float rp_v4f __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_sum_parts_colsum(const float *__restrict__ part, int nparts, int rows, int cols,
+                                                          float *__restrict__ dst, float *__restrict__ cs) {
+  __shared__ rp_v4f red[4][64];
+  const int g = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int r0 = blockIdx.x * 32;
+  const long long n = (long long)rows * cols;
+  for (int c4 = g; c4 * 4 < cols; c4 += 64) {
+    rp_v4f colsum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int i = 0; i < 8; ++i) {
+      const int r = r0 + ph + 4 * i;
+      if (r < rows) {
+        const long long e = (long long)r * cols + 4 * c4;
+        rp_v4f v = *reinterpret_cast<const rp_v4f *>(part + e);
+        for (int p = 1; p < nparts; ++p) v += *reinterpret_cast<const rp_v4f *>(part + (long long)p * n + e);
+        *reinterpret_cast<rp_v4f *>(dst + e) = v;
+        colsum += v;
+      }
+    }
+    red[ph][g] = colsum;
+    __syncthreads();
+    if (ph == 0) *reinterpret_cast<rp_v4f *>(cs + (long long)blockIdx.x * cols + 4 * c4) = (red[0][g] + red[1][g]) + (red[2][g] + red[3][g]);
+    __syncthreads();
+  }
+}
+hipError_t sum_parts_colsum_launch(const float *part, int nparts, int rows, int cols, float *dst, float *cs, hipStream_t s) {
+  hipLaunchKernelGGL(k_sum_parts_colsum, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, s, part, nparts, rows, cols, dst, cs);
+  return hipGetLastError();
+}
 hipError_t reduce_partials_launch(const float *part, int nparts, long long n, float *dst, hipStream_t s) {
   hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, part, nparts, n, dst);
   return hipGetLastError();

@@ -131,6 +131,8 @@ constexpr int COLSUM_TALL_ROWS = 1024;
 inline int colsum_tall_blocks(long long R) { return (int)((R + COLSUM_TALL_ROWS - 1) / COLSUM_TALL_ROWS); }
 hipError_t colsum_tall_launch(const float *X, long long R, int C, int ld, float *partial, hipStream_t s);
 // dst[e] = sum_p part[p][e] for e < n (fixed order)
+// dst[rows, cols] = sum of nparts partials + per-32-row column sums cs [ceil(rows / 32), cols]  (cols % 4 == 0)
+hipError_t sum_parts_colsum_launch(const float *part, int nparts, int rows, int cols, float *dst, float *cs, hipStream_t s);
 hipError_t reduce_partials_launch(const float *part, int nparts, long long n, float *dst, hipStream_t s);
 // the same for `ninst` independent instances laid out back to back: part [ninst][nparts][n] -> dst [ninst][n]
 hipError_t reduce_partials_batched_launch(const float *part, int ninst, int nparts, long long n, float *dst, hipStream_t s);

@@ -35,7 +35,8 @@ struct WsArgs {
   int lda[1 + WS_MAX_MINOR], ldw[1 + WS_MAX_MINOR];
   int dual;                  // 1: C = f(all segments but the last), C2 = f(all)
   int hf_q, hf_ldw;          // head fusion: outputs per row (2), 0 = off
-  int grad;                  // 1: dgrad form - weights K-strided (element (k, n) at W[k*ldw + n]), x *= LeakyReLU'(ref), column sums
+  int grad;                  // dgrad forms - weights K-strided (element (k, n) at W[k*ldw + n]): 1: x *= LeakyReLU'(ref), column sums;
+                             // 2: plain (no gate, no sums: one network's share of an input gradient)
   int fz, fz_ldw;            // dgrad form: A0 formed from (fz_h, dY = A1, fz_w) while it is staged
   int wg_first[WS_MAX_INST + 1];   // workgroups [wg_first[i], wg_first[i+1]) serve instance i (block j, j + n, ... of it)
   WsInst inst[WS_MAX_INST];

@@ -455,8 +455,11 @@ __device__ __forceinline__ float ws_sum32(float x) {   // sum over the 32 lanes 
   return x;
 }
 
-template <bool FUSE>
+// PLAIN: no gate and no column sums (C = A0 W0 + dY W1: one network's share of an input gradient that several networks add up
+// to, e.g. d state of the critics), K-strided weights of any row pitch.
+template <bool FUSE, bool PLAIN = false>
 __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
+  static_assert(!(FUSE && PLAIN), "the fused head dgrad belongs to a gated layer");
   extern __shared__ __attribute__((aligned(16))) float lds[];   // two images [32][P]
   constexpr int NMINOR = 1;
   constexpr int P = WS_KMAIN + 8 * NMINOR + 4, IMG = WS_BM * P;
@@ -474,21 +477,22 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
   const WsInst &I = a.inst[inst];
   const float *A0 = ws_uni(FUSE ? I.fz_h : I.A[0]);
   const float *A1 = ws_uni(I.A[1]);
-  const float *ref = ws_uni(I.ref);
+  const float *ref = PLAIN ? nullptr : ws_uni(I.ref);
   float *const C = ws_uni(I.C), *const fz_out = ws_uni(I.fz_out);
   const int lda0 = FUSE ? LD : a.lda[0], lda1 = a.lda[1];
 
   // ---- stationary weights, K-strided: wb[tn][s][c] = W0[32 (s / 4) + 16 lh + 4 (s % 4) + c][n0 + 32 tn + li]
   v4f wb[2][NSTEP];
   {
-    // (row pitch LD of the K-strided weights is compile-time: every load is base + lane offset + immediate)
-    gcf W0 = (gcf)ws_uni(I.W[0]) + (16 * lh * LD + n0 + li);
+    // (gated form: the row pitch LD of the K-strided weights is compile-time - every load is base + lane offset + immediate)
+    const int ldw0 = PLAIN ? a.ldw[0] : LD;
+    gcf W0 = (gcf)ws_uni(I.W[0]) + (16 * lh * ldw0 + n0 + li);
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
       for (int s = 0; s < NSTEP; ++s)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) wb[tn][s][c] = W0[(32 * (s >> 2) + 4 * (s & 3) + c) * LD + 32 * tn];
+        for (int c = 0; c < 4; ++c) wb[tn][s][c] = W0[(32 * (s >> 2) + 4 * (s & 3) + c) * ldw0 + 32 * tn];
   }
   v4f wn[2];
   {
@@ -550,6 +554,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
     return t;
   };
   auto ref_load = [&](v4f &dst, int blkid, int kq) __attribute__((always_inline)) {
+    if constexpr (PLAIN) return;
     const int tn = (kq >> 2) & 1, q = kq & 3;
     gcf base = ws_uni((gcf)ref + (long long)blkid * WS_BM * LD + n0 + 32 * tn + 8 * q);
     dst = *(gcf4)(&base[vo_c]);
@@ -560,9 +565,13 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const float v = pv[tn][4 * q + c];
-      const float y = rq[kq & 1][c] > 0.f ? v : 0.01f * v;
-      cs[tn][4 * q + c] += y;
-      x[c] = y;
+      if constexpr (PLAIN) {
+        x[c] = v;
+      } else {
+        const float y = rq[kq & 1][c] > 0.f ? v : 0.01f * v;
+        cs[tn][4 * q + c] += y;
+        x[c] = y;
+      }
     }
     gf base = ws_uni((gf)C + (long long)pblk * WS_BM * LD + n0 + 32 * tn + 8 * q);
     *(gf4)(&base[vo_c]) = x;
@@ -683,7 +692,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
   if (set == 1) flush(acc[0]);
   else flush(acc[1]);
   // ---- the workgroup's partial rows of the column sums
-  {
+  if constexpr (!PLAIN) {
     gf colsum = (gf)ws_uni(I.colsum) + (long long)j0 * WS_N;
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn)
@@ -725,13 +734,18 @@ bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
   const GemmProblem &p0 = probs[ref_i];
   const int main0 = main_of(p0);
   if (main0 < 0 || p0.N != WS_N || p0.M % WS_BM || p0.M < WS_BM || p0.ksplit != 1 || p0.ldc != WS_N) return false;
-  const bool grad = p0.epi == EPI_LRELU_GRAD;
-  if (!grad && p0.epi != EPI_LRELU) return false;
+  // dgrad forms: K-strided weights; gated (EPI_LRELU_GRAD: a hidden layer's pre-activation gradient) or plain (EPI_NONE: a
+  // network's share of an input gradient)
+  const bool grad = !p0.seg[main0].b_kc;
+  const bool plain = grad && p0.epi == EPI_NONE;
+  if (grad ? (p0.epi != EPI_LRELU_GRAD && !plain) : p0.epi != EPI_LRELU) return false;
   if (grad && env && !strcmp(env, "fwd")) return false;
   const int nminor = p0.nseg - 1;
   if (nminor > WS_MAX_MINOR) return false;
   const bool fz = p0.fz_h != nullptr;
-  if (grad) {
+  if (plain) {
+    if (p0.bias || p0.ref || p0.colsum || p0.hf_w || dual || nminor != 1 || fz) return false;
+  } else if (grad) {
     if (p0.bias || !p0.ref || p0.ldref != WS_N || !p0.colsum || p0.hf_w || dual || nminor != 1) return false;
     if (p0.seg[main0].ldb != WS_N) return false;   // K-strided weights: compile-time row pitch
     if (fz && (p0.seg[1 - main0].K != 2 || p0.seg[1 - main0].lda % 2)) return false;   // dY rows read as float2
@@ -741,7 +755,7 @@ bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
     if (p0.hf_w && p0.hf_q != 2) return false;
   }
   args.M = p0.M; args.ninst = nprob; args.blocks_per_inst = p0.M / WS_BM;
-  args.nminor = nminor; args.dual = dual; args.grad = grad; args.fz = fz; args.fz_ldw = p0.fz_ldw;
+  args.nminor = nminor; args.dual = dual; args.grad = grad ? (plain ? 2 : 1) : 0; args.fz = fz; args.fz_ldw = p0.fz_ldw;
   args.hf_q = p0.hf_w ? p0.hf_q : 0; args.hf_ldw = p0.hf_ldw;
   int cost[WS_MAX_INST], cost_sum = 0;
   for (int i = 0; i < nprob; ++i) {
@@ -809,7 +823,7 @@ bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
     if (per < 1) per = 1;
     if (per > args.blocks_per_inst) per = args.blocks_per_inst;
     // the dgrad form's column sums: one partial row per workgroup in buffers sized for one per 64 rows
-    if (grad && per > (p0.M + 63) / 64) per = (p0.M + 63) / 64;
+    if (grad && !plain && per > (p0.M + 63) / 64) per = (p0.M + 63) / 64;
     args.wg_first[i + 1] = args.wg_first[i] + per;
   }
   return true;
@@ -856,15 +870,16 @@ static hipError_t ws_launch(const WsArgs &a, hipStream_t s) {
   constexpr int lds_bytes = (2 * WS_BM * (WS_KMAIN + 8 * NMINOR + 4) + 4 * 2 * 32 + 4 * 8 * 32) * 4;   // two images + per-wave constants
   return ws_launch_kernel(&k_wstat<NMINOR, DUAL, HFQ>, lds_bytes, attr, a, s);
 }
-template <bool FUSE>
+template <bool FUSE, bool PLAIN>
 static hipError_t ws_launch_grad(const WsArgs &a, hipStream_t s) {
   static bool attr[64];
   constexpr int lds_bytes = 2 * WS_BM * (WS_KMAIN + 8 + 4) * 4;
-  return ws_launch_kernel(&k_wstat_grad<FUSE>, lds_bytes, attr, a, s);
+  return ws_launch_kernel(&k_wstat_grad<FUSE, PLAIN>, lds_bytes, attr, a, s);
 }
 
 hipError_t wstat_launch(const WsArgs &a, hipStream_t s) {
-  if (a.grad) return a.fz ? ws_launch_grad<true>(a, s) : ws_launch_grad<false>(a, s);
+  if (a.grad == 2) return ws_launch_grad<false, true>(a, s);
+  if (a.grad) return a.fz ? ws_launch_grad<true, false>(a, s) : ws_launch_grad<false, false>(a, s);
   if (a.dual) return a.hf_q ? ws_launch<2, true, 2>(a, s) : ws_launch<2, true, 0>(a, s);
   if (a.nminor == 0) return a.hf_q ? ws_launch<0, false, 2>(a, s) : ws_launch<0, false, 0>(a, s);
   if (a.nminor == 1) return a.hf_q ? ws_launch<1, false, 2>(a, s) : ws_launch<1, false, 0>(a, s);
