@@ -317,6 +317,22 @@ def secondary(name, dev, steps=200, warmup=10, **kw):
     return out
 
 
+def config4_per_rank(dev, full_ms):
+    """What ONE rank of the N-GPU job computes per step (config 4, global B = 1024 split B/N), measured on this one GPU
+    without the collective: a compute-only bound on the strong-scaling curve (speed-up <= t(B) / t(B/N))."""
+    w = WORKLOADS["config4"]
+    out = {"what": "config 4 per-rank batch on one GPU, no all-reduce: ms/step and the compute-only bound on the N-GPU speed-up",
+           "B1024_ms": round(full_ms, 4)}
+    for n in (2, 4, 8):
+        job = Job(w, dev, w["B"] // n, w["T"], ring_slots=200_000)
+        med, rates, max_ms = job.timed_windows(100, 10)
+        out[f"N{n}_B{w['B'] // n}_ms"] = round(1e3 / med, 4)
+        out[f"N{n}_speedup_bound"] = round(full_ms / (1e3 / med), 2)
+        del job
+        torch.cuda.empty_cache()
+    return out
+
+
 def config3_her_ingest(dev, episodes=400):
     """Config 3's write path: episodes of 50 through fdql_ring_append_episode with the hindsight copy and the n-step
     return computed on the device (her.py:55-95, nstep_return.py:36-72); records/s including the host packing."""
@@ -512,6 +528,11 @@ def bench_single(args, dev, T):
             except Exception as e:   # noqa: BLE001 - a secondary figure must never take the headline line down
                 extras[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
             torch.cuda.empty_cache()
+        try:
+            if "ms_per_step" in extras.get("config4_1gpu_B1024", {}):
+                extras["config4_per_rank"] = config4_per_rank(dev, extras["config4_1gpu_B1024"]["ms_per_step"])
+        except Exception as e:   # noqa: BLE001
+            extras["config4_per_rank"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     cpu = None if args.no_cpu_baseline else cpu_baseline(w, T, B)
     return {
         "metric": "gradient-steps/sec", "value": round(args.steps / el, 2), "unit": "steps/s", "n_gpus": 1,
@@ -548,32 +569,41 @@ def bench_distributed(args, dev, T, rank, world, backend, dist, nat):
     agent, grads = job.agent, job.agent.grads
     side = torch.cuda.Stream(dev)
     main_stream = torch.cuda.current_stream(dev)
-    ev_grad, ev_red = torch.cuda.Event(), torch.cuda.Event()
+    ev_a, ev_b, ev_red = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+    bucket = agent.grad_bucket()      # grads[bucket:] = critics + log_alpha, final after PHASE_GRAD_CRITICS
+
+    def all_reduce(g):
+        if backend == "nccl":
+            dist.all_reduce(g)                       # RCCL sum over xGMI; the row weights already carry 1/B_global
+        else:
+            h = g.cpu()
+            dist.all_reduce(h)
+            g.copy_(h)
 
     def step(i):
+        # two buckets: the critics' gradients are all-reduced on the side stream while the actor / encoder backward runs
         job.ring.sample_windows(T, job.B, seed=job.seed, counter=i, outs=job.outs)
-        agent.update(job.xp, seed=job.seed, phase=nat.PHASE_GRAD)
-        # the all-reduce runs on its own stream: the arena is complete only when the slab reduction at the end of
-        # PHASE_GRAD has run, so what it can overlap with is host-side launch work of the apply phase, not the backward
-        ev_grad.record(main_stream)
+        agent.update(job.xp, seed=job.seed, phase=nat.PHASE_GRAD_CRITICS)
+        ev_a.record(main_stream)
         with torch.cuda.stream(side):
-            side.wait_event(ev_grad)
-            if backend == "nccl":
-                dist.all_reduce(grads)                   # RCCL sum over xGMI; the row weights already carry 1/B_global
-            else:
-                g = grads.cpu()
-                dist.all_reduce(g)
-                grads.copy_(g)
+            side.wait_event(ev_a)
+            all_reduce(grads[bucket:])
+        agent.update(None, phase=nat.PHASE_GRAD_REST)
+        ev_b.record(main_stream)
+        with torch.cuda.stream(side):
+            side.wait_event(ev_b)
+            all_reduce(grads[:bucket])
             ev_red.record(side)
         main_stream.wait_event(ev_red)
         agent.update(None, phase=nat.PHASE_APPLY)
 
     def sync():
-        dist.barrier()
-        torch.cuda.synchronize(dev)
+        torch.cuda.synchronize(dev)                  # (the collectives of the step are this rank's barrier)
 
     for i in range(args.warmup):
         step(i)
+    sync()
+    dist.barrier()                                   # ranks start the timed region together; none inside it
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):

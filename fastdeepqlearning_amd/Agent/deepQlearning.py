@@ -80,6 +80,7 @@ class DeepQLearning:
         self.replays = []
         self._seed = int(kwargs.get("seed", 0))
         self._last_xp = None
+        self._side, self._ev = None, None   # data-parallel: side stream + events of the bucketed all-reduce
         self._trainer = None
         self._stop_training = False
         self.trainer_error = None
@@ -140,18 +141,44 @@ class DeepQLearning:
     def _distributed(self):
         return int(getattr(self.conf, "world_size", 1) or 1) > 1
 
-    def _all_reduce_gradients(self):
-        """One all-reduce(sum) of the contiguous gradient arena: RCCL over xGMI when the process group is
-        nccl; with gloo (CPU rehearsals, tests) the arena is staged through the host.  The row weights of every rank's
+    def _all_reduce(self, g):
+        """all-reduce(sum) of a contiguous slice of the gradient arena: RCCL over xGMI when the process group
+        is nccl; with gloo (CPU rehearsals, tests) the slice is staged through the host.  The row weights of every rank's
         loss already carry 1 / (B_local * world_size), so the sum IS the global-batch gradient."""
         import torch.distributed as dist
-        g = self.native.grads
+        if g.numel() == 0:
+            return
         if dist.get_backend() == "nccl":
             dist.all_reduce(g)
         else:
             h = g.cpu()
             dist.all_reduce(h)
             g.copy_(h)
+
+    def _distributed_step(self, xp, nt, na):
+        """Two buckets: the critics' gradients (+ log_alpha: arena[b:], 2/3 of it at config 2) are final after
+        PHASE_GRAD_CRITICS and their all-reduce runs on a side stream beside the actor / encoder backward
+        (PHASE_GRAD_REST); the rest follows; Adam waits for both."""
+        nat = self.native
+        dev = nat.device
+        if self._side is None:
+            self._side = torch.cuda.Stream(dev)
+            self._ev = [torch.cuda.Event() for _ in range(3)]
+        main, side, (e_a, e_b, e_red) = torch.cuda.current_stream(dev), self._side, self._ev
+        b, g = nat.grad_bucket(), nat.grads
+        nat.update(xp, nt, na, seed=self._seed, phase=N.PHASE_GRAD_CRITICS)
+        e_a.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(e_a)
+            self._all_reduce(g[b:])
+        nat.update(None, phase=N.PHASE_GRAD_REST)
+        e_b.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(e_b)
+            self._all_reduce(g[:b])
+            e_red.record(side)
+        main.wait_event(e_red)
+        nat.update(None, phase=N.PHASE_APPLY)
 
     def train_step(self, noise=None):
         """deepQlearning.py:105-127: for every shard: sample -> loss -> backward -> Adam -> polyak.
@@ -162,9 +189,7 @@ class DeepQLearning:
             xp = replay.temporal_sample()
             self._last_xp = xp
             if self._distributed():
-                self.native.update(xp, nt, na, seed=self._seed, phase=N.PHASE_GRAD)
-                self._all_reduce_gradients()
-                self.native.update(None, phase=N.PHASE_APPLY)
+                self._distributed_step(xp, nt, na)
             else:
                 self.native.update(xp, nt, na, seed=self._seed, phase=N.PHASE_ALL)
             self.conf.train_step.value += 1

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FDQL_LIB_PATH") or os.path.join(_HERE, "libfdql_hip.so")
 
 FDQL_OK, FDQL_EINVAL, FDQL_EHIP, FDQL_EOVERSAMPLE, FDQL_ESTATE, FDQL_ENOMEM = 0, -1, -2, -3, -4, -5
-PHASE_ALL, PHASE_GRAD, PHASE_APPLY = 0, 1, 2
+PHASE_ALL, PHASE_GRAD, PHASE_APPLY, PHASE_GRAD_CRITICS, PHASE_GRAD_REST = 0, 1, 2, 3, 4
 MAX_HIDDEN = 4
 MAX_CONV = 3
 
@@ -116,6 +116,7 @@ SIGNATURES = {
     "fdql_agent_workspace_bytes": (_i64, [_vp]),
     "fdql_agent_bind": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64]),
     "fdql_agent_update": (C.c_int, [_vp, C.POINTER(Batch), _vp, _vp, _u64, _i32, _vp]),
+    "fdql_agent_grad_bucket": (C.c_int, [_vp, C.POINTER(_i64)]),
     "fdql_agent_scalars": (C.c_int, [_vp, C.POINTER(_f32), _vp]),
     "fdql_agent_set_alpha": (C.c_int, [_vp, _f32, _vp]),
     "fdql_agent_set_step": (C.c_int, [_vp, _i32, _vp]),

@@ -283,6 +283,13 @@ class NativeAgent:
             N.check(self.lib.fdql_agent_update(self.handle, C.byref(b), N.ptr(noise_target), N.ptr(noise_actor), seed,
                                                phase, N.current_stream(self.device)))
 
+    def grad_bucket(self):
+        """First float of the gradient arena's EARLY bucket: grads[b:] (critics + log_alpha) is final after
+        PHASE_GRAD_CRITICS, grads[:b] after PHASE_GRAD_REST; b == grads.numel() when the agent is not data-parallel."""
+        out = C.c_int64(0)
+        N.check(self.lib.fdql_agent_grad_bucket(self.handle, C.byref(out)))
+        return int(out.value)
+
     def profile_update(self, xp, noise_target=None, noise_actor=None, seed=0):
         b, keep = self._batch(xp)
         arr = (N.KernelTime * 256)()

@@ -126,10 +126,13 @@ struct Stage {
   int blocks = 0;
   double flops = 0, bytes = 0;
   int phase = FDQL_PHASE_GRAD;
+  int gpart = 1;  // FDQL_PHASE_GRAD stages of a bucketed plan: 0 = up to the critics' gradients (FDQL_PHASE_GRAD_CRITICS), 1 = the rest
   int when = 0;   // 0: whenever its phase runs; 1: only in a split (GRAD / APPLY) call; 2: only in a FDQL_PHASE_ALL call
   std::function<hipError_t(hipStream_t)> fn;
   bool runs_in(int call_phase) const {
     if (call_phase == FDQL_PHASE_ALL) return when != 1;
+    if (call_phase == FDQL_PHASE_GRAD_CRITICS || call_phase == FDQL_PHASE_GRAD_REST)
+      return phase == FDQL_PHASE_GRAD && when != 2 && gpart == (call_phase == FDQL_PHASE_GRAD_REST ? 1 : 0);
     return phase == call_phase && when != 2;
   }
 };
@@ -203,6 +206,10 @@ struct fdql_agent {
   // (a handful of workgroups would walk all segments serially), or many rows with critics the weight-stationary kernel
   // takes (wstat.h, plain dgrad form) - one problem per network into partials + a reduction
   bool dstate_split = false;
+  // Data-parallel plans (world_size > 1) finish the critics' gradients - and log_alpha's: arena range [grad_bucket, n_train) -
+  // right after the critics' backward (FDQL_PHASE_GRAD_CRITICS), so that their all-reduce runs beside the actor / encoder
+  // backward (FDQL_PHASE_GRAD_REST); n_train: the plan is not bucketed
+  int64_t grad_bucket = 0;
   const float *noise_t = nullptr, *noise_a = nullptr;  // per-call (read by the policy stage lambdas)
   uint64_t seed = 0;
 
@@ -427,6 +434,24 @@ struct Builder {
   // dense 256 x 256 weight-gradient blocks: candidates for the output-stationary launch (wgrad.h), each with the index of the
   // stage it rides in otherwise (-1: the tail stage)
   std::vector<std::pair<GemmProblem, int>> wg_cand;
+  // The candidates gathered so far become ONE output-stationary launch (stage `name`, appended) when there are enough row
+  // tiles for every workgroup to amortise its 256 KiB partial result; else they ride in their host stages / `fallback`.
+  void flush_wgrad_stat(const std::string &name, Stage &fallback) {
+    if (wg_cand.empty()) return;
+    std::vector<GemmProblem> probs;
+    for (auto &pc : wg_cand) probs.push_back(pc.first);
+    Stage wst;
+    wst.kind = ST_WGRAD_STAT; wst.name = name;
+    const long long tiles = (long long)probs.size() * (probs[0].seg[0].K / WG_BM);
+    if (tiles >= 8 * a->rows_min_tiles && wgrad_stat_from_problems(probs.data(), (int)probs.size(), a->nsplit, a->n_train, wst.wga)) {
+      wst.flops = wgrad_stat_flops(wst.wga);
+      wst.bytes = 8.0 * wst.wga.M * WG_N * wst.wga.ninst;
+      st.push_back(wst);
+    } else {
+      for (auto &pc : wg_cand) (pc.second >= 0 ? st[pc.second] : fallback).gemm.push_back(pc.first);
+    }
+    wg_cand.clear();
+  }
 
   Stage &gemm_stage(const std::string &name) {
     st.emplace_back();
@@ -1337,6 +1362,26 @@ int build_plan(fdql_agent *a) {
       }
     }
   }
+  // ---- data-parallel plans: the critics' weight gradients now, and their slab sum, so that the all-reduce of the arena
+  // range [crit_begin, n_train) (critics + log_alpha: 2/3 of the arena at config 2) can run beside everything below
+  const bool bucketed = c.world_size > 1 && getenv("FDQL_NO_BUCKETS") == nullptr;
+  a->grad_bucket = bucketed ? a->crit_begin : a->n_train;
+  size_t first_rest_stage = 0;
+  if (bucketed) {
+    Stage cn, cws;
+    cn.kind = ST_GEMM; cn.name = "wgrad.critics.narrow";
+    cws.kind = ST_SKINNY_WGRAD; cws.name = "colsums.critics";
+    for (int k = 0; k < C; ++k) b.wgrads(co[k], a->buf("dz") + k * Q, Nq, nullptr, cn, cn, cws);
+    b.flush_wgrad_stat("wgrad.critics", cn);
+    a->stages.push_back(cn);
+    a->stages.push_back(cws);
+    const float *slabs = a->buf("slabs");
+    float *grads = a->grads;
+    const int S = a->nsplit;
+    const long long P = a->n_train, first = a->crit_begin;
+    b.func_stage("reduce_slabs.critics", [=](hipStream_t s) { return reduce_slabs_range_launch(slabs, S, P, first, P - first, grads, s); }).when = 1;
+    first_rest_stage = a->stages.size();
+  }
   // ---- policy backward
   {
     const float *lo = ao.out, *nz = a->buf("noise_actor"), *pi = a->buf("pi"), *dpi = a->buf("dpi_part"), *w = a->buf("w");
@@ -1480,7 +1525,8 @@ int build_plan(fdql_agent *a) {
     tail.kind = ST_GEMM; tail.name = "wgrad.enc";
     ws.kind = ST_SKINNY_WGRAD; ws.name = "colsums";
     // critics: spread over the dgrad launches that follow their backward (they are ready by then)
-    for (int k = 0; k < C; ++k) b.wgrads(co[k], a->buf("dz") + k * Q, Nq, nullptr, a->stages[hosts[k % hosts.size()]], tail, ws);
+    if (!bucketed)
+      for (int k = 0; k < C; ++k) b.wgrads(co[k], a->buf("dz") + k * Q, Nq, nullptr, a->stages[hosts[k % hosts.size()]], tail, ws);
     // actor: needs d logits / its dpre -> from the d state launch on
     b.wgrads(ao, a->buf("dlogits"), a->actor.dout, nullptr, a->stages[idx_dstate], tail, ws);
     // joiner: needs d state and its dpre -> the d enc launch; encoder MLP: needs d enc and its dpre -> the tail
@@ -1524,22 +1570,7 @@ int build_plan(fdql_agent *a) {
         return e;
       });
     }
-    // The dense 256 x 256 blocks: one output-stationary launch (wgrad.hip) when there are enough row tiles for every
-    // workgroup to amortise its 256 KiB partial result; else they ride in the dgrad launches / the tail as before.
-    if (!b.wg_cand.empty()) {
-      std::vector<GemmProblem> probs;
-      for (auto &pc : b.wg_cand) probs.push_back(pc.first);
-      Stage wst;
-      wst.kind = ST_WGRAD_STAT; wst.name = "wgrad.dense";
-      const long long tiles = (long long)probs.size() * (probs[0].seg[0].K / WG_BM);
-      if (tiles >= 8 * a->rows_min_tiles && wgrad_stat_from_problems(probs.data(), (int)probs.size(), a->nsplit, a->n_train, wst.wga)) {
-        wst.flops = wgrad_stat_flops(wst.wga);
-        wst.bytes = 8.0 * wst.wga.M * WG_N * wst.wga.ninst;
-        a->stages.push_back(wst);
-      } else {
-        for (auto &pc : b.wg_cand) (pc.second >= 0 ? a->stages[pc.second] : tail).gemm.push_back(pc.first);
-      }
-    }
+    b.flush_wgrad_stat("wgrad.dense", tail);
     a->stages.push_back(tail);
     a->stages.push_back(ws);
     if (!conv_post.empty())
@@ -1555,7 +1586,8 @@ int build_plan(fdql_agent *a) {
     const long long P = a->n_train;
     // a split call (data-parallel: the all-reduce sits between the phases) sums the slabs into grads here; the
     // single-process step forms the sum inside k_adam_polyak
-    b.func_stage("reduce_slabs", [=](hipStream_t s) { return reduce_slabs_launch(slabs, S, P, grads, s); }).when = 1;
+    const long long count = a->grad_bucket;   // a bucketed plan has summed [grad_bucket, P) already
+    b.func_stage("reduce_slabs", [=](hipStream_t s) { return reduce_slabs_range_launch(slabs, S, P, 0, count, grads, s); }).when = 1;
   }
   // ---- Adam + polyak (+ frozen copy)
   {
@@ -1572,6 +1604,7 @@ int build_plan(fdql_agent *a) {
     af.slabs = a->buf("slabs"); af.nslab = a->nsplit; af.grads_out = a->grads;
     b.func_stage("adam_polyak", [=](hipStream_t s) { return adam_launch(af, s); }, FDQL_PHASE_APPLY).when = 2;
   }
+  for (size_t i = 0; i < a->stages.size(); ++i) a->stages[i].gpart = (bucketed && i < first_rest_stage) ? 0 : 1;
   int rc = upload_tables(a);
   if (rc) return rc;
   a->plan_ready = true;
@@ -1836,11 +1869,12 @@ int fdql_agent_update(fdql_agent_t *a, const fdql_batch_t *batch, const float *n
                       uint64_t seed, int32_t phase, void *stream) {
   if (!a) { set_error("null agent"); return FDQL_EINVAL; }
   std::lock_guard<std::mutex> lk(a->mu);
-  if (phase != FDQL_PHASE_APPLY) {
+  if (phase < FDQL_PHASE_ALL || phase > FDQL_PHASE_GRAD_REST) { set_error("unknown phase %d", (int)phase); return FDQL_EINVAL; }
+  if (phase != FDQL_PHASE_APPLY && phase != FDQL_PHASE_GRAD_REST) {
     int rc = prepare_update(a, batch, noise_target, noise_actor, seed);
     if (rc) return rc;
   } else if (!a->plan_ready) {
-    set_error("FDQL_PHASE_APPLY before any FDQL_PHASE_GRAD");
+    set_error("FDQL_PHASE_APPLY / FDQL_PHASE_GRAD_REST before the phase that starts the step");
     return FDQL_ESTATE;
   }
   hipStream_t s = (hipStream_t)stream;
@@ -1866,6 +1900,13 @@ int fdql_agent_update(fdql_agent_t *a, const fdql_batch_t *batch, const float *n
     hipError_t e = run_stage(a, st, s);
     if (e != hipSuccess) { set_error("stage %s: %s", st.name.c_str(), hipGetErrorString(e)); return FDQL_EHIP; }
   }
+  return 0;
+}
+
+int fdql_agent_grad_bucket(fdql_agent_t *a, int64_t *first_early_float) {
+  FDQL_REQUIRE(a && first_early_float, "null argument");
+  std::lock_guard<std::mutex> lk(a->mu);
+  *first_early_float = (a->cfg.world_size > 1 && getenv("FDQL_NO_BUCKETS") == nullptr) ? a->crit_begin : a->n_train;
   return 0;
 }
 

@@ -675,22 +675,28 @@ hipError_t loss_finish_launch(const float *partials, int nblocks, int M, int Nq,
 // ======================================================================================
 // Slab reduction, Adam + polyak (+ critic_frozen copy)
 // ======================================================================================
-__global__ void k_reduce_slabs(const float4 *__restrict__ slabs, int nslab, long long n4, float4 *__restrict__ grads) {
+__global__ void k_reduce_slabs(const float4 *__restrict__ slabs, int nslab, long long n4, long long stride4, float4 *__restrict__ grads) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
   float4 s = slabs[i];
   for (int k = 1; k < nslab; ++k) {
-    const float4 v = slabs[(long long)k * n4 + i];
+    const float4 v = slabs[(long long)k * stride4 + i];
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
   grads[i] = s;
 }
 
 hipError_t reduce_slabs_launch(const float *slabs, int nslab, long long n, float *grads, hipStream_t s) {
-  const long long n4 = n / 4;
+  return reduce_slabs_range_launch(slabs, nslab, n, 0, n, grads, s);
+}
+// the sub-range [first, first + count) of the arena (both multiples of 4): slabs of `stride` floats each
+hipError_t reduce_slabs_range_launch(const float *slabs, int nslab, long long stride, long long first, long long count, float *grads,
+                                     hipStream_t s) {
+  const long long n4 = count / 4;
+  if (n4 <= 0) return hipSuccess;
   const int blocks = (int)((n4 + 255) / 256);
-  hipLaunchKernelGGL(k_reduce_slabs, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4 *>(slabs), nslab, n4,
-                     reinterpret_cast<float4 *>(grads));
+  hipLaunchKernelGGL(k_reduce_slabs, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4 *>(slabs + first), nslab, n4,
+                     stride / 4, reinterpret_cast<float4 *>(grads + first));
   return hipGetLastError();
 }
 

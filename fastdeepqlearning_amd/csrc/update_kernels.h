@@ -108,6 +108,8 @@ struct BootArgs {
 hipError_t boot_lowerbound_launch(const BootArgs &a, hipStream_t s);
 hipError_t loss_finish_launch(const float *partials, int nblocks, int M, int Nq, DevState *st, float *scalars,
                               float *dlog_alpha, double lr, double b1, double b2, hipStream_t s);
+hipError_t reduce_slabs_range_launch(const float *slabs, int nslab, long long stride, long long first, long long count, float *grads,
+                                     hipStream_t s);
 hipError_t reduce_slabs_launch(const float *slabs, int nslab, long long n, float *grads, hipStream_t s);
 hipError_t adam_launch(const AdamArgs &a, hipStream_t s);
 hipError_t prep_launch(const float *task_done, const float *episode_step, int T, int B, int burn_in, int cumprod,

@@ -280,6 +280,13 @@ typedef struct {
 #define FDQL_PHASE_ALL 0   /* loss + backward + Adam + polyak                               */
 #define FDQL_PHASE_GRAD 1  /* ... up to the gradient arena (then all-reduce it)             */
 #define FDQL_PHASE_APPLY 2 /* Adam + polyak from the gradient arena                          */
+/* Data-parallel agents (world_size > 1) can take FDQL_PHASE_GRAD in two parts, so that the all-reduce of the first bucket
+ * runs beside the second part (the reference averages nothing: one process, deepQlearning.py:105-127):
+ *   FDQL_PHASE_GRAD_CRITICS: ... up to the critics' (and log_alpha's) gradients - arena floats [bucket, n) are final;
+ *   FDQL_PHASE_GRAD_REST (batch = NULL): the actor / encoder backward - arena floats [0, bucket) are final.
+ * FDQL_PHASE_GRAD = both.  bucket: fdql_agent_grad_bucket (= n when the agent was created with world_size 1: nothing early). */
+#define FDQL_PHASE_GRAD_CRITICS 3
+#define FDQL_PHASE_GRAD_REST 4
 
 /* train_step() for one shard.  noise_target / noise_actor: the draws the reference takes
  * from torch's global RNG in that order (gaussian_mlp.py:31 / ExpRelaxedCategorical):
@@ -287,6 +294,8 @@ typedef struct {
  * device with Philox(seed, step).  No host synchronisation.                              */
 int fdql_agent_update(fdql_agent_t *agent, const fdql_batch_t *batch, const float *noise_target,
                       const float *noise_actor, uint64_t seed, int32_t phase, void *stream);
+
+int fdql_agent_grad_bucket(fdql_agent_t *agent, int64_t *first_early_float);
 
 /* Scalars of the last update (device -> host copy; synchronises `stream`):
  * [0] loss (deepQlearning.py:249)  [1] mean q_loss  [2] mean pi_loss  [3] mean alpha_loss

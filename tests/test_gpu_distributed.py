@@ -87,12 +87,19 @@ def _rank_main(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_process_data_parallel_train_step(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_multi_process_data_parallel_train_step(tmp_path, world):
+    """world ranks (fresh processes, gloo, all on cuda:0) through the facade's bucketed step: PHASE_GRAD_CRITICS, all-reduce
+    of arena[bucket:] on a side stream beside PHASE_GRAD_REST, all-reduce of arena[:bucket], PHASE_APPLY."""
     import torch.multiprocessing as mp
     assert torch.cuda.is_available()
-    world, port = 2, 29500 + (os.getpid() % 400)
+    port = 29500 + (os.getpid() % 400) + world
     mp.spawn(_rank_main, args=(world, port, str(tmp_path)), nprocs=world, join=True)
-    r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in range(world))
+    rs = [torch.load(tmp_path / f"rank{r}.pt") for r in range(world)]
+    r0, r1 = rs[0], rs[-1]
+    for r in rs[1:]:
+        for k in r0:
+            assert torch.equal(r0[k], r[k]), k
     dev = torch.device("cuda:0")
     xp, nt, na = _global_batch()
     whole = _one_step(_conf(dev, B, 1), dev, xp, nt, na)

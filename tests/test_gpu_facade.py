@@ -284,6 +284,37 @@ def test_phase_split_equals_single_call(dev):
         assert torch.equal(a1.tensors[k], a2.tensors[k]), k
 
 
+@pytest.mark.parametrize("world", [1, 2])
+def test_bucketed_phases_equal_one_grad_call(dev, world):
+    """FDQL_PHASE_GRAD_CRITICS + FDQL_PHASE_GRAD_REST (+ APPLY) - the data-parallel sequence whose first bucket
+    (arena[bucket:]: critics + log_alpha) is all-reduced beside the second part - leaves bit-identical gradients and
+    weights to FDQL_PHASE_GRAD (+ APPLY), and arena[bucket:] is already final after the first part.  world 1: the plan is
+    not bucketed (bucket = arena length) and the first part does nothing but bind the batch."""
+    import dataclasses
+    from fastdeepqlearning_amd import _native as nat
+    from test_gpu_parity import _agent_for
+    g = load("update_tqc_small")
+    spec = dataclasses.replace(spec_from_case(g["case"]), world_size=world)
+    rec = g["step0"]
+    xp = {k: torch.tensor(v).to(dev) for k, v in rec["batch"].items()}
+    nt, na = torch.tensor(rec["noise_target"]).to(dev), torch.tensor(rec["noise_actor"]).to(dev)
+    a1, a2 = _agent_for(spec, dev, world_size=world), _agent_for(spec, dev, world_size=world)
+    for a in (a1, a2):
+        a.load_tensors({k: torch.tensor(v) for k, v in g["init"].items()})
+    b = a2.grad_bucket()
+    assert (b < a2.grads.numel()) == (world > 1) and b % 4 == 0
+    a1.update(xp, nt, na, phase=nat.PHASE_GRAD)
+    a2.update(xp, nt, na, phase=nat.PHASE_GRAD_CRITICS)
+    torch.cuda.synchronize(dev)
+    assert torch.equal(a1.grads[b:], a2.grads[b:])                 # the early bucket is final
+    a2.update(None, phase=nat.PHASE_GRAD_REST)
+    assert torch.equal(a1.grads, a2.grads)
+    a1.update(None, phase=nat.PHASE_APPLY)
+    a2.update(None, phase=nat.PHASE_APPLY)
+    for k in a1.tensors:
+        assert torch.equal(a1.tensors[k], a2.tensors[k]), k
+
+
 def test_data_parallel_sharding_on_device(dev):
     """The multi-GPU sequence on one card: two agents configured as ranks of a world of 2 take half the windows each
     (FDQL_PHASE_GRAD), their gradient arenas are summed (what the RCCL all-reduce does) and applied
