@@ -193,6 +193,20 @@ def kernel_label(name):
     return f"k_gemm_grouped<{name[4:]} tile> (fp32 v_mfma_f32_32x32x2_f32)"
 
 
+def rocprof_tag(name):
+    """Substring of the rocprofv3 kernel name behind a profile entry (profiles/*: which kernel a PMC file is about)."""
+    if name.startswith("chain"):
+        return "k_chain"
+    if name.startswith("wgstat"):
+        return "k_wgrad_stat"
+    if name.startswith("wstat"):
+        return "k_wstat_grad" if "KS" in name else "k_wstat<"
+    if name.startswith("rows"):
+        return "k_rowgemm"
+    shape_id = {"128x128": 0, "128x32": 1, "32x128": 2, "64x128": 3, "64x64dual": 4, "64x64": 5, "64x64hf": 6}
+    return f"k_gemm_grouped<{shape_id.get(name[4:], 5)},"
+
+
 def roofline_of(job, committed_pmc=True):
     prof = job.kernel_profile()
     name, ms, fl, n, all_ms, all_fl, total_ms, by = dominant(prof)
@@ -208,13 +222,13 @@ def roofline_of(job, committed_pmc=True):
         return r, top
     # PMC figures (HBM traffic, MFMA pipe utilisation, clock) cannot be measured from inside this process: they come from
     # the committed rocprofv3 --pmc passes of the SAME workload, and only if those were collected on THIS csrc revision
-    tj = os.path.join(ROOT, "profiles", "r02_dominant_kernel_traffic.json")
+    tj = os.path.join(ROOT, "profiles", "r03_dominant_kernel_traffic.json")
     if os.path.exists(tj):
         tr = json.load(open(tj))
-        if tr.get("csrc_sha") == csrc_hash():
+        if tr.get("csrc_sha") == csrc_hash() and rocprof_tag(name) in tr.get("kernel", ""):
             r["traffic"] = tr["hbm_bytes_per_launch"]
             r["traffic_unit"] = "bytes/launch (L2<->fabric read+write, PMC FETCH_SIZE x2 + WRITE_SIZE)"
-            r["traffic_source"] = "profiles/r02_hbm_traffic_pmc.txt (" + tr["source"] + ")"
+            r["traffic_source"] = "profiles/r03_hbm_traffic_pmc.txt (" + tr["source"] + ")"
             r["algorithmic_bytes_per_launch"] = by / max(n, 1)
             for k in ("mfma_pipe_busy_frac", "shader_clock_ghz_under_load"):
                 if k in tr:

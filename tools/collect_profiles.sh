@@ -18,4 +18,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/tools/profile_stages.py --reps 1 > $OUT/pmc_write.log 2>&1 || exit 1
 # 4. matrix-pipe utilisation of every GEMM launch of one update (SQ counters, their own pass)
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $OUT/pmc_sq -- python3 $R/tools/profile_stages.py --reps 1 > $OUT/pmc_sq.log 2>&1 || exit 1
+# 5. instruction mix of every dense kernel (what the fp32 MFMA stream is shared with: VALU / LDS / vector-memory instructions
+#    take MFMA issue time on gfx950): counts in their own pass
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU --output-format csv -d $OUT/pmc_insts -- python3 $R/tools/profile_stages.py --reps 1 > $OUT/pmc_insts.log 2>&1 || exit 1
 python3 $R/tools/summarize_profiles.py $OUT

@@ -27,6 +27,7 @@ def per_kernel(rows, counter):
     return acc
 
 
+DENSE = ("k_gemm", "k_chain", "k_rowgemm", "k_wstat", "k_wgrad_stat")   # the MFMA kernels
 fetch = per_kernel(counter_rows("pmc_fetch"), "FETCH_SIZE")
 write = per_kernel(counter_rows("pmc_write"), "WRITE_SIZE")
 lines = ["# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, --kernel-trace only) over",
@@ -54,6 +55,13 @@ try:
 except (OSError, KeyError, IndexError, ValueError):
     pass
 dom_tag = f"k_gemm_grouped<{shape_id[dom_shape]}," if dom_shape in shape_id else ("k_rowgemm" if dom_shape == "rows" else "k_chain")
+try:
+    if "k_wstat" in kn:
+        dom_tag = "k_wstat_grad" if "dgrad" in kn else "k_wstat<"
+    elif "k_wgrad_stat" in kn:
+        dom_tag = "k_wgrad_stat"
+except NameError:
+    pass
 dom = [k for k in tot if dom_tag in k]
 
 
@@ -82,7 +90,7 @@ sq_rows = counter_rows("pmc_sq")
 if sq_rows:
     per = collections.OrderedDict()
     for r in sq_rows:
-        if "k_gemm" not in r["Kernel_Name"] and "k_chain" not in r["Kernel_Name"] and "k_rowgemm" not in r["Kernel_Name"]:
+        if not any(t in r["Kernel_Name"] for t in DENSE):
             continue
         key = (r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0], int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0))
         d = per.setdefault(key, collections.defaultdict(float))
@@ -92,7 +100,7 @@ if sq_rows:
     kt = sorted(glob.glob(os.path.join(out, "pmc_sq", "**", "*_kernel_trace.csv"), recursive=True), key=os.path.getmtime)
     if kt:
         for r in csv.DictReader(open(kt[-1])):
-            if "k_gemm" in r["Kernel_Name"] or "k_chain" in r["Kernel_Name"] or "k_rowgemm" in r["Kernel_Name"]:
+            if any(t in r["Kernel_Name"] for t in DENSE):
                 key = (r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0], int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0))
                 dur[key][0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
                 dur[key][1] += 1
@@ -128,6 +136,35 @@ if sq_rows:
             traffic["shader_clock_ghz_under_load"] = round(csum / wsum, 2)
             traffic["pmc_source"] = ("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES, time-weighted over the "
                                      "kernel's launches; the 157.3 TFLOP/s peak assumes 2.4 GHz")
+# instruction mix per dense kernel: what shares the issue stream with the fp32 MFMAs.  Cost model (tools/proto/mfma_coissue*.hip,
+# profiles/r02_rowgemm_notes.txt): an MFMA 32x32x2 holds the SIMD 64 cycles; a VALU instruction beside it ~5 (9 for the first
+# after an MFMA), an LDS instruction ~7, a vector-memory instruction 25-57: predicted fraction of the MFMA rate
+#   = 64 M / (64 M + 5 V + 7 L + 40 G)   with M = MFMA, V = other VALU, L = LDS, G = vector-memory instructions.
+ins_rows = counter_rows("pmc_insts")
+if ins_rows:
+    per = collections.OrderedDict()
+    for r in ins_rows:
+        if not any(t in r["Kernel_Name"] for t in DENSE):
+            continue
+        key = (r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0], int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0))
+        d = per.setdefault(key, collections.defaultdict(float))
+        d[r["Counter_Name"]] += float(r["Counter_Value"])
+        d["n_" + r["Counter_Name"]] += 1
+    il = ["# rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU over",
+          "# tools/profile_stages.py --reps 1 (config 2, T=50, B=256); wave-instructions per dispatch (means over a kernel's dispatches of one grid).",
+          "# other_VALU = SQ_INSTS_VALU - SQ_INSTS_MFMA.  per_MFMA columns: instructions issued per MFMA instruction.",
+          "# predicted = 64 M / (64 M + 5 V + 7 L + 40 G): fraction of the bare fp32-MFMA rate left by the instruction mix alone",
+          "# (no stalls, no start-up); the measured fraction of a launch is in mfma_utilisation_pmc.txt (mfma_util)."]
+    for key, d in per.items():
+        g = lambda c: d[c] / max(d["n_" + c], 1.0)   # noqa: E731
+        M = g("SQ_INSTS_MFMA")
+        if M <= 0:
+            continue
+        V, L, G, S = g("SQ_INSTS_VALU") - M, g("SQ_INSTS_LDS"), g("SQ_INSTS_VMEM_RD") + g("SQ_INSTS_VMEM_WR"), g("SQ_INSTS_SALU")
+        pred = 64 * M / (64 * M + 5 * max(V, 0) + 7 * L + 40 * G)
+        il.append(f"{key[0]:58s} grid={key[1]:8d} n={int(d['n_SQ_INSTS_MFMA']):3d} MFMA={M:12.0f} other_VALU/MFMA={V / M:6.3f} LDS/MFMA={L / M:6.3f} "
+                  f"VMEM/MFMA={G / M:6.3f} SALU/MFMA={S / M:6.3f} predicted={pred:5.3f}")
+    open(os.path.join(out, "valu_per_mfma.txt"), "w").write("\n".join(il) + "\n")
 if traffic is not None:
     json.dump(traffic, open(os.path.join(out, "dominant_kernel_traffic.json"), "w"), indent=1)
 # kernel stats csv of the bench run
