@@ -81,6 +81,7 @@ class DeepQLearning:
         self._seed = int(kwargs.get("seed", 0))
         self._last_xp = None
         self._side, self._ev = None, None   # data-parallel: side stream + events of the bucketed all-reduce
+        self.last_summaries = None
         self._trainer = None
         self._stop_training = False
         self.trainer_error = None
@@ -192,7 +193,30 @@ class DeepQLearning:
                 self._distributed_step(xp, nt, na)
             else:
                 self.native.update(xp, nt, na, seed=self._seed, phase=N.PHASE_ALL)
+            self._log_summaries()
             self.conf.train_step.value += 1
+
+    def _log_summaries(self):
+        """The reference writes its trainer scalars to tensorboard every log_interval steps and the gradient norms every
+        4 x log_interval (deepQlearning.py:114-122, 231-247).  Here: when the conf carries a callable ``summary_hook(step,
+        scalars: dict)`` the same quantities are read back on those steps (one small kernel + a device -> host copy; the
+        step itself never synchronises) and handed to it; ``last_summaries`` keeps the latest."""
+        hook = self.conf.get("summary_hook") if hasattr(self.conf, "get") else getattr(self.conf, "summary_hook", None)
+        step = int(self.conf.train_step.value)
+        every = int(getattr(self.conf, "log_interval", 50) or 50)
+        if not callable(hook) or step % every:
+            return
+        sc = self.native.scalars()
+        sm = self.native.summaries(grad_norms=(step % (4 * every) == 0))
+        out = {"Trainer/RL_Loss/Critic": sc["q_loss"], "Trainer/RL_Loss/Actor": sc["pi_loss"], "Trainer/RL_Loss/Alpha": sc["alpha_loss"],
+               "Trainer/Critic_q_pred_mu": sc["q_pred_mu"], "Trainer/Critic_q_pred_var": sm["q_pred_var"],
+               "Trainer/Critic_mc_constraint_violations": sc["mc_constraint_violations"], "Trainer/alpha": sc["alpha"],
+               "Trainer/Valid_Portion/mean": sm["valid_portion_mean"], "Trainer/Valid_Portion/max": sm["valid_portion_max"],
+               "Trainer/Valid_Portion/min": sm["valid_portion_min"]}
+        for k, v in sm.get("grad_norms", {}).items():
+            out[f"GradNorms/{k}"] = v
+        self.last_summaries = out
+        hook(step, out)
 
     def get_losses(self, xp, noise_target=None, noise_actor=None):
         """deepQlearning.py:198-249: loss of one [T,B,*] batch (also leaves d loss/d theta in the

@@ -19,8 +19,9 @@ from .episode_ops import SparseL2Reward, _dev
 
 
 class HindsightVmapWrite(ReplayMemoryWrapper):
-    def __init__(self, replay_buffer, compute_reward, ignore_keys=("info",), num_virtual_goals=32, device=None):
+    def __init__(self, replay_buffer, compute_reward, ignore_keys=("info",), num_virtual_goals=32, device=None, fused=True):
         super().__init__(replay_buffer)
+        self.fused = fused    # False: always the per-record path (tests compare the two)
         # a SparseL2Reward is evaluated K x n times on the device; any other callable (the reference takes any
         # ``compute_reward(achieved_goal, goal) -> (reward, done)``, her_vmap.py:18-28) on the host like 'final'/'random' do
         self.compute_reward = compute_reward
@@ -43,7 +44,81 @@ class HindsightVmapWrite(ReplayMemoryWrapper):
         newest_first = np.random.randint(0, n, size=self.num_virtual_goals)
         return (n - 1 - newest_first).astype(np.int32)
 
+    def _fused_target(self):
+        """(ring shard, NStepReturnVmap or None) when a finished episode can go to the ring as DEVICE rows in one call: a
+        device reward function, and underneath nothing but (optionally) the vmap n-step wrapper with an empty buffer."""
+        from ..replay_memory import ReplayMemory
+        from .nstep_return_vmap import NStepReturnVmap
+        if not self.fused or not isinstance(self.compute_reward, SparseL2Reward):
+            return None
+        child, nstep = self.replay_buffer, None
+        if type(child) is NStepReturnVmap:
+            nstep, child = child, child.replay_buffer
+            if nstep.buffer:
+                return None
+        return (child, nstep) if isinstance(child, ReplayMemory) else None
+
+    def _flush_fused(self, mem, nstep):
+        """The relabel (fdql_episode_her_vmap), the per-column returns (fdql_episode_mc_return_vmap, incl. the one-shot _pop
+        record of nstep_return_vmap.py:33-34, 50-57) and the packed rows stay on the device: one H2D copy of the episode's
+        own columns, one append - no device -> host -> device round trip, no per-record add."""
+        lib = N.load()
+        n, K = len(self.buffer), self.num_virtual_goals
+        dev = self._device
+        col = lambda k: np.asarray([np.asarray(x[k].detach().cpu().numpy() if isinstance(x[k], torch.Tensor) else x[k],
+                                               np.float32).reshape(-1) for x in self.buffer], np.float32)
+        ag, dg = col("achieved_goal"), col("desired_goal")
+        g = ag.shape[1]
+        # the record the per-record path would hand down (key order = insertion order), virtual columns last
+        rec0 = {k: v for k, v in self.buffer[0].items() if k not in self._ignored_keys}
+        template = dict(rec0)
+        template["virtual_goals"] = np.zeros((K + 1, g), np.float32)
+        template["virtual_rewards"] = np.zeros(K + 1, np.float32)
+        template["virtual_dones"] = np.zeros(K + 1, np.float32)
+        if nstep is not None:
+            template[nstep.return_name] = np.zeros(K + 1, np.float32)
+        mem._ensure_ring(template)
+        off = {k: (int(mem._offsets[j]), int(mem._offsets[j + 1])) for j, k in enumerate(mem._keys)}
+        host = np.zeros((n, int(mem._offsets[-1])), np.float32)
+        for k in mem._keys:
+            if k in rec0:
+                host[:, off[k][0]:off[k][1]] = col(k)
+        rows = torch.from_numpy(host).to(dev)
+        idx = torch.as_tensor(self._draw_goal_indices(n), dtype=torch.int32, device=dev)
+        r, td = rows[:, off["reward"][0]].contiguous(), rows[:, off["task_done"][0]].contiguous()
+        agd = rows[:, off["achieved_goal"][0]:off["achieved_goal"][1]].contiguous()
+        dgd = rows[:, off["desired_goal"][0]:off["desired_goal"][1]].contiguous()
+        vg = torch.empty(n, (K + 1) * g, device=dev)
+        vr, vd = torch.empty(n, K + 1, device=dev), torch.empty(n, K + 1, device=dev)
+        fn = self.compute_reward.native()
+        with torch.cuda.device(dev):
+            st = N.current_stream(dev)
+            N.check(lib.fdql_episode_her_vmap(N.ptr(r), N.ptr(td), N.ptr(agd), N.ptr(dgd), C.c_void_p(idx.data_ptr()), n, g, K,
+                                              C.byref(fn), N.ptr(vg), N.ptr(vr), N.ptr(vd), st))
+            rows[:, off["virtual_goals"][0]:off["virtual_goals"][1]] = vg
+            rows[:, off["virtual_rewards"][0]:off["virtual_rewards"][1]] = vr
+            rows[:, off["virtual_dones"][0]:off["virtual_dones"][1]] = vd
+            if nstep is not None:
+                lo, hi = off[nstep.return_name]
+                ret = torch.empty(n, K + 1, device=dev)
+                N.check(lib.fdql_episode_mc_return_vmap(N.ptr(vr), N.ptr(vd), N.ptr(ret), n, K + 1, float(nstep.discount), st))
+                rows[:, lo:hi] = ret
+                if n > nstep.n_step:      # _pop fired once, when the buffer held n_step records: record 0 with THAT return
+                    ns = int(nstep.n_step)
+                    part = torch.empty(ns, K + 1, device=dev)
+                    N.check(lib.fdql_episode_mc_return_vmap(N.ptr(vr[:ns].contiguous()), N.ptr(vd[:ns].contiguous()), N.ptr(part), ns,
+                                                            K + 1, float(nstep.discount), st))
+                    pop = rows[:1].clone()
+                    pop[0, lo:hi] = part[0]
+                    rows = torch.cat([pop, rows], 0)
+            mem.add_rows(rows.contiguous())
+        if hasattr(mem, "_len"):          # AsyncReplayMemory's own saturating counter (async_replay_memory.py:27-29)
+            mem._len = min(mem._len + int(rows.shape[0]), mem._maxlen)
+
     def _hindsight_flush(self):
+        target = self._fused_target()
+        if target is not None:
+            return self._flush_fused(*target)
         lib = N.load()
         n, K = len(self.buffer), self.num_virtual_goals
         dev = self._device

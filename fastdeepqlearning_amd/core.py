@@ -365,6 +365,20 @@ class NativeAgent:
         keys = ("loss", "q_loss", "pi_loss", "alpha_loss", "q_pred_mu", "mc_constraint_violations", "alpha", "step")
         return dict(zip(keys, [float(x) for x in out]))
 
+    def summaries(self, grad_norms=False):
+        """What franQ's trainer logs besides the losses (deepQlearning.py:231-247): q_pred_var, Valid_Portion mean / max / min
+        and - grad_norms - the L2 norm of every trainable tensor's gradient; computed on demand, outside the step."""
+        cap = 4 + len(self.trainable)
+        out = (C.c_float * cap)()
+        with torch.cuda.device(self.device):
+            n = self.lib.fdql_agent_summaries(self.handle, out, cap, int(bool(grad_norms)), N.current_stream(self.device))
+        if n < 0:
+            N.check(n)
+        d = dict(zip(("q_pred_var", "valid_portion_mean", "valid_portion_max", "valid_portion_min"), [float(x) for x in out[:4]]))
+        if grad_norms:
+            d["grad_norms"] = dict(zip(self.trainable, [float(x) for x in out[4:n]]))
+        return d
+
     def stats(self):
         s = N.AgentStats()
         N.check(self.lib.fdql_agent_stats(self.handle, C.byref(s)))

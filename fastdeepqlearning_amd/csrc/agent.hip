@@ -2133,6 +2133,30 @@ int fdql_agent_scalars(fdql_agent_t *a, float *host_out8, void *stream) {
   return 0;
 }
 
+int fdql_agent_summaries(fdql_agent_t *a, float *host_out, int32_t cap, int32_t with_grad_norms, void *stream) {
+  if (!a || !host_out) { set_error("null argument"); return FDQL_EINVAL; }
+  std::lock_guard<std::mutex> lk(a->mu);
+  if (!a->bound || !a->plan_ready) { set_error("no update has run yet"); return FDQL_ESTATE; }
+  // gradient-norm ranges: one per trainable tensor, in fdql_agent_tensor_info order (arena 0)
+  std::vector<long long> ranges;
+  if (with_grad_norms)
+    for (const TensorInfo &t : a->tensors)
+      if (t.arena == 0) { ranges.push_back(t.off); ranges.push_back(t.cols > 0 ? (long long)t.rows * t.cols : (t.rows > 0 ? t.rows : 1)); }
+  const int nr = (int)ranges.size() / 2;
+  FDQL_REQUIRE(cap >= 4 + nr, "summaries need room for %d floats", 4 + nr);
+  hipStream_t s = (hipStream_t)stream;
+  // scratch: the loss partials are dead between updates (rebuilt by the next loss launch)
+  float *out_dev = a->buf("loss_partials");
+  FDQL_REQUIRE(a->named.at("loss_partials").second >= (int64_t)(4 + nr) + (int64_t)ranges.size() * 2, "scratch too small for the summaries");
+  long long *ranges_dev = reinterpret_cast<long long *>(out_dev + ((4 + nr + 1) & ~1));
+  if (nr) FDQL_HIP(hipMemcpyAsync(ranges_dev, ranges.data(), ranges.size() * sizeof(long long), hipMemcpyHostToDevice, s));
+  hipError_t e = summaries_launch(a->buf("q_pred"), a->M, a->Nq, a->buf("is_contiguous"), a->T - 1, a->B, a->T, a->grads, ranges_dev, nr, out_dev, s);
+  if (e != hipSuccess) { set_error("summaries: %s", hipGetErrorString(e)); return FDQL_EHIP; }
+  FDQL_HIP(hipMemcpyAsync(host_out, out_dev, (4 + nr) * sizeof(float), hipMemcpyDeviceToHost, s));
+  FDQL_HIP(hipStreamSynchronize(s));
+  return 4 + nr;
+}
+
 int fdql_agent_set_alpha(fdql_agent_t *a, float alpha, void *stream) {
   if (!a) { set_error("null agent"); return FDQL_EINVAL; }
   std::lock_guard<std::mutex> lk(a->mu);

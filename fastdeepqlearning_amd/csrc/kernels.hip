@@ -1075,6 +1075,75 @@ hipError_t reduce_partials_batched_launch(const float *part, int ninst, int npar
   hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n + 63) / 64), ninst), dim3(256), 0, s, part, nparts, n, dst);
   return hipGetLastError();
 }
+// Trainer-side summaries of the last update, on demand (never in the step): franQ logs them every log_interval steps
+// (deepQlearning.py:231-247, distributional_soft_actor_critic.py:65-67):
+//   out[0] = mean over rows of the UNBIASED variance of q_pred over its Nq atoms   (q_pred.var(-1).mean())
+//   out[1] = mean of is_contiguous, out[2] / out[3] = max / min over the B windows of (sum_t is_contiguous) / temporal_len
+//   out[4 + i] = L2 norm of gradient arena range i (i < nranges: one per parameter tensor the caller lists)
+// One workgroup: the inputs are a few hundred KB.
+__global__ __launch_bounds__(1024) void k_summaries(const float *__restrict__ q_pred, int M, int Nq, const float *__restrict__ ic, int Tm1, int B,
+                                                    int temporal_len, const float *__restrict__ grads, const long long *__restrict__ ranges,
+                                                    int nranges, float *__restrict__ out) {
+  __shared__ float red[1024];
+  __shared__ float red2[1024];
+  const int t = threadIdx.x;
+  auto block_sum = [&](float v) {
+    red[t] = v;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+      if (t < s) red[t] += red[t + s];
+      __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+  };
+  float v = 0.f;
+  for (int m = t; m < M; m += 1024) {
+    float mu = 0.f;
+    for (int i = 0; i < Nq; ++i) mu += q_pred[(long long)m * Nq + i];
+    mu /= (float)Nq;
+    float s2 = 0.f;
+    for (int i = 0; i < Nq; ++i) { const float d = q_pred[(long long)m * Nq + i] - mu; s2 += d * d; }
+    v += Nq > 1 ? s2 / (float)(Nq - 1) : 0.f;
+  }
+  const float qvar = block_sum(v) / (float)M;
+  float tot = 0.f, mx = -1e30f, mn = 1e30f;
+  for (int b = t; b < B; b += 1024) {
+    float s = 0.f;
+    for (int k = 0; k < Tm1; ++k) s += ic[(long long)k * B + b];
+    tot += s;
+    mx = fmaxf(mx, s);
+    mn = fminf(mn, s);
+  }
+  const float total = block_sum(tot);
+  red[t] = mx; red2[t] = mn;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if (t < s) { red[t] = fmaxf(red[t], red[t + s]); red2[t] = fminf(red2[t], red2[t + s]); }
+    __syncthreads();
+  }
+  if (t == 0) {
+    out[0] = qvar;
+    out[1] = total / (float)((long long)Tm1 * B);
+    out[2] = red[0] / (float)temporal_len;
+    out[3] = red2[0] / (float)temporal_len;
+  }
+  __syncthreads();
+  for (int r = 0; r < nranges; ++r) {
+    const long long b0 = ranges[2 * r], n = ranges[2 * r + 1];
+    float s = 0.f;
+    for (long long i = t; i < n; i += 1024) { const float g = grads[b0 + i]; s += g * g; }
+    const float ss = block_sum(s);
+    if (t == 0) out[4 + r] = sqrtf(ss);
+  }
+}
+hipError_t summaries_launch(const float *q_pred, int M, int Nq, const float *ic, int Tm1, int B, int temporal_len, const float *grads,
+                            const long long *ranges_dev, int nranges, float *out_dev, hipStream_t s) {
+  hipLaunchKernelGGL(k_summaries, dim3(1), dim3(1024), 0, s, q_pred, M, Nq, ic, Tm1, B, temporal_len, grads, ranges_dev, nranges, out_dev);
+  return hipGetLastError();
+}
+
 // dst[rows, cols] = sum over nparts partials of the same shape, + column sums of dst per 32-row block (cs [ceil(rows/32), cols]):
 // the sum of the per-network shares of an input gradient, and the bias-gradient partials of the layer that produced its input.
 // One workgroup per 32-row block: thread -> (row phase t / 64, float4 column group t % 64 + 64 j).  cols % 4 == 0.

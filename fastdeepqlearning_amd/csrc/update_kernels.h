@@ -133,6 +133,8 @@ constexpr int COLSUM_TALL_ROWS = 1024;
 inline int colsum_tall_blocks(long long R) { return (int)((R + COLSUM_TALL_ROWS - 1) / COLSUM_TALL_ROWS); }
 hipError_t colsum_tall_launch(const float *X, long long R, int C, int ld, float *partial, hipStream_t s);
 // dst[e] = sum_p part[p][e] for e < n (fixed order)
+hipError_t summaries_launch(const float *q_pred, int M, int Nq, const float *ic, int Tm1, int B, int temporal_len, const float *grads,
+                            const long long *ranges_dev, int nranges, float *out_dev, hipStream_t s);
 // dst[rows, cols] = sum of nparts partials + per-32-row column sums cs [ceil(rows / 32), cols]  (cols % 4 == 0)
 hipError_t sum_parts_colsum_launch(const float *part, int nparts, int rows, int cols, float *dst, float *cs, hipStream_t s);
 hipError_t reduce_partials_launch(const float *part, int nparts, long long n, float *dst, hipStream_t s);

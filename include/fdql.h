@@ -301,6 +301,12 @@ int fdql_agent_grad_bucket(fdql_agent_t *agent, int64_t *first_early_float);
  * [0] loss (deepQlearning.py:249)  [1] mean q_loss  [2] mean pi_loss  [3] mean alpha_loss
  * [4] q_pred mean  [5] mc-constraint violation rate  [6] alpha used  [7] optimiser step   */
 int fdql_agent_scalars(fdql_agent_t *agent, float *host_out8, void *stream);
+/* The rest of what the reference's trainer logs every log_interval steps (deepQlearning.py:114-122, 231-247;
+ * distributional_soft_actor_critic.py:65-67), computed on demand from the last update's buffers - never inside a step
+ * (device -> host copy; synchronises `stream`): [0] q_pred.var(-1).mean()  [1] Valid_Portion mean  [2] max  [3] min;
+ * with_grad_norms: [4 + i] = L2 norm of the gradient of trainable tensor i (fdql_agent_tensor_info order, arena 0), as the
+ * gradient arena holds it (after FDQL_PHASE_GRAD / FDQL_PHASE_ALL).  Returns the number of floats written (< 0: error). */
+int fdql_agent_summaries(fdql_agent_t *agent, float *host_out, int32_t cap, int32_t with_grad_norms, void *stream);
 /* curr_alpha carried between steps (soft_actor_critic.py:41,152). */
 int fdql_agent_set_alpha(fdql_agent_t *agent, float alpha, void *stream);
 int fdql_agent_set_step(fdql_agent_t *agent, int32_t step, void *stream);

@@ -264,6 +264,43 @@ def test_agent_facade_life_cycle(dev, tmp_path):
     assert agent2.iteration == agent.iteration
 
 
+def test_trainer_summaries_and_hook(dev):
+    """What franQ's trainer logs every log_interval steps (deepQlearning.py:114-122, 231-247; q_pred_var:
+    distributional_soft_actor_critic.py:65-67): fdql_agent_summaries against the same expressions in torch on the step's own
+    buffers, and the facade's summary_hook firing on the reference's schedule."""
+    from fastdeepqlearning_amd import Agent, Replay
+    conf = _conf(dev)
+    conf.log_interval = 2
+    seen = []
+    conf.summary_hook = lambda step, d: seen.append((step, dict(d)))
+    read_heads, write_heads = Replay.make(conf)
+    agent = Agent.make(conf)
+    agent.enable_training(read_heads[:1])
+    rng = np.random.RandomState(1)
+    for ep in range(6):
+        for i in range(120):
+            write_heads[0].add({"obs_1d": rng.standard_normal(5), "action": rng.uniform(-1, 1, 3).astype(np.float32),
+                                "reward": float(rng.standard_normal()), "task_done": bool(rng.rand() < 0.05),
+                                "episode_done": i == 119, "episode_step": i, "idx": 0})
+    for _ in range(9):
+        agent.train_step()
+    assert [s for s, _ in seen] == [0, 2, 4, 6, 8]                       # step % log_interval == 0, counted like the reference
+    assert any(k.startswith("GradNorms/") for k in seen[0][1]) and any(k.startswith("GradNorms/") for k in seen[4][1])
+    assert not any(k.startswith("GradNorms/") for k in seen[1][1])       # every 4 x log_interval only
+    nat = agent.native
+    T, B = int(nat.cfg.T), int(nat.cfg.B)
+    sm = nat.summaries(grad_norms=True)
+    q = nat.debug("q_pred", (T - 1, B, nat.cfg.n_critics * nat.cfg.n_quantiles)).double()
+    ic = nat.debug("is_contiguous", (T - 1, B)).double()
+    assert abs(sm["q_pred_var"] - float(q.var(-1).mean())) <= 1e-5 * max(1.0, float(q.var(-1).mean()))
+    assert abs(sm["valid_portion_mean"] - float(ic.mean())) < 1e-6
+    assert abs(sm["valid_portion_max"] - float(ic.sum(0).max() / T)) < 1e-6
+    assert abs(sm["valid_portion_min"] - float(ic.sum(0).min() / T)) < 1e-6
+    for k, v in sm["grad_norms"].items():
+        ref = float(nat.grad_views[k].double().norm())
+        assert abs(v - ref) <= 1e-5 * max(ref, 1e-6), k
+
+
 def test_phase_split_equals_single_call(dev):
     """FDQL_PHASE_GRAD + FDQL_PHASE_APPLY (the multi-GPU sequence, all-reduce in between) gives
     bit-identical weights to FDQL_PHASE_ALL."""
@@ -460,7 +497,7 @@ def _l2_callable(ag, dg, thr=0.25):
 
 
 @pytest.mark.parametrize("case", ["k4", "k32_pop"])
-@pytest.mark.parametrize("reward_kind", ["device", "host_callable"])
+@pytest.mark.parametrize("reward_kind", ["device", "device_per_record", "host_callable"])
 def test_her_vmap_stack_matches_reference(dev, case, reward_kind):
     """HindsightVmapWrite -> NStepReturnVmap -> HBM ring -> HindsightVmapRead against what the reference's own
     her_vmap.py / nstep_return_vmap.py emitted and sampled (tests/golden/her_vmap.npz): fdql_episode_her_vmap (or the
@@ -472,8 +509,12 @@ def test_her_vmap_stack_matches_reference(dev, case, reward_kind):
     K, T, B = int(g["K"]), int(g["T"]), int(g["B"])
     ring = ReplayMemory(64, B, T, device=dev)
     inner = NStepReturnVmap(ring, int(g["n_step"]), float(g["gamma"]))
-    fn = SparseL2Reward(float(g["thr"]), -1.0) if reward_kind == "device" else _l2_callable
-    w = HindsightVmapWrite(inner, fn, num_virtual_goals=K)
+    # "device": the fused path (relabel, returns and packed rows stay on the device, one append per episode);
+    # "device_per_record": the same kernels, records re-added one by one; "host_callable": an arbitrary Python reward function
+    fn = SparseL2Reward(float(g["thr"]), -1.0) if reward_kind.startswith("device") else _l2_callable
+    w = HindsightVmapWrite(inner, fn, num_virtual_goals=K, fused=reward_kind == "device")
+    if reward_kind == "device":
+        assert w._fused_target() is not None
     inp = g["in"]
     np.random.seed(100 + K)                 # the generator's seed: her_vmap.py:75 draws from numpy's global state
     for i in range(inp["reward"].shape[0]):
