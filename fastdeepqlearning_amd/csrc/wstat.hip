@@ -529,13 +529,23 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
   };
 
   f32x16 acc[2][2];
-  float cs[2][16];                  // running column sums of C over this lane's rows (register r <-> column 8 (r/4) + 4 lh + r%4)
+  // running column sums of C over this lane's rows (quad kq = 4 tn + q, component c <-> column 32 tn + 8 q + 4 lh + c): 32
+  // private fp32 accumulators per lane.  They live in LDS ([quad][thread] float4: conflict-free b128), read one quad ahead
+  // and written back after the add: 32 registers this kernel does not have beside 64 accumulators, the staged rows and
+  // the 256 stationary weights (the allocator parked weights in scratch and re-read them every tile).
+  float *const csl = lds + 2 * IMG;
+  const unsigned cs_addr = ws_lds_addr(csl) + (unsigned)tid * 16u;
+  v4f csq[2];
+  if constexpr (!PLAIN) {
 #pragma unroll
-  for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) cs[tn][r] = 0.f;
+    for (int k = 0; k < 8; ++k) *reinterpret_cast<v4f *>(csl + (k * 256 + tid) * 4) = v4f{0.f, 0.f, 0.f, 0.f};
+  }
+  auto cs_read = [&](auto kqc) __attribute__((always_inline)) {
+    constexpr int kq = decltype(kqc)::value & 7;
+    if constexpr (!PLAIN) ws_rd128<kq * 4096>(csq[kq & 1], cs_addr);
+  };
   v4f fcs = {0.f, 0.f, 0.f, 0.f};   // FUSE: running column sums of the formed A0 over the rows this thread stages
-  v4f sh[8];                        // FUSE: rows in flight (fz_h pieces)
+  v4f sh[4];                        // FUSE: row pieces in flight (fz_h)
   v2f sdz = {0.f, 0.f};             // FUSE: dY of this wave's 8 rows of the tile in flight, row u in lane u
   float stm = 0.f;
   v4f rq[2];                        // gate references of the quads in flight
@@ -553,13 +563,13 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
     }
     return t;
   };
-  auto ref_load = [&](v4f &dst, int blkid, int kq) __attribute__((always_inline)) {
+  // (uniform bases once per tile, the quad's columns as instruction offsets: one scalar register pair per pointer)
+  auto ref_load = [&](v4f &dst, gcf rbase, int kq) __attribute__((always_inline)) {
     if constexpr (PLAIN) return;
     const int tn = (kq >> 2) & 1, q = kq & 3;
-    gcf base = ws_uni((gcf)ref + (long long)blkid * WS_BM * LD + n0 + 32 * tn + 8 * q);
-    dst = *(gcf4)(&base[vo_c]);
+    dst = *(gcf4)(&ws_uni(rbase + 32 * tn + 8 * q)[vo_c]);
   };
-  auto quad = [&](f32x16 (&pv)[2], int pblk, int kq) __attribute__((always_inline)) {
+  auto quad = [&](f32x16 (&pv)[2], gf cbase, int kq) __attribute__((always_inline)) {
     const int tn = (kq >> 2) & 1, q = kq & 3;
     v4f x;
 #pragma unroll
@@ -569,12 +579,14 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
         x[c] = v;
       } else {
         const float y = rq[kq & 1][c] > 0.f ? v : 0.01f * v;
-        cs[tn][4 * q + c] += y;
         x[c] = y;
       }
     }
-    gf base = ws_uni((gf)C + (long long)pblk * WS_BM * LD + n0 + 32 * tn + 8 * q);
-    *(gf4)(&base[vo_c]) = x;
+    *(gf4)(&ws_uni(cbase + 32 * tn + 8 * q)[vo_c]) = x;
+    if constexpr (!PLAIN) {   // (requested a quad ahead: in order behind it, the LDS write below is seen by the next tile's read)
+      csq[kq & 1] += x;
+      *reinterpret_cast<v4f *>(csl + ((kq & 7) * 256 + tid) * 4) = csq[kq & 1];
+    }
   };
 
   auto block = [&](auto has_prev, auto imgc, f32x16 (&ac)[2], f32x16 (&pv)[2], int nxt, int pblk, float live) __attribute__((always_inline)) {
@@ -584,11 +596,17 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
     asm volatile("s_barrier" ::: "memory");
     const float *nsrc = ws_uni(A0 + (long long)nxt * WS_BM * lda0);
     const float *ndz = ws_uni(A1 + (long long)nxt * m_tile);
-    float *nout = ws_uni(fz_out + (long long)nxt * WS_BM * LD);
+    // FUSE: this wave stages rows 8 wave .. 8 wave + 7 of the next tile: ONE base per pointer (row 8 wave + 4), the rows
+    // as signed instruction offsets (-4 .. +3 KiB)
+    gcf4 nsrc_w = (gcf4)ws_uni(nsrc + (8 * wave + 4) * LD);
+    gf4 nout_w = (gf4)ws_uni(fz_out + ((long long)nxt * WS_BM + 8 * wave + 4) * LD);
+    gf cprev = (gf)ws_uni(C + (long long)pblk * WS_BM * LD + n0);
+    gcf rprev = PLAIN ? nullptr : (gcf)ws_uni(ref + (long long)pblk * WS_BM * LD + n0);
     v4f af[2], nf;
     ws_rd128<IOFF>(af[0], abase);
     ws_rd128<IOFF>(nf, nbase);
-    if constexpr (HP) ref_load(rq[0], pblk, 0);
+    if constexpr (HP) ref_load(rq[0], rprev, 0);
+    if constexpr (HP) cs_read(std::integral_constant<int, 0>{});
     sfor<0, NSTEP>([&](auto sc) __attribute__((always_inline)) {
       constexpr int s = decltype(sc)::value;
       if constexpr (s + 1 < NSTEP) {
@@ -605,25 +623,31 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
       if constexpr (HP) {
         if constexpr (s == 0) ws_anchor(pv[0], pv[1]);
         if constexpr (s < 8) {
-          if constexpr (s + 1 < 8) ref_load(rq[(s + 1) & 1], pblk, s + 1);   // requested a step ahead, ahead of this quad's store
-          quad(pv, pblk, s);
+          if constexpr (!PLAIN) asm volatile("" : "+v"(csq[s & 1]));
+          if constexpr (s + 1 < 8) {   // requested a step ahead (the reference: ahead of this quad's store)
+            ref_load(rq[(s + 1) & 1], rprev, s + 1);
+            cs_read(std::integral_constant<int, s + 1>{});
+          }
+          quad(pv, cprev, s);
         }
       }
       if constexpr (FUSE) {
-        if constexpr (s >= 8 && s < 16) {   // request row s - 8 of this wave's 8
-          constexpr int u = s - 8;
-          const int row = wave + 4 * u;
-          sh[u] = ws_uni((gcf4)(nsrc + row * LD))[(unsigned)lane];
-          if constexpr (u == 0) sdz = *(const __attribute__((address_space(1))) v2f *)(ndz + (wave + 4 * (lane & 7)) * lda1);
+        // this wave's 8 rows of the next tile in two groups of 4 (at most 4 row pieces live in registers): requested at
+        // steps 6..9 / 16..19, formed 8 steps (~4 k cycles) later at 14..17 / 24..27
+        constexpr int ureq = (s >= 6 && s < 10) ? s - 6 : ((s >= 16 && s < 20) ? s - 12 : -1);
+        constexpr int uuse = (s >= 14 && s < 18) ? s - 14 : ((s >= 24 && s < 28) ? s - 20 : -1);
+        if constexpr (ureq >= 0) {
+          sh[ureq & 3] = (nsrc_w + (ureq - 4) * (LD / 4))[(unsigned)lane];
+          if constexpr (ureq == 0) sdz = *(const __attribute__((address_space(1))) v2f *)(ndz + (8 * wave + (lane & 7)) * lda1);
         }
-        if constexpr (s >= 22 && s < 30) {  // form it, keep it for the weight gradients, put it into the other image
-          constexpr int u = s - 22;
-          const int row = wave + 4 * u;
+        if constexpr (uuse >= 0) {  // form it, keep it for the weight gradients, put it into the other image
+          constexpr int u = uuse;
+          const int row = 8 * wave + u;
           // (copies first: __builtin_bit_cast of a vector ELEMENT lvalue reads the vector's first element)
           const float d0 = sdz.x, d1 = sdz.y;
-          const v4f t = fuse_row(sh[u], __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d0), u)),
+          const v4f t = fuse_row(sh[u & 3], __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d0), u)),
                                  __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d1), u)), live);
-          ws_uni((gf4)(nout + row * LD))[(unsigned)lane] = t;
+          (nout_w + (u - 4) * (LD / 4))[(unsigned)lane] = t;
           *reinterpret_cast<v4f *>(lds + (IM ^ 1) * IMG + row * P + lane * 4) = t;
         }
       } else {
@@ -651,7 +675,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
       float *out = fz_out + (long long)blk * WS_BM * LD;
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int row = wave + 4 * u;
+        const int row = 8 * wave + u;
         const v4f h = ((gcf4)(src + row * LD))[(unsigned)lane];
         const v2f dz = *(const __attribute__((address_space(1))) v2f *)(dzs + row * lda1);
         const v4f t = fuse_row(h, dz.x, dz.y, 1.f);
@@ -683,11 +707,16 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
   auto flush = [&](f32x16 (&pv)[2]) __attribute__((always_inline)) {
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
     ws_anchor(pv[0], pv[1]);
-#pragma unroll
-    for (int kq = 0; kq < 8; ++kq) {
-      ref_load(rq[kq & 1], prv, kq);
-      quad(pv, prv, kq);
-    }
+    gf cprev = (gf)ws_uni(C + (long long)prv * WS_BM * LD + n0);
+    gcf rprev = PLAIN ? nullptr : (gcf)ws_uni(ref + (long long)prv * WS_BM * LD + n0);
+    sfor<0, 8>([&](auto kc) __attribute__((always_inline)) {
+      constexpr int kq = decltype(kc)::value;
+      ref_load(rq[kq & 1], rprev, kq);
+      cs_read(kc);
+      ws_lgkm_wait<0>();
+      if constexpr (!PLAIN) asm volatile("" : "+v"(csq[kq & 1]));
+      quad(pv, cprev, kq);
+    });
   };
   if (set == 1) flush(acc[0]);
   else flush(acc[1]);
@@ -698,7 +727,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
     for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float t = ws_sum32(cs[tn][r]);
+        const float t = ws_sum32(csl[((4 * tn + (r >> 2)) * 256 + tid) * 4 + (r & 3)]);
         if (li == 31) colsum[n0 + 32 * tn + (r & 3) + 8 * (r >> 2) + 4 * lh] = t;
       }
     if constexpr (FUSE) {
@@ -873,7 +902,7 @@ static hipError_t ws_launch(const WsArgs &a, hipStream_t s) {
 template <bool FUSE, bool PLAIN>
 static hipError_t ws_launch_grad(const WsArgs &a, hipStream_t s) {
   static bool attr[64];
-  constexpr int lds_bytes = 2 * WS_BM * (WS_KMAIN + 8 + 4) * 4;
+  constexpr int lds_bytes = 2 * WS_BM * (WS_KMAIN + 8 + 4) * 4 + (PLAIN ? 0 : 32 * 256 * 4);   // images + column-sum accumulators
   return ws_launch_kernel(&k_wstat_grad<FUSE, PLAIN>, lds_bytes, attr, a, s);
 }
 

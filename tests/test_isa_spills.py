@@ -12,7 +12,8 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 # file -> substrings of the (demangled) kernels that must be spill-free
 MUST_BE_CLEAN = {
-    "wstat.hip": ["k_wstat"],
+    "wstat.hip": ["k_wstat"],          # forward forms, gated / fused / plain dgrad forms
+    "wgrad.hip": ["k_wgrad_stat"],
 }
 
 
