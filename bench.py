@@ -185,7 +185,8 @@ def kernel_label(name):
     if name.startswith("chain"):
         return "k_chain (row-block MLP chain, fp32 v_mfma_f32_32x32x2_f32)"
     if name.startswith("wstat"):
-        return "k_wstat (weight-stationary persistent row-block GEMM, " + ("dgrad" if "KS" in name else "forward") + " form, fp32 v_mfma_f32_32x32x2_f32)"
+        return rocprof_tag(name) + " (weight-stationary persistent row-block GEMM, " + ("dgrad" if name.startswith("wstatg") else "forward") + \
+               " form, fp32 v_mfma_f32_32x32x2_f32)"
     if name.startswith("wgstat"):
         return "k_wgrad_stat (output-stationary weight-gradient blocks, fp32 v_mfma_f32_32x32x2_f32)"
     if name.startswith("rows"):
@@ -199,8 +200,12 @@ def rocprof_tag(name):
         return "k_chain"
     if name.startswith("wgstat"):
         return "k_wgrad_stat"
-    if name.startswith("wstat"):
-        return "k_wstat_grad" if "KS" in name else "k_wstat<"
+    if name.startswith("wstatg<"):       # "wstatg<fuse,plain>:stage" -> k_wstat_grad<true, false>
+        f, pl = name[7:name.index(">")].split(",")
+        return f"k_wstat_grad<{'true' if f == '1' else 'false'}, {'true' if pl == '1' else 'false'}>"
+    if name.startswith("wstat<"):        # "wstat<nminor,dual,hfq>:stage" -> k_wstat<0, false, 2>
+        n, d, q = name[6:name.index(">")].split(",")
+        return f"k_wstat<{n}, {'true' if d == '1' else 'false'}, {q}>"
     if name.startswith("rows"):
         return "k_rowgemm"
     shape_id = {"128x128": 0, "128x32": 1, "32x128": 2, "64x128": 3, "64x64dual": 4, "64x64": 5, "64x64hf": 6}

@@ -1965,9 +1965,13 @@ int32_t fdql_agent_profile_update(fdql_agent_t *a, const fdql_batch_t *batch, co
       if (rl.ws) {
         flops = wstat_flops(rl.wa);
         bytes = 4.0 * rl.wa.M * rl.wa.ninst * (double)(WS_KMAIN + WS_N * (rl.wa.dual ? 2 : 1));
-        if (rl.wa.grad) bytes = 4.0 * rl.wa.M * rl.wa.ninst * (double)(WS_KMAIN * (rl.wa.fz ? 2 : 1) + 2 * WS_N);
-        snprintf(out[cnt].name, sizeof(out[cnt].name), "wstat%s%s%s:%s", rl.wa.grad ? (rl.wa.fz ? "KSfz" : "KS") : "", rl.wa.dual ? "dual" : "",
-                 rl.wa.hf_q ? "hf" : "", st.name.c_str());
+        // (the name carries the kernel's template arguments: bench.py / tools map it to the rocprofv3 kernel name)
+        if (rl.wa.grad) {
+          bytes = 4.0 * rl.wa.M * rl.wa.ninst * (double)(WS_KMAIN * (rl.wa.fz ? 2 : 1) + 2 * WS_N);
+          snprintf(out[cnt].name, sizeof(out[cnt].name), "wstatg<%d,%d>:%s", rl.wa.fz ? 1 : 0, rl.wa.grad == 2 ? 1 : 0, st.name.c_str());
+        } else {
+          snprintf(out[cnt].name, sizeof(out[cnt].name), "wstat<%d,%d,%d>:%s", rl.wa.nminor, rl.wa.dual ? 1 : 0, rl.wa.hf_q, st.name.c_str());
+        }
       } else {
       const RowGemmArgs &ra = rl.rg;
       flops = rowgemm_flops(ra);

@@ -548,7 +548,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
   v4f sh[4];                        // FUSE: row pieces in flight (fz_h)
   v2f sdz = {0.f, 0.f};             // FUSE: dY of this wave's 8 rows of the tile in flight, row u in lane u
   float stm = 0.f;
-  v4f rq[2];                        // gate references of the quads in flight
+  v4f rq[3];                        // gate references of the quads in flight (requested two steps ahead: an L2 hit takes longer than one)
 
   // FUSE: one staged row piece: h -> LeakyReLU'(h) * (dY . Wh), k_head_dgrad's order and rounding (fma chain over q)
   auto fuse_row = [&](v4f h, float dz0, float dz1, float live) __attribute__((always_inline)) {
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
       if constexpr (PLAIN) {
         x[c] = v;
       } else {
-        const float y = rq[kq & 1][c] > 0.f ? v : 0.01f * v;
+        const float y = rq[kq % 3][c] > 0.f ? v : 0.01f * v;
         x[c] = y;
       }
     }
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
     v4f af[2], nf;
     ws_rd128<IOFF>(af[0], abase);
     ws_rd128<IOFF>(nf, nbase);
-    if constexpr (HP) ref_load(rq[0], rprev, 0);
+    if constexpr (HP) { ref_load(rq[0], rprev, 0); ref_load(rq[1], rprev, 1); }
     if constexpr (HP) cs_read(std::integral_constant<int, 0>{});
     sfor<0, NSTEP>([&](auto sc) __attribute__((always_inline)) {
       constexpr int s = decltype(sc)::value;
@@ -624,22 +624,25 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
         if constexpr (s == 0) ws_anchor(pv[0], pv[1]);
         if constexpr (s < 8) {
           if constexpr (!PLAIN) asm volatile("" : "+v"(csq[s & 1]));
-          if constexpr (s + 1 < 8) {   // requested a step ahead (the reference: ahead of this quad's store)
-            ref_load(rq[(s + 1) & 1], rprev, s + 1);
-            cs_read(std::integral_constant<int, s + 1>{});
-          }
+          if constexpr (s + 2 < 8) ref_load(rq[(s + 2) % 3], rprev, s + 2);   // two steps ahead, ahead of this quad's store
+          if constexpr (s + 1 < 8) cs_read(std::integral_constant<int, s + 1>{});
           quad(pv, cprev, s);
         }
       }
       if constexpr (FUSE) {
         // this wave's 8 rows of the next tile in two groups of 4 (at most 4 row pieces live in registers): requested at
-        // steps 6..9 / 16..19, formed 8 steps (~4 k cycles) later at 14..17 / 24..27
+        // steps 2..5 / 10..13, formed 8 steps (~4 k cycles) later at 10..13 / 18..21 - the last global store of a tile is 10
+        // steps old when the tile ends (vmcnt completes in order: a younger load would wait for it)
+#ifndef WS_FZ_SCHED
+#define WS_FZ_SCHED 0   // measured: 0.200 ms against 0.218 ms (early schedule) for critics.dpre1+0 at config 2
+#endif
+#if WS_FZ_SCHED == 1
+        constexpr int ureq = (s >= 2 && s < 6) ? s - 2 : ((s >= 10 && s < 14) ? s - 6 : -1);
+        constexpr int uuse = (s >= 10 && s < 14) ? s - 10 : ((s >= 18 && s < 22) ? s - 14 : -1);
+#else
         constexpr int ureq = (s >= 6 && s < 10) ? s - 6 : ((s >= 16 && s < 20) ? s - 12 : -1);
         constexpr int uuse = (s >= 14 && s < 18) ? s - 14 : ((s >= 24 && s < 28) ? s - 20 : -1);
-        if constexpr (ureq >= 0) {
-          sh[ureq & 3] = (nsrc_w + (ureq - 4) * (LD / 4))[(unsigned)lane];
-          if constexpr (ureq == 0) sdz = *(const __attribute__((address_space(1))) v2f *)(ndz + (8 * wave + (lane & 7)) * lda1);
-        }
+#endif
         if constexpr (uuse >= 0) {  // form it, keep it for the weight gradients, put it into the other image
           constexpr int u = uuse;
           const int row = 8 * wave + u;
@@ -650,16 +653,26 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
           (nout_w + (u - 4) * (LD / 4))[(unsigned)lane] = t;
           *reinterpret_cast<v4f *>(lds + (IM ^ 1) * IMG + row * P + lane * 4) = t;
         }
+        if constexpr (ureq >= 0) {   // (after the use of the register it refills)
+          sh[ureq & 3] = (nsrc_w + (ureq - 4) * (LD / 4))[(unsigned)lane];
+          if constexpr (ureq == 0) sdz = *(const __attribute__((address_space(1))) v2f *)(ndz + (8 * wave + (lane & 7)) * lda1);
+        }
       } else {
         if constexpr (s >= 16 && s < 16 + WS_BM / 4) dma_row(nsrc, IM ^ 1, wave + 4 * (s - 16));
       }
-      if constexpr (s == 12) stm = ((gcf)ndz)[m_src];
-      if constexpr (s == 30) m_dst[(IM ^ 1) * IMG] = m_ok ? stm : 0.f;
+      if constexpr (s == 8) stm = ((gcf)ndz)[m_src];
+      if constexpr (s == 26) m_dst[(IM ^ 1) * IMG] = m_ok ? stm : 0.f;
       asm volatile("" ::: "memory");
     });
     asm volatile("" : "+v"(nf));
     ws_step_v(ac[0], ac[1], wn[0], wn[1], nf);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // this wave's part of the next image has landed: LDS-DMA pieces (vmcnt) or, FUSE, its own LDS writes only - the
+    // global stores of the tile need not have completed
+#ifndef WS_FZ_WAIT
+#define WS_FZ_WAIT 1
+#endif
+    if constexpr (FUSE && WS_FZ_WAIT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   };
   using T = std::true_type;
   using F = std::false_type;
@@ -711,7 +724,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
     gcf rprev = PLAIN ? nullptr : (gcf)ws_uni(ref + (long long)prv * WS_BM * LD + n0);
     sfor<0, 8>([&](auto kc) __attribute__((always_inline)) {
       constexpr int kq = decltype(kc)::value;
-      ref_load(rq[kq & 1], rprev, kq);
+      ref_load(rq[kq % 3], rprev, kq);
       cs_read(kc);
       ws_lgkm_wait<0>();
       if constexpr (!PLAIN) asm volatile("" : "+v"(csq[kq & 1]));
