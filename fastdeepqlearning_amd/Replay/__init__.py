@@ -27,7 +27,8 @@ def make(conf, **kwargs):
     heads are the shards themselves (the gather kernel already returns float32 device tensors), wrapped only
     for the read-time goal selection of HER-vmap."""
     device = getattr(conf, "training_device", "cuda:0")
-    shards = [AsyncReplayMemory(int(conf.replay_size), conf.batch_size, conf.temporal_len, device=device, seed=i)
+    # (sample_buffers=3: the trainer's read heads recycle three batch buffers, so the agent's cached launch plans recur)
+    shards = [AsyncReplayMemory(int(conf.replay_size), conf.batch_size, conf.temporal_len, device=device, seed=i, sample_buffers=3)
               for i in range(conf.num_instances)]
     reward_fn = kwargs.get("compute_reward") if conf.use_HER else None
     if conf.use_HER and reward_fn is None:

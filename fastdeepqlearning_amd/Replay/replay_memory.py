@@ -24,11 +24,12 @@ class ReplayMemory:
     """Same constructor and methods as the reference; returns torch device tensors (float32),
     i.e. what ``TorchDataLoader(ReplayMemory(...))`` returns in the reference."""
 
-    def __init__(self, maxlen, batch_size, temporal_len, device=None, seed=0, sample_buffers=3, **kwargs):
-        """sample_buffers: temporal_sample() writes into a rotating pool of this many persistent output sets, so a
-        returned batch stays valid until `sample_buffers` further samples have been drawn (the reference's loader
-        hands out one prefetched batch at a time, torch_dataloader.py:22,47-50) and the agent sees a small, recurring
-        set of batch addresses - its launch plans are cached per address set.  0: fresh tensors on every call."""
+    def __init__(self, maxlen, batch_size, temporal_len, device=None, seed=0, sample_buffers=0, **kwargs):
+        """sample_buffers: 0 (default, like the reference: fresh tensors on every call).  n > 0: temporal_sample() writes
+        into a rotating pool of n persistent output sets - a returned batch is OVERWRITTEN once n further samples have
+        been drawn (the reference's loader hands out one prefetched batch at a time, torch_dataloader.py:22,47-50) and
+        the agent sees a small, recurring set of batch addresses: its launch plans are cached per address set.
+        Replay.make() turns it on (3) for the shards it builds for the trainer."""
         self._batch_size, self._temporal_len, self._maxlen = int(batch_size), int(temporal_len), int(maxlen)
         self._pool, self._pool_i, self._pool_n = [], 0, max(0, int(sample_buffers))
         self._init_lock = threading.Lock()     # first add() from two writer threads: one of them lays the ring out

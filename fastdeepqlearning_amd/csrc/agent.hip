@@ -88,7 +88,7 @@ constexpr int GRU_KSPLIT_FWD = 4, GRU_KSPLIT_BWD = 8;
 // Few rows (temporal_len 2, small batches): d state as one problem is a handful of workgroups walking all 2(C+1)
 // K-segments serially; below this row count each network's contribution is its own problem and a reduction sums them
 constexpr int DSTATE_SPLIT_MAX_ROWS = 1024;
-constexpr size_t PLAN_CACHE_MAX = 4;   // finished plans kept besides the current one
+constexpr size_t PLAN_CACHE_DEFAULT = 11;   // finished plans kept besides the current one (FDQL_PLAN_CACHE): e.g. 4 shards x a 3-buffer sample pool
 // K-split of a conv weight gradient over its R = images * positions rows: ~4096 rows per workgroup, at most 1024 parts
 inline int conv_wsplit(long long R) { return (int)std::max<long long>(1, std::min<long long>(1024, (R + 4095) / 4096)); }
 
@@ -199,7 +199,8 @@ struct fdql_agent {
   int use_graph = 0;    // FDQL_GRAPH (read at create): "1" replay, default eager launches
   long long graph_launches = 0;
   struct CachedPlan { fdql_batch_t batch; std::vector<Stage> stages; void *tables_dev; PlanGraph graph; };
-  std::vector<CachedPlan> plan_cache;   // most recently stashed last
+  std::vector<CachedPlan> plan_cache;   // most recently stashed last; a hit moves a plan out (it becomes current): the front is the least recently used
+  size_t plan_cache_max = PLAN_CACHE_DEFAULT;
   long long plans_built = 0;
   long long rows_min_tiles = 512;   // FDQL_ROWGEMM: "0" never; default: groups with at least two tiles per CU
   // d state = sum over the online critics and the actor: one problem accumulating every network's K-segments, or - few rows
@@ -1676,7 +1677,7 @@ int prepare_update(fdql_agent *a, const fdql_batch_t *batch, const float *noise_
       a->graph = fdql_agent::PlanGraph();
       a->tables_dev = nullptr;
       a->plan_ready = false;
-      if (a->plan_cache.size() > PLAN_CACHE_MAX) {
+      if (a->plan_cache.size() > a->plan_cache_max) {
         (void)hipFree(a->plan_cache.front().tables_dev);   // synchronises: nothing still reads the evicted tables
         a->plan_cache.front().graph.reset();
         a->plan_cache.erase(a->plan_cache.begin());
@@ -1762,6 +1763,10 @@ int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {
     const char *e = getenv("FDQL_GRAPH");
     a->use_graph = e && e[0] == '1';
     const char *r = getenv("FDQL_ROWGEMM");   // "0": off; "all": every eligible group whatever its size (tests)
+    if (const char *pc = getenv("FDQL_PLAN_CACHE")) {
+      const int v = atoi(pc);
+      if (v >= 0 && v <= 256) a->plan_cache_max = (size_t)v;
+    }
     if (r && r[0] == '0') a->rows_min_tiles = 1LL << 60;
     else if (r && !strcmp(r, "all")) a->rows_min_tiles = 1;
   }
@@ -1787,7 +1792,7 @@ int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {
     const char *we = getenv("FDQL_WSTAT");
     bool ws_ok = !(we && (we[0] == '0' || !strcmp(we, "fwd"))) && getenv("FDQL_NO_DSTATE_SPLIT") == nullptr;
     for (const MlpDesc &d : a->critic) ws_ok = ws_ok && !d.hid.empty() && d.hid[0] == WS_N;
-    ws_ok = ws_ok && c.latent == WS_N && a->M % WS_BM == 0 && c.n_critics <= WS_MAX_INST && c.n_quantiles <= 8 &&
+    ws_ok = ws_ok && c.latent == WS_N && a->M % WS_BM == 0 && c.n_critics <= WS_MAX_INST && c.n_quantiles <= 32 &&
             (long long)c.n_critics * (a->M / RG_BM) >= a->rows_min_tiles;
     a->dstate_split = a->M <= DSTATE_SPLIT_MAX_ROWS || ws_ok;
   }
@@ -2289,6 +2294,27 @@ int fdql_test_gemm(const float *A, int32_t lda, int32_t a_kc, const float *B, in
   if (e != hipSuccess) { set_error("gemm launch: %s", hipGetErrorString(e)); (void)hipFree(dev); return FDQL_EHIP; }
   FDQL_HIP(hipStreamSynchronize((hipStream_t)stream));
   FDQL_HIP(hipFree(dev));
+  return 0;
+}
+
+/* Test hook for the output-stationary weight-gradient kernel (wgrad.hip): nprob blocks dW[i] [256, ldw] (slab 0 at dW + i *
+ * 256 * ldw, slabs slab_stride floats apart, nslab of them) = G[i]^T X[i] over M rows each (G, X: [nprob * M, 256]).  Every
+ * slab of every block is written (partials or zeros): their sum is the gradient.  FDQL_EINVAL: the kernel does not take the form. */
+int fdql_test_wgrad_stat(const float *G, const float *X, float *dW, int32_t M, int32_t nprob, int32_t ldw, int32_t nslab,
+                         int64_t slab_stride, void *stream) {
+  std::vector<GemmProblem> probs;
+  for (int i = 0; i < nprob; ++i) {
+    GemmProblem p;
+    memset(&p, 0, sizeof(p));
+    p.M = WG_N; p.N = WG_N; p.C = dW + (long long)i * WG_N * ldw; p.ldc = ldw; p.ksplit = nslab; p.split_stride = slab_stride; p.emit_seg = -1;
+    GemmSeg &sg = p.seg[p.nseg++];
+    sg.A = G + (long long)i * M * WG_N; sg.lda = WG_N; sg.a_kc = 0; sg.B = X + (long long)i * M * WG_N; sg.ldb = WG_N; sg.b_kc = 0; sg.K = M;
+    probs.push_back(p);
+  }
+  WgArgs wa;
+  FDQL_REQUIRE(wgrad_stat_from_problems(probs.data(), nprob, nslab, slab_stride, wa), "the output-stationary kernel does not take this form");
+  hipError_t e = wgrad_stat_launch(wa, (hipStream_t)stream);
+  if (e != hipSuccess) { set_error("wgrad_stat launch: %s", hipGetErrorString(e)); return FDQL_EHIP; }
   return 0;
 }
 

@@ -19,6 +19,8 @@
 // staging of B, no barrier inside a K loop; the next group's fragments are requested before the current group's 64 MFMAs.
 #include "chain.h"
 
+#include <mutex>
+
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -691,17 +693,26 @@ int chain_finalize(ChainProblem *probs, int nprob) {
 hipError_t chain_launch(const ChainProblem *probs_dev, int nprob, const ChainOp *ops_dev, int total_blocks, int lds_floats,
                         hipStream_t stream) {
   if (total_blocks <= 0) return hipSuccess;
-  static bool attr_set = false;
+  // dynamic LDS beyond 64 KiB has to be allowed once per (device, function): a process may drive several GPUs, and two
+  // agents may launch from two threads
+  static bool attr_set[64];
+  static std::mutex attr_mu;
   static int minb_pref = 1;
-  if (!attr_set) {   // dynamic LDS beyond 64 KiB has to be allowed once per process
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       CH_LDS_FLOATS * 4);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<2>), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_FLOATS * 4);
+  {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    if (const char *v = getenv("FDQL_CHAIN_MINB")) minb_pref = atoi(v) == 2 ? 2 : 1;   // tuning hook
-    if (getenv("FDQL_CHAIN_STAMPS")) chain_enable_stamps(1);
-    attr_set = true;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lk(attr_mu);
+    if (!attr_set[dev]) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<1>), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_FLOATS * 4);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<2>), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_FLOATS * 4);
+      if (e != hipSuccess) return e;
+      if (const char *v = getenv("FDQL_CHAIN_MINB")) minb_pref = atoi(v) == 2 ? 2 : 1;   // tuning hook
+      if (getenv("FDQL_CHAIN_STAMPS")) chain_enable_stamps(1);
+      attr_set[dev] = true;
+    }
   }
   const size_t lds_bytes = (size_t)lds_floats * 4;
   const bool two = minb_pref == 2 && lds_bytes + CH_MAX_OPS * sizeof(ChainOp) + 512 <= 81920;

@@ -16,6 +16,8 @@
 // every consumer of a B fragment, which serialises the loop (profiles/r02_rowgemm_notes.txt).
 #include "rowgemm.h"
 
+#include <mutex>
+
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -724,24 +726,40 @@ double rowgemm_flops(const RowGemmArgs &a) {
 
 template <bool KS, int NMINOR, bool DUAL, int HFQ, bool GRAD, bool FUSE = false>
 static hipError_t rg_launch(const RowGemmArgs &a, int grid, int lds_bytes, hipStream_t s) {
-  static bool attr = false;
+  // the opt-in to > 64 KiB of dynamic LDS belongs to the (device, function) pair
+  static bool attr[64];
+  static std::mutex mu;
   auto kern = &k_rowgemm<KS, NMINOR, DUAL, HFQ, GRAD, FUSE>;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+  {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    attr = true;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!attr[dev]) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+      if (e != hipSuccess) return e;
+      attr[dev] = true;
+    }
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, s, a);
   return hipGetLastError();
 }
 
 hipError_t rowgemm_launch(const RowGemmArgs &a, hipStream_t s) {
-  static int ncu = 0;
-  if (!ncu) {
+  static int ncu_of[64];
+  static std::mutex ncu_mu;
+  int ncu = 0;
+  {
     int dev = 0;
-    hipDeviceProp_t p;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return hipErrorUnknown;
-    ncu = p.multiProcessorCount;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorUnknown;
+    std::lock_guard<std::mutex> lk(ncu_mu);
+    if (!ncu_of[dev]) {
+      hipDeviceProp_t p;
+      if (hipGetDeviceProperties(&p, dev) != hipSuccess) return hipErrorUnknown;
+      ncu_of[dev] = p.multiProcessorCount;
+    }
+    ncu = ncu_of[dev];
   }
   const int ntiles = a.ninst * a.blocks_per_inst;
   const int grid = ntiles < ncu ? ntiles : ncu;

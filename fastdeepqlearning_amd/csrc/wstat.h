@@ -1,6 +1,6 @@
 // Weight-stationary persistent row-block GEMM (wstat.hip) for the forward layers of the critic ensemble: a launch is a set
 // of INSTANCES (critic k x {target, online, frozen}) of one Linear layer of 256 outputs,
-//   C[M, 256] = LeakyReLU( A0[M, 256] W0^T + A1[M, K1] W1^T (+ A2[M, K2] W2^T) + bias )      K1, K2 <= 8 (the action columns)
+//   C[M, 256] = LeakyReLU( A0[M, 256] W0^T + A1[M, K1] W1^T (+ A2[M, K2] W2^T) + bias )      K1, K2 <= 32 (the action columns)
 // and every workgroup belongs to ONE instance for its whole life: the instance's 256 x 256 weights sit in the AccVGPRs
 // of its four waves (64 output columns x 256 k = 256 registers per lane), so the K loop issues no weight loads at all.
 #pragma once
@@ -11,7 +11,8 @@ namespace fdql {
 constexpr int WS_BM = 32;          // rows per tile
 constexpr int WS_N = 256;          // output columns (4 waves x 64)
 constexpr int WS_KMAIN = 256;      // K of the main segment
-constexpr int WS_MAX_MINOR = 2;    // narrow K-segments beside it, one 8-k MFMA step each
+constexpr int WS_MAX_MINOR = 2;    // narrow K-segments beside it (K <= 32 each: ceil(K / 8) MFMA steps of 8 k)
+constexpr int WS_MAX_SLOTS = 8;    // 8-k steps of all narrow segments together
 constexpr int WS_MAX_INST = 16;    // the table travels in the kernel arguments (scalar loads): 16 x 144 B + header < 4 KiB
 
 struct WsInst {
@@ -32,6 +33,8 @@ struct WsArgs {
   int M;                     // rows per instance, multiple of 32
   int ninst, blocks_per_inst;
   int nminor, kminor[WS_MAX_MINOR];
+  int nslot_loop, nslot_tail;          // 8-k steps of the narrow segments: inside a tile's K loop / of a two-output launch's last segment
+  int slot_seg[WS_MAX_SLOTS], slot_k0[WS_MAX_SLOTS];   // slot -> (narrow segment, its first k)
   int lda[1 + WS_MAX_MINOR], ldw[1 + WS_MAX_MINOR];
   int dual;                  // 1: C = f(all segments but the last), C2 = f(all)
   int hf_q, hf_ldw;          // head fusion: outputs per row (2), 0 = off

@@ -136,16 +136,19 @@ __device__ __forceinline__ float ws_sum_halves(float x) {   // x[l] + x[l ^ 32] 
   return a + b;
 }
 
-template <int NMINOR, bool DUAL, int HFQ>
+// NSL: narrow 8-k steps inside a tile's K loop (a narrow segment of K <= 32 columns takes ceil(K / 8) of them: the action
+// columns of critic layer 0 - 6 at config 2, 17 at config 4).  NST: steps of the LAST narrow segment of a two-output launch,
+// applied to the previous tile between its two outputs (0: one output).  HFQ: head-fusion outputs per row (0 = off).
+template <int NSL, int NST, int HFQ>
 __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
-  static_assert(!DUAL || NMINOR >= 1, "a dual launch emits before its last narrow segment");
   static_assert(HFQ == 0 || HFQ == 2, "head-fusion riders: 2 outputs per row");
-  extern __shared__ __attribute__((aligned(16))) float lds[];   // two images [32][P]
+  constexpr bool DUAL = NST > 0;
+  constexpr int NS = NSL + NST;
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // two images [32][P], then the per-wave constants
   WS_STAMP_DECL;
   WS_STAMP(0);
-  constexpr int P = WS_KMAIN + 8 * NMINOR + 4, IMG = WS_BM * P;   // (P / 4) odd: conflict-free ds_read_b128
-  constexpr int NM_LOOP = DUAL ? NMINOR - 1 : NMINOR;             // narrow steps inside a tile's K loop
-  constexpr int LD = WS_N;                                        // row pitch of the outputs (compile-time)
+  constexpr int P = WS_KMAIN + 8 * NS + 4, IMG = WS_BM * P;   // (P / 4) odd: conflict-free ds_read_b128
+  constexpr int LD = WS_N;                                    // row pitch of the outputs (compile-time)
   const int tid = threadIdx.x, lane = tid & 63, wave = ws_uni(tid >> 6);
   const int li = lane & 31, lh = lane >> 5, n0 = wave * 64;
 
@@ -161,14 +164,13 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
   const float *A0 = ws_uni(I.A[0]);
   float *const C = ws_uni(I.C), *const C2 = ws_uni(I.C2);
   // DUAL launches may mix two-output instances with plain ones (critic layer 0: online + frozen pass / target pass): a plain
-  // instance has no second output and no last narrow segment - its slot is staged from the first one's memory and never used
+  // instance has no second output and no last narrow segment - those slots are staged from the first segment's memory and
+  // never used
   const bool has2 = DUAL && C2 != nullptr;
-  const float *An[WS_MAX_MINOR] = {ws_uni(I.A[1]), (DUAL && !has2) ? ws_uni(I.A[1]) : ws_uni(I.A[2])};
   float *const hf_out = ws_uni(I.hf_out), *const hf_out2 = ws_uni(I.hf_out2);
   const int lda0 = a.lda[0];
 
-  // ---- stationary operands
-  // main weights: wb[tn][s] = W0[n0 + 32 tn + li][32 (s / 4) + 16 lh + 4 (s % 4) .. + 3]
+  // ---- stationary main weights: wb[tn][s] = W0[n0 + 32 tn + li][32 (s / 4) + 16 lh + 4 (s % 4) .. + 3]
   v4f wb[2][NSTEP];
   {
     const float *W0 = ws_uni(I.W[0]);
@@ -179,25 +181,16 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
       for (int s = 0; s < NSTEP; ++s)
         wb[tn][s] = *(gcf4)(W0 + (long long)(n0 + 32 * tn + li) * ldw0 + 32 * (s >> 2) + 16 * lh + 4 * (s & 3));
   }
-  // narrow segments: one step each, k = 4 lh + c (zero beyond the segment's K)
-  v4f wn[NMINOR > 0 ? NMINOR : 1][2];
-#pragma unroll
-  for (int s = 0; s < NMINOR; ++s) {
-    const float *Ws = ws_uni((DUAL && !has2 && s == NMINOR - 1) ? I.W[1] : I.W[1 + s]);
-    const int Ks = a.kminor[s], ldw = a.ldw[1 + s];
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int k = 4 * lh + c, kc = k < Ks ? k : Ks - 1;   // clamped, unconditional loads
-        const float x = ((gcf)Ws)[(long long)(n0 + 32 * tn + li) * ldw + kc];
-        wn[s][tn][c] = k < Ks ? x : 0.f;
-      }
-  }
-  // Per-wave constants in LDS (behind the images), read one register quad ahead of their use:
+  // Per-wave constants in LDS (behind the images), read shortly before their use:
   //   bias of the columns 8 q + 4 lh + c of each column tile                                        [wave][lh][tn][q][c]
   //   head-fusion rider weights: lane 4 b + i holds row i (< HFQ) of the head over those columns    [wave][i][lh][tn][q][c]
-  float *const cbias = lds + 2 * IMG, *const cwh = cbias + 4 * 2 * 32;
+  //   narrow-step weights: slot j covers k = k0_j + 4 lh + c of its segment (zero beyond its K)     [wave][slot][tn][lane][c]
+  float *const cbias = lds + 2 * IMG, *const cwh = cbias + 4 * 2 * 32, *const cnw = cwh + 4 * 8 * 32;
+  // slot j of the narrow steps: segment 0 (k = 8 j ..) inside the K loop, segment 1 (k = 8 (j - NSL) ..) in the tail
+  const float *Aseg[2] = {ws_uni(I.A[1]), ws_uni((DUAL && has2) ? I.A[2] : I.A[1])};
+  const int ldaseg[2] = {a.lda[1], a.lda[2]};
+  bool m_ok[NS > 0 ? NS : 1];
+  const int m_r = tid >> 3, m_c = tid & 7;   // narrow staging: thread -> (row tid / 8, column tid % 8) of every [32, 8] slot
   {
     const float *bias = ws_uni(I.bias);
 #pragma unroll
@@ -216,28 +209,37 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
           *reinterpret_cast<v4f *>(cwh + ((wave * 4 + i) * 2 + lh) * 32 + (tn * 4 + q) * 4) = i < HFQ ? x : v4f{0.f, 0.f, 0.f, 0.f};
         }
     }
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      // (a plain instance of a two-output launch: its tail slots read the first segment's memory and are never used)
+      const int sgl = j < NSL ? 0 : 1, k0 = 8 * (j < NSL ? j : j - NSL);
+      const int sg = (DUAL && !has2) ? 0 : sgl;
+      const int Ks = a.kminor[sgl], ldw = a.ldw[1 + sg];
+      const float *Ws = ws_uni(I.W[1 + sg]);
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        v4f w;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int k = k0 + 4 * lh + c, kc = k < Ks ? k : Ks - 1;   // clamped, unconditional loads
+          const float x = ((gcf)Ws)[(long long)(n0 + 32 * tn + li) * ldw + kc];
+          w[c] = k < Ks ? x : 0.f;
+        }
+        *reinterpret_cast<v4f *>(cnw + (((wave * (NS > 0 ? NS : 1) + j) * 2 + tn) * 64 + lane) * 4) = w;
+      }
+      m_ok[j] = k0 + m_c < Ks;
+    }
     // (lanes that share a slot write the same values; read back by this wave only, after its s_waitcnt below)
   }
   const unsigned cb_addr = ws_lds_addr(cbias) + (unsigned)((wave * 2 + lh) * 32) * 4u;
   const unsigned cw_addr = ws_lds_addr(cwh) + (unsigned)(((wave * 4 + (lane & 3)) * 2 + lh) * 32) * 4u;
+  const unsigned nw_addr = ws_lds_addr(cnw) + (unsigned)((wave * (NS > 0 ? NS : 1) * 2 * 64 + lane) * 4) * 4u;   // + (2 slot + tn) KiB
 
   // ---- addresses
   const unsigned abase = ws_lds_addr(lds) + (unsigned)(li * P + 16 * lh) * 4u;                 // main fragments: k = 16 lh + ...
   const unsigned nbase = ws_lds_addr(lds) + (unsigned)(li * P + WS_KMAIN + 4 * lh) * 4u;       // narrow fragments: k = 4 lh + c
   const unsigned vo_c = (unsigned)(li * LD + 4 * lh);   // lane offset of a row's quad in an output tile
-  // narrow staging: thread -> (row tid / 8, column tid % 8) of every segment's [32, 8] slot
-  const int m_r = tid >> 3, m_c = tid & 7;
-  int m_src[NMINOR > 0 ? NMINOR : 1];
-  bool m_ok[NMINOR > 0 ? NMINOR : 1];
-#pragma unroll
-  for (int s = 0; s < NMINOR; ++s) {
-    m_ok[s] = m_c < a.kminor[s];
-    m_src[s] = m_r * a.lda[1 + s] + (m_ok[s] ? m_c : 0);
-  }
   float *const m_dst = lds + m_r * P + WS_KMAIN + m_c;
-  int m_tile[NMINOR > 0 ? NMINOR : 1];   // floats between consecutive tiles of a narrow input
-#pragma unroll
-  for (int s = 0; s < NMINOR; ++s) m_tile[s] = ws_uni(WS_BM * a.lda[1 + s]);
 
   auto dma_row = [&](const float *src_tile, int img, int r) __attribute__((always_inline)) {   // one row: 1 KiB global -> LDS
     __builtin_amdgcn_global_load_lds((glb_vp)(src_tile + (long long)r * lda0 + lane * 4), (lds_vp)(lds + img * IMG + r * P), 16, 0, 0);
@@ -245,8 +247,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
 
   f32x16 acc[2][2];   // [set][tn]: the tile being accumulated and the previous one (being finished)
   v4f hacc[2], hacc2[2];   // rider sums per column tile (second output of a dual launch: hacc2)
-  v4f pa = {0.f, 0.f, 0.f, 0.f};   // DUAL: fragment of the last narrow segment of the previous tile
-  float stm[NMINOR > 0 ? NMINOR : 1];
+  float stm[NS > 0 ? NS : 1];
 
   // constants of register quad kq = 4 tn + q (bias, rider weights): requested one quad ahead of their use
   v4f cb[2], cw[2];
@@ -254,6 +255,14 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
     constexpr int kq = decltype(kqc)::value & 7;
     ws_rd128<kq * 16>(cb[kq & 1], cb_addr);
     if constexpr (HFQ > 0) ws_rd128<kq * 16>(cw[kq & 1], cw_addr);
+  };
+  // operands of narrow step j (fragment from image IMX, the slot's weights): requested one step ahead of their use
+  v4f nfr[2], nw0[2], nw1[2];
+  auto read_narrow = [&](auto jc, auto imc) __attribute__((always_inline)) {
+    constexpr int j = decltype(jc)::value, IMX = decltype(imc)::value;
+    ws_rd128<IMX * IMG * 4 + 8 * j * 4>(nfr[j & 1], nbase);
+    ws_rd128<(2 * j) * 1024>(nw0[j & 1], nw_addr);
+    ws_rd128<(2 * j + 1) * 1024>(nw1[j & 1], nw_addr);
   };
   // finish + store one register quad of a finished set; the rider takes the finished values as its B operand
   auto quad = [&](f32x16 (&pv)[2], float *Cout, v4f (&hs)[2], int pblk, int kq) __attribute__((always_inline)) {
@@ -280,6 +289,17 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
       }
     }
   };
+  // the NST tail steps of a two-output instance: (previous tile) += last narrow segment, fragments from ITS image IMX
+  // (intact until this tile's prefetch starts at step 16); step 0's operands were requested a main step earlier
+  auto tail_steps = [&](f32x16 (&pv)[2], auto imc) __attribute__((always_inline)) {
+    sfor<0, NST>([&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      if constexpr (j + 1 < NST) read_narrow(std::integral_constant<int, NSL + j + 1>{}, imc);
+      if constexpr (j > 0) { if constexpr (j + 1 < NST) ws_lgkm_wait<3>(); else ws_lgkm_wait<0>(); }
+      asm volatile("" : "+v"(nfr[(NSL + j) & 1]), "+v"(nw0[(NSL + j) & 1]), "+v"(nw1[(NSL + j) & 1]));
+      ws_step_v(pv[0], pv[1], nw0[(NSL + j) & 1], nw1[(NSL + j) & 1], nfr[(NSL + j) & 1]);
+    });
+  };
 
   // One tile: K loop into `ac` from image IM; the previous tile `pv` (block pblk) is finished and stored, the rows of the
   // next tile (block nxt) are fetched into the other image.
@@ -291,17 +311,13 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
     // narrow writes before it arrived here)
     asm volatile("s_barrier" ::: "memory");
     const float *nsrc = ws_uni(A0 + (long long)nxt * WS_BM * lda0);
-    const v4f pa_prev = pa;
-    v4f af[2], nf[NM_LOOP > 0 ? NM_LOOP : 1];
+    v4f af[2];
     ws_rd128<IOFF>(af[0], abase);
-#pragma unroll
-    for (int s = 0; s < NM_LOOP; ++s) ws_rd128<IOFF>(nf[s], nbase + (unsigned)(8 * s) * 4u);
-    if constexpr (DUAL) ws_rd128<IOFF>(pa, nbase + (unsigned)(8 * (NMINOR - 1)) * 4u);
     if constexpr (HP) read_consts(std::integral_constant<int, 0>{});
     sfor<0, NSTEP>([&](auto sc) __attribute__((always_inline)) {
       constexpr int s = decltype(sc)::value;
-      // fragment of the next step requested; everything older (this step's fragment, the constants requested during the
-      // previous step) has arrived: LDS operations complete in order
+      // fragment of the next step requested; everything older (this step's fragment, the constants / narrow operands
+      // requested during the previous step) has arrived: LDS operations complete in order
       if constexpr (s + 1 < NSTEP) {
         constexpr int s1 = s + 1;
         ws_rd128<IOFF + (s1 >> 2) * 128 + (s1 & 3) * 16>(af[s1 & 1], abase);
@@ -327,10 +343,11 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
           if constexpr (s == 9) hf_store(hacc, hf_out, pblk);
         } else {
           if constexpr (s == 10) hf_store(hacc, hf_out, pblk);
-          if constexpr (s >= 8 && s <= 18) {
+          if constexpr (s >= 7 && s <= 18) {
             if (has2) {   // (uniform: the instance's second output)
+              if constexpr (s == 7) read_narrow(std::integral_constant<int, NSL>{}, std::integral_constant<int, IM ^ 1>{});
               if constexpr (s == 8) {
-                ws_step_v(pv[0], pv[1], wn[NMINOR - 1][0], wn[NMINOR - 1][1], pa_prev);   // the previous tile becomes its second output
+                tail_steps(pv, std::integral_constant<int, IM ^ 1>{});   // the previous tile becomes its second output
                 read_consts(std::integral_constant<int, 8>{});
               }
               if constexpr (s >= 9 && s < 17) {
@@ -347,20 +364,27 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
       }
       if constexpr (s == 12) {
 #pragma unroll
-        for (int u = 0; u < NMINOR; ++u) stm[u] = ((gcf)(An[u] + (long long)nxt * m_tile[u]))[m_src[u]];
+        for (int u = 0; u < NS; ++u) {
+          const int sg = u < NSL ? 0 : 1, k0 = 8 * (u < NSL ? u : u - NSL), ld = ldaseg[(DUAL && !has2) ? 0 : sg];
+          stm[u] = ((gcf)(Aseg[sg] + (long long)nxt * WS_BM * ld))[m_r * ld + (m_ok[u] ? k0 + m_c : 0)];
+        }
       }
       if constexpr (s >= 16 && s < 16 + WS_BM / 4) dma_row(nsrc, IM ^ 1, wave + 4 * (s - 16));
       if constexpr (s == 27) {
 #pragma unroll
-        for (int u = 0; u < NMINOR; ++u) m_dst[(IM ^ 1) * IMG + 8 * u] = m_ok[u] ? stm[u] : 0.f;
+        for (int u = 0; u < NS; ++u) m_dst[(IM ^ 1) * IMG + 8 * u] = m_ok[u] ? stm[u] : 0.f;
       }
+      if constexpr (NSL > 0 && s == NSTEP - 1) read_narrow(std::integral_constant<int, 0>{}, imgc);   // the K loop's first narrow step
       asm volatile("" ::: "memory");   // the memory operations of a step stay in their step
     });
-#pragma unroll
-    for (int s = 0; s < NM_LOOP; ++s) {
-      asm volatile("" : "+v"(nf[s]));
-      ws_step_v(ac[0], ac[1], wn[s][0], wn[s][1], nf[s]);
-    }
+    // ---- the narrow steps of this tile
+    sfor<0, NSL>([&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      if constexpr (j + 1 < NSL) { read_narrow(std::integral_constant<int, j + 1>{}, imgc); ws_lgkm_wait<3>(); }
+      else ws_lgkm_wait<0>();
+      asm volatile("" : "+v"(nfr[j & 1]), "+v"(nw0[j & 1]), "+v"(nw1[j & 1]));
+      ws_step_v(ac[0], ac[1], nw0[j & 1], nw1[j & 1], nfr[j & 1]);
+    });
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's part of the next image has landed
   };
   using T = std::true_type;
@@ -375,8 +399,9 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
 #pragma unroll
     for (int u = 0; u < WS_BM / 4; ++u) dma_row(src, 0, wave + 4 * u);
 #pragma unroll
-    for (int u = 0; u < NMINOR; ++u) {
-      const float x = ((gcf)(An[u] + (long long)blk * m_tile[u]))[m_src[u]];
+    for (int u = 0; u < NS; ++u) {
+      const int sg = u < NSL ? 0 : 1, k0 = 8 * (u < NSL ? u : u - NSL), ld = ldaseg[(DUAL && !has2) ? 0 : sg];
+      const float x = ((gcf)(Aseg[sg] + (long long)blk * WS_BM * ld))[m_r * ld + (m_ok[u] ? k0 + m_c : 0)];
       m_dst[8 * u] = m_ok[u] ? x : 0.f;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -401,8 +426,8 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
     prv = blk; blk += stride; set = 1;
   }
   WS_STAMP(3);
-  // ---- the last tile's result, not overlapped
-  auto flush = [&](f32x16 (&pv)[2]) __attribute__((always_inline)) {
+  // ---- the last tile's result, not overlapped.  Its image is still in place: image (set ^ 1) - the last block ran on it
+  auto flush = [&](f32x16 (&pv)[2], auto imc) __attribute__((always_inline)) {
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // MFMA results -> VALU readers
     ws_anchor(pv[0], pv[1]);
     sfor<0, 8>([&](auto kc) __attribute__((always_inline)) {
@@ -412,7 +437,11 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
       quad(pv, C, hacc, prv, decltype(kc)::value);
     });
     if (DUAL && has2) {
-      ws_step_v(pv[0], pv[1], wn[NMINOR - 1][0], wn[NMINOR - 1][1], pa);   // pa: read at the start of this tile's K loop
+      if constexpr (DUAL) {
+        read_narrow(std::integral_constant<int, NSL>{}, imc);
+        ws_lgkm_wait<0>();
+        tail_steps(pv, imc);
+      }
       asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
       ws_anchor(pv[0], pv[1]);
       sfor<0, 8>([&](auto kc) __attribute__((always_inline)) {
@@ -426,8 +455,8 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
     hf_store(hacc, hf_out, prv);
     if (DUAL && has2) hf_store(hacc2, hf_out2, prv);
   };
-  if (set == 1) flush(acc[0]);
-  else flush(acc[1]);
+  if (set == 1) flush(acc[0], I0());
+  else flush(acc[1], I1());
   WS_STAMP(4);
   WS_STAMP_OUT;
 }
@@ -457,12 +486,13 @@ __device__ __forceinline__ float ws_sum32(float x) {   // sum over the 32 lanes 
 
 // PLAIN: no gate and no column sums (C = A0 W0 + dY W1: one network's share of an input gradient that several networks add up
 // to, e.g. d state of the critics), K-strided weights of any row pitch.
-template <bool FUSE, bool PLAIN = false>
+// NS: 8-k steps of the narrow segment dY (2 columns at config 2: one step; 25 at config 4: four).
+template <bool FUSE, bool PLAIN = false, int NS = 1>
 __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
   static_assert(!(FUSE && PLAIN), "the fused head dgrad belongs to a gated layer");
-  extern __shared__ __attribute__((aligned(16))) float lds[];   // two images [32][P]
-  constexpr int NMINOR = 1;
-  constexpr int P = WS_KMAIN + 8 * NMINOR + 4, IMG = WS_BM * P;
+  static_assert(!FUSE || NS == 1, "the fused head dgrad reads dY as two columns");
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // two images [32][P], column-sum accumulators, narrow weights
+  constexpr int P = WS_KMAIN + 8 * NS + 4, IMG = WS_BM * P;
   constexpr int LD = WS_N;
   const int tid = threadIdx.x, lane = tid & 63, wave = ws_uni(tid >> 6);
   const int li = lane & 31, lh = lane >> 5, n0 = wave * 64;
@@ -494,19 +524,27 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) wb[tn][s][c] = W0[(32 * (s >> 2) + 4 * (s & 3) + c) * ldw0 + 32 * tn];
   }
-  v4f wn[2];
+  // narrow-step weights (K-strided: element (k, n) at W1[k*ldw + n]; zero beyond dY's K) in LDS, read shortly before their
+  // use: [wave][slot][tn][lane][c], behind the images and the column-sum accumulators
+  float *const cnw = lds + 2 * IMG + (PLAIN ? 0 : 32 * 256);
   {
     const float *W1 = ws_uni(I.W[1]);
     const int Ks = a.kminor[0], ldw = a.ldw[1];
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn)
+    for (int j = 0; j < NS; ++j)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int k = 4 * lh + c, kc = k < Ks ? k : Ks - 1;
-        const float x = ((gcf)W1)[(long long)kc * ldw + n0 + 32 * tn + li];
-        wn[tn][c] = k < Ks ? x : 0.f;
+      for (int tn = 0; tn < 2; ++tn) {
+        v4f w;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int k = 8 * j + 4 * lh + c, kc = k < Ks ? k : Ks - 1;
+          const float x = ((gcf)W1)[(long long)kc * ldw + n0 + 32 * tn + li];
+          w[c] = k < Ks ? x : 0.f;
+        }
+        *reinterpret_cast<v4f *>(cnw + (((wave * NS + j) * 2 + tn) * 64 + lane) * 4) = w;
       }
   }
+  const unsigned nw_addr = ws_lds_addr(cnw) + (unsigned)((wave * NS * 2 * 64 + lane) * 4) * 4u;
   // FUSE: head weight rows q = 0, 1 over this lane's 4 columns of a staged row
   v4f fw0 = {0.f, 0.f, 0.f, 0.f}, fw1 = {0.f, 0.f, 0.f, 0.f};
   if constexpr (FUSE) {
@@ -519,8 +557,13 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
   const unsigned nbase = ws_lds_addr(lds) + (unsigned)(li * P + WS_KMAIN + 4 * lh) * 4u;
   const unsigned vo_c = (unsigned)(li * LD + 4 * lh);
   const int m_r = tid >> 3, m_c = tid & 7;
-  const bool m_ok = m_c < a.kminor[0];
-  const int m_src = m_r * lda1 + (m_ok ? m_c : 0);
+  bool m_ok[NS];
+  int m_src[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    m_ok[j] = 8 * j + m_c < a.kminor[0];
+    m_src[j] = m_r * lda1 + (m_ok[j] ? 8 * j + m_c : 0);
+  }
   float *const m_dst = lds + m_r * P + WS_KMAIN + m_c;
   const int m_tile = ws_uni(WS_BM * lda1);
 
@@ -547,7 +590,14 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
   v4f fcs = {0.f, 0.f, 0.f, 0.f};   // FUSE: running column sums of the formed A0 over the rows this thread stages
   v4f sh[4];                        // FUSE: row pieces in flight (fz_h)
   v2f sdz = {0.f, 0.f};             // FUSE: dY of this wave's 8 rows of the tile in flight, row u in lane u
-  float stm = 0.f;
+  float stm[NS];
+  v4f nfr[2], nw0[2], nw1[2];       // operands of a narrow step (fragment, the slot's weights), requested a step ahead
+  auto read_narrow = [&](auto jc, auto imc) __attribute__((always_inline)) {
+    constexpr int j = decltype(jc)::value, IMX = decltype(imc)::value;
+    ws_rd128<IMX * IMG * 4 + 8 * j * 4>(nfr[j & 1], nbase);
+    ws_rd128<(2 * j) * 1024>(nw0[j & 1], nw_addr);
+    ws_rd128<(2 * j + 1) * 1024>(nw1[j & 1], nw_addr);
+  };
   v4f rq[3];                        // gate references of the quads in flight (requested two steps ahead: an L2 hit takes longer than one)
 
   // FUSE: one staged row piece: h -> LeakyReLU'(h) * (dY . Wh), k_head_dgrad's order and rounding (fma chain over q)
@@ -602,9 +652,8 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
     gf4 nout_w = (gf4)ws_uni(fz_out + ((long long)nxt * WS_BM + 8 * wave + 4) * LD);
     gf cprev = (gf)ws_uni(C + (long long)pblk * WS_BM * LD + n0);
     gcf rprev = PLAIN ? nullptr : (gcf)ws_uni(ref + (long long)pblk * WS_BM * LD + n0);
-    v4f af[2], nf;
+    v4f af[2];
     ws_rd128<IOFF>(af[0], abase);
-    ws_rd128<IOFF>(nf, nbase);
     if constexpr (HP) { ref_load(rq[0], rprev, 0); ref_load(rq[1], rprev, 1); }
     if constexpr (HP) cs_read(std::integral_constant<int, 0>{});
     sfor<0, NSTEP>([&](auto sc) __attribute__((always_inline)) {
@@ -660,12 +709,24 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
       } else {
         if constexpr (s >= 16 && s < 16 + WS_BM / 4) dma_row(nsrc, IM ^ 1, wave + 4 * (s - 16));
       }
-      if constexpr (s == 8) stm = ((gcf)ndz)[m_src];
-      if constexpr (s == 26) m_dst[(IM ^ 1) * IMG] = m_ok ? stm : 0.f;
+      if constexpr (s == 8) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) stm[j] = ((gcf)ndz)[m_src[j]];
+      }
+      if constexpr (s == 26) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) m_dst[(IM ^ 1) * IMG + 8 * j] = m_ok[j] ? stm[j] : 0.f;
+      }
+      if constexpr (s == NSTEP - 1) read_narrow(std::integral_constant<int, 0>{}, imgc);   // the first narrow step's operands
       asm volatile("" ::: "memory");
     });
-    asm volatile("" : "+v"(nf));
-    ws_step_v(ac[0], ac[1], wn[0], wn[1], nf);
+    sfor<0, NS>([&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      if constexpr (j + 1 < NS) { read_narrow(std::integral_constant<int, j + 1>{}, imgc); ws_lgkm_wait<3>(); }
+      else ws_lgkm_wait<0>();
+      asm volatile("" : "+v"(nfr[j & 1]), "+v"(nw0[j & 1]), "+v"(nw1[j & 1]));
+      ws_step_v(ac[0], ac[1], nw0[j & 1], nw1[j & 1], nfr[j & 1]);
+    });
     // this wave's part of the next image has landed: LDS-DMA pieces (vmcnt) or, FUSE, its own LDS writes only - the
     // global stores of the tile need not have completed
 #ifndef WS_FZ_WAIT
@@ -699,8 +760,11 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
 #pragma unroll
       for (int u = 0; u < WS_BM / 4; ++u) dma_row(src, 0, wave + 4 * u);
     }
-    const float x = ((gcf)(A1 + (long long)blk * m_tile))[m_src];
-    m_dst[0] = m_ok ? x : 0.f;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      const float x = ((gcf)(A1 + (long long)blk * m_tile))[m_src[j]];
+      m_dst[8 * j] = m_ok[j] ? x : 0.f;
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   }
   int nxt = blk + stride < nblk ? blk + stride : blk;
@@ -794,6 +858,7 @@ bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
   } else {
     if (!p0.bias || p0.colsum || p0.ref || fz) return false;
     if (dual && (p0.emit_seg != p0.nseg - 2 || main0 == p0.nseg - 1 || !p0.C2 || p0.ldc2 != WS_N || nminor != 2)) return false;
+    if (!dual && nminor > 1) return false;
     if (p0.hf_w && p0.hf_q != 2) return false;
   }
   args.M = p0.M; args.ninst = nprob; args.blocks_per_inst = p0.M / WS_BM;
@@ -823,7 +888,7 @@ bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
       const GemmSeg &sg = p.seg[s], &s0 = p0.seg[s];
       if (!sg.a_kc || sg.b_kc != (grad ? 0 : 1) || sg.K != s0.K || sg.lda != s0.lda || sg.ldb != s0.ldb) return false;
       const int slot = s == main0 ? 0 : 1 + m++;
-      if (slot > 0 && (sg.K < 1 || sg.K > 8)) return false;
+      if (slot > 0 && (sg.K < 1 || sg.K > 32)) return false;
       if (slot == 0 && !fz && (sg.lda % 4 || !aligned(sg.A, 16))) return false;   // rows move as 16-byte pieces
       if (slot > 0 && fz && !aligned(sg.A, 8)) return false;
       I.A[slot] = sg.A; I.W[slot] = sg.B;
@@ -842,6 +907,27 @@ bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
       const int slot = s == main0 ? 0 : 1 + m++;
       args.lda[slot] = p0.seg[s].lda; args.ldw[slot] = p0.seg[s].ldb;
       if (slot > 0) args.kminor[slot - 1] = p0.seg[s].K;
+    }
+    // 8-k steps: the narrow segments in order; a two-output launch's last segment is its tail
+    int ns = 0;
+    for (int sg = 0; sg < nminor; ++sg) {
+      const int steps = (args.kminor[sg] + 7) / 8;
+      const bool tail = dual && sg == nminor - 1;
+      for (int j = 0; j < steps; ++j) {
+        if (ns >= WS_MAX_SLOTS) return false;
+        args.slot_seg[ns] = sg; args.slot_k0[ns] = 8 * j;
+        ++ns;
+      }
+      (tail ? args.nslot_tail : args.nslot_loop) += steps;
+    }
+    // instantiated forms (wstat_launch)
+    const int L = args.nslot_loop, Tn = args.nslot_tail;
+    if (grad) {
+      if (!((L == 1) || (L == 4 && !fz))) return false;
+    } else {
+      const bool small = (L == 0 && Tn == 0) || (L == 1 && Tn == 0) || (L == 1 && Tn == 1);
+      const bool wide = (L == 3 && Tn == 0) || (L == 3 && Tn == 3);
+      if (!(small || (wide && !args.hf_q))) return false;
     }
   }
   // workgroups per instance: a share of the CUs in proportion to the instance's work (at most one per tile)
@@ -906,26 +992,32 @@ static hipError_t ws_launch_kernel(K kern, int lds_bytes, bool (&attr)[64], cons
   hipLaunchKernelGGL(kern, dim3(a.wg_first[a.ninst]), dim3(256), lds_bytes, s, a);
   return hipGetLastError();
 }
-template <int NMINOR, bool DUAL, int HFQ>
+template <int NSL, int NST, int HFQ>
 static hipError_t ws_launch(const WsArgs &a, hipStream_t s) {
   static bool attr[64];
-  constexpr int lds_bytes = (2 * WS_BM * (WS_KMAIN + 8 * NMINOR + 4) + 4 * 2 * 32 + 4 * 8 * 32) * 4;   // two images + per-wave constants
-  return ws_launch_kernel(&k_wstat<NMINOR, DUAL, HFQ>, lds_bytes, attr, a, s);
+  // two images + per-wave constants (bias, rider weights, 8 KiB of narrow weights per slot)
+  constexpr int lds_bytes = (2 * WS_BM * (WS_KMAIN + 8 * (NSL + NST) + 4) + 4 * 2 * 32 + 4 * 8 * 32 + (NSL + NST) * 2048) * 4;
+  return ws_launch_kernel(&k_wstat<NSL, NST, HFQ>, lds_bytes, attr, a, s);
 }
-template <bool FUSE, bool PLAIN>
+template <bool FUSE, bool PLAIN, int NS>
 static hipError_t ws_launch_grad(const WsArgs &a, hipStream_t s) {
   static bool attr[64];
-  constexpr int lds_bytes = 2 * WS_BM * (WS_KMAIN + 8 + 4) * 4 + (PLAIN ? 0 : 32 * 256 * 4);   // images + column-sum accumulators
-  return ws_launch_kernel(&k_wstat_grad<FUSE, PLAIN>, lds_bytes, attr, a, s);
+  // images + column-sum accumulators + narrow weights
+  constexpr int lds_bytes = 2 * WS_BM * (WS_KMAIN + 8 * NS + 4) * 4 + (PLAIN ? 0 : 32 * 256 * 4) + NS * 2048 * 4;
+  return ws_launch_kernel(&k_wstat_grad<FUSE, PLAIN, NS>, lds_bytes, attr, a, s);
 }
 
 hipError_t wstat_launch(const WsArgs &a, hipStream_t s) {
-  if (a.grad == 2) return ws_launch_grad<false, true>(a, s);
-  if (a.grad) return a.fz ? ws_launch_grad<true, false>(a, s) : ws_launch_grad<false, false>(a, s);
-  if (a.dual) return a.hf_q ? ws_launch<2, true, 2>(a, s) : ws_launch<2, true, 0>(a, s);
-  if (a.nminor == 0) return a.hf_q ? ws_launch<0, false, 2>(a, s) : ws_launch<0, false, 0>(a, s);
-  if (a.nminor == 1) return a.hf_q ? ws_launch<1, false, 2>(a, s) : ws_launch<1, false, 0>(a, s);
-  return a.hf_q ? ws_launch<2, false, 2>(a, s) : ws_launch<2, false, 0>(a, s);
+  const int L = a.nslot_loop, T = a.nslot_tail;
+  if (a.grad == 2) return L == 4 ? ws_launch_grad<false, true, 4>(a, s) : ws_launch_grad<false, true, 1>(a, s);
+  if (a.grad) {
+    if (a.fz) return ws_launch_grad<true, false, 1>(a, s);
+    return L == 4 ? ws_launch_grad<false, false, 4>(a, s) : ws_launch_grad<false, false, 1>(a, s);
+  }
+  if (L == 3) return T == 3 ? ws_launch<3, 3, 0>(a, s) : ws_launch<3, 0, 0>(a, s);
+  if (L == 0) return a.hf_q ? ws_launch<0, 0, 2>(a, s) : ws_launch<0, 0, 0>(a, s);
+  if (T == 1) return a.hf_q ? ws_launch<1, 1, 2>(a, s) : ws_launch<1, 1, 0>(a, s);
+  return a.hf_q ? ws_launch<1, 0, 2>(a, s) : ws_launch<1, 0, 0>(a, s);
 }
 
 }  // namespace fdql

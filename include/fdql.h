@@ -398,6 +398,13 @@ int fdql_test_rowgemm(const float *A0, const float *A1, int32_t k1, const float 
                       int32_t ks, int32_t grad, int32_t dual, int32_t planes, const float *fz_h, const float *fz_w, int32_t fz_ldw,
                       float *fz_colsum, void *stream);
 
+/* Test hook: one launch of the output-stationary weight-gradient kernel (csrc/wgrad.hip): nprob blocks
+ * dW[i] [256, ldw] = G[i]^T X[i] over M rows (G, X: [nprob * M, 256] row-major), block i's slab 0 at dW + i * 256 * ldw, the
+ * nslab K-split slabs slab_stride floats apart: every slab is written (a workgroup's partial result, or zeros) and their sum
+ * is the gradient (franQ: autograd's addmm backward of mlp.py:88-94).  Asynchronous on `stream`. */
+int fdql_test_wgrad_stat(const float *G, const float *X, float *dW, int32_t M, int32_t nprob, int32_t ldw, int32_t nslab,
+                         int64_t slab_stride, void *stream);
+
 /* Tuning hook: build of the GEMM main loop: 1 (default) = K-chunk 16 with next-step fragment prefetch, 0 = K-chunk 16
  * without it, 4 = K-chunk 8; 2 and 3 alias 0.  Affects speed only. */
 int fdql_debug_set_gemm_variant(int32_t variant);

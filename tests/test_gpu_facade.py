@@ -253,6 +253,13 @@ def test_agent_facade_life_cycle(dev, tmp_path):
     assert agent.iteration == 3 * len(read_heads)
     sc = agent.native.scalars()
     assert np.isfinite(sc["loss"]) and sc["step"] == 6
+    # two shards x a 3-buffer sample pool = 6 batch address sets: all of them stay in the agent's plan cache
+    built = agent.native.stats()["plans_built"]
+    assert built == 3 * len(read_heads)
+    for _ in range(6):
+        agent.train_step()
+    assert agent.native.stats()["plans_built"] == built
+    assert agent.native.scalars()["step"] == 18
     after = agent.state_dict()
     assert any(not torch.equal(before[k], after[k]) for k in before)
     action, hidden, info = agent.act({"obs_1d": torch.randn(7, 5), "exploit_mask": torch.zeros(7, 1, dtype=torch.bool)})

@@ -924,7 +924,7 @@ def test_graph_replay_matches_eager_launches(dev, T, B, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("wstat", ["1", "0"])
-@pytest.mark.parametrize("form", ["fwd", "fwd_hf", "fwd_minor_hf", "dgrad", "dgrad_fused", "dual_hf"])
+@pytest.mark.parametrize("form", ["fwd", "fwd_hf", "fwd_minor_hf", "dgrad", "dgrad_fused", "dual_hf", "fwd_wide", "dual_wide", "dgrad_wide"])
 @pytest.mark.parametrize("M,ninst", [(64, 1), (192, 3), (1280, 15), (12544, 10)])
 def test_rowgemm_forms(dev, form, M, ninst, wstat, monkeypatch):
     """The persistent row-block kernels through fdql_test_rowgemm against fp64 torch - the weight-stationary one
@@ -937,12 +937,15 @@ def test_rowgemm_forms(dev, form, M, ninst, wstat, monkeypatch):
     monkeypatch.setenv("FDQL_WSTAT", wstat)
     if M > 2000 and wstat == "0":
         pytest.skip("the large case is the weight-stationary kernel's")
+    wide = form.endswith("_wide")       # narrow blocks of 17 / 25 columns (config 4: act 17, 25 quantiles): 3 / 4 steps of 8
+    if wide and wstat == "0":
+        pytest.skip("narrow blocks beyond 8 columns are the weight-stationary kernel's")
     lib = nat.load(); st = nat.current_stream(dev)
     g = torch.Generator().manual_seed(7 + M + ninst)
     rnd = lambda *s: torch.randn(*s, generator=g)
-    R, Q, k1 = M * ninst, 2, 6
+    R, Q, k1 = M * ninst, (25 if form == "dgrad_wide" else 2), (17 if wide else 6)
     ks = form.startswith("dgrad")
-    dual, fused = form == "dual_hf", form == "dgrad_fused"
+    dual, fused = form in ("dual_hf", "dual_wide"), form == "dgrad_fused"
     bmm = lambda x, w, k: torch.bmm(x.double().view(ninst, M, k), w.double())
     A0, A1, A2, W1, W2, bias, ref, hfw, fzh, fzw = (None,) * 10
     if ks:
@@ -961,14 +964,14 @@ def test_rowgemm_forms(dev, form, M, ninst, wstat, monkeypatch):
     else:
         A0, W0, bias = rnd(R, 256), rnd(ninst, 256, 256) / 16, rnd(ninst, 256)      # W0 [n][k]
         pre = bmm(A0, W0.transpose(1, 2), 256) + bias.double()[:, None, :]
-        if form in ("fwd_minor_hf", "dual_hf"):
+        if form in ("fwd_minor_hf", "dual_hf", "fwd_wide", "dual_wide"):
             A1, W1 = rnd(R, k1), rnd(ninst, 256, k1)
             pre = pre + bmm(A1, W1.transpose(1, 2), k1)
         want = torch.nn.functional.leaky_relu(pre, 0.01)
         if dual:
             A2, W2 = rnd(R, k1), rnd(ninst, 256, k1)
             want2 = torch.nn.functional.leaky_relu(pre + bmm(A2, W2.transpose(1, 2), k1), 0.01)
-        if form != "fwd":
+        if form != "fwd" and not wide:
             hfw = rnd(ninst, Q, 300)
     d = lambda t: None if t is None else t.to(dev).contiguous()
     A0_d, A1_d, A2_d, W0_d, W1_d, W2_d, bias_d, ref_d, hfw_d, fzh_d, fzw_d = map(d, (A0, A1, A2, W0, W1, W2, bias, ref, hfw, fzh, fzw))
@@ -977,7 +980,7 @@ def test_rowgemm_forms(dev, form, M, ninst, wstat, monkeypatch):
     cs = torch.full((ninst, M // 64, 256), float("nan"), device=dev) if ks else None
     fcs = torch.full((ninst, M // 64, 256), float("nan"), device=dev) if fused else None
     hfo = torch.full((ninst, 8, M, Q), float("nan"), device=dev) if hfw is not None else None
-    hfo2 = torch.full((ninst, 8, M, Q), float("nan"), device=dev) if dual else None
+    hfo2 = torch.full((ninst, 8, M, Q), float("nan"), device=dev) if dual and hfw is not None else None
     rc = lib.fdql_test_rowgemm(nat.ptr(A0_d), nat.ptr(A1_d), 0 if A1 is None else A1.shape[1], nat.ptr(A2_d), 0 if A2 is None else k1,
                                nat.ptr(W0_d), 256, nat.ptr(W1_d), nat.ptr(W2_d), nat.ptr(bias_d), nat.ptr(C), nat.ptr(C2), nat.ptr(ref_d),
                                nat.ptr(cs), nat.ptr(hfw_d), 300, Q if hfw is not None else 0, nat.ptr(hfo), nat.ptr(hfo2), M, ninst,
@@ -1004,3 +1007,30 @@ def test_rowgemm_forms(dev, form, M, ninst, wstat, monkeypatch):
         assert close(hfo, torch.einsum("impc,iqpc->ipmq", want.view(ninst, M, 8, 32), w), 1e-4)
         if dual:
             assert close(hfo2, torch.einsum("impc,iqpc->ipmq", want2.view(ninst, M, 8, 32), w), 1e-4)
+    if wide and not ks:
+        assert float(want.abs().max()) > 1.0   # (the wide narrow block contributes: 17 columns of unit-variance weights)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,nprob,ldw,nslab", [(64, 1, 256, 4), (12544, 15, 256, 32), (2048, 5, 262, 32), (320, 3, 273, 8)])
+def test_wgrad_stat_blocks(dev, M, nprob, ldw, nslab):
+    """The output-stationary weight-gradient kernel (csrc/wgrad.hip) against fp64 torch: dW[i] = G[i]^T X[i] over M rows for
+    nprob 256 x 256 blocks, written as K-split slabs (one partial per workgroup of a block, the other slabs cleared) into
+    weight tensors of row pitch 256 / 262 (critic layer 0) / 273 (encoder head, 4-byte aligned rows): the slab sum is the
+    gradient, everything outside the blocks' columns stays untouched."""
+    from fastdeepqlearning_amd import _native as nat
+    lib = nat.load(); st = nat.current_stream(dev)
+    g = torch.Generator().manual_seed(M + nprob)
+    G = torch.randn(nprob * M, 256, generator=g)
+    X = torch.randn(nprob * M, 256, generator=g)
+    stride = nprob * 256 * ldw + 8
+    slabs = torch.full((nslab, stride), 7.0, device=dev)
+    G_d, X_d = G.to(dev), X.to(dev)
+    rc = lib.fdql_test_wgrad_stat(nat.ptr(G_d), nat.ptr(X_d), nat.ptr(slabs), M, nprob, ldw, nslab, stride, st)
+    assert rc == 0, lib.fdql_last_error().decode()
+    torch.cuda.synchronize()
+    got = slabs[:, :nprob * 256 * ldw].double().cpu().view(nslab, nprob, 256, ldw)
+    want = torch.bmm(G.double().view(nprob, M, 256).transpose(1, 2), X.double().view(nprob, M, 256))
+    err = float((got[..., :256].sum(0) - want).abs().max() / want.abs().max())
+    assert err < 2e-5, err
+    assert bool((got[..., 256:] == 7.0).all()) and bool((slabs[:, nprob * 256 * ldw:] == 7.0).all())   # nothing outside the blocks
