@@ -27,6 +27,9 @@ struct WsInst {
   float *colsum;                      // [workgroups of the instance, 256] column sums of C (one partial row per workgroup)
   const float *fz_h, *fz_w;           // fused head dgrad (GemmProblem::fz_*)
   float *fz_out, *fz_colsum;          // fz_colsum: [workgroups of the instance, 256]
+  // plain dgrad form: the networks whose shares are summed differ in their narrow segment (critic: dz, 2 columns of a head of
+  // pitch 774; actor: d logits, 12 columns of a head of pitch 512) and in the row pitch of their layer-0 weights
+  int k1, lda1, ldw0, ldw1;
 };
 
 struct WsArgs {

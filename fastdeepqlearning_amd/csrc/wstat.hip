@@ -509,13 +509,14 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
   const float *A1 = ws_uni(I.A[1]);
   const float *ref = PLAIN ? nullptr : ws_uni(I.ref);
   float *const C = ws_uni(I.C), *const fz_out = ws_uni(I.fz_out);
-  const int lda0 = FUSE ? LD : a.lda[0], lda1 = a.lda[1];
+  const int lda0 = FUSE ? LD : a.lda[0], lda1 = PLAIN ? ws_uni(I.lda1) : a.lda[1];
+  const int k1 = PLAIN ? ws_uni(I.k1) : a.kminor[0];   // dY's columns (plain form: per instance)
 
   // ---- stationary weights, K-strided: wb[tn][s][c] = W0[32 (s / 4) + 16 lh + 4 (s % 4) + c][n0 + 32 tn + li]
   v4f wb[2][NSTEP];
   {
     // (gated form: the row pitch LD of the K-strided weights is compile-time - every load is base + lane offset + immediate)
-    const int ldw0 = PLAIN ? a.ldw[0] : LD;
+    const int ldw0 = PLAIN ? ws_uni(I.ldw0) : LD;
     gcf W0 = (gcf)ws_uni(I.W[0]) + (16 * lh * ldw0 + n0 + li);
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn)
@@ -529,7 +530,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
   float *const cnw = lds + 2 * IMG + (PLAIN ? 0 : 32 * 256);
   {
     const float *W1 = ws_uni(I.W[1]);
-    const int Ks = a.kminor[0], ldw = a.ldw[1];
+    const int Ks = k1, ldw = PLAIN ? ws_uni(I.ldw1) : a.ldw[1];
 #pragma unroll
     for (int j = 0; j < NS; ++j)
 #pragma unroll
@@ -561,7 +562,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
   int m_src[NS];
 #pragma unroll
   for (int j = 0; j < NS; ++j) {
-    m_ok[j] = 8 * j + m_c < a.kminor[0];
+    m_ok[j] = 8 * j + m_c < k1;
     m_src[j] = m_r * lda1 + (m_ok[j] ? 8 * j + m_c : 0);
   }
   float *const m_dst = lds + m_r * P + WS_KMAIN + m_c;
@@ -837,6 +838,15 @@ bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
   bool dual = false;
   for (int i = 0; i < nprob; ++i)
     if (is_dual(probs[i])) { ref_i = i; dual = true; break; }
+  // plain dgrad problems (shares of an input gradient) may differ in their narrow segment: the widest one shapes the launch
+  bool all_plain = !dual;
+  for (int i = 0; i < nprob && all_plain; ++i) {
+    const GemmProblem &p = probs[i];
+    all_plain = p.epi == EPI_NONE && p.nseg == 2 && main_of(p) >= 0 && !p.seg[main_of(p)].b_kc && main_of(p) == main_of(probs[0]);
+  }
+  if (all_plain)
+    for (int i = 1; i < nprob; ++i)
+      if (probs[i].seg[1 - main_of(probs[i])].K > probs[ref_i].seg[1 - main_of(probs[ref_i])].K) ref_i = i;
   const GemmProblem &p0 = probs[ref_i];
   const int main0 = main_of(p0);
   if (main0 < 0 || p0.N != WS_N || p0.M % WS_BM || p0.M < WS_BM || p0.ksplit != 1 || p0.ldc != WS_N) return false;
@@ -851,6 +861,7 @@ bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
   const bool fz = p0.fz_h != nullptr;
   if (plain) {
     if (p0.bias || p0.ref || p0.colsum || p0.hf_w || dual || nminor != 1 || fz) return false;
+    // (instances may differ in dY's width / pitches: the launch takes the widest, WsInst carries each one's own)
   } else if (grad) {
     if (p0.bias || !p0.ref || p0.ldref != WS_N || !p0.colsum || p0.hf_w || dual || nminor != 1) return false;
     if (p0.seg[main0].ldb != WS_N) return false;   // K-strided weights: compile-time row pitch
@@ -886,8 +897,11 @@ bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
     int m = 0;
     for (int s = 0; s < p.nseg; ++s) {
       const GemmSeg &sg = p.seg[s], &s0 = p0.seg[s];
-      if (!sg.a_kc || sg.b_kc != (grad ? 0 : 1) || sg.K != s0.K || sg.lda != s0.lda || sg.ldb != s0.ldb) return false;
       const int slot = s == main0 ? 0 : 1 + m++;
+      if (!sg.a_kc || sg.b_kc != (grad ? 0 : 1)) return false;
+      if (plain ? (slot == 0 ? (sg.K != s0.K || sg.lda != s0.lda) : sg.K > s0.K) : (sg.K != s0.K || sg.lda != s0.lda || sg.ldb != s0.ldb)) return false;
+      if (slot == 0) I.ldw0 = sg.ldb;
+      if (slot == 1) { I.k1 = sg.K; I.lda1 = sg.lda; I.ldw1 = sg.ldb; }
       if (slot > 0 && (sg.K < 1 || sg.K > 32)) return false;
       if (slot == 0 && !fz && (sg.lda % 4 || !aligned(sg.A, 16))) return false;   // rows move as 16-byte pieces
       if (slot > 0 && fz && !aligned(sg.A, 8)) return false;
@@ -923,7 +937,7 @@ bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
     // instantiated forms (wstat_launch)
     const int L = args.nslot_loop, Tn = args.nslot_tail;
     if (grad) {
-      if (!((L == 1) || (L == 4 && !fz))) return false;
+      if (!((L == 1) || (L == 4 && !fz) || (L == 2 && plain))) return false;
     } else {
       const bool small = (L == 0 && Tn == 0) || (L == 1 && Tn == 0) || (L == 1 && Tn == 1);
       const bool wide = (L == 3 && Tn == 0) || (L == 3 && Tn == 3);
@@ -1009,7 +1023,7 @@ static hipError_t ws_launch_grad(const WsArgs &a, hipStream_t s) {
 
 hipError_t wstat_launch(const WsArgs &a, hipStream_t s) {
   const int L = a.nslot_loop, T = a.nslot_tail;
-  if (a.grad == 2) return L == 4 ? ws_launch_grad<false, true, 4>(a, s) : ws_launch_grad<false, true, 1>(a, s);
+  if (a.grad == 2) return L == 4 ? ws_launch_grad<false, true, 4>(a, s) : (L == 2 ? ws_launch_grad<false, true, 2>(a, s) : ws_launch_grad<false, true, 1>(a, s));
   if (a.grad) {
     if (a.fz) return ws_launch_grad<true, false, 1>(a, s);
     return L == 4 ? ws_launch_grad<false, false, 4>(a, s) : ws_launch_grad<false, false, 1>(a, s);
