@@ -72,6 +72,10 @@ __device__ __forceinline__ void sfor(F &&f) {
 __device__ __forceinline__ unsigned ws_lds_addr(const float *p) { return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)p; }
 template <int OFF>
 __device__ __forceinline__ void ws_rd128(v4f &d, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(d) : "v"(addr), "n"(OFF)); }
+template <int OFF>
+__device__ __forceinline__ void ws_rd128a(v4f &d, unsigned addr) {   // destination in the AccVGPRs
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(d) : "v"(addr), "n"(OFF));
+}
 template <int N>
 __device__ __forceinline__ void ws_lgkm_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ int ws_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -171,15 +175,32 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
   const int lda0 = a.lda[0];
 
   // ---- stationary main weights: wb[tn][s] = W0[n0 + 32 tn + li][32 (s / 4) + 16 lh + 4 (s % 4) .. + 3]
+  // Loaded as whole ROWS (a wave instruction = one 1 KiB row: 8 cache lines, not the 64 lines a lane-per-row load touches:
+  // the lane-per-row form took 21-24 k cycles = 1.4 tile times per workgroup, tools/ws_stamps.py) and redistributed through
+  // the wave's own slice of LDS - the image / constant areas are not in use yet: 32 rows x (256 + 4) floats per wave and pass,
+  // conflict-free ds_read_b128 straight into the AccVGPRs.
   v4f wb[2][NSTEP];
   {
     const float *W0 = ws_uni(I.W[0]);
     const int ldw0 = a.ldw[0];
+    constexpr int WP = WS_KMAIN + 4;
+    float *const wst = lds + wave * (32 * WP);
+    const unsigned wst_rd = ws_lds_addr(wst) + (unsigned)(li * WP + 16 * lh) * 4u;
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn)
+    for (int tn = 0; tn < 2; ++tn) {
+      v4f row[32];
 #pragma unroll
-      for (int s = 0; s < NSTEP; ++s)
-        wb[tn][s] = *(gcf4)(W0 + (long long)(n0 + 32 * tn + li) * ldw0 + 32 * (s >> 2) + 16 * lh + 4 * (s & 3));
+      for (int r = 0; r < 32; ++r) row[r] = ((gcf4)(ws_uni(W0 + (long long)(n0 + 32 * tn + r) * ldw0)))[(unsigned)lane];
+#pragma unroll
+      for (int r = 0; r < 32; ++r) *reinterpret_cast<v4f *>(wst + r * WP + lane * 4) = row[r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (this wave's own writes; nobody else touches its slice)
+      sfor<0, NSTEP>([&](auto sc) __attribute__((always_inline)) {
+        constexpr int st = decltype(sc)::value;
+        ws_rd128a<((st >> 2) * 32 + (st & 3) * 4) * 4>(wb[tn][st], wst_rd);
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read before the next pass overwrites the slice
+    }
+    __syncthreads();   // every wave is done with its slice before images and constants land there
   }
   // Per-wave constants in LDS (behind the images), read shortly before their use:
   //   bias of the columns 8 q + 4 lh + c of each column tile                                        [wave][lh][tn][q][c]
@@ -1010,7 +1031,9 @@ template <int NSL, int NST, int HFQ>
 static hipError_t ws_launch(const WsArgs &a, hipStream_t s) {
   static bool attr[64];
   // two images + per-wave constants (bias, rider weights, 8 KiB of narrow weights per slot)
-  constexpr int lds_bytes = (2 * WS_BM * (WS_KMAIN + 8 * (NSL + NST) + 4) + 4 * 2 * 32 + 4 * 8 * 32 + (NSL + NST) * 2048) * 4;
+  constexpr int lds_need = (2 * WS_BM * (WS_KMAIN + 8 * (NSL + NST) + 4) + 4 * 2 * 32 + 4 * 8 * 32 + (NSL + NST) * 2048) * 4;
+  constexpr int lds_stage = 4 * 32 * (WS_KMAIN + 4) * 4;   // the weight load's transposition area (4 waves x 32 rows)
+  constexpr int lds_bytes = lds_need > lds_stage ? lds_need : lds_stage;
   return ws_launch_kernel(&k_wstat<NSL, NST, HFQ>, lds_bytes, attr, a, s);
 }
 template <bool FUSE, bool PLAIN, int NS>
