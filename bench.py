@@ -200,12 +200,12 @@ def rocprof_tag(name):
         return "k_chain"
     if name.startswith("wgstat"):
         return "k_wgrad_stat"
-    if name.startswith("wstatg<"):       # "wstatg<fuse,plain>:stage" -> k_wstat_grad<true, false>
-        f, pl = name[7:name.index(">")].split(",")
-        return f"k_wstat_grad<{'true' if f == '1' else 'false'}, {'true' if pl == '1' else 'false'}>"
-    if name.startswith("wstat<"):        # "wstat<nminor,dual,hfq>:stage" -> k_wstat<0, false, 2>
-        n, d, q = name[6:name.index(">")].split(",")
-        return f"k_wstat<{n}, {'true' if d == '1' else 'false'}, {q}>"
+    if name.startswith("wstatg<"):       # "wstatg<fuse,plain,ns>:stage" -> k_wstat_grad<true, false, 1>
+        f, pl, ns = name[7:name.index(">")].split(",")
+        return f"k_wstat_grad<{'true' if f == '1' else 'false'}, {'true' if pl == '1' else 'false'}, {ns}>"
+    if name.startswith("wstat<"):        # "wstat<nsl,nst,hfq>:stage" -> k_wstat<0, 0, 2>
+        n, t, q = name[6:name.index(">")].split(",")
+        return f"k_wstat<{n}, {t}, {q}>"
     if name.startswith("rows"):
         return "k_rowgemm"
     shape_id = {"128x128": 0, "128x32": 1, "32x128": 2, "64x128": 3, "64x64dual": 4, "64x64": 5, "64x64hf": 6}

@@ -1973,9 +1973,9 @@ int32_t fdql_agent_profile_update(fdql_agent_t *a, const fdql_batch_t *batch, co
         // (the name carries the kernel's template arguments: bench.py / tools map it to the rocprofv3 kernel name)
         if (rl.wa.grad) {
           bytes = 4.0 * rl.wa.M * rl.wa.ninst * (double)(WS_KMAIN * (rl.wa.fz ? 2 : 1) + 2 * WS_N);
-          snprintf(out[cnt].name, sizeof(out[cnt].name), "wstatg<%d,%d>:%s", rl.wa.fz ? 1 : 0, rl.wa.grad == 2 ? 1 : 0, st.name.c_str());
+          snprintf(out[cnt].name, sizeof(out[cnt].name), "wstatg<%d,%d,%d>:%s", rl.wa.fz ? 1 : 0, rl.wa.grad == 2 ? 1 : 0, rl.wa.nslot_loop, st.name.c_str());
         } else {
-          snprintf(out[cnt].name, sizeof(out[cnt].name), "wstat<%d,%d,%d>:%s", rl.wa.nminor, rl.wa.dual ? 1 : 0, rl.wa.hf_q, st.name.c_str());
+          snprintf(out[cnt].name, sizeof(out[cnt].name), "wstat<%d,%d,%d>:%s", rl.wa.nslot_loop, rl.wa.nslot_tail, rl.wa.hf_q, st.name.c_str());
         }
       } else {
       const RowGemmArgs &ra = rl.rg;
