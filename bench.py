@@ -12,9 +12,11 @@ N = 1 (the driver's BENCH line): BASELINE config 2 - obs 17, act 6, TQC 5 critic
   `other_configs` (configs 3, 4 at B=1024 on one GPU, 5), `facade_path` (the franQ-shaped objects end to end).
 N > 1 (launched by torch.distributed.run, one process per GPU): BASELINE config 4 - obs 376, act 17,
   TQC 5 x 25 quantiles, GLOBAL batch B = 1024 windows split B/N per GPU, a 2M-slot ring shard per rank; each rank
-  runs FDQL_PHASE_GRAD on its windows, the 5.27 MB gradient arena is summed by ONE RCCL all-reduce (the row weights
-  already carry 1/(B_global), so the sum is the global-batch gradient), then FDQL_PHASE_APPLY: identical Adam on every
-  rank.  `value` = GLOBAL optimiser steps/s (one step of the whole job, not multiplied by N): "scaling": "strong".
+  runs its backward in two phases: FDQL_PHASE_GRAD_CRITICS leaves the critics' share of the 5.27 MB gradient arena
+  final, its RCCL all-reduce starts on a side stream while FDQL_PHASE_GRAD_REST (encoder / joiner / actor gradients)
+  runs, a second all-reduce takes the rest (the row weights already carry 1/(B_global), so the sums are the
+  global-batch gradient), then FDQL_PHASE_APPLY: identical Adam on every rank.  No barrier inside the timed region.
+  `value` = GLOBAL optimiser steps/s (one step of the whole job, not multiplied by N): "scaling": "strong".
   The line also carries `same_workload_1gpu` (rank 0 running the whole B = 1024 batch alone, measured in the same
   process before the distributed phase) so that speed-up is computable from the line itself.
 
