@@ -113,6 +113,7 @@ struct Stage {
   std::string name;
   std::vector<GemmProblem> gemm;
   GemmSub sub[GEMM_NSHAPES];  // the problems of `gemm`, grouped by tile shape (one launch each)
+  bool stream = false;        // ST_SKINNY_WGRAD: the streaming form (k_stream_wgrad: 256-wide X, one workgroup per slab)
   bool try_rows = false;      // ST_GEMM: groups of like problems may run on the persistent row-block kernel (rowgemm.hip)
   std::vector<RowsLaunch> rows;    // the groups that do (one launch each); their problems are not in `sub`
   std::vector<SkinnyWgradProblem> swg;
@@ -445,6 +446,15 @@ struct Builder {
     wst.kind = ST_WGRAD_STAT; wst.name = name;
     const long long tiles = (long long)probs.size() * (probs[0].seg[0].K / WG_BM);
     if (tiles >= 8 * a->rows_min_tiles && wgrad_stat_from_problems(probs.data(), (int)probs.size(), a->nsplit, a->n_train, wst.wga)) {
+      // the few-column / few-row gradients that share an operand with one of the blocks (a critic's action columns, its
+      // skip head's rows over the state and over h0) ride with it instead of re-reading the operand in the tail launches
+      for (size_t i = 0; i < fallback.gemm.size();) {
+        bool taken = false;
+        for (int k = 0; k < wst.wga.ninst && !taken; ++k) taken = wgrad_stat_add_rider(wst.wga, k, fallback.gemm[i]);
+        if (taken) fallback.gemm.erase(fallback.gemm.begin() + i);
+        else ++i;
+      }
+      wgrad_stat_balance(wst.wga);
       wst.flops = wgrad_stat_flops(wst.wga);
       wst.bytes = 8.0 * wst.wga.M * WG_N * wst.wga.ninst;
       st.push_back(wst);
@@ -583,6 +593,48 @@ struct Builder {
     else { p.M = R; p.X = dOut; p.ldx = ldo; }
     p.dW = dst; p.sq = 0; p.sk = 1; p.split_stride = a->n_train; p.nsplit = a->nsplit;
     ws.swg.push_back(p);
+  }
+  // The narrow weight gradients left in `from` after the riders were dealt (flush_wgrad_stat) that have the streaming
+  // form - a few outputs over a 256-wide input, or a few input columns under a 256-wide output gradient (roles swapped) -
+  // move to the one-launch streaming stage `to` (kernels.hip, k_stream_wgrad); FDQL_STREAM_WGRAD=0: none.
+  // The ones that are narrow BOTH ways (a skip head's rows over the action columns: 2 x 6) join the column sums' launch
+  // (`skinny`, k_skinny_wgrad: any K) - left on the tile kernel they were a 40 us launch of their own for 2 MB.
+  void take_stream_wgrads(Stage &from, Stage &to, Stage &skinny) {
+    const char *env = getenv("FDQL_STREAM_WGRAD");
+    if (env && env[0] == '0') return;
+    for (size_t i = 0; i < from.gemm.size();) {
+      const GemmProblem &p = from.gemm[i];
+      SkinnyWgradProblem q;
+      memset(&q, 0, sizeof(q));
+      bool ok = p.nseg == 1 && p.ksplit == a->nsplit && p.split_stride == a->n_train && !p.bias && p.epi == EPI_NONE && !p.colsum && !p.C2 &&
+                !p.seg[0].a_kc && !p.seg[0].b_kc;
+      if (ok && p.M <= SKINNY_MAX_OUT && p.N <= 64) {
+        const GemmSeg &sg = p.seg[0];
+        q.M = sg.K; q.Nout = p.M; q.K = p.N; q.dY = sg.A; q.lddy = sg.lda; q.X = sg.B; q.ldx = sg.ldb;
+        q.dW = p.C; q.sq = p.ldc; q.sk = 1; q.split_stride = p.split_stride; q.nsplit = p.ksplit;
+        skinny.swg.push_back(q);
+        from.gemm.erase(from.gemm.begin() + i);
+        continue;
+      }
+      if (ok) {
+        const GemmSeg &sg = p.seg[0];   // dW[nout = p.M][width = p.N] = dOut[R, nout]^T X[R, width]
+        q.M = sg.K; q.K = 256; q.ldx = 256; q.dW = p.C; q.split_stride = p.split_stride; q.nsplit = p.ksplit;
+        if (p.N == 256 && sg.ldb == 256 && p.M <= 32) {          // few outputs over a 256-wide input
+          q.Nout = p.M; q.dY = sg.A; q.lddy = sg.lda; q.X = sg.B; q.sq = p.ldc; q.sk = 1;
+        } else if (p.M == 256 && sg.lda == 256 && p.N <= 32) {   // few input columns: dW^T[a][n] = X2[R, a]^T dOut[R, n]
+          q.Nout = p.N; q.dY = sg.B; q.lddy = sg.ldb; q.X = sg.A; q.sq = 1; q.sk = p.ldc;
+        } else {
+          ok = false;
+        }
+        ok = ok && stream_wgrad_takes(q);
+      }
+      if (ok) {
+        to.swg.push_back(q);
+        from.gemm.erase(from.gemm.begin() + i);
+      } else {
+        ++i;
+      }
+    }
   }
   // all weight / bias gradients of one MLP instance into the K-split slabs.  Every weight
   // gradient is a K-split GEMM (the narrow ones on the 128x32 / 32x128 tiles); bias gradients
@@ -897,7 +949,7 @@ int upload_tables(fdql_agent *a) {
         off += pad(bytes);
       }
     } else if (s.kind == ST_SKINNY_WGRAD) {
-      s.blocks = skinny_wgrad_finalize(s.swg.data(), (int)s.swg.size());
+      s.blocks = s.stream ? stream_wgrad_finalize(s.swg.data(), (int)s.swg.size()) : skinny_wgrad_finalize(s.swg.data(), (int)s.swg.size());
       s.flops = 0; s.bytes = 0;
       for (auto &p : s.swg) {
         s.flops += 2.0 * p.M * (double)p.K * p.Nout;
@@ -1374,7 +1426,11 @@ int build_plan(fdql_agent *a) {
     cws.kind = ST_SKINNY_WGRAD; cws.name = "colsums.critics";
     for (int k = 0; k < C; ++k) b.wgrads(co[k], a->buf("dz") + k * Q, Nq, nullptr, cn, cn, cws);
     b.flush_wgrad_stat("wgrad.critics", cn);
-    a->stages.push_back(cn);
+    Stage cnw;
+    cnw.kind = ST_SKINNY_WGRAD; cnw.stream = true; cnw.name = "wgrad.critics.stream";
+    b.take_stream_wgrads(cn, cnw, cws);
+    if (!cn.gemm.empty()) a->stages.push_back(cn);
+    if (!cnw.swg.empty()) a->stages.push_back(cnw);
     a->stages.push_back(cws);
     const float *slabs = a->buf("slabs");
     float *grads = a->grads;
@@ -1572,7 +1628,11 @@ int build_plan(fdql_agent *a) {
       });
     }
     b.flush_wgrad_stat("wgrad.dense", tail);
-    a->stages.push_back(tail);
+    Stage nws;
+    nws.kind = ST_SKINNY_WGRAD; nws.stream = true; nws.name = "wgrad.stream";
+    b.take_stream_wgrads(tail, nws, ws);
+    if (!tail.gemm.empty()) a->stages.push_back(tail);
+    if (!nws.swg.empty()) a->stages.push_back(nws);
     a->stages.push_back(ws);
     if (!conv_post.empty())
       b.func_stage("conv.wgrad_reduce", [=](hipStream_t s) {
@@ -1626,7 +1686,9 @@ hipError_t run_stage(fdql_agent *a, Stage &s, hipStream_t stream) {
         if (e != hipSuccess) return e;
       }
       return hipSuccess;
-    case ST_SKINNY_WGRAD: return skinny_wgrad_launch_host(s.swg.data(), (const SkinnyWgradProblem *)s.dev, (int)s.swg.size(), s.blocks, stream);
+    case ST_SKINNY_WGRAD:
+      if (s.stream) return stream_wgrad_launch((const SkinnyWgradProblem *)s.dev, (int)s.swg.size(), s.blocks, stream);
+      return skinny_wgrad_launch_host(s.swg.data(), (const SkinnyWgradProblem *)s.dev, (int)s.swg.size(), s.blocks, stream);
     case ST_FUNC: return s.fn(stream);
     case ST_HEAD_DGRAD: return head_dgrad_launch((const HeadDgradProblem *)s.dev, (int)s.hdg.size(), s.blocks, stream);
     case ST_WGRAD_STAT: return wgrad_stat_launch(s.wga, stream);
@@ -1985,7 +2047,7 @@ int32_t fdql_agent_profile_update(fdql_agent_t *a, const fdql_batch_t *batch, co
       }
     } else {
       snprintf(out[cnt].name, sizeof(out[cnt].name), "%s%s",
-               st.kind == ST_SKINNY_WGRAD ? "colsum:" : (st.kind == ST_CHAIN ? "chain:" : (st.kind == ST_WGRAD_STAT ? "wgstat:" : "k:")),
+               st.kind == ST_SKINNY_WGRAD ? (st.stream ? "nwgrad:" : "colsum:") : (st.kind == ST_CHAIN ? "chain:" : (st.kind == ST_WGRAD_STAT ? "wgstat:" : "k:")),
                st.name.c_str());
     }
     out[cnt].ms = ms;
@@ -2302,17 +2364,34 @@ int fdql_test_gemm(const float *A, int32_t lda, int32_t a_kc, const float *B, in
  * slab of every block is written (partials or zeros): their sum is the gradient.  FDQL_EINVAL: the kernel does not take the form. */
 int fdql_test_wgrad_stat(const float *G, const float *X, float *dW, int32_t M, int32_t nprob, int32_t ldw, int32_t nslab,
                          int64_t slab_stride, void *stream) {
+  return fdql_test_wgrad_stat_riders(G, X, dW, M, nprob, ldw, nslab, slab_stride, nullptr, 0, 0, nullptr, 0, 1, nullptr, 0, 0, nullptr, 0, stream);
+}
+
+int fdql_test_wgrad_stat_riders(const float *G, const float *X, float *dW, int32_t M, int32_t nprob, int32_t ldw, int32_t nslab,
+                                int64_t slab_stride, const float *X2, int32_t nx2, int32_t ldx2, float *dW2, int32_t ldw2, int32_t x2_every,
+                                const float *G2, int32_t ng2, int32_t ldg2, float *dW3, int32_t ldw3, void *stream) {
   std::vector<GemmProblem> probs;
-  for (int i = 0; i < nprob; ++i) {
+  auto wgrad_problem = [&](int nout, int width, float *dst, int ldd, const float *dOut, int ldo, const float *Xp, int ldx) {
     GemmProblem p;
     memset(&p, 0, sizeof(p));
-    p.M = WG_N; p.N = WG_N; p.C = dW + (long long)i * WG_N * ldw; p.ldc = ldw; p.ksplit = nslab; p.split_stride = slab_stride; p.emit_seg = -1;
+    p.M = nout; p.N = width; p.C = dst; p.ldc = ldd; p.ksplit = nslab; p.split_stride = slab_stride; p.emit_seg = -1;
     GemmSeg &sg = p.seg[p.nseg++];
-    sg.A = G + (long long)i * M * WG_N; sg.lda = WG_N; sg.a_kc = 0; sg.B = X + (long long)i * M * WG_N; sg.ldb = WG_N; sg.b_kc = 0; sg.K = M;
-    probs.push_back(p);
-  }
+    sg.A = dOut; sg.lda = ldo; sg.a_kc = 0; sg.B = Xp; sg.ldb = ldx; sg.b_kc = 0; sg.K = M;
+    return p;
+  };
+  for (int i = 0; i < nprob; ++i)
+    probs.push_back(wgrad_problem(WG_N, WG_N, dW + (long long)i * WG_N * ldw, ldw, G + (long long)i * M * WG_N, WG_N, X + (long long)i * M * WG_N, WG_N));
   WgArgs wa;
   FDQL_REQUIRE(wgrad_stat_from_problems(probs.data(), nprob, nslab, slab_stride, wa), "the output-stationary kernel does not take this form");
+  for (int i = 0; i < nprob; ++i) {
+    if (X2 && x2_every > 0 && i % x2_every == 0)
+      FDQL_REQUIRE(wgrad_stat_add_rider(wa, i, wgrad_problem(WG_N, nx2, dW2 + (long long)i * WG_N * ldw2, ldw2, G + (long long)i * M * WG_N, WG_N,
+                                                            X2 + (long long)i * M * ldx2, ldx2)), "narrow-input rider refused");
+    if (G2)
+      FDQL_REQUIRE(wgrad_stat_add_rider(wa, i, wgrad_problem(ng2, WG_N, dW3 + (long long)i * ng2 * ldw3, ldw3, G2 + (long long)i * M * ldg2, ldg2,
+                                                            X + (long long)i * M * WG_N, WG_N)), "narrow-output rider refused");
+  }
+  FDQL_REQUIRE(wgrad_stat_balance(wa), "no workgroups to deal");
   hipError_t e = wgrad_stat_launch(wa, (hipStream_t)stream);
   if (e != hipSuccess) { set_error("wgrad_stat launch: %s", hipGetErrorString(e)); return FDQL_EHIP; }
   return 0;

@@ -16,14 +16,13 @@ enum ChainOpKind { CH_END = 0, CH_LOAD = 1, CH_GEMM = 2, CH_NARROW = 3 };
 enum ChainFlags {
   CHF_ZERO = 1,      // GEMM: clear the accumulators first
   CHF_EMIT = 2,      // GEMM: run the epilogue (bias, activation, stores) after the K loop
-  CHF_KS = 4,        // weights are K-strided: element (k, n) at W[k*ldw + n] (dgrad); default K-contiguous W[n*ldw + k]
   CHF_BEGIN = 8,     // NARROW: clear the head accumulators first
   CHF_FINISH = 16,   // NARROW: add the bias and store the wave's 16 rows
   CHF_HBEGIN = 32,   // GEMM with a head rider: clear the head accumulators first
 };
-enum ChainAct { CHA_NONE = 0, CHA_LRELU = 1, CHA_LRELU_GRAD = 2 };
+enum ChainAct { CHA_NONE = 0, CHA_LRELU = 1 };
 
-// A operand of a segment: LDS slot (float offset, row pitch); B operand: weights in global memory
+// Activation operand of a segment: LDS slot (float offset, row pitch); weights: global memory, K contiguous (element (n, k) at W[n*ldw + k])
 struct ChainSeg {
   const float *W;
   int ldw;
@@ -41,12 +40,10 @@ struct ChainOp {
   int slot, pitch, kpad;        // LOAD: destination image; columns [sum of widths, kpad) are zeroed.  NARROW: `slot` = staging
                                 // area of N * (roundup(max K, 16) + 4) floats for the head weights of one segment
   int out_slot, out_pitch;      // GEMM: LDS image that receives the output tile (-1: none)
-  int ldo, ldref;
+  int ldo;
   int row_lo, row_hi, row_shift;   // global rows written / referenced: row_lo <= row < row_hi, at index row - row_shift
   const float *bias;
   float *out;                   // global output [*, ldo] or null
-  const float *ref;             // CHA_LRELU_GRAD: activation output whose sign gates the gradient, [*, ldref]
-  float *colsum;                // optional [blocks, N]: column sums of the emitted tile over this block's valid rows
   const float *hw;              // GEMM (K-contiguous weights, N > 192): a narrow skip head's weight block over this op's
   int hldw, hN;                 // input columns rides in the K loop: head row n at hw[n*hldw + k], hN <= 32 outputs (CH_NARROW
                                 // + CHF_FINISH later stores them); null: none

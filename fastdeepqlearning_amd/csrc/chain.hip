@@ -7,14 +7,17 @@
 // (chain.h) on them:
 //   CH_LOAD    global rows (the K-segments of a torch.cat) -> an LDS image [64][pitch]
 //   CH_GEMM    acc[64 x N<=256] (+)= sum over K-segments of image x W^T; wave w owns columns [64w, 64w+64) as 2x2 MFMA
-//              tiles (v_mfma_f32_32x32x2_f32); epilogue: bias, LeakyReLU / LeakyReLU' mask, store to an LDS image (the
-//              next layer's input) and / or to global memory, per-block column sums (bias gradients)
+//              tiles (v_mfma_f32_32x32x2_f32), computed TRANSPOSED (the weights are the MFMA's A operand, the activations
+//              its B operand): a lane then holds, for ITS batch row, four consecutive output columns per register quad,
+//              so the epilogue (bias, LeakyReLU) writes the next layer's LDS image with ds_write_b128 and global memory
+//              with global_store_dwordx4 straight from the accumulators (round 3; before: 64 ds_write_b32 per lane, a
+//              barrier, and a second pass image -> memory with its index arithmetic: 10 k of a layer's 50 k cycles)
 //   CH_NARROW  skip heads and other N <= 32 outputs: the K range is dealt round-robin to the four waves, partial
 //              32-column tiles are summed through LDS in wave order
 // The A operand is read from LDS by ds_read_b128 ((pitch / 4) odd: the 32 rows of a fragment hit distinct banks); the B
 // operand (weights) goes global -> registers directly as MFMA fragments: lane (li, lh) of a column tile holds, for a
 // 32-k group, the 16 k's 32g + 16 lh + 0..15 of ITS column - K-contiguous weights: 64 contiguous bytes per lane
-// (4 x dwordx4), K-strided weights (dgrad): column pairs (dwordx2) of 16 rows.  A and B pair the same k's in every MFMA
+// (4 x dwordx4).  Activations and weights pair the same k's in every MFMA
 // step, so the fp32 sum runs over a fixed permutation of k (bitwise a k-ordered fma chain, like gemm.hip).  No LDS
 // staging of B, no barrier inside a K loop; the next group's fragments are requested before the current group's 64 MFMAs.
 #include "chain.h"
@@ -55,12 +58,11 @@ __device__ __forceinline__ const float *ch_uni(const float *p) {
 // s_memtime at its entry, after the program fetch and after every operation.
 __device__ unsigned long long g_ch_stamps[8 * CH_MAX_OPS + 4];
 __device__ int g_ch_stamps_on = 0;
+__device__ int g_ch_stagger = 0;   // experiment (FDQL_CHAIN_STAGGER): workgroup j starts (j & 3) x this many kilo-cycles late
 
-// MINB = workgroups per CU the register budget is cut for (1: 512 registers per lane; 2: 256 - two workgroups per CU
-// overlap each other's load / epilogue phases when the program's LDS allows)
-template <int MINB>
-__global__ __launch_bounds__(CH_THREADS, MINB) void k_chain(const ChainProblem *__restrict__ probs, int nprob,
-                                                             const ChainOp *__restrict__ ops_all) {
+// One workgroup per CU (512 registers per lane: the accumulators live in AccVGPRs, two weight-fragment buffers in VGPRs).
+__global__ __launch_bounds__(CH_THREADS, 1) void k_chain(const ChainProblem *__restrict__ probs, int nprob,
+                                                         const ChainOp *__restrict__ ops_all) {
   __shared__ ChainOp s_ops[CH_MAX_OPS];
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -91,6 +93,7 @@ __global__ __launch_bounds__(CH_THREADS, MINB) void k_chain(const ChainProblem *
     }
   }
   const int r0 = blk * CH_BM;
+  for (int i = (bid & 3) * g_ch_stagger; i > 0; --i) __builtin_amdgcn_s_sleep(16);
   {   // the program -> LDS in one coalesced round (fields are then read from LDS, not through L2)
     const int *src = reinterpret_cast<const int *>(ops_all + op_start);
     int *dst = reinterpret_cast<int *>(s_ops);
@@ -102,6 +105,8 @@ __global__ __launch_bounds__(CH_THREADS, MINB) void k_chain(const ChainProblem *
   const unsigned lds0 = ch_lds_addr(lds);
   // The weight slices of every CH_NARROW operation -> their staging areas, once, before anything else is in flight:
   // fetched inside the operation they would cost a memory round trip (behind the layer's own stores) per operation.
+  // Slice of a segment: [N][wp = roundup(K, 16) + 4] floats, k >= K zero.  Whole 16-byte quads when rows allow it (all of
+  // a slice's requests in flight at once, then the LDS writes), single floats otherwise.
   {
     bool any = false;
     for (int ip = 0; ip < nops; ++ip) {
@@ -109,27 +114,45 @@ __global__ __launch_bounds__(CH_THREADS, MINB) void k_chain(const ChainProblem *
       if (ch_uni(op.kind) != CH_NARROW) continue;
       any = true;
       const int N = ch_uni(op.N), nseg = ch_uni(op.nseg);
-      const bool ks = (ch_uni(op.flags) & CHF_KS) != 0;
       int wslot = ch_uni(op.slot);
       for (int s = 0; s < nseg; ++s) {
         gcf W = (gcf)ch_uni(op.seg[s].W);
         const int ldw = ch_uni(op.seg[s].ldw), K = ch_uni(op.seg[s].K);
-        const int k16 = (K + 15) & ~15, wp = k16 + 4, total = N * k16;   // (wp / 4) odd: conflict-free B fragments
-        for (int base = 0; base < total; base += 8 * CH_THREADS) {
-          float v[8];
+        const int k16 = (K + 15) & ~15, wp = k16 + 4;   // (wp / 4) odd: conflict-free B fragments
+        if (((K | ldw) & 3) == 0 && (reinterpret_cast<uintptr_t>(op.seg[s].W) & 15) == 0) {
+          const int kq = k16 >> 2, total = N * kq;   // quads
+          for (int base = 0; base < total; base += 8 * CH_THREADS) {
+            v4f v[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int e = base + tid + u * CH_THREADS;
-            int n, k;
-            if (!ks) { n = e / k16; k = e - n * k16; } else { k = e / N; n = e - k * N; }
-            v[u] = (e < total && k < K) ? (ks ? W[(long long)k * ldw + n] : W[(long long)n * ldw + k]) : 0.f;
+            for (int u = 0; u < 8; ++u) {
+              const int e = min(base + tid + u * CH_THREADS, total - 1);
+              const int n = e / kq, k = (e - n * kq) * 4;
+              v[u] = *(gcf4)(W + (long long)n * ldw + min(k, K - 4));
+              if (k >= K) v[u] = v4f{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int e = base + tid + u * CH_THREADS;
+              const int n = e / kq, k = (e - n * kq) * 4;
+              if (e < total) *reinterpret_cast<v4f *>(&lds[wslot + n * wp + k]) = v[u];
+            }
           }
+        } else {
+          const int total = N * k16;
+          for (int base = 0; base < total; base += 8 * CH_THREADS) {
+            float v[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int e = base + tid + u * CH_THREADS;
-            int n, k;
-            if (!ks) { n = e / k16; k = e - n * k16; } else { k = e / N; n = e - k * N; }
-            if (e < total) lds[wslot + n * wp + k] = v[u];
+            for (int u = 0; u < 8; ++u) {
+              const int e = base + tid + u * CH_THREADS;
+              const int n = e / k16, k = e - n * k16;
+              v[u] = (e < total && k < K) ? W[(long long)n * ldw + k] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int e = base + tid + u * CH_THREADS;
+              const int n = e / k16, k = e - n * k16;
+              if (e < total) lds[wslot + n * wp + k] = v[u];
+            }
           }
         }
         wslot += N * wp;
@@ -198,7 +221,7 @@ __global__ __launch_bounds__(CH_THREADS, MINB) void k_chain(const ChainProblem *
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
           for (int tn = 0; tn < 2; ++tn)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(j == 0 ? af[tm][c] : a[j & 1][tm][c], b[tn][j][c], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[tn][j][c], j == 0 ? af[tm][c] : a[j & 1][tm][c], acc[tm][tn], 0, 0, 0);
     }
     if constexpr (RIDER) {
 #pragma unroll
@@ -213,30 +236,6 @@ __global__ __launch_bounds__(CH_THREADS, MINB) void k_chain(const ChainProblem *
     af[1] = an[1];
     asm volatile("" ::"v"(a0), "v"(a1), "v"(na0), "v"(na1), "v"(a16g));
   };
-  auto mfma_group_ks = [&](unsigned a0, unsigned a1, const v2f (&b)[4][4]) __attribute__((always_inline)) {
-    v4f a[2][2];
-    ch_rd128(a[0][0], a0);
-    ch_rd128(a[0][1], a1);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (j < 3) {
-        ch_rd128(a[(j + 1) & 1][0], a0 + 16 * (j + 1));
-        ch_rd128(a[(j + 1) & 1][1], a1 + 16 * (j + 1));
-        ch_lgkm_wait<2>();
-      } else {
-        ch_lgkm_wait<0>();
-      }
-      asm volatile("" : "+v"(a[j & 1][0]), "+v"(a[j & 1][1]));
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < 2; ++tn)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j & 1][tm][c], b[j][c][tn], acc[tm][tn], 0, 0, 0);
-    }
-    asm volatile("" ::"v"(a0), "v"(a1));
-  };
   // 8-k tail group: lanes lh = 0 / 1 hold k = kb + 0..3 / kb + 4..7 (component c -> MFMA step c)
   auto mfma_tail = [&](unsigned a0, unsigned a1, const v4f &b0, const v4f &b1) __attribute__((always_inline)) {
     v4f a[2];
@@ -246,10 +245,10 @@ __global__ __launch_bounds__(CH_THREADS, MINB) void k_chain(const ChainProblem *
     asm volatile("" : "+v"(a[0]), "+v"(a[1]));
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][c], b0[c], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][c], b1[c], acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][c], b0[c], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][c], b1[c], acc[1][1], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[c], a[0][c], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[c], a[0][c], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[c], a[1][c], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[c], a[1][c], acc[1][1], 0, 0, 0);
     }
     asm volatile("" ::"v"(a0), "v"(a1));
   };
@@ -278,18 +277,26 @@ __global__ __launch_bounds__(CH_THREADS, MINB) void k_chain(const ChainProblem *
       hp1 = (gcf)(hw + (long long)min(16 + lj, hN - 1) * hldw + 4 * kq);
       a16 = lds0 + (unsigned)(slot + (16 * wave + lj) * pitch + 4 * kq) * 4u;
     }
-    // first tail group's fragments are requested before the full groups (their latency hides behind them)
-    v4f tb0 = {0.f, 0.f, 0.f, 0.f}, tb1 = {0.f, 0.f, 0.f, 0.f};
-    auto load_tail = [&](int t) __attribute__((always_inline)) {
+    // the tail groups' fragments (at most four 8-k groups) are requested before the full groups: their latency hides
+    // behind them, one request round instead of a memory round trip per tail group (with a rider: only the first one
+    // up front - the rider's operands need the registers)
+    constexpr int NPRE = RIDER ? 1 : 4;
+    v4f tb0[NPRE], tb1[NPRE];
+    auto load_tail = [&](int t, v4f &d0, v4f &d1) __attribute__((always_inline)) {
       const int kb = 32 * G + 8 * t + 4 * lh;     // this lane's 4 k's
       gcf pa = (gcf)(W + (long long)na * ldw + kb), pb = (gcf)(W + (long long)nb * ldw + kb);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        tb0[c] = kb + c < K ? pa[c] : 0.f;
-        tb1[c] = kb + c < K ? pb[c] : 0.f;
+        d0[c] = kb + c < K ? pa[c] : 0.f;
+        d1[c] = kb + c < K ? pb[c] : 0.f;
       }
     };
-    if (ntail > 0) load_tail(0);
+#pragma unroll
+    for (int t = 0; t < NPRE; ++t) {
+      tb0[t] = v4f{0.f, 0.f, 0.f, 0.f};
+      tb1[t] = v4f{0.f, 0.f, 0.f, 0.f};
+      if (t < ntail) load_tail(t, tb0[t], tb1[t]);
+    }
     if (G > 0) {
       v4f b[2][2][4];   // [buffer][tn][j]
       v4f rb[2][2][2];  // rider: [buffer][half group][head tile]
@@ -327,11 +334,14 @@ __global__ __launch_bounds__(CH_THREADS, MINB) void k_chain(const ChainProblem *
       ch_lgkm_wait<0>();   // the last group's look-ahead reads
       asm volatile("" : "+v"(af[0]), "+v"(af[1]));
     }
-    for (int t = 0; t < ntail; ++t) {
-      if (t > 0) load_tail(t);
-      // tail A fragment: k = 32 G + 8 t + 4 lh + c: the lane-half offset inside a tail group is 4 floats, not 16
-      const unsigned off = (unsigned)(32 * G + 8 * t) * 4u - (unsigned)(12 * lh) * 4u;
-      mfma_tail(a0 + off, a1 + off, tb0, tb1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t < ntail) {
+        if (t >= NPRE) load_tail(t, tb0[0], tb1[0]);
+        // tail A fragment: k = 32 G + 8 t + 4 lh + c: the lane-half offset inside a tail group is 4 floats, not 16
+        const unsigned off = (unsigned)(32 * G + 8 * t) * 4u - (unsigned)(12 * lh) * 4u;
+        mfma_tail(a0 + off, a1 + off, tb0[t < NPRE ? t : 0], tb1[t < NPRE ? t : 0]);
+      }
     }
     if constexpr (RIDER) {   // the rider's own tail: the k's past the last full group, in guarded 16-k steps
       for (int kb0 = 32 * G; kb0 < K; kb0 += 16) {
@@ -355,118 +365,82 @@ __global__ __launch_bounds__(CH_THREADS, MINB) void k_chain(const ChainProblem *
       asm volatile("" ::"v"(a16));
     }
   };
-  // ---------------------------------------------------------------- K-strided weights (dgrad): columns n0 + 2 li + tn
-  auto gemm_seg_ks = [&](const ChainSeg &S, int N, int n0) __attribute__((always_inline)) {
-    const float *W = ch_uni(S.W);
-    const int ldw = ch_uni(S.ldw), K = ch_uni(S.K), pitch = ch_uni(S.pitch), slot = ch_uni(S.slot);
-    const int nc = max(0, min(n0 + 2 * li, N - 2));   // column pair this lane reads (clamped; never stored when shifted)
-    gcf wp = (gcf)(W + nc + (long long)(16 * lh) * ldw);
-    const unsigned a0 = lds0 + (unsigned)(slot + li * pitch + 16 * lh) * 4u, a1 = a0 + (unsigned)(32 * pitch) * 4u;
-    const int G = K >> 5, ntail = ((K & 31) + 7) >> 3;
-    if (G > 0) {
-      v2f b[2][4][4];   // [buffer][j][c]
-      auto load_b = [&](int buf, int g) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) b[buf][j][c] = *(gcf2)(wp + (long long)(32 * g + 4 * j + c) * ldw);
-      };
-      load_b(0, 0);
-      int g = 0;
-      for (; g + 2 <= G; g += 2) {
-        load_b(1, g + 1);
-        mfma_group_ks(a0 + 128u * g, a1 + 128u * g, b[0]);
-        load_b(0, min(g + 2, G - 1));
-        mfma_group_ks(a0 + 128u * (g + 1), a1 + 128u * (g + 1), b[1]);
-      }
-      if (g < G) mfma_group_ks(a0 + 128u * g, a1 + 128u * g, b[0]);
-    }
-    for (int t = 0; t < ntail; ++t) {
-      const int kb = 32 * G + 8 * t + 4 * lh;
-      v4f tb0, tb1;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        v2f x = {0.f, 0.f};
-        if (kb + c < K) x = *(gcf2)((gcf)(W + nc) + (long long)(kb + c) * ldw);
-        tb0[c] = x.x;
-        tb1[c] = x.y;
-      }
-      const unsigned off = (unsigned)(32 * G + 8 * t) * 4u - (unsigned)(12 * lh) * 4u;
-      mfma_tail(a0 + off, a1 + off, tb0, tb1);
-    }
-  };
-
   // ---------------------------------------------------------------- epilogue of a GEMM
-  auto epilogue = [&](const ChainOp &op) __attribute__((always_inline)) {
-    const int N = ch_uni(op.N), flags = ch_uni(op.flags), act = ch_uni(op.act);
+  // Accumulator layout (transposed tile): lane (li, lh) holds, for batch row 32 tm + li, the outputs
+  //   n0 + 32 tn + 8 q + 4 lh + c       of register 4 q + c of acc[tm][tn]  -  four consecutive columns per register quad.
+  auto epilogue = [&](const ChainOp &op, bool fast) __attribute__((always_inline)) {
+    const int N = ch_uni(op.N), act = ch_uni(op.act);
     const int out_slot = ch_uni(op.out_slot), out_pitch = ch_uni(op.out_pitch);
     const int row_lo = ch_uni(op.row_lo), row_hi = ch_uni(op.row_hi), shift = ch_uni(op.row_shift);
-    const int ldo = ch_uni(op.ldo), ldref = ch_uni(op.ldref);
+    const int ldo = ch_uni(op.ldo);
     gcf bias = (gcf)ch_uni(op.bias);
     gf out = (gf)ch_uni(op.out);
-    gcf ref = (gcf)ch_uni(op.ref);
-    gf colsum = (gf)ch_uni(op.colsum);
-    const bool ks = (flags & CHF_KS) != 0;
     const int n0 = wave * 64;
-    // global stores: one dword per lane and accumulator register is store-issue bound (64 of them per lane and layer);
-    // when the tile also goes to an LDS image, memory is written FROM the image instead, 16 bytes per lane
-    const bool wide = out && out_slot >= 0 && ((N | ldo) & 3) == 0 && (reinterpret_cast<uintptr_t>(op.out) & 15) == 0;
-    if (out_slot >= 0) __syncthreads();   // every wave has finished reading the images this op may overwrite
-    CH_STAMP();
-    // Fast path (the common case: forward layer, tile inside the matrix and inside the row window, tile goes to an LDS
-    // image and memory is written from there): straight-line, no per-element predicates.  Everything else - partial
-    // tiles, LeakyReLU' masks from memory, column sums, direct global stores - takes the general loop below.
-    const bool fast = !ks && act != CHA_LRELU_GRAD && !colsum && out_slot >= 0 && (!out || wide) && n0 + 64 <= N;
-    if (fast) {
+    // the fast path's bias quads: requested before the barrier, which hides most of their latency
+    v4f bq[2][4];
 #pragma unroll
-      for (int tn = 0; tn < 2; ++tn) {
-        const int col = n0 + 32 * tn + li;
-        const float bv = bias ? bias[col] : 0.f;
+    for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
-          float *dst = &lds[out_slot + (32 * tm + 4 * lh) * out_pitch + col];
+      for (int q = 0; q < 4; ++q) bq[tn][q] = v4f{0.f, 0.f, 0.f, 0.f};
+    if (fast && bias) {
+      gcf bp = bias + n0 + 4 * lh;
+      if ((reinterpret_cast<uintptr_t>(op.bias) & 15) == 0) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float x = acc[tm][tn][r] + bv;
-            if (act == CHA_LRELU) x = fmaxf(x, 0.01f * x);   // == x > 0 ? x : 0.01 x
-            dst[((r & 3) + 8 * (r >> 2)) * out_pitch] = x;
-          }
-        }
-      }
-    } else {
+        for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-      const int col = ks ? n0 + 2 * li + tn : n0 + 32 * tn + li;
-      const bool cok = col < N;
-      const float bv = (bias && cok) ? bias[col] : 0.f;
-      float csum = 0.f;
+          for (int q = 0; q < 4; ++q) bq[tn][q] = *(gcf4)(bp + 32 * tn + 8 * q);
+      } else {
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm) {
-        float rv[16];
-        if (act == CHA_LRELU_GRAD) {   // reference values first, then the stores (gemm.hip: loads behind stores would wait)
+        for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int grow = r0 + 32 * tm + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            rv[r] = (cok && grow >= row_lo && grow < row_hi) ? ref[(long long)(grow - shift) * ldref + col] : 0.f;
-          }
-        }
+          for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rl = 32 * tm + (r & 3) + 8 * (r >> 2) + 4 * lh, grow = r0 + rl;
-          float x = acc[tm][tn][r] + bv;
-          if (act == CHA_LRELU) x = x > 0.f ? x : 0.01f * x;
-          else if (act == CHA_LRELU_GRAD) x = rv[r] > 0.f ? x : 0.01f * x;
-          const bool rok = grow >= row_lo && grow < row_hi;
-          if (out_slot >= 0 && cok) lds[out_slot + rl * out_pitch + col] = x;
-          if (out && !wide && cok && rok) out[(long long)(grow - shift) * ldo + col] = x;
-          if (rok) csum += x;
-        }
-      }
-      if (colsum) {   // fixed order: the 32 rows of lane half 0, then those of lane half 1
-        const float other = __shfl_xor(csum, 32);
-        if (lh == 0 && cok) colsum[(long long)blk * N + col] = csum + other;
+            for (int c = 0; c < 4; ++c) bq[tn][q][c] = bp[32 * tn + 8 * q + c];
       }
     }
+    if (out_slot >= 0) __syncthreads();   // every wave has finished reading the images this op may overwrite
+    CH_STAMP();
+    if (fast) {
+      // the common case (a full 64-column tile per wave, 16-byte aligned rows): straight-line, 16 ds_write_b128 and
+      // 16 global_store_dwordx4 per lane, no per-element predicates
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) {
+        const int rl = 32 * tm + li, grow = r0 + rl;
+        const bool rok = out && grow >= row_lo && grow < row_hi;
+        float *drow = &lds[out_slot + rl * out_pitch + n0 + 4 * lh];
+        gf orow = out + (long long)(grow - shift) * ldo + n0 + 4 * lh;
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            v4f x;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              x[c] = acc[tm][tn][4 * q + c] + bq[tn][q][c];
+              if (act == CHA_LRELU) x[c] = fmaxf(x[c], 0.01f * x[c]);   // == x > 0 ? x : 0.01 x
+            }
+            *reinterpret_cast<v4f *>(drow + 32 * tn + 8 * q) = x;
+            if (rok) *reinterpret_cast<__attribute__((address_space(1))) v4f *>(orow + 32 * tn + 8 * q) = x;
+          }
+      }
+    } else {
+      // everything else - partial column tiles, unaligned rows, no LDS image: one element at a time
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int col = n0 + 32 * tn + 8 * (r >> 2) + 4 * lh + (r & 3);
+          const bool cok = col < N;
+          const float bv = (bias && cok) ? bias[col] : 0.f;
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm) {
+            const int rl = 32 * tm + li, grow = r0 + rl;
+            float x = acc[tm][tn][r] + bv;
+            if (act == CHA_LRELU) x = x > 0.f ? x : 0.01f * x;
+            if (out_slot >= 0 && cok) lds[out_slot + rl * out_pitch + col] = x;
+            if (out && cok && grow >= row_lo && grow < row_hi) out[(long long)(grow - shift) * ldo + col] = x;
+          }
+        }
     }
     CH_STAMP();
     if (out_slot >= 0) {
@@ -478,30 +452,14 @@ __global__ __launch_bounds__(CH_THREADS, MINB) void k_chain(const ChainProblem *
       }
       __syncthreads();
       CH_STAMP();
-      if (wide) {
-        // memory is written from the image, 16 bytes per lane.  (Tried and not kept: trickling this copy out under the
-        // next layer's MFMA steps - the stores cost the K loop what they cost here: a wave's vector-memory operations
-        // retire in order, so the loop's weight loads wait for the stores ahead of them, and with every CU writing its
-        // 64 KB tile at the same moment the burst runs at the chip's HBM write rate either way.)
-        const int nq = N >> 2, total = CH_BM * nq;
-        for (int base = 0; base < total; base += 8 * CH_THREADS) {
-          v4f v[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int e = min(base + tid + u * CH_THREADS, total - 1);
-            const int r = e / nq, c = (e - r * nq) * 4;
-            v[u] = *reinterpret_cast<const v4f *>(&lds[out_slot + r * out_pitch + c]);
-          }
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int e = base + tid + u * CH_THREADS;
-            const int r = e / nq, c = (e - r * nq) * 4, grow = r0 + r;
-            if (e < total && grow >= row_lo && grow < row_hi)
-              *reinterpret_cast<__attribute__((address_space(1))) v4f *>(out + (long long)(grow - shift) * ldo + c) = v[u];
-          }
-        }
-      }
     }
+  };
+  // is this GEMM's epilogue the straight-line one?  (wave-uniform)
+  auto epilogue_fast = [&](const ChainOp &op) __attribute__((always_inline)) {
+    const int N = ch_uni(op.N), out_slot = ch_uni(op.out_slot), ldo = ch_uni(op.ldo);
+    const float *out = ch_uni(op.out);
+    const bool out_ok = !out || ((ldo & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    return out_slot >= 0 && out_ok && wave * 64 + 64 <= N;
   };
 
   // ---------------------------------------------------------------- the program
@@ -575,10 +533,9 @@ __global__ __launch_bounds__(CH_THREADS, MINB) void k_chain(const ChainProblem *
       }
       const float *hw = ch_uni(op.hw);
       if (hw && (flags & CHF_HBEGIN)) { hacc[0] = v4f{0.f, 0.f, 0.f, 0.f}; hacc[1] = v4f{0.f, 0.f, 0.f, 0.f}; }
+      const bool fast = (flags & CHF_EMIT) && epilogue_fast(op);
       if (n0 < N) {   // wave-uniform: a wave whose 64 columns lie beyond N has no tile
-        if (flags & CHF_KS) {
-          for (int s = 0; s < nseg; ++s) gemm_seg_ks(op.seg[s], N, n0);
-        } else if (hw) {   // (the builder attaches a rider only when every wave has a tile: N > 192)
+        if (hw) {   // (the builder attaches a rider only when every wave has a tile: N > 192)
           const int hldw = ch_uni(op.hldw), hN = ch_uni(op.hN);
           int kcol = 0;
           for (int s = 0; s < nseg; ++s) {
@@ -591,14 +548,13 @@ __global__ __launch_bounds__(CH_THREADS, MINB) void k_chain(const ChainProblem *
         }
       }
       if (stamp) g_ch_stamps[nstamp++] = __builtin_amdgcn_s_memtime();
-      if (flags & CHF_EMIT) epilogue(op);
+      if (flags & CHF_EMIT) epilogue(op, fast);
     } else if (kind == CH_NARROW) {
       // Narrow outputs (skip heads, N <= 32): every wave computes the COMPLETE K sum for its own 16 rows with
       // v_mfma_f32_16x16x4_f32 - lane (i = l & 15, kq = l >> 4) holds A[row 16 w + i][16 h + 4 kq + c] and
       // B[..][col l & 15] for MFMA step c of 16-k half group h - so there is no cross-wave reduction, no scratch and
       // no barrier, and the accumulators are 4 registers per 16 columns.
       const int N = ch_uni(op.N), flags = ch_uni(op.flags), nseg = ch_uni(op.nseg);
-      const bool ks = (flags & CHF_KS) != 0;
       const int lj = lane & 15, kq = lane >> 4;
       if (flags & CHF_BEGIN) { hacc[0] = v4f{0.f, 0.f, 0.f, 0.f}; hacc[1] = v4f{0.f, 0.f, 0.f, 0.f}; }
       const int n0c = min(lj, N - 1), n1c = min(16 + lj, N - 1);   // clamped columns (never stored when shifted)
@@ -697,7 +653,6 @@ hipError_t chain_launch(const ChainProblem *probs_dev, int nprob, const ChainOp 
   // agents may launch from two threads
   static bool attr_set[64];
   static std::mutex attr_mu;
-  static int minb_pref = 1;
   {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -705,19 +660,14 @@ hipError_t chain_launch(const ChainProblem *probs_dev, int nprob, const ChainOp 
     if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     std::lock_guard<std::mutex> lk(attr_mu);
     if (!attr_set[dev]) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<1>), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_FLOATS * 4);
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<2>), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_FLOATS * 4);
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_FLOATS * 4);
       if (e != hipSuccess) return e;
-      if (const char *v = getenv("FDQL_CHAIN_MINB")) minb_pref = atoi(v) == 2 ? 2 : 1;   // tuning hook
       if (getenv("FDQL_CHAIN_STAMPS")) chain_enable_stamps(1);
+      if (const char *v = getenv("FDQL_CHAIN_STAGGER")) { const int k = atoi(v); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ch_stagger), &k, sizeof(k)); }
       attr_set[dev] = true;
     }
   }
-  const size_t lds_bytes = (size_t)lds_floats * 4;
-  const bool two = minb_pref == 2 && lds_bytes + CH_MAX_OPS * sizeof(ChainOp) + 512 <= 81920;
-  if (two) hipLaunchKernelGGL(k_chain<2>, dim3(total_blocks), dim3(CH_THREADS), lds_bytes, stream, probs_dev, nprob, ops_dev);
-  else hipLaunchKernelGGL(k_chain<1>, dim3(total_blocks), dim3(CH_THREADS), lds_bytes, stream, probs_dev, nprob, ops_dev);
+  hipLaunchKernelGGL(k_chain, dim3(total_blocks), dim3(CH_THREADS), (size_t)lds_floats * 4, stream, probs_dev, nprob, ops_dev);
   return hipGetLastError();
 }
 

@@ -60,18 +60,74 @@ __global__ __launch_bounds__(SW_THREADS) void k_skinny_wgrad(const SkinnyWgradPr
     }
     return;
   }
+  if (dY && Nout <= 2 && P.K <= 8 && P.col_blocks == 1) {
+    // tiny outer products (a skip head's rows over the action columns: 2 x 6): threads take different ROWS, then reduce -
+    // one column per thread would be 100 dependent round trips for a few kilobytes
+    float a2[2][8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) a2[q][c] = 0.f;
+    for (int m = m0 + tid; m < m1; m += SW_THREADS) {
+      gcf x = X + (long long)m * P.ldx, d = dY + (long long)m * P.lddy;
+      float xv[8], dv[2];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) xv[c] = c < P.K ? x[c] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) dv[q] = q < Nout ? d[q] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) a2[q][c] = fmaf(dv[q], xv[c], a2[q][c]);
+    }
+    __shared__ float pred[SW_THREADS / 64][16];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        float v = a2[q][c];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) pred[rg][8 * q + c] = v;
+      }
+    __syncthreads();
+    if (tid < 16 && (tid >> 3) < Nout && (tid & 7) < P.K) {
+      gf dst = (gf)(P.dW + (long long)split * P.split_stride);
+      dst[(long long)(tid >> 3) * P.sq + (long long)(tid & 7) * P.sk] = ((pred[0][tid] + pred[1][tid]) + pred[2][tid]) + pred[3][tid];
+    }
+    return;
+  }
   float acc[NOUT_MAX];
 #pragma unroll
   for (int q = 0; q < NOUT_MAX; ++q) acc[q] = 0.f;
-  for (int m = m0 + rg; m < m1; m += 4) {
-    const float xv = (kin && X) ? X[(long long)m * P.ldx + k] : 1.f;
-    if (dY) {
-      gcf d = dY + (long long)m * P.lddy;
+  // four rows per round (rows m, m + 4, m + 8, m + 12 of this row lane), their loads requested together: a loop of single
+  // rows is one memory round trip per row
+  for (int m = m0 + rg; m < m1; m += 16) {
+    float xv[4];
+    gcf dp[4];
 #pragma unroll
-      for (int q = 0; q < NOUT_MAX; ++q)
-        if (q < Nout) acc[q] = fmaf(d[q], xv, acc[q]);
+    for (int u = 0; u < 4; ++u) {
+      const int mc = min(m + 4 * u, m1 - 1);
+      xv[u] = (kin && X) ? X[(long long)mc * P.ldx + k] : 1.f;
+      dp[u] = dY + (long long)mc * P.lddy;
+    }
+    if (dY) {
+      float dv[4][NOUT_MAX];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int q = 0; q < NOUT_MAX; ++q) dv[u][q] = q < Nout ? dp[u][q] : 0.f;
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float xu = m + 4 * u < m1 ? xv[u] : 0.f;
+#pragma unroll
+        for (int q = 0; q < NOUT_MAX; ++q) acc[q] = fmaf(dv[u][q], xu, acc[q]);
+      }
     } else {
-      acc[0] += xv;
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[0] += m + 4 * u < m1 ? xv[u] : 0.f;
     }
   }
   if (rg > 0) {
@@ -106,6 +162,117 @@ hipError_t skinny_wgrad_launch_host(const SkinnyWgradProblem *host, const Skinny
   if (max_out <= 4) hipLaunchKernelGGL(k_skinny_wgrad<4>, dim3(total_blocks), dim3(SW_THREADS), 0, s, dev, n);
   else if (max_out <= 16) hipLaunchKernelGGL(k_skinny_wgrad<16>, dim3(total_blocks), dim3(SW_THREADS), 0, s, dev, n);
   else hipLaunchKernelGGL(k_skinny_wgrad<32>, dim3(total_blocks), dim3(SW_THREADS), 0, s, dev, n);
+  return hipGetLastError();
+}
+
+// ======================================================================================
+// Streaming narrow weight gradients: dW[q, k] (slab) = sum_{m in split} dY[m, q] * X[m, k] for X of exactly 256 columns
+// (row pitch 256) and Nout <= 32 - the skip heads' rows over a 256-wide activation, the few input columns (observation,
+// action) of a 256-wide layer with the roles swapped.  HBM-bound by construction: a workgroup = one K-split slab of one
+// problem, wave w owns columns [64 w, 64 w + 64) for ALL rows of the split, so nothing is reduced across waves and
+// nothing goes through LDS; per row pair a lane issues one 8-byte load of X (two of its wave's columns) and one 4-byte
+// load of dY (lane li = output q, lane half = row parity) - directly the B and A operands of two v_mfma_f32_32x32x2_f32
+// (64 flops per byte loaded: the matrix pipe idles) - and SW2_U row pairs are in flight per wave.
+// ======================================================================================
+#ifndef FDQL_SW2_U
+#define FDQL_SW2_U 8
+#endif
+constexpr int SW2_U = FDQL_SW2_U;   // row pairs per request round and wave (two rounds in flight)
+
+__global__ __launch_bounds__(256) void k_stream_wgrad(const SkinnyWgradProblem *__restrict__ probs, int nprob) {
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  typedef const __attribute__((address_space(1))) float *gcf;
+  typedef const __attribute__((address_space(1))) v2f *gcf2;
+  typedef __attribute__((address_space(1))) float *gf;
+  const int bid = blockIdx.x;
+  const int pi = find_problem<SkinnyWgradProblem, &SkinnyWgradProblem::block_start>(probs, nprob, bid, threadIdx.x & 63);
+  const SkinnyWgradProblem &P = probs[pi];
+  const int split = bid - P.block_start;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int Nout = P.Nout, M = P.M;
+  const int per = (((M + P.nsplit - 1) / P.nsplit) + 1) & ~1;   // even: row pairs
+  const int m0 = split * per, m1 = min(M, m0 + per);
+  gcf2 X = (gcf2)(P.X + 64 * wave + 2 * li);
+  gcf dY = (gcf)P.dY + min(li, Nout - 1);
+  const int lddy = P.lddy;
+  const bool qok = li < Nout;
+
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  // row of this lane in pair u of a group starting at row g: g + 2 u + lh; rows past the split read the split's last row
+  // (a valid address) with dY = 0
+  auto load = [&](int g, v2f (&x)[SW2_U], float (&d)[SW2_U]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < SW2_U; ++u) {
+      const int mc = min(g + 2 * u + lh, m1 - 1);
+      x[u] = X[(long long)mc * 128];                // (v2f units: row pitch 256 floats)
+      d[u] = dY[(long long)mc * lddy];
+    }
+  };
+  // (the dY = 0 of a row past the split / a lane past Nout is applied where the value is USED: a select next to the load
+  // would make every request wait for its own answer)
+  auto use = [&](int g, const v2f (&x)[SW2_U], const float (&d)[SW2_U]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < SW2_U; ++u) {
+      const float dv = (qok && g + 2 * u + lh < m1) ? d[u] : 0.f;
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(dv, x[u].x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(dv, x[u].y, acc1, 0, 0, 0);
+    }
+  };
+  if (m0 < m1) {
+    v2f xa[SW2_U], xb[SW2_U];
+    float da[SW2_U], db[SW2_U];
+    // (the empty asm statements pin the order requests-then-uses: the scheduler otherwise sinks every load next to its use)
+    load(m0, xa, da);
+    asm volatile("" ::: "memory");
+#pragma unroll 1
+    for (int g = m0; g < m1; g += 4 * SW2_U) {
+      load(g + 2 * SW2_U, xb, db);   // (past the end: clamped rows, used with dY = 0 or not at all)
+      asm volatile("" ::: "memory");
+      use(g, xa, da);
+      asm volatile("" ::: "memory");
+      if (g + 2 * SW2_U < m1) {
+        load(g + 4 * SW2_U, xa, da);
+        asm volatile("" ::: "memory");
+        use(g + 2 * SW2_U, xb, db);
+        asm volatile("" ::: "memory");
+      }
+    }
+  }
+  // D[q][column]: lane (li, lh) holds column 64 w + 2 li + t of tile t, rows q = 8 (r / 4) + 4 lh + r % 4.  A split without
+  // rows writes zeros (the slab sum runs over every slab).
+  gf dst = (gf)(P.dW + (long long)split * P.split_stride);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int q = 8 * (r >> 2) + 4 * lh + (r & 3);
+    if (q < Nout) {
+      const long long at = (long long)q * P.sq + (long long)(64 * wave + 2 * li) * P.sk;
+      dst[at] = acc0[r];
+      dst[at + P.sk] = acc1[r];
+    }
+  }
+}
+
+int stream_wgrad_finalize(SkinnyWgradProblem *p, int n) {
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    p[i].col_blocks = 1;
+    p[i].block_start = total;
+    total += p[i].nsplit;
+  }
+  return total;
+}
+
+bool stream_wgrad_takes(const SkinnyWgradProblem &p) {
+  return p.dY && p.X && p.K == 256 && p.ldx == 256 && p.Nout >= 1 && p.Nout <= 32 && p.M >= 1 && p.nsplit >= 1 &&
+         (reinterpret_cast<uintptr_t>(p.X) & 7) == 0;
+}
+
+hipError_t stream_wgrad_launch(const SkinnyWgradProblem *dev, int n, int total_blocks, hipStream_t s) {
+  if (total_blocks <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_stream_wgrad, dim3(total_blocks), dim3(256), 0, s, dev, n);
   return hipGetLastError();
 }
 

@@ -93,6 +93,10 @@ hipError_t act_policy_launch(const ActPolicyArgs &a, hipStream_t s);
 hipError_t head_dgrad_launch(const HeadDgradProblem *dev, int n, int total_blocks, hipStream_t s);
 hipError_t skinny_wgrad_launch_host(const SkinnyWgradProblem *host, const SkinnyWgradProblem *dev, int n,
                                     int total_blocks, hipStream_t s);
+// Streaming form (kernels.hip, k_stream_wgrad): X of exactly 256 columns (pitch 256), Nout <= 32; one workgroup per slab.
+bool stream_wgrad_takes(const SkinnyWgradProblem &p);
+int stream_wgrad_finalize(SkinnyWgradProblem *p, int n);
+hipError_t stream_wgrad_launch(const SkinnyWgradProblem *dev, int n, int total_blocks, hipStream_t s);
 hipError_t loss_launch(const LossArgs &a, hipStream_t s);
 // use_bootstrap_minibatch_nstep (soft_actor_critic.py:102-132, deepQlearning.py:226-228), SAC-min only:
 //   bound[b] = sum_t gamma^t r[t+1][b] + gamma^(T-1) td_target[T-2][b];

@@ -10,6 +10,13 @@
 // Column assignment: lane li of the A operand holds columns n0 + 2 li + tn (tn = 0, 1), of the B operand columns
 // 128 (t / 4) + 4 li + t % 4 (t = 0..7): consecutive lanes read consecutive 8 / 16 bytes (no bank conflicts) and the four
 // results a lane holds for t % 4 = 0..3 are consecutive in memory (one 16-byte store).
+//
+// Riders (WgInst::X2 / G2): the operand registers are, read as 16 blocks of 4 lanes, also operands of
+// v_mfma_f32_4x4x1_16b_f32 (block b = lane / 4 multiplies A[lane 4b + i] by B[lane 4b + j] into D register i of lane
+// 4b + j): the G registers give dW2[n][a] += G[m][n] X2[m][a] (B = the row's few X2 columns, 4 MFMAs per k-step), the X
+// columns give dW3[q][k] += G2[m][q] X[m][k] (A = the row's few G2 columns; wave w takes column groups t = 2w, 2w + 1:
+// 2 MFMAs per k-step).  Lane half lh holds the sums over the rows 2 s + lh; the halves are added at the end.  The X2 / G2
+// tiles (32 x 8, 32 x 4 floats, zero-padded) are staged through registers one tile ahead, like the images.
 #include "wgrad.h"
 
 #include <stdio.h>
@@ -76,6 +83,30 @@ __device__ __forceinline__ void wg_step(f32x16 (&c)[2][8], const v2f &g, const v
                  : "v"(g.x), "v"(g.y), "v"(x0.x), "v"(x0.y), "v"(x0.z), "v"(x0.w), "v"(x1.x), "v"(x1.y), "v"(x1.z), "v"(x1.w));
 }
 
+// riders: independent accumulators inside a statement; a rider's accumulator is next touched 16 MFMAs later
+__device__ __forceinline__ void wg_rider_x(v4f (&r)[2][2], const v2f &g, const v2f &b) {
+  asm volatile(
+      "v_mfma_f32_4x4x1_16b_f32 %0, %4, %6, %0\n\t"
+      "v_mfma_f32_4x4x1_16b_f32 %1, %4, %7, %1\n\t"
+      "v_mfma_f32_4x4x1_16b_f32 %2, %5, %6, %2\n\t"
+      "v_mfma_f32_4x4x1_16b_f32 %3, %5, %7, %3"
+      : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[1][0]), "+v"(r[1][1])
+      : "v"(g.x), "v"(g.y), "v"(b.x), "v"(b.y));
+}
+__device__ __forceinline__ void wg_rider_g(v4f (&r)[2], float dz, const v2f &x) {
+  asm volatile(
+      "v_mfma_f32_4x4x1_16b_f32 %0, %2, %3, %0\n\t"
+      "v_mfma_f32_4x4x1_16b_f32 %1, %2, %4, %1"
+      : "+v"(r[0]), "+v"(r[1])
+      : "v"(dz), "v"(x.x), "v"(x.y));
+}
+template <int OFF>
+__device__ __forceinline__ void wg_rd32(float &d, unsigned addr) { asm volatile("ds_read_b32 %0, %1 offset:%2" : "=&v"(d) : "v"(addr), "n"(OFF)); }
+
+constexpr int X2S = 4 * IMG, G2S = X2S + 2 * WG_BM * 8;   // rider stages behind the images: X2 [2][32][8], G2 [2][32][4] floats
+constexpr int LDS_FLOATS = 4 * IMG, LDS_FLOATS_RIDERS = G2S + 2 * WG_BM * 4;
+
+template <bool RIDERS>
 __global__ __launch_bounds__(256, 1) void k_wgrad_stat(const WgArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // G images [2][32][P], X images [2][32][P]
   const int tid = threadIdx.x, lane = tid & 63, wave = wg_uni(tid >> 6);
@@ -94,26 +125,61 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_stat(const WgArgs a) {
   const unsigned gbase = wg_lds_addr(lds) + (unsigned)(lh * P + n0 + 2 * li) * 4u;             // G[row 2 s + lh][n0 + 2 li ..]
   const unsigned xbase = wg_lds_addr(lds) + (unsigned)(2 * IMG + lh * P + 4 * li) * 4u;        // X[row 2 s + lh][4 li ..], [128 + 4 li ..]
 
-  // one row of a tile: 1 KiB global -> LDS (the hardware adds the lane's 16 bytes on the LDS side)
-  auto dma_row = [&](const float *src_tile, int img_floats, int r) __attribute__((always_inline)) {
-    __builtin_amdgcn_global_load_lds((glb_vp)(src_tile + r * WG_N + lane * 4), (lds_vp)(lds + img_floats + r * P), 16, 0, 0);
+  // one row of a tile: 1 KiB global -> LDS (the hardware adds the lane's 16 bytes on the LDS side).  The row offsets of the
+  // wave's eight pieces live in VGPRs (computed once): one scalar base per tile instead of one per row.
+  unsigned voff[WG_BM / 4];
+#pragma unroll
+  for (int u = 0; u < WG_BM / 4; ++u) voff[u] = (unsigned)((wave + 4 * u) * WG_N + lane * 4) * 4u;
+  auto dma_row = [&](const float *src_tile, int img_floats, int u) __attribute__((always_inline)) {
+    __builtin_amdgcn_global_load_lds((glb_vp)(reinterpret_cast<const char *>(src_tile) + voff[u]), (lds_vp)(lds + img_floats + (wave + 4 * u) * P), 16, 0, 0);
   };
 
   f32x16 acc[2][8];   // [tn][t]: AccVGPRs for the whole life of the workgroup
+  // riders
+  const float *X2 = nullptr, *G2 = nullptr;
+  int ldx2 = 0, ldg2 = 0;
+  if constexpr (RIDERS) { X2 = wg_uni(I.X2); G2 = wg_uni(I.G2); ldx2 = I.ldx2; ldg2 = I.ldg2; }
+  v4f rxa[2][2], rga[2];   // [tn][column group a = 4 ag + j], [t = 2 wave + u]
+#pragma unroll
+  for (int u = 0; u < 2; ++u) { rxa[u][0] = rxa[u][1] = rga[u] = v4f{0.f, 0.f, 0.f, 0.f}; }
+  const bool x2_lane = RIDERS && (tid & 7) < I.nx2, g2_lane = RIDERS && tid < 4 * WG_BM && (tid & 3) < I.ng2;
+  // staging: thread -> element (row tid / 8, column a = tid % 8) of the X2 tile, stored at [row][2 (a % 4) + a / 4] (a lane's
+  // two column groups side by side); (row tid / 4, q = tid % 4) of the G2 tile
+  const int x2_at = X2S + (tid >> 3) * 8 + 2 * (tid & 3) + ((tid >> 2) & 1), g2_at = G2S + tid;
+  const unsigned x2base = wg_lds_addr(lds) + (unsigned)(X2S + lh * 8 + 2 * (lane & 3)) * 4u;    // X2[row 2 s + lh][j, 4 + j]
+  const unsigned g2base = wg_lds_addr(lds) + (unsigned)(G2S + lh * 4 + (lane & 3)) * 4u;        // G2[row 2 s + lh][i]
+  const unsigned xpbase = xbase + (unsigned)(128 * (wave >> 1) + 2 * (wave & 1)) * 4u;          // X[row 2 s + lh][t = 2 wave, 2 wave + 1 of this lane]
+  auto stage_load = [&](int blk_, float &sx, float &sg, auto rxc, auto rgc) __attribute__((always_inline)) {
+    sx = 0.f; sg = 0.f;
+    if constexpr (decltype(rxc)::value) { if (x2_lane) sx = X2[(long long)(blk_ * WG_BM + (tid >> 3)) * ldx2 + (tid & 7)]; }
+    if constexpr (decltype(rgc)::value) { if (g2_lane) sg = G2[(long long)(blk_ * WG_BM + (tid >> 2)) * ldg2 + (tid & 3)]; }
+  };
+  auto stage_store = [&](int im, float sx, float sg, auto rxc, auto rgc) __attribute__((always_inline)) {
+    if constexpr (decltype(rxc)::value) lds[x2_at + im * WG_BM * 8] = sx;
+    if constexpr (decltype(rgc)::value) { if (tid < 4 * WG_BM) lds[g2_at + im * WG_BM * 4] = sg; }
+  };
 
   // One tile from image pair IM; the rows of tile `nxt` are fetched into the other pair during its first 8 k-steps.
-  auto tile = [&](auto firstc, auto imgc, int nxt) __attribute__((always_inline)) {
+  auto tile = [&](auto firstc, auto imgc, auto rxc, auto rgc, int nxt) __attribute__((always_inline)) {
     constexpr bool FIRST = decltype(firstc)::value;
     constexpr int IM = decltype(imgc)::value;
-    constexpr int IOFF = IM * IMG * 4;
+    constexpr bool RX = decltype(rxc)::value, RG = decltype(rgc)::value;
+    constexpr int NR = 3 + (RX ? 1 : 0) + (RG ? 2 : 0);   // LDS reads per k-step
+    constexpr int IOFF = IM * IMG * 4, XOFF = IM * WG_BM * 8 * 4, GOFF = IM * WG_BM * 4 * 4;
     // every wave is done with the other image pair and this pair has landed (each wave waited for its own pieces)
     asm volatile("s_barrier" ::: "memory");
     const float *ng = wg_uni(G + (long long)nxt * WG_BM * WG_N), *nx = wg_uni(X + (long long)nxt * WG_BM * WG_N);
+    float sx, sg;   // the next tile's rider elements: requested ahead of the DMA pieces (vector memory returns in order)
+    stage_load(nxt, sx, sg, rxc, rgc);
     v2f ga[2];
     v4f xa[2], xb[2];
+    v2f bx[2], xp[2];
+    float dz[2];
     wg_rd64<IOFF>(ga[0], gbase);
     wg_rd128<IOFF>(xa[0], xbase);
     wg_rd128<IOFF + 512>(xb[0], xbase);
+    if constexpr (RX) wg_rd64<XOFF>(bx[0], x2base);
+    if constexpr (RG) { wg_rd32<GOFF>(dz[0], g2base); wg_rd64<IOFF>(xp[0], xpbase); }
     sfor<0, NKS>([&](auto sc) __attribute__((always_inline)) {
       constexpr int s = decltype(sc)::value;
       if constexpr (s + 1 < NKS) {
@@ -121,16 +187,27 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_stat(const WgArgs a) {
         wg_rd64<off>(ga[(s + 1) & 1], gbase);
         wg_rd128<off>(xa[(s + 1) & 1], xbase);
         wg_rd128<off + 512>(xb[(s + 1) & 1], xbase);
-        wg_lgkm_wait<3>();
+        if constexpr (RX) wg_rd64<XOFF + (s + 1) * 64>(bx[(s + 1) & 1], x2base);
+        if constexpr (RG) { wg_rd32<GOFF + (s + 1) * 32>(dz[(s + 1) & 1], g2base); wg_rd64<off>(xp[(s + 1) & 1], xpbase); }
+        wg_lgkm_wait<NR>();
       } else {
         wg_lgkm_wait<0>();
       }
       asm volatile("" : "+v"(ga[s & 1]), "+v"(xa[s & 1]), "+v"(xb[s & 1]));
       wg_step<FIRST && s == 0>(acc, ga[s & 1], xa[s & 1], xb[s & 1]);
-      if constexpr (s < 8) {   // two pieces of the next tile per k-step: rows wave + 4 u of G (u < 8) and of X
-        dma_row(ng, (IM ^ 1) * IMG, wave + 4 * s);
-        dma_row(nx, (2 + (IM ^ 1)) * IMG, wave + 4 * s);
+      if constexpr (RX) {
+        asm volatile("" : "+v"(bx[s & 1]));
+        wg_rider_x(rxa, ga[s & 1], bx[s & 1]);
       }
+      if constexpr (RG) {
+        asm volatile("" : "+v"(dz[s & 1]), "+v"(xp[s & 1]));
+        wg_rider_g(rga, dz[s & 1], xp[s & 1]);
+      }
+      if constexpr (s < 8) {   // two pieces of the next tile per k-step: rows wave + 4 u of G (u < 8) and of X
+        dma_row(ng, (IM ^ 1) * IMG, s);
+        dma_row(nx, (2 + (IM ^ 1)) * IMG, s);
+      }
+      if constexpr (s == 11) stage_store(IM ^ 1, sx, sg, rxc, rgc);
       asm volatile("" ::: "memory");
     });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next pair have landed
@@ -140,62 +217,118 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_stat(const WgArgs a) {
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
 
-  // ---- first tile's images (once per workgroup)
-  int blk = j0;
-  {
-    const float *g0 = G + (long long)blk * WG_BM * WG_N, *x0 = X + (long long)blk * WG_BM * WG_N;
-#pragma unroll
-    for (int u = 0; u < WG_BM / 4; ++u) {
-      dma_row(g0, 0, wave + 4 * u);
-      dma_row(x0, 2 * IMG, wave + 4 * u);
+  auto finish = [&](auto rxc, auto rgc) __attribute__((always_inline)) {
+    // ---- this workgroup's partial -> slab j0; the slabs beyond the workgroups of the block are cleared (j0, j0 + per, ...)
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // MFMA results -> v_accvgpr_read (no compiler hazard handling around asm)
+  #pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+  #pragma unroll
+      for (int t = 0; t < 8; ++t) asm volatile("" : "+a"(acc[tn][t]));
+    float *const dW = wg_uni(I.dW);
+    const int ldw = I.ldw;
+    // element (n, k): n = n0 + 2 ((r & 3) + 8 (r >> 2) + 4 lh) + tn, k = 128 tq + 4 li + (0..3)
+    const unsigned vo = (unsigned)((n0 + 8 * lh) * ldw + 4 * li);
+    {
+      gf dst = (gf)(dW + (long long)j0 * a.slab_stride);
+  #pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+  #pragma unroll
+        for (int tq = 0; tq < 2; ++tq)
+  #pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const v4f v = {acc[tn][4 * tq][r], acc[tn][4 * tq + 1][r], acc[tn][4 * tq + 2][r], acc[tn][4 * tq + 3][r]};
+            *(gf4)(&dst[vo + (unsigned)((2 * ((r & 3) + 8 * (r >> 2)) + tn) * ldw + 128 * tq)]) = v;
+          }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  int nxt = blk + stride < nblk ? blk + stride : blk;   // the last tile prefetches itself again (nobody reads it)
-  tile(T(), I0(), nxt);
-  blk += stride;
-#pragma unroll 1
-  while (blk < nblk) {
-    nxt = blk + stride < nblk ? blk + stride : blk;
-    tile(F(), I1(), nxt);
-    blk += stride;
-    if (blk >= nblk) break;
-    nxt = blk + stride < nblk ? blk + stride : blk;
-    tile(F(), I0(), nxt);
-    blk += stride;
-  }
+    for (int e = j0 + stride; e < a.nslab; e += stride) {
+      gf dst = (gf)wg_uni(dW + (long long)e * a.slab_stride);
+      const v4f z = {0.f, 0.f, 0.f, 0.f};
+  #pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+  #pragma unroll
+        for (int tq = 0; tq < 2; ++tq)
+  #pragma unroll
+          for (int r = 0; r < 16; ++r) *(gf4)(&dst[vo + (unsigned)((2 * ((r & 3) + 8 * (r >> 2)) + tn) * ldw + 128 * tq)]) = z;
+    }
+    if constexpr (decltype(rxc)::value || decltype(rgc)::value) {
+      // rider results: register i of lane 4 b + j; the lane halves (rows 2 s, rows 2 s + 1) are added, half 0 stores
+      asm volatile("" : "+v"(rxa[0][0]), "+v"(rxa[0][1]), "+v"(rxa[1][0]), "+v"(rxa[1][1]), "+v"(rga[0]), "+v"(rga[1]));
+      const int b8 = (lane >> 2) & 7, j = lane & 3;
+      if constexpr (decltype(rxc)::value) {   // dW2[n = n0 + 2 (4 b8 + i) + tn][a = 4 ag + j]
+        float *const dW2 = wg_uni(I.dW2);
+        const int ldw2 = I.ldw2, nx2 = I.nx2;
+  #pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+  #pragma unroll
+          for (int ag = 0; ag < 2; ++ag)
+  #pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              float v = rxa[tn][ag][i];
+              v += __shfl_xor(v, 32);
+              const int at = (n0 + 2 * (4 * b8 + i) + tn) * ldw2 + 4 * ag + j;
+              if (lh == 0 && 4 * ag + j < nx2) {
+                ((gf)(dW2 + (long long)j0 * a.slab_stride))[at] = v;
+                for (int e = j0 + stride; e < a.nslab; e += stride) ((gf)(dW2 + (long long)e * a.slab_stride))[at] = 0.f;
+              }
+            }
+      }
+      if constexpr (decltype(rgc)::value) {   // dW3[q = i][k = 128 (wave / 2) + 16 b8 + 4 j + 2 (wave % 2) + u]
+        float *const dW3 = wg_uni(I.dW3);
+        const int ldw3 = I.ldw3, ng2 = I.ng2;
+  #pragma unroll
+        for (int u = 0; u < 2; ++u)
+  #pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float v = rga[u][i];
+            v += __shfl_xor(v, 32);
+            const int at = i * ldw3 + 128 * (wave >> 1) + 16 * b8 + 4 * j + 2 * (wave & 1) + u;
+            if (lh == 0 && i < ng2) {
+              ((gf)(dW3 + (long long)j0 * a.slab_stride))[at] = v;
+              for (int e = j0 + stride; e < a.nslab; e += stride) ((gf)(dW3 + (long long)e * a.slab_stride))[at] = 0.f;
+            }
+          }
+      }
+    }
+  };
 
-  // ---- this workgroup's partial -> slab j0; the slabs beyond the workgroups of the block are cleared (j0, j0 + per, ...)
-  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // MFMA results -> v_accvgpr_read (no compiler hazard handling around asm)
+  auto run = [&](auto rxc, auto rgc) __attribute__((always_inline)) {
+    // ---- first tile's images (once per workgroup)
+    int blk = j0;
+    {
+      const float *g0 = G + (long long)blk * WG_BM * WG_N, *x0 = X + (long long)blk * WG_BM * WG_N;
+      float sx, sg;
+      stage_load(blk, sx, sg, rxc, rgc);
 #pragma unroll
-  for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-    for (int t = 0; t < 8; ++t) asm volatile("" : "+a"(acc[tn][t]));
-  float *const dW = wg_uni(I.dW);
-  const int ldw = I.ldw;
-  // element (n, k): n = n0 + 2 ((r & 3) + 8 (r >> 2) + 4 lh) + tn, k = 128 tq + 4 li + (0..3)
-  const unsigned vo = (unsigned)((n0 + 8 * lh) * ldw + 4 * li);
-  {
-    gf dst = (gf)(dW + (long long)j0 * a.slab_stride);
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-      for (int tq = 0; tq < 2; ++tq)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const v4f v = {acc[tn][4 * tq][r], acc[tn][4 * tq + 1][r], acc[tn][4 * tq + 2][r], acc[tn][4 * tq + 3][r]};
-          *(gf4)(&dst[vo + (unsigned)((2 * ((r & 3) + 8 * (r >> 2)) + tn) * ldw + 128 * tq)]) = v;
-        }
-  }
-  for (int e = j0 + stride; e < a.nslab; e += stride) {
-    gf dst = (gf)wg_uni(dW + (long long)e * a.slab_stride);
-    const v4f z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-      for (int tq = 0; tq < 2; ++tq)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) *(gf4)(&dst[vo + (unsigned)((2 * ((r & 3) + 8 * (r >> 2)) + tn) * ldw + 128 * tq)]) = z;
+      for (int u = 0; u < WG_BM / 4; ++u) {
+        dma_row(g0, 0, u);
+        dma_row(x0, 2 * IMG, u);
+      }
+      stage_store(0, sx, sg, rxc, rgc);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    int nxt = blk + stride < nblk ? blk + stride : blk;   // the last tile prefetches itself again (nobody reads it)
+    tile(T(), I0(), rxc, rgc, nxt);
+    blk += stride;
+#pragma unroll 1
+    while (blk < nblk) {
+      nxt = blk + stride < nblk ? blk + stride : blk;
+      tile(F(), I1(), rxc, rgc, nxt);
+      blk += stride;
+      if (blk >= nblk) break;
+      nxt = blk + stride < nblk ? blk + stride : blk;
+      tile(F(), I0(), rxc, rgc, nxt);
+      blk += stride;
+    }
+    finish(rxc, rgc);
+  };
+  // workgroup-uniform: one of the four loop bodies (each with its own end: the accumulators never cross a join)
+  if constexpr (RIDERS) {
+    if (X2 && G2) run(T(), T());
+    else if (G2) run(F(), T());
+    else if (X2) run(T(), F());
+    else run(F(), F());
+  } else {
+    run(F(), F());
   }
 }
 
@@ -237,20 +370,72 @@ bool wgrad_stat_from_problems(const GemmProblem *probs, int nprob, int nslab, lo
       ncu_of[dev] = pr.multiProcessorCount;
     }
   }
-  int per = ncu_of[dev] / nprob;
-  if (per > args.blocks_per_inst) per = args.blocks_per_inst;
-  if (per > nslab) per = nslab;   // one slab per workgroup of a block
-  if (per < 1) return false;
-  for (int i = 0; i <= nprob; ++i) args.wg_first[i] = i * per;
+  args.ncu = ncu_of[dev];
+  return wgrad_stat_balance(args);
+}
+
+// Workgroups per block: one per CU in all, dealt so that the slowest block finishes as early as possible - a block with
+// riders costs more per tile (measured: + 7 % with the narrow-input rider, + 4 % with the narrow-output one), and tiles come
+// in whole numbers.  At most one workgroup per slab and per tile.
+bool wgrad_stat_balance(WgArgs &args) {
+  const int n = args.ninst, tiles = args.blocks_per_inst;
+  int cap = tiles < args.nslab ? tiles : args.nslab;
+  if (n < 1 || cap < 1 || args.ncu < n) return false;
+  int w[WG_MAX_INST];
+  double cost[WG_MAX_INST];
+  for (int i = 0; i < n; ++i) {
+    w[i] = 1;
+    cost[i] = 1.0 + (args.inst[i].X2 ? 0.07 : 0.0) + (args.inst[i].G2 ? 0.04 : 0.0);
+  }
+  auto time_of = [&](int i, int wi) { return cost[i] * ((tiles + wi - 1) / wi); };
+  for (int left = args.ncu - n; left > 0; --left) {
+    int worst = -1;
+    for (int i = 0; i < n; ++i)
+      if (w[i] < cap && (worst < 0 || time_of(i, w[i]) > time_of(worst, w[worst]))) worst = i;
+    if (worst < 0) break;
+    ++w[worst];
+  }
+  // trim: a workgroup that does not lower its block's tile count only adds a slab to write
+  for (int i = 0; i < n; ++i)
+    while (w[i] > 1 && (tiles + w[i] - 2) / (w[i] - 1) == (tiles + w[i] - 1) / w[i]) --w[i];
+  args.wg_first[0] = 0;
+  for (int i = 0; i < n; ++i) args.wg_first[i + 1] = args.wg_first[i] + w[i];
   return true;
 }
 
-double wgrad_stat_flops(const WgArgs &a) { return 2.0 * a.M * (double)WG_N * WG_N * a.ninst; }
+bool wgrad_stat_add_rider(WgArgs &args, int inst, const GemmProblem &p) {
+  const char *env = getenv("FDQL_WGRAD_RIDERS");   // "0": never (tuning / test hook; read per plan build)
+  if (env && env[0] == '0') return false;
+  if (inst < 0 || inst >= args.ninst) return false;
+  WgInst &I = args.inst[inst];
+  if (p.nseg != 1 || p.ksplit != args.nslab || p.split_stride != args.slab_stride || p.bias || p.epi != EPI_NONE || p.colsum || p.C2 ||
+      p.hf_w || p.fz_h)
+    return false;
+  const GemmSeg &s = p.seg[0];
+  if (s.a_kc || s.b_kc || s.K != args.M) return false;
+  auto aligned4 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 3) == 0; };
+  if (!aligned4(s.A) || !aligned4(s.B) || !aligned4(p.C)) return false;
+  if (p.M == WG_N && p.N >= 1 && p.N <= 8 && s.A == I.G && s.lda == WG_N && !I.X2) {   // few input columns under the same G
+    I.X2 = s.B; I.nx2 = p.N; I.ldx2 = s.ldb; I.dW2 = p.C; I.ldw2 = p.ldc;
+    return true;
+  }
+  if (p.N == WG_N && p.M >= 1 && p.M <= 4 && s.B == I.X && s.ldb == WG_N && !I.G2) {   // few output rows over the same X
+    I.G2 = s.A; I.ng2 = p.M; I.ldg2 = s.lda; I.dW3 = p.C; I.ldw3 = p.ldc;
+    return true;
+  }
+  return false;
+}
+// (the caller re-deals the workgroups with wgrad_stat_balance() once the riders are attached)
+
+double wgrad_stat_flops(const WgArgs &a) {
+  double f = 2.0 * a.M * (double)WG_N * WG_N * a.ninst;
+  for (int i = 0; i < a.ninst; ++i) f += 2.0 * a.M * (double)WG_N * (a.inst[i].nx2 + a.inst[i].ng2);
+  return f;
+}
 
 hipError_t wgrad_stat_launch(const WgArgs &a, hipStream_t s) {
   static bool attr[64];
   static std::mutex mu;
-  constexpr int lds_bytes = 4 * IMG * 4;
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
@@ -258,12 +443,17 @@ hipError_t wgrad_stat_launch(const WgArgs &a, hipStream_t s) {
   {
     std::lock_guard<std::mutex> lk(mu);
     if (!attr[dev]) {   // the opt-in to > 64 KiB of dynamic LDS belongs to the (device, function) pair
-      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wgrad_stat), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wgrad_stat<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FLOATS * 4);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wgrad_stat<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FLOATS_RIDERS * 4);
       if (e != hipSuccess) return e;
       attr[dev] = true;
     }
   }
-  hipLaunchKernelGGL(k_wgrad_stat, dim3(a.wg_first[a.ninst]), dim3(256), lds_bytes, s, a);
+  bool riders = false;
+  for (int i = 0; i < a.ninst; ++i) riders = riders || a.inst[i].X2 || a.inst[i].G2;
+  if (riders) hipLaunchKernelGGL(k_wgrad_stat<true>, dim3(a.wg_first[a.ninst]), dim3(256), LDS_FLOATS_RIDERS * 4, s, a);
+  else hipLaunchKernelGGL(k_wgrad_stat<false>, dim3(a.wg_first[a.ninst]), dim3(256), LDS_FLOATS * 4, s, a);
   return hipGetLastError();
 }
 

@@ -404,6 +404,13 @@ int fdql_test_rowgemm(const float *A0, const float *A1, int32_t k1, const float 
  * is the gradient (franQ: autograd's addmm backward of mlp.py:88-94).  Asynchronous on `stream`. */
 int fdql_test_wgrad_stat(const float *G, const float *X, float *dW, int32_t M, int32_t nprob, int32_t ldw, int32_t nslab,
                          int64_t slab_stride, void *stream);
+/* The same with riders (csrc/wgrad.h): block i (every x2_every-th when X2 is given) also produces
+ *   dW2[i] [256, ldw2] (columns < nx2 <= 8) = G[i]^T X2[i]   (X2: [nprob * M, ldx2], the block's few extra input columns) and
+ *   dW3[i] [ng2 <= 4, ldw3] (256 columns)    = G2[i]^T X[i]   (G2: [nprob * M, ldg2], a few extra output rows over the same input)
+ * in the K-split slabs like dW.  X2 / G2 may be null. */
+int fdql_test_wgrad_stat_riders(const float *G, const float *X, float *dW, int32_t M, int32_t nprob, int32_t ldw, int32_t nslab,
+                                int64_t slab_stride, const float *X2, int32_t nx2, int32_t ldx2, float *dW2, int32_t ldw2, int32_t x2_every,
+                                const float *G2, int32_t ng2, int32_t ldg2, float *dW3, int32_t ldw3, void *stream);
 
 /* Tuning hook: build of the GEMM main loop: 1 (default) = K-chunk 16 with next-step fragment prefetch, 0 = K-chunk 16
  * without it, 4 = K-chunk 8; 2 and 3 alias 0.  Affects speed only. */

@@ -1034,3 +1034,55 @@ def test_wgrad_stat_blocks(dev, M, nprob, ldw, nslab):
     err = float((got[..., :256].sum(0) - want).abs().max() / want.abs().max())
     assert err < 2e-5, err
     assert bool((got[..., 256:] == 7.0).all()) and bool((slabs[:, nprob * 256 * ldw:] == 7.0).all())   # nothing outside the blocks
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,nprob,nx2,x2_every,ng2,nslab", [(64, 1, 6, 1, 2, 4), (12544, 15, 6, 3, 2, 32), (2048, 4, 8, 2, 4, 32),
+                                                         (320, 3, 1, 1, 1, 8), (1024, 5, 3, 2, 0, 16), (1024, 5, 0, 0, 3, 16)])
+def test_wgrad_stat_riders(dev, M, nprob, nx2, x2_every, ng2, nslab):
+    """Riders of the output-stationary weight-gradient kernel (csrc/wgrad.h): next to dW[i] = G[i]^T X[i], block i (every
+    x2_every-th) also yields the gradient of a few extra INPUT columns, dW2[i] = G[i]^T X2[i] (a critic's action columns:
+    columns 256.. of its layer-0 weight, row pitch 262), and every block the gradient of a few extra OUTPUT rows over the same
+    input, dW3[i] = G2[i]^T X[i] (the skip head's rows over this layer's input: row pitch 774) - as v_mfma_f32_4x4x1 on the
+    operand registers of the main block.  fp64 torch is the reference; slabs hold partials or zeros, nothing else is touched."""
+    from fastdeepqlearning_amd import _native as nat
+    lib = nat.load(); st = nat.current_stream(dev)
+    g = torch.Generator().manual_seed(M + 7 * nprob + nx2)
+    G = torch.randn(nprob * M, 256, generator=g)
+    X = torch.randn(nprob * M, 256, generator=g)
+    ldw, ldx2, ldg2, ldw3 = (262 if nx2 <= 6 else 265), max(nx2, 1), max(ng2, 1) + 1, 774
+    X2 = torch.randn(nprob * M, ldx2, generator=g)
+    G2 = torch.randn(nprob * M, ldg2, generator=g)
+    # one arena per slab: [dense blocks incl. the action columns | head rows]
+    n_dense, n_head = nprob * 256 * ldw, nprob * max(ng2, 1) * ldw3
+    stride = n_dense + n_head + 8
+    slabs = torch.full((nslab, stride), 7.0, device=dev)
+    G_d, X_d, X2_d, G2_d = G.to(dev), X.to(dev), X2.to(dev), G2.to(dev)
+    base = slabs.data_ptr()
+    rc = lib.fdql_test_wgrad_stat_riders(nat.ptr(G_d), nat.ptr(X_d), base, M, nprob, ldw, nslab, stride,
+                                         nat.ptr(X2_d) if nx2 else None, nx2, ldx2, base + 4 * 256, ldw, x2_every,
+                                         nat.ptr(G2_d) if ng2 else None, ng2, ldg2, base + 4 * n_dense, ldw3, st)
+    assert rc == 0, lib.fdql_last_error().decode()
+    torch.cuda.synchronize()
+    tot = slabs.double().sum(0).cpu()
+    dense = tot[:n_dense].view(nprob, 256, ldw)
+    head = tot[n_dense:n_dense + n_head].view(nprob, max(ng2, 1), ldw3)
+    Gd, Xd = G.double().view(nprob, M, 256), X.double().view(nprob, M, 256)
+    want = torch.bmm(Gd.transpose(1, 2), Xd)
+    assert float((dense[..., :256] - want).abs().max() / want.abs().max()) < 2e-5
+    untouched = 7.0 * nslab
+    for i in range(nprob):
+        if nx2 and i % x2_every == 0:
+            w2 = Gd[i].T @ X2.double().view(nprob, M, ldx2)[i][:, :nx2]
+            assert float((dense[i, :, 256:256 + nx2] - w2).abs().max() / w2.abs().max()) < 2e-5, i
+            assert bool((dense[i, :, 256 + nx2:] == untouched).all())
+        else:
+            assert bool((dense[i, :, 256:] == untouched).all())
+    if ng2:
+        w3 = torch.bmm(G2.double().view(nprob, M, ldg2)[:, :, :ng2].transpose(1, 2), Xd)
+        assert float((head[:, :ng2, :256] - w3).abs().max() / w3.abs().max()) < 2e-5
+        assert bool((head[:, :, 256:] == untouched).all())
+    else:
+        assert bool((head == untouched).all())
+    assert bool((tot[n_dense + n_head:] == untouched).all())
+    # (a slab the kernel left alone inside a block or a rider would put 7.0 into the sums checked above)
