@@ -1845,11 +1845,37 @@ int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {
   // 8 -> 0.57 ms, 16 -> 0.45 ms, 32 -> 0.41 ms for the wgrad stage; the slab reduction grows by 0.02 ms)
   int s = a->M / 384;
   a->nsplit = s < 1 ? 1 : (s > 32 ? 32 : s);
+  layout(a);
+  {
+    // With the dense 256 x 256 blocks on the output-stationary kernel (wgrad.h: one slab per workgroup of a block, ncu /
+    // blocks of them - 16 to 18 at config 2) and the narrow ones on single-wave streaming workgroups (k_stream_wgrad), slabs
+    // beyond that count are only cleared and summed: the split is sized to it (config 2: 32 -> 20 slabs, the slab sum in
+    // k_adam_polyak 0.031 -> 0.023 ms, the cleared slabs' 50 MB of stores gone from the weight-gradient launch).
+    const char *e1 = getenv("FDQL_WGRAD_STAT"), *e2 = getenv("FDQL_STREAM_WGRAD");
+    int nblk = 0;
+    auto count = [&](const MlpDesc &d, int copies) {
+      int feat = d.din;
+      for (size_t i = 0; i < d.hid.size(); ++i) {
+        if (d.hid[i] == WG_N) nblk += copies * ((i == 0 ? d.din : (d.hid[i - 1] == WG_N ? WG_N : 0)) / WG_N);
+        feat += d.hid[i];
+      }
+      if (d.dout == WG_N) nblk += copies * (feat / WG_N);
+    };
+    for (const MlpDesc &d : a->critic) count(d, 1);
+    count(a->actor, 1); count(a->joiner, 1); count(a->enc_obs, 1);
+    hipDeviceProp_t pr;
+    int dev = 0;
+    if (!(e1 && e1[0] == '0') && !(e2 && e2[0] == '0') && nblk > 0 && nblk <= WG_MAX_INST && a->M % WG_BM == 0 &&
+        (long long)nblk * (a->M / WG_BM) >= 8 * a->rows_min_tiles && hipGetDevice(&dev) == hipSuccess &&
+        hipGetDeviceProperties(&pr, dev) == hipSuccess) {
+      const int want = std::max(8, pr.multiProcessorCount / nblk + 3);
+      if (want < a->nsplit) a->nsplit = want;
+    }
+  }
   if (const char *e = getenv("FDQL_NSPLIT")) {  // tuning hook: K-split of the weight-gradient GEMMs
     const int v = atoi(e);
     if (v >= 1 && v <= 64) a->nsplit = v;
   }
-  layout(a);
   {
     const char *we = getenv("FDQL_WSTAT");
     bool ws_ok = !(we && (we[0] == '0' || !strcmp(we, "fwd"))) && getenv("FDQL_NO_DSTATE_SPLIT") == nullptr;
@@ -1858,9 +1884,6 @@ int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {
             (long long)c.n_critics * (a->M / RG_BM) >= a->rows_min_tiles;
     a->dstate_split = a->M <= DSTATE_SPLIT_MAX_ROWS || ws_ok;
   }
-  // (The output-stationary weight-gradient launch (wgrad.h) writes ncu / blocks slabs per block - 17 at config 2 - and clears
-  // the others.  Sizing the K-split to that count was measured: the slab sum drops 0.037 -> 0.024 ms, but the narrow
-  // HBM-bound weight gradients, which share the split, lose their parallelism: 0.106 -> 0.142 ms.  The split stays.)
   carve(a);
   a->ws_need = a->carve_top;
   *out = a;
@@ -2107,6 +2130,61 @@ hipError_t act_mlp(const fdql_agent *a, const MlpDesc &d, const ActSeg *in, int 
   top += pad4((int64_t)rows * d.dout);
   return act_layer_launch(l, s);
 }
+// The one-launch form (k_act_fused): feed-forward encoder / joiner / actor, at most ACTF_ROWS rows.  Feature rows of an MLP
+// in LDS: [input blocks | h_0 | h_1 ...], every block starting on a multiple of 4 floats; a layer reads blocks of its own
+// MLP's rows, the skip head all of them (mlp.py:88-94) and writes the next MLP's first input block.
+bool act_fused_build(const fdql_agent *a, const ActSeg *in, int nin, int rows, ActFusedArgs &fa) {
+  // Opt-in (FDQL_ACT_FUSED=1): measured SLOWER than the launch-per-layer form - 60.8 us against 39.7 us for one row at
+  // config-2 widths - one CU pulling a layer's 256 KB of weights takes ~10 us per layer, more than the launch it saves
+  // (DESIGN.md section 5).  Kept for the parity test and as the starting point of a multi-workgroup form.
+  const char *env = getenv("FDQL_ACT_FUSED");
+  if (!env || env[0] != '1') return false;
+  if (rows > ACTF_ROWS || a->cfg.joiner_gru || !a->conv.empty() || nin > ACTF_MAX_IN) return false;
+  memset(&fa, 0, sizeof(fa));
+  fa.rows = rows;
+  const MlpDesc *mlps[3] = {&a->enc_obs, &a->joiner, &a->actor};
+  int top = 0;
+  struct Rows { int base, pitch; std::vector<int> off, width; } fr[3];
+  for (int m = 0; m < 3; ++m) {
+    const MlpDesc &d = *mlps[m];
+    int at = 0;
+    auto block = [&](int w) { fr[m].off.push_back(at); fr[m].width.push_back(w); at += (int)pad4(w); };
+    if (m == 0) for (int j = 0; j < nin; ++j) block(in[j].width);
+    else block(mlps[m - 1]->dout);
+    for (int h : d.hid) block(h);
+    fr[m].base = top; fr[m].pitch = at;
+    top += ACTF_ROWS * at;
+  }
+  fa.logits_off = top; fa.logits_pitch = (int)pad4(a->actor.dout);
+  top += ACTF_ROWS * fa.logits_pitch;
+  if (top > ACTF_LDS_FLOATS) return false;
+  for (int j = 0; j < nin; ++j) fa.in[j] = {in[j].ptr, in[j].ld, in[j].width, fr[0].base + fr[0].off[j], fr[0].pitch};
+  fa.nin = nin;
+  for (int m = 0; m < 3; ++m) {
+    const MlpDesc &d = *mlps[m];
+    const int nfirst = m == 0 ? nin : 1, nh = (int)d.hid.size();
+    if (nfirst + nh > ACTF_MAX_SEG) return false;
+    for (int i = 0; i <= nh; ++i) {   // i == nh: the skip head
+      if (fa.nlayers >= ACTF_MAX_LAYERS) return false;
+      ActFusedLayer &L = fa.L[fa.nlayers++];
+      L.x_pitch = fr[m].pitch;
+      int wcol = 0;
+      auto seg = [&](int blk) { L.seg[L.nseg++] = {fr[m].base + fr[m].off[blk], wcol, fr[m].width[blk]}; wcol += fr[m].width[blk]; };
+      if (i == 0 || i == nh) for (int j = 0; j < nfirst; ++j) seg(j);
+      if (i == nh) for (int j = 0; j < nh; ++j) seg(nfirst + j);
+      else if (i > 0) seg(nfirst + i - 1);
+      if (i < nh) {
+        L.W = a->params + d.w_off[i]; L.ldw = d.in_of(i); L.bias = a->params + d.b_off[i]; L.N = d.hid[i]; L.leaky = 1;
+        L.out_off = fr[m].base + fr[m].off[nfirst + i]; L.out_pitch = fr[m].pitch;
+      } else {
+        L.W = a->params + d.hw_off; L.ldw = d.head_ld(); L.bias = a->params + d.hb_off; L.N = d.dout; L.leaky = 0;
+        if (m < 2) { L.out_off = fr[m + 1].base; L.out_pitch = fr[m + 1].pitch; }
+        else { L.out_off = fa.logits_off; L.out_pitch = fa.logits_pitch; }
+      }
+    }
+  }
+  return true;
+}
 }  // namespace
 
 int fdql_agent_act(fdql_agent_t *a, const float *obs_1d, const float *achieved_goal, const float *desired_goal,
@@ -2137,6 +2215,18 @@ int fdql_agent_act(fdql_agent_t *a, const float *obs_1d, const float *achieved_g
   }
   float *enc = nullptr, *state = nullptr, *logits = nullptr;
   hipError_t e = hipSuccess;
+  {   // a handful of rows through feed-forward networks: the whole of act() in one launch
+    ActFusedArgs fa;
+    if (act_fused_build(a, in, nin, rows, fa)) {
+      ActPolicyArgs &p = fa.pol;
+      p.ld = a->actor.dout; p.rows = rows; p.A = c.act_dim; p.discrete = c.discrete;
+      p.exploit_mask = exploit_mask; p.noise = noise; p.seed = seed; p.counter = counter;
+      p.action = action; p.log_prob = log_prob; p.explore = explore_action; p.exploit = exploit_action;
+      e = act_fused_launch(fa, s);
+      if (e != hipSuccess) { set_error("fdql_agent_act: %s", hipGetErrorString(e)); return FDQL_EHIP; }
+      return 0;
+    }
+  }
   {   // pixel encoder: im2col + one skinny layer launch per conv layer (rows * OH * OW "batch rows")
     const float *cin = obs_2d;
     for (size_t i = 0; i < a->conv.size() && e == hipSuccess; ++i) {

@@ -168,9 +168,9 @@ hipError_t skinny_wgrad_launch_host(const SkinnyWgradProblem *host, const Skinny
 // ======================================================================================
 // Streaming narrow weight gradients: dW[q, k] (slab) = sum_{m in split} dY[m, q] * X[m, k] for X of exactly 256 columns
 // (row pitch 256) and Nout <= 32 - the skip heads' rows over a 256-wide activation, the few input columns (observation,
-// action) of a 256-wide layer with the roles swapped.  HBM-bound by construction: a workgroup = one K-split slab of one
-// problem, wave w owns columns [64 w, 64 w + 64) for ALL rows of the split, so nothing is reduced across waves and
-// nothing goes through LDS; per row pair a lane issues one 8-byte load of X (two of its wave's columns) and one 4-byte
+// action) of a 256-wide layer with the roles swapped.  HBM-bound by construction: a single-wave workgroup = 64 columns
+// [64 w, 64 w + 64) of one K-split slab of one problem for ALL rows of the split, so nothing is reduced across waves,
+// nothing goes through LDS, and the number of waves does not hang on the K-split alone; per row pair a lane issues one 8-byte load of X (two of its wave's columns) and one 4-byte
 // load of dY (lane li = output q, lane half = row parity) - directly the B and A operands of two v_mfma_f32_32x32x2_f32
 // (64 flops per byte loaded: the matrix pipe idles) - and SW2_U row pairs are in flight per wave.
 // ======================================================================================
@@ -179,7 +179,7 @@ hipError_t skinny_wgrad_launch_host(const SkinnyWgradProblem *host, const Skinny
 #endif
 constexpr int SW2_U = FDQL_SW2_U;   // row pairs per request round and wave (two rounds in flight)
 
-__global__ __launch_bounds__(256) void k_stream_wgrad(const SkinnyWgradProblem *__restrict__ probs, int nprob) {
+__global__ __launch_bounds__(64) void k_stream_wgrad(const SkinnyWgradProblem *__restrict__ probs, int nprob) {
   typedef float f32x16 __attribute__((ext_vector_type(16)));
   typedef float v2f __attribute__((ext_vector_type(2)));
   typedef const __attribute__((address_space(1))) float *gcf;
@@ -188,8 +188,8 @@ __global__ __launch_bounds__(256) void k_stream_wgrad(const SkinnyWgradProblem *
   const int bid = blockIdx.x;
   const int pi = find_problem<SkinnyWgradProblem, &SkinnyWgradProblem::block_start>(probs, nprob, bid, threadIdx.x & 63);
   const SkinnyWgradProblem &P = probs[pi];
-  const int split = bid - P.block_start;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int split = (bid - P.block_start) >> 2, wave = (bid - P.block_start) & 3;   // a workgroup is ONE wave: 64 columns of one slab
+  const int lane = threadIdx.x, li = lane & 31, lh = lane >> 5;
   const int Nout = P.Nout, M = P.M;
   const int per = (((M + P.nsplit - 1) / P.nsplit) + 1) & ~1;   // even: row pairs
   const int m0 = split * per, m1 = min(M, m0 + per);
@@ -258,9 +258,9 @@ __global__ __launch_bounds__(256) void k_stream_wgrad(const SkinnyWgradProblem *
 int stream_wgrad_finalize(SkinnyWgradProblem *p, int n) {
   int total = 0;
   for (int i = 0; i < n; ++i) {
-    p[i].col_blocks = 1;
+    p[i].col_blocks = 4;
     p[i].block_start = total;
-    total += p[i].nsplit;
+    total += 4 * p[i].nsplit;
   }
   return total;
 }
@@ -272,7 +272,7 @@ bool stream_wgrad_takes(const SkinnyWgradProblem &p) {
 
 hipError_t stream_wgrad_launch(const SkinnyWgradProblem *dev, int n, int total_blocks, hipStream_t s) {
   if (total_blocks <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_stream_wgrad, dim3(total_blocks), dim3(256), 0, s, dev, n);
+  hipLaunchKernelGGL(k_stream_wgrad, dim3(total_blocks), dim3(64), 0, s, dev, n);
   return hipGetLastError();
 }
 
@@ -1549,17 +1549,16 @@ __global__ __launch_bounds__(256) void k_act_layer(ActLayerArgs a) {
 
 // explore / exploit actions, log-prob of the explored one, and the exploit_mask select
 // (gaussian_mlp.py:15-39 or gumbel_mlp.py:7-54, then deepQlearning.py:175-180)
-__global__ void k_act_policy(ActPolicyArgs a) {
+// (row m; `lrow`: its logits, in global memory or LDS)
+__device__ __forceinline__ void act_policy_row(const ActPolicyArgs &a, int m, const float *lrow) {
 #pragma clang fp contract(off)
-  const int m = blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= a.rows) return;
   const bool use_exploit = a.exploit_mask && a.exploit_mask[m] != 0;
   const int A = a.A;
   if (a.discrete) {
     float lo[GUMBEL_MAXN], u[GUMBEL_MAXN], norm[GUMBEL_MAXN], relaxed[GUMBEL_MAXN];
     int greedy = 0;
     for (int j = 0; j < A; ++j) {
-      lo[j] = a.logits[(long long)m * a.ld + j];
+      lo[j] = lrow[j];
       u[j] = a.noise ? a.noise[(long long)m * A + j]
                      : device_noise(a.seed, (uint32_t)a.counter, 7u, (uint32_t)(m * A + j), false);
       if (lo[j] > lo[greedy]) greedy = j;
@@ -1581,7 +1580,7 @@ __global__ void k_act_policy(ActPolicyArgs a) {
     a.action[m] = (float)(use_exploit ? greedy : best_st);
     return;
   }
-  const float *lo = a.logits + (long long)m * a.ld;
+  const float *lo = lrow;
   float logp = 0.f;
   for (int j = 0; j < A; ++j) {
     const float mean = lo[j];
@@ -1601,6 +1600,104 @@ __global__ void k_act_policy(ActPolicyArgs a) {
     a.action[(long long)m * A + j] = use_exploit ? gr : ex;
   }
   if (a.log_prob) a.log_prob[m] = logp;
+}
+
+__global__ void k_act_policy(ActPolicyArgs a) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= a.rows) return;
+  act_policy_row(a, m, a.logits + (long long)m * a.ld);
+}
+
+// --------------------------------------------------------------------------------------
+// act() in one launch (update_kernels.h, ActFusedArgs): seven dependent launches of 5-6 us each were the whole latency of a
+// 1-row act(); a grid-wide barrier between layers costs as much as a launch (measured), so ONE workgroup does all
+// of it: 16 waves, wave w owns the output tiles n = 16 w, 16 (w + 16), ... of a layer as v_mfma_f32_16x16x4_f32 with the
+// weights as the A operand (lane (i, kq): 16 bytes W[n0 + i][16 g + 4 kq ..] - whole 64-byte runs of a weight row per four
+// lanes, every request of a layer in flight before the first MFMA) and the <= 8 rows' activations as the B operand from
+// LDS; D[n][row] goes back to LDS as the next layer's input.  Bound by what one CU can pull from L2 (256 KB per layer).
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_act_fused(const ActFusedArgs a) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef const __attribute__((address_space(1))) float *gcf;
+  typedef const __attribute__((address_space(1))) v4f *gcf4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int rows = a.rows;
+  // inputs: global rows -> feature rows (rows past the batch as zeros)
+  for (int s = 0; s < a.nin; ++s) {
+    const ActFusedInput in = a.in[s];
+    for (int e = tid; e < ACTF_ROWS * in.width; e += 1024) {
+      const int r = e / in.width, k = e - r * in.width;
+      lds[in.x_off + r * in.x_pitch + k] = r < rows ? in.ptr[(long long)r * in.ld + k] : 0.f;
+    }
+  }
+  __syncthreads();
+  for (int l = 0; l < a.nlayers; ++l) {
+    const ActFusedLayer &L = a.L[l];
+    const int N = L.N, ldw = L.ldw, nseg = L.nseg, xp = L.x_pitch;
+    gcf W = (gcf)L.W;
+    for (int n0 = 16 * wave; n0 < N; n0 += 256) {
+      const int n = min(n0 + li, N - 1);   // (rows of a partial tile repeat row N - 1; never stored)
+      float bv[4];                         // requested with the weights, not after the MFMAs (one round trip less per layer)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[r] = ((gcf)L.bias)[min(n0 + 4 * kq + r, N - 1)];
+      v4f acc[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = v4f{0.f, 0.f, 0.f, 0.f};
+      for (int s = 0; s < nseg; ++s) {
+        const ActFusedSeg sg = L.seg[s];
+        gcf wrow = W + (long long)n * ldw + sg.wcol + 4 * kq;
+        const float *xrow = lds + sg.x_off + (li & 7) * xp + 4 * kq;   // B operand: lane (j = li, kq) = x[row li][..]; rows 8..15 mirror 0..7 (never stored)
+        const int G = sg.width >> 4;
+        for (int g0 = 0; g0 < G; g0 += 16) {   // up to 16 groups (256 k) of requests in flight
+          v4f wv[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u)
+            if (g0 + u < G) wv[u] = *(gcf4)(wrow + 16 * (g0 + u));
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            if (g0 + u < G) {
+              const v4f xv = *reinterpret_cast<const v4f *>(xrow + 16 * (g0 + u));
+#pragma unroll
+              for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][c], xv[c], acc[c], 0, 0, 0);
+            }
+          }
+        }
+        const int kt = 16 * G + 4 * kq;   // the segment's tail (< 16 columns): guarded single elements
+        if (16 * G < sg.width) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const bool ok = kt + c < sg.width;
+            const float wv = ok ? wrow[16 * G + c] : 0.f;
+            const float xv = ok ? xrow[16 * G + c] : 0.f;
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xv, acc[c], 0, 0, 0);
+          }
+        }
+      }
+      // D[i][j]: lane (j = li, kq) holds outputs n0 + 4 kq + reg of row li
+      const v4f sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+      if (li < ACTF_ROWS) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int nn = n0 + 4 * kq + r;
+          if (nn < N) {
+            float y = sum[r] + bv[r];
+            if (L.leaky) y = y > 0.f ? y : 0.01f * y;
+            lds[L.out_off + li * L.out_pitch + nn] = li < rows ? y : 0.f;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (tid < rows) act_policy_row(a.pol, tid, lds + a.logits_off + tid * a.logits_pitch);
+}
+
+hipError_t act_fused_launch(const ActFusedArgs &a, hipStream_t s) {
+  if (a.rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_act_fused, dim3(1), dim3(1024), ACTF_LDS_FLOATS * 4, s, a);
+  return hipGetLastError();
 }
 
 hipError_t act_layer_launch(const ActLayerArgs &a, hipStream_t s) {

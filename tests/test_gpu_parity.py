@@ -716,6 +716,53 @@ def test_act_matches_oracle(dev, rows, kw):
     rep.finish()
 
 
+@pytest.mark.parametrize("rows,kw", [
+    (1, {}), (8, {}), (3, dict(goal=3)), (5, dict(enc_hidden=(), joint_hidden=(), pi_hidden=())),
+    (7, dict(enc_hidden=(40, 24), joint_hidden=(24, 24, 16), pi_hidden=(48, 40))), (6, dict(discrete=True, act=5)),
+    (2, dict(latent=256, enc_features=256, enc_hidden=(256,), joint_hidden=(256,), pi_hidden=(256,))),   # config-2 widths
+])
+def test_act_one_launch_equals_layerwise(dev, rows, kw, monkeypatch):
+    """Up to 8 rows take the one-launch form of act() (k_act_fused: one workgroup, activations in LDS, 16x16x4 MFMA); more
+    rows, FDQL_ACT_FUSED=0, GRU or pixel encoders the launch-per-layer form.  Both against the CPU oracle, and against each
+    other on the same noise (different summation orders: 1e-5)."""
+    from oracle import update as oup
+    base = dict(obs=17, act=6, C=3, Q=2, latent=64, enc_features=48, enc_hidden=(64,), joint_hidden=(48,),
+                pi_hidden=(64,), critic_hidden=(32,), T=2, B=4)
+    base.update(kw)
+    spec = oup.Spec(**base)
+    params = oup.init_params(spec, seed=100 + rows)
+    gen = torch.Generator().manual_seed(rows)
+    for k in params:
+        params[k] = params[k] + 0.05 * torch.randn(params[k].shape, generator=gen)
+    ag = _agent_for(spec, dev)
+    ag.load_tensors(params)
+    xp = {"obs_1d": torch.randn(rows, spec.obs, generator=gen)}
+    if spec.goal:
+        xp["achieved_goal"] = torch.randn(rows, spec.goal, generator=gen)
+        xp["desired_goal"] = torch.randn(rows, spec.goal, generator=gen)
+    mask = torch.rand(rows, 1, generator=gen) < 0.4
+    noise = torch.rand(rows, spec.act, generator=gen) if spec.discrete else torch.randn(rows, spec.act, generator=gen)
+    want = oup.act(params, spec, dict(xp, exploit_mask=mask), noise)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FDQL_ACT_FUSED", mode)
+        got = ag.act(xp["obs_1d"], xp.get("achieved_goal"), xp.get("desired_goal"), mask, noise=noise)
+        outs[mode] = [g.cpu() for g in got[:4]]
+        rep = Report(f"act one-launch={mode} rows={rows} {kw}")
+        if spec.discrete:
+            for gt, wt, key in zip(got[:1] + got[2:4], want[:1] + want[2:4], ("action", "explore", "exploit")):
+                assert np.array_equal(gt.cpu().numpy().astype(np.int64), wt.numpy()), key
+            rep.check("log_prob", got[1], want[1])
+        else:
+            rep.check("action", got[0], want[0])
+            rep.check("explore", got[2], want[2])
+            rep.check("exploit", got[3], want[3])
+            rep.check("log_prob", got[1], want[1], extra=logp_cond(want[2].numpy()))
+        rep.finish()
+    for x, y in zip(outs["1"], outs["0"]):
+        assert float((x - y).abs().max()) <= 1e-5 * max(1.0, float(y.abs().max()))
+
+
 def test_act_device_noise_and_live_weights(dev):
     """Without caller noise the device draws Philox noise keyed by (seed, counter): reproducible per
     key, different across counters, N(0,1) through the tanh-Gaussian; exploit rows ignore it; and
