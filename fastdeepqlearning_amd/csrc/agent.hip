@@ -429,6 +429,8 @@ void carve(fdql_agent *a) {
 }
 
 // --------------------------------------------------------------------------- plan builder
+constexpr int STREAM_WGRAD_MAX_SLAB_ROWS = 640;
+
 struct Builder {
   fdql_agent *a;
   std::vector<Stage> &st;
@@ -602,6 +604,10 @@ struct Builder {
   void take_stream_wgrads(Stage &from, Stage &to, Stage &skinny) {
     const char *env = getenv("FDQL_STREAM_WGRAD");
     if (env && env[0] == '0') return;
+    // Only where the tile kernels' narrow launches are latency-bound: a K-split slab of a few hundred rows (config 2: 392 -
+    // 25 dependent K iterations per workgroup, 0.7-2.4 TB/s).  With long slabs (config 4 at B = 1024: 1568 rows) the tile
+    // kernel streams at 5 TB/s and the one-wave-per-64-columns form (2.4 TB/s) would be the slower one.
+    if (!(env && env[0] == '2') && a->M / a->nsplit > STREAM_WGRAD_MAX_SLAB_ROWS) return;
     for (size_t i = 0; i < from.gemm.size();) {
       const GemmProblem &p = from.gemm[i];
       SkinnyWgradProblem q;
@@ -1866,6 +1872,7 @@ int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {
     hipDeviceProp_t pr;
     int dev = 0;
     if (!(e1 && e1[0] == '0') && !(e2 && e2[0] == '0') && nblk > 0 && nblk <= WG_MAX_INST && a->M % WG_BM == 0 &&
+        a->M / a->nsplit <= STREAM_WGRAD_MAX_SLAB_ROWS &&   // (long slabs keep the tile kernels' narrow launches, which want the splits)
         (long long)nblk * (a->M / WG_BM) >= 8 * a->rows_min_tiles && hipGetDevice(&dev) == hipSuccess &&
         hipGetDeviceProperties(&pr, dev) == hipSuccess) {
       const int want = std::max(8, pr.multiProcessorCount / nblk + 3);
