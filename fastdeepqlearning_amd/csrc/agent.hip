@@ -203,7 +203,10 @@ struct fdql_agent {
   std::vector<CachedPlan> plan_cache;   // most recently stashed last; a hit moves a plan out (it becomes current): the front is the least recently used
   size_t plan_cache_max = PLAN_CACHE_DEFAULT;
   long long plans_built = 0;
-  long long rows_min_tiles = 512;   // FDQL_ROWGEMM: "0" never; default: groups with at least two tiles per CU
+  long long rows_min_tiles = 256;   // FDQL_ROWGEMM: "0" never, "all" always, a number = the threshold; default: groups with at least one
+                                    // 64-row tile per CU (a weight-stationary workgroup with 2 + 2 32-row tiles still beats the tile
+                                    // kernels: config 4 at 128 windows per GPU)
+  int wgrad_stat_factor = 4;        // x rows_min_tiles 32-row tiles for the output-stationary weight-gradient launch (4 per workgroup)
   // d state = sum over the online critics and the actor: one problem accumulating every network's K-segments, or - few rows
   // (a handful of workgroups would walk all segments serially), or many rows with critics the weight-stationary kernel
   // takes (wstat.h, plain dgrad form) - one problem per network into partials + a reduction
@@ -447,7 +450,7 @@ struct Builder {
     Stage wst;
     wst.kind = ST_WGRAD_STAT; wst.name = name;
     const long long tiles = (long long)probs.size() * (probs[0].seg[0].K / WG_BM);
-    if (tiles >= 8 * a->rows_min_tiles && wgrad_stat_from_problems(probs.data(), (int)probs.size(), a->nsplit, a->n_train, wst.wga)) {
+    if (tiles >= a->wgrad_stat_factor * a->rows_min_tiles && wgrad_stat_from_problems(probs.data(), (int)probs.size(), a->nsplit, a->n_train, wst.wga)) {
       // the few-column / few-row gradients that share an operand with one of the blocks (a critic's action columns, its
       // skip head's rows over the state and over h0) ride with it instead of re-reading the operand in the tail launches
       for (size_t i = 0; i < fallback.gemm.size();) {
@@ -1108,7 +1111,9 @@ int build_plan(fdql_agent *a) {
   const char *chain_env = getenv("FDQL_CHAIN");
   const std::string chain_mode = chain_env ? chain_env : "1";
   const bool chain_all = chain_mode == "all";
-  const bool want_chain = chain_all || (chain_mode != "0" && getenv("FDQL_NO_CHAIN") == nullptr && N >= 128 * CH_BM);
+  int chain_min_blocks = 96;   // (tuning hook FDQL_CHAIN_MIN_BLOCKS)
+  if (const char *v = getenv("FDQL_CHAIN_MIN_BLOCKS")) chain_min_blocks = atoi(v);
+  const bool want_chain = chain_all || (chain_mode != "0" && getenv("FDQL_NO_CHAIN") == nullptr && N >= (long long)chain_min_blocks * CH_BM);
   bool enc_chained = false;
   if (want_chain && !gru) {
     Stage cs;
@@ -1837,6 +1842,8 @@ int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {
     }
     if (r && r[0] == '0') a->rows_min_tiles = 1LL << 60;
     else if (r && !strcmp(r, "all")) a->rows_min_tiles = 1;
+    else if (r && atoi(r) > 1) a->rows_min_tiles = atoi(r);
+    if (const char *f = getenv("FDQL_WGRAD_STAT_FACTOR")) { if (atoi(f) >= 1) a->wgrad_stat_factor = atoi(f); }
   }
   a->T = c.T; a->B = c.B; a->N = c.T * c.B; a->M = (c.T - 1) * c.B; a->A = c.act_dim; a->L = c.latent;
   a->Nq = c.n_critics * c.n_quantiles;
@@ -1873,7 +1880,7 @@ int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {
     int dev = 0;
     if (!(e1 && e1[0] == '0') && !(e2 && e2[0] == '0') && nblk > 0 && nblk <= WG_MAX_INST && a->M % WG_BM == 0 &&
         a->M / a->nsplit <= STREAM_WGRAD_MAX_SLAB_ROWS &&   // (long slabs keep the tile kernels' narrow launches, which want the splits)
-        (long long)nblk * (a->M / WG_BM) >= 8 * a->rows_min_tiles && hipGetDevice(&dev) == hipSuccess &&
+        (long long)nblk * (a->M / WG_BM) >= a->wgrad_stat_factor * a->rows_min_tiles && hipGetDevice(&dev) == hipSuccess &&
         hipGetDeviceProperties(&pr, dev) == hipSuccess) {
       const int want = std::max(8, pr.multiProcessorCount / nblk + 3);
       if (want < a->nsplit) a->nsplit = want;
