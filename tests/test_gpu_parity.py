@@ -840,6 +840,17 @@ def _gpu_branch_pattern(ag, spec, xp_cpu):
      dict(obs=17, act=6, C=5, Q=2, T=4, B=64, env={"FDQL_ROWGEMM": "all", "FDQL_WSTAT": "0", "FDQL_ROWGEMM_FORMS": "7"})),
     ("config 2 full size without the row-block kernel (FDQL_ROWGEMM=0: k_head_dgrad + tile kernels)",
      dict(obs=17, act=6, C=5, Q=2, T=50, B=256, env={"FDQL_ROWGEMM": "0"})),
+    ("config 2 full size, weight gradients without riders and without the streaming launch (FDQL_WGRAD_RIDERS=0 "
+     "FDQL_STREAM_WGRAD=0 FDQL_NSPLIT=32: the head / action-column gradients on the tile kernels' narrow launches)",
+     dict(obs=17, act=6, C=5, Q=2, T=50, B=256, env={"FDQL_WGRAD_RIDERS": "0", "FDQL_STREAM_WGRAD": "0", "FDQL_NSPLIT": "32"})),
+    ("config 2 full size, every narrow weight gradient through the streaming launch (FDQL_WGRAD_RIDERS=0: head rows over "
+     "state / h0 / h1, action columns with the roles swapped)",
+     dict(obs=17, act=6, C=5, Q=2, T=50, B=256, env={"FDQL_WGRAD_RIDERS": "0"})),
+    ("config 2 full size, dense weight gradients riding in the dgrad launches (FDQL_WGRAD_STAT=0)",
+     dict(obs=17, act=6, C=5, Q=2, T=50, B=256, env={"FDQL_WGRAD_STAT": "0"})),
+    ("config 4 dims (5x25 quantiles, 17 action columns) at T=6, B=64 with the stationary and streaming launches forced "
+     "(FDQL_ROWGEMM=all FDQL_STREAM_WGRAD=2: 25 head rows and 17 input columns per streaming problem, no riders fit)",
+     dict(obs=376, act=17, C=5, Q=25, T=6, B=64, env={"FDQL_ROWGEMM": "all", "FDQL_STREAM_WGRAD": "2", "FDQL_WGRAD_STAT_FACTOR": "1"})),
 ])
 def test_gradient_parity_three_way_fp64(dev, name, kw, monkeypatch):
     """north_star: gradients within 1e-5 rel fp32 of the reference CPU path.  Two fp32 evaluations of this loss cannot
