@@ -1375,6 +1375,7 @@ int build_plan(fdql_agent *a) {
           p.fz_ldw = m->d->head_ld();
           p.fz_out = m->dpre[1];
           p.fz_colsum = m->dpre_cs[1];
+          p.fz_discard = which == 1 && getenv("FDQL_KEEP_FROZEN_DPRE1") == nullptr;   // frozen copy: its dpre1 feeds nothing but this GEMM
           cand.push_back(p);
           ++which;
         }

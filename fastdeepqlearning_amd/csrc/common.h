@@ -75,6 +75,7 @@ struct GemmProblem {
   // head), written to fz_out [M, 256] for the weight gradients, its per-64-row column sums to fz_colsum.
   const float *fz_h, *fz_w;
   int fz_ldw;
+  int fz_discard;          // 1: nobody reads fz_out afterwards (frozen critics have no weight gradients): the weight-stationary kernel skips the store
   float *fz_out, *fz_colsum;
   int tiles_m, tiles_n;    // filled by gemm_finalize
   int tile_start;          // first block id of this problem in its launch

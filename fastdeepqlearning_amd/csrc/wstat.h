@@ -30,6 +30,7 @@ struct WsInst {
   // plain dgrad form: the networks whose shares are summed differ in their narrow segment (critic: dz, 2 columns of a head of
   // pitch 774; actor: d logits, 12 columns of a head of pitch 512) and in the row pitch of their layer-0 weights
   int k1, lda1, ldw0, ldw1;
+  int fz_keep, pad;                   // fused form: 1 = store the formed A0 rows to fz_out (0: only the GEMM consumes them)
 };
 
 struct WsArgs {

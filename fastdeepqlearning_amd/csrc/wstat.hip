@@ -530,6 +530,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
   const float *A1 = ws_uni(I.A[1]);
   const float *ref = PLAIN ? nullptr : ws_uni(I.ref);
   float *const C = ws_uni(I.C), *const fz_out = ws_uni(I.fz_out);
+  const bool keep_fz = I.fz_keep != 0;   // fused form: is the formed A0 (d pre-activation of the layer above) also stored?
   const int lda0 = FUSE ? LD : a.lda[0], lda1 = PLAIN ? ws_uni(I.lda1) : a.lda[1];
   const int k1 = PLAIN ? ws_uni(I.k1) : a.kminor[0];   // dY's columns (plain form: per instance)
 
@@ -721,7 +722,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
           const float d0 = sdz.x, d1 = sdz.y;
           const v4f t = fuse_row(sh[u & 3], __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d0), u)),
                                  __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d1), u)), live);
-          (nout_w + (u - 4) * (LD / 4))[(unsigned)lane] = t;
+          if (keep_fz) (nout_w + (u - 4) * (LD / 4))[(unsigned)lane] = t;   // (workgroup-uniform: frozen instances have no weight gradients)
           *reinterpret_cast<v4f *>(lds + (IM ^ 1) * IMG + row * P + lane * 4) = t;
         }
         if constexpr (ureq >= 0) {   // (after the use of the register it refills)
@@ -775,7 +776,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
         const v4f h = ((gcf4)(src + row * LD))[(unsigned)lane];
         const v2f dz = *(const __attribute__((address_space(1))) v2f *)(dzs + row * lda1);
         const v4f t = fuse_row(h, dz.x, dz.y, 1.f);
-        ((gf4)(out + row * LD))[(unsigned)lane] = t;
+        if (keep_fz) ((gf4)(out + row * LD))[(unsigned)lane] = t;
         *reinterpret_cast<v4f *>(lds + row * P + lane * 4) = t;
       }
     } else {
@@ -931,7 +932,7 @@ bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
     I.bias = p.bias; I.C = p.C; I.C2 = p.C2;
     I.hf_w = p.hf_w; I.hf_out = p.hf_out; I.hf_out2 = p.hf_out2;
     I.ref = p.ref; I.colsum = p.colsum;
-    I.fz_h = p.fz_h; I.fz_w = p.fz_w; I.fz_out = p.fz_out; I.fz_colsum = p.fz_colsum;
+    I.fz_h = p.fz_h; I.fz_w = p.fz_w; I.fz_out = p.fz_out; I.fz_colsum = p.fz_colsum; I.fz_keep = p.fz_discard ? 0 : 1;
     args.inst[i] = I;
     cost[i] = pd ? 12 : 11;   // a two-output instance finishes twice as many register quads per tile
     cost_sum += cost[i];
