@@ -113,6 +113,7 @@ struct Stage {
   std::string name;
   std::vector<GemmProblem> gemm;
   GemmSub sub[GEMM_NSHAPES];  // the problems of `gemm`, grouped by tile shape (one launch each)
+  int chain_bm = CH_BM;       // ST_CHAIN: rows per workgroup (64, or 32: chain.h)
   bool stream = false;        // ST_SKINNY_WGRAD: the streaming form (k_stream_wgrad: 256-wide X, one workgroup per slab)
   bool try_rows = false;      // ST_GEMM: groups of like problems may run on the persistent row-block kernel (rowgemm.hip)
   std::vector<RowsLaunch> rows;    // the groups that do (one launch each); their problems are not in `sub`
@@ -693,10 +694,10 @@ struct ChainBuilder {
   int stage_top = CH_LDS_FLOATS;      // weight staging areas of the CH_NARROW operations: carved downwards from the top of
                                       // LDS, alive for the whole program (they are filled before its first operation)
   std::vector<std::pair<int, int>> used;   // live LDS ranges (offset, size) of the program being built
-  explicit ChainBuilder(Stage &s) : st(s) {}
+  int bm;                             // rows per workgroup: images are [bm][pitch]
+  explicit ChainBuilder(Stage &s) : st(s), bm(s.chain_bm) {}
 
   void begin(int nrows) { rows = nrows; op_start = (int)st.cops.size(); used.clear(); peak = 0; stage_top = CH_LDS_FLOATS; }
-  void reserve_head_stage(int, int) {}
   void end() {
     ChainOp e;
     memset(&e, 0, sizeof(e));
@@ -729,7 +730,7 @@ struct ChainBuilder {
   }
   ChainImg image(int K, int min_size = 0) {
     ChainImg im;
-    im.K = K; im.pitch = chain_pitch(K); im.size = std::max(CH_BM * im.pitch, min_size);
+    im.K = K; im.pitch = chain_pitch(K); im.size = std::max(bm * im.pitch, min_size);
     im.slot = alloc(im.size);
     return im;
   }
@@ -819,7 +820,7 @@ struct ChainBuilder {
       bool cur_dies = in_dies;
       for (int i = 0; i < nh; ++i) {
         // the layer's output image: in place of its (single, dying) input when possible, else a new one
-        const int need = CH_BM * chain_pitch(d.hid[i]);
+        const int need = bm * chain_pitch(d.hid[i]);
         ChainImg dst;
         if (cur_dies && cur.size() == 1 && cur[0].size >= need) {
           dst = cur[0];
@@ -980,7 +981,7 @@ int upload_tables(fdql_agent *a) {
       s.dev = (char *)a->tables_dev + off;
       off += pad(bytes);
     } else if (s.kind == ST_CHAIN) {
-      s.blocks = chain_finalize(s.cprobs.data(), (int)s.cprobs.size());
+      s.blocks = chain_finalize(s.cprobs.data(), (int)s.cprobs.size(), s.chain_bm);
       size_t bytes = s.cprobs.size() * sizeof(ChainProblem);
       memcpy(host.data() + off, s.cprobs.data(), bytes);
       s.dev = (char *)a->tables_dev + off;
@@ -1113,18 +1114,28 @@ int build_plan(fdql_agent *a) {
   const bool chain_all = chain_mode == "all";
   int chain_min_blocks = 96;   // (tuning hook FDQL_CHAIN_MIN_BLOCKS)
   if (const char *v = getenv("FDQL_CHAIN_MIN_BLOCKS")) chain_min_blocks = atoi(v);
-  const bool want_chain = chain_all || (chain_mode != "0" && getenv("FDQL_NO_CHAIN") == nullptr && N >= (long long)chain_min_blocks * CH_BM);
+  // Rows per workgroup: 64 when that many blocks fill the chip, else 32 (twice the workgroups - one rank's share of a
+  // data-parallel batch - and images of half the size: 64 rows of a 376-column observation next to a hidden image do not fit
+  // the LDS, 32 do).  FDQL_CHAIN_BM = 32 / 64 forces one.
+  const bool chain_on = chain_mode != "0" && getenv("FDQL_NO_CHAIN") == nullptr;
+  std::vector<int> bms;
+  if (const char *v = getenv("FDQL_CHAIN_BM")) {
+    bms.push_back(atoi(v) == 32 ? 32 : CH_BM);
+  } else {
+    if (chain_all || N >= (long long)chain_min_blocks * CH_BM) bms.push_back(CH_BM);
+    // 32-row blocks only while they are one round of workgroups (one per CU): measured at config 4, 128 windows per GPU
+    // (200 blocks) 1.172 -> 1.154 ms per step against the six per-layer launches; at 256 windows (400 blocks, 1.6 rounds) the
+    // chain is the slower one (1.902 -> 1.987 ms)
+    int ncu = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (chain_all || (N >= (long long)chain_min_blocks * 32 && (N + 31) / 32 <= ncu)) bms.push_back(32);
+  }
   bool enc_chained = false;
-  if (want_chain && !gru) {
+  for (size_t t = 0; t < bms.size() && !enc_chained && (chain_all || chain_on) && !gru; ++t) {
     Stage cs;
-    cs.kind = ST_CHAIN; cs.name = "enc_joiner_actors";
+    cs.kind = ST_CHAIN; cs.name = "enc_joiner_actors"; cs.chain_bm = bms[t];
     ChainBuilder cb(cs);
     cb.begin(N);
-    {
-      int mk = L;
-      for (int h : a->actor.hid) mk = std::max(mk, h);
-      cb.reserve_head_stage(a->actor.dout, mk);
-    }
     ChainImg xi = cb.load(eo.in);
     ChainImg ei = cb.mlp(eo, {xi}, true, true, {0, N, 0}, true);
     ChainImg si = cb.mlp(jo, {ei}, true, true, {0, N, 0}, true);
@@ -1215,16 +1226,12 @@ int build_plan(fdql_agent *a) {
     if (chain_all) {   // every critic instance as one chain program: cat(s, a) -> hidden layers -> skip head
       Stage cs;
       cs.kind = ST_CHAIN; cs.name = "critics.fwd";
+      if (const char *v = getenv("FDQL_CHAIN_BM")) cs.chain_bm = atoi(v) == 32 ? 32 : CH_BM;
       ChainBuilder cb(cs);
       for (int k = 0; k < C && cb.ok; ++k) {
         int which = 0;
         for (MlpInst *m : {&ct[k], &co[k], &cf[k]}) {
           cb.begin(M);
-          {
-            int mk = m->d->din;
-            for (int h : m->d->hid) mk = std::max(mk, h);
-            cb.reserve_head_stage(m->d->dout, mk);
-          }
           ChainImg xi = cb.load(m->in);
           cb.mlp(*m, {xi}, true, which != 0, {0, M, 0}, false);   // target activations are never needed again
           cb.end();
@@ -1705,7 +1712,7 @@ hipError_t run_stage(fdql_agent *a, Stage &s, hipStream_t stream) {
     case ST_HEAD_DGRAD: return head_dgrad_launch((const HeadDgradProblem *)s.dev, (int)s.hdg.size(), s.blocks, stream);
     case ST_WGRAD_STAT: return wgrad_stat_launch(s.wga, stream);
     case ST_CHAIN:
-      return chain_launch((const ChainProblem *)s.dev, (int)s.cprobs.size(), (const ChainOp *)s.cops_dev, s.blocks, s.lds_floats, stream);
+      return chain_launch((const ChainProblem *)s.dev, (int)s.cprobs.size(), (const ChainOp *)s.cops_dev, s.blocks, s.lds_floats, s.chain_bm, stream);
   }
   return hipSuccess;
 }
@@ -2417,25 +2424,21 @@ int fdql_test_chain_mlp(const float *x, int32_t rows, int32_t din, const int32_t
   m.out = out; m.ldout = dout;
   Stage cs;
   cs.kind = ST_CHAIN; cs.name = "test";
+  if (const char *v = getenv("FDQL_CHAIN_BM")) cs.chain_bm = atoi(v) == 32 ? 32 : CH_BM;   // (test hook: 32-row blocks)
   ChainBuilder cb(cs);
   cb.begin(rows);
-  if (dout <= 32) {
-    int mk = din;
-    for (int i = 0; i < nh; ++i) mk = std::max(mk, (int)hid[i]);
-    cb.reserve_head_stage(dout, mk);
-  }
   ChainImg xi = cb.load(m.in);
   cb.mlp(m, {xi}, true, h_out != nullptr, {0, rows, 0}, false);
   cb.end();
   FDQL_REQUIRE(cb.ok, "this MLP does not fit the chain kernel");
-  const int blocks = chain_finalize(cs.cprobs.data(), (int)cs.cprobs.size());
+  const int blocks = chain_finalize(cs.cprobs.data(), (int)cs.cprobs.size(), cs.chain_bm);
   void *dev = nullptr;
   const size_t pb = cs.cprobs.size() * sizeof(ChainProblem), ob = cs.cops.size() * sizeof(ChainOp);
   FDQL_HIP(hipMalloc(&dev, pb + ob + 256));
   FDQL_HIP(hipMemcpy(dev, cs.cprobs.data(), pb, hipMemcpyHostToDevice));
   void *odev = (char *)dev + (pb + 255) / 256 * 256;
   FDQL_HIP(hipMemcpy(odev, cs.cops.data(), ob, hipMemcpyHostToDevice));
-  hipError_t e = chain_launch((const ChainProblem *)dev, (int)cs.cprobs.size(), (const ChainOp *)odev, blocks, cs.lds_floats, (hipStream_t)stream);
+  hipError_t e = chain_launch((const ChainProblem *)dev, (int)cs.cprobs.size(), (const ChainOp *)odev, blocks, cs.lds_floats, cs.chain_bm, (hipStream_t)stream);
   if (e != hipSuccess) { set_error("chain launch: %s", hipGetErrorString(e)); (void)hipFree(dev); return FDQL_EHIP; }
   FDQL_HIP(hipStreamSynchronize((hipStream_t)stream));
   FDQL_HIP(hipFree(dev));

@@ -6,7 +6,7 @@
 
 namespace fdql {
 
-constexpr int CH_BM = 64;          // rows per workgroup
+constexpr int CH_BM = 64;          // rows per workgroup (or 32: chain_launch's bm)
 constexpr int CH_THREADS = 256;    // 4 waves, one per SIMD
 constexpr int CH_MAX_SEG = 4;      // K-segments of one operation (torch.cat of up to 4 row blocks)
 constexpr int CH_MAX_OPS = 16;      // operations per program (the program is copied to LDS)
@@ -26,7 +26,7 @@ enum ChainAct { CHA_NONE = 0, CHA_LRELU = 1 };
 struct ChainSeg {
   const float *W;
   int ldw;
-  int slot, pitch;   // LDS image [64][pitch] of the activation block, columns >= K zero up to the next multiple of 8
+  int slot, pitch;   // LDS image [bm][pitch] of the activation block, columns >= K zero up to the next multiple of 8
   int K;
 };
 // CH_LOAD: global rows -> LDS slot columns [col, col + width)
@@ -62,9 +62,9 @@ struct ChainProblem {
 inline int chain_pitch(int K) { return (K + 7) / 8 * 8 + 4; }   // (pitch / 4) odd: conflict-free ds_read_b128 across 32 rows
 inline int chain_kpad(int K) { return (K + 7) / 8 * 8; }
 
-// Fills block_start; returns the number of workgroups.
-int chain_finalize(ChainProblem *probs, int nprob);
-hipError_t chain_launch(const ChainProblem *probs_dev, int nprob, const ChainOp *ops_dev, int total_blocks, int lds_floats,
+// Fills block_start; returns the number of workgroups.  bm: rows per workgroup, 64 or 32 (images are [bm][pitch]).
+int chain_finalize(ChainProblem *probs, int nprob, int bm);
+hipError_t chain_launch(const ChainProblem *probs_dev, int nprob, const ChainOp *ops_dev, int total_blocks, int lds_floats, int bm,
                         hipStream_t stream);
 double chain_op_flops(const ChainOp &op, int rows);
 int chain_read_stamps(unsigned long long *out, int cap);   // diagnostic (FDQL_CHAIN_STAMPS): s_memtime per operation of the last launch

@@ -58,11 +58,15 @@ __device__ __forceinline__ const float *ch_uni(const float *p) {
 // s_memtime at its entry, after the program fetch and after every operation.
 __device__ unsigned long long g_ch_stamps[8 * CH_MAX_OPS + 4];
 __device__ int g_ch_stamps_on = 0;
-__device__ int g_ch_stagger = 0;   // experiment (FDQL_CHAIN_STAGGER): workgroup j starts (j & 3) x this many kilo-cycles late
 
 // One workgroup per CU (512 registers per lane: the accumulators live in AccVGPRs, two weight-fragment buffers in VGPRs).
+// TM = row tiles of 32 per workgroup: 2 (64 rows: the weights a workgroup streams are shared by two tiles) or 1 (32 rows:
+// twice the workgroups - small batches, e.g. one rank's share of a data-parallel step - and half the LDS per image, which
+// is what lets a 376-column observation image and a hidden image live together).
+template <int TM>
 __global__ __launch_bounds__(CH_THREADS, 1) void k_chain(const ChainProblem *__restrict__ probs, int nprob,
                                                          const ChainOp *__restrict__ ops_all) {
+  constexpr int BM = 32 * TM;
   __shared__ ChainOp s_ops[CH_MAX_OPS];
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -92,8 +96,7 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_chain(const ChainProblem *__r
       blk = bid - __builtin_amdgcn_readlane(bs, src);
     }
   }
-  const int r0 = blk * CH_BM;
-  for (int i = (bid & 3) * g_ch_stagger; i > 0; --i) __builtin_amdgcn_s_sleep(16);
+  const int r0 = blk * BM;
   {   // the program -> LDS in one coalesced round (fields are then read from LDS, not through L2)
     const int *src = reinterpret_cast<const int *>(ops_all + op_start);
     int *dst = reinterpret_cast<int *>(s_ops);
@@ -162,13 +165,15 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_chain(const ChainProblem *__r
   }
   if (stamp) g_ch_stamps[nstamp++] = __builtin_amdgcn_s_memtime();
 
-  f32x16 acc[2][2];   // [tm][tn]: rows 32 tm + ..., columns of column tile tn
+  f32x16 acc[TM][2];   // [tm][tn]: rows 32 tm + ..., columns of column tile tn
   v4f hacc[2];        // narrow-head accumulators: this wave's 16 rows x 16 columns per tile (v_mfma_f32_16x16x4_f32)
   v4f hodd[2];        // CH_NARROW: the odd 16-k steps' sums (two independent MFMA chains; added at CHF_FINISH)
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
+  for (int a = 0; a < TM; ++a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[a][0][r] = 0.f; acc[a][1][r] = 0.f; }
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
     hacc[a] = v4f{0.f, 0.f, 0.f, 0.f};
     hodd[a] = v4f{0.f, 0.f, 0.f, 0.f};
   }
@@ -196,18 +201,20 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_chain(const ChainProblem *__r
     for (int j = 0; j < 4; ++j) {
       if (j < 3) {
         ch_rd128(a[(j + 1) & 1][0], a0 + 16 * (j + 1));
-        ch_rd128(a[(j + 1) & 1][1], a1 + 16 * (j + 1));
-        ch_lgkm_wait<2>();
+        if constexpr (TM > 1) ch_rd128(a[(j + 1) & 1][1], a1 + 16 * (j + 1));
+        ch_lgkm_wait<TM>();
       } else {
         ch_lgkm_wait<0>();
         ch_rd128(an[0], na0);
-        ch_rd128(an[1], na1);
+        if constexpr (TM > 1) ch_rd128(an[1], na1);
       }
       if (j == 0) {
-        asm volatile("" : "+v"(af[0]), "+v"(af[1]));
+        asm volatile("" : "+v"(af[0]));
+        if constexpr (TM > 1) asm volatile("" : "+v"(af[1]));
         if constexpr (RIDER) asm volatile("" : "+v"(ra[0]), "+v"(ra[1]));
       } else {
-        asm volatile("" : "+v"(a[j & 1][0]), "+v"(a[j & 1][1]));
+        asm volatile("" : "+v"(a[j & 1][0]));
+        if constexpr (TM > 1) asm volatile("" : "+v"(a[j & 1][1]));
       }
       bn[0][j] = *(gcf4)(pa + 4 * j);
       bn[1][j] = *(gcf4)(pb + 4 * j);
@@ -218,7 +225,7 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_chain(const ChainProblem *__r
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
+        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
           for (int tn = 0; tn < 2; ++tn)
             acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[tn][j][c], j == 0 ? af[tm][c] : a[j & 1][tm][c], acc[tm][tn], 0, 0, 0);
@@ -233,23 +240,24 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_chain(const ChainProblem *__r
         }
     }
     af[0] = an[0];
-    af[1] = an[1];
+    if constexpr (TM > 1) af[1] = an[1];
     asm volatile("" ::"v"(a0), "v"(a1), "v"(na0), "v"(na1), "v"(a16g));
   };
   // 8-k tail group: lanes lh = 0 / 1 hold k = kb + 0..3 / kb + 4..7 (component c -> MFMA step c)
   auto mfma_tail = [&](unsigned a0, unsigned a1, const v4f &b0, const v4f &b1) __attribute__((always_inline)) {
     v4f a[2];
     ch_rd128(a[0], a0);
-    ch_rd128(a[1], a1);
+    if constexpr (TM > 1) ch_rd128(a[1], a1);
     ch_lgkm_wait<0>();
-    asm volatile("" : "+v"(a[0]), "+v"(a[1]));
+    asm volatile("" : "+v"(a[0]));
+    if constexpr (TM > 1) asm volatile("" : "+v"(a[1]));
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[c], a[0][c], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[c], a[0][c], acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[c], a[1][c], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[c], a[1][c], acc[1][1], 0, 0, 0);
-    }
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[c], a[tm][c], acc[tm][0], 0, 0, 0);
+        acc[tm][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[c], a[tm][c], acc[tm][1], 0, 0, 0);
+      }
     asm volatile("" ::"v"(a0), "v"(a1));
   };
 
@@ -275,7 +283,7 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_chain(const ChainProblem *__r
     if constexpr (RIDER) {
       hp0 = (gcf)(hw + (long long)min(lj, hN - 1) * hldw + 4 * kq);
       hp1 = (gcf)(hw + (long long)min(16 + lj, hN - 1) * hldw + 4 * kq);
-      a16 = lds0 + (unsigned)(slot + (16 * wave + lj) * pitch + 4 * kq) * 4u;
+      a16 = lds0 + (unsigned)(slot + (16 * (wave & (2 * TM - 1)) + lj) * pitch + 4 * kq) * 4u;   // (32-row blocks: waves 2, 3 repeat 0, 1; never stored)
     }
     // the tail groups' fragments (at most four 8-k groups) are requested before the full groups: their latency hides
     // behind them, one request round instead of a memory round trip per tail group (with a rider: only the first one
@@ -316,7 +324,7 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_chain(const ChainProblem *__r
       load_b(0, 0);
       v4f af[2];
       ch_rd128(af[0], a0);
-      ch_rd128(af[1], a1);
+      if constexpr (TM > 1) ch_rd128(af[1], a1);
       int g = 0;
       for (; g + 2 <= G; g += 2) {   // branch-free pairs: the last pair re-requests group G-1 (harmless)
         mfma_group_kc(a0 + 128u * g, a1 + 128u * g, a0 + 128u * (g + 1), a1 + 128u * (g + 1), af, b[0], a16 + 128u * g, rb[0],
@@ -332,7 +340,8 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_chain(const ChainProblem *__r
         asm volatile("" ::"v"(bd[0][0]), "v"(bd[1][3]));
       }
       ch_lgkm_wait<0>();   // the last group's look-ahead reads
-      asm volatile("" : "+v"(af[0]), "+v"(af[1]));
+      asm volatile("" : "+v"(af[0]));
+      if constexpr (TM > 1) asm volatile("" : "+v"(af[1]));
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -404,7 +413,7 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_chain(const ChainProblem *__r
       // the common case (a full 64-column tile per wave, 16-byte aligned rows): straight-line, 16 ds_write_b128 and
       // 16 global_store_dwordx4 per lane, no per-element predicates
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm) {
+      for (int tm = 0; tm < TM; ++tm) {
         const int rl = 32 * tm + li, grow = r0 + rl;
         const bool rok = out && grow >= row_lo && grow < row_hi;
         float *drow = &lds[out_slot + rl * out_pitch + n0 + 4 * lh];
@@ -433,7 +442,7 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_chain(const ChainProblem *__r
           const bool cok = col < N;
           const float bv = (bias && cok) ? bias[col] : 0.f;
 #pragma unroll
-          for (int tm = 0; tm < 2; ++tm) {
+          for (int tm = 0; tm < TM; ++tm) {
             const int rl = 32 * tm + li, grow = r0 + rl;
             float x = acc[tm][tn][r] + bv;
             if (act == CHA_LRELU) x = x > 0.f ? x : 0.01f * x;
@@ -446,7 +455,7 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_chain(const ChainProblem *__r
     if (out_slot >= 0) {
       // columns [N, next multiple of 8) of the image stay zero: the next layer's last k-group reads them
       const int npad = ((N + 7) & ~7) - N;
-      for (int e = tid; e < CH_BM * npad; e += CH_THREADS) {
+      for (int e = tid; e < BM * npad; e += CH_THREADS) {
         const int r = e / npad, c = e - r * npad;
         lds[out_slot + r * out_pitch + N + c] = 0.f;
       }
@@ -478,14 +487,14 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_chain(const ChainProblem *__r
         // eight loads in flight per thread, then the eight LDS stores (a load -> store loop would expose one memory
         // round trip per iteration: 16 of them for a 256-wide block)
         if (vec) {
-          const int wq = width >> 2, total = CH_BM * wq;
+          const int wq = width >> 2, total = BM * wq;
           for (int base = 0; base < total; base += 16 * CH_THREADS) {
             v4f v[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
               const int e = base + tid + u * CH_THREADS;
               const int r = e / wq, c = (e - r * wq) * 4;
-              const int grow = min(r0 + min(r, CH_BM - 1), rows - 1);   // rows beyond the batch repeat its last row (never stored)
+              const int grow = min(r0 + min(r, BM - 1), rows - 1);   // rows beyond the batch repeat its last row (never stored)
               v[u] = *(gcf4)(src + (long long)grow * ld + c);
             }
 #pragma unroll
@@ -496,14 +505,14 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_chain(const ChainProblem *__r
             }
           }
         } else {
-          const int total = CH_BM * width;
+          const int total = BM * width;
           for (int base = 0; base < total; base += 8 * CH_THREADS) {
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
               const int e = base + tid + u * CH_THREADS;
               const int r = e / width, c = e - r * width;
-              const int grow = min(r0 + min(r, CH_BM - 1), rows - 1);
+              const int grow = min(r0 + min(r, BM - 1), rows - 1);
               v[u] = src[(long long)grow * ld + c];
             }
 #pragma unroll
@@ -517,7 +526,7 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_chain(const ChainProblem *__r
         ktot = max(ktot, col + width);
       }
       const int npad = kpad - ktot;
-      for (int e = tid; e < CH_BM * npad; e += CH_THREADS) {
+      for (int e = tid; e < BM * npad; e += CH_THREADS) {
         const int r = e / npad, c = e - r * npad;
         lds[slot + r * pitch + ktot + c] = 0.f;
       }
@@ -527,7 +536,7 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_chain(const ChainProblem *__r
       const int n0 = wave * 64;
       if (flags & CHF_ZERO) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < TM; ++a)
 #pragma unroll
           for (int r = 0; r < 16; ++r) { acc[a][0][r] = 0.f; acc[a][1][r] = 0.f; }
       }
@@ -563,7 +572,7 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_chain(const ChainProblem *__r
       for (int s = 0; s < nseg; ++s) {
         const int K = ch_uni(op.seg[s].K), pitch = ch_uni(op.seg[s].pitch), slot = ch_uni(op.seg[s].slot);
         const int k16 = (K + 15) & ~15, wp = k16 + 4;
-        const unsigned a0 = lds0 + (unsigned)(slot + (16 * wave + lj) * pitch + 4 * kq) * 4u;
+        const unsigned a0 = lds0 + (unsigned)(slot + (16 * (wave & (2 * TM - 1)) + lj) * pitch + 4 * kq) * 4u;
         const unsigned w0 = lds0 + (unsigned)(wslot + n0c * wp + 4 * kq) * 4u, w1 = lds0 + (unsigned)(wslot + n1c * wp + 4 * kq) * 4u;
         wslot += N * wp;
         const int nh = k16 >> 4;
@@ -610,7 +619,7 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_chain(const ChainProblem *__r
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int col = 16 * t + lj;
-          if (col < N) {
+          if (col < N && wave < 2 * TM) {   // (32-row blocks: the rows live in waves 0 and 1)
             const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -637,18 +646,19 @@ int chain_read_stamps(unsigned long long *out, int cap) {
 }
 void chain_enable_stamps(int on) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ch_stamps_on), &on, sizeof(on)); }
 
-int chain_finalize(ChainProblem *probs, int nprob) {
+int chain_finalize(ChainProblem *probs, int nprob, int bm) {
   int total = 0;
   for (int i = 0; i < nprob; ++i) {
     probs[i].block_start = total;
-    total += (probs[i].rows + CH_BM - 1) / CH_BM;
+    total += (probs[i].rows + bm - 1) / bm;
   }
   return total;
 }
 
-hipError_t chain_launch(const ChainProblem *probs_dev, int nprob, const ChainOp *ops_dev, int total_blocks, int lds_floats,
+hipError_t chain_launch(const ChainProblem *probs_dev, int nprob, const ChainOp *ops_dev, int total_blocks, int lds_floats, int bm,
                         hipStream_t stream) {
   if (total_blocks <= 0) return hipSuccess;
+  if (bm != 32 && bm != CH_BM) return hipErrorInvalidValue;
   // dynamic LDS beyond 64 KiB has to be allowed once per (device, function): a process may drive several GPUs, and two
   // agents may launch from two threads
   static bool attr_set[64];
@@ -660,14 +670,16 @@ hipError_t chain_launch(const ChainProblem *probs_dev, int nprob, const ChainOp 
     if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     std::lock_guard<std::mutex> lk(attr_mu);
     if (!attr_set[dev]) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_FLOATS * 4);
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<2>), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_FLOATS * 4);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<1>), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_FLOATS * 4);
       if (e != hipSuccess) return e;
       if (getenv("FDQL_CHAIN_STAMPS")) chain_enable_stamps(1);
-      if (const char *v = getenv("FDQL_CHAIN_STAGGER")) { const int k = atoi(v); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ch_stagger), &k, sizeof(k)); }
       attr_set[dev] = true;
     }
   }
-  hipLaunchKernelGGL(k_chain, dim3(total_blocks), dim3(CH_THREADS), (size_t)lds_floats * 4, stream, probs_dev, nprob, ops_dev);
+  if (bm == 32) hipLaunchKernelGGL(k_chain<1>, dim3(total_blocks), dim3(CH_THREADS), (size_t)lds_floats * 4, stream, probs_dev, nprob, ops_dev);
+  else hipLaunchKernelGGL(k_chain<2>, dim3(total_blocks), dim3(CH_THREADS), (size_t)lds_floats * 4, stream, probs_dev, nprob, ops_dev);
   return hipGetLastError();
 }
 

@@ -482,6 +482,18 @@ def test_update_matches_oracle_config2(dev, T, B, hid):
           joint_hidden=(64, 64), latent=64, enc_features=48, env={"FDQL_CHAIN": "all"})),
     ("chain kernel, discrete SAC head (Gumbel-softmax, one-hot critic input)",
      dict(obs=64, act=6, discrete=True, C=2, Q=5, T=4, B=128, env={"FDQL_CHAIN": "all"})),
+    ("chain kernel with 32-row blocks (FDQL_CHAIN_BM=32), config 2 dims: encoder/joiner/actors in one program, each critic "
+     "instance in one", dict(obs=17, act=6, C=5, Q=2, T=4, B=72, env={"FDQL_CHAIN": "all", "FDQL_CHAIN_BM": "32"})),
+    ("chain kernel with 32-row blocks, goal-conditioned input, 25-quantile heads, partial last block (B=70)",
+     dict(obs=28, goal=10, act=6, C=3, Q=25, T=4, B=70, env={"FDQL_CHAIN": "all", "FDQL_CHAIN_BM": "32"})),
+    ("chain kernel with 32-row blocks, ragged sizes (B=7, odd widths 18/33/21)",
+     dict(obs=3, act=2, C=2, Q=3, T=3, B=7, critic_hidden=(33, 18), pi_hidden=(21,), enc_hidden=(18,), joint_hidden=(33,),
+          latent=21, enc_features=18, env={"FDQL_CHAIN": "all", "FDQL_CHAIN_BM": "32"})),
+    ("chain kernel with 32-row blocks, deep nets (wide heads over three feature blocks)",
+     dict(obs=9, act=4, C=3, Q=5, T=4, B=40, critic_hidden=(64, 96, 64), pi_hidden=(64, 48), enc_hidden=(80, 64),
+          joint_hidden=(64, 64), latent=64, enc_features=48, env={"FDQL_CHAIN": "all", "FDQL_CHAIN_BM": "32"})),
+    ("config 4 dims (376 observation columns: only 32-row blocks fit the chain kernel's LDS), encoder -> joiner -> actors chained "
+     "(FDQL_CHAIN_MIN_BLOCKS=1), 5x25 quantiles", dict(obs=376, act=17, C=5, Q=25, T=3, B=80, env={"FDQL_CHAIN_MIN_BLOCKS": "1"})),
     ("config 2 dims on the LDS-DMA GEMM, 128x128 tiles (dense shape 7: dual outputs + head fusion in that kernel)",
      dict(obs=17, act=6, C=5, Q=2, T=6, B=64, dense_shape=7)),
     ("ragged sizes on the LDS-DMA GEMM, 64x64 tiles (edge tiles and ragged chunks through its guarded path)",

@@ -136,6 +136,29 @@ if sq_rows:
             traffic["shader_clock_ghz_under_load"] = round(csum / wsum, 2)
             traffic["pmc_source"] = ("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES, time-weighted over the "
                                      "kernel's launches; the 157.3 TFLOP/s peak assumes 2.4 GHz")
+        # the same figures for every dense kernel: two launches of a step are within a microsecond of each other
+        # (k_wstat<0,0,2> and k_wgrad_stat at config 2), and which of them bench.py finds "dominant" changes from run to run
+        allk = {}
+        for name, t in tot.items():
+            if not any(tag in name for tag in DENSE) or not t[2]:
+                continue
+            e = {"hbm_read_MB_per_launch": t[0] / t[2], "hbm_write_MB_per_launch": t[1] / t[2],
+                 "hbm_bytes_per_launch": (t[0] + t[1]) / t[2] * 1e6, "dispatches_measured": t[2]}
+            wsum = usum = csum = 0.0
+            for key, d in per.items():
+                if key[0] != name or not dur[key][1]:
+                    continue
+                n = max(d["n_SQ_BUSY_CYCLES"], 1.0)
+                busy = d["SQ_BUSY_CYCLES"] / n / 32.0
+                mf = d["SQ_VALU_MFMA_BUSY_CYCLES"] / max(d["n_SQ_VALU_MFMA_BUSY_CYCLES"], 1.0) / 1024.0
+                us = dur[key][0] / dur[key][1]
+                wgt = us * dur[key][1]
+                wsum += wgt; usum += wgt * (mf / busy if busy else 0.0); csum += wgt * (busy / us / 1e3)
+            if wsum > 0:
+                e["mfma_pipe_busy_frac"] = round(usum / wsum, 3)
+                e["shader_clock_ghz_under_load"] = round(csum / wsum, 2)
+            allk[name] = e
+        traffic["kernels"] = allk
 # instruction mix per dense kernel: what shares the issue stream with the fp32 MFMAs.  Cost model (tools/proto/mfma_coissue*.hip,
 # profiles/r02_rowgemm_notes.txt): an MFMA 32x32x2 holds the SIMD 64 cycles; a VALU instruction beside it ~5 (9 for the first
 # after an MFMA), an LDS instruction ~7, a vector-memory instruction 25-57: predicted fraction of the MFMA rate
