@@ -1,5 +1,10 @@
 """Per-step HIP-event times of the first 80 steps of bench.py's Job right after set-up (config 2): the start-up clock ramp."""
-sys.path.insert(0, "/root/repo")
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 dev = torch.device("cuda:0")
 w = bench.WORKLOADS["config2"]
