@@ -494,6 +494,12 @@ def test_update_matches_oracle_config2(dev, T, B, hid):
           joint_hidden=(64, 64), latent=64, enc_features=48, env={"FDQL_CHAIN": "all", "FDQL_CHAIN_BM": "32"})),
     ("config 4 dims (376 observation columns: only 32-row blocks fit the chain kernel's LDS), encoder -> joiner -> actors chained "
      "(FDQL_CHAIN_MIN_BLOCKS=1), 5x25 quantiles", dict(obs=376, act=17, C=5, Q=25, T=3, B=80, env={"FDQL_CHAIN_MIN_BLOCKS": "1"})),
+    ("config 2 dims with an odd row count (T=4, B=33: 99 gradient rows, one K-split slab), every narrow weight gradient on the "
+     "streaming kernel (FDQL_STREAM_WGRAD=2): the last row pair is half empty",
+     dict(obs=17, act=6, C=5, Q=2, T=4, B=33, env={"FDQL_STREAM_WGRAD": "2"})),
+    ("config 2 dims, T=9, B=100 (800 gradient rows, 2 slabs of 400): riders on the output-stationary launch forced at a small "
+     "size (FDQL_ROWGEMM=all FDQL_WGRAD_STAT_FACTOR=1), streaming kernel for the rest",
+     dict(obs=17, act=6, C=5, Q=2, T=9, B=100, env={"FDQL_ROWGEMM": "all", "FDQL_WGRAD_STAT_FACTOR": "1", "FDQL_STREAM_WGRAD": "2"})),
     ("config 2 dims on the LDS-DMA GEMM, 128x128 tiles (dense shape 7: dual outputs + head fusion in that kernel)",
      dict(obs=17, act=6, C=5, Q=2, T=6, B=64, dense_shape=7)),
     ("ragged sizes on the LDS-DMA GEMM, 64x64 tiles (edge tiles and ragged chunks through its guarded path)",
