@@ -102,6 +102,16 @@ __global__ __launch_bounds__(SW_THREADS) void k_skinny_wgrad(const SkinnyWgradPr
   for (int q = 0; q < NOUT_MAX; ++q) acc[q] = 0.f;
   // four rows per round (rows m, m + 4, m + 8, m + 12 of this row lane), their loads requested together: a loop of single
   // rows is one memory round trip per row
+  if (!dY) {   // column sums: sixteen rows per round (one register per request)
+    for (int m = m0 + rg; m < m1; m += 64) {
+      float xv[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) xv[u] = (kin && X) ? X[(long long)min(m + 4 * u, m1 - 1) * P.ldx + k] : 1.f;
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc[0] += m + 4 * u < m1 ? xv[u] : 0.f;
+    }
+  } else
   for (int m = m0 + rg; m < m1; m += 16) {
     float xv[4];
     gcf dp[4];
