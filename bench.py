@@ -173,7 +173,7 @@ def dominant(prof):
     the row-block chain kernel): name, ms/step, flops/step, launches/step, and the all-MFMA-kernel totals."""
     groups = {}
     for k, v in prof.items():
-        if k.startswith(("gemm", "chain", "rows", "wstat", "wgstat")):
+        if k.startswith(("gemm", "chain", "rows", "rowd", "wstat", "wgstat")):
             groups.setdefault(k.split(":")[0], []).append(v)
     name, rows = max(groups.items(), key=lambda kv: sum(r[0] for r in kv[1]))
     ms, fl, n = sum(r[0] for r in rows), sum(r[1] * r[3] for r in rows), sum(r[3] for r in rows)
@@ -191,6 +191,8 @@ def kernel_label(name):
                " form, fp32 v_mfma_f32_32x32x2_f32)"
     if name.startswith("wgstat"):
         return "k_wgrad_stat (output-stationary weight-gradient blocks, fp32 v_mfma_f32_32x32x2_f32)"
+    if name.startswith("rowd"):
+        return "k_rowdgrad (row-block dgrad, K-strided weights, fp32 v_mfma_f32_16x16x4_f32)"
     if name.startswith("rows"):
         return "k_rowgemm (persistent row-block GEMM, " + ("dgrad" if "KS" in name else "forward") + " form, fp32 v_mfma_f32_32x32x2_f32)"
     return f"k_gemm_grouped<{name[4:]} tile> (fp32 v_mfma_f32_32x32x2_f32)"
@@ -202,6 +204,8 @@ def rocprof_tag(name):
         return "k_chain"
     if name.startswith("wgstat"):
         return "k_wgrad_stat"
+    if name.startswith("rowd<"):
+        return "k_rowdgrad"
     if name.startswith("wstatg<"):       # "wstatg<fuse,plain,ns>:stage" -> k_wstat_grad<true, false, 1>
         f, pl, ns = name[7:name.index(">")].split(",")
         return f"k_wstat_grad<{'true' if f == '1' else 'false'}, {'true' if pl == '1' else 'false'}, {ns}>"

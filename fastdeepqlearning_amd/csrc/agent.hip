@@ -22,6 +22,7 @@
 #include "rowgemm.h"
 #include "wstat.h"
 #include "wgrad.h"
+#include "rowdgrad.h"
 #include "common.h"
 #include "update_kernels.h"
 
@@ -97,9 +98,11 @@ enum StageKind { ST_GEMM, ST_SKINNY_WGRAD, ST_FUNC, ST_HEAD_DGRAD, ST_CHAIN, ST_
 // one launch of a row-block kernel: the weight-stationary one (wstat.hip, forward forms) or the streamed-weights one
 struct RowsLaunch {
   bool ws = false;
+  bool rd = false;      // single-network dgrad on 64-row blocks (rowdgrad.h)
   RowGemmArgs rg;
   WsArgs wa;
-  hipError_t launch(hipStream_t s) const { return ws ? wstat_launch(wa, s) : rowgemm_launch(rg, s); }
+  RowDgradArgs rda;
+  hipError_t launch(hipStream_t s) const { return rd ? rowdgrad_launch(rda, s) : (ws ? wstat_launch(wa, s) : rowgemm_launch(rg, s)); }
 };
 
 struct GemmSub {
@@ -207,6 +210,7 @@ struct fdql_agent {
   long long rows_min_tiles = 256;   // FDQL_ROWGEMM: "0" never, "all" always, a number = the threshold; default: groups with at least one
                                     // 64-row tile per CU (a weight-stationary workgroup with 2 + 2 32-row tiles still beats the tile
                                     // kernels: config 4 at 128 windows per GPU)
+  int rowdgrad_min_blocks = 128;    // 64-row blocks a single-network dgrad needs for the row-block dgrad kernel (FDQL_ROWDGRAD_MIN_BLOCKS)
   int wgrad_stat_factor = 4;        // x rows_min_tiles 32-row tiles for the output-stationary weight-gradient launch (4 per workgroup)
   // d state = sum over the online critics and the actor: one problem accumulating every network's K-segments, or - few rows
   // (a handful of workgroups would walk all segments serially), or many rows with critics the weight-stationary kernel
@@ -928,6 +932,15 @@ int upload_tables(fdql_agent *a) {
           } else {
             for (size_t j : idx) taken[j] = 2;   // looked at, stays on the tile kernels
           }
+        }
+      }
+      // single-network dgrads (256-wide K-strided segments, gate / column sums) with enough 64-row blocks to fill most of the chip
+      for (size_t i = 0; i < s.gemm.size(); ++i) {
+        RowsLaunch rl;
+        if (taken[i] != 1 && s.gemm[i].M / RD_BM >= a->rowdgrad_min_blocks && rowdgrad_from_problem(s.gemm[i], rl.rda)) {
+          rl.rd = true;
+          s.rows.push_back(rl);
+          taken[i] = 1;
         }
       }
       for (size_t i = 0; i < s.gemm.size(); ++i) {
@@ -1852,6 +1865,7 @@ int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {
     else if (r && !strcmp(r, "all")) a->rows_min_tiles = 1;
     else if (r && atoi(r) > 1) a->rows_min_tiles = atoi(r);
     if (const char *f = getenv("FDQL_WGRAD_STAT_FACTOR")) { if (atoi(f) >= 1) a->wgrad_stat_factor = atoi(f); }
+    if (const char *f = getenv("FDQL_ROWDGRAD_MIN_BLOCKS")) { if (atoi(f) >= 1) a->rowdgrad_min_blocks = atoi(f); }
   }
   a->T = c.T; a->B = c.B; a->N = c.T * c.B; a->M = (c.T - 1) * c.B; a->A = c.act_dim; a->L = c.latent;
   a->Nq = c.n_critics * c.n_quantiles;
@@ -2074,7 +2088,11 @@ int32_t fdql_agent_profile_update(fdql_agent_t *a, const fdql_batch_t *batch, co
       snprintf(out[cnt].name, sizeof(out[cnt].name), "gemm%s:%s", shape_names[parts[i].shape], st.name.c_str());
     } else if (parts[i].shape < -1) {
       const RowsLaunch &rl = st.rows[-2 - parts[i].shape];
-      if (rl.ws) {
+      if (rl.rd) {
+        flops = rowdgrad_flops(rl.rda);
+        bytes = 4.0 * rl.rda.M * (double)RD_N * (rl.rda.nseg + 1 + (rl.rda.gate ? 1 : 0));
+        snprintf(out[cnt].name, sizeof(out[cnt].name), "rowd<%d,%d>:%s", rl.rda.nseg, rl.rda.gate, st.name.c_str());
+      } else if (rl.ws) {
         flops = wstat_flops(rl.wa);
         bytes = 4.0 * rl.wa.M * rl.wa.ninst * (double)(WS_KMAIN + WS_N * (rl.wa.dual ? 2 : 1));
         // (the name carries the kernel's template arguments: bench.py / tools map it to the rocprofv3 kernel name)

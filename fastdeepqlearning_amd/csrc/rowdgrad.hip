@@ -1,0 +1,194 @@
+// Row-block dgrad kernel (rowdgrad.h): single-network input gradients on 64-row blocks with K-strided weights streamed
+// straight into MFMA operands.
+//
+// Why not the tile kernel: joiner.dpre0 / d enc / enc_obs.dpre0 are [12 544 x 256] x [256 x 256] products - 784 tiles of
+// 64 x 64, one wave per SIMD, 16 dependent K iterations each: 47-60 TFLOP/s.  Why not the
+// weight-stationary kernels: one network = one instance, and 256 workgroups each loading the same 256 KB of weights spend
+// half their life in the prologue.  Here a workgroup takes 64 rows x all 256 columns:
+//   * the A tiles (one or two segments of 256 k) go global -> LDS once, by LDS-DMA;
+//   * weights are K-strided (element (k, n) at W[k*ldw + n]: a dgrad multiplies by the layer's weight matrix as stored).  A
+//     lane's 16-byte load W[k][n0 + 4 j .. + 3] (j = lane % 16, k = kb + 8 (lane / 16) + i) is, component c, the B operand
+//     (lane (j, kq) = B[k = kq][n = j]) of a v_mfma_f32_16x16x4_f32 whose 16 output columns are n0 + 4 j + c: four
+//     accumulators per 16-row tile cover a wave's 64 columns and no transpose is needed anywhere; the matching A operand
+//     (lane (row, kq) = x[row][kb + 8 kq + i]) is a component of two ds_read_b128.  8 global loads + 8 LDS reads per
+//     128 MFMAs (4096 MFMA cycles) per wave;
+//   * a lane ends up with four consecutive columns of a row per (tile, register): the LeakyReLU' gate reads the reference
+//     activation as float4, the result leaves as global_store_dwordx4, and the column sums of the block (bias gradients)
+//     are 16 in-lane adds + two cross-lane steps per column quad.
+// Measured at config 2 (12 544 rows): 28 us per 256 x 256 layer against 31 us on the tile kernel (1.303 -> 1.295 ms per
+// update for the three launches); 32-row blocks, two workgroups per CU: another 2 us per launch (would need the column-sum
+// consumers to read twice the partial rows: not done).
+#include "rowdgrad.h"
+
+#include <stdlib.h>
+#include <string.h>
+#include <mutex>
+
+namespace fdql {
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) float *gcf;
+typedef const __attribute__((address_space(1))) v4f *gcf4;
+typedef __attribute__((address_space(1))) v4f *gf4;
+typedef __attribute__((address_space(3))) void *lds_vp;
+typedef const __attribute__((address_space(1))) void *glb_vp;
+
+constexpr int P = RD_K + 4;            // image row pitch: (P / 4) odd
+constexpr int RD_RT = RD_BM / 16;      // 16-row MFMA tiles per workgroup
+constexpr int IMG = RD_BM * P;
+
+__device__ __forceinline__ int rd_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+template <int NSEG, bool GATE>
+__global__ __launch_bounds__(256, 1) void k_rowdgrad(const RowDgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // A images [NSEG][64][P]
+  const int tid = threadIdx.x, lane = tid & 63, wave = rd_uni(tid >> 6);
+  const int j = lane & 15, kq = lane >> 4;
+  const int blk = blockIdx.x, r0 = blk * RD_BM, n0 = wave * 64;
+
+  // ---- A tiles -> LDS (wave w: rows w, w + 4, ...: one 1 KiB row per instruction)
+#pragma unroll
+  for (int s = 0; s < NSEG; ++s) {
+    const float *src = a.A[s] + (long long)r0 * RD_K;
+#pragma unroll
+    for (int u = 0; u < RD_BM / 4; ++u) {
+      const int row = wave + 4 * u;
+      __builtin_amdgcn_global_load_lds((glb_vp)(src + row * RD_K + lane * 4), (lds_vp)(lds + s * IMG + row * P), 16, 0, 0);
+    }
+  }
+
+  v4f acc[RD_RT][4];   // [16-row tile][c]: register r = row 16 rt + 4 kq + r, column n0 + 4 j + c
+#pragma unroll
+  for (int rt = 0; rt < RD_RT; ++rt)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[rt][c] = v4f{0.f, 0.f, 0.f, 0.f};
+
+  // weight fragments of a 32-k group: load i = row kb + 8 kq + i
+  auto load_w = [&](gcf w, int ldw, int kb, v4f (&wv)[8]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) wv[i] = *(gcf4)(w + (long long)(kb + 8 * kq + i) * ldw);
+  };
+  v4f wv[2][8];
+  {
+    gcf w0 = (gcf)a.W[0] + n0 + 4 * j;
+    load_w(w0, a.ldw[0], 0, wv[0]);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA pieces have landed (and the first weight fragments with them)
+  __syncthreads();
+
+  v4f rq[GATE ? 4 * RD_RT : 1];   // the gate's reference quads: requested under the last group's MFMAs
+#pragma unroll
+  for (int s = 0; s < NSEG; ++s) {
+    gcf w = (gcf)a.W[s] + n0 + 4 * j;
+    const int ldw = a.ldw[s];
+    const float *img = lds + s * IMG + j * P + 8 * kq;
+#pragma unroll
+    for (int g = 0; g < RD_K / 32; ++g) {
+      const int cur = (s * (RD_K / 32) + g) & 1;
+      // next group's weights (of this segment, or the first of the next one)
+      if (g + 1 < RD_K / 32) {
+        load_w(w, ldw, 32 * (g + 1), wv[cur ^ 1]);
+      } else if (s + 1 < NSEG) {
+        load_w((gcf)a.W[s + 1] + n0 + 4 * j, a.ldw[s + 1], 0, wv[cur ^ 1]);
+      } else if constexpr (GATE) {
+#pragma unroll
+        for (int rt = 0; rt < RD_RT; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            rq[4 * rt + r] = *(gcf4)((gcf)a.ref + (long long)(r0 + 16 * rt + 4 * kq + r) * RD_N + n0 + 4 * j);
+      }
+      v4f xa[RD_RT], xb[RD_RT];
+#pragma unroll
+      for (int rt = 0; rt < RD_RT; ++rt) {
+        xa[rt] = *reinterpret_cast<const v4f *>(img + 16 * rt * P + 32 * g);
+        xb[rt] = *reinterpret_cast<const v4f *>(img + 16 * rt * P + 32 * g + 4);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int rt = 0; rt < RD_RT; ++rt) {
+          const float av = i < 4 ? xa[rt][i] : xb[rt][i - 4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wv[cur][i][c], acc[rt][c], 0, 0, 0);
+        }
+    }
+  }
+
+  // ---- epilogue: gate, store, column sums
+  v4f cs = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int rt = 0; rt < RD_RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v4f x = {acc[rt][0][r], acc[rt][1][r], acc[rt][2][r], acc[rt][3][r]};
+      if constexpr (GATE) {
+        const v4f h = rq[4 * rt + r];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) x[c] = h[c] > 0.f ? x[c] : 0.01f * x[c];
+      }
+      *(gf4)(a.C + (long long)(r0 + 16 * rt + 4 * kq + r) * RD_N + n0 + 4 * j) = x;
+      cs += x;
+    }
+  if (a.colsum) {   // rows 4 kq + .. of every tile are in this lane; the other three quarters sit 16, 32, 48 lanes away
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v = cs[c];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      cs[c] = v;
+    }
+    if (kq == 0) *(gf4)(a.colsum + (long long)blk * RD_N + n0 + 4 * j) = cs;
+  }
+}
+
+}  // namespace
+
+bool rowdgrad_from_problem(const GemmProblem &p, RowDgradArgs &args) {
+  const char *env = getenv("FDQL_ROWDGRAD");   // "0": never (tuning / test hook; read per plan build)
+  if (env && env[0] == '0') return false;
+  if (p.M < RD_BM || p.M % RD_BM || p.N != RD_N || p.nseg < 1 || p.nseg > RD_MAX_SEG || p.ksplit != 1 || p.bias || p.C2 || p.hf_w || p.fz_h ||
+      p.ldc != RD_N || (p.epi != EPI_NONE && p.epi != EPI_LRELU_GRAD))
+    return false;
+  auto aligned = [](const void *q, uintptr_t n) { return (reinterpret_cast<uintptr_t>(q) & (n - 1)) == 0; };
+  memset(&args, 0, sizeof(args));
+  args.M = p.M; args.nseg = p.nseg; args.gate = p.epi == EPI_LRELU_GRAD;
+  for (int s = 0; s < p.nseg; ++s) {
+    const GemmSeg &sg = p.seg[s];
+    if (sg.K != RD_K || !sg.a_kc || sg.b_kc || sg.lda != RD_K || !aligned(sg.A, 16) || !aligned(sg.B, 4)) return false;
+    args.A[s] = sg.A; args.W[s] = sg.B; args.ldw[s] = sg.ldb;
+  }
+  if (args.gate && (!p.ref || p.ldref != RD_N || !aligned(p.ref, 16))) return false;
+  if (!aligned(p.C, 16) || (p.colsum && !aligned(p.colsum, 16))) return false;
+  args.ref = p.ref; args.C = p.C; args.colsum = p.colsum;
+  return true;
+}
+
+hipError_t rowdgrad_launch(const RowDgradArgs &a, hipStream_t s) {
+  static bool attr[64];
+  static std::mutex mu;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (!attr[dev]) {   // the opt-in to > 64 KiB of dynamic LDS belongs to the (device, function) pair
+      const void *fns[4] = {reinterpret_cast<const void *>(&k_rowdgrad<1, false>), reinterpret_cast<const void *>(&k_rowdgrad<1, true>),
+                            reinterpret_cast<const void *>(&k_rowdgrad<2, false>), reinterpret_cast<const void *>(&k_rowdgrad<2, true>)};
+      for (int i = 0; i < 4 && e == hipSuccess; ++i)
+        e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (i < 2 ? 1 : 2) * IMG * 4);
+      if (e != hipSuccess) return e;
+      attr[dev] = true;
+    }
+  }
+  const dim3 grid(a.M / RD_BM), block(256);
+  const size_t lds_bytes = (size_t)a.nseg * IMG * 4;
+  if (a.nseg == 1 && !a.gate) hipLaunchKernelGGL((k_rowdgrad<1, false>), grid, block, lds_bytes, s, a);
+  else if (a.nseg == 1) hipLaunchKernelGGL((k_rowdgrad<1, true>), grid, block, lds_bytes, s, a);
+  else if (!a.gate) hipLaunchKernelGGL((k_rowdgrad<2, false>), grid, block, lds_bytes, s, a);
+  else hipLaunchKernelGGL((k_rowdgrad<2, true>), grid, block, lds_bytes, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace fdql

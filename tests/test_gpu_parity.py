@@ -500,6 +500,8 @@ def test_update_matches_oracle_config2(dev, T, B, hid):
     ("config 2 dims, T=9, B=100 (800 gradient rows, 2 slabs of 400): riders on the output-stationary launch forced at a small "
      "size (FDQL_ROWGEMM=all FDQL_WGRAD_STAT_FACTOR=1), streaming kernel for the rest",
      dict(obs=17, act=6, C=5, Q=2, T=9, B=100, env={"FDQL_ROWGEMM": "all", "FDQL_WGRAD_STAT_FACTOR": "1", "FDQL_STREAM_WGRAD": "2"})),
+    ("config 2 dims, T=5, B=64: the row-block dgrad kernel forced at 4 blocks (FDQL_ROWDGRAD_MIN_BLOCKS=1: gated one-segment "
+     "form, plain two-segment form, column sums)", dict(obs=17, act=6, C=5, Q=2, T=5, B=64, env={"FDQL_ROWDGRAD_MIN_BLOCKS": "1"})),
     ("config 2 dims on the LDS-DMA GEMM, 128x128 tiles (dense shape 7: dual outputs + head fusion in that kernel)",
      dict(obs=17, act=6, C=5, Q=2, T=6, B=64, dense_shape=7)),
     ("ragged sizes on the LDS-DMA GEMM, 64x64 tiles (edge tiles and ragged chunks through its guarded path)",
@@ -864,6 +866,8 @@ def _gpu_branch_pattern(ag, spec, xp_cpu):
     ("config 2 full size, every narrow weight gradient through the streaming launch (FDQL_WGRAD_RIDERS=0: head rows over "
      "state / h0 / h1, action columns with the roles swapped)",
      dict(obs=17, act=6, C=5, Q=2, T=50, B=256, env={"FDQL_WGRAD_RIDERS": "0"})),
+    ("config 2 full size, the single-network dgrads (joiner / d enc / encoder) on the tile kernel instead of the row-block "
+     "dgrad kernel (FDQL_ROWDGRAD=0)", dict(obs=17, act=6, C=5, Q=2, T=50, B=256, env={"FDQL_ROWDGRAD": "0"})),
     ("config 2 full size, dense weight gradients riding in the dgrad launches (FDQL_WGRAD_STAT=0)",
      dict(obs=17, act=6, C=5, Q=2, T=50, B=256, env={"FDQL_WGRAD_STAT": "0"})),
     ("config 4 dims (5x25 quantiles, 17 action columns) at T=6, B=64 with the stationary and streaming launches forced "

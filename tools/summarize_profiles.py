@@ -27,7 +27,7 @@ def per_kernel(rows, counter):
     return acc
 
 
-DENSE = ("k_gemm", "k_chain", "k_rowgemm", "k_wstat", "k_wgrad_stat")   # the MFMA kernels
+DENSE = ("k_gemm", "k_chain", "k_rowgemm", "k_rowdgrad", "k_wstat", "k_wgrad_stat")   # the MFMA kernels
 fetch = per_kernel(counter_rows("pmc_fetch"), "FETCH_SIZE")
 write = per_kernel(counter_rows("pmc_write"), "WRITE_SIZE")
 lines = ["# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, --kernel-trace only) over",
