@@ -15,9 +15,9 @@
 //   * a lane ends up with four consecutive columns of a row per (tile, register): the LeakyReLU' gate reads the reference
 //     activation as float4, the result leaves as global_store_dwordx4, and the column sums of the block (bias gradients)
 //     are 16 in-lane adds + two cross-lane steps per column quad.
-// Measured at config 2 (12 544 rows): 28 us per 256 x 256 layer against 31 us on the tile kernel (1.303 -> 1.295 ms per
-// update for the three launches); 32-row blocks, two workgroups per CU: another 2 us per launch (would need the column-sum
-// consumers to read twice the partial rows: not done).
+// Measured at config 2 (12 544 rows, HIP events around the launch): 27-28 us per 256 x 256 layer and 43 us for the
+// two-segment one against 35 / 55 us on the tile kernel (1.303 -> 1.280 ms per update).  With the weight requests left to
+// the scheduler (sunk next to their uses, each waited for in turn) it was 32 / 53 us.
 #include "rowdgrad.h"
 
 #include <stdlib.h>
@@ -98,6 +98,9 @@ __global__ __launch_bounds__(256, 1) void k_rowdgrad(const RowDgradArgs a) {
           for (int r = 0; r < 4; ++r)
             rq[4 * rt + r] = *(gcf4)((gcf)a.ref + (long long)(r0 + 16 * rt + 4 * kq + r) * RD_N + n0 + 4 * j);
       }
+      // (the empty asm pins the requests ahead of this group's MFMAs: the scheduler otherwise sinks every load next to its
+      // use, one group later, and waits for each one in turn)
+      asm volatile("" ::: "memory");
       v4f xa[RD_RT], xb[RD_RT];
 #pragma unroll
       for (int rt = 0; rt < RD_RT; ++rt) {
