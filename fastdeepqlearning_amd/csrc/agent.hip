@@ -211,6 +211,8 @@ struct fdql_agent {
                                     // 64-row tile per CU (a weight-stationary workgroup with 2 + 2 32-row tiles still beats the tile
                                     // kernels: config 4 at 128 windows per GPU)
   int rowdgrad_min_blocks = 128;    // 64-row blocks a single-network dgrad needs for the row-block dgrad kernel (FDQL_ROWDGRAD_MIN_BLOCKS)
+  int rowdgrad_max_blocks = 256;    // ... and may have: one round of workgroups (config 4 at B = 1024, 784 blocks = 3.06 rounds: the tile
+                                    // kernel's 3136 tiles are the better fit there: 0.138 against 0.153 ms for d enc)
   int wgrad_stat_factor = 4;        // x rows_min_tiles 32-row tiles for the output-stationary weight-gradient launch (4 per workgroup)
   // d state = sum over the online critics and the actor: one problem accumulating every network's K-segments, or - few rows
   // (a handful of workgroups would walk all segments serially), or many rows with critics the weight-stationary kernel
@@ -612,28 +614,33 @@ struct Builder {
   void take_stream_wgrads(Stage &from, Stage &to, Stage &skinny) {
     const char *env = getenv("FDQL_STREAM_WGRAD");
     if (env && env[0] == '0') return;
-    // Only where the tile kernels' narrow launches are latency-bound: a K-split slab of a few hundred rows (config 2: 392 -
-    // 25 dependent K iterations per workgroup, 0.7-2.4 TB/s).  With long slabs (config 4 at B = 1024: 1568 rows) the tile
-    // kernel streams at 5 TB/s and the one-wave-per-64-columns form (2.4 TB/s) would be the slower one.
-    if (!(env && env[0] == '2') && a->M / a->nsplit > STREAM_WGRAD_MAX_SLAB_ROWS) return;
+    // Short K-split slabs (a few hundred rows, config 2: the tile kernels' narrow launches are one memory round trip per K
+    // iteration there, 0.7-2.4 TB/s): everything that has the form.  Long slabs (config 4 at B = 1024: 1568 rows): the
+    // 32x128 tile streams the head rows at 5 TB/s - better than the 4.4 TB/s here - but the 128x32 launch of the few-input-
+    // column gradients does 1.8 TB/s: only those move, and the tiny ones stay where they are (the column sums' launch
+    // would take them one column per thread).  FDQL_STREAM_WGRAD=2: everything, whatever the slab length (tests).
+    const bool all = (env && env[0] == '2') || a->M / a->nsplit <= STREAM_WGRAD_MAX_SLAB_ROWS;
     for (size_t i = 0; i < from.gemm.size();) {
       const GemmProblem &p = from.gemm[i];
       SkinnyWgradProblem q;
       memset(&q, 0, sizeof(q));
       bool ok = p.nseg == 1 && p.ksplit == a->nsplit && p.split_stride == a->n_train && !p.bias && p.epi == EPI_NONE && !p.colsum && !p.C2 &&
                 !p.seg[0].a_kc && !p.seg[0].b_kc;
-      if (ok && p.M <= SKINNY_MAX_OUT && p.N <= 64) {
+      if (ok && p.M <= SKINNY_MAX_OUT && p.N <= 64) {   // narrow both ways
         const GemmSeg &sg = p.seg[0];
         q.M = sg.K; q.Nout = p.M; q.K = p.N; q.dY = sg.A; q.lddy = sg.lda; q.X = sg.B; q.ldx = sg.ldb;
         q.dW = p.C; q.sq = p.ldc; q.sk = 1; q.split_stride = p.split_stride; q.nsplit = p.ksplit;
-        skinny.swg.push_back(q);
+        const bool tiny = q.Nout <= 2 && q.K <= 8;   // (k_skinny_wgrad's threads-over-rows path: 0.001 ms beside the column sums)
+        if (tiny && !all) { ++i; continue; }
+        if (!tiny && !stream_wgrad_takes(q)) { ++i; continue; }
+        (tiny ? skinny : to).swg.push_back(q);
         from.gemm.erase(from.gemm.begin() + i);
         continue;
       }
       if (ok) {
         const GemmSeg &sg = p.seg[0];   // dW[nout = p.M][width = p.N] = dOut[R, nout]^T X[R, width]
         q.M = sg.K; q.K = 256; q.ldx = 256; q.dW = p.C; q.split_stride = p.split_stride; q.nsplit = p.ksplit;
-        if (p.N == 256 && sg.ldb == 256 && p.M <= 32) {          // few outputs over a 256-wide input
+        if (all && p.N == 256 && sg.ldb == 256 && p.M <= 32) {   // few outputs over a 256-wide input
           q.Nout = p.M; q.dY = sg.A; q.lddy = sg.lda; q.X = sg.B; q.sq = p.ldc; q.sk = 1;
         } else if (p.M == 256 && sg.lda == 256 && p.N <= 32) {   // few input columns: dW^T[a][n] = X2[R, a]^T dOut[R, n]
           q.Nout = p.N; q.dY = sg.B; q.lddy = sg.ldb; q.X = sg.A; q.sq = 1; q.sk = p.ldc;
@@ -937,7 +944,8 @@ int upload_tables(fdql_agent *a) {
       // single-network dgrads (256-wide K-strided segments, gate / column sums) with enough 64-row blocks to fill most of the chip
       for (size_t i = 0; i < s.gemm.size(); ++i) {
         RowsLaunch rl;
-        if (taken[i] != 1 && s.gemm[i].M / RD_BM >= a->rowdgrad_min_blocks && rowdgrad_from_problem(s.gemm[i], rl.rda)) {
+        if (taken[i] != 1 && s.gemm[i].M / RD_BM >= a->rowdgrad_min_blocks && s.gemm[i].M / RD_BM <= a->rowdgrad_max_blocks &&
+            rowdgrad_from_problem(s.gemm[i], rl.rda)) {
           rl.rd = true;
           s.rows.push_back(rl);
           taken[i] = 1;
@@ -1866,6 +1874,7 @@ int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {
     else if (r && atoi(r) > 1) a->rows_min_tiles = atoi(r);
     if (const char *f = getenv("FDQL_WGRAD_STAT_FACTOR")) { if (atoi(f) >= 1) a->wgrad_stat_factor = atoi(f); }
     if (const char *f = getenv("FDQL_ROWDGRAD_MIN_BLOCKS")) { if (atoi(f) >= 1) a->rowdgrad_min_blocks = atoi(f); }
+    if (const char *f = getenv("FDQL_ROWDGRAD_MAX_BLOCKS")) { if (atoi(f) >= 1) a->rowdgrad_max_blocks = atoi(f); }
   }
   a->T = c.T; a->B = c.B; a->N = c.T * c.B; a->M = (c.T - 1) * c.B; a->A = c.act_dim; a->L = c.latent;
   a->Nq = c.n_critics * c.n_quantiles;

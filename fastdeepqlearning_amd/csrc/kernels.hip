@@ -3,6 +3,7 @@
 #include "common.h"
 #include "update_kernels.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace fdql {
 
@@ -180,104 +181,180 @@ hipError_t skinny_wgrad_launch_host(const SkinnyWgradProblem *host, const Skinny
 // (row pitch 256) and Nout <= 32 - the skip heads' rows over a 256-wide activation, the few input columns (observation,
 // action) of a 256-wide layer with the roles swapped.  HBM-bound by construction: a single-wave workgroup = 64 columns
 // [64 w, 64 w + 64) of one K-split slab of one problem for ALL rows of the split, so nothing is reduced across waves,
-// nothing goes through LDS, and the number of waves does not hang on the K-split alone; per row pair a lane issues one 8-byte load of X (two of its wave's columns) and one 4-byte
-// load of dY (lane li = output q, lane half = row parity) - directly the B and A operands of two v_mfma_f32_32x32x2_f32
-// (64 flops per byte loaded: the matrix pipe idles) - and SW2_U row pairs are in flight per wave.
+// nothing goes through LDS, and the number of waves does not hang on the K-split alone.  A row is ONE
+// v_mfma_f32_4x4x1_16b_f32 per four outputs (8 cycles): lane l holds X[m][64 w + l] (a 256-byte coalesced load per row) as
+// the B operand of its block l / 4, and the A operand - dY[m][4 g .. 4 g + 3] for all 16 blocks - is BROADCAST by the
+// instruction itself (CBSZ = 4, ABID = r) from a register that holds the dY quads of 16 rows (one load per 16 rows).  The
+// result needs no rearrangement: register i of lane l is dW[4 g + i][64 w + l].  (First version, round 3: row pairs as
+// v_mfma_f32_32x32x2_f32 - 64 cycles per row on two dependent accumulator chains, 18 us of MFMA latency per wave.)
 // ======================================================================================
-#ifndef FDQL_SW2_U
-#define FDQL_SW2_U 8
+#ifndef FDQL_SW2_R
+#define FDQL_SW2_R 32
 #endif
-constexpr int SW2_U = FDQL_SW2_U;   // row pairs per request round and wave (two rounds in flight)
+constexpr int SW2_R = FDQL_SW2_R;   // rows per request round and wave (two rounds in flight); multiple of 16
 
-__global__ __launch_bounds__(64) void k_stream_wgrad(const SkinnyWgradProblem *__restrict__ probs, int nprob) {
-  typedef float f32x16 __attribute__((ext_vector_type(16)));
-  typedef float v2f __attribute__((ext_vector_type(2)));
+template <int I, int N, typename F>
+__device__ __forceinline__ void sw2_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    sw2_for<I + 1, N>(f);
+  }
+}
+
+template <int NG>   // groups of four outputs
+__device__ __forceinline__ void stream_wgrad_body(const SkinnyWgradProblem &P, int split, int wave) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
   typedef const __attribute__((address_space(1))) float *gcf;
-  typedef const __attribute__((address_space(1))) v2f *gcf2;
   typedef __attribute__((address_space(1))) float *gf;
-  const int bid = blockIdx.x;
-  const int pi = find_problem<SkinnyWgradProblem, &SkinnyWgradProblem::block_start>(probs, nprob, bid, threadIdx.x & 63);
-  const SkinnyWgradProblem &P = probs[pi];
-  const int split = (bid - P.block_start) >> 2, wave = (bid - P.block_start) & 3;   // a workgroup is ONE wave: 64 columns of one slab
-  const int lane = threadIdx.x, li = lane & 31, lh = lane >> 5;
-  const int Nout = P.Nout, M = P.M;
-  const int per = (((M + P.nsplit - 1) / P.nsplit) + 1) & ~1;   // even: row pairs
+  const int lane = threadIdx.x;
+  const int Nout = P.Nout, M = P.M, lddy = P.lddy;
+  const int per = (M + P.nsplit - 1) / P.nsplit;
   const int m0 = split * per, m1 = min(M, m0 + per);
-  gcf2 X = (gcf2)(P.X + 64 * wave + 2 * li);
-  gcf dY = (gcf)P.dY + min(li, Nout - 1);
-  const int lddy = P.lddy;
-  const bool qok = li < Nout;
-
-  f32x16 acc0, acc1;
+  gcf X = (gcf)P.X + 64 * wave + lane;
+  // dY quads of 16 rows: lane l <-> (row l / 4 of the 16, output 4 g + l % 4)
+  const int dq = lane & 3, dr = lane >> 2;
+  gcf dY = (gcf)P.dY;
+  v4f acc[NG];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-  // row of this lane in pair u of a group starting at row g: g + 2 u + lh; rows past the split read the split's last row
-  // (a valid address) with dY = 0
-  auto load = [&](int g, v2f (&x)[SW2_U], float (&d)[SW2_U]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int u = 0; u < SW2_U; ++u) {
-      const int mc = min(g + 2 * u + lh, m1 - 1);
-      x[u] = X[(long long)mc * 128];                // (v2f units: row pitch 256 floats)
-      d[u] = dY[(long long)mc * lddy];
-    }
-  };
-  // (the dY = 0 of a row past the split / a lane past Nout is applied where the value is USED: a select next to the load
+  for (int g = 0; g < NG; ++g) acc[g] = v4f{0.f, 0.f, 0.f, 0.f};
+  // rows past the split read its last row (a valid address); their dY is zeroed where it is USED (a select next to the load
   // would make every request wait for its own answer)
-  auto use = [&](int g, const v2f (&x)[SW2_U], const float (&d)[SW2_U]) __attribute__((always_inline)) {
+  auto load = [&](int r0, float (&x)[SW2_R], float (&d)[NG][SW2_R / 16]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int u = 0; u < SW2_U; ++u) {
-      const float dv = (qok && g + 2 * u + lh < m1) ? d[u] : 0.f;
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(dv, x[u].x, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(dv, x[u].y, acc1, 0, 0, 0);
+    for (int u = 0; u < SW2_R; ++u) x[u] = X[(long long)min(r0 + u, m1 - 1) * 256];
+#pragma unroll
+    for (int t = 0; t < SW2_R / 16; ++t)
+#pragma unroll
+      for (int g = 0; g < NG; ++g) d[g][t] = dY[(long long)min(r0 + 16 * t + dr, m1 - 1) * lddy + min(4 * g + dq, Nout - 1)];
+  };
+  auto use = [&](int r0, const float (&x)[SW2_R], const float (&d)[NG][SW2_R / 16]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < SW2_R / 16; ++t) {
+      float dv[NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) dv[g] = (r0 + 16 * t + dr < m1 && 4 * g + dq < Nout) ? d[g][t] : 0.f;
+      sw2_for<0, 16>([&](auto rc) __attribute__((always_inline)) {   // (ABID is an immediate)
+        constexpr int r = decltype(rc)::value;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(dv[g], x[16 * t + r], acc[g], 4, r, 0);
+      });
     }
   };
   if (m0 < m1) {
-    v2f xa[SW2_U], xb[SW2_U];
-    float da[SW2_U], db[SW2_U];
+    float xa[SW2_R], xb[SW2_R], da[NG][SW2_R / 16], db[NG][SW2_R / 16];
     // (the empty asm statements pin the order requests-then-uses: the scheduler otherwise sinks every load next to its use)
     load(m0, xa, da);
     asm volatile("" ::: "memory");
 #pragma unroll 1
-    for (int g = m0; g < m1; g += 4 * SW2_U) {
-      load(g + 2 * SW2_U, xb, db);   // (past the end: clamped rows, used with dY = 0 or not at all)
+    for (int g = m0; g < m1; g += 2 * SW2_R) {
+      load(g + SW2_R, xb, db);   // (past the end: clamped rows, used with dY = 0 or not at all)
       asm volatile("" ::: "memory");
       use(g, xa, da);
       asm volatile("" ::: "memory");
-      if (g + 2 * SW2_U < m1) {
-        load(g + 4 * SW2_U, xa, da);
+      if (g + SW2_R < m1) {
+        load(g + 2 * SW2_R, xa, da);
         asm volatile("" ::: "memory");
-        use(g + 2 * SW2_U, xb, db);
+        use(g + SW2_R, xb, db);
         asm volatile("" ::: "memory");
       }
     }
   }
-  // D[q][column]: lane (li, lh) holds column 64 w + 2 li + t of tile t, rows q = 8 (r / 4) + 4 lh + r % 4.  A split without
-  // rows writes zeros (the slab sum runs over every slab).
+  // register i of lane l = dW[4 g + i][64 w + l].  A split without rows writes zeros (the slab sum runs over every slab).
+  gf dst = (gf)(P.dW + (long long)split * P.split_stride);
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (4 * g + i < Nout) dst[(long long)(4 * g + i) * P.sq + (long long)(64 * wave + lane) * P.sk] = acc[g][i];
+}
+
+// Both sides narrow (K <= 32 input columns, Nout <= 32 outputs: a 25-quantile head's rows over 17 action columns): one wave per
+// slab, a row pair = one v_mfma_f32_32x32x2_f32 (A: lane (q, parity) = dY[m + parity][q], B: lane (k, parity) = X[m + parity][k]),
+// 32 pairs per request round.  (On the tile kernel these were a 0.16 ms launch for 42 MB at config 4: one memory round trip per
+// 16 rows; one column per thread in k_skinny_wgrad: 0.18 ms.)
+constexpr int SW2_TP = 32;   // row pairs per request round
+__device__ __forceinline__ void stream_wgrad_tiny(const SkinnyWgradProblem &P, int split) {
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  typedef const __attribute__((address_space(1))) float *gcf;
+  typedef __attribute__((address_space(1))) float *gf;
+  const int lane = threadIdx.x, li = lane & 31, lh = lane >> 5;
+  const int Nout = P.Nout, K = P.K, M = P.M;
+  const int per = (((M + P.nsplit - 1) / P.nsplit) + 1) & ~1;   // even: row pairs
+  const int m0 = split * per, m1 = min(M, m0 + per);
+  gcf X = (gcf)P.X + min(li, K - 1), dY = (gcf)P.dY + min(li, Nout - 1);
+  const int ldx = P.ldx, lddy = P.lddy;
+  const bool qok = li < Nout, kok = li < K;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  auto load = [&](int g, float (&x)[SW2_TP], float (&d)[SW2_TP]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < SW2_TP; ++u) {
+      const int mc = min(g + 2 * u + lh, m1 - 1);
+      x[u] = X[(long long)mc * ldx];
+      d[u] = dY[(long long)mc * lddy];
+    }
+  };
+  auto use = [&](int g, const float (&x)[SW2_TP], const float (&d)[SW2_TP]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < SW2_TP; ++u) {
+      const bool in = g + 2 * u + lh < m1;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32((qok && in) ? d[u] : 0.f, (kok && in) ? x[u] : 0.f, acc, 0, 0, 0);
+    }
+  };
+  if (m0 < m1) {
+    float xa[SW2_TP], xb[SW2_TP], da[SW2_TP], db[SW2_TP];
+    load(m0, xa, da);
+    asm volatile("" ::: "memory");
+#pragma unroll 1
+    for (int g = m0; g < m1; g += 4 * SW2_TP) {
+      load(g + 2 * SW2_TP, xb, db);
+      asm volatile("" ::: "memory");
+      use(g, xa, da);
+      asm volatile("" ::: "memory");
+      if (g + 2 * SW2_TP < m1) {
+        load(g + 4 * SW2_TP, xa, da);
+        asm volatile("" ::: "memory");
+        use(g + 2 * SW2_TP, xb, db);
+        asm volatile("" ::: "memory");
+      }
+    }
+  }
+  // D[q][k]: lane (k = li, lh), register r = output q = 8 (r / 4) + 4 lh + r % 4
   gf dst = (gf)(P.dW + (long long)split * P.split_stride);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int q = 8 * (r >> 2) + 4 * lh + (r & 3);
-    if (q < Nout) {
-      const long long at = (long long)q * P.sq + (long long)(64 * wave + 2 * li) * P.sk;
-      dst[at] = acc0[r];
-      dst[at + P.sk] = acc1[r];
-    }
+    if (q < Nout && kok) dst[(long long)q * P.sq + (long long)li * P.sk] = acc[r];
   }
+}
+
+__global__ __launch_bounds__(64) void k_stream_wgrad(const SkinnyWgradProblem *__restrict__ probs, int nprob) {
+  const int bid = blockIdx.x;
+  const int pi = find_problem<SkinnyWgradProblem, &SkinnyWgradProblem::block_start>(probs, nprob, bid, threadIdx.x & 63);
+  const SkinnyWgradProblem &P = probs[pi];
+  if (P.K <= 32) { stream_wgrad_tiny(P, bid - P.block_start); return; }   // (workgroup-uniform)
+  const int split = (bid - P.block_start) >> 2, wave = (bid - P.block_start) & 3;   // a workgroup is ONE wave: 64 columns of one slab
+  const int ng = (P.Nout + 3) >> 2;   // workgroup-uniform: one of four loop bodies
+  if (ng <= 1) stream_wgrad_body<1>(P, split, wave);
+  else if (ng <= 3) stream_wgrad_body<3>(P, split, wave);
+  else if (ng <= 5) stream_wgrad_body<5>(P, split, wave);
+  else stream_wgrad_body<8>(P, split, wave);
 }
 
 int stream_wgrad_finalize(SkinnyWgradProblem *p, int n) {
   int total = 0;
   for (int i = 0; i < n; ++i) {
-    p[i].col_blocks = 4;
+    p[i].col_blocks = p[i].K <= 32 ? 1 : 4;
     p[i].block_start = total;
-    total += 4 * p[i].nsplit;
+    total += p[i].col_blocks * p[i].nsplit;
   }
   return total;
 }
 
 bool stream_wgrad_takes(const SkinnyWgradProblem &p) {
-  return p.dY && p.X && p.K == 256 && p.ldx == 256 && p.Nout >= 1 && p.Nout <= 32 && p.M >= 1 && p.nsplit >= 1 &&
-         (reinterpret_cast<uintptr_t>(p.X) & 7) == 0;
+  if (!p.dY || !p.X || p.Nout < 1 || p.Nout > 32 || p.M < 1 || p.nsplit < 1) return false;
+  return (p.K == 256 && p.ldx == 256) || (p.K >= 1 && p.K <= 32);   // 256-wide X, or narrow both ways
 }
 
 hipError_t stream_wgrad_launch(const SkinnyWgradProblem *dev, int n, int total_blocks, hipStream_t s) {
