@@ -191,6 +191,8 @@ def kernel_label(name):
                " form, fp32 v_mfma_f32_32x32x2_f32)"
     if name.startswith("wgstat"):
         return "k_wgrad_stat (output-stationary weight-gradient blocks, fp32 v_mfma_f32_32x32x2_f32)"
+    if name.startswith("rowdot"):
+        return "k_rowdot (narrow-output dgrads, fp32 v_mfma_f32_16x16x4_f32)"
     if name.startswith("rowd"):
         return "k_rowdgrad (row-block dgrad, K-strided weights, fp32 v_mfma_f32_16x16x4_f32)"
     if name.startswith("rows"):
@@ -204,6 +206,8 @@ def rocprof_tag(name):
         return "k_chain"
     if name.startswith("wgstat"):
         return "k_wgrad_stat"
+    if name.startswith("rowdot<"):
+        return "k_rowdot"
     if name.startswith("rowd<"):
         return "k_rowdgrad"
     if name.startswith("wstatg<"):       # "wstatg<fuse,plain,ns>:stage" -> k_wstat_grad<true, false, 1>

@@ -99,10 +99,15 @@ enum StageKind { ST_GEMM, ST_SKINNY_WGRAD, ST_FUNC, ST_HEAD_DGRAD, ST_CHAIN, ST_
 struct RowsLaunch {
   bool ws = false;
   bool rd = false;      // single-network dgrad on 64-row blocks (rowdgrad.h)
+  bool dot = false;     // narrow-output dgrads of several networks (rowdgrad.h, k_rowdot)
   RowGemmArgs rg;
   WsArgs wa;
   RowDgradArgs rda;
-  hipError_t launch(hipStream_t s) const { return rd ? rowdgrad_launch(rda, s) : (ws ? wstat_launch(wa, s) : rowgemm_launch(rg, s)); }
+  RowDotArgs rdot;
+  hipError_t launch(hipStream_t s) const {
+    if (dot) return rowdot_launch(rdot, s);
+    return rd ? rowdgrad_launch(rda, s) : (ws ? wstat_launch(wa, s) : rowgemm_launch(rg, s));
+  }
 };
 
 struct GemmSub {
@@ -211,6 +216,7 @@ struct fdql_agent {
                                     // 64-row tile per CU (a weight-stationary workgroup with 2 + 2 32-row tiles still beats the tile
                                     // kernels: config 4 at 128 windows per GPU)
   int rowdgrad_min_blocks = 128;    // 64-row blocks a single-network dgrad needs for the row-block dgrad kernel (FDQL_ROWDGRAD_MIN_BLOCKS)
+  int rowdot_min_rows = 4096;       // rows from which a stage of narrow-output dgrads runs on k_rowdot
   int rowdgrad_max_blocks = 256;    // ... and may have: one round of workgroups (config 4 at B = 1024, 784 blocks = 3.06 rounds: the tile
                                     // kernel's 3136 tiles are the better fit there: 0.138 against 0.153 ms for d enc)
   int wgrad_stat_factor = 4;        // x rows_min_tiles 32-row tiles for the output-stationary weight-gradient launch (4 per workgroup)
@@ -939,6 +945,15 @@ int upload_tables(fdql_agent *a) {
           } else {
             for (size_t j : idx) taken[j] = 2;   // looked at, stays on the tile kernels
           }
+        }
+      }
+      // a whole stage of narrow-output dgrads (d pi: one problem per frozen critic) as one streaming launch
+      if (!s.gemm.empty() && std::find(taken.begin(), taken.end(), (char)1) == taken.end() && s.gemm[0].M >= a->rowdot_min_rows) {
+        RowsLaunch rl;
+        if (rowdot_from_problems(s.gemm.data(), (int)s.gemm.size(), rl.rdot)) {
+          rl.dot = true;
+          s.rows.push_back(rl);
+          std::fill(taken.begin(), taken.end(), 1);
         }
       }
       // single-network dgrads (256-wide K-strided segments, gate / column sums) with enough 64-row blocks to fill most of the chip
@@ -2097,7 +2112,11 @@ int32_t fdql_agent_profile_update(fdql_agent_t *a, const fdql_batch_t *batch, co
       snprintf(out[cnt].name, sizeof(out[cnt].name), "gemm%s:%s", shape_names[parts[i].shape], st.name.c_str());
     } else if (parts[i].shape < -1) {
       const RowsLaunch &rl = st.rows[-2 - parts[i].shape];
-      if (rl.rd) {
+      if (rl.dot) {
+        flops = rowdot_flops(rl.rdot);
+        bytes = 4.0 * rl.rdot.M * rl.rdot.nprob * (double)(RD_K + rl.rdot.Q + rl.rdot.A);
+        snprintf(out[cnt].name, sizeof(out[cnt].name), "rowdot<%d>:%s", rl.rdot.A, st.name.c_str());
+      } else if (rl.rd) {
         flops = rowdgrad_flops(rl.rda);
         bytes = 4.0 * rl.rda.M * (double)RD_N * (rl.rda.nseg + 1 + (rl.rda.gate ? 1 : 0));
         snprintf(out[cnt].name, sizeof(out[cnt].name), "rowd<%d,%d>:%s", rl.rda.nseg, rl.rda.gate, st.name.c_str());

@@ -22,6 +22,23 @@ struct RowDgradArgs {
   float *colsum;                     // [M / 64, 256] or null
 };
 
+// Narrow-output dgrads of several networks in one launch (k_rowdot): out_p[M, A <= 16] = X_p[M, 256] W_p + D_p[M, Q <= 32] V_p with
+// K-strided W_p (element (k, a) at W_p[k*ldw + a]) and V_p - the gradient of the policy's action through each frozen critic
+// (d pi = dpre_0 W_0[:, action columns] + dz W_head[:, action columns]).  HBM-bound: X is read once, 16 rows per wave and tile.
+constexpr int RDOT_MAX_PROB = 8;
+struct RowDotArgs {
+  int M, A, Q, nprob, wgs_per_prob;
+  const float *X[RDOT_MAX_PROB];     // [M, 256], 16-byte aligned
+  const float *W[RDOT_MAX_PROB];     // K-strided [256, ldw]
+  const float *D[RDOT_MAX_PROB];     // [M, lddy] narrow segment (Q columns) or null
+  const float *V[RDOT_MAX_PROB];     // K-strided [Q, ldv]
+  float *out[RDOT_MAX_PROB];         // [M, ldo]
+  int ldw, lddy, ldv, ldo;
+};
+bool rowdot_from_problems(const GemmProblem *probs, int nprob, RowDotArgs &args);
+hipError_t rowdot_launch(const RowDotArgs &args, hipStream_t stream);
+inline double rowdot_flops(const RowDotArgs &a) { return 2.0 * a.M * (double)a.A * (RD_K + a.Q) * a.nprob; }
+
 // Does this problem have the kernel's form?  Fills args when it does.  FDQL_ROWDGRAD=0: never.
 bool rowdgrad_from_problem(const GemmProblem &p, RowDgradArgs &args);
 hipError_t rowdgrad_launch(const RowDgradArgs &args, hipStream_t stream);

@@ -145,7 +145,119 @@ __global__ __launch_bounds__(256, 1) void k_rowdgrad(const RowDgradArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_rowdot (rowdgrad.h): wave = 16-row tiles of one problem, walked with a stride; v_mfma_f32_16x16x4_f32 with the rows as the
+// A operand (lane (row, kq): 16 bytes X[row][16 g + 4 kq ..]: sixteen requests = the tile's 16 KB in flight, two tiles deep)
+// and the network's few weight columns as the B operand, held in registers for the wave's life (lane (a, kq):
+// W[16 g + 4 kq + c][a]).  Four accumulators (one per c) keep the MFMA chains independent.
+__global__ __launch_bounds__(256) void k_rowdot(const RowDotArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  const int prob = blockIdx.x / a.wgs_per_prob, wg = blockIdx.x - prob * a.wgs_per_prob;
+  const int M = a.M, A = a.A, Q = a.Q;
+  gcf X = (gcf)a.X[prob], W = (gcf)a.W[prob], D = (gcf)a.D[prob], V = (gcf)a.V[prob];
+  const bool aok = j < A;
+  float wm[16][4];   // main weights of this lane: [g][c] = W[16 g + 4 kq + c][a = j]
+#pragma unroll
+  for (int g = 0; g < 16; ++g)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) wm[g][c] = aok ? W[(long long)(16 * g + 4 * kq + c) * a.ldw + j] : 0.f;
+  float wv[8];       // narrow segment: step s multiplies D[row][4 s + kq] by V[4 s + kq][a]
+#pragma unroll
+  for (int s = 0; s < 8; ++s) wv[s] = (D && aok && 4 * s + kq < Q) ? V[(long long)(4 * s + kq) * a.ldv + j] : 0.f;
+  const int nsteps = D ? (Q + 3) >> 2 : 0;
+  const int ntiles = (M + 15) >> 4, stride = a.wgs_per_prob * 4;
+  auto load = [&](int t, v4f (&x)[16], float (&d)[8]) __attribute__((always_inline)) {
+    const int row = min(16 * t + j, M - 1);   // (rows past the batch repeat its last row; never stored)
+    gcf xr = X + (long long)row * RD_K + 4 * kq;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) x[g] = *(gcf4)(xr + 16 * g);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) d[s] = (s < nsteps) ? D[(long long)row * a.lddy + min(4 * s + kq, Q - 1)] : 0.f;
+  };
+  auto tile = [&](int t, const v4f (&x)[16], const float (&d)[8]) __attribute__((always_inline)) {
+    v4f acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 16; ++g)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[g][c], wm[g][c], acc[c], 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      if (s < nsteps) acc[s & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(4 * s + kq < Q ? d[s] : 0.f, wv[s], acc[s & 3], 0, 0, 0);
+    const v4f sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    // D[row][a]: lane (a = j, kq) holds rows 4 kq + r
+    if (aok) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * t + 4 * kq + r;
+        if (row < M) ((__attribute__((address_space(1))) float *)a.out[prob])[(long long)row * a.ldo + j] = sum[r];
+      }
+    }
+  };
+  int t = wg * 4 + wave;
+  if (t >= ntiles) return;
+  v4f xa[16], xb[16];
+  float da[8], db[8];
+  load(t, xa, da);
+  asm volatile("" ::: "memory");
+#pragma unroll 1
+  for (; t < ntiles; t += 2 * stride) {
+    const bool more = t + stride < ntiles;
+    load(more ? t + stride : t, xb, db);
+    asm volatile("" ::: "memory");
+    tile(t, xa, da);
+    asm volatile("" ::: "memory");
+    if (more) {
+      load(t + 2 * stride < ntiles ? t + 2 * stride : t, xa, da);
+      asm volatile("" ::: "memory");
+      tile(t + stride, xb, db);
+      asm volatile("" ::: "memory");
+    }
+  }
+}
+
 }  // namespace
+
+bool rowdot_from_problems(const GemmProblem *probs, int nprob, RowDotArgs &args) {
+  const char *env = getenv("FDQL_ROWDGRAD");
+  if (env && env[0] == '0') return false;
+  if (nprob < 1 || nprob > RDOT_MAX_PROB) return false;
+  memset(&args, 0, sizeof(args));
+  auto aligned = [](const void *q, uintptr_t n) { return (reinterpret_cast<uintptr_t>(q) & (n - 1)) == 0; };
+  const GemmProblem &p0 = probs[0];
+  if (p0.N < 1 || p0.N > 16 || p0.M < 16) return false;
+  args.M = p0.M; args.A = p0.N; args.nprob = nprob; args.ldo = p0.ldc;
+  for (int i = 0; i < nprob; ++i) {
+    const GemmProblem &p = probs[i];
+    if (p.M != p0.M || p.N != p0.N || p.ldc != p0.ldc || p.nseg < 1 || p.nseg > 2 || p.ksplit != 1 || p.bias || p.colsum || p.C2 || p.hf_w ||
+        p.fz_h || p.epi != EPI_NONE || p.nseg != p0.nseg)
+      return false;
+    const GemmSeg *mainseg = nullptr, *nar = nullptr;
+    for (int s = 0; s < p.nseg; ++s) {
+      const GemmSeg &sg = p.seg[s];
+      if (!sg.a_kc || sg.b_kc) return false;
+      if (sg.K == RD_K && !mainseg) mainseg = &sg;
+      else if (sg.K >= 1 && sg.K <= 32 && !nar) nar = &sg;
+      else return false;
+    }
+    if (!mainseg || mainseg->lda != RD_K || !aligned(mainseg->A, 16)) return false;
+    if (i == 0) { args.ldw = mainseg->ldb; args.Q = nar ? nar->K : 0; args.lddy = nar ? nar->lda : 0; args.ldv = nar ? nar->ldb : 0; }
+    if (mainseg->ldb != args.ldw || (nar && (nar->K != args.Q || nar->lda != args.lddy || nar->ldb != args.ldv))) return false;
+    args.X[i] = mainseg->A; args.W[i] = mainseg->B; args.D[i] = nar ? nar->A : nullptr; args.V[i] = nar ? nar->B : nullptr; args.out[i] = p.C;
+  }
+  const int ntiles = (args.M + 15) / 16;
+  int wgs = (ntiles + 4 * 4 - 1) / (4 * 4);   // ~4 tiles per wave (measured at config 2: 12 / 4 / 2 tiles per wave = 0.038 / 0.022 / 0.026 ms; tile kernel 0.030)
+  if (wgs < 1) wgs = 1;
+  args.wgs_per_prob = wgs;
+  return true;
+}
+
+hipError_t rowdot_launch(const RowDotArgs &a, hipStream_t s) {
+  hipLaunchKernelGGL(k_rowdot, dim3(a.nprob * a.wgs_per_prob), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
 
 bool rowdgrad_from_problem(const GemmProblem &p, RowDgradArgs &args) {
   const char *env = getenv("FDQL_ROWDGRAD");   // "0": never (tuning / test hook; read per plan build)

@@ -17,7 +17,7 @@ MUST_BE_CLEAN = {
     "wstat.hip": ["k_wstat"],          # forward forms, gated / fused / plain dgrad forms
     "wgrad.hip": ["k_wgrad_stat"],     # with and without riders
     "chain.hip": ["k_chain"],
-    "rowdgrad.hip": ["k_rowdgrad"],
+    "rowdgrad.hip": ["k_rowdgrad", "k_rowdot"],
     "gemm.hip": ["k_gemm_groupedILi5ELi16ELi1EE", "k_gemm_groupedILi1ELi16ELi1EE", "k_gemm_groupedILi2ELi16ELi1EE"],   # 64x64, 128x32, 32x128
     "kernels.hip": ["6k_prepE", "12k_policy_fwdE", "12k_policy_bwdE", "6k_lossE", "13k_loss_finishE", "13k_head_finishE",
                     "18k_sum_parts_colsumE", "11k_summariesE", "14k_reduce_slabsE", "17k_reduce_partialsE", "13k_adam_polyakE",
