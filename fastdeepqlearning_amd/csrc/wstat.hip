@@ -898,6 +898,8 @@ bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
   args.nminor = nminor; args.dual = dual; args.grad = grad ? (plain ? 2 : 1) : 0; args.fz = fz; args.fz_ldw = p0.fz_ldw;
   args.hf_q = p0.hf_w ? p0.hf_q : 0; args.hf_ldw = p0.hf_ldw;
   int cost[WS_MAX_INST], cost_sum = 0;
+  int dual_cost = 12;
+  if (const char *dc = getenv("FDQL_WSTAT_DUAL_COST")) dual_cost = atoi(dc) > 0 ? atoi(dc) : 12;   // tuning hook
   for (int i = 0; i < nprob; ++i) {
     const GemmProblem &p = probs[i];
     const bool pd = is_dual(p);
@@ -934,7 +936,7 @@ bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
     I.ref = p.ref; I.colsum = p.colsum;
     I.fz_h = p.fz_h; I.fz_w = p.fz_w; I.fz_out = p.fz_out; I.fz_colsum = p.fz_colsum; I.fz_keep = p.fz_discard ? 0 : 1;
     args.inst[i] = I;
-    cost[i] = pd ? 12 : 11;   // a two-output instance finishes twice as many register quads per tile
+    cost[i] = pd ? dual_cost : 11;   // a two-output instance finishes twice as many register quads per tile
     cost_sum += cost[i];
   }
   {
@@ -981,15 +983,25 @@ bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
   }
   const int ncu = ncu_of[dev];
   if (nprob > ncu) return false;
-  args.wg_first[0] = 0;
-  for (int i = 0; i < nprob; ++i) {
-    int per = (int)((long long)ncu * cost[i] / cost_sum);
-    if (per < 1) per = 1;
-    if (per > args.blocks_per_inst) per = args.blocks_per_inst;
-    // the dgrad form's column sums: one partial row per workgroup in buffers sized for one per 64 rows
-    if (grad && !plain && per > (p0.M + 63) / 64) per = (p0.M + 63) / 64;
-    args.wg_first[i + 1] = args.wg_first[i] + per;
+  // Workgroups per instance: one per CU in all, dealt so that the slowest instance finishes as early as possible (tiles come in
+  // whole numbers: 392 tiles over 26 workgroups are 16 each, over 27 they are 15).
+  int per[WS_MAX_INST], cap = args.blocks_per_inst;
+  // the dgrad form's column sums: one partial row per workgroup in buffers sized for one per 64 rows
+  if (grad && !plain && cap > (p0.M + 63) / 64) cap = (p0.M + 63) / 64;
+  const int tiles = args.blocks_per_inst;
+  for (int i = 0; i < nprob; ++i) per[i] = 1;
+  auto time_of = [&](int i, int w) { return (long long)cost[i] * ((tiles + w - 1) / w); };
+  for (int left = ncu - nprob; left > 0; --left) {
+    int worst = -1;
+    for (int i = 0; i < nprob; ++i)
+      if (per[i] < cap && (worst < 0 || time_of(i, per[i]) > time_of(worst, per[worst]))) worst = i;
+    if (worst < 0) break;
+    ++per[worst];
   }
+  for (int i = 0; i < nprob; ++i)   // a workgroup that does not lower its instance's tile count only repeats the prologue
+    while (per[i] > 1 && (tiles + per[i] - 2) / (per[i] - 1) == (tiles + per[i] - 1) / per[i]) --per[i];
+  args.wg_first[0] = 0;
+  for (int i = 0; i < nprob; ++i) args.wg_first[i + 1] = args.wg_first[i] + per[i];
   return true;
 }
 
