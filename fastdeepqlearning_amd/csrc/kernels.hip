@@ -1263,9 +1263,13 @@ __global__ __launch_bounds__(64) void k_head_finish(HeadFinishArgs a) {
   }
   if (nok) bq = bsel[q];
   hf_v4f acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // even / odd 16-k blocks: two independent MFMA chains
-  const bool vec = (L & 15) == 0 && ((G.lds | G.ldw) & 3) == 0 && ((reinterpret_cast<uintptr_t>(G.s) | reinterpret_cast<uintptr_t>(wrow)) & 15) == 0;
-  if (vec) {   // whole 16-k blocks, 16-byte aligned rows: one dwordx4 per operand and block, sixteen blocks in flight
-    const hf_v4f *sp = reinterpret_cast<const hf_v4f *>(srow) + kq, *wp = reinterpret_cast<const hf_v4f *>(wrow) + kq;
+  // (the weight rows need no 16-byte alignment - a head over cat(h1, h0, s, a) has a row pitch of 774 floats, so every odd row
+  // starts 8 bytes off: gfx950 serves dwordx4 loads from 4-byte aligned addresses; requiring it sent half the lanes down the
+  // element-wise path below, 16 dependent round trips, 27 us for this kernel)
+  const bool vec = (L & 15) == 0 && (G.lds & 3) == 0 && (reinterpret_cast<uintptr_t>(G.s) & 15) == 0;   // wave-uniform
+  if (vec) {   // whole 16-k blocks: one dwordx4 per operand and block, sixteen blocks in flight
+    typedef const __attribute__((address_space(1))) hf_v4f *gq;
+    gq sp = (gq)(srow + 4 * kq), wp = (gq)(wrow + 4 * kq);
     for (int k0 = 0; k0 < L; k0 += 256) {
       hf_v4f av[16], bv[16];
 #pragma unroll
