@@ -399,16 +399,26 @@ __global__ __launch_bounds__(256) void k_head_dgrad(const HeadDgradProblem *__re
   const float *h = P.h + (long long)r0 * P.N + n;
   float *out = P.dpre + (long long)r0 * P.N + n;
   float csum = 0.f;
-#pragma unroll 8
-  for (int r = 0; r < nr; ++r) {
-    float g = 0.f;
+  // 32 rows per round, their activations requested together (a loop of single rows is a memory round trip per row: at 256
+  // rows - temporal_len 2 - the kernel was 64 dependent round trips long)
+  for (int rb0 = 0; rb0 < nr; rb0 += 32) {
+    float hv[32];
 #pragma unroll
-    for (int q = 0; q < HEAD_DGRAD_MAXQ; ++q)
-      if (q < Q) g = fmaf(dys[r * Q + q], w[q], g);
-    const float a = h[(long long)r * P.N];
-    const float x = a > 0.f ? g : 0.01f * g;
-    out[(long long)r * P.N] = x;
-    csum += x;
+    for (int u = 0; u < 32; ++u) hv[u] = h[(long long)min(rb0 + u, nr - 1) * P.N];
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+      const int r = rb0 + u;
+      if (r < nr) {
+        float g = 0.f;
+#pragma unroll
+        for (int q = 0; q < HEAD_DGRAD_MAXQ; ++q)
+          if (q < Q) g = fmaf(dys[r * Q + q], w[q], g);
+        const float x = hv[u] > 0.f ? g : 0.01f * g;
+        out[(long long)r * P.N] = x;
+        csum += x;
+      }
+    }
   }
   if (P.colsum) P.colsum[(long long)rb * P.N + n] = csum;
 }
