@@ -621,7 +621,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
     ws_rd128<(2 * j) * 1024>(nw0[j & 1], nw_addr);
     ws_rd128<(2 * j + 1) * 1024>(nw1[j & 1], nw_addr);
   };
-  v4f rq[3];                        // gate references of the quads in flight (requested two steps ahead: an L2 hit takes longer than one)
+  v4f rq[4];                        // gate references of the quads in flight (requested three steps ahead: an L2 hit takes longer than one or two)
 
   // FUSE: one staged row piece: h -> LeakyReLU'(h) * (dY . Wh), k_head_dgrad's order and rounding (fma chain over q)
   auto fuse_row = [&](v4f h, float dz0, float dz1, float live) __attribute__((always_inline)) {
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
       if constexpr (PLAIN) {
         x[c] = v;
       } else {
-        const float y = rq[kq % 3][c] > 0.f ? v : 0.01f * v;
+        const float y = rq[kq % 4][c] > 0.f ? v : 0.01f * v;
         x[c] = y;
       }
     }
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
     gcf rprev = PLAIN ? nullptr : (gcf)ws_uni(ref + (long long)pblk * WS_BM * LD + n0);
     v4f af[2];
     ws_rd128<IOFF>(af[0], abase);
-    if constexpr (HP) { ref_load(rq[0], rprev, 0); ref_load(rq[1], rprev, 1); }
+    if constexpr (HP) { ref_load(rq[0], rprev, 0); ref_load(rq[1], rprev, 1); ref_load(rq[2], rprev, 2); }
     if constexpr (HP) cs_read(std::integral_constant<int, 0>{});
     sfor<0, NSTEP>([&](auto sc) __attribute__((always_inline)) {
       constexpr int s = decltype(sc)::value;
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
         if constexpr (s == 0) ws_anchor(pv[0], pv[1]);
         if constexpr (s < 8) {
           if constexpr (!PLAIN) asm volatile("" : "+v"(csq[s & 1]));
-          if constexpr (s + 2 < 8) ref_load(rq[(s + 2) % 3], rprev, s + 2);   // two steps ahead, ahead of this quad's store
+          if constexpr (s + 3 < 8) ref_load(rq[(s + 3) % 4], rprev, s + 3);   // three steps ahead (four: no further gain), ahead of this quad's store
           if constexpr (s + 1 < 8) cs_read(std::integral_constant<int, s + 1>{});
           quad(pv, cprev, s);
         }
@@ -811,7 +811,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
     gcf rprev = PLAIN ? nullptr : (gcf)ws_uni(ref + (long long)prv * WS_BM * LD + n0);
     sfor<0, 8>([&](auto kc) __attribute__((always_inline)) {
       constexpr int kq = decltype(kc)::value;
-      ref_load(rq[kq % 3], rprev, kq);
+      ref_load(rq[kq % 4], rprev, kq);
       cs_read(kc);
       ws_lgkm_wait<0>();
       if constexpr (!PLAIN) asm volatile("" : "+v"(csq[kq & 1]));
