@@ -1857,6 +1857,7 @@ int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {
     }
   }
   FDQL_REQUIRE(!c.discrete || c.act_dim <= 32, "discrete actor: at most 32 actions");
+  FDQL_REQUIRE(c.act_dim <= 64, "at most 64 action dimensions (the policy kernels give a row's actions the lanes of one wave)");
   FDQL_REQUIRE(c.n_critics > 0 && c.n_quantiles > 0 && c.n_critics * c.n_quantiles <= 256, "need 0 < C*Q <= 256");
   FDQL_REQUIRE(2 * c.n_critics + 2 <= GEMM_MAX_SEG, "too many critics for one d(state) GEMM");
   FDQL_REQUIRE(c.T >= 2 && c.B >= 1, "need T >= 2, B >= 1");

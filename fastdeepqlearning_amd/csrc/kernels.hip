@@ -539,17 +539,23 @@ __device__ void tick_adam(DevState *st, double lr, double b1, double b2) {
 // ======================================================================================
 // tanh-Gaussian policy head: sample, log-prob (gaussian_mlp.py:15-39) and its backward
 // ======================================================================================
+// One thread per (row, action): the per-element work is four double-precision transcendentals (~600 instructions) - with a
+// thread per ROW (six elements in sequence, 392 waves for 12 544 rows x 2 passes) the kernel was one long dependent
+// instruction stream per SIMD: 12 us.  AG = lanes per row (power of two >= A); the row's log-prob is summed by the row's first
+// lane in the order j = 0, 1, ... (the order of the sequential loop this replaces).
+template <int AG>
 __global__ void k_policy_fwd(PolicyFwdArgs a0, PolicyFwdArgs a1, int nprob, int M, int A, const DevState *st,
                              uint64_t seed) {
 #pragma clang fp contract(off)
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int p = gid / M;
-  if (p >= nprob) return;
-  const int m = gid - p * M;
+  const int rowid = gid / AG, j = gid - rowid * AG;
+  const int p = rowid / M;
+  const bool live = p < nprob && j < A;
+  const int m = rowid - p * M;
   const PolicyFwdArgs &a = p == 0 ? a0 : a1;
-  const float *lo = a.logits + (long long)m * 2 * A;
-  float logp = 0.f;
-  for (int j = 0; j < A; ++j) {
+  float lp = 0.f;
+  if (live) {
+    const float *lo = a.logits + (long long)m * 2 * A;
     const float mean = lo[j];
     const float ls = fminf(fmaxf(lo[A + j], -20.f), 2.f);
     // transcendental functions through double, rounded once to f32: the log-prob below is
@@ -561,42 +567,44 @@ __global__ void k_policy_fwd(PolicyFwdArgs a0, PolicyFwdArgs a1, int nprob, int 
     if (a.noise_out) a.noise_out[(long long)m * A + j] = eps;
     const float x = mean + eps * sd;
     const float d = x - mean;
-    float lp = -(d * d) / (2.f * (sd * sd)) - (float)log((double)sd) - 0.91893853320467274178f;
+    lp = -(d * d) / (2.f * (sd * sd)) - (float)log((double)sd) - 0.91893853320467274178f;
     const float act = (float)tanh((double)x);
     lp -= (float)log((double)((1.f - act * act) + 1e-4f));
-    logp += lp;
     a.action[(long long)m * A + j] = act;
     if (a.diff) a.diff[(long long)m * A + j] = act - a.sub[(long long)m * A + j];
   }
-  a.logp[m] = logp;
+  // sum over the row's lanes, in order (every lane of the wave takes part in the shuffles)
+  const int base = (threadIdx.x & 63) - j;
+  float logp = 0.f;
+  for (int k = 0; k < A; ++k) logp += __shfl(lp, base + k, 64);
+  if (live && j == 0) a.logp[m] = logp;
 }
 
-// d logits from d pi (through the frozen critics) and d logp = w*alpha.
+// d logits from d pi (through the frozen critics) and d logp = w*alpha.  One thread per (row, action).
 __global__ void k_policy_bwd(const float *__restrict__ logits, const float *__restrict__ noise,
                              const float *__restrict__ action, const float *__restrict__ dpi_parts, int nparts,
                              float *__restrict__ dpi_sum, const float *__restrict__ w, const DevState *st, int M, int A,
                              float *__restrict__ dlogits) {
-  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int m = (int)(gid / A), j = (int)(gid - (long long)m * A);
   if (m >= M) return;
   const float glp = w[m] * st->alpha_cur;
   const float *lo = logits + (long long)m * 2 * A;
-  for (int j = 0; j < A; ++j) {
-    const float lsr = lo[A + j];
-    const float ls = fminf(fmaxf(lsr, -20.f), 2.f);
-    const float sd = (float)exp((double)ls);
-    const float eps = noise[(long long)m * A + j];
-    const float act = action[(long long)m * A + j];
-    const float om = 1.f - act * act;
-    float g = 0.f;   // d loss / d pi_j = sum over the frozen critics' partials, fixed order
-    for (int c = 0; c < nparts; ++c) g += dpi_parts[((long long)c * M + m) * A + j];
-    dpi_sum[(long long)m * A + j] = g;
-    const float dx = g * om + glp * (2.f * act * om / (om + 1e-4f));
-    const float dsd = dx * eps - glp / sd;
-    float dls = dsd * sd;
-    if (lsr < -20.f || lsr > 2.f) dls = 0.f;
-    dlogits[(long long)m * 2 * A + j] = dx;
-    dlogits[(long long)m * 2 * A + A + j] = dls;
-  }
+  const float lsr = lo[A + j];
+  const float ls = fminf(fmaxf(lsr, -20.f), 2.f);
+  const float sd = (float)exp((double)ls);
+  const float eps = noise[(long long)m * A + j];
+  const float act = action[(long long)m * A + j];
+  const float om = 1.f - act * act;
+  float g = 0.f;   // d loss / d pi_j = sum over the frozen critics' partials, fixed order
+  for (int c = 0; c < nparts; ++c) g += dpi_parts[((long long)c * M + m) * A + j];
+  dpi_sum[(long long)m * A + j] = g;
+  const float dx = g * om + glp * (2.f * act * om / (om + 1e-4f));
+  const float dsd = dx * eps - glp / sd;
+  float dls = dsd * sd;
+  if (lsr < -20.f || lsr > 2.f) dls = 0.f;
+  dlogits[(long long)m * 2 * A + j] = dx;
+  dlogits[(long long)m * 2 * A + A + j] = dls;
 }
 
 // ======================================================================================
@@ -1052,8 +1060,14 @@ hipError_t policy_fwd_launch(const PolicyFwdArgs &a0, const PolicyFwdArgs &a1, i
   const int total = nprob * M;
   if (discrete)
     hipLaunchKernelGGL(k_policy_fwd_gumbel, dim3((total + 63) / 64), dim3(64), 0, s, a0, a1, nprob, M, A, st, seed);
+  else if (A <= 8)
+    hipLaunchKernelGGL(k_policy_fwd<8>, dim3((unsigned)(((long long)total * 8 + 255) / 256)), dim3(256), 0, s, a0, a1, nprob, M, A, st, seed);
+  else if (A <= 32)
+    hipLaunchKernelGGL(k_policy_fwd<32>, dim3((unsigned)(((long long)total * 32 + 255) / 256)), dim3(256), 0, s, a0, a1, nprob, M, A, st, seed);
+  else if (A <= 64)
+    hipLaunchKernelGGL(k_policy_fwd<64>, dim3((unsigned)(((long long)total * 64 + 255) / 256)), dim3(256), 0, s, a0, a1, nprob, M, A, st, seed);
   else
-    hipLaunchKernelGGL(k_policy_fwd, dim3((total + 255) / 256), dim3(256), 0, s, a0, a1, nprob, M, A, st, seed);
+    return hipErrorInvalidValue;   // (act_dim <= 64 is checked at fdql_agent_create)
   return hipGetLastError();
 }
 
@@ -1069,7 +1083,7 @@ hipError_t policy_bwd_launch(const float *logits, const float *noise, const floa
     hipLaunchKernelGGL(k_policy_bwd_gumbel, dim3((M + 63) / 64), dim3(64), 0, s, logits, noise, dpi_parts, nparts, dpi_sum,
                        w, st, M, A, dlogits);
   else
-    hipLaunchKernelGGL(k_policy_bwd, dim3((M + 255) / 256), dim3(256), 0, s, logits, noise, action, dpi_parts, nparts,
+    hipLaunchKernelGGL(k_policy_bwd, dim3((unsigned)(((long long)M * A + 255) / 256)), dim3(256), 0, s, logits, noise, action, dpi_parts, nparts,
                        dpi_sum, w, st, M, A, dlogits);
   return hipGetLastError();
 }
