@@ -2442,7 +2442,7 @@ int fdql_agent_stats(const fdql_agent_t *a, fdql_agent_stats_t *out) {
 }
 
 int fdql_debug_set_gemm_variant(int32_t variant) {
-  FDQL_REQUIRE(variant >= 0 && variant <= 5, "variant must be 0..5");
+  FDQL_REQUIRE(variant >= 0 && variant <= 6, "variant must be 0..6");
   gemm_set_variant(variant);
   return 0;
 }

@@ -502,6 +502,8 @@ def test_update_matches_oracle_config2(dev, T, B, hid):
      dict(obs=17, act=6, C=5, Q=2, T=9, B=100, env={"FDQL_ROWGEMM": "all", "FDQL_WGRAD_STAT_FACTOR": "1", "FDQL_STREAM_WGRAD": "2"})),
     ("config 2 dims, T=5, B=64: the row-block dgrad kernel forced at 4 blocks (FDQL_ROWDGRAD_MIN_BLOCKS=1: gated one-segment "
      "form, plain two-segment form, column sums)", dict(obs=17, act=6, C=5, Q=2, T=5, B=64, env={"FDQL_ROWDGRAD_MIN_BLOCKS": "1"})),
+    ("config 2 dims at T=4, B=64 on the tile kernel's K-chunk-16 build for every shape (FDQL_GEMM_VARIANT=6, FDQL_ROWGEMM=0: the "
+     "default takes K-chunk 32 on the 64x64 shapes)", dict(obs=17, act=6, C=5, Q=2, T=4, B=64, gemm_variant=6, env={"FDQL_ROWGEMM": "0"})),
     ("config 2 dims on the LDS-DMA GEMM, 128x128 tiles (dense shape 7: dual outputs + head fusion in that kernel)",
      dict(obs=17, act=6, C=5, Q=2, T=6, B=64, dense_shape=7)),
     ("ragged sizes on the LDS-DMA GEMM, 64x64 tiles (edge tiles and ragged chunks through its guarded path)",
@@ -518,11 +520,17 @@ def test_update_matches_oracle_other_configs(dev, name, kw, monkeypatch):
     if dense_shape is not None:
         from fastdeepqlearning_amd import _native as nat
         nat.check(nat.load().fdql_debug_set_gemm_dense_shape(dense_shape))
+    gemm_variant = kw.pop("gemm_variant", None)   # build of the tile kernel's main loop (process-wide setting too)
+    if gemm_variant is not None:
+        from fastdeepqlearning_amd import _native as nat
+        nat.check(nat.load().fdql_debug_set_gemm_variant(gemm_variant))
     try:
         _run_other_config(dev, name, kw)
     finally:
         if dense_shape is not None:
             nat.check(nat.load().fdql_debug_set_gemm_dense_shape(5))
+        if gemm_variant is not None:
+            nat.check(nat.load().fdql_debug_set_gemm_variant(1))
 
 
 def _run_other_config(dev, name, kw):
