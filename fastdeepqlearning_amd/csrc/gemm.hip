@@ -1212,11 +1212,14 @@ template <int SHAPE>
 static void launch_shape(const GemmProblem *probs_dev, int nprob, int total_blocks, int variant, hipStream_t stream) {
   const dim3 g(total_blocks), b(GEMM_THREADS);
   switch (variant) {
-    case 1:   // default: K-chunk 32 for the 64x64 shapes (half the chunks and barriers of a K loop: temporal_len 2 0.380 -> 0.353 ms,
-              // one rank's share of config 4 1.068 -> 1.058 ms, config 2 unchanged), K-chunk 16 for the others (at 32 the narrow
-              // shapes leave their register caps: 116 VGPR, SGPR spills)
-      if constexpr (SHAPE == GEMM_64x64 || SHAPE == GEMM_64x64_HF) hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 32, 1>), g, b, 0, stream, probs_dev, nprob);
-      else hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 16, 1>), g, b, 0, stream, probs_dev, nprob);
+    case 1:   // default: K-chunk 32 for a SMALL launch of the 64x64 shapes (at most two workgroups per CU: the launch is as long as
+              // one workgroup's K loop, and half the chunks and barriers shorten that - temporal_len 2 0.380 -> 0.353 ms, one rank's
+              // share of config 4 at 128 windows 1.068 -> 1.058 ms); K-chunk 16 for big launches (81 instead of 63 VGPR cost them two
+              // waves per SIMD: config 4 at B = 1024 6.09 -> 6.26 ms with 32 everywhere) and for the narrow shapes (116 VGPR at 32)
+      if constexpr (SHAPE == GEMM_64x64 || SHAPE == GEMM_64x64_HF) {
+        if (total_blocks <= 512) { hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 32, 1>), g, b, 0, stream, probs_dev, nprob); break; }
+      }
+      hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 16, 1>), g, b, 0, stream, probs_dev, nprob);
       break;
     case 6: hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 16, 1>), g, b, 0, stream, probs_dev, nprob); break;   // K-chunk 16 everywhere (round 2's default)
     case 4: hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 8, 1>), g, b, 0, stream, probs_dev, nprob); break;

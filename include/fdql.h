@@ -412,8 +412,8 @@ int fdql_test_wgrad_stat_riders(const float *G, const float *X, float *dW, int32
                                 int64_t slab_stride, const float *X2, int32_t nx2, int32_t ldx2, float *dW2, int32_t ldw2, int32_t x2_every,
                                 const float *G2, int32_t ng2, int32_t ldg2, float *dW3, int32_t ldw3, void *stream);
 
-/* Tuning hook: build of the GEMM main loop: 1 (default) = next-step fragment prefetch, K-chunk 32 for the 64x64 tile shapes and 16
- * for the others, 6 = K-chunk 16 for every shape, 0 = K-chunk 16 without the prefetch, 4 = K-chunk 8, 5 = b128 fragments; 2 and 3
+/* Tuning hook: build of the GEMM main loop: 1 (default) = next-step fragment prefetch, K-chunk 32 for small launches (<= 512 workgroups) of the
+ * 64x64 tile shapes and 16 otherwise, 6 = K-chunk 16 for every shape, 0 = K-chunk 16 without the prefetch, 4 = K-chunk 8, 5 = b128 fragments; 2 and 3
  * alias 0.  Affects speed only. */
 int fdql_debug_set_gemm_variant(int32_t variant);
 /* Tuning / test hook: tile shape of the dense problems: 5 = 64x64 (default), 3 = 64x128, 0 = 128x128.
