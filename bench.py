@@ -10,17 +10,25 @@ N = 1 (the driver's BENCH line): BASELINE config 2 - obs 17, act 6, TQC 5 critic
   exactly --steps steps; extra keys: `sustained` (>= 2 s of back-to-back steps), `roofline` (dominant kernel, HIP
   events on the launch stream), `cpu_baseline` (the CPU oracle timed on this host), `sampler_roofline`,
   `other_configs` (configs 3, 4 at B=1024 on one GPU, 5), `facade_path` (the franQ-shaped objects end to end).
-N > 1 (launched by torch.distributed.run, one process per GPU): BASELINE config 4 - obs 376, act 17,
-  TQC 5 x 25 quantiles, GLOBAL batch B = 1024 windows split B/N per GPU, a 2M-slot ring shard per rank; each rank
-  runs its backward in two phases: FDQL_PHASE_GRAD_CRITICS leaves the critics' share of the 5.27 MB gradient arena
-  final, its RCCL all-reduce starts on a side stream while FDQL_PHASE_GRAD_REST (encoder / joiner / actor gradients)
-  runs, a second all-reduce takes the rest (the row weights already carry 1/(B_global), so the sums are the
-  global-batch gradient), then FDQL_PHASE_APPLY: identical Adam on every rank.  No barrier inside the timed region.
-  `value` = GLOBAL optimiser steps/s (one step of the whole job, not multiplied by N): "scaling": "strong".
-  The line also carries `same_workload_1gpu` (rank 0 running the whole B = 1024 batch alone, measured in the same
-  process before the distributed phase) so that speed-up is computable from the line itself.
+N > 1 (one process per GPU - started by torch.distributed.run, or by this script itself when WORLD_SIZE is
+  not set: the parent touches no GPU, starts N fresh `python bench.py` children with RANK / LOCAL_RANK / WORLD_SIZE /
+  MASTER_* set, relays rank 0's JSON line and exits non-zero if any child does).  Every rank keeps a full replica and its own
+  ring shard and runs its backward in two phases: FDQL_PHASE_GRAD_CRITICS leaves the critics' share of the gradient arena
+  final, its RCCL all-reduce starts on a side stream while FDQL_PHASE_GRAD_REST (encoder / joiner / actor gradients) runs, a
+  second all-reduce takes the rest (the row weights already carry 1/(B_global), so the sums are the global-batch gradient),
+  then FDQL_PHASE_APPLY: identical Adam on every rank.  No barrier inside a timed region.  Three workloads per line:
+  * `value` - the metric's literal reading, "gradient-steps/sec (1M buffer, batch=256) at 1/2/4/8": BASELINE config 2 with
+    B = 256 windows PER GPU on a 1M-slot ring shard per rank ("scaling": "weak"; the N = 1 point IS the single-GPU line).
+    `value` = minibatch gradient steps per second of the whole job = N x optimiser iterations/s (each iteration every rank
+    differentiates its own 256-window minibatch; the reference's trainer likewise counts one step per shard,
+    deepQlearning.py:106); `optimizer_iterations_per_s` and `transitions_per_s` are listed beside it.
+  * `config2_strong` - the same config with the GLOBAL batch fixed at 256 windows, split 256/N per GPU.
+  * `config4_strong` - SURVEY 8(d)'s multi-GPU workload: BASELINE config 4 (obs 376, act 17, TQC 5 x 25, 2M-slot ring shard
+    per rank), GLOBAL batch 1024 windows split 1024/N, with `same_workload_1gpu` (rank 0 alone on the whole batch, measured
+    in the same process) so that the strong-scaling speed-up is computable from the line itself.
 
     python bench.py --gpus 1 --steps 50 --warmup 10
+    python bench.py --gpus N --steps K --warmup W            # starts its own N rank processes
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 """
@@ -30,6 +38,8 @@ import hashlib
 import json
 import os
 import re
+import socket
+import subprocess
 import sys
 import time
 
@@ -134,6 +144,22 @@ class Job:
             self.step(first + warmup + i)
         torch.cuda.synchronize(self.dev)
         return time.perf_counter() - t0
+
+    def timed_with_events(self, steps, warmup, first=0):
+        """timed() plus the longest single step of the window (HIP events between the steps; recording one costs the host
+        about a microsecond and the device nothing)."""
+        for i in range(warmup):
+            self.step(first + i)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        torch.cuda.synchronize(self.dev)
+        t0 = time.perf_counter()
+        evs[0].record()
+        for i in range(steps):
+            self.step(first + warmup + i)
+            evs[i + 1].record()
+        torch.cuda.synchronize(self.dev)
+        el = time.perf_counter() - t0
+        return el, max(evs[i].elapsed_time(evs[i + 1]) for i in range(steps)) if steps else 0.0
 
     def timed_windows(self, steps, warmup, windows=3):
         """`windows` back-to-back timed windows of `steps` steps after `warmup`: per-window steps/s (wall clock around a
@@ -494,6 +520,56 @@ def facade_path(dev, steps=100):
             "what": "DeepQLearning.train_step() on Replay.make()'s shard, config 2 dims, T=50, B=256, 200k-slot ring"}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: this (parent) process never touches a GPU; it starts N FRESH children
+    of the same command line with the rendezvous variables torch.distributed.run would set, relays rank 0's stdout (the JSON
+    line) and returns non-zero if any rank fails (the others are then stopped: they would wait in a collective forever)."""
+    backend = os.environ.get("FDQL_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()            # (counting devices does not initialise the GPU runtime)
+    if backend == "nccl" and ndev < n:
+        print(f"bench.py --gpus {n}: {ndev} GPU(s) visible; RCCL needs one per rank (FDQL_BENCH_BACKEND=gloo rehearses the N>1 "
+              f"code path with ranks sharing a card)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)   # drains rank 0's pipe
+    reader.start()
+    rc = 0
+    try:
+        while any(p.poll() is None for p in procs):
+            bad = [p for p in procs if p.poll() not in (None, 0)]
+            if bad:
+                rc = bad[0].returncode or 1
+                break
+            time.sleep(0.2)
+    finally:
+        for p in procs:                       # exact children only, never a pattern
+            if p.poll() is None and rc:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    reader.join(timeout=10)
+    rc = rc or next((p.returncode for p in procs if p.returncode), 0)
+    if chunks and chunks[0]:
+        sys.stdout.write(chunks[0])
+        sys.stdout.flush()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -508,8 +584,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))              # parent: no GPU call before or after this
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one process per GPU")
     import torch.distributed as dist
     # FDQL_BENCH_BACKEND=gloo: rehearsal of the N>1 code path on a box with fewer GPUs than ranks (ranks share devices,
     # the gradient all-reduce goes through the host); the driver uses nccl (= RCCL)
@@ -540,11 +618,16 @@ def bench_single(args, dev, T):
     w = WORKLOADS["config2"]
     B = args.batch or w["B"]
     job = Job(w, dev, B, T)
-    el = job.timed(args.steps, args.warmup)
-    ms_per_step = 1e3 * el / max(args.steps, 1)
-    # sustained: >= 2 s of back-to-back steps (DVFS: short dispatch trains clock higher than sustained ones)
-    n_sus = max(200, int(2.2 / max(el / max(args.steps, 1), 1e-6)))
+    # Steady state first ("steady state, excluding warm-up"): a fresh process rides the chip's clock ramp for its
+    # first ~15 steps (profiles/r03_step_time_trend_after_start.txt), so >= 2 s of back-to-back steps run BEFORE the W warm-up
+    # steps and the K timed ones - they are also the `sustained` figure
+    probe = job.timed(20, 5, first=200_000)
+    n_sus = max(200, int(2.2 / max(probe / 20, 1e-6)))
     el_sus = job.timed(n_sus, 0, first=100_000)
+    el, max_step_ms = job.timed_with_events(args.steps, args.warmup)
+    ms_per_step = 1e3 * el / max(args.steps, 1)
+    # two more windows of the same length right behind it: one stalled step in a short window shows up here
+    more = [job.timed_with_events(args.steps, 0, first=300_000 + 1000 * k) for k in range(2)]
     roofline, top = roofline_of(job)
     sampler = sampler_roofline(job)
     extras, t2, facade = None, None, None
@@ -580,90 +663,144 @@ def bench_single(args, dev, T):
                    "global_batch_windows": B, "temporal_len": T, "transitions_per_step": B * T, "ring": w["ring"],
                    "parallelism": "dp1"},
         "roofline": roofline, "cpu_baseline": cpu,
+        "max_step_ms": round(max_step_ms, 4),
+        "windows_after": [{"value": round(args.steps / e, 2), "max_step_ms": round(m, 4)} for e, m in more],
         "sustained": {"value": round(n_sus / el_sus, 2), "unit": "steps/s", "steps": n_sus, "seconds": round(el_sus, 2)},
         "sampler_roofline": sampler, "kernel_ms_top": top, "also_temporal_len_2": t2, "facade_path": facade,
         "other_configs": extras, "csrc_sha": csrc_hash(),
     }
 
 
-def bench_distributed(args, dev, T, rank, world, backend, dist, nat):
-    """BASELINE config 4, strong scaling: the global batch of 1024 windows is split over the ranks."""
-    w = WORKLOADS["config4"]
-    Bg = args.batch or w["B"]
-    assert Bg % world == 0, "the global batch must divide by the number of GPUs"
-    ring_slots = int(os.environ.get("FDQL_BENCH_RING", w["ring"]))      # rehearsal knob (ranks sharing one card)
-    # the same workload on ONE GPU, measured by rank 0 before the distributed phase (never `value`)
-    single = None
-    if rank == 0 and os.environ.get("FDQL_BENCH_SKIP_1GPU") is None:
-        j1 = Job(w, dev, Bg, T, ring_slots=ring_slots)
-        e1 = j1.timed(max(4, args.steps // 4), 2)
-        single = {"value": round(max(4, args.steps // 4) / e1, 2), "unit": "steps/s", "global_batch_windows": Bg,
-                  "what": "rank 0 alone on the whole batch, same process, before the distributed phase"}
-        del j1
-        torch.cuda.empty_cache()
-    dist.barrier()
-    job = Job(w, dev, Bg // world, T, world=world, rank=rank, ring_slots=ring_slots)
-    agent, grads = job.agent, job.agent.grads
-    side = torch.cuda.Stream(dev)
-    main_stream = torch.cuda.current_stream(dev)
-    ev_a, ev_b, ev_red = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
-    bucket = agent.grad_bucket()      # grads[bucket:] = critics + log_alpha, final after PHASE_GRAD_CRITICS
+class DPRun:
+    """One data-parallel workload on this rank: Job + the bucketed step (the facade's
+    DeepQLearning._distributed_step runs the same three calls)."""
 
-    def all_reduce(g):
-        if backend == "nccl":
-            dist.all_reduce(g)                       # RCCL sum over xGMI; the row weights already carry 1/B_global
-        else:
+    def __init__(self, w, dev, B_local, T, rank, world, backend, dist, nat, ring_slots=None):
+        self.job = Job(w, dev, B_local, T, world=world, rank=rank, ring_slots=ring_slots)
+        self.dev, self.backend, self.dist, self.nat = dev, backend, dist, nat
+        self.side = torch.cuda.Stream(dev)
+        self.ev = [torch.cuda.Event() for _ in range(3)]
+        self.bucket = self.job.agent.grad_bucket()   # grads[bucket:] = critics + log_alpha, final after PHASE_GRAD_CRITICS
+
+    def all_reduce(self, g):
+        if g.numel() == 0:                           # (FDQL_NO_BUCKETS: the early bucket is empty)
+            return
+        if self.backend == "nccl":
+            self.dist.all_reduce(g)                  # RCCL sum over xGMI; the row weights already carry 1/B_global
+        else:                                        # gloo rehearsal: through the host
             h = g.cpu()
-            dist.all_reduce(h)
+            self.dist.all_reduce(h)
             g.copy_(h)
 
-    def step(i):
+    def step(self, i):
         # two buckets: the critics' gradients are all-reduced on the side stream while the actor / encoder backward runs
-        job.ring.sample_windows(T, job.B, seed=job.seed, counter=i, outs=job.outs)
+        job, agent, nat, side = self.job, self.job.agent, self.nat, self.side
+        main_stream = torch.cuda.current_stream(self.dev)
+        ev_a, ev_b, ev_red = self.ev
+        grads = agent.grads
+        job.ring.sample_windows(job.T, job.B, seed=job.seed, counter=i, outs=job.outs)
         agent.update(job.xp, seed=job.seed, phase=nat.PHASE_GRAD_CRITICS)
         ev_a.record(main_stream)
         with torch.cuda.stream(side):
             side.wait_event(ev_a)
-            all_reduce(grads[bucket:])
+            self.all_reduce(grads[self.bucket:])
         agent.update(None, phase=nat.PHASE_GRAD_REST)
         ev_b.record(main_stream)
         with torch.cuda.stream(side):
             side.wait_event(ev_b)
-            all_reduce(grads[:bucket])
+            self.all_reduce(grads[:self.bucket])
             ev_red.record(side)
         main_stream.wait_event(ev_red)
         agent.update(None, phase=nat.PHASE_APPLY)
 
-    def sync():
-        torch.cuda.synchronize(dev)                  # (the collectives of the step are this rank's barrier)
+    def timed(self, steps, warmup):
+        """W untimed steps, then exactly `steps` steps between barrier + synchronize on both sides; MAX over the ranks."""
+        dist, dev = self.dist, self.dev
+        for i in range(warmup):
+            self.step(i)
+        torch.cuda.synchronize(dev)                  # (the collectives of a step are this rank's barrier)
+        dist.barrier()                               # ranks start the timed region together; no barrier inside it
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            self.step(warmup + i)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        el = time.perf_counter() - t0
+        t = torch.tensor([el], device=dev if self.backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    for i in range(args.warmup):
-        step(i)
-    sync()
-    dist.barrier()                                   # ranks start the timed region together; none inside it
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    sync()
-    el = time.perf_counter() - t0
-    t = torch.tensor([el], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    el = float(t.item())
-    roofline, top = (roofline_of(job, committed_pmc=False) if rank == 0 else (None, None))
-    value = args.steps / el                                  # ONE optimiser step of the whole job per step
+
+def bench_distributed(args, dev, T, rank, world, backend, dist, nat):
+    """N > 1: config 2 weak scaling (`value`), config 2 strong scaling, config 4 strong scaling (module docstring)."""
+    w2, w4 = WORKLOADS["config2"], WORKLOADS["config4"]
+    K, W = args.steps, args.warmup
+    shrink = os.environ.get("FDQL_BENCH_RING")                           # rehearsal knob (ranks sharing one card)
+    ring2 = int(shrink) if shrink else w2["ring"]
+    ring4 = int(shrink) if shrink else w4["ring"]
+    extra = os.environ.get("FDQL_BENCH_SKIP_EXTRA") is None
+
+    # ---- headline: config 2, B = 256 windows per GPU, 1M-slot shard per rank
+    B2 = args.batch or w2["B"]
+    run = DPRun(w2, dev, B2, T, rank, world, backend, dist, nat, ring_slots=ring2)
+    el = run.timed(K, W)
+    it_s = K / el
+    roofline, top = (roofline_of(run.job, committed_pmc=False) if rank == 0 else (None, None))
+    arena_mb = run.job.agent.grads.numel() * 4 / 1e6
+    bucket_frac = 1.0 - run.bucket / max(run.job.agent.grads.numel(), 1)
+    del run
+    torch.cuda.empty_cache()
+
+    strong2, strong4, single4 = None, None, None
+    if extra:
+        # ---- config 2, global batch fixed at 256 windows
+        if B2 % world == 0:
+            r2 = DPRun(w2, dev, B2 // world, T, rank, world, backend, dist, nat, ring_slots=ring2)
+            e2 = r2.timed(max(K, 50), max(W, 5))
+            strong2 = {"workload": f"{w2['text']}, GLOBAL batch {B2} windows split {B2 // world} per GPU x T={T}", "scaling": "strong",
+                       "value": round(max(K, 50) / e2, 2), "unit": "steps/s", "ms_per_step": round(1e3 * e2 / max(K, 50), 4),
+                       "steps": max(K, 50)}
+            del r2
+            torch.cuda.empty_cache()
+        # ---- config 4, global batch 1024 windows: rank 0 alone on the whole batch first, then the split
+        B4 = w4["B"]
+        if B4 % world == 0:
+            if rank == 0 and os.environ.get("FDQL_BENCH_SKIP_1GPU") is None:
+                j1 = Job(w4, dev, B4, T, ring_slots=ring4)
+                n1 = max(8, K // 2)
+                e1 = j1.timed(n1, 3)
+                single4 = {"value": round(n1 / e1, 2), "unit": "steps/s", "global_batch_windows": B4, "steps": n1,
+                           "what": "rank 0 alone on the whole batch, same process, before the distributed phase"}
+                del j1
+                torch.cuda.empty_cache()
+            dist.barrier()
+            r4 = DPRun(w4, dev, B4 // world, T, rank, world, backend, dist, nat, ring_slots=ring4)
+            n4 = max(K, 30)
+            e4 = r4.timed(n4, max(W, 5))
+            strong4 = {"workload": f"{w4['text']} per rank, GLOBAL batch {B4} windows split {B4 // world} per GPU x T={T}",
+                       "scaling": "strong", "value": round(n4 / e4, 2), "unit": "steps/s", "ms_per_step": round(1e3 * e4 / n4, 4),
+                       "steps": n4, "transitions_per_s": round(n4 / e4 * B4 * T, 0),
+                       "grad_arena_MB": round(r4.job.agent.grads.numel() * 4 / 1e6, 2), "same_workload_1gpu": single4}
+            if single4:
+                strong4["speedup_vs_1gpu"] = round(strong4["value"] / single4["value"], 3)
+            del r4
+            torch.cuda.empty_cache()
     return {
-        "metric": "gradient-steps/sec", "value": round(value, 2), "unit": "steps/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / max(args.steps, 1), 4),
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{w['text']} per rank, GLOBAL batch {Bg} windows split {Bg // world} per GPU x temporal_len "
-                               f"T={T}, sample+loss+backward, all-reduce of the {agent.grads.numel() * 4 / 1e6:.2f} MB gradient "
-                               f"arena ({backend}), Adam+polyak on every rank",
-                   "global_batch_windows": Bg, "temporal_len": T, "transitions_per_step": Bg * T, "ring": ring_slots,
-                   "parallelism": f"dp{world}", "collective_ranks": dist.get_world_size(), "backend": backend},
-        "transitions_per_s": round(value * Bg * T, 0),
-        "same_workload_1gpu": single, "roofline": roofline, "cpu_baseline": None, "kernel_ms_top": top,
-        "csrc_sha": csrc_hash(),
+        "metric": "gradient-steps/sec", "value": round(world * it_s, 2), "unit": "steps/s", "n_gpus": world,
+        "steps": K, "warmup": W, "ms_per_step": round(1e3 * el / max(K, 1), 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{w2['text']} per rank, B={B2} windows PER GPU x temporal_len T={T} (global batch {B2 * world}), "
+                               f"sample+loss+backward, all-reduce of the {arena_mb:.2f} MB gradient arena in two buckets "
+                               f"({backend}; {bucket_frac:.0%} of it beside the actor / encoder backward), Adam+polyak on every rank",
+                   "windows_per_gpu": B2, "global_batch_windows": B2 * world, "temporal_len": T,
+                   "transitions_per_step": B2 * world * T, "ring": ring2, "parallelism": f"dp{world}",
+                   "collective_ranks": dist.get_world_size(), "backend": backend},
+        "value_is": "256-window minibatch gradient steps per second over the whole job = n_gpus x optimizer_iterations_per_s "
+                    "(every iteration each GPU differentiates its own minibatch; the gradients are averaged by the all-reduce)",
+        "optimizer_iterations_per_s": round(it_s, 2), "transitions_per_s": round(it_s * B2 * world * T, 0),
+        "config2_strong": strong2, "config4_strong": strong4,
+        "roofline": roofline, "cpu_baseline": None, "kernel_ms_top": top, "csrc_sha": csrc_hash(),
     }
 
 

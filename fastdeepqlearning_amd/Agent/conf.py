@@ -44,7 +44,7 @@ _RUNTIME = dict(algorithm="deep_q_learning", log_extra_debug_info=False, enable_
                 param_update_interval=50, use_async_train=True,
                 inference_input_keys=("obs_1d", "obs_2d", "idx", "achieved_goal", "desired_goal", "agent_state"))
 # additions of this implementation: ring shards per process (the reference's launcher sets it) and data-parallel ranks
-_ADDED = dict(num_instances=1, world_size=1)
+_ADDED = dict(num_instances=1, world_size=1, force_distributed_step=False)
 
 
 class AgentConf(AttrDict):

@@ -140,7 +140,9 @@ class DeepQLearning:
             t.join(timeout)
 
     def _distributed(self):
-        return int(getattr(self.conf, "world_size", 1) or 1) > 1
+        """world_size > 1, or conf.force_distributed_step (tests: the bucketed step over a process group of ONE rank, so that the
+        RCCL path runs on a one-GPU box; conf.world_size keeps its meaning - the loss is scaled by 1 / (B * world_size))."""
+        return int(getattr(self.conf, "world_size", 1) or 1) > 1 or bool(getattr(self.conf, "force_distributed_step", False))
 
     def _all_reduce(self, g):
         """all-reduce(sum) of a contiguous slice of the gradient arena: RCCL over xGMI when the process group

@@ -132,6 +132,7 @@ SIGNATURES = {
     "fdql_test_gemm": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32,
                                  _i32, _vp]),
     "fdql_debug_rowgemm_life": (C.c_int, [_vp, _i32]),
+    "fdql_debug_side_copy": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "fdql_test_wgrad_stat": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _vp]),
     "fdql_test_wgrad_stat_riders": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _vp, _i32, _i32, _vp, _i32, _i32,
                                               _vp, _i32, _i32, _vp, _i32, _vp]),

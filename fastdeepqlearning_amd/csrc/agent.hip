@@ -228,6 +228,13 @@ struct fdql_agent {
   // right after the critics' backward (FDQL_PHASE_GRAD_CRITICS), so that their all-reduce runs beside the actor / encoder
   // backward (FDQL_PHASE_GRAD_REST); n_train: the plan is not bucketed
   int64_t grad_bucket = 0;
+  bool no_buckets = false;   // FDQL_NO_BUCKETS, latched at create: the plan builder and fdql_agent_grad_bucket must agree
+  bool force_buckets = false;
+  bool bucketed() const { return (cfg.world_size > 1 || force_buckets) && !no_buckets; }
+  // where the current step stands in the split-phase protocol (fdql_agent_update): a phase out of order is FDQL_ESTATE
+  // instead of an optimiser step on a half-stale gradient arena
+  enum StepState { STEP_NONE, STEP_CRITICS_DONE, STEP_GRAD_DONE };
+  StepState step_state = STEP_NONE;
   const float *noise_t = nullptr, *noise_a = nullptr;  // per-call (read by the policy stage lambdas)
   uint64_t seed = 0;
 
@@ -442,6 +449,11 @@ void carve(fdql_agent *a) {
   a->alloc("dpi_part", (int64_t)c.n_critics * M * c.act_dim);
   a->alloc("loss_partials", (int64_t)loss_blocks((int)M, 256) * LOSS_NPART + (int64_t)M * LOSS_NPART + LOSS_NPART);
   a->alloc("slabs", (int64_t)a->nsplit * a->n_train);
+  {   // fdql_agent_summaries: 4 scalars + one norm per trainable tensor, then the int64 (offset, count) table (8-byte aligned)
+    int64_t nt = 0;
+    for (const TensorInfo &t : a->tensors) nt += t.arena == 0;
+    a->alloc("summaries", ((4 + nt + 1) & ~(int64_t)1) + 4 * nt + 4);
+  }
 }
 
 // --------------------------------------------------------------------------- plan builder
@@ -1472,7 +1484,7 @@ int build_plan(fdql_agent *a) {
   }
   // ---- data-parallel plans: the critics' weight gradients now, and their slab sum, so that the all-reduce of the arena
   // range [crit_begin, n_train) (critics + log_alpha: 2/3 of the arena at config 2) can run beside everything below
-  const bool bucketed = c.world_size > 1 && getenv("FDQL_NO_BUCKETS") == nullptr;
+  const bool bucketed = a->bucketed();
   a->grad_bucket = bucketed ? a->crit_begin : a->n_train;
   size_t first_rest_stage = 0;
   if (bucketed) {
@@ -1880,6 +1892,8 @@ int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {
     // T=50 and at T=2 - the step is bound by its kernels' own latency, the host stays ahead of the queue - so it is opt-in
     const char *e = getenv("FDQL_GRAPH");
     a->use_graph = e && e[0] == '1';
+    a->no_buckets = getenv("FDQL_NO_BUCKETS") != nullptr;
+    a->force_buckets = getenv("FDQL_FORCE_BUCKETS") != nullptr;   // test hook: the two-bucket plan at world_size 1
     const char *r = getenv("FDQL_ROWGEMM");   // "0": off; "all": every eligible group whatever its size (tests)
     if (const char *pc = getenv("FDQL_PLAN_CACHE")) {
       const int v = atoi(pc);
@@ -2028,6 +2042,17 @@ int fdql_agent_update(fdql_agent_t *a, const fdql_batch_t *batch, const float *n
     set_error("FDQL_PHASE_APPLY / FDQL_PHASE_GRAD_REST before the phase that starts the step");
     return FDQL_ESTATE;
   }
+  // split-phase protocol: GRAD_CRITICS -> GRAD_REST -> APPLY, or GRAD -> APPLY; GRAD / GRAD_CRITICS / ALL (re)start a step
+  if (phase == FDQL_PHASE_GRAD_REST && a->step_state != fdql_agent::STEP_CRITICS_DONE) {
+    set_error("FDQL_PHASE_GRAD_REST needs FDQL_PHASE_GRAD_CRITICS of the same step right before it");
+    return FDQL_ESTATE;
+  }
+  if (phase == FDQL_PHASE_APPLY && a->step_state != fdql_agent::STEP_GRAD_DONE) {
+    set_error("FDQL_PHASE_APPLY needs a finished gradient (FDQL_PHASE_GRAD, or FDQL_PHASE_GRAD_CRITICS + FDQL_PHASE_GRAD_REST) of the same step");
+    return FDQL_ESTATE;
+  }
+  a->step_state = phase == FDQL_PHASE_GRAD_CRITICS ? fdql_agent::STEP_CRITICS_DONE
+                  : (phase == FDQL_PHASE_GRAD || phase == FDQL_PHASE_GRAD_REST) ? fdql_agent::STEP_GRAD_DONE : fdql_agent::STEP_NONE;
   hipStream_t s = (hipStream_t)stream;
   if (phase == FDQL_PHASE_ALL && a->use_graph) {
     fdql_agent::PlanGraph &g = a->graph;
@@ -2057,7 +2082,7 @@ int fdql_agent_update(fdql_agent_t *a, const fdql_batch_t *batch, const float *n
 int fdql_agent_grad_bucket(fdql_agent_t *a, int64_t *first_early_float) {
   FDQL_REQUIRE(a && first_early_float, "null argument");
   std::lock_guard<std::mutex> lk(a->mu);
-  *first_early_float = (a->cfg.world_size > 1 && getenv("FDQL_NO_BUCKETS") == nullptr) ? a->crit_begin : a->n_train;
+  *first_early_float = a->bucketed() ? a->crit_begin : a->n_train;
   return 0;
 }
 
@@ -2375,9 +2400,8 @@ int fdql_agent_summaries(fdql_agent_t *a, float *host_out, int32_t cap, int32_t 
   const int nr = (int)ranges.size() / 2;
   FDQL_REQUIRE(cap >= 4 + nr, "summaries need room for %d floats", 4 + nr);
   hipStream_t s = (hipStream_t)stream;
-  // scratch: the loss partials are dead between updates (rebuilt by the next loss launch)
-  float *out_dev = a->buf("loss_partials");
-  FDQL_REQUIRE(a->named.at("loss_partials").second >= (int64_t)(4 + nr) + (int64_t)ranges.size() * 2, "scratch too small for the summaries");
+  float *out_dev = a->buf("summaries");
+  FDQL_REQUIRE(a->named.at("summaries").second >= (int64_t)((4 + nr + 1) & ~1) + (int64_t)ranges.size() * 2, "scratch too small for the summaries");
   long long *ranges_dev = reinterpret_cast<long long *>(out_dev + ((4 + nr + 1) & ~1));
   if (nr) FDQL_HIP(hipMemcpyAsync(ranges_dev, ranges.data(), ranges.size() * sizeof(long long), hipMemcpyHostToDevice, s));
   hipError_t e = summaries_launch(a->buf("q_pred"), a->M, a->Nq, a->buf("is_contiguous"), a->T - 1, a->B, a->T, a->grads, ranges_dev, nr, out_dev, s);

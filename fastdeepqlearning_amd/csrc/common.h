@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 
@@ -27,6 +28,15 @@ void set_error(const char *fmt, ...);
       return FDQL_EINVAL;            \
     }                                \
   } while (0)
+
+// Compute units the persistent one-workgroup-per-CU launches (wstat / wgrad / rowgemm) may occupy: all of them, minus
+// FDQL_CU_RESERVE (tuning hook, read when a plan is built).  A data-parallel job can leave a few CUs to the collective's
+// channel kernels, which cannot share a CU with a workgroup that holds ~158 KB of LDS (tools/dp_overlap.py measures both ways).
+inline int cu_budget(int ncu) {
+  const char *e = getenv("FDQL_CU_RESERVE");
+  const int r = e ? atoi(e) : 0;
+  return (r > 0 && r < ncu - 16) ? ncu - r : ncu;
+}
 
 // ---------------------------------------------------------------------------------------
 // Grouped, K-segmented fp32 MFMA GEMM (gemm.hip)

@@ -614,7 +614,15 @@ __global__ void k_policy_bwd(const float *__restrict__ logits, const float *__re
 // ======================================================================================
 constexpr int GUMBEL_MAXN = 32;
 
-__device__ __forceinline__ float row_logsumexp(const float *x, int n) {
+// A thread's per-action values live in LDS (element j of lane l at p[j * stride], stride = the workgroup's thread count:
+// lane-contiguous, conflict-free): as runtime-indexed local arrays they were 272 / 528 bytes of scratch per thread.
+struct LaneArr {
+  float *p;
+  int stride;
+  __device__ __forceinline__ float &operator[](int j) const { return p[j * stride]; }
+};
+
+__device__ __forceinline__ float row_logsumexp(const LaneArr &x, int n) {
   float mx = -INFINITY;
   for (int j = 0; j < n; ++j) mx = fmaxf(mx, x[j]);
   float s = 0.f;
@@ -623,9 +631,9 @@ __device__ __forceinline__ float row_logsumexp(const float *x, int n) {
 }
 
 // forward pieces shared by fwd and bwd: norm = logits - lse, relaxed = softmax(norm + gumbel), hard index
-__device__ __forceinline__ int gumbel_forward(const float *lo, const float *u, int n, float *norm, float *relaxed) {
+__device__ __forceinline__ int gumbel_forward(const LaneArr &lo, const LaneArr &u, int n, const LaneArr &norm, const LaneArr &relaxed,
+                                              const LaneArr &sc) {
   const float tiny = 1.1920928955078125e-07f;  // torch.finfo(float32).eps (clamp_probs)
-  float sc[GUMBEL_MAXN];
   const float lse = row_logsumexp(lo, n);
   for (int j = 0; j < n; ++j) {
     norm[j] = lo[j] - lse;
@@ -635,33 +643,41 @@ __device__ __forceinline__ int gumbel_forward(const float *lo, const float *u, i
   }
   const float lse2 = row_logsumexp(sc, n);
   int best = 0;
+  float best_v = -INFINITY;
   for (int j = 0; j < n; ++j) {
-    relaxed[j] = (float)exp((double)(sc[j] - lse2));
-    if (relaxed[j] > relaxed[best]) best = j;   // first maximum, like torch.argmax
+    const float r = (float)exp((double)(sc[j] - lse2));
+    relaxed[j] = r;
+    if (j == 0 || r > best_v) { best_v = r; best = j; }   // first maximum, like torch.argmax
   }
   return best;
 }
 
-__global__ void k_policy_fwd_gumbel(PolicyFwdArgs a0, PolicyFwdArgs a1, int nprob, int M, int n, const DevState *st,
-                                    uint64_t seed) {
+constexpr int GUMBEL_THREADS = 64;
+
+__global__ __launch_bounds__(GUMBEL_THREADS) void k_policy_fwd_gumbel(PolicyFwdArgs a0, PolicyFwdArgs a1, int nprob, int M, int n, const DevState *st,
+                                                                     uint64_t seed) {
 #pragma clang fp contract(off)
+  __shared__ float lane_vals[5 * GUMBEL_MAXN * GUMBEL_THREADS];
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int p = gid / M;
   if (p >= nprob) return;
   const int m = gid - p * M;
   const PolicyFwdArgs &a = p == 0 ? a0 : a1;
-  float lo[GUMBEL_MAXN], u[GUMBEL_MAXN], norm[GUMBEL_MAXN], relaxed[GUMBEL_MAXN];
+  auto arr = [&](int k) { return LaneArr{lane_vals + k * GUMBEL_MAXN * GUMBEL_THREADS + threadIdx.x, GUMBEL_THREADS}; };
+  const LaneArr lo = arr(0), u = arr(1), norm = arr(2), relaxed = arr(3), sc = arr(4);
   for (int j = 0; j < n; ++j) {
     lo[j] = a.logits[(long long)m * n + j];
-    u[j] = a.noise ? a.noise[(long long)m * n + j] : device_noise(seed, (uint32_t)st->step, a.which, (uint32_t)(m * n + j), false);
-    if (a.noise_out) a.noise_out[(long long)m * n + j] = u[j];
+    const float uj = a.noise ? a.noise[(long long)m * n + j] : device_noise(seed, (uint32_t)st->step, a.which, (uint32_t)(m * n + j), false);
+    u[j] = uj;
+    if (a.noise_out) a.noise_out[(long long)m * n + j] = uj;
   }
-  const int best = gumbel_forward(lo, u, n, norm, relaxed);
+  const int best = gumbel_forward(lo, u, n, norm, relaxed, sc);
   const float lse3 = row_logsumexp(norm, n);   // log_softmax of the already normalised logits
   float logp = 0.f;
   for (int j = 0; j < n; ++j) {
     const float hard = j == best ? 1.f : 0.f;
-    const float stv = (hard - relaxed[j]) + relaxed[j];   // straight-through value, same fp order as torch
+    const float rj = relaxed[j];
+    const float stv = (hard - rj) + rj;   // straight-through value, same fp order as torch
     a.action[(long long)m * n + j] = stv;
     if (a.diff) a.diff[(long long)m * n + j] = stv - a.sub[(long long)m * n + j];
     logp += -stv * (norm[j] - lse3);
@@ -669,15 +685,17 @@ __global__ void k_policy_fwd_gumbel(PolicyFwdArgs a0, PolicyFwdArgs a1, int npro
   a.logp[m] = -logp;
 }
 
-__global__ void k_policy_bwd_gumbel(const float *__restrict__ logits, const float *__restrict__ noise,
-                                    const float *__restrict__ dpi_parts, int nparts, float *__restrict__ dpi_sum,
-                                    const float *__restrict__ w, const DevState *st, int M, int n,
-                                    float *__restrict__ dlogits) {
+__global__ __launch_bounds__(GUMBEL_THREADS) void k_policy_bwd_gumbel(const float *__restrict__ logits, const float *__restrict__ noise,
+                                                                     const float *__restrict__ dpi_parts, int nparts, float *__restrict__ dpi_sum,
+                                                                     const float *__restrict__ w, const DevState *st, int M, int n,
+                                                                     float *__restrict__ dlogits) {
+  __shared__ float lane_vals[7 * GUMBEL_MAXN * GUMBEL_THREADS];
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
-  float lo[GUMBEL_MAXN], u[GUMBEL_MAXN], norm[GUMBEL_MAXN], relaxed[GUMBEL_MAXN], gst[GUMBEL_MAXN], dnorm[GUMBEL_MAXN];
+  auto arr = [&](int k) { return LaneArr{lane_vals + k * GUMBEL_MAXN * GUMBEL_THREADS + threadIdx.x, GUMBEL_THREADS}; };
+  const LaneArr lo = arr(0), u = arr(1), norm = arr(2), relaxed = arr(3), sc = arr(4), gst = arr(5), dnorm = arr(6);
   for (int j = 0; j < n; ++j) { lo[j] = logits[(long long)m * n + j]; u[j] = noise[(long long)m * n + j]; }
-  const int best = gumbel_forward(lo, u, n, norm, relaxed);
+  const int best = gumbel_forward(lo, u, n, norm, relaxed, sc);
   const float lse3 = row_logsumexp(norm, n);
   const float glp = w[m] * st->alpha_cur;   // d loss / d logp
   float dot_st = 0.f, sum_glogsm = 0.f;
@@ -686,19 +704,23 @@ __global__ void k_policy_bwd_gumbel(const float *__restrict__ logits, const floa
     for (int c = 0; c < nparts; ++c) g += dpi_parts[((long long)c * M + m) * n + j];
     dpi_sum[(long long)m * n + j] = g;
     const float logsm = norm[j] - lse3;
-    gst[j] = g + glp * logsm;                       // logp = sum st * logsm
-    dot_st += gst[j] * relaxed[j];
+    const float gj = g + glp * logsm;                 // logp = sum st * logsm
+    gst[j] = gj;
+    const float rj = relaxed[j];
+    dot_st += gj * rj;
     const float hard = j == best ? 1.f : 0.f;
-    sum_glogsm += glp * ((hard - relaxed[j]) + relaxed[j]);
+    sum_glogsm += glp * ((hard - rj) + rj);
   }
   float sum_dnorm = 0.f;
   for (int j = 0; j < n; ++j) {
     const float hard = j == best ? 1.f : 0.f;
-    const float stv = (hard - relaxed[j]) + relaxed[j];
-    const float d_scores = relaxed[j] * (gst[j] - dot_st);                                     // softmax backward
+    const float rj = relaxed[j];
+    const float stv = (hard - rj) + rj;
+    const float d_scores = rj * (gst[j] - dot_st);                                             // softmax backward
     const float d_logsm = glp * stv - (float)exp((double)(norm[j] - lse3)) * sum_glogsm;       // log_softmax backward
-    dnorm[j] = d_scores + d_logsm;
-    sum_dnorm += dnorm[j];
+    const float dn = d_scores + d_logsm;
+    dnorm[j] = dn;
+    sum_dnorm += dn;
   }
   for (int j = 0; j < n; ++j)
     dlogits[(long long)m * n + j] = dnorm[j] - (float)exp((double)norm[j]) * sum_dnorm;        // norm = logits - lse
@@ -1665,27 +1687,35 @@ __global__ __launch_bounds__(256) void k_act_layer(ActLayerArgs a) {
 // explore / exploit actions, log-prob of the explored one, and the exploit_mask select
 // (gaussian_mlp.py:15-39 or gumbel_mlp.py:7-54, then deepQlearning.py:175-180)
 // (row m; `lrow`: its logits, in global memory or LDS)
-__device__ __forceinline__ void act_policy_row(const ActPolicyArgs &a, int m, const float *lrow) {
+// `vals`: 5 x GUMBEL_MAXN floats of this thread, element (k, j) at vals[(k * GUMBEL_MAXN + j) * stride] (discrete actor only)
+// MODE: 1 discrete only, 0 continuous only (k_act_policy: one instantiation each keeps the argument block's live ranges
+// inside the SGPR file), -1 either (k_act_fused)
+template <int MODE>
+__device__ __forceinline__ void act_policy_row(const ActPolicyArgs &a, int m, const float *lrow, float *vals, int stride) {
 #pragma clang fp contract(off)
   const bool use_exploit = a.exploit_mask && a.exploit_mask[m] != 0;
   const int A = a.A;
-  if (a.discrete) {
-    float lo[GUMBEL_MAXN], u[GUMBEL_MAXN], norm[GUMBEL_MAXN], relaxed[GUMBEL_MAXN];
+  if (MODE == 1 || (MODE < 0 && a.discrete)) {
+    auto arr = [&](int k) { return LaneArr{vals + k * GUMBEL_MAXN * stride, stride}; };
+    const LaneArr lo = arr(0), u = arr(1), norm = arr(2), relaxed = arr(3), sc = arr(4);
     int greedy = 0;
+    float greedy_v = -INFINITY;
     for (int j = 0; j < A; ++j) {
-      lo[j] = lrow[j];
+      const float l = lrow[j];
+      lo[j] = l;
       u[j] = a.noise ? a.noise[(long long)m * A + j]
                      : device_noise(a.seed, (uint32_t)a.counter, 7u, (uint32_t)(m * A + j), false);
-      if (lo[j] > lo[greedy]) greedy = j;
+      if (j == 0 || l > greedy_v) { greedy_v = l; greedy = j; }
     }
-    const int best = gumbel_forward(lo, u, A, norm, relaxed);
+    const int best = gumbel_forward(lo, u, A, norm, relaxed, sc);
     const float lse3 = row_logsumexp(norm, A);
     float logp = 0.f;
     int best_st = 0;
     float best_v = -INFINITY;
     for (int j = 0; j < A; ++j) {
       const float hard = j == best ? 1.f : 0.f;
-      const float stv = (hard - relaxed[j]) + relaxed[j];
+      const float rj = relaxed[j];
+      const float stv = (hard - rj) + rj;
       if (stv > best_v) { best_v = stv; best_st = j; }   // argmax of the straight-through sample
       logp += -stv * (norm[j] - lse3);
     }
@@ -1717,10 +1747,12 @@ __device__ __forceinline__ void act_policy_row(const ActPolicyArgs &a, int m, co
   if (a.log_prob) a.log_prob[m] = logp;
 }
 
-__global__ void k_act_policy(ActPolicyArgs a) {
+template <int MODE>
+__global__ __launch_bounds__(64) void k_act_policy(ActPolicyArgs a) {
+  __shared__ float lane_vals[MODE ? 5 * GUMBEL_MAXN * 64 : 1];
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= a.rows) return;
-  act_policy_row(a, m, a.logits + (long long)m * a.ld);
+  act_policy_row<MODE>(a, m, a.logits + (long long)m * a.ld, lane_vals + (MODE ? threadIdx.x : 0), 64);
 }
 
 // --------------------------------------------------------------------------------------
@@ -1806,7 +1838,8 @@ __global__ __launch_bounds__(1024) void k_act_fused(const ActFusedArgs a) {
     }
     __syncthreads();
   }
-  if (tid < rows) act_policy_row(a.pol, tid, lds + a.logits_off + tid * a.logits_pitch);
+  __shared__ float lane_vals[5 * GUMBEL_MAXN * ACTF_ROWS];
+  if (tid < rows) act_policy_row<-1>(a.pol, tid, lds + a.logits_off + tid * a.logits_pitch, lane_vals + tid, ACTF_ROWS);
 }
 
 hipError_t act_fused_launch(const ActFusedArgs &a, hipStream_t s) {
@@ -1821,10 +1854,79 @@ hipError_t act_layer_launch(const ActLayerArgs &a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// Continuous actor, one thread per (row, action) like k_policy_fwd (AG lanes per row, the row's log-prob summed in the order
+// j = 0, 1, ... of the sequential loop in act_policy_row): a handful of rows x 6 actions are one short instruction stream per
+// lane instead of six in sequence, and nothing of the double-precision math is hoisted into (spilled) SGPRs.
+template <int AG>
+__global__ __launch_bounds__(64) void k_act_policy_gauss(ActPolicyArgs a) {
+#pragma clang fp contract(off)
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int m = gid / AG, j = gid - m * AG;
+  const int A = a.A;
+  const bool live = m < a.rows && j < A;
+  float lp = 0.f;
+  if (live) {
+    const bool use_exploit = a.exploit_mask && a.exploit_mask[m] != 0;
+    const float *lo = a.logits + (long long)m * a.ld;
+    const float mean = lo[j];
+    const float ls = fminf(fmaxf(lo[A + j], -20.f), 2.f);
+    const float sd = (float)exp((double)ls);
+    const float eps = a.noise ? a.noise[(long long)m * A + j]
+                              : device_noise(a.seed, (uint32_t)a.counter, 7u, (uint32_t)(m * A + j), true);
+    const float x = mean + eps * sd;
+    const float d = x - mean;
+    lp = -(d * d) / (2.f * (sd * sd)) - (float)log((double)sd) - 0.91893853320467274178f;
+    const float ex = (float)tanh((double)x);
+    lp -= (float)log((double)((1.f - ex * ex) + 1e-4f));
+    const float gr = (float)tanh((double)mean);
+    if (a.explore) a.explore[(long long)m * A + j] = ex;
+    if (a.exploit) a.exploit[(long long)m * A + j] = gr;
+    a.action[(long long)m * A + j] = use_exploit ? gr : ex;
+  }
+  const int base = (threadIdx.x & 63) - j;
+  float logp = 0.f;
+  for (int k = 0; k < A; ++k) logp += __shfl(lp, base + k, 64);
+  if (live && j == 0 && a.log_prob) a.log_prob[m] = logp;
+}
+
 hipError_t act_policy_launch(const ActPolicyArgs &a, hipStream_t s) {
   if (a.rows <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_act_policy, dim3((a.rows + 63) / 64), dim3(64), 0, s, a);
+  if (a.discrete) hipLaunchKernelGGL(k_act_policy<1>, dim3((a.rows + 63) / 64), dim3(64), 0, s, a);
+  else if (a.A <= 8) hipLaunchKernelGGL(k_act_policy_gauss<8>, dim3((a.rows * 8 + 63) / 64), dim3(64), 0, s, a);
+  else if (a.A <= 32) hipLaunchKernelGGL(k_act_policy_gauss<32>, dim3((a.rows * 32 + 63) / 64), dim3(64), 0, s, a);
+  else if (a.A <= 64) hipLaunchKernelGGL(k_act_policy_gauss<64>, dim3(a.rows), dim3(64), 0, s, a);
+  else return hipErrorInvalidValue;   // (act_dim <= 64 is checked at fdql_agent_create)
   return hipGetLastError();
 }
 
+// stand-in for a collective's channel kernels (include/fdql.h, fdql_debug_side_copy)
+__global__ __launch_bounds__(256) void k_side_copy(const float4 *__restrict__ src, float4 *__restrict__ dst, long long n4, int passes,
+                                                   long long hold_ticks) {
+  extern __shared__ float side_lds[];
+  const unsigned long long t0 = wall_clock64();       // constant 100 MHz counter
+  if (side_lds && threadIdx.x == 0 && hold_ticks < 0) side_lds[0] = 0.f;   // (never: keeps the allocation referenced)
+  for (int p = 0; p < passes; ++p)
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+      float4 v = src[i];
+      v.x += (float)p;   // (keeps the passes from being folded into one)
+      dst[i] = v;
+    }
+  // a collective's workgroups mostly WAIT (for their peers, for the links) while they hold their CU: stay resident until
+  // hold_ticks have passed since the start.  The clock runs on its own, so every wave reaches the exit.
+  while ((long long)(wall_clock64() - t0) < hold_ticks) __builtin_amdgcn_s_sleep(64);
+}
+
 }  // namespace fdql
+
+extern "C" int fdql_debug_side_copy(const float *src, float *dst, int64_t n, int32_t workgroups, int32_t passes, int32_t hold_us,
+                                    int32_t lds_bytes, void *stream) {
+  using namespace fdql;
+  FDQL_REQUIRE(src && dst && n >= 0 && n % 4 == 0 && workgroups >= 1 && workgroups <= 4096 && passes >= 0, "bad side-copy arguments");
+  FDQL_REQUIRE(hold_us >= 0 && hold_us <= 5000 && lds_bytes >= 0 && lds_bytes <= 65536, "side copy: hold_us in [0, 5000], lds_bytes in [0, 64 KiB]");
+  FDQL_REQUIRE((reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0, "side copy needs 16-byte aligned buffers");
+  hipLaunchKernelGGL(k_side_copy, dim3(workgroups), dim3(256), lds_bytes, (hipStream_t)stream, (const float4 *)src, (float4 *)dst,
+                     (long long)(n / 4), passes, (long long)hold_us * 100);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("side copy: %s", hipGetErrorString(e)); return FDQL_EHIP; }
+  return 0;
+}

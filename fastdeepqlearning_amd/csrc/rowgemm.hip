@@ -759,7 +759,7 @@ hipError_t rowgemm_launch(const RowGemmArgs &a, hipStream_t s) {
       if (hipGetDeviceProperties(&p, dev) != hipSuccess) return hipErrorUnknown;
       ncu_of[dev] = p.multiProcessorCount;
     }
-    ncu = ncu_of[dev];
+    ncu = cu_budget(ncu_of[dev]);
   }
   const int ntiles = a.ninst * a.blocks_per_inst;
   const int grid = ntiles < ncu ? ntiles : ncu;

@@ -370,7 +370,7 @@ bool wgrad_stat_from_problems(const GemmProblem *probs, int nprob, int nslab, lo
       ncu_of[dev] = pr.multiProcessorCount;
     }
   }
-  args.ncu = ncu_of[dev];
+  args.ncu = cu_budget(ncu_of[dev]);
   return wgrad_stat_balance(args);
 }
 

@@ -981,7 +981,7 @@ bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
       ncu_of[dev] = pr.multiProcessorCount;
     }
   }
-  const int ncu = ncu_of[dev];
+  const int ncu = cu_budget(ncu_of[dev]);
   if (nprob > ncu) return false;
   // Workgroups per instance: one per CU in all, dealt so that the slowest instance finishes as early as possible (tiles come in
   // whole numbers: 392 tiles over 26 workgroups are 16 each, over 27 they are 15).
@@ -1000,6 +1000,13 @@ bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
   }
   for (int i = 0; i < nprob; ++i)   // a workgroup that does not lower its instance's tile count only repeats the prologue
     while (per[i] > 1 && (tiles + per[i] - 2) / (per[i] - 1) == (tiles + per[i] - 1) / per[i]) --per[i];
+  // gated dgrad form: the caller reduces wstat_colsum_rows() partial rows of column sums for EVERY instance, so every instance
+  // gets the same number of workgroups (the smallest share: dealing by remainder can leave them one apart)
+  if (grad && !plain) {
+    int mn = per[0];
+    for (int i = 1; i < nprob; ++i) mn = per[i] < mn ? per[i] : mn;
+    for (int i = 0; i < nprob; ++i) per[i] = mn;
+  }
   args.wg_first[0] = 0;
   for (int i = 0; i < nprob; ++i) args.wg_first[i + 1] = args.wg_first[i] + per[i];
   return true;

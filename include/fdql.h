@@ -412,6 +412,16 @@ int fdql_test_wgrad_stat_riders(const float *G, const float *X, float *dW, int32
                                 int64_t slab_stride, const float *X2, int32_t nx2, int32_t ldx2, float *dW2, int32_t ldw2, int32_t x2_every,
                                 const float *G2, int32_t ng2, int32_t ldg2, float *dW3, int32_t ldw3, void *stream);
 
+/* Diagnostic (tools/dp_overlap.py): a stand-in for the channel kernels of a collective - `workgroups` workgroups of 256
+ * threads (each holding lds_bytes of LDS) copy n floats from src to dst `passes` times (the ring steps of an all-reduce
+ * re-read their chunk) and then stay resident until hold_us microseconds have passed since they started (a collective's
+ * workgroups mostly wait for their peers and links while they occupy their compute units).  Launched on a
+ * side stream beside the update's launches it shows, on ONE GPU, whether a small kernel gets compute units while the
+ * persistent one-workgroup-per-CU kernels run and what it costs them (the data-parallel step of SURVEY 8e all-reduces the
+ * gradient arena beside FDQL_PHASE_GRAD_REST).  Asynchronous on `stream`. */
+int fdql_debug_side_copy(const float *src, float *dst, int64_t n, int32_t workgroups, int32_t passes, int32_t hold_us,
+                         int32_t lds_bytes, void *stream);
+
 /* Tuning hook: build of the GEMM main loop: 1 (default) = next-step fragment prefetch, K-chunk 32 for small launches (<= 512 workgroups) of the
  * 64x64 tile shapes and 16 otherwise, 6 = K-chunk 16 for every shape, 0 = K-chunk 16 without the prefetch, 4 = K-chunk 8, 5 = b128 fragments; 2 and 3
  * alias 0.  Affects speed only. */

@@ -115,3 +115,47 @@ def test_multi_process_data_parallel_train_step(tmp_path, world):
     assert sum(close) >= 0.9 * len(close)                                 # and fp32 summation order elsewhere
     moved = [not torch.equal(ref[k], v.cpu()) for k, v in _one_step(_conf(dev, B, 1), dev, xp, nt, na, steps=0).state_dict().items()]
     assert any(moved)
+
+
+def _nccl_rank_main(rank, world, port, out_dir):
+    """ONE rank over an nccl (= RCCL) process group: the facade's bucketed step exactly as a multi-GPU job runs it."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["FDQL_FORCE_BUCKETS"] = "1"                 # the two-bucket plan at world_size 1 (latched at agent create)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert dist.get_backend() == "nccl"
+    xp, nt, na = _global_batch()
+    conf = _conf(dev, B, 1)
+    conf.force_distributed_step = True
+    stepped = _one_step(conf, dev, xp, nt, na)             # GRAD_CRITICS | all_reduce(g[b:]) on the side stream | GRAD_REST | all_reduce(g[:b]) | APPLY
+    b, n = stepped.native.grad_bucket(), stepped.native.grads.numel()
+    assert 0 < b < n, (b, n)                               # both buckets are non-empty: both all-reduces ran through RCCL
+    whole = _one_step(_conf(dev, B, 1), dev, xp, nt, na)   # same (bucketed) plan, one FDQL_PHASE_ALL call per step
+    # RCCL really executed a collective on this device (a sum over one rank is the identity, so the weights cannot show it)
+    probe = torch.arange(1024, device=dev, dtype=torch.float32)
+    dist.all_reduce(probe)
+    torch.cuda.synchronize(dev)
+    torch.save({"dp": {k: v.cpu() for k, v in stepped.state_dict().items()}, "all": {k: v.cpu() for k, v in whole.state_dict().items()},
+                "bucket": (b, n), "probe_ok": bool(torch.equal(probe.cpu(), torch.arange(1024, dtype=torch.float32)))},
+               os.path.join(out_dir, "nccl.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_step_over_rccl_process_group(tmp_path):
+    """The nccl branch of DeepQLearning._all_reduce / bench.py (RCCL; world_size 1 - this box has one GPU): RCCL loads, both
+    buckets are all-reduced on the side stream inside the event chain, and the weights after two steps are BIT-equal to the same
+    plan stepped with FDQL_PHASE_ALL."""
+    import torch.multiprocessing as mp
+    assert torch.cuda.is_available()
+    port = 29500 + (os.getpid() % 400) + 17
+    mp.spawn(_nccl_rank_main, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    r = torch.load(tmp_path / "nccl.pt")
+    assert r["probe_ok"]
+    assert set(r["dp"]) == set(r["all"])
+    for k in r["dp"]:
+        assert torch.equal(r["dp"][k], r["all"][k]), k

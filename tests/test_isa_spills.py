@@ -10,18 +10,26 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-# file -> substrings of the (mangled) names of the kernels that must be spill-free: everything a default plan of the
-# headline configuration (config 2, T = 50) launches, plus the ring's kernels.  (Length-prefixed tokens such as
-# "12k_policy_fwdI" keep a name from matching its longer siblings - k_policy_fwd_gumbel belongs to the discrete config 5.)
-MUST_BE_CLEAN = {
-    "wstat.hip": ["k_wstat"],          # forward forms, gated / fused / plain dgrad forms
-    "wgrad.hip": ["k_wgrad_stat"],     # with and without riders
-    "chain.hip": ["k_chain"],
-    "rowdgrad.hip": ["k_rowdgrad", "k_rowdot"],
+# Every kernel of these files must be spill-free except the ones listed: that covers every kernel a default plan of ANY
+# BASELINE config launches (config 2 / 3: k_wstat*, k_wgrad_stat, k_chain<2>, k_rowdgrad, k_rowdot, the tile shapes, the update /
+# loss / policy kernels; config 4: + k_chain<1>, the 128x32 / 32x128 tile shapes; config 5: + the Gumbel policy kernels, one-hot,
+# im2col / col2im / column sums; act(): k_act_layer, k_act_policy<1>, k_act_policy_gauss) and the ring's kernels.
+# Allowed to spill: alternatives behind switches that no default plan launches, each with a measured reason for not being
+# the default: the LDS-DMA tile builds, the two-output 64x64 tile (FDQL_WSTAT=0 fallback of critic
+# layer 0), the one-launch act() (FDQL_ACT_FUSED=1) and the streamed-weights row-block kernel (rowgemm.hip, FDQL_WSTAT=0).
+MAY_SPILL = {
+    "wstat.hip": [], "wgrad.hip": [], "chain.hip": [], "rowdgrad.hip": [], "ring.hip": [],
+    "gemm.hip": ["k_gemm_dma", "k_gemm_groupedILi4E"],
+    "kernels.hip": ["k_act_fused"],
+}
+# kernels that must exist (a renamed kernel would silently drop out of the gate above)
+MUST_EXIST = {
+    "wstat.hip": ["k_wstat"], "wgrad.hip": ["k_wgrad_stat"], "chain.hip": ["k_chainILi1E", "k_chainILi2E"], "rowdgrad.hip": ["k_rowdgrad", "k_rowdot"],
     "gemm.hip": ["k_gemm_groupedILi5ELi16ELi1EE", "k_gemm_groupedILi1ELi16ELi1EE", "k_gemm_groupedILi2ELi16ELi1EE"],   # 64x64, 128x32, 32x128
-    "kernels.hip": ["6k_prepE", "12k_policy_fwdI", "12k_policy_bwdE", "6k_lossE", "13k_loss_finishE", "13k_head_finishE",
-                    "18k_sum_parts_colsumE", "11k_summariesE", "14k_reduce_slabsE", "17k_reduce_partialsE", "13k_adam_polyakE",
-                    "k_skinny_wgrad", "14k_stream_wgradE", "17k_boot_lowerboundE", "12k_head_dgradE", "11k_act_layerE"],
+    "kernels.hip": ["6k_prepE", "12k_policy_fwdI", "12k_policy_bwdE", "19k_policy_fwd_gumbelE", "19k_policy_bwd_gumbelE", "6k_lossE",
+                    "13k_loss_finishE", "13k_head_finishE", "18k_sum_parts_colsumE", "11k_summariesE", "14k_reduce_slabsE",
+                    "17k_reduce_partialsE", "13k_adam_polyakE", "k_skinny_wgrad", "14k_stream_wgradE", "17k_boot_lowerboundE",
+                    "12k_head_dgradE", "11k_act_layerE", "12k_act_policyI", "18k_act_policy_gaussI", "8k_onehotE", "k_im2col", "13k_col2im_maskE"],
     "ring.hip": ["k_gather_windows", "k_scatter_rows", "k_pack_slots", "k_mc_return", "k_her_relabel", "k_episode_expand", "k_her_vmap"],
 }
 
@@ -31,13 +39,14 @@ def isa():
     import isa_report
     if not os.path.exists(isa_report.HIPCC):
         pytest.skip("hipcc not available")
-    return isa_report.report(sorted(MUST_BE_CLEAN))
+    return isa_report.report(sorted(MAY_SPILL))
 
 
-@pytest.mark.parametrize("fname", sorted(MUST_BE_CLEAN))
+@pytest.mark.parametrize("fname", sorted(MAY_SPILL))
 def test_default_path_kernels_do_not_spill(isa, fname):
-    for pat in MUST_BE_CLEAN[fname]:
-        hits = [(name, d) for name, d in isa[fname] if pat in name]
-        assert hits, f"no kernel of {fname} matches {pat!r}"
-        for name, d in hits:
-            assert d["vgpr_spill"] == 0 and d["sgpr_spill"] == 0 and d["scratch"] == 0, (name, d)
+    for pat in MUST_EXIST[fname]:
+        assert any(pat in name for name, _ in isa[fname]), f"no kernel of {fname} matches {pat!r}"
+    for name, d in isa[fname]:
+        if any(pat in name for pat in MAY_SPILL[fname]):
+            continue
+        assert d["vgpr_spill"] == 0 and d["sgpr_spill"] == 0 and d["scratch"] == 0, (name, d)
