@@ -154,7 +154,7 @@ def summarize(d):
                 continue
             o = min(s1, k1) - max(s0, k0)
             ov += o
-            short = nm.split("(")[0][:70]
+            short = nm.replace("(anonymous namespace)::", "").split("(")[0][:70]
             beside[short] = beside.get(short, 0) + o
     print(f"{len(side)} stand-in launches, mean duration {tot / max(len(side), 1) / 1e3:.1f} us; "
           f"{100.0 * ov / max(tot, 1):.1f} % of their time a kernel of the main stream was running as well")
