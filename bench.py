@@ -126,14 +126,46 @@ class Job:
             n = min(fill_chunk, slots + 1000 - c0)
             self.ring.add_rows(synth_rows(w, n, 1000 * rank + c0 // fill_chunk, dev))
         assert len(self.ring) == slots - 1
-        self.outs = [torch.empty(T, B, d, device=dev) for d in self.dims]
-        self.xp = dict(zip(self.keys, self.outs))
+        # three persistent sample buffers: the batch in use, the one being gathered ahead, the one the previous update read
+        # (what Replay.make()'s shards give the facade: sample_buffers=3; the agent caches one launch plan per buffer set)
+        self.pool = [[torch.empty(T, B, d, device=dev) for d in self.dims] for _ in range(3)]
+        self.xps = [dict(zip(self.keys, outs)) for outs in self.pool]
+        self.outs, self.xp = self.pool[0], self.xps[0]
         self.seed = 1234 + rank
         self.rowbytes = 4 * sum(self.dims)
+        # FDQL_BENCH_PREFETCH=1: one batch ahead, like the reference's loader thread (torch_dataloader.py:40-50) - step i's
+        # update runs beside the gather of step i + 1 on a side stream.  Measured SLOWER on MI355X (797-803 against 810 steps/s,
+        # round 4: the gather's workgroups delay the persistent one-per-CU launches by more than the 12 us they hide), so the
+        # default is gather and update back to back on one stream.
+        self.prefetch = os.environ.get("FDQL_BENCH_PREFETCH") == "1"
+        self.side = torch.cuda.Stream(dev) if self.prefetch else None
+        self.ev_main = torch.cuda.Event()
+        self.ev_done = [torch.cuda.Event() for _ in range(3)]
+        self.pending_for = None
+
+    def sample(self, i):
+        """The batch of step i (index into pool / xps); with prefetch also issues the gather of step i + 1."""
+        k = i % 3
+        if not self.prefetch:
+            self.ring.sample_windows(self.T, self.B, seed=self.seed, counter=i, outs=self.pool[k])
+            return k
+        main = torch.cuda.current_stream(self.dev)
+        if self.pending_for == i:
+            main.wait_event(self.ev_done[k])
+        else:                                   # first step of a run: drawn in place
+            self.ring.sample_windows(self.T, self.B, seed=self.seed, counter=i, outs=self.pool[k])
+        k1 = (i + 1) % 3
+        self.ev_main.record(main)               # the update that last read pool[k1] (step i - 2) is behind this point
+        self.side.wait_event(self.ev_main)
+        with torch.cuda.stream(self.side):
+            self.ring.sample_windows(self.T, self.B, seed=self.seed, counter=i + 1, outs=self.pool[k1])
+            self.ev_done[k1].record(self.side)
+        self.pending_for = i + 1
+        return k
 
     def step(self, i):
-        self.ring.sample_windows(self.T, self.B, seed=self.seed, counter=i, outs=self.outs)
-        self.agent.update(self.xp, seed=self.seed)
+        k = self.sample(i)
+        self.agent.update(self.xps[k], seed=self.seed)
 
     def timed(self, steps, warmup, first=0):
         for i in range(warmup):
@@ -698,8 +730,8 @@ class DPRun:
         main_stream = torch.cuda.current_stream(self.dev)
         ev_a, ev_b, ev_red = self.ev
         grads = agent.grads
-        job.ring.sample_windows(job.T, job.B, seed=job.seed, counter=i, outs=job.outs)
-        agent.update(job.xp, seed=job.seed, phase=nat.PHASE_GRAD_CRITICS)
+        k = job.sample(i)
+        agent.update(job.xps[k], seed=job.seed, phase=nat.PHASE_GRAD_CRITICS)
         ev_a.record(main_stream)
         with torch.cuda.stream(side):
             side.wait_event(ev_a)

@@ -1936,6 +1936,7 @@ int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {
       if (d.dout == WG_N) nblk += copies * (feat / WG_N);
     };
     for (const MlpDesc &d : a->critic) count(d, 1);
+    const int nblk_critics = nblk;
     count(a->actor, 1); count(a->joiner, 1); count(a->enc_obs, 1);
     hipDeviceProp_t pr;
     int dev = 0;
@@ -1943,7 +1944,11 @@ int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {
         a->M / a->nsplit <= STREAM_WGRAD_MAX_SLAB_ROWS &&   // (long slabs keep the tile kernels' narrow launches, which want the splits)
         (long long)nblk * (a->M / WG_BM) >= a->wgrad_stat_factor * a->rows_min_tiles && hipGetDevice(&dev) == hipSuccess &&
         hipGetDeviceProperties(&pr, dev) == hipSuccess) {
-      const int want = std::max(8, pr.multiProcessorCount / nblk + 3);
+      // a data-parallel (two-bucket) plan launches the critics' blocks and the rest separately (at most one workgroup per slab
+      // and block): sized to the larger launch, the critics' (config 2: 10 blocks -> 28 slabs; the 5-block launch of the
+      // rest then runs 140 workgroups instead of 100)
+      const int per_launch = a->bucketed() && nblk_critics > 0 ? std::max(nblk_critics, nblk - nblk_critics) : nblk;
+      const int want = std::max(8, pr.multiProcessorCount / per_launch + 3);
       if (want < a->nsplit) a->nsplit = want;
     }
   }

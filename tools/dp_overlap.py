@@ -62,8 +62,8 @@ class Stepper:
         side = main if self.mode == "serial" else self.side
         e_a, e_b, e_red = self.ev
         n = agent.grads.numel()
-        job.ring.sample_windows(job.T, job.B, seed=job.seed, counter=i, outs=job.outs)
-        agent.update(job.xp, seed=job.seed, phase=nat.PHASE_GRAD_CRITICS)
+        k = job.sample(i)
+        agent.update(job.xps[k], seed=job.seed, phase=nat.PHASE_GRAD_CRITICS)
         e_a.record(main)
         side.wait_event(e_a)
         self.copy(self.bucket, n, side)

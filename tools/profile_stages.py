@@ -11,11 +11,12 @@ ap.add_argument("--obs", type=int, default=17); ap.add_argument("--act", type=in
 ap.add_argument("--C", type=int, default=5); ap.add_argument("--Q", type=int, default=2)
 ap.add_argument("--hid", type=int, default=256); ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--gru", default="", help="GRU joiner with this latent-state mode: zero | learned")
+ap.add_argument("--world", type=int, default=1, help="> 1: the data-parallel (two-bucket) plan of one rank")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 cfg = make_config(a.obs, a.act, a.T, a.B, n_critics=a.C, n_quantiles=a.Q, latent=a.hid, enc_features=a.hid,
                   enc_hidden=(a.hid,), joint_hidden=(a.hid,), pi_hidden=(a.hid,), critic_hidden=(a.hid, a.hid),
-                  joiner_gru=bool(a.gru), gru_state_mode=a.gru or 0)
+                  joiner_gru=bool(a.gru), gru_state_mode=a.gru or 0, world_size=a.world)
 ag = NativeAgent(cfg, dev); ag.init_weights(0)
 T, B = a.T, a.B
 xp = {"obs_1d": torch.randn(T, B, a.obs, device=dev), "action": torch.rand(T, B, a.act, device=dev) * 2 - 1,
