@@ -220,6 +220,7 @@ struct fdql_agent {
   int rowdgrad_max_blocks = 256;    // ... and may have: one round of workgroups (config 4 at B = 1024, 784 blocks = 3.06 rounds: the tile
                                     // kernel's 3136 tiles are the better fit there: 0.138 against 0.153 ms for d enc)
   int wgrad_stat_factor = 4;        // x rows_min_tiles 32-row tiles for the output-stationary weight-gradient launch (4 per workgroup)
+  int small_max_tiles = 128;        // a GEMM stage of at most this many 64x64 tiles runs on the small-batch kernel (smallgemm.hip); 0: never
   // d state = sum over the online critics and the actor: one problem accumulating every network's K-segments, or - few rows
   // (a handful of workgroups would walk all segments serially), or many rows with critics the weight-stationary kernel
   // takes (wstat.h, plain dgrad form) - one problem per network into partials + a reduction
@@ -449,6 +450,7 @@ void carve(fdql_agent *a) {
   a->alloc("dpi_part", (int64_t)c.n_critics * M * c.act_dim);
   a->alloc("loss_partials", (int64_t)loss_blocks((int)M, 256) * LOSS_NPART + (int64_t)M * LOSS_NPART + LOSS_NPART);
   a->alloc("slabs", (int64_t)a->nsplit * a->n_train);
+  a->alloc("loss_fin_args", 32);   // LossFinishArgs (update_kernels.h): k_loss's fused finish
   {   // fdql_agent_summaries: 4 scalars + one norm per trainable tensor, then the int64 (offset, count) table (8-byte aligned)
     int64_t nt = 0;
     for (const TensorInfo &t : a->tensors) nt += t.arena == 0;
@@ -978,10 +980,32 @@ int upload_tables(fdql_agent *a) {
           taken[i] = 1;
         }
       }
+      // Small batches (temporal_len 2, a handful of env rows): a stage whose problems are too few tiles to fill the chip is as
+      // long as one workgroup's serial K loop on the tile kernels; the small-batch kernel (smallgemm.hip) splits K over the 16
+      // waves of a workgroup instead.  Per stage: every problem left for the tile kernels must have the form, and together they
+      // are at most small_max_tiles 64x64 tiles (FDQL_SMALL_GEMM=0: never; FDQL_SMALL_GEMM_MAX_TILES).
+      // A non-default tile shape / main-loop build (tests, experiments) keeps its kernels; dense shape GEMM_SMALL (test hook)
+      // forces the small-batch kernel on every problem that has the form, whatever the size.
+      const int dshape = gemm_dense_shape();
+      const bool small_forced = dshape == GEMM_SMALL;
+      bool small = a->small_max_tiles > 0 && dshape == GEMM_64x64 && gemm_variant() == GEMM_DEFAULT_VARIANT;
+      long long tiles64 = 0;
+      for (size_t i = 0; i < s.gemm.size() && small; ++i) {
+        if (taken[i] == 1) continue;
+        small = gemm_small_takes(s.gemm[i]);
+        tiles64 += (long long)((s.gemm[i].M + 63) / 64) * ((s.gemm[i].N + 63) / 64);
+      }
+      // (short-K stages - the rank-Q outer product of a last hidden layer's gradient under a Q-wide head - are one load round per
+      // workgroup whatever their tile count: up to 4x the tiles)
+      int kmax = 0;
+      for (size_t i = 0; i < s.gemm.size(); ++i)
+        if (taken[i] != 1) { int k = 0; for (int sg = 0; sg < s.gemm[i].nseg; ++sg) k += s.gemm[i].seg[sg].K; kmax = std::max(kmax, k); }
+      small = small && tiles64 > 0 && (tiles64 <= a->small_max_tiles || (kmax <= 32 && tiles64 <= 4LL * a->small_max_tiles));
       for (size_t i = 0; i < s.gemm.size(); ++i) {
         if (taken[i] == 1) continue;
         if (s.gemm[i].fz_h) { set_error("stage %s: a fused head-dgrad problem was not taken by the row-block kernel", s.name.c_str()); return FDQL_ESTATE; }
-        s.sub[gemm_pick_shape(s.gemm[i], gemm_dense_shape())].probs.push_back(s.gemm[i]);
+        const bool sm = small || (small_forced && gemm_small_takes(s.gemm[i]));
+        s.sub[sm ? (int)GEMM_SMALL : gemm_pick_shape(s.gemm[i], small_forced ? (int)GEMM_64x64 : dshape)].probs.push_back(s.gemm[i]);
       }
       for (auto &sub : s.sub) total += pad(sub.probs.size() * sizeof(GemmProblem));
     }
@@ -1107,6 +1131,9 @@ int build_plan(fdql_agent *a) {
   const float *log_alpha = params + a->log_alpha_off;
 
   // ---- stage 0: tick + prep
+  bool fold_prep = false;
+  PrepArgs prep_args;
+  memset(&prep_args, 0, sizeof(prep_args));
   {
     const float inv_gb = 1.0f / (float)(B * (c.world_size > 0 ? c.world_size : 1));
     float *w = a->buf("w"), *ic = a->buf("is_contiguous");
@@ -1114,7 +1141,11 @@ int build_plan(fdql_agent *a) {
     const int T = a->T;
     const int burn = c.burn_in_steps;
     const int cumprod = gru ? 1 : 0;   // encoder.py:80
-    b.func_stage("prep", [=](hipStream_t s) { return prep_launch(td, es, T, B, burn, cumprod, inv_gb, w, ic, dst, log_alpha, s); });
+    // continuous policies: prep's workgroups ride in the policy-forward launch (nothing before the loss reads what it writes)
+    fold_prep = !c.discrete && getenv("FDQL_NO_PREP_FOLD") == nullptr;
+    prep_args = PrepArgs{td, es, T, B, burn, cumprod, inv_gb, w, ic, dst, log_alpha};
+    if (!fold_prep)
+      b.func_stage("prep", [=](hipStream_t s) { return prep_launch(td, es, T, B, burn, cumprod, inv_gb, w, ic, dst, log_alpha, s); });
     if (c.discrete) {   // stored action index -> one-hot critic input (deepQlearning.py:206-210)
       const float *act = x.action;
       float *oh = a->buf("action_onehot");
@@ -1240,11 +1271,13 @@ int build_plan(fdql_agent *a) {
     PolicyFwdArgs p1{ao.out, nullptr, a->buf("noise_actor"), a->buf("pi"), a->buf("log_pi"), 1u,
                      c.discrete ? a->buf("action_onehot") : x.action, a->buf("pi_diff")};
     fdql_agent *ag = a;
+    const PrepArgs pra = prep_args;
+    const bool with_prep = fold_prep;
     b.func_stage("policy_fwd", [=](hipStream_t s) {
       PolicyFwdArgs q0 = p0, q1 = p1;
       q0.noise = ag->noise_t;
       q1.noise = ag->noise_a;
-      return policy_fwd_launch(q0, q1, 2, M, A, dst, ag->seed, ag->cfg.discrete, s);
+      return policy_fwd_launch(q0, q1, 2, M, A, dst, ag->seed, ag->cfg.discrete, s, with_prep ? &pra : nullptr);
     });
   }
   // ---- critics forward: target(next, a'), online(cur, a), frozen(cur, pi)
@@ -1392,8 +1425,20 @@ int build_plan(fdql_agent *a) {
     la.w = a->buf("w"); la.dz = a->buf("dz"); la.dzf = a->buf("dzf"); la.td_target = a->buf("td_target");
     la.q_loss = a->buf("q_loss"); la.pi_loss = a->buf("pi_loss"); la.alpha_loss = a->buf("alpha_loss");
     la.partials = a->buf("loss_partials");
-    b.func_stage("loss", [=](hipStream_t s) { return loss_launch(la, s); });
     int nblocks = loss_blocks(M, G);
+    // few workgroups (temporal_len 2): the last one to finish also sums the partial rows (kernels.hip, LossFinishArgs) - one
+    // launch less; many workgroups would serialise on the arrival counter (round 2: ~80 ns per atomic)
+    const bool fuse_finish = nblocks <= 64 && !c.bootstrap_nstep && getenv("FDQL_NO_LOSS_FINISH_FUSE") == nullptr;
+    if (fuse_finish) {
+      LossFinishArgs fa;
+      memset(&fa, 0, sizeof(fa));
+      fa.nblocks = nblocks; fa.M = M; fa.Nq = Nq; fa.st = dst; fa.scalars = a->buf("scalars");
+      fa.dlog_alpha = a->buf("slabs") + a->log_alpha_off; fa.lr = c.lr; fa.b1 = c.beta1; fa.b2 = c.beta2;
+      LossFinishArgs *fdev = reinterpret_cast<LossFinishArgs *>(a->buf("loss_fin_args"));
+      FDQL_HIP(hipMemcpy(fdev, &fa, sizeof(fa), hipMemcpyHostToDevice));
+      la.fin = fdev;
+    }
+    b.func_stage("loss", [=](hipStream_t s) { return loss_launch(la, s); });
     if (c.bootstrap_nstep) {   // soft_actor_critic.py:102-132: its loss value rides as one more partial row
       BootArgs ba;
       memset(&ba, 0, sizeof(ba));
@@ -1410,7 +1455,8 @@ int build_plan(fdql_agent *a) {
     const float *parts = la.partials;
     // also the Adam bias corrections of the step about to be applied (torch.optim.Adam's Python floats)
     const double lr = c.lr, b1 = c.beta1, b2 = c.beta2;
-    b.func_stage("loss_finish", [=](hipStream_t s) { return loss_finish_launch(parts, nblocks, M, Nq, dst, scal, dla, lr, b1, b2, s); });
+    if (!fuse_finish)
+      b.func_stage("loss_finish", [=](hipStream_t s) { return loss_finish_launch(parts, nblocks, M, Nq, dst, scal, dla, lr, b1, b2, s); });
   }
   // ---- critic backward (online: wgrad + d state; frozen: d pi only)
   {
@@ -1446,8 +1492,12 @@ int build_plan(fdql_agent *a) {
             for (MlpInst *m : {&co[k], &cf[k]}) m->dpre_cs_rows[0] = m->dpre_cs_rows[1] = wstat_colsum_rows(rl.wa);
       }
     }
+    // few rows (temporal_len 2): the last layer's rank-Q product as GEMM problems on the small-batch kernel (one load round per
+    // workgroup) instead of the streaming kernel's row loop: 0.022 -> 0.011 ms at 256 rows
+    const bool head_dgrad_as_gemm = a->small_max_tiles > 0 && gemm_dense_shape() == GEMM_64x64 && gemm_variant() == GEMM_DEFAULT_VARIANT &&
+                                    (long long)2 * C * ((M + 63) / 64) * ((a->critic[0].hid.empty() ? 0 : a->critic[0].hid.back()) + 63) / 64 <= 4LL * a->small_max_tiles;
     for (int i = (int)nh - 1; i >= 0 && !fused1; --i) {
-      if (Builder::narrow_head_last(a->critic[0], i)) {
+      if (Builder::narrow_head_last(a->critic[0], i) && !head_dgrad_as_gemm) {
         Stage st;
         st.kind = ST_HEAD_DGRAD; st.name = "critics.dpre" + std::to_string(i);
         for (int k = 0; k < C; ++k) {
@@ -1903,6 +1953,8 @@ int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {
     else if (r && !strcmp(r, "all")) a->rows_min_tiles = 1;
     else if (r && atoi(r) > 1) a->rows_min_tiles = atoi(r);
     if (const char *f = getenv("FDQL_WGRAD_STAT_FACTOR")) { if (atoi(f) >= 1) a->wgrad_stat_factor = atoi(f); }
+    if (const char *f = getenv("FDQL_SMALL_GEMM")) { if (f[0] == '0') a->small_max_tiles = 0; }
+    if (const char *f = getenv("FDQL_SMALL_GEMM_MAX_TILES")) { if (atoi(f) >= 0) a->small_max_tiles = atoi(f); }
     if (const char *f = getenv("FDQL_ROWDGRAD_MIN_BLOCKS")) { if (atoi(f) >= 1) a->rowdgrad_min_blocks = atoi(f); }
     if (const char *f = getenv("FDQL_ROWDGRAD_MAX_BLOCKS")) { if (atoi(f) >= 1) a->rowdgrad_max_blocks = atoi(f); }
   }
@@ -1962,6 +2014,8 @@ int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {
     for (const MlpDesc &d : a->critic) ws_ok = ws_ok && !d.hid.empty() && d.hid[0] == WS_N;
     ws_ok = ws_ok && c.latent == WS_N && a->M % WS_BM == 0 && c.n_critics <= WS_MAX_INST && c.n_quantiles <= 32 &&
             (long long)c.n_critics * (a->M / RG_BM) >= a->rows_min_tiles;
+    // (few rows: one problem per network + a summing pass also beats the one-problem form on the small-batch kernel, whose
+    // slices would walk 2 (C + 1) K-segments in four serial load passes: 0.344 against 0.325 ms per temporal_len-2 step)
     a->dstate_split = a->M <= DSTATE_SPLIT_MAX_ROWS || ws_ok;
   }
   carve(a);
@@ -2130,7 +2184,7 @@ int32_t fdql_agent_profile_update(fdql_agent_t *a, const fdql_batch_t *batch, co
     FDQL_HIP(hipEventRecord(ev[i + 1], s));
   }
   FDQL_HIP(hipStreamSynchronize(s));
-  static const char *shape_names[GEMM_NSHAPES] = {"128x128", "128x32", "32x128", "64x128", "64x64dual", "64x64", "64x64hf", "dma128x128", "dma128x64", "dma64x64"};
+  static const char *shape_names[GEMM_NSHAPES] = {"128x128", "128x32", "32x128", "64x128", "64x64dual", "64x64", "64x64hf", "dma128x128", "dma128x64", "dma64x64", "small"};
   int32_t cnt = 0;
   for (size_t i = 0; i < n && cnt < cap; ++i, ++cnt) {
     float ms = 0;
@@ -2477,7 +2531,8 @@ int fdql_debug_set_gemm_variant(int32_t variant) {
 }
 
 int fdql_debug_set_gemm_dense_shape(int32_t shape) {
-  FDQL_REQUIRE(gemm_shape_is_dense(shape), "dense shape must be 0 (128x128), 3 (64x128), 5 (64x64) or an LDS-DMA shape 7 (128x128), 8 (128x64), 9 (64x64)");
+  FDQL_REQUIRE(gemm_shape_is_dense(shape) || shape == GEMM_SMALL,
+               "dense shape must be 0 (128x128), 3 (64x128), 5 (64x64), an LDS-DMA shape 7 (128x128), 8 (128x64), 9 (64x64), or 10 (the small-batch kernel wherever it has the form)");
   gemm_set_dense_shape(shape);
   return 0;
 }

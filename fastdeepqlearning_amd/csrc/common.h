@@ -55,7 +55,8 @@ struct GemmSeg {
 
 enum GemmEpilogue { EPI_NONE = 0, EPI_LRELU = 1, EPI_LRELU_GRAD = 2, EPI_ADD_REF = 3 /* x += ref[row][col] */ };
 enum GemmShape { GEMM_128x128 = 0, GEMM_128x32 = 1, GEMM_32x128 = 2, GEMM_64x128 = 3, GEMM_64x128_DUAL = 4, GEMM_64x64 = 5, GEMM_64x64_HF = 6,
-                 GEMM_DMA_128x128 = 7, GEMM_DMA_128x64 = 8, GEMM_DMA_64x64 = 9 /* LDS-DMA staged dense shapes */, GEMM_NSHAPES = 10 };
+                 GEMM_DMA_128x128 = 7, GEMM_DMA_128x64 = 8, GEMM_DMA_64x64 = 9 /* LDS-DMA staged dense shapes */,
+                 GEMM_SMALL = 10 /* smallgemm.hip: 64x32 tiles, K split over the 16 waves of a workgroup (small batches) */, GEMM_NSHAPES = 11 };
 
 struct GemmProblem {
   int M, N;
@@ -102,6 +103,9 @@ double gemm_flops(const GemmProblem &p);
 double gemm_bytes(const GemmProblem &p);
 // probs_dev: device copy of the finalized group (all problems of one tile shape).
 hipError_t gemm_launch(const GemmProblem *probs_dev, int nprob, int total_blocks, int shape, hipStream_t stream);
+// Small-batch kernel (smallgemm.hip): does it take the problem's form (no K-split slabs, no second output / head fusion)?
+bool gemm_small_takes(const GemmProblem &p);
+hipError_t gemm_small_launch(const GemmProblem *probs_dev, int nprob, int total_blocks, hipStream_t stream);
 constexpr int GEMM_DEFAULT_VARIANT = 1;
 int gemm_variant();
 void gemm_set_variant(int v);

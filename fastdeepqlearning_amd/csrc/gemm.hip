@@ -1142,6 +1142,7 @@ __global__ __launch_bounds__(GEMM_THREADS, DmaCfg<SHAPE>::MINB) void k_gemm_dma(
 }
 
 static void shape_dims(int shape, int &bm, int &bn) {
+  if (shape == GEMM_SMALL) { bm = 64; bn = 32; return; }
   if (shape == GEMM_DMA_128x128) { bm = 128; bn = 128; return; }
   if (shape == GEMM_DMA_128x64) { bm = 128; bn = 64; return; }
   if (shape == GEMM_DMA_64x64) { bm = 64; bn = 64; return; }
@@ -1183,6 +1184,10 @@ int gemm_dense_shape() {
 static bool shape_is_dma(int shape) { return shape == GEMM_DMA_128x128 || shape == GEMM_DMA_128x64 || shape == GEMM_DMA_64x64; }
 
 int gemm_pick_shape(const GemmProblem &p, int dense_shape) {
+  if (dense_shape == GEMM_SMALL) {   // test hook: the small-batch kernel wherever it has the form, else the default shapes
+    if (gemm_small_takes(p)) return GEMM_SMALL;
+    dense_shape = GEMM_64x64;
+  }
   if (shape_is_dma(dense_shape)) {   // dual outputs and the head-fusion epilogue are run-time features of that kernel
     if (p.emit_seg >= 0 || p.hf_w) return dense_shape;
   } else {
@@ -1244,6 +1249,7 @@ void gemm_set_variant(int v) { g_variant = v; }
 
 hipError_t gemm_launch(const GemmProblem *probs_dev, int nprob, int total_blocks, int shape, hipStream_t stream) {
   if (total_blocks <= 0) return hipSuccess;
+  if (shape == GEMM_SMALL) return gemm_small_launch(probs_dev, nprob, total_blocks, stream);
   if (shape_is_dma(shape)) {
     const dim3 g(total_blocks), b(GEMM_THREADS);
     if (shape == GEMM_DMA_128x128) hipLaunchKernelGGL((k_gemm_dma<GEMM_DMA_128x128>), g, b, 0, stream, probs_dev, nprob);

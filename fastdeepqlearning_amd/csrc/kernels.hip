@@ -469,19 +469,20 @@ __device__ __forceinline__ float device_noise(uint64_t seed, uint32_t step, uint
 //   deepQlearning.py:201-203, 222-225, 249
 // ======================================================================================
 // block = 16 windows x 16 time lanes; consecutive threads -> consecutive b (coalesced rows)
-__global__ __launch_bounds__(256) void k_prep(const float *__restrict__ task_done, const float *__restrict__ episode_step,
-                                              int T, int B, int burn_in, int cumprod, float inv_global_batch,
-                                              float *__restrict__ w, float *__restrict__ contig, DevState *st,
-                                              const float *log_alpha) {
+// (workgroup `blk` of (B + 15) / 16, 256 threads; also runs as extra workgroups of the policy-forward launch: PrepArgs)
+__device__ __forceinline__ void prep_block(int blk, const float *__restrict__ task_done, const float *__restrict__ episode_step,
+                                           int T, int B, int burn_in, int cumprod, float inv_global_batch,
+                                           float *__restrict__ w, float *__restrict__ contig, DevState *st,
+                                           const float *log_alpha) {
   // get_losses() side effect in the reference: curr_alpha <- exp(log_alpha) AFTER it was used (soft_actor_critic.py:152);
   // rides in this launch (nothing here reads alpha) instead of a one-thread kernel of its own
-  if (st && blockIdx.x == 0 && threadIdx.x == 0) {
+  if (st && blk == 0 && threadIdx.x == 0) {
     st->alpha_cur = st->alpha_next;
     st->alpha_next = expf(*log_alpha);
   }
   __shared__ float cnt[16][17];
   const int bl = threadIdx.x & 15, tl = threadIdx.x >> 4;
-  const int b = blockIdx.x * 16 + bl;
+  const int b = blk * 16 + bl;
   float c_local = 0.f;
   if (b < B) {
     if (cumprod) {
@@ -522,6 +523,13 @@ __global__ __launch_bounds__(256) void k_prep(const float *__restrict__ task_don
   }
 }
 
+__global__ __launch_bounds__(256) void k_prep(const float *__restrict__ task_done, const float *__restrict__ episode_step,
+                                              int T, int B, int burn_in, int cumprod, float inv_global_batch,
+                                              float *__restrict__ w, float *__restrict__ contig, DevState *st,
+                                              const float *log_alpha) {
+  prep_block((int)blockIdx.x, task_done, episode_step, T, B, burn_in, cumprod, inv_global_batch, w, contig, st, log_alpha);
+}
+
 // ======================================================================================
 // tick: optimiser step counter, Adam bias corrections (double, like the Python floats in
 // torch.optim.Adam), and the one-step-lagged alpha (soft_actor_critic.py:41,152)
@@ -543,10 +551,17 @@ __device__ void tick_adam(DevState *st, double lr, double b1, double b2) {
 // thread per ROW (six elements in sequence, 392 waves for 12 544 rows x 2 passes) the kernel was one long dependent
 // instruction stream per SIMD: 12 us.  AG = lanes per row (power of two >= A); the row's log-prob is summed by the row's first
 // lane in the order j = 0, 1, ... (the order of the sequential loop this replaces).
+// pr.nblocks > 0: the launch carries that many extra 256-thread workgroups behind its own, which do k_prep's work (nothing
+// here reads what prep writes: row weights, is_contiguous, the lagged alpha) - one launch less in a latency-bound step.
 template <int AG>
-__global__ void k_policy_fwd(PolicyFwdArgs a0, PolicyFwdArgs a1, int nprob, int M, int A, const DevState *st,
-                             uint64_t seed) {
+__global__ __launch_bounds__(256) void k_policy_fwd(PolicyFwdArgs a0, PolicyFwdArgs a1, int nprob, int M, int A, const DevState *st,
+                                                    uint64_t seed, PrepArgs pr, int own_blocks) {
 #pragma clang fp contract(off)
+  if ((int)blockIdx.x >= own_blocks) {   // uniform
+    prep_block((int)blockIdx.x - own_blocks, pr.task_done, pr.episode_step, pr.T, pr.B, pr.burn_in, pr.cumprod, pr.inv_global_batch,
+               pr.w, pr.contig, pr.st, pr.log_alpha);
+    return;
+  }
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int rowid = gid / AG, j = gid - rowid * AG;
   const int p = rowid / M;
@@ -754,6 +769,9 @@ __device__ __forceinline__ float group_sum(float v, float *scratch, int g, int i
   return r;
 }
 
+__device__ __forceinline__ void loss_finish_block(const float *__restrict__ partials, int nblocks, int M, int Nq, DevState *st,
+                                                  float *__restrict__ scalars, float *__restrict__ dlog_alpha, double lr, double b1, double b2);
+
 __global__ __launch_bounds__(256) void k_loss(LossArgs a) {
   extern __shared__ float sm[];
   const int G = a.G, RPB = 256 / G;
@@ -875,6 +893,19 @@ __global__ __launch_bounds__(256) void k_loss(LossArgs a) {
     for (int r = 0; r < RPB; ++r) s += bsum[r * LOSS_NPART + tid];
     a.partials[(long long)blockIdx.x * LOSS_NPART + tid] = s;
   }
+  if (a.fin) {   // (uniform) fused finish: the last workgroup to arrive sums all partial rows
+    __shared__ int is_last;
+    __threadfence();                       // this workgroup's row is visible device-wide before it is counted
+    __syncthreads();
+    const LossFinishArgs f = *a.fin;
+    if (tid == 0) is_last = atomicAdd(&f.st->loss_blocks_done, 1u) + 1u == (unsigned)gridDim.x;
+    __syncthreads();
+    if (is_last) {
+      __threadfence();
+      loss_finish_block(a.partials, f.nblocks, f.M, f.Nq, f.st, f.scalars, f.dlog_alpha, f.lr, f.b1, f.b2);
+      if (tid == 0) f.st->loss_blocks_done = 0u;   // ready for the next step
+    }
+  }
 }
 
 hipError_t loss_launch(const LossArgs &a, hipStream_t s) {
@@ -886,9 +917,9 @@ hipError_t loss_launch(const LossArgs &a, hipStream_t s) {
 }
 
 // Sums the per-block partials in a fixed order; publishes the scalars and d log_alpha.
-__global__ __launch_bounds__(256) void k_loss_finish(const float *__restrict__ partials, int nblocks, int M, int Nq,
-                                                     DevState *st, float *__restrict__ scalars,
-                                                     float *__restrict__ dlog_alpha, double lr, double b1, double b2) {
+__device__ __forceinline__ void loss_finish_block(const float *__restrict__ partials, int nblocks, int M, int Nq,
+                                                  DevState *st, float *__restrict__ scalars,
+                                                  float *__restrict__ dlog_alpha, double lr, double b1, double b2) {
   __shared__ float red[256][LOSS_NPART];
   if (threadIdx.x == 255) tick_adam(st, lr, b1, b2);
   const int tid = threadIdx.x;
@@ -918,6 +949,11 @@ __global__ __launch_bounds__(256) void k_loss_finish(const float *__restrict__ p
     scalars[7] = (float)st->step;
     *dlog_alpha = red[0][6];
   }
+}
+__global__ __launch_bounds__(256) void k_loss_finish(const float *__restrict__ partials, int nblocks, int M, int Nq,
+                                                     DevState *st, float *__restrict__ scalars,
+                                                     float *__restrict__ dlog_alpha, double lr, double b1, double b2) {
+  loss_finish_block(partials, nblocks, M, Nq, st, scalars, dlog_alpha, lr, b1, b2);
 }
 
 // window-long n-step lower bound on q(t=0): one thread per window walks its T-1 transitions
@@ -1078,17 +1114,28 @@ hipError_t prep_launch(const float *task_done, const float *episode_step, int T,
 }
 
 hipError_t policy_fwd_launch(const PolicyFwdArgs &a0, const PolicyFwdArgs &a1, int nprob, int M, int A,
-                             const DevState *st, uint64_t seed, int discrete, hipStream_t s) {
+                             const DevState *st, uint64_t seed, int discrete, hipStream_t s, const PrepArgs *prep) {
   const int total = nprob * M;
+  PrepArgs pr = {};
+  if (prep && !discrete) pr = *prep;
+  else if (prep) {   // (the Gumbel kernel has its own block shape: prep stays a launch of its own)
+    hipError_t e = prep_launch(prep->task_done, prep->episode_step, prep->T, prep->B, prep->burn_in, prep->cumprod, prep->inv_global_batch,
+                               prep->w, prep->contig, prep->st, prep->log_alpha, s);
+    if (e != hipSuccess) return e;
+  }
+  const int extra = pr.B > 0 ? (pr.B + 15) / 16 : 0;
   if (discrete)
     hipLaunchKernelGGL(k_policy_fwd_gumbel, dim3((total + 63) / 64), dim3(64), 0, s, a0, a1, nprob, M, A, st, seed);
-  else if (A <= 8)
-    hipLaunchKernelGGL(k_policy_fwd<8>, dim3((unsigned)(((long long)total * 8 + 255) / 256)), dim3(256), 0, s, a0, a1, nprob, M, A, st, seed);
-  else if (A <= 32)
-    hipLaunchKernelGGL(k_policy_fwd<32>, dim3((unsigned)(((long long)total * 32 + 255) / 256)), dim3(256), 0, s, a0, a1, nprob, M, A, st, seed);
-  else if (A <= 64)
-    hipLaunchKernelGGL(k_policy_fwd<64>, dim3((unsigned)(((long long)total * 64 + 255) / 256)), dim3(256), 0, s, a0, a1, nprob, M, A, st, seed);
-  else
+  else if (A <= 8) {
+    const int own = (int)(((long long)total * 8 + 255) / 256);
+    hipLaunchKernelGGL(k_policy_fwd<8>, dim3((unsigned)(own + extra)), dim3(256), 0, s, a0, a1, nprob, M, A, st, seed, pr, own);
+  } else if (A <= 32) {
+    const int own = (int)(((long long)total * 32 + 255) / 256);
+    hipLaunchKernelGGL(k_policy_fwd<32>, dim3((unsigned)(own + extra)), dim3(256), 0, s, a0, a1, nprob, M, A, st, seed, pr, own);
+  } else if (A <= 64) {
+    const int own = (int)(((long long)total * 64 + 255) / 256);
+    hipLaunchKernelGGL(k_policy_fwd<64>, dim3((unsigned)(own + extra)), dim3(256), 0, s, a0, a1, nprob, M, A, st, seed, pr, own);
+  } else
     return hipErrorInvalidValue;   // (act_dim <= 64 is checked at fdql_agent_create)
   return hipGetLastError();
 }
@@ -1450,35 +1497,48 @@ hipError_t summaries_launch(const float *q_pred, int M, int Nq, const float *ic,
 
 // dst[rows, cols] = sum over nparts partials of the same shape, + column sums of dst per 32-row block (cs [ceil(rows/32), cols]):
 // the sum of the per-network shares of an input gradient, and the bias-gradient partials of the layer that produced its input.
-// One workgroup per 32-row block: thread -> (row phase t / 64, float4 column group t % 64 + 64 j).  cols % 4 == 0.
+// One 1024-thread workgroup per 32-row block: thread -> (row phase t / 64: rows r0 + ph and r0 + ph + 16, float4 column
+// group t % 64 + 64 j); every share of both rows is requested before the first add (the round-3 form - 256 threads, 8 rows
+// per thread, a share at a time - was 8 x nparts dependent round trips: 16 us for 256 rows).  cols % 4 == 0.
 typedef float rp_v4f __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void k_sum_parts_colsum(const float *__restrict__ part, int nparts, int rows, int cols,
-                                                          float *__restrict__ dst, float *__restrict__ cs) {
-  __shared__ rp_v4f red[4][64];
+__global__ __launch_bounds__(1024) void k_sum_parts_colsum(const float *__restrict__ part, int nparts, int rows, int cols,
+                                                           float *__restrict__ dst, float *__restrict__ cs) {
+  __shared__ rp_v4f red[16][64];
   const int g = threadIdx.x & 63, ph = threadIdx.x >> 6;
   const int r0 = blockIdx.x * 32;
   const long long n = (long long)rows * cols;
   for (int c4 = g; c4 * 4 < cols; c4 += 64) {
     rp_v4f colsum = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int i = 0; i < 8; ++i) {
-      const int r = r0 + ph + 4 * i;
-      if (r < rows) {
-        const long long e = (long long)r * cols + 4 * c4;
-        rp_v4f v = *reinterpret_cast<const rp_v4f *>(part + e);
-        for (int p = 1; p < nparts; ++p) v += *reinterpret_cast<const rp_v4f *>(part + (long long)p * n + e);
-        *reinterpret_cast<rp_v4f *>(dst + e) = v;
-        colsum += v;
+    const int ra = r0 + ph, rb = r0 + ph + 16;
+    const long long ea = (long long)(ra < rows ? ra : rows - 1) * cols + 4 * c4, eb = (long long)(rb < rows ? rb : rows - 1) * cols + 4 * c4;
+    rp_v4f va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+    for (int p0 = 0; p0 < nparts; p0 += 8) {   // shares in rounds of eight, added in index order
+      rp_v4f xa[8], xb[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const long long po = (long long)(p0 + u < nparts ? p0 + u : nparts - 1) * n;
+        xa[u] = *reinterpret_cast<const rp_v4f *>(part + po + ea);
+        xb[u] = *reinterpret_cast<const rp_v4f *>(part + po + eb);
       }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (p0 + u < nparts) { va += xa[u]; vb += xb[u]; }
     }
+    if (ra < rows) { *reinterpret_cast<rp_v4f *>(dst + ea) = va; colsum += va; }
+    if (rb < rows) { *reinterpret_cast<rp_v4f *>(dst + eb) = vb; colsum += vb; }
     red[ph][g] = colsum;
     __syncthreads();
-    if (ph == 0) *reinterpret_cast<rp_v4f *>(cs + (long long)blockIdx.x * cols + 4 * c4) = (red[0][g] + red[1][g]) + (red[2][g] + red[3][g]);
+    if (ph == 0) {
+      rp_v4f t = red[0][g];
+#pragma unroll
+      for (int j = 1; j < 16; ++j) t += red[j][g];
+      *reinterpret_cast<rp_v4f *>(cs + (long long)blockIdx.x * cols + 4 * c4) = t;
+    }
     __syncthreads();
   }
 }
 hipError_t sum_parts_colsum_launch(const float *part, int nparts, int rows, int cols, float *dst, float *cs, hipStream_t s) {
-  hipLaunchKernelGGL(k_sum_parts_colsum, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, s, part, nparts, rows, cols, dst, cs);
+  hipLaunchKernelGGL(k_sum_parts_colsum, dim3((unsigned)((rows + 31) / 32)), dim3(1024), 0, s, part, nparts, rows, cols, dst, cs);
   return hipGetLastError();
 }
 hipError_t reduce_partials_launch(const float *part, int nparts, long long n, float *dst, hipStream_t s) {

@@ -11,7 +11,8 @@ struct DevState {
   float alpha_next;
   float neg_step_size;  // -lr / (1 - beta1^(step+1)): of the step about to be applied (k_loss_finish)
   float bc2_sqrt;       // sqrt(1 - beta2^(step+1))
-  float pad[3];
+  unsigned loss_blocks_done;   // k_loss workgroups that have published their partial row (fused finish; back to 0 when the step's loss is done)
+  float pad[2];
 };
 
 constexpr int LOSS_NPART = 8;
@@ -44,6 +45,15 @@ struct LossArgs {
   float *td_target;        // [M, Nt]
   float *q_loss, *pi_loss, *alpha_loss;  // [M]
   float *partials;         // [blocks, LOSS_NPART]
+  // optional (few workgroups: temporal_len 2): the LAST workgroup to publish its partial row also does k_loss_finish's work
+  // - one launch less in a latency-bound step; the partial rows are summed in the same fixed order either way
+  const struct LossFinishArgs *fin;
+};
+struct LossFinishArgs {   // lives in the workspace (one pointer in the kernel arguments)
+  int nblocks, M, Nq, pad;
+  DevState *st;
+  float *scalars, *dlog_alpha;
+  double lr, b1, b2;
 };
 
 struct AdamArgs {
@@ -211,8 +221,18 @@ hipError_t gru_cell_bwd_launch(const float *dstate, const float *carry_a, const 
                                float *dh_direct, int rows, int L, hipStream_t s);
 // d encoder.hidden_state[l] = sum_b (a[b][l] + b[b][l])  (learned start state), fixed order
 hipError_t gru_dh0_launch(const float *a, const float *b, int nparts_b, int B, int L, float *out, hipStream_t s);
+// prep: optional - the work of prep_launch as extra workgroups of this launch (continuous policies; a launch of its own
+// in front of the Gumbel kernel)
+struct PrepArgs {
+  const float *task_done, *episode_step;
+  int T, B, burn_in, cumprod;
+  float inv_global_batch;
+  float *w, *contig;
+  DevState *st;
+  const float *log_alpha;
+};
 hipError_t policy_fwd_launch(const PolicyFwdArgs &a0, const PolicyFwdArgs &a1, int nprob, int M, int A,
-                             const DevState *st, uint64_t seed, int discrete, hipStream_t s);
+                             const DevState *st, uint64_t seed, int discrete, hipStream_t s, const PrepArgs *prep = nullptr);
 hipError_t onehot_launch(const float *action, int rows, int n, float *out, hipStream_t s);
 hipError_t policy_bwd_launch(const float *logits, const float *noise, const float *action, const float *dpi_parts,
                              int nparts, float *dpi_sum, const float *w, const DevState *st, int M, int A,

@@ -426,7 +426,8 @@ int fdql_debug_side_copy(const float *src, float *dst, int64_t n, int32_t workgr
  * 64x64 tile shapes and 16 otherwise, 6 = K-chunk 16 for every shape, 0 = K-chunk 16 without the prefetch, 4 = K-chunk 8, 5 = b128 fragments; 2 and 3
  * alias 0.  Affects speed only. */
 int fdql_debug_set_gemm_variant(int32_t variant);
-/* Tuning / test hook: tile shape of the dense problems: 5 = 64x64 (default), 3 = 64x128, 0 = 128x128.
+/* Tuning / test hook: tile shape of the dense problems: 5 = 64x64 (default), 3 = 64x128, 0 = 128x128, 7 / 8 / 9 = the LDS-DMA
+ * builds, 10 = the small-batch kernel (csrc/smallgemm.hip) on every problem that has its form, whatever the size.
  * Applies to plans built afterwards and to fdql_test_gemm. */
 int fdql_debug_set_gemm_dense_shape(int32_t shape);
 

@@ -38,7 +38,7 @@ def dev():
 @pytest.mark.parametrize("M,N,K", [(128, 128, 16), (256, 256, 256), (200, 70, 33), (1000, 262, 258), (64, 6, 300),
                                    (513, 129, 17), (1024, 384, 272)])
 @pytest.mark.parametrize("form", ["nt", "nn", "tn"])
-@pytest.mark.parametrize("dense", [7, 8, 9, 5, 3, 0])     # LDS-DMA 128x128 / 128x64 / 64x64; register-staged 64x64, 64x128, 128x128
+@pytest.mark.parametrize("dense", [7, 8, 9, 5, 3, 0, 10])     # LDS-DMA 128x128 / 128x64 / 64x64; register-staged 64x64, 64x128, 128x128; small-batch kernel
 def test_gemm_forms(dev, M, N, K, form, dense):
     from fastdeepqlearning_amd import _native as nat
     lib = nat.load()
@@ -504,6 +504,18 @@ def test_update_matches_oracle_config2(dev, T, B, hid):
      "form, plain two-segment form, column sums)", dict(obs=17, act=6, C=5, Q=2, T=5, B=64, env={"FDQL_ROWDGRAD_MIN_BLOCKS": "1"})),
     ("config 2 dims at T=4, B=64 on the tile kernel's K-chunk-16 build for every shape (FDQL_GEMM_VARIANT=6, FDQL_ROWGEMM=0: the "
      "default takes K-chunk 32 on the 64x64 shapes)", dict(obs=17, act=6, C=5, Q=2, T=4, B=64, gemm_variant=6, env={"FDQL_ROWGEMM": "0"})),
+    ("temporal_len 2 at config 2 dims, B=256 (512 rows): every GEMM stage that is not a row-block launch on the small-batch "
+     "kernel (smallgemm.hip: K split over the waves of a workgroup; forward with K-segments, gated dgrads + column sums, "
+     "weight gradients, d state shares)", dict(obs=17, act=6, C=5, Q=2, T=2, B=256)),
+    ("temporal_len 2, B=7, goal-conditioned rows, 25-quantile heads (partial 64-row tiles, 17-wide and 10-wide K-segments, "
+     "unaligned head rows on the small-batch kernel)", dict(obs=28, goal=10, act=17, C=3, Q=25, T=2, B=7)),
+    ("config 2 dims at T=6, B=64 with the small-batch kernel forced on every problem that has its form (dense shape 10: "
+     "320-row problems, the dual / head-fusion problems stay on their tile shapes)", dict(obs=17, act=6, C=5, Q=2, T=6, B=64, dense_shape=10)),
+    ("temporal_len 2 at config 2 dims on the tile kernels (FDQL_SMALL_GEMM=0: the path the small-batch kernel replaces)",
+     dict(obs=17, act=6, C=5, Q=2, T=2, B=256, env={"FDQL_SMALL_GEMM": "0"})),
+    ("ragged sizes on the tile kernels (FDQL_SMALL_GEMM=0; B=7, odd widths 18/33/21: unaligned rows, partial tiles, M < one tile)",
+     dict(obs=3, act=2, C=2, Q=4, T=3, B=7, critic_hidden=(33, 18), pi_hidden=(21,), enc_hidden=(18,), joint_hidden=(33,),
+          latent=21, enc_features=18, env={"FDQL_SMALL_GEMM": "0"})),
     ("config 2 dims on the LDS-DMA GEMM, 128x128 tiles (dense shape 7: dual outputs + head fusion in that kernel)",
      dict(obs=17, act=6, C=5, Q=2, T=6, B=64, dense_shape=7)),
     ("ragged sizes on the LDS-DMA GEMM, 64x64 tiles (edge tiles and ragged chunks through its guarded path)",
@@ -878,6 +890,8 @@ def _gpu_branch_pattern(ag, spec, xp_cpu):
      "dgrad kernel (FDQL_ROWDGRAD=0)", dict(obs=17, act=6, C=5, Q=2, T=50, B=256, env={"FDQL_ROWDGRAD": "0"})),
     ("config 2 full size, dense weight gradients riding in the dgrad launches (FDQL_WGRAD_STAT=0)",
      dict(obs=17, act=6, C=5, Q=2, T=50, B=256, env={"FDQL_WGRAD_STAT": "0"})),
+    ("temporal_len 2 at config 2 dims, B=256: the small-batch kernel on every GEMM stage of the plan",
+     dict(obs=17, act=6, C=5, Q=2, T=2, B=256)),
     ("config 4 dims (5x25 quantiles, 17 action columns) at T=6, B=64 with the stationary and streaming launches forced "
      "(FDQL_ROWGEMM=all FDQL_STREAM_WGRAD=2: 25 head rows and 17 input columns per streaming problem, no riders fit)",
      dict(obs=376, act=17, C=5, Q=25, T=6, B=64, env={"FDQL_ROWGEMM": "all", "FDQL_STREAM_WGRAD": "2", "FDQL_WGRAD_STAT_FACTOR": "1"})),
