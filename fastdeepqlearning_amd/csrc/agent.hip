@@ -2256,11 +2256,30 @@ int64_t fdql_agent_act_workspace_bytes(const fdql_agent_t *a, int32_t rows) {
 
 namespace {
 // hidden layers then the skip head over cat(in, h_0..h_{n-1}) (mlp.py:88-94); returns the output buffer
+// pol: the policy head follows this MLP - when its last layer is narrow enough both run as one launch (*fused_policy = true)
 hipError_t act_mlp(const fdql_agent *a, const MlpDesc &d, const ActSeg *in, int nin, int rows, float *&top, float **out,
-                   hipStream_t s) {
+                   hipStream_t s, const ActPolicyArgs *pol = nullptr, bool *fused_policy = nullptr) {
   ActSeg feats[ACT_MAX_SEG];
   int nf = 0;
   for (int i = 0; i < nin; ++i) feats[nf++] = in[i];
+  const bool no_fuse = getenv("FDQL_ACT_NO_FUSE") != nullptr;   // (tuning / test hook: every layer its own launch, policy its own)
+  // One hidden layer over a few input columns (the observation encoder at config 2 / 3: 17 / 48 columns): the skip head's
+  // launch recomputes it per workgroup (ActLayerArgs::pre_*) instead of waiting for a launch of its own
+  int kin = 0;
+  for (int i = 0; i < nin; ++i) kin += in[i].width;
+  if (!no_fuse && d.hid.size() == 1 && kin <= 64 && d.hid[0] <= 256 && nin + 1 <= ACT_MAX_SEG) {
+    ActLayerArgs l;
+    memset(&l, 0, sizeof(l));
+    for (int j = 0; j < nin; ++j) l.in[j] = in[j];
+    l.in[nin] = {nullptr, d.hid[0], d.hid[0]};
+    l.nseg = nin + 1;
+    l.pre_W = a->params + d.w_off[0]; l.pre_ldw = d.in_of(0); l.pre_bias = a->params + d.b_off[0]; l.pre_N = d.hid[0]; l.pre_nseg = nin;
+    l.W = a->params + d.hw_off; l.ldw = d.head_ld(); l.bias = a->params + d.hb_off;
+    l.out = top; l.ldo = d.dout; l.N = d.dout; l.rows = rows; l.leaky = 0;
+    *out = top;
+    top += pad4((int64_t)rows * d.dout);
+    return act_layer_launch(l, s);
+  }
   for (size_t i = 0; i < d.hid.size(); ++i) {
     ActLayerArgs l;
     memset(&l, 0, sizeof(l));
@@ -2281,6 +2300,10 @@ hipError_t act_mlp(const fdql_agent *a, const MlpDesc &d, const ActSeg *in, int 
   l.out = top; l.ldo = d.dout; l.N = d.dout; l.rows = rows; l.leaky = 0;
   *out = top;
   top += pad4((int64_t)rows * d.dout);
+  if (pol && fused_policy && !no_fuse && act_head_policy_takes(l, *pol)) {
+    *fused_policy = true;
+    return act_head_policy_launch(l, *pol, s);
+  }
   return act_layer_launch(l, s);
 }
 // The one-launch form (k_act_fused): feed-forward encoder / joiner / actor, at most ACTF_ROWS rows.  Feature rows of an MLP
@@ -2422,13 +2445,15 @@ int fdql_agent_act(fdql_agent_t *a, const float *obs_1d, const float *achieved_g
     if (e == hipSuccess) e = gru_cell_fwd_launch(gi, gh, nullptr, 0, nullptr, hp, hout, nullptr, rows, L, s);
     state = hout;
   }
-  if (e == hipSuccess) { ActSeg x = {state, a->joiner.dout, a->joiner.dout}; e = act_mlp(a, a->actor, &x, 1, rows, top, &logits, s); }
-  if (e == hipSuccess) {
-    ActPolicyArgs p;
-    memset(&p, 0, sizeof(p));
-    p.logits = logits; p.ld = a->actor.dout; p.rows = rows; p.A = c.act_dim; p.discrete = c.discrete;
-    p.exploit_mask = exploit_mask; p.noise = noise; p.seed = seed; p.counter = counter;
-    p.action = action; p.log_prob = log_prob; p.explore = explore_action; p.exploit = exploit_action;
+  ActPolicyArgs p;
+  memset(&p, 0, sizeof(p));
+  p.ld = a->actor.dout; p.rows = rows; p.A = c.act_dim; p.discrete = c.discrete;
+  p.exploit_mask = exploit_mask; p.noise = noise; p.seed = seed; p.counter = counter;
+  p.action = action; p.log_prob = log_prob; p.explore = explore_action; p.exploit = exploit_action;
+  bool fused_policy = false;
+  if (e == hipSuccess) { ActSeg x = {state, a->joiner.dout, a->joiner.dout}; e = act_mlp(a, a->actor, &x, 1, rows, top, &logits, s, &p, &fused_policy); }
+  if (e == hipSuccess && !fused_policy) {
+    p.logits = logits;
     e = act_policy_launch(p, s);
   }
   if (e != hipSuccess) { set_error("fdql_agent_act: %s", hipGetErrorString(e)); return FDQL_EHIP; }

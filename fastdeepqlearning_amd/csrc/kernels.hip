@@ -1671,14 +1671,47 @@ hipError_t gru_dh0_launch(const float *a, const float *b, int nparts_b, int B, i
 constexpr int ACT_RCH = 8;
 constexpr int ACT_KT = 1024;   // K-tile of the input rows staged in LDS (8 x 1024 floats = 32 KB)
 
-__global__ __launch_bounds__(256) void k_act_layer(ActLayerArgs a) {
-  __shared__ float xs[ACT_RCH * ACT_KT];
+constexpr int ACT_PRE_MAXN = 256, ACT_PRE_MAXK = 64;
+// WAVES waves per workgroup, two output columns per wave.  POLICY: the launch is one workgroup per 8 rows that holds ALL N <= 32
+// outputs (the policy logits), leaves them in LDS and returns them to the caller (k_act_head_policy) instead of storing them.
+template <int WAVES, bool POLICY>
+__device__ __forceinline__ void act_layer_body(const ActLayerArgs &a, float *xs, float *hpre, float *logits_lds, int logits_pitch) {
+  constexpr int THREADS = 64 * WAVES;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n0 = (blockIdx.x * 4 + wave) * 2;
+  const int n0 = (blockIdx.x * WAVES + wave) * 2;
   const bool live = n0 < a.N;  // wave-uniform; dead waves still help staging and hit the barriers
   const bool has1 = n0 + 1 < a.N;
   const int r0 = blockIdx.y * ACT_RCH;
   const int nr = min(ACT_RCH, a.rows - r0);
+  if (a.pre_N > 0) {   // the pre-layer, recomputed by every workgroup: thread -> one of its <= 256 outputs, <= 64 input columns
+    int kp = 0;
+    for (int s = 0; s < a.pre_nseg; ++s) {
+      const ActSeg sg = a.in[s];
+      for (int idx = threadIdx.x; idx < ACT_RCH * sg.width; idx += THREADS) {
+        const int r = idx / sg.width, k = idx - r * sg.width;
+        xs[r * ACT_KT + kp + k] = r < nr ? sg.ptr[(long long)(r0 + r) * sg.ld + k] : 0.f;
+      }
+      kp += sg.width;
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n < a.pre_N; n += THREADS) {
+      float acc[ACT_RCH];
+#pragma unroll
+      for (int r = 0; r < ACT_RCH; ++r) acc[r] = 0.f;
+      const float *wr = a.pre_W + (long long)n * a.pre_ldw;
+      for (int k = 0; k < kp; ++k) {
+        const float w = wr[k];
+#pragma unroll
+        for (int r = 0; r < ACT_RCH; ++r) acc[r] = fmaf(xs[r * ACT_KT + k], w, acc[r]);
+      }
+      const float bn = a.pre_bias[n];
+#pragma unroll
+      for (int r = 0; r < ACT_RCH; ++r) {
+        const float y = acc[r] + bn;
+        hpre[r * ACT_PRE_MAXN + n] = y > 0.f ? y : 0.01f * y;
+      }
+    }
+  }
   float acc0[ACT_RCH], acc1[ACT_RCH];
 #pragma unroll
   for (int r = 0; r < ACT_RCH; ++r) acc0[r] = acc1[r] = 0.f;
@@ -1696,9 +1729,11 @@ __global__ __launch_bounds__(256) void k_act_layer(ActLayerArgs a) {
       const int lo = max(soff, kt0), hi = min(soff + sg.width, kt0 + kt);
       const int w = hi - lo;
       if (w > 0) {
-        for (int idx = threadIdx.x; idx < ACT_RCH * w; idx += 256) {
+        for (int idx = threadIdx.x; idx < ACT_RCH * w; idx += THREADS) {
           const int r = idx / w, k = idx - r * w;
-          xs[r * ACT_KT + (lo - kt0) + k] = r < nr ? sg.ptr[(long long)(r0 + r) * sg.ld + (lo - soff) + k] : 0.f;
+          float v = 0.f;
+          if (r < nr) v = sg.ptr ? sg.ptr[(long long)(r0 + r) * sg.ld + (lo - soff) + k] : hpre[r * ACT_PRE_MAXN + (lo - soff) + k];
+          xs[r * ACT_KT + (lo - kt0) + k] = v;
         }
       }
       soff += sg.width;
@@ -1717,7 +1752,7 @@ __global__ __launch_bounds__(256) void k_act_layer(ActLayerArgs a) {
       }
     }
   }
-  if (!live) return;
+  if (!live) return;   // (the caller's barriers come after every wave is back)
 #pragma unroll
   for (int r = 0; r < ACT_RCH; ++r) {
 #pragma unroll
@@ -1736,12 +1771,23 @@ __global__ __launch_bounds__(256) void k_act_layer(ActLayerArgs a) {
           y0 = y0 > 0.f ? y0 : 0.01f * y0;
           y1 = y1 > 0.f ? y1 : 0.01f * y1;
         }
-        float *o = a.out + (long long)(r0 + r) * a.ldo + n0;
-        o[0] = y0;
-        if (has1) o[1] = y1;
+        if constexpr (POLICY) {
+          logits_lds[r * logits_pitch + n0] = y0;
+          if (has1) logits_lds[r * logits_pitch + n0 + 1] = y1;
+        } else {
+          float *o = a.out + (long long)(r0 + r) * a.ldo + n0;
+          o[0] = y0;
+          if (has1) o[1] = y1;
+        }
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void k_act_layer(ActLayerArgs a) {
+  __shared__ float xs[ACT_RCH * ACT_KT];
+  __shared__ float hpre[ACT_RCH * ACT_PRE_MAXN];
+  act_layer_body<4, false>(a, xs, hpre, nullptr, 0);
 }
 
 // explore / exploit actions, log-prob of the explored one, and the exploit_mask select
@@ -1917,17 +1963,13 @@ hipError_t act_layer_launch(const ActLayerArgs &a, hipStream_t s) {
 // Continuous actor, one thread per (row, action) like k_policy_fwd (AG lanes per row, the row's log-prob summed in the order
 // j = 0, 1, ... of the sequential loop in act_policy_row): a handful of rows x 6 actions are one short instruction stream per
 // lane instead of six in sequence, and nothing of the double-precision math is hoisted into (spilled) SGPRs.
-template <int AG>
-__global__ __launch_bounds__(64) void k_act_policy_gauss(ActPolicyArgs a) {
+// (m, j): this thread's row and action; lo: the row's logits (global memory or LDS); every lane of the wave calls it.
+__device__ __forceinline__ void act_gauss_elem(const ActPolicyArgs &a, int m, int j, bool live, const float *lo) {
 #pragma clang fp contract(off)
-  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int m = gid / AG, j = gid - m * AG;
   const int A = a.A;
-  const bool live = m < a.rows && j < A;
   float lp = 0.f;
   if (live) {
     const bool use_exploit = a.exploit_mask && a.exploit_mask[m] != 0;
-    const float *lo = a.logits + (long long)m * a.ld;
     const float mean = lo[j];
     const float ls = fminf(fmaxf(lo[A + j], -20.f), 2.f);
     const float sd = (float)exp((double)ls);
@@ -1947,6 +1989,40 @@ __global__ __launch_bounds__(64) void k_act_policy_gauss(ActPolicyArgs a) {
   float logp = 0.f;
   for (int k = 0; k < A; ++k) logp += __shfl(lp, base + k, 64);
   if (live && j == 0 && a.log_prob) a.log_prob[m] = logp;
+}
+template <int AG>
+__global__ __launch_bounds__(64) void k_act_policy_gauss(ActPolicyArgs a) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int m = gid / AG, j = gid - m * AG;
+  const bool live = m < a.rows && j < a.A;
+  act_gauss_elem(a, m, j, live, a.logits + (long long)(live ? m : 0) * a.ld);
+}
+
+// The policy's last layer + the policy head in one launch (update_kernels.h): 16 waves x 2 columns hold all N <= 32 logits of
+// the workgroup's 8 rows; they stay in LDS and the sample / log-prob / select follows behind one barrier.
+constexpr int ACT_HP_PITCH = 36;
+__global__ __launch_bounds__(1024) void k_act_head_policy(ActLayerArgs l, ActPolicyArgs p) {
+  __shared__ float xs[ACT_RCH * ACT_KT];
+  __shared__ float hpre[1];
+  __shared__ float lg[ACT_RCH * ACT_HP_PITCH];
+  __shared__ float lane_vals[5 * GUMBEL_MAXN * ACT_RCH];
+  act_layer_body<16, true>(l, xs, hpre, lg, ACT_HP_PITCH);
+  __syncthreads();
+  const int r0 = blockIdx.y * ACT_RCH, t = threadIdx.x;
+  if (p.discrete) {
+    if (t < ACT_RCH && r0 + t < p.rows) act_policy_row<1>(p, r0 + t, lg + t * ACT_HP_PITCH, lane_vals + t, ACT_RCH);
+  } else if (t < ACT_RCH * 16) {   // (row, action) = (t / 16, t % 16): A <= 16
+    const int r = t >> 4, j = t & 15;
+    act_gauss_elem(p, r0 + r, j, r0 + r < p.rows && j < p.A, lg + r * ACT_HP_PITCH);
+  }
+}
+bool act_head_policy_takes(const ActLayerArgs &l, const ActPolicyArgs &p) {
+  return l.N <= 32 && l.pre_N == 0 && !l.leaky && (p.discrete ? p.A <= GUMBEL_MAXN && l.N == p.A : p.A <= 16 && l.N == 2 * p.A);
+}
+hipError_t act_head_policy_launch(const ActLayerArgs &l, const ActPolicyArgs &p, hipStream_t s) {
+  if (l.rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_act_head_policy, dim3(1, (l.rows + ACT_RCH - 1) / ACT_RCH), dim3(1024), 0, s, l, p);
+  return hipGetLastError();
 }
 
 hipError_t act_policy_launch(const ActPolicyArgs &a, hipStream_t s) {

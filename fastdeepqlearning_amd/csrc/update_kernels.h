@@ -87,6 +87,11 @@ struct ActLayerArgs {
   const float *bias;  // [N]
   float *out;         // [rows, ldo]
   int ldo, N, rows, leaky;
+  // Optional pre-layer (a first hidden layer over FEW input columns - the observation): every workgroup of the launch
+  // recomputes h = LeakyReLU(pre_W cat(in[0 .. pre_nseg)) + pre_bias) [rows, pre_N <= 256] into LDS; the segment whose ptr is
+  // null (width pre_N) reads it.  One dependent launch less per act(); 0: off.
+  const float *pre_W, *pre_bias;
+  int pre_ldw, pre_N, pre_nseg;
 };
 struct ActPolicyArgs {
   const float *logits;  // [rows, ld]: (mean | log_std) or discrete logits
@@ -99,6 +104,10 @@ struct ActPolicyArgs {
 };
 hipError_t act_layer_launch(const ActLayerArgs &a, hipStream_t s);
 hipError_t act_policy_launch(const ActPolicyArgs &a, hipStream_t s);
+// the policy's (narrow: N <= 32, A <= 16 / <= 32 discrete) last layer and the sample / select in ONE launch: a 1024-thread workgroup per 8 rows
+// computes the logits into LDS and continues with the policy head (p.logits / p.ld are ignored)
+bool act_head_policy_takes(const ActLayerArgs &l, const ActPolicyArgs &p);
+hipError_t act_head_policy_launch(const ActLayerArgs &l, const ActPolicyArgs &p, hipStream_t s);
 
 // act() in ONE launch for a handful of rows (kernels.hip, k_act_fused): a single 1024-thread workgroup walks the Linear
 // layers of encoder -> joiner -> actor with the activations of its <= 8 rows in LDS and ends with the policy head.  A

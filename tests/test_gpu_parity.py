@@ -803,6 +803,38 @@ def test_act_one_launch_equals_layerwise(dev, rows, kw, monkeypatch):
         assert float((x - y).abs().max()) <= 1e-5 * max(1.0, float(y.abs().max()))
 
 
+@pytest.mark.parametrize("rows,kw", [(1, {}), (9, dict(goal=3)), (6, dict(discrete=True, act=5)),
+                                     (2, dict(latent=256, enc_features=256, enc_hidden=(256,), joint_hidden=(256,), pi_hidden=(256,)))])
+def test_act_fused_launches_equal_layerwise(dev, rows, kw, monkeypatch):
+    """act()'s default launch list folds the encoder's first layer into its skip head's launch (few input columns: every
+    workgroup recomputes it) and the policy head into the actor's last layer (k_act_head_policy); FDQL_ACT_NO_FUSE=1 is one
+    launch per layer + the policy kernel.  Same results up to summation order."""
+    from oracle import update as oup
+    base = dict(obs=17, act=6, C=3, Q=2, latent=64, enc_features=48, enc_hidden=(64,), joint_hidden=(48,),
+                pi_hidden=(64,), critic_hidden=(32,), T=2, B=4)
+    base.update(kw)
+    spec = oup.Spec(**base)
+    params = oup.init_params(spec, seed=200 + rows)
+    gen = torch.Generator().manual_seed(rows)
+    for k in params:
+        params[k] = params[k] + 0.05 * torch.randn(params[k].shape, generator=gen)
+    ag = _agent_for(spec, dev)
+    ag.load_tensors(params)
+    xp = {"obs_1d": torch.randn(rows, spec.obs, generator=gen)}
+    if spec.goal:
+        xp["achieved_goal"] = torch.randn(rows, spec.goal, generator=gen)
+        xp["desired_goal"] = torch.randn(rows, spec.goal, generator=gen)
+    mask = torch.rand(rows, 1, generator=gen) < 0.4
+    noise = torch.rand(rows, spec.act, generator=gen) if spec.discrete else torch.randn(rows, spec.act, generator=gen)
+    outs = {}
+    for mode in ("fused", "layerwise"):
+        if mode == "layerwise":
+            monkeypatch.setenv("FDQL_ACT_NO_FUSE", "1")
+        outs[mode] = [g.cpu() for g in ag.act(xp["obs_1d"], xp.get("achieved_goal"), xp.get("desired_goal"), mask, noise=noise)[:4]]
+    for x, y in zip(outs["fused"], outs["layerwise"]):
+        assert float((x - y).abs().max()) <= 1e-5 * max(1.0, float(y.abs().max()))
+
+
 def test_act_device_noise_and_live_weights(dev):
     """Without caller noise the device draws Philox noise keyed by (seed, counter): reproducible per
     key, different across counters, N(0,1) through the tanh-Gaussian; exploit rows ignore it; and
