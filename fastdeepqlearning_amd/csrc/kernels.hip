@@ -379,7 +379,8 @@ int head_dgrad_finalize(HeadDgradProblem *p, int n) {
 }
 
 __global__ __launch_bounds__(256) void k_head_dgrad(const HeadDgradProblem *__restrict__ probs, int nprob) {
-  __shared__ float dys[64 * HEAD_DGRAD_MAXQ];
+  constexpr int MAXQ = HEAD_DGRAD_MAXQ;
+  __shared__ float dys[64 * MAXQ];
   const int pi = find_problem<HeadDgradProblem, &HeadDgradProblem::block_start>(probs, nprob, (int)blockIdx.x, threadIdx.x & 63);
   const HeadDgradProblem P = probs[pi];
   const int local = blockIdx.x - P.block_start;
@@ -390,9 +391,9 @@ __global__ __launch_bounds__(256) void k_head_dgrad(const HeadDgradProblem *__re
     const int r = e / Q, q = e - r * Q;
     dys[e] = (r0 + r < P.M) ? P.dY[(long long)(r0 + r) * P.lddy + q] : 0.f;
   }
-  float w[HEAD_DGRAD_MAXQ];
+  float w[MAXQ];
 #pragma unroll
-  for (int q = 0; q < HEAD_DGRAD_MAXQ; ++q) w[q] = (q < Q && n < P.N) ? P.Wh[(long long)q * P.ldw + n] : 0.f;
+  for (int q = 0; q < MAXQ; ++q) w[q] = (q < Q && n < P.N) ? P.Wh[(long long)q * P.ldw + n] : 0.f;
   __syncthreads();
   if (n >= P.N) return;
   const int nr = min(64, P.M - r0);
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(256) void k_head_dgrad(const HeadDgradProblem *__re
       if (r < nr) {
         float g = 0.f;
 #pragma unroll
-        for (int q = 0; q < HEAD_DGRAD_MAXQ; ++q)
+        for (int q = 0; q < MAXQ; ++q)
           if (q < Q) g = fmaf(dys[r * Q + q], w[q], g);
         const float x = hv[u] > 0.f ? g : 0.01f * g;
         out[(long long)r * P.N] = x;
@@ -908,7 +909,180 @@ __global__ __launch_bounds__(256) void k_loss(LossArgs a) {
   }
 }
 
+// TQC loss for many atoms (32 < Nq <= 128: BASELINE config 4 has 125): ONE WAVE PER ROW, the row's atoms in registers
+// (SLOTS per lane: atom lane + 64 s).  The thread-per-atom kernel above does 125 LDS reads per thread to rank its atom and
+// 100 more for the pair terms, with ~28 workgroup barriers around its group sums; here
+//   * the pooled atoms are SORTED in registers (bitonic network: 28 compare-exchange stages over 128 elements, partners by
+//     lane shuffle / between a lane's own slots) - equal atoms give equal targets, so no stable tie-break is needed for the values
+//     torch.sort()[0][:Nt] returns (distributional_soft_actor_critic.py:50-53);
+//   * target j of the pair loop is a v_readlane broadcast, shared by the lane's SLOTS atoms; the pair terms are accumulated in the
+//     same order j = 0 .. Nt - 1 (the Huber term in a branch-free form with the same fp32 values);
+//   * the four per-row sums are wave reductions in the order of the LDS tree above (slot 1 onto slot 0, then lane + off).
+template <int SLOTS>
+__global__ __launch_bounds__(256) void k_loss_wave(LossArgs a) {
+  __shared__ float bsum[4 * LOSS_NPART];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int m = blockIdx.x * 4 + wv;
+  const bool row_ok = m < a.M;
+  const int mm = row_ok ? m : a.M - 1;
+  const int Nq = a.Nq, Nt = a.Nt;
+  const float alpha = a.st->alpha_cur;
+  const float log_alpha = *a.log_alpha;
+  const float lpn = a.logp_next[mm];
+  const float ent = alpha * (-lpn);
+  const float rew = a.reward[mm + a.B];
+  const float maskg = (a.task_done[mm + a.B] == 0.f ? 1.f : 0.f) * a.gamma;
+  const float mc = a.mc_return ? a.mc_return[mm + a.B] : 0.f;
+  const float wm = a.w[mm];
+  float z[SLOTS], q[SLOTS], zf[SLOTS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    const int i = lane + 64 * s;
+    z[s] = i < Nq ? a.z_target[(long long)mm * Nq + i] : INFINITY;
+    q[s] = i < Nq ? a.q_pred[(long long)mm * Nq + i] : 0.f;
+    zf[s] = i < Nq ? a.z_frozen[(long long)mm * Nq + i] : 0.f;
+  }
+  // ---- ascending sort of the 64 SLOTS values: element e = lane + 64 slot
+#pragma unroll
+  for (int k = 2; k <= 64 * SLOTS; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j >= 1; j >>= 1) {
+      if (j == 64) {   // (SLOTS == 2, k == 128) partner in the lane's other slot: ascending
+        const float lo = fminf(z[0], z[SLOTS - 1]), hi = fmaxf(z[0], z[SLOTS - 1]);
+        z[0] = lo; z[SLOTS - 1] = hi;
+      } else {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+          const int e = lane + 64 * s;
+          const float other = __shfl_xor(z[s], j, 64);
+          const bool asc = (e & k) == 0, low = (lane & j) == 0;
+          z[s] = (asc == low) ? fminf(z[s], other) : fmaxf(z[s], other);
+        }
+      }
+    }
+  }
+  // ---- targets of the kept atoms (rank r = lane + 64 slot < Nt): entropy bonus after truncation, then the Bellman backup
+  float y[SLOTS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    const int r = lane + 64 * s;
+    float tq = z[s];
+    if (a.max_entropy) tq = tq + ent;
+    y[s] = rew + maskg * tq;
+    if (row_ok && r < Nt) a.td_target[(long long)m * Nt + r] = y[s];
+  }
+  // ---- pairwise quantile-Huber terms, j = 0 .. Nt - 1
+  float tau[SLOTS], omt[SLOTS], sl[SLOTS], sg[SLOTS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    tau[s] = (float)(lane + 64 * s) / (float)Nq + a.half_inv_nq;
+    omt[s] = fabsf(tau[s] - 1.f);
+    sl[s] = 0.f; sg[s] = 0.f;
+  }
+#pragma unroll
+  for (int ys = 0; ys < SLOTS; ++ys) {
+    const int jn = min(64, Nt - 64 * ys);   // uniform
+    for (int jj = 0; jj < jn; ++jj) {
+      const float yj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y[ys]), jj));
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s) {
+        // 6.5 vector instructions per pair (the literal formulas are 12.5): with c = clamp(d, -1, 1) the Huber value
+        // |d| > 1 ? |d| - 0.5 : 0.5 d^2 is |c| (|d| - 0.5 |c|) - the same fp32 value in both branches (0.5 x is exact) - and
+        // its derivative is c itself
+        const float d = yj - q[s];
+        const float c = __builtin_amdgcn_fmed3f(d, -1.f, 1.f);
+        float t, hub;   // |c| and |d| as source modifiers (the compiler's packed-math pairing would materialise them with v_and)
+        asm("v_fma_f32 %0, |%1|, -0.5, |%2|" : "=v"(t) : "v"(c), "v"(d));
+        asm("v_mul_f32 %0, |%1|, %2" : "=v"(hub) : "v"(c), "v"(t));
+        const float wt = d < 0.f ? omt[s] : tau[s];
+        sl[s] = fmaf(wt, hub, sl[s]);
+        sg[s] = fmaf(-wt, c, sg[s]);
+      }
+    }
+  }
+  float tot[SLOTS], viol[SLOTS];
+  const float inv = 1.f / (float)(Nq * Nt);
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    const int i = lane + 64 * s;
+    float loss_i = 0.f, grad_i = 0.f, lb_i = 0.f;
+    viol[s] = 0.f;
+    if (i < Nq) {
+      loss_i = sl[s] * inv;
+      grad_i = sg[s] * inv;
+      if (a.lowerbound) {
+        const float lb = mc - q[s];
+        if (lb > 0.f) { lb_i = lb / (float)Nq; grad_i -= 1.f / (float)Nq; viol[s] = 1.f; }
+      }
+      if (row_ok) {
+        a.dz[(long long)m * Nq + i] = wm * grad_i;
+        a.dzf[(long long)m * Nq + i] = -wm / (float)Nq;
+      }
+    }
+    tot[s] = loss_i + lb_i;
+  }
+  auto row_sum = [&](const float (&x)[SLOTS]) {
+    float v = x[0];
+    if (SLOTS == 2) v += x[SLOTS - 1];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;   // lane 0
+  };
+  const float qloss = row_sum(tot), zfsum = row_sum(zf), qsum = row_sum(q), nviol = row_sum(viol);
+  if (lane == 0) {
+    float part[LOSS_NPART];
+#pragma unroll
+    for (int k = 0; k < LOSS_NPART; ++k) part[k] = 0.f;
+    if (row_ok) {
+      const float lp = a.logp[m];
+      const float qpi = zfsum / (float)Nq;
+      const float pil = -(alpha * (-lp)) - qpi;
+      const float all = -(log_alpha * (a.target_entropy - (-lp)));
+      a.q_loss[m] = qloss;
+      a.pi_loss[m] = pil;
+      a.alpha_loss[m] = all;
+      part[0] = wm * ((qloss + pil) + all);
+      part[1] = qloss; part[2] = pil; part[3] = all;
+      part[4] = qsum; part[5] = nviol;
+      part[6] = -wm * (a.target_entropy + lp);   // d loss / d log_alpha
+    }
+#pragma unroll
+    for (int k = 0; k < LOSS_NPART; ++k) bsum[wv * LOSS_NPART + k] = part[k];
+  }
+  __syncthreads();
+  if (tid < LOSS_NPART) {
+    float s = 0.f;
+    for (int r = 0; r < 4; ++r) s += bsum[r * LOSS_NPART + tid];
+    a.partials[(long long)blockIdx.x * LOSS_NPART + tid] = s;
+  }
+  if (a.fin) {   // (uniform) fused finish, as in k_loss
+    __shared__ int is_last;
+    __threadfence();
+    __syncthreads();
+    const LossFinishArgs f = *a.fin;
+    if (tid == 0) is_last = atomicAdd(&f.st->loss_blocks_done, 1u) + 1u == (unsigned)gridDim.x;
+    __syncthreads();
+    if (is_last) {
+      __threadfence();
+      loss_finish_block(a.partials, f.nblocks, f.M, f.Nq, f.st, f.scalars, f.dlog_alpha, f.lr, f.b1, f.b2);
+      if (tid == 0) f.st->loss_blocks_done = 0u;
+    }
+  }
+}
+
+// wave-per-row form: TQC with 32 < Nq <= 128 (LossArgs::G == 64 then: four rows per workgroup); FDQL_LOSS_WAVE=0: never
+bool loss_wave_form(int distributional, int Nq) {
+  const char *e = getenv("FDQL_LOSS_WAVE");
+  return distributional && Nq > 32 && Nq <= 128 && !(e && e[0] == '0');
+}
+
 hipError_t loss_launch(const LossArgs &a, hipStream_t s) {
+  if (a.G == 64 && a.Nq > 32 && a.distributional && loss_wave_form(a.distributional, a.Nq)) {
+    const int blocks = (a.M + 3) / 4;
+    if (a.Nq <= 64) hipLaunchKernelGGL(k_loss_wave<1>, dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_loss_wave<2>, dim3(blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+  }
   const int RPB = 256 / a.G;
   const int blocks = (a.M + RPB - 1) / RPB;
   const size_t lds = (size_t)(3 * RPB * a.G + RPB * LOSS_NPART) * sizeof(float);

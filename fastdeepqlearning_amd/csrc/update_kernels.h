@@ -248,5 +248,6 @@ hipError_t policy_bwd_launch(const float *logits, const float *noise, const floa
                              float *dlogits, int discrete, hipStream_t s);
 
 inline int loss_blocks(int M, int G) { return (M + (256 / G) - 1) / (256 / G); }
+bool loss_wave_form(int distributional, int Nq);   // kernels.hip: the wave-per-row TQC loss takes this shape (then G = 64)
 
 }  // namespace fdql

@@ -926,7 +926,7 @@ bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
       if (plain ? (slot == 0 ? (sg.K != s0.K || sg.lda != s0.lda) : sg.K > s0.K) : (sg.K != s0.K || sg.lda != s0.lda || sg.ldb != s0.ldb)) return false;
       if (slot == 0) I.ldw0 = sg.ldb;
       if (slot == 1) { I.k1 = sg.K; I.lda1 = sg.lda; I.ldw1 = sg.ldb; }
-      if (slot > 0 && (sg.K < 1 || sg.K > 32)) return false;
+      if (slot > 0 && (sg.K < 1 || sg.K > (plain ? 40 : 32))) return false;   // (plain form: up to 5 steps - an actor's 2 x 17 logits)
       if (slot == 0 && !fz && (sg.lda % 4 || !aligned(sg.A, 16))) return false;   // rows move as 16-byte pieces
       if (slot > 0 && fz && !aligned(sg.A, 8)) return false;
       I.A[slot] = sg.A; I.W[slot] = sg.B;
@@ -961,7 +961,7 @@ bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
     // instantiated forms (wstat_launch)
     const int L = args.nslot_loop, Tn = args.nslot_tail;
     if (grad) {
-      if (!((L == 1) || (L == 4 && !fz) || (L == 2 && plain))) return false;
+      if (!((L == 1) || (L == 4 && !fz) || ((L == 2 || L == 5) && plain))) return false;
     } else {
       const bool small = (L == 0 && Tn == 0) || (L == 1 && Tn == 0) || (L == 1 && Tn == 1);
       const bool wide = (L == 3 && Tn == 0) || (L == 3 && Tn == 3);
@@ -1066,7 +1066,9 @@ static hipError_t ws_launch_grad(const WsArgs &a, hipStream_t s) {
 
 hipError_t wstat_launch(const WsArgs &a, hipStream_t s) {
   const int L = a.nslot_loop, T = a.nslot_tail;
-  if (a.grad == 2) return L == 4 ? ws_launch_grad<false, true, 4>(a, s) : (L == 2 ? ws_launch_grad<false, true, 2>(a, s) : ws_launch_grad<false, true, 1>(a, s));
+  if (a.grad == 2)
+    return L == 5 ? ws_launch_grad<false, true, 5>(a, s)
+                  : (L == 4 ? ws_launch_grad<false, true, 4>(a, s) : (L == 2 ? ws_launch_grad<false, true, 2>(a, s) : ws_launch_grad<false, true, 1>(a, s)));
   if (a.grad) {
     if (a.fz) return ws_launch_grad<true, false, 1>(a, s);
     return L == 4 ? ws_launch_grad<false, false, 4>(a, s) : ws_launch_grad<false, false, 1>(a, s);

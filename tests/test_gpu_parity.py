@@ -504,6 +504,12 @@ def test_update_matches_oracle_config2(dev, T, B, hid):
      "form, plain two-segment form, column sums)", dict(obs=17, act=6, C=5, Q=2, T=5, B=64, env={"FDQL_ROWDGRAD_MIN_BLOCKS": "1"})),
     ("config 2 dims at T=4, B=64 on the tile kernel's K-chunk-16 build for every shape (FDQL_GEMM_VARIANT=6, FDQL_ROWGEMM=0: the "
      "default takes K-chunk 32 on the 64x64 shapes)", dict(obs=17, act=6, C=5, Q=2, T=4, B=64, gemm_variant=6, env={"FDQL_ROWGEMM": "0"})),
+    ("TQC loss, one wave per row with ONE atom per lane (5 x 8 = 40 pooled atoms, 32 kept: k_loss_wave<1>)",
+     dict(obs=9, act=3, C=5, Q=8, T=4, B=50)),
+    ("TQC loss, one wave per row, 3 x 25 = 75 atoms over two slots per lane with a ragged second slot (k_loss_wave<2>), odd row count",
+     dict(obs=9, act=3, C=3, Q=25, T=3, B=33)),
+    ("config4 dims with the thread-per-atom loss kernel (FDQL_LOSS_WAVE=0: 125 atoms on 128-thread groups)",
+     dict(obs=376, act=17, C=5, Q=25, T=3, B=96, env={"FDQL_LOSS_WAVE": "0"})),
     ("temporal_len 2 at config 2 dims, B=256 (512 rows): every GEMM stage that is not a row-block launch on the small-batch "
      "kernel (smallgemm.hip: K split over the waves of a workgroup; forward with K-segments, gated dgrads + column sums, "
      "weight gradients, d state shares)", dict(obs=17, act=6, C=5, Q=2, T=2, B=256)),
