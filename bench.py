@@ -454,6 +454,97 @@ def config3_her_ingest(dev, episodes=400):
     return round(n / (time.perf_counter() - t0), 0)
 
 
+def config3_her_vmap(dev, episodes=8000, K=32, steps=100):
+    """Config 3 with sample-time relabelling (SURVEY 8d "per-window sample-time relabel", franQ/Replay/wrappers/her_vmap.py):
+    K = 32 virtual goals + the real one stored per step of a 1M-slot ring through the facade's write stack
+    (HindsightVmapWrite over NStepReturnVmap: relabel and per-column returns on the device, one append per episode),
+    HindsightVmapRead's column select inside the gather kernel, DeepQLearning.train_step() on that read head."""
+    import random
+    from fastdeepqlearning_amd import Agent, Replay
+    from fastdeepqlearning_amd.Agent import AgentConf
+    from fastdeepqlearning_amd.Replay.wrappers import SparseL2Reward
+    w = WORKLOADS["config3"]
+    conf = AgentConf()
+    conf.obs_space = _Space(spaces={"obs_1d": _Space(shape=(w["obs"],)), "achieved_goal": _Space(shape=(w["goal"],)),
+                                    "desired_goal": _Space(shape=(w["goal"],))})
+    conf.action_space = _Space(shape=(w["act"],))
+    conf.discrete = False
+    conf.training_device = conf.inference_device = dev
+    conf.batch_size, conf.temporal_len, conf.replay_size = w["B"], w["T"], w["ring"]
+    conf.num_critics, conf.num_q_predictions = w["C"], w["Q"]
+    conf.use_async_train, conf.num_instances = False, 1
+    conf.use_HER, conf.her_mode, conf.use_nStep_lowerbounds = True, "vmap", True
+    read_heads, write_heads = Replay.make(conf, compute_reward=SparseL2Reward(0.05, -1.0))
+    wh = write_heads[0]
+    wh.num_virtual_goals = K
+    rng = np.random.RandomState(0)
+    np.random.seed(0)
+    random.seed(0)
+    ep_len = w["ep_len"]
+
+    def episode():
+        dg = rng.uniform(-1, 1, w["goal"]).astype(np.float32)
+        obs = rng.standard_normal((ep_len, w["obs"])).astype(np.float32)
+        ag = rng.uniform(-1, 1, (ep_len, w["goal"])).astype(np.float32)
+        act = rng.uniform(-1, 1, (ep_len, w["act"])).astype(np.float32)
+        return [{"obs_1d": obs[i], "achieved_goal": ag[i], "desired_goal": dg, "action": act[i], "reward": -1.0, "task_done": False,
+                 "episode_done": i == ep_len - 1, "episode_step": i} for i in range(ep_len)]
+
+    eps = [episode() for _ in range(200)]          # a pool of host episodes, appended round-robin (the relabel differs per append)
+    for rec in eps[0]:
+        wh.add(rec)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    n_rec = 0
+    for e in range(1, episodes):
+        for rec in eps[e % len(eps)]:
+            wh.add(rec)
+        n_rec += ep_len
+    torch.cuda.synchronize(dev)
+    ingest = n_rec / (time.perf_counter() - t0)
+    rh = read_heads[0]
+    # sampler alone: T x B windows with the virtual column selected inside the gather
+    for _ in range(5):
+        xp = rh.temporal_sample()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        xp = rh.temporal_sample()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / 50
+    row_floats = sum(int(np.prod(v.shape[2:])) for v in xp.values())
+    nbytes = 2.0 * w["T"] * w["B"] * 4 * row_floats + 8 * w["B"]
+    agent = Agent.make(conf)
+    agent.enable_training(read_heads)
+    for _ in range(15):
+        agent.train_step()
+    torch.cuda.synchronize(dev)
+    rates = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            agent.train_step()
+        torch.cuda.synchronize(dev)
+        rates.append(steps / (time.perf_counter() - t0))
+    rates.sort()
+    ring = rh.replay_buffer._ring if hasattr(rh, "replay_buffer") else None
+    out = {"workload": f"BASELINE config 3 with sample-time relabelling: K={K} virtual goals + the real one per step "
+                       f"({ring.row_floats if ring else '?'} floats = {4 * ring.row_floats if ring else '?'} B per slot) in a {w['ring']}-slot ring holding "
+                       f"{len(rh)} records, HindsightVmapRead column select inside the gather, B={w['B']} x T={w['T']}",
+           "value": round(rates[1], 2), "unit": "steps/s", "ms_per_step": round(1e3 / rates[1], 4), "steps": steps,
+           "windows": [round(r, 2) for r in rates], "plans_built": agent.native.stats()["plans_built"],
+           "sampler_ms": round(ms, 4), "sampler_gbs": round(nbytes / (ms * 1e-3) / 1e9, 1), "sampler_algorithmic_bytes": nbytes,
+           "sampler_note": "algorithmic bytes = 2 x T x B x the SELECTED row (one goal column of 33); latency-bound at 6 MB like config 2's gather",
+           "her_vmap_ingest_records_per_s": round(ingest, 0),
+           "ingest_what": f"{episodes - 1} episodes of {ep_len} through HindsightVmapWrite -> NStepReturnVmap -> ring (per-record add() calls; "
+                          f"relabel + returns + append on the device once per episode)"}
+    del agent, read_heads, write_heads
+    torch.cuda.empty_cache()
+    return out
+
+
 def config5_secondary(dev, ring=200_000, B=512, T=50, steps=20):
     """BASELINE config 5 (discrete SAC on 4x84x84 uint8 frame stacks, conv encoder of this build - no reference exists,
     SURVEY 8d) at the full batch on a 200k-frame uint8 ring (5.6 GB; the step does not depend on the ring's length)."""
@@ -673,6 +764,7 @@ def bench_single(args, dev, T):
         facade = facade_path(dev)
         extras = {}
         for name, fn in (("config3_her", lambda: dict(secondary("config3", dev), her_ingest_records_per_s=config3_her_ingest(dev))),
+                         ("config3_her_vmap", lambda: config3_her_vmap(dev)),
                          ("config4_1gpu_B1024", lambda: secondary("config4", dev, steps=100, warmup=5)),
                          ("config5_B512", lambda: config5_secondary(dev))):
             try:
