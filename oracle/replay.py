@@ -98,6 +98,19 @@ def discounted_return_newest_first(rewards_newest_first, gamma):
     return r
 
 
+def discounted_return_numba_arithmetic(rewards_newest_first, gamma):
+    """The same recurrence in the arithmetic REAL numba gives the reference's ``@numba.njit _inner`` (nstep_return.py:69-72):
+    ``rewards`` is a float32 array and ``gamma`` a Python float, which numba types float64, so ``rewards[i - 1] * gamma`` and
+    the sum are formed in double and rounded ONCE when stored back into the float32 array.  (The goldens were produced with
+    njit = identity under numpy 2, where the Python float is weak: float32 product, float32 sum, float32(gamma) - the
+    function above.  This one is the known-answer yardstick the n-step tests report their distance to.)"""
+    r = np.asarray(rewards_newest_first, dtype=np.float32).reshape(-1).copy()
+    g = float(gamma)
+    for i in range(1, r.shape[0]):
+        r[i] = np.float32(float(r[i]) + float(r[i - 1]) * g)
+    return r
+
+
 class NStepOracle:
     """NStepReturn wrapper, nstep_return.py:8-57, writing into ``sink.add(dict)``.
 

@@ -8,6 +8,7 @@ fp32 products of mixed sign, for which both CPU formulations (reference vs oracl
 differ by a few 1e-6 — they get 5e-5 on the same normalised measure.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -182,6 +183,46 @@ def test_mc_return_matches_golden(dev, case):
         nat.check(lib.fdql_episode_mc_return(nat.ptr(r), nat.ptr(out), L, float(g["gamma"]), nat.current_stream()))
         np.testing.assert_array_equal(out.cpu().numpy(), want[pos:pos + L])
         pos += L
+
+
+def test_nstep_kernel_known_answers_and_numba_distance(dev):
+    """k_mc_return against hand-derived known answers (gamma = 0.5, power-of-two rewards: exact in every arithmetic) and its
+    distance to the arithmetic REAL numba gives the reference's loop (float64 product and sum, one rounding; the goldens are
+    identity-njit float32 arithmetic, which the kernel matches bit for bit above).  The distance goes to the parity report."""
+    from fastdeepqlearning_amd import _native as nat
+    from oracle import replay as orp
+    lib = nat.load()
+
+    def kernel(r_oldest_first, gamma):
+        r = torch.tensor(np.asarray(r_oldest_first, np.float32)).to(dev)
+        out = torch.empty(r.numel(), device=dev)
+        nat.check(lib.fdql_episode_mc_return(nat.ptr(r), nat.ptr(out), r.numel(), float(gamma), nat.current_stream()))
+        return out.cpu().numpy()
+
+    n = 20
+    want = (2.0 - 0.5 ** np.arange(n)).astype(np.float32)[::-1]         # oldest first: reward-to-go of n, n - 1, ... ones
+    assert np.array_equal(kernel(np.ones(n), 0.5), want)
+    sparse = np.zeros(n, np.float32)
+    sparse[-1] = 8.0
+    assert np.array_equal(kernel(sparse, 0.5), (8.0 * 0.5 ** np.arange(n)).astype(np.float32)[::-1])
+    rng = np.random.RandomState(3)
+    lines = []
+    for L, gamma in ((50, 0.99), (1000, 0.99), (1000, 0.999)):
+        r = rng.standard_normal(L).astype(np.float32)
+        got = kernel(r, gamma)
+        nb = orp.discounted_return_numba_arithmetic(r[::-1], gamma)[::-1]
+        f32 = orp.discounted_return_newest_first(r[::-1], gamma)[::-1]
+        assert np.array_equal(got, f32)                                  # the goldens' arithmetic: bit for bit
+        rel = float(np.max(np.abs(got.astype(np.float64) - nb)) / np.max(np.abs(nb)))
+        ulps = np.abs(got.astype(np.float64) - nb) / np.spacing(np.abs(nb).astype(np.float32)).astype(np.float64)
+        lines.append(f"n-step scan, {L} steps, gamma {gamma}: vs numba arithmetic max rel {rel:.2e}, max {ulps.max():.1f} ulp, "
+                     f"{float(np.mean(ulps == 0)) * 100:.0f} % of the values identical")
+        assert rel < 1e-5
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity_report.txt", "a") as f:
+        f.write("== n-step return: kernel vs the arithmetic of real numba (nstep_return.py:69-72; goldens are identity-njit)\n")
+        for ln in lines:
+            f.write(ln + "\n")
 
 
 @pytest.mark.parametrize("case", ["final", "random"])
@@ -997,6 +1038,7 @@ def test_gradient_parity_three_way_fp64(dev, name, kw, monkeypatch):
     lines.append("max-norm-relative errors; 'forced' = the GPU's branch choices imposed on the CPU evaluation")
     lines.append(f"{'tensor':66s} {'oracle32-f64':>12s} {'gpu-f64':>10s} {'o32-f64 forced':>14s} {'gpu-f64 forced':>14s} "
                  f"{'>1e-5':>6s} {'viol.(b)':>8s}")
+    by_1e5, by_cpu_clause = [], []   # which clause each tensor passes by (so "within 1e-5" is never read more broadly than it holds)
     for n in g_gpu:
         ref, reff = g64[n].double(), g64f[n].double()
         sc, scf = float(ref.abs().max()) + 1e-300, float(reff.abs().max()) + 1e-300
@@ -1014,6 +1056,10 @@ def test_gradient_parity_three_way_fp64(dev, name, kw, monkeypatch):
             bad.append(("(b) violated element-wise", n, viol, e_f.numel()))
         if float(e_f.max()) / scf > max(TOL_G, 1.25 * float(e_orf.max()) / scf):
             bad.append(("(b) violated in the max norm", n, float(e_f.max()) / scf, float(e_orf.max()) / scf))
+        (by_1e5 if float(e_f.max()) / scf <= TOL_G else by_cpu_clause).append(f"{n} ({float(e_f.max()) / scf:.1e} vs CPU fp32 {float(e_orf.max()) / scf:.1e})")
+    lines.append(f"SUMMARY {name}: {len(by_1e5)} of {len(by_1e5) + len(by_cpu_clause)} tensors within 1e-5 of fp64 in the max norm; "
+                 + ("the others pass by the 'no farther from fp64 than 1.25 x the CPU path's own fp32 error' clause: " + "; ".join(by_cpu_clause)
+                    if by_cpu_clause else "none needs the CPU-error clause"))
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/parity_three_way.txt", "a") as f:
         f.write("\n".join(lines) + "\n")

@@ -86,6 +86,40 @@ def test_nstep_matches_reference(case):
         np.testing.assert_array_equal(np.asarray(out[k], v.dtype), v, err_msg=k)
 
 
+def _ulps(a, b):
+    """distance in float32 units in the last place of b"""
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    return np.abs(a.astype(np.float64) - b.astype(np.float64)) / np.spacing(np.abs(b)).astype(np.float64)
+
+
+def test_nstep_known_answers_and_numba_arithmetic():
+    """Known-answer episodes for the n-step scan (nstep_return.py:60-72).  (a) gamma = 0.5 and rewards of powers of two: every
+    partial sum is exactly representable, so the float32 loop (the goldens' identity-njit arithmetic), numba's float64-product
+    arithmetic and the closed form agree BIT FOR BIT.  (b) gamma = 0.99 over 1000 dense random rewards: the two arithmetics
+    differ by rounding (and by float32(0.99) vs the double 0.99): the distance is reported and bounded - the claim for this
+    column is "within 1e-5 of the reference under real numba", not bit-exactness."""
+    n = 20
+    ones = np.ones(n, np.float32)
+    closed = (2.0 - 0.5 ** np.arange(n)).astype(np.float32)              # newest first: 1, 1.5, 1.75, ...
+    assert np.array_equal(orp.discounted_return_newest_first(ones, 0.5), closed)
+    assert np.array_equal(orp.discounted_return_numba_arithmetic(ones, 0.5), closed)
+    sparse = np.zeros(n, np.float32)
+    sparse[0] = 8.0                                                      # terminal reward, newest record
+    want = (8.0 * 0.5 ** np.arange(n)).astype(np.float32)
+    assert np.array_equal(orp.discounted_return_newest_first(sparse, 0.5), want)
+    assert np.array_equal(orp.discounted_return_numba_arithmetic(sparse, 0.5), want)
+    rng = np.random.RandomState(3)
+    r = rng.standard_normal(1000).astype(np.float32)
+    f32, nb = orp.discounted_return_newest_first(r, 0.99), orp.discounted_return_numba_arithmetic(r, 0.99)
+    rel = np.abs(f32.astype(np.float64) - nb) / np.max(np.abs(nb))
+    assert rel.max() < 1e-5, rel.max()
+    # and the reference's own test signal (tests/test_replays.py:16-33: reward 1 at the last step): both within its np.allclose
+    last = np.zeros(1000, np.float32)
+    last[0] = 1.0
+    for fn in (orp.discounted_return_newest_first, orp.discounted_return_numba_arithmetic):
+        assert np.allclose(fn(last, 0.99), 0.99 ** np.arange(1000))
+
+
 def test_nstep_reference_own_test():
     """tests/test_replays.py:16-33 restated: mc_return == 0.99 ** (999 - step)."""
     sink = Sink()
