@@ -1379,9 +1379,22 @@ int build_plan(fdql_agent *a) {
             gn.parts[k][0] = hf_sum + (long long)inst_id(k, 0) * MQ;
           }
         }
+        // the plane sum inside the finish (its 16-row waves add the planes as they read them) instead of a reduction launch in
+        // front of it; FDQL_HEAD_SUM_LAUNCH=1: the round-3 pair of launches
+        const bool sum_in_finish = okf && getenv("FDQL_HEAD_SUM_LAUNCH") == nullptr;
+        if (sum_in_finish) {
+          ha.sum_planes = 1;
+          const long long inst_stride = (long long)a->hf_planes * MQ;
+          for (int k = 0; k < C; ++k) {
+            ha.g[0].parts[k][0] = hf_parts + inst_id(k, 1) * inst_stride;
+            ha.g[0].parts[k][1] = hf_parts + inst_id(k, 2) * inst_stride;
+            ha.g[1].parts[k][0] = hf_parts + inst_id(k, 0) * inst_stride;
+          }
+        }
         if (okf) {
           const int ninst = 3 * C, planes = a->hf_planes;
-          b.func_stage("critics.head_sum", [=](hipStream_t s) { return reduce_partials_batched_launch(hf_parts, ninst, planes, MQ, hf_sum, s); });
+          if (!sum_in_finish)
+            b.func_stage("critics.head_sum", [=](hipStream_t s) { return reduce_partials_batched_launch(hf_parts, ninst, planes, MQ, hf_sum, s); });
           b.func_stage("critics.head", [=](hipStream_t s) { return head_finish_launch(ha, s); });
           finished = true;
         }
@@ -1409,6 +1422,9 @@ int build_plan(fdql_agent *a) {
     }
   }
   // ---- loss
+  bool ride_finish = false;
+  LossFinishArgs finish_args;
+  memset(&finish_args, 0, sizeof(finish_args));
   {
     LossArgs la;
     memset(&la, 0, sizeof(la));
@@ -1456,7 +1472,12 @@ int build_plan(fdql_agent *a) {
     const float *parts = la.partials;
     // also the Adam bias corrections of the step about to be applied (torch.optim.Adam's Python floats)
     const double lr = c.lr, b1 = c.beta1, b2 = c.beta2;
-    if (!fuse_finish)
+    // single-process plans: the finish rides in the policy-backward launch (its next consumer is the optimiser); a two-bucket
+    // plan needs d log_alpha in the early bucket, before that launch
+    ride_finish = !fuse_finish && !a->bucketed() && getenv("FDQL_NO_LOSS_FINISH_RIDE") == nullptr;
+    finish_args.nblocks = nblocks; finish_args.M = M; finish_args.Nq = Nq; finish_args.st = dst; finish_args.scalars = scal;
+    finish_args.dlog_alpha = dla; finish_args.lr = lr; finish_args.b1 = b1; finish_args.b2 = b2;
+    if (!fuse_finish && !ride_finish)
       b.func_stage("loss_finish", [=](hipStream_t s) { return loss_finish_launch(parts, nblocks, M, Nq, dst, scal, dla, lr, b1, b2, s); });
   }
   // ---- critic backward (online: wgrad + d state; frozen: d pi only)
@@ -1562,7 +1583,12 @@ int build_plan(fdql_agent *a) {
     const float *lo = ao.out, *nz = a->buf("noise_actor"), *pi = a->buf("pi"), *dpi = a->buf("dpi_part"), *w = a->buf("w");
     float *dlo = a->buf("dlogits"), *dpi_sum = a->buf("dpi");
     const int disc = c.discrete;
-    b.func_stage("policy_bwd", [=](hipStream_t s) { return policy_bwd_launch(lo, nz, pi, dpi, C, dpi_sum, w, dst, M, A, dlo, disc, s); });
+    const float *lparts = a->buf("loss_partials");
+    const LossFinishArgs fa = finish_args;
+    const bool ride = ride_finish;
+    b.func_stage("policy_bwd", [=](hipStream_t s) {
+      return policy_bwd_launch(lo, nz, pi, dpi, C, dpi_sum, w, dst, M, A, dlo, disc, s, lparts, ride ? &fa : nullptr);
+    });
   }
   // ---- actor backward
   // The weight gradients of a network only need that network's own dpre/dY, so instead of one big

@@ -597,10 +597,22 @@ __global__ __launch_bounds__(256) void k_policy_fwd(PolicyFwdArgs a0, PolicyFwdA
 }
 
 // d logits from d pi (through the frozen critics) and d logp = w*alpha.  One thread per (row, action).
-__global__ void k_policy_bwd(const float *__restrict__ logits, const float *__restrict__ noise,
-                             const float *__restrict__ action, const float *__restrict__ dpi_parts, int nparts,
-                             float *__restrict__ dpi_sum, const float *__restrict__ w, const DevState *st, int M, int A,
-                             float *__restrict__ dlogits) {
+// fin.nblocks > 0: one extra 256-thread workgroup behind the launch's own does k_loss_finish's work (sums the loss partials,
+// publishes the scalars and d log_alpha, the Adam bias corrections): nothing before the optimiser reads those - one launch less.
+__device__ __forceinline__ void loss_finish_block(const float *__restrict__ partials, int nblocks, int M, int Nq, DevState *st,
+                                                  float *__restrict__ scalars, float *__restrict__ dlog_alpha, double lr, double b1, double b2);
+struct LossFinishRider {
+  const float *partials;
+  LossFinishArgs f;
+};
+__global__ __launch_bounds__(256) void k_policy_bwd(const float *__restrict__ logits, const float *__restrict__ noise,
+                                                    const float *__restrict__ action, const float *__restrict__ dpi_parts, int nparts,
+                                                    float *__restrict__ dpi_sum, const float *__restrict__ w, const DevState *st, int M, int A,
+                                                    float *__restrict__ dlogits, LossFinishRider fin, int own_blocks) {
+  if ((int)blockIdx.x >= own_blocks) {   // (uniform)
+    loss_finish_block(fin.partials, fin.f.nblocks, fin.f.M, fin.f.Nq, fin.f.st, fin.f.scalars, fin.f.dlog_alpha, fin.f.lr, fin.f.b1, fin.f.b2);
+    return;
+  }
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int m = (int)(gid / A), j = (int)(gid - (long long)m * A);
   if (m >= M) return;
@@ -1321,13 +1333,22 @@ hipError_t onehot_launch(const float *action, int rows, int n, float *out, hipSt
 
 hipError_t policy_bwd_launch(const float *logits, const float *noise, const float *action, const float *dpi_parts,
                              int nparts, float *dpi_sum, const float *w, const DevState *st, int M, int A,
-                             float *dlogits, int discrete, hipStream_t s) {
-  if (discrete)
+                             float *dlogits, int discrete, hipStream_t s, const float *loss_partials, const LossFinishArgs *fin) {
+  if (discrete) {
     hipLaunchKernelGGL(k_policy_bwd_gumbel, dim3((M + 63) / 64), dim3(64), 0, s, logits, noise, dpi_parts, nparts, dpi_sum,
                        w, st, M, A, dlogits);
-  else
-    hipLaunchKernelGGL(k_policy_bwd, dim3((unsigned)(((long long)M * A + 255) / 256)), dim3(256), 0, s, logits, noise, action, dpi_parts, nparts,
-                       dpi_sum, w, st, M, A, dlogits);
+    if (fin) {   // (the Gumbel kernel has its own block shape: the finish stays a launch of its own)
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return e;
+      return loss_finish_launch(loss_partials, fin->nblocks, fin->M, fin->Nq, fin->st, fin->scalars, fin->dlog_alpha, fin->lr, fin->b1, fin->b2, s);
+    }
+  } else {
+    LossFinishRider r = {};
+    if (fin) { r.partials = loss_partials; r.f = *fin; }
+    const int own = (int)(((long long)M * A + 255) / 256);
+    hipLaunchKernelGGL(k_policy_bwd, dim3((unsigned)(own + (fin ? 1 : 0))), dim3(256), 0, s, logits, noise, action, dpi_parts, nparts,
+                       dpi_sum, w, st, M, A, dlogits, r, own);
+  }
   return hipGetLastError();
 }
 
@@ -1526,6 +1547,27 @@ __global__ __launch_bounds__(64) void k_head_finish(HeadFinishArgs a) {
     for (int r = 0; r < 4; ++r) {
       const int row = row0 + 4 * kq + r;
       pval[v][r] = (pp && row < M) ? pp[(long long)row * Q + q] : 0.f;
+    }
+    if (a.sum_planes && pp) {   // (uniform flag) the other planes, in order, eight requests in flight per row
+      const long long ps = (long long)M * Q;
+      for (int p0 = 1; p0 < a.planes; p0 += 8) {
+        float x[8][4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int pl = p0 + u < a.planes ? p0 + u : a.planes - 1;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = min(row0 + 4 * kq + r, M - 1);
+            x[u][r] = pp[pl * ps + (long long)row * Q + q];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (p0 + u < a.planes) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pval[v][r] += x[u][r];
+          }
+      }
     }
   }
   if (nok) bq = bsel[q];

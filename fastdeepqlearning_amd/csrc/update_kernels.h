@@ -206,10 +206,12 @@ struct HeadFinishGroup {
   int lda[2];
   float *out[2];                             // per variant: [M, ldo[v]], set k writes columns k*Q .. k*Q+Q-1
   int ldo[2];
-  const float *parts[HEAD_FINISH_MAX_SETS][2];   // per (set, variant): [M][Q], the hidden layers' parts with the planes summed
+  const float *parts[HEAD_FINISH_MAX_SETS][2];   // per (set, variant): [M][Q], the hidden layers' parts with the planes summed - or,
+                                                 // HeadFinishArgs::sum_planes, plane 0 of the instance's `planes` planes [planes][M][Q]
 };
 struct HeadFinishArgs {
   int M, L, A, Q, planes, ngroups;
+  int sum_planes;   // 1: the kernel adds the planes itself (in plane order): no reduction launch in front of it
   HeadFinishGroup g[2];
 };
 hipError_t head_finish_launch(const HeadFinishArgs &a, hipStream_t s);
@@ -243,9 +245,11 @@ struct PrepArgs {
 hipError_t policy_fwd_launch(const PolicyFwdArgs &a0, const PolicyFwdArgs &a1, int nprob, int M, int A,
                              const DevState *st, uint64_t seed, int discrete, hipStream_t s, const PrepArgs *prep = nullptr);
 hipError_t onehot_launch(const float *action, int rows, int n, float *out, hipStream_t s);
+// fin (optional): k_loss_finish's work rides in this launch as one extra workgroup (continuous policies)
 hipError_t policy_bwd_launch(const float *logits, const float *noise, const float *action, const float *dpi_parts,
                              int nparts, float *dpi_sum, const float *w, const DevState *st, int M, int A,
-                             float *dlogits, int discrete, hipStream_t s);
+                             float *dlogits, int discrete, hipStream_t s, const float *loss_partials = nullptr,
+                             const LossFinishArgs *fin = nullptr);
 
 inline int loss_blocks(int M, int G) { return (M + (256 / G) - 1) / (256 / G); }
 bool loss_wave_form(int distributional, int Nq);   // kernels.hip: the wave-per-row TQC loss takes this shape (then G = 64)
