@@ -403,6 +403,9 @@ void carve(fdql_agent *a) {
     a->alloc("gru.dhz1", Bw * c.latent);
     a->alloc("gru.dhw", GRU_KSPLIT_BWD * Bw * c.latent);  // part of d h_{t-1} through W_hh, K-split partials
     a->alloc("gru.ghp", GRU_KSPLIT_FWD * Bw * L3);        // K-split partials of W_hh h_{t-1} for the current step
+    a->alloc("gru.wpack_f", (int64_t)c.latent * L3);      // persistent scans (gruscan.hip): W_hh packed in the forward scan's stream order
+    a->alloc("gru.wpack_b", (int64_t)c.latent * L3);      // ... and W_hh^T in the backward scan's
+    a->alloc("gru.dh_init", Bw * c.latent);               // ... and d h_{-1} per row (learned start state)
   } else {
     mlp_bufs("joiner", a->joiner, N, true, false);
   }
@@ -1247,7 +1250,16 @@ int build_plan(fdql_agent *a) {
       const float *src = mode == 1 ? x.agent_state : (mode == 2 ? params + a->gru_h0 : nullptr);
       b.func_stage("gru.h0", [=](hipStream_t s) { return gru_h0_launch(mode, src, h0, B, L, s); });
     }
-    for (int t = 0; t < T; ++t) {
+    const bool scan = gru_scan_takes(B, L);   // the whole scan as ONE persistent launch (gruscan.hip) instead of T x (GEMM + gate kernel)
+    if (scan) {
+      GruScanArgs ga;
+      memset(&ga, 0, sizeof(ga));
+      float *pf = a->buf("gru.wpack_f"), *pb = a->buf("gru.wpack_b");
+      ga.T = T; ga.B = B; ga.L = L; ga.W = pf; ga.bhh = bhh; ga.gi = gi; ga.h0 = h0; ga.gh = gh; ga.state = state; ga.hprev = hprev;
+      b.func_stage("gru.pack", [=](hipStream_t s) { return gru_pack_launch(whh, L, pf, pb, s); });
+      b.func_stage("gru.scan", [=](hipStream_t s) { return gru_scan_fwd_launch(ga, s); });
+    }
+    for (int t = 0; t < T && !scan; ++t) {
       const float *hp = t == 0 ? h0 : state + (int64_t)(t - 1) * B * L;
       float *gh_t = gh + (int64_t)t * B * L3, *h_t = state + (int64_t)t * B * L, *hs_t = hprev + (int64_t)t * B * L;
       const float *gi_t = gi + (int64_t)t * B * L3;
@@ -1656,7 +1668,20 @@ int build_plan(fdql_agent *a) {
     float *dhz[2] = {a->buf("gru.dhz0"), a->buf("gru.dhz1")};
     const float *gi = a->buf("gru.gi"), *gh = a->buf("gru.gh"), *hprev = a->buf("gru.hprev"), *dstate = a->buf("dstate");
     const float *whh = params + a->gru_whh;
-    for (int t = T - 2; t >= 0; --t) {
+    const bool scan = gru_scan_takes(B, L);
+    if (scan) {
+      float *dh_init = a->buf("gru.dh_init");
+      GruScanArgs ga;
+      memset(&ga, 0, sizeof(ga));
+      ga.T = T; ga.B = B; ga.L = L; ga.W = a->buf("gru.wpack_b"); ga.gi = gi; ga.gh = const_cast<float *>(gh); ga.hprev = const_cast<float *>(hprev);
+      ga.dstate = dstate; ga.dgi = dgi; ga.dgh = dgh; ga.dh_init = c.gru_state_mode == 2 ? dh_init : nullptr;
+      b.func_stage("gru.scan_bwd", [=](hipStream_t s) { return gru_scan_bwd_launch(ga, s); });
+      if (c.gru_state_mode == 2) {
+        float *out = a->buf("slabs") + a->gru_h0;
+        b.func_stage("gru.dh0", [=](hipStream_t s) { return gru_dh0_launch(dh_init, nullptr, 0, B, L, out, s); });
+      }
+    }
+    for (int t = T - 2; t >= 0 && !scan; --t) {
       const int64_t r3 = (int64_t)t * B * L3, r1 = (int64_t)t * B * L;
       const bool last = t == T - 2;
       const float *ca = last ? nullptr : dhz[(t + 1) & 1], *cb = last ? nullptr : dhw;
@@ -1672,7 +1697,7 @@ int build_plan(fdql_agent *a) {
       p.split_stride = (long long)B * L;
       gs.gemm.push_back(p);
     }
-    if (c.gru_state_mode == 2) {   // learned start state: d hidden_state = sum_b d h_{-1}
+    if (c.gru_state_mode == 2 && !scan) {   // learned start state: d hidden_state = sum_b d h_{-1}
       float *out = a->buf("slabs") + a->gru_h0;
       const float *za = dhz[0];
       b.func_stage("gru.dh0", [=](hipStream_t s) { return gru_dh0_launch(za, dhw, GRU_KSPLIT_BWD, B, L, out, s); });

@@ -232,6 +232,22 @@ hipError_t gru_cell_bwd_launch(const float *dstate, const float *carry_a, const 
                                float *dh_direct, int rows, int L, hipStream_t s);
 // d encoder.hidden_state[l] = sum_b (a[b][l] + b[b][l])  (learned start state), fixed order
 hipError_t gru_dh0_launch(const float *a, const float *b, int nparts_b, int B, int L, float *out, hipStream_t s);
+// The whole scan as ONE persistent launch (gruscan.hip): a workgroup owns 4 (or 8) batch rows for all T steps, the recurrent
+// weights streamed through an LDS-DMA ring from copies packed in stream order (gru_pack_launch, once per update).
+struct GruScanArgs {
+  int T, B, L, pad;
+  const float *W, *bhh;      // W: the scan's packed weight stream (forward / backward copy); bhh: forward only
+  const float *gi;           // [T*B, 3L]
+  const float *h0;           // forward: start state [B, L]
+  float *gh, *state, *hprev; // forward: outputs [T*B, 3L], [T*B, L], [T*B, L]; backward: gh / hprev are read
+  const float *dstate;       // backward: [(T-1)*B, L]
+  float *dgi, *dgh;          // backward: outputs [(T-1)*B, 3L]
+  float *dh_init;            // backward: optional [B, L]: d h_{-1} per row (learned start state)
+};
+bool gru_scan_takes(int B, int L);
+hipError_t gru_scan_fwd_launch(const GruScanArgs &a, hipStream_t s);
+hipError_t gru_scan_bwd_launch(const GruScanArgs &a, hipStream_t s);
+hipError_t gru_pack_launch(const float *Whh, int L, float *pack_fwd, float *pack_bwd, hipStream_t s);
 // prep: optional - the work of prep_launch as extra workgroups of this launch (continuous policies; a launch of its own
 // in front of the Gumbel kernel)
 struct PrepArgs {

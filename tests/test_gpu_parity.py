@@ -474,6 +474,15 @@ def test_update_matches_oracle_config2(dev, T, B, hid):
     ("GRU joiner, stored start state + burn-in rows", dict(obs=9, act=3, C=2, Q=3, T=12, B=40, gru="store", burn_in=2,
                                                           latent=64, enc_features=48, enc_hidden=(64,), joint_hidden=(64,),
                                                           pi_hidden=(64,), critic_hidden=(64, 64))),
+    ("GRU joiner, persistent scans at the default width (latent 256: four waves per workgroup), 30 windows (a partial 4-row tile), "
+     "zero start state", dict(obs=9, act=3, C=2, Q=3, T=9, B=30, gru="zero", latent=256, enc_features=64, enc_hidden=(64,),
+                              joint_hidden=(64,), pi_hidden=(64,), critic_hidden=(64, 64))),
+    ("GRU joiner, persistent scans at latent 128 (two waves), learned start state, T=50",
+     dict(obs=9, act=3, C=2, Q=3, T=50, B=20, gru="learned", latent=128, enc_features=48, enc_hidden=(64,), joint_hidden=(64,),
+          pi_hidden=(64,), critic_hidden=(64, 64))),
+    ("GRU joiner on the step-by-step launches (FDQL_GRU_SCAN=0: T x (recurrent GEMM + gate kernel))",
+     dict(obs=9, act=3, C=2, Q=3, T=12, B=40, gru="learned", latent=64, enc_features=48, enc_hidden=(64,), joint_hidden=(64,),
+          pi_hidden=(64,), critic_hidden=(64, 64), env={"FDQL_GRU_SCAN": "0"})),
     ("pixel encoder, 2 conv layers on 2x12x12 frames + obs_1d, discrete head (no reference: vs torch conv2d)",
      dict(obs=4, act=5, discrete=True, C=2, Q=3, T=3, B=20, img=(2, 12, 12), conv=((8, 4, 2), (16, 3, 1)), latent=32,
           enc_features=32, enc_hidden=(48,), joint_hidden=(32,), pi_hidden=(32,), critic_hidden=(32, 32))),
