@@ -637,6 +637,11 @@ struct Builder {
   void take_stream_wgrads(Stage &from, Stage &to, Stage &skinny) {
     const char *env = getenv("FDQL_STREAM_WGRAD");
     if (env && env[0] == '0') return;
+    // few rows (temporal_len 2): the narrow gradients stay GEMM problems of the tail stage, which the small-batch kernel takes
+    // in its one launch - a streaming launch of their own is 15 us of a 0.28 ms step (0.277 -> 0.264 ms)
+    if (!(env && env[0] == '2') && a->small_max_tiles > 0 && a->M <= 1024 && gemm_dense_shape() == GEMM_64x64 &&
+        gemm_variant() == GEMM_DEFAULT_VARIANT)
+      return;
     // Short K-split slabs (a few hundred rows, config 2: the tile kernels' narrow launches are one memory round trip per K
     // iteration there, 0.7-2.4 TB/s): everything that has the form.  Long slabs (config 4 at B = 1024: 1568 rows): the
     // 32x128 tile streams the head rows at 5 TB/s - better than the 4.4 TB/s here - but the 128x32 launch of the few-input-
