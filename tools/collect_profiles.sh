@@ -22,3 +22,14 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_C
 #    take MFMA issue time on gfx950): counts in their own pass
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU --output-format csv -d $OUT/pmc_insts -- python3 $R/tools/profile_stages.py --reps 1 > $OUT/pmc_insts.log 2>&1 || exit 1
 python3 $R/tools/summarize_profiles.py $OUT
+# 6. (round 4) the other workloads' per-stage times, the small-batch step, act() latency, the GRU joiner step, the sampler
+python3 $R/tools/profile_stages.py --obs 376 --act 17 --Q 25 --B 1024 --reps 3 > $OUT/stage_times_config4_B1024.txt 2>&1 || exit 1
+python3 $R/tools/profile_stages.py --obs 376 --act 17 --Q 25 --B 128 --reps 5 > $OUT/stage_times_config4_B128_per_rank.txt 2>&1 || exit 1
+python3 $R/tools/profile_stages.py --world 2 > $OUT/stage_times_config2_two_bucket_plan.txt 2>&1 || exit 1
+python3 $R/tools/t2_latency.py stages > $OUT/temporal_len_2_stages.txt 2>&1 || exit 1
+python3 $R/tools/act_bench.py 1 8 64 256 > $OUT/act_latency.txt 2>&1 || exit 1
+python3 $R/tools/profile_stages.py --gru zero --reps 3 > $OUT/stage_times_gru.txt 2>&1 || exit 1
+python3 $R/tools/sampler_bench.py > $OUT/sampler_hbm.txt 2>&1 || exit 1
+# 7. (round 4) the N > 1 code path from the plain command line (ranks share this box's one GPU: gloo rehearsal, not a scaling figure)
+FDQL_BENCH_BACKEND=gloo FDQL_BENCH_RING=200000 python3 $R/bench.py --gpus 2 --steps 20 --warmup 5 > $OUT/bench_2rank_gloo_plain_launch.json 2> $OUT/bench_2rank.err || exit 1
+
