@@ -1396,9 +1396,11 @@ int build_plan(fdql_agent *a) {
             gn.parts[k][0] = hf_sum + (long long)inst_id(k, 0) * MQ;
           }
         }
-        // the plane sum inside the finish (its 16-row waves add the planes as they read them) instead of a reduction launch in
-        // front of it; FDQL_HEAD_SUM_LAUNCH=1: the round-3 pair of launches
-        const bool sum_in_finish = okf && getenv("FDQL_HEAD_SUM_LAUNCH") == nullptr;
+        // few rows (temporal_len 2): the plane sum inside the finish (its 16-row waves add the planes as they read them) instead
+        // of a reduction launch in front of it - one launch less; at many rows the pair of launches is the faster one (config 2:
+        // 0.0105 + 0.0153 ms against 0.0278 ms folded).  FDQL_HEAD_SUM_LAUNCH=1 / =0 forces either form.
+        const char *hsl = getenv("FDQL_HEAD_SUM_LAUNCH");
+        const bool sum_in_finish = okf && (hsl ? hsl[0] == '0' : M <= 4096);
         if (sum_in_finish) {
           ha.sum_planes = 1;
           const long long inst_stride = (long long)a->hf_planes * MQ;
