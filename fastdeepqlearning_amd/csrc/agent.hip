@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <map>
 #include <mutex>
 #include <string>
@@ -138,8 +139,17 @@ struct Stage {
   int phase = FDQL_PHASE_GRAD;
   int gpart = 1;  // FDQL_PHASE_GRAD stages of a bucketed plan: 0 = up to the critics' gradients (FDQL_PHASE_GRAD_CRITICS), 1 = the rest
   int when = 0;   // 0: whenever its phase runs; 1: only in a split (GRAD / APPLY) call; 2: only in a FDQL_PHASE_ALL call
+  bool off = false;   // decided with the kernels (upload_tables): the stage has nothing left to do in this plan
+  // head fusion (critics): 1 = a hidden layer's launch that leaves head partial sums, 2 = their plane sum, 3 = the head's finish.
+  // When every layer runs weight-stationary, the kernels sum a tile's planes themselves (WsArgs::hf_presum): stage 2 is switched
+  // off and stage 3 adds one plane per layer as it reads them (hfin_presum instead of hfin_plain).
+  int hf_role = 0;
+  std::shared_ptr<HeadFinishArgs> hfin;
+  HeadFinishArgs hfin_plain, hfin_presum;
+  bool hfin_can_presum = false;
   std::function<hipError_t(hipStream_t)> fn;
   bool runs_in(int call_phase) const {
+    if (off) return false;
     if (call_phase == FDQL_PHASE_ALL) return when != 1;
     if (call_phase == FDQL_PHASE_GRAD_CRITICS || call_phase == FDQL_PHASE_GRAD_REST)
       return phase == FDQL_PHASE_GRAD && when != 2 && gpart == (call_phase == FDQL_PHASE_GRAD_REST ? 1 : 0);
@@ -1073,6 +1083,30 @@ int upload_tables(fdql_agent *a) {
     }
   }
   if (total) FDQL_HIP(hipMemcpy(a->tables_dev, host.data(), total, hipMemcpyHostToDevice));
+  // head-fusion planes: with every hidden layer of the critics on weight-stationary launches, those launches sum a tile's column
+  // planes themselves, the plane-sum stage is switched off and the finish adds one plane per layer (Stage::hf_role)
+  {
+    Stage *fin = nullptr, *sum = nullptr;
+    int nfwd = 0;
+    bool all = true;
+    for (Stage &s : a->stages) {
+      if (s.hf_role == 2) sum = &s;
+      if (s.hf_role == 3) fin = &s;
+      if (s.hf_role != 1) continue;
+      ++nfwd;
+      size_t n = 0;
+      bool ok = !s.rows.empty();
+      for (const RowsLaunch &rl : s.rows) { ok = ok && rl.ws && rl.wa.hf_q > 0; n += (size_t)rl.wa.ninst; }
+      all = all && ok && n == s.gemm.size();
+    }
+    const bool presum = fin && fin->hfin_can_presum && nfwd > 0 && nfwd == fin->hfin_presum.planes && all;
+    for (Stage &s : a->stages)
+      if (s.hf_role == 1)
+        for (RowsLaunch &rl : s.rows)
+          if (rl.ws) rl.wa.hf_presum = presum ? 1 : 0;
+    if (fin) *fin->hfin = presum ? fin->hfin_presum : fin->hfin_plain;
+    if (sum) sum->off = presum;
+  }
   return 0;
 }
 
@@ -1343,6 +1377,7 @@ int build_plan(fdql_agent *a) {
     } else if (nh > 0 && getenv("FDQL_NO_DUAL") == nullptr) {
       Stage &gs = b.gemm_stage("critics.fwd0");
       gs.try_rows = true;
+      gs.hf_role = fuse ? 1 : 0;
       for (int k = 0; k < C; ++k) {
         GemmProblem pt = b.fwd_layer(ct[k], 0);
         pt.emit_seg = pt.nseg - 1;   // no tail: rides in the same launch as the dual problems
@@ -1360,6 +1395,7 @@ int build_plan(fdql_agent *a) {
       for (size_t i = 1; i < nh; ++i) {
         Stage &ls = b.gemm_stage("critics.fwd" + std::to_string(i));
         ls.try_rows = true;
+        ls.hf_role = fuse ? 1 : 0;
         for (int k = 0; k < C; ++k) {
           int which = 0;
           for (MlpInst *m : {&ct[k], &co[k], &cf[k]}) {
@@ -1413,8 +1449,27 @@ int build_plan(fdql_agent *a) {
         if (okf) {
           const int ninst = 3 * C, planes = a->hf_planes;
           if (!sum_in_finish)
-            b.func_stage("critics.head_sum", [=](hipStream_t s) { return reduce_partials_batched_launch(hf_parts, ninst, planes, MQ, hf_sum, s); });
-          b.func_stage("critics.head", [=](hipStream_t s) { return head_finish_launch(ha, s); });
+            b.func_stage("critics.head_sum", [=](hipStream_t s) { return reduce_partials_batched_launch(hf_parts, ninst, planes, MQ, hf_sum, s); }).hf_role = 2;
+          // the form the finish takes when every hidden layer's launch sums its own planes (decided in upload_tables): one plane
+          // per layer, added while they are read
+          HeadFinishArgs hp = ha;
+          bool same = true;
+          for (size_t i = 1; i < nh; ++i) same = same && a->critic[0].hid[i] == a->critic[0].hid[0];
+          hp.sum_planes = 1;
+          hp.planes = (int)nh;
+          hp.plane_step = ((a->critic[0].hid[0] + 63) / 64) * 2;
+          {
+            const long long inst_stride = (long long)a->hf_planes * MQ;
+            for (int k = 0; k < C; ++k) {
+              hp.g[0].parts[k][0] = hf_parts + inst_id(k, 1) * inst_stride;
+              hp.g[0].parts[k][1] = hf_parts + inst_id(k, 2) * inst_stride;
+              hp.g[1].parts[k][0] = hf_parts + inst_id(k, 0) * inst_stride;
+            }
+          }
+          auto hap = std::make_shared<HeadFinishArgs>(ha);
+          Stage &fs = b.func_stage("critics.head", [=](hipStream_t s) { return head_finish_launch(*hap, s); });
+          fs.hf_role = 3; fs.hfin = hap; fs.hfin_plain = ha; fs.hfin_presum = hp;
+          fs.hfin_can_presum = same && getenv("FDQL_NO_HEAD_PRESUM") == nullptr;
           finished = true;
         }
       }
@@ -1598,6 +1653,7 @@ int build_plan(fdql_agent *a) {
     first_rest_stage = a->stages.size();
   }
   // ---- policy backward
+  bool fuse_pd = false;
   {
     const float *lo = ao.out, *nz = a->buf("noise_actor"), *pi = a->buf("pi"), *dpi = a->buf("dpi_part"), *w = a->buf("w");
     float *dlo = a->buf("dlogits"), *dpi_sum = a->buf("dpi");
@@ -1605,9 +1661,23 @@ int build_plan(fdql_agent *a) {
     const float *lparts = a->buf("loss_partials");
     const LossFinishArgs fa = finish_args;
     const bool ride = ride_finish;
-    b.func_stage("policy_bwd", [=](hipStream_t s) {
-      return policy_bwd_launch(lo, nz, pi, dpi, C, dpi_sum, w, dst, M, A, dlo, disc, s, lparts, ride ? &fa : nullptr);
-    });
+    // the actor's last hidden layer under its narrow head: its pre-activation gradient in the same launch (FDQL_NO_POLICY_DPRE_FUSE:
+    // a GEMM stage of its own, as before round 4)
+    const int last = (int)a->actor.hid.size() - 1;
+    fuse_pd = last >= 0 && policy_bwd_dpre_takes(disc, A, a->actor.hid[last]) && a->actor.dout == 2 * A && ao.dpre[last] &&
+              getenv("FDQL_NO_POLICY_DPRE_FUSE") == nullptr;
+    if (fuse_pd) {
+      const float *Wh = ao.HW() + b.head_col_of_hidden(*ao.d, last), *h = ao.h[last];
+      const int ldw = ao.d->head_ld();
+      float *dpre = ao.dpre[last], *cs = ao.dpre_cs[last];
+      b.func_stage("policy_bwd+actor.dpre" + std::to_string(last), [=](hipStream_t s) {
+        return policy_bwd_dpre_launch(lo, nz, pi, dpi, C, dpi_sum, w, dst, M, A, dlo, Wh, ldw, h, dpre, cs, s, lparts, ride ? &fa : nullptr);
+      });
+    } else {
+      b.func_stage("policy_bwd", [=](hipStream_t s) {
+        return policy_bwd_launch(lo, nz, pi, dpi, C, dpi_sum, w, dst, M, A, dlo, disc, s, lparts, ride ? &fa : nullptr);
+      });
+    }
   }
   // ---- actor backward
   // The weight gradients of a network only need that network's own dpre/dY, so instead of one big
@@ -1615,6 +1685,7 @@ int build_plan(fdql_agent *a) {
   // (same tile shape -> same launch): those launches have only ~400 workgroups of their own.
   std::vector<size_t> hosts;  // stage indices of the dense dgrad launches after the critics' backward
   for (int i = (int)a->actor.hid.size() - 1; i >= 0; --i) {
+    if (fuse_pd && i == (int)a->actor.hid.size() - 1) continue;   // formed by the policy backward's launch
     // (the rank-2A product on the streaming kernel k_head_dgrad - 12 broadcast LDS reads per element - measured 0.050 ms against
     // 0.015 ms for this K = 12 problem on MFMA tiles at config 2: it stays a GEMM problem)
     Stage &gs = b.gemm_stage("actor.dpre" + std::to_string(i));
@@ -2776,6 +2847,14 @@ int fdql_test_rowgemm(const float *A0, const float *A1, int32_t k1, const float 
     const size_t bytes = (size_t)ninst * (M / 64) * RG_N * sizeof(float);
     FDQL_HIP(hipMemsetAsync(colsum, 0, bytes, (hipStream_t)stream));
     if (fz_colsum) FDQL_HIP(hipMemsetAsync(fz_colsum, 0, bytes, (hipStream_t)stream));
+  }
+  if (rl.ws && rl.wa.hf_q && getenv("FDQL_TEST_HF_PRESUM")) {
+    // the planes summed inside the kernel (WsArgs::hf_presum): plane 0 of each instance holds the total, the caller's other
+    // planes are cleared so that its sum over the plane axis is the total either way
+    const size_t bytes = (size_t)ninst * planes * M * hf_q * sizeof(float);
+    FDQL_HIP(hipMemsetAsync(hf_out, 0, bytes, (hipStream_t)stream));
+    if (dual) FDQL_HIP(hipMemsetAsync(hf_out2, 0, bytes, (hipStream_t)stream));
+    rl.wa.hf_presum = 1;
   }
   hipError_t e = rl.launch((hipStream_t)stream);
   if (e != hipSuccess) { set_error("row-block launch: %s", hipGetErrorString(e)); return FDQL_EHIP; }

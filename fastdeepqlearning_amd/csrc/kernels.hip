@@ -635,6 +635,122 @@ __global__ __launch_bounds__(256) void k_policy_bwd(const float *__restrict__ lo
   dlogits[(long long)m * 2 * A + A + j] = dls;
 }
 
+// The policy backward of 64 rows and, in the same launch, the pre-activation gradient of the actor's LAST hidden layer under
+// its narrow head (franQ: autograd through mlp.py:88-94 / soft_actor_critic.py:136-154):
+//   d logits[m, 0..2A)  as k_policy_bwd;   dpre[m, n] = LeakyReLU'(h[m, n]) * sum_k d logits[m, k] Wh[k, n]   (n < 256, fma chain over k)
+// and the per-64-row column sums of dpre (the bias gradient's partials, the tile kernel's layout).  The K = 2A product was a
+// GEMM launch of its own (12 us at config 2 on tiles that are 5 % MFMA work) behind a 6 us launch that produced its operand:
+// here the 64 rows' d logits stay in LDS, a lane owns four columns (Wh's 2A x 4 values in registers), a wave four rows.
+// 1024 threads per 64 rows: phase 1 has 64 A (row, action) items, phase 2 streams 64 KiB in and out per workgroup.
+constexpr int PBD_ROWS = 64, PBD_N = 256, PBD_MAXK = 16;
+struct PolicyBwdDpreArgs {
+  const float *Wh;      // head weights of the hidden layer's columns: element (k, n) at Wh[k * ldw + n]
+  int ldw;
+  const float *h;       // [M, 256] the layer's activations (gate reference)
+  float *dpre;          // [M, 256]
+  float *colsum;        // [ceil(M / 64), 256]
+};
+__global__ __launch_bounds__(1024) void k_policy_bwd_dpre(const float *__restrict__ logits, const float *__restrict__ noise,
+                                                          const float *__restrict__ action, const float *__restrict__ dpi_parts, int nparts,
+                                                          float *__restrict__ dpi_sum, const float *__restrict__ w, const DevState *st, int M, int A,
+                                                          float *__restrict__ dlogits, PolicyBwdDpreArgs d, LossFinishRider fin, int own_blocks) {
+  if ((int)blockIdx.x >= own_blocks) {   // (uniform; the finish is written for 256 threads)
+    if (threadIdx.x < 256)
+      loss_finish_block(fin.partials, fin.f.nblocks, fin.f.M, fin.f.Nq, fin.f.st, fin.f.scalars, fin.f.dlog_alpha, fin.f.lr, fin.f.b1, fin.f.b2);
+    return;
+  }
+  typedef float pv4 __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) float dl[PBD_ROWS][PBD_MAXK];
+  __shared__ __attribute__((aligned(16))) float cs[16][PBD_N];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = blockIdx.x * PBD_ROWS, K = 2 * A;
+  // the gate references of this wave's rows and the head's K x 256 weights (-> LDS, rows beyond K zero): requested before
+  // phase 1's dependent loads
+  __shared__ __attribute__((aligned(16))) float wl[PBD_MAXK][PBD_N];
+  pv4 hq[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int m = min(r0 + 4 * wave + u, M - 1);
+    hq[u] = *reinterpret_cast<const pv4 *>(d.h + (long long)m * PBD_N + lane * 4);
+  }
+  {
+    float wv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = 4 * i + (tid >> 8), n = tid & 255;   // (k, n) of element tid + 1024 i
+      wv[i] = d.Wh[(long long)min(k, K - 1) * d.ldw + n];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = 4 * i + (tid >> 8);
+      wl[k][tid & 255] = k < K ? wv[i] : 0.f;
+    }
+  }
+  // ---- phase 1: d logits of the 64 rows (k_policy_bwd's arithmetic), kept in LDS
+  if (tid < PBD_ROWS * A) {
+    const int rl = tid / A, j = tid - rl * A, m = r0 + rl;
+    float dx = 0.f, dls = 0.f;
+    if (m < M) {
+      const float glp = w[m] * st->alpha_cur;
+      const float *lo = logits + (long long)m * 2 * A;
+      const float lsr = lo[A + j];
+      const float ls = fminf(fmaxf(lsr, -20.f), 2.f);
+      const float sd = (float)exp((double)ls);
+      const float eps = noise[(long long)m * A + j];
+      const float act = action[(long long)m * A + j];
+      const float om = 1.f - act * act;
+      float g = 0.f, gp[8];   // (the frozen critics' partials, fixed order; all requested before the first add)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) gp[c] = dpi_parts[((long long)min(c, nparts - 1) * M + m) * A + j];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) g += c < nparts ? gp[c] : 0.f;
+      for (int c = 8; c < nparts; ++c) g += dpi_parts[((long long)c * M + m) * A + j];
+      dpi_sum[(long long)m * A + j] = g;
+      dx = g * om + glp * (2.f * act * om / (om + 1e-4f));
+      const float dsd = dx * eps - glp / sd;
+      dls = dsd * sd;
+      if (lsr < -20.f || lsr > 2.f) dls = 0.f;
+      dlogits[(long long)m * 2 * A + j] = dx;
+      dlogits[(long long)m * 2 * A + A + j] = dls;
+    }
+    dl[rl][j] = dx;
+    dl[rl][A + j] = dls;
+  }
+  for (int e = tid; e < PBD_ROWS * (PBD_MAXK - K); e += 1024) dl[e / (PBD_MAXK - K)][K + e % (PBD_MAXK - K)] = 0.f;
+  __syncthreads();
+  // ---- phase 2: this wave's four rows
+  pv4 wk[PBD_MAXK];
+#pragma unroll
+  for (int k = 0; k < PBD_MAXK; ++k) wk[k] = *reinterpret_cast<const pv4 *>(&wl[k][lane * 4]);
+  pv4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int rl = 4 * wave + u, m = r0 + rl;
+    pv4 dq[PBD_MAXK / 4];
+#pragma unroll
+    for (int q = 0; q < PBD_MAXK / 4; ++q) dq[q] = *reinterpret_cast<const pv4 *>(&dl[rl][4 * q]);   // (same address in every lane: broadcast)
+    pv4 x = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < PBD_MAXK; ++k)   // (k >= K: 0 * 0 added)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) x[c] = fmaf(dq[k >> 2][k & 3], wk[k][c], x[c]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) x[c] = hq[u][c] > 0.f ? x[c] : 0.01f * x[c];
+    if (m < M) {
+      *reinterpret_cast<pv4 *>(d.dpre + (long long)m * PBD_N + lane * 4) = x;
+      sum += x;
+    }
+  }
+  *reinterpret_cast<pv4 *>(&cs[wave][lane * 4]) = sum;
+  __syncthreads();
+  if (tid < PBD_N) {
+    float t = 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) t += cs[v][tid];
+    d.colsum[(long long)blockIdx.x * PBD_N + tid] = t;
+  }
+}
+
 // ======================================================================================
 // Discrete actor: Gumbel-softmax straight-through sample and log-prob
 // (franQ/Agent/models/gumbel_mlp.py:7-54 on torch's ExpRelaxedCategorical.rsample, temperature 1)
@@ -1331,6 +1447,21 @@ hipError_t onehot_launch(const float *action, int rows, int n, float *out, hipSt
   return hipGetLastError();
 }
 
+bool policy_bwd_dpre_takes(int discrete, int A, int hidden) { return !discrete && 2 * A <= PBD_MAXK && A >= 1 && hidden == PBD_N; }
+hipError_t policy_bwd_dpre_launch(const float *logits, const float *noise, const float *action, const float *dpi_parts, int nparts,
+                                  float *dpi_sum, const float *w, const DevState *st, int M, int A, float *dlogits, const float *Wh,
+                                  int ldw, const float *h, float *dpre, float *colsum, hipStream_t s, const float *loss_partials,
+                                  const LossFinishArgs *fin) {
+  if (M <= 0) return hipSuccess;
+  if (2 * A > PBD_MAXK || (reinterpret_cast<uintptr_t>(h) & 15) || (reinterpret_cast<uintptr_t>(dpre) & 15)) return hipErrorInvalidValue;
+  LossFinishRider r = {};
+  if (fin) { r.partials = loss_partials; r.f = *fin; }
+  PolicyBwdDpreArgs d = {Wh, ldw, h, dpre, colsum};
+  const int own = (M + PBD_ROWS - 1) / PBD_ROWS;
+  hipLaunchKernelGGL(k_policy_bwd_dpre, dim3((unsigned)(own + (fin ? 1 : 0))), dim3(1024), 0, s, logits, noise, action, dpi_parts, nparts,
+                     dpi_sum, w, st, M, A, dlogits, d, r, own);
+  return hipGetLastError();
+}
 hipError_t policy_bwd_launch(const float *logits, const float *noise, const float *action, const float *dpi_parts,
                              int nparts, float *dpi_sum, const float *w, const DevState *st, int M, int A,
                              float *dlogits, int discrete, hipStream_t s, const float *loss_partials, const LossFinishArgs *fin) {
@@ -1549,16 +1680,18 @@ __global__ __launch_bounds__(64) void k_head_finish(HeadFinishArgs a) {
       pval[v][r] = (pp && row < M) ? pp[(long long)row * Q + q] : 0.f;
     }
     if (a.sum_planes && pp) {   // (uniform flag) the other planes, in order, eight requests in flight per row
-      const long long ps = (long long)M * Q;
+      const long long ps = (long long)M * Q * (a.plane_step > 1 ? a.plane_step : 1);
       for (int p0 = 1; p0 < a.planes; p0 += 8) {
         float x[8][4];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const int pl = p0 + u < a.planes ? p0 + u : a.planes - 1;
+          const int pl = p0 + u;
+          if (pl < a.planes) {   // (uniform: two planes when the layers' launches sum their own)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = min(row0 + 4 * kq + r, M - 1);
-            x[u][r] = pp[pl * ps + (long long)row * Q + q];
+            for (int r = 0; r < 4; ++r) {
+              const int row = min(row0 + 4 * kq + r, M - 1);
+              x[u][r] = pp[pl * ps + (long long)row * Q + q];
+            }
           }
         }
 #pragma unroll

@@ -212,6 +212,7 @@ struct HeadFinishGroup {
 struct HeadFinishArgs {
   int M, L, A, Q, planes, ngroups;
   int sum_planes;   // 1: the kernel adds the planes itself (in plane order): no reduction launch in front of it
+  int plane_step;   // ... planes 0, plane_step, 2 plane_step, ... (`planes` of them); 0 = 1.  > 1: one pre-summed plane per hidden layer
   HeadFinishGroup g[2];
 };
 hipError_t head_finish_launch(const HeadFinishArgs &a, hipStream_t s);
@@ -266,6 +267,13 @@ hipError_t policy_bwd_launch(const float *logits, const float *noise, const floa
                              int nparts, float *dpi_sum, const float *w, const DevState *st, int M, int A,
                              float *dlogits, int discrete, hipStream_t s, const float *loss_partials = nullptr,
                              const LossFinishArgs *fin = nullptr);
+// ... and the pre-activation gradient of the actor's last hidden layer (256 wide, continuous policy, 2A <= 16) in the same launch:
+// dpre = LeakyReLU'(h) * (d logits Wh), column sums per 64 rows
+bool policy_bwd_dpre_takes(int discrete, int A, int hidden);
+hipError_t policy_bwd_dpre_launch(const float *logits, const float *noise, const float *action, const float *dpi_parts, int nparts,
+                                  float *dpi_sum, const float *w, const DevState *st, int M, int A, float *dlogits, const float *Wh,
+                                  int ldw, const float *h, float *dpre, float *colsum, hipStream_t s,
+                                  const float *loss_partials = nullptr, const LossFinishArgs *fin = nullptr);
 
 inline int loss_blocks(int M, int G) { return (M + (256 / G) - 1) / (256 / G); }
 bool loss_wave_form(int distributional, int Nq);   // kernels.hip: the wave-per-row TQC loss takes this shape (then G = 64)

@@ -42,6 +42,7 @@ struct WsArgs {
   int lda[1 + WS_MAX_MINOR], ldw[1 + WS_MAX_MINOR];
   int dual;                  // 1: C = f(all segments but the last), C2 = f(all)
   int hf_q, hf_ldw;          // head fusion: outputs per row (2), 0 = off
+  int hf_presum;             // head fusion: 1 = a tile's eight column planes are summed in the kernel, hf_out holds ONE plane [M][hf_q]
   int grad;                  // dgrad forms - weights K-strided (element (k, n) at W[k*ldw + n]): 1: x *= LeakyReLU'(ref), column sums;
                              // 2: plain (no gate, no sums: one network's share of an input gradient)
   int fz, fz_ldw;            // dgrad form: A0 formed from (fz_h, dY = A1, fz_w) while it is staged

@@ -76,6 +76,8 @@ template <int OFF>
 __device__ __forceinline__ void ws_rd128a(v4f &d, unsigned addr) {   // destination in the AccVGPRs
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(d) : "v"(addr), "n"(OFF));
 }
+template <int OFF>
+__device__ __forceinline__ void ws_rd32(float &d, unsigned addr) { asm volatile("ds_read_b32 %0, %1 offset:%2" : "=&v"(d) : "v"(addr), "n"(OFF)); }
 template <int N>
 __device__ __forceinline__ void ws_lgkm_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ int ws_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
     if ((int)blockIdx.x >= a.wg_first[i]) inst = i;
   inst = ws_uni(inst);
   const int j0 = (int)blockIdx.x - a.wg_first[inst], stride = a.wg_first[inst + 1] - a.wg_first[inst];
-  const int nblk = a.blocks_per_inst, M = a.M;
+  const int nblk = a.blocks_per_inst;   // (M = 32 nblk)
   if (j0 >= nblk) return;
   const WsInst &I = a.inst[inst];   // kernel-argument segment: scalar loads, each field read once
   const float *A0 = ws_uni(I.A[0]);
@@ -172,6 +174,10 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
   // never used
   const bool has2 = DUAL && C2 != nullptr;
   float *const hf_out = ws_uni(I.hf_out), *const hf_out2 = ws_uni(I.hf_out2);
+  // presum: the tile whose sums the last block left in hfx (-1: none yet); -2: the launch writes every plane (one scalar
+  // register carries both: this kernel has none to spare)
+  int pprv = (HFQ > 0 && a.hf_presum != 0) ? -1 : -2;
+  float *const hfx = lds + (2 * IMG + 4 * 2 * 32 + 4 * 8 * 32 + NS * 2048);   // behind the per-wave constants: [2][2][4][32 * HFQ]
   const int lda0 = a.lda[0];
 
   // ---- stationary main weights: wb[tn][s] = W0[n0 + 32 tn + li][32 (s / 4) + 16 lh + 4 (s % 4) .. + 3]
@@ -298,15 +304,39 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
       ws_rider(hs[tn], cw[kq & 1], x);
     }
   };
-  // the head partial sums of a finished tile: plane = wave * 2 + tn (its 32 columns), both lane halves summed
-  auto hf_store = [&](v4f (&hs)[2], float *hout, int pblk) __attribute__((always_inline)) {
+  // the head partial sums of a finished tile: plane = wave * 2 + tn (its 32 columns), both lane halves summed.
+  // WsArgs::hf_presum (round 4): the eight planes of a tile are summed HERE - each wave leaves its two column tiles' sum in LDS
+  // (hfx[parity of the block][output][wave][32 rows x HFQ]), wave 0 adds the four waves in order one block later (behind that
+  // block's barrier) and writes ONE plane: the plane-sum launch in front of the head's finish and 7/8 of its input go away.
+  auto hf_store = [&](v4f (&hs)[2], float *hout, int pblk, int par, int o) __attribute__((always_inline)) {
     if constexpr (HFQ > 0) {
+      if (pprv != -2) {   // (uniform)
+        ws_anchor(hs[0]); ws_anchor(hs[1]);
+        const v2f y = {ws_sum_halves(hs[0][0]) + ws_sum_halves(hs[1][0]), ws_sum_halves(hs[0][1]) + ws_sum_halves(hs[1][1])};
+        *reinterpret_cast<v2f *>(hfx + (((par * 2 + o) * 4 + wave) * 32 + li) * HFQ) = y;   // (both lane halves write the same sums)
+        return;
+      }
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn) {
         ws_anchor(hs[tn]);
         const v2f y = {ws_sum_halves(hs[tn][0]), ws_sum_halves(hs[tn][1])};
-        gf base = ws_uni((gf)hout + ((long long)(wave * 2 + tn) * M + (long long)pblk * WS_BM) * HFQ);
+        gf base = ws_uni((gf)hout + ((long long)(wave * 2 + tn) * nblk + pblk) * (WS_BM * HFQ));
         *(gf2)(&base[(unsigned)(li * HFQ)]) = y;   // (both lane halves hold and write the same sums)
+      }
+    }
+  };
+  // presum: the sums a block left in hfx[par] -> one plane in memory, by wave 0 (block pp's 32 rows x HFQ = 64 floats, one per lane)
+  auto hf_emit = [&](int par, int pp) __attribute__((always_inline)) {
+    if constexpr (HFQ > 0) {
+      if (wave == 0 && pp >= 0) {   // (uniform; pp < 0: nothing pending, or not a presum launch)
+        const float *src = hfx + (par * 2) * 4 * 32 * HFQ + lane;
+        const float t = (src[0] + src[32 * HFQ]) + (src[2 * 32 * HFQ] + src[3 * 32 * HFQ]);
+        ((gf)ws_uni(hf_out + (long long)pp * WS_BM * HFQ))[(unsigned)lane] = t;
+        if (DUAL && has2) {
+          const float *src2 = src + 4 * 32 * HFQ;
+          const float t2 = (src2[0] + src2[32 * HFQ]) + (src2[2 * 32 * HFQ] + src2[3 * 32 * HFQ]);
+          ((gf)ws_uni(hf_out2 + (long long)pp * WS_BM * HFQ))[(unsigned)lane] = t2;
+        }
       }
     }
   };
@@ -324,7 +354,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
 
   // One tile: K loop into `ac` from image IM; the previous tile `pv` (block pblk) is finished and stored, the rows of the
   // next tile (block nxt) are fetched into the other image.
-  auto block = [&](auto has_prev, auto imgc, f32x16 (&ac)[2], f32x16 (&pv)[2], int nxt, int pblk) __attribute__((always_inline)) {
+  auto block = [&](auto has_prev, auto imgc, f32x16 (&ac)[2], f32x16 (&pv)[2], int nxt, int pblk, int ppblk) __attribute__((always_inline)) {
     constexpr bool HP = decltype(has_prev)::value;
     constexpr int IM = decltype(imgc)::value;
     constexpr int IOFF = IM * IMG * 4;   // < 64 KiB: fits the ds offset field
@@ -333,6 +363,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
     asm volatile("s_barrier" ::: "memory");
     const float *nsrc = ws_uni(A0 + (long long)nxt * WS_BM * lda0);
     v4f af[2];
+    float em[8];   // presum: the four waves' sums of the tile before the previous one (first / second output), wave 0
     ws_rd128<IOFF>(af[0], abase);
     if constexpr (HP) read_consts(std::integral_constant<int, 0>{});
     sfor<0, NSTEP>([&](auto sc) __attribute__((always_inline)) {
@@ -360,10 +391,31 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
         }
         if constexpr (s == 0) ws_anchor(pv[0], pv[1]);
         if constexpr (s < 8) quad(pv, C, hacc, pblk, kq);
+        // what the block before this one left in hfx[IM ^ 1]: wave 0 requests the four waves' sums at step 3 (uncounted asm
+        // reads: in order behind them, step 4's counted wait covers their arrival) and adds / stores them at step 4
+        if constexpr (HFQ > 0 && (s == 3 || s == 4)) {
+          if (wave == 0 && ppblk >= 0) {   // (uniform)
+            constexpr int EB = ((IM ^ 1) * 2) * 4 * 32 * HFQ * 4, WSTEP = 32 * HFQ * 4;   // bytes
+            if constexpr (s == 3) {
+              const unsigned ea = ws_lds_addr(hfx) + (unsigned)lane * 4u;
+              ws_rd32<EB>(em[0], ea); ws_rd32<EB + WSTEP>(em[1], ea); ws_rd32<EB + 2 * WSTEP>(em[2], ea); ws_rd32<EB + 3 * WSTEP>(em[3], ea);
+              if (DUAL && has2) {
+                ws_rd32<EB + 4 * WSTEP>(em[4], ea); ws_rd32<EB + 5 * WSTEP>(em[5], ea); ws_rd32<EB + 6 * WSTEP>(em[6], ea); ws_rd32<EB + 7 * WSTEP>(em[7], ea);
+              }
+            } else {
+              asm volatile("" : "+v"(em[0]), "+v"(em[1]), "+v"(em[2]), "+v"(em[3]));
+              ((gf)ws_uni(hf_out + (long long)ppblk * WS_BM * HFQ))[(unsigned)lane] = (em[0] + em[1]) + (em[2] + em[3]);
+              if (DUAL && has2) {
+                asm volatile("" : "+v"(em[4]), "+v"(em[5]), "+v"(em[6]), "+v"(em[7]));
+                ((gf)ws_uni(hf_out2 + (long long)ppblk * WS_BM * HFQ))[(unsigned)lane] = (em[4] + em[5]) + (em[6] + em[7]);
+              }
+            }
+          }
+        }
         if constexpr (!DUAL) {
-          if constexpr (s == 9) hf_store(hacc, hf_out, pblk);
+          if constexpr (s == 9) hf_store(hacc, hf_out, pblk, IM, 0);
         } else {
-          if constexpr (s == 10) hf_store(hacc, hf_out, pblk);
+          if constexpr (s == 10) hf_store(hacc, hf_out, pblk, IM, 0);
           if constexpr (s >= 7 && s <= 18) {
             if (has2) {   // (uniform: the instance's second output)
               if constexpr (s == 7) read_narrow(std::integral_constant<int, NSL>{}, std::integral_constant<int, IM ^ 1>{});
@@ -378,7 +430,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
                 if constexpr (s == 9) ws_anchor(pv[0], pv[1]);
                 quad(pv, C2, hacc2, pblk, kq);
               }
-              if constexpr (s == 18) hf_store(hacc2, hf_out2, pblk);
+              if constexpr (s == 18) hf_store(hacc2, hf_out2, pblk, IM, 1);
             }
           }
         }
@@ -429,7 +481,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
   }
   WS_STAMP(1);
   int nxt = blk + stride < nblk ? blk + stride : blk;   // a workgroup's last tile prefetches itself again (nobody reads it)
-  block(F(), I0(), acc[0], acc[1], nxt, 0);
+  block(F(), I0(), acc[0], acc[1], nxt, 0, -1);
   WS_STAMP(2);
   WS_STAMP_TILE;
   int prv = blk, set = 1;
@@ -437,14 +489,14 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
 #pragma unroll 1
   while (blk < nblk) {
     nxt = blk + stride < nblk ? blk + stride : blk;
-    block(T(), I1(), acc[1], acc[0], nxt, prv);
+    block(T(), I1(), acc[1], acc[0], nxt, prv, pprv);
     WS_STAMP_TILE;
-    prv = blk; blk += stride; set = 0;
+    pprv = pprv == -2 ? -2 : prv; prv = blk; blk += stride; set = 0;
     if (blk >= nblk) break;
     nxt = blk + stride < nblk ? blk + stride : blk;
-    block(T(), I0(), acc[0], acc[1], nxt, prv);
+    block(T(), I0(), acc[0], acc[1], nxt, prv, pprv);
     WS_STAMP_TILE;
-    prv = blk; blk += stride; set = 1;
+    pprv = pprv == -2 ? -2 : prv; prv = blk; blk += stride; set = 1;
   }
   WS_STAMP(3);
   // ---- the last tile's result, not overlapped.  Its image is still in place: image (set ^ 1) - the last block ran on it
@@ -473,8 +525,19 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
       });
     }
     asm volatile("s_nop 7" ::: "memory");   // rider results -> VALU readers
-    hf_store(hacc, hf_out, prv);
-    if (DUAL && has2) hf_store(hacc2, hf_out2, prv);
+    constexpr int PL = decltype(imc)::value;   // the last block ran on image PL and left tile pprv's sums in hfx[PL]
+    if constexpr (HFQ > 0) {
+      if (pprv != -2) __syncthreads();   // wave 0 has taken what it had to take from hfx[PL ^ 1] (the last block's step 3)
+    }
+    hf_store(hacc, hf_out, prv, PL ^ 1, 0);
+    if (DUAL && has2) hf_store(hacc2, hf_out2, prv, PL ^ 1, 1);
+    if constexpr (HFQ > 0) {
+      if (pprv != -2) {
+        __syncthreads();
+        hf_emit(PL, pprv);
+        hf_emit(PL ^ 1, prv);
+      }
+    }
   };
   if (set == 1) flush(acc[0], I0());
   else flush(acc[1], I1());
@@ -492,6 +555,9 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
 // over ROWS that the bias gradients need run over lanes: each lane keeps its own running sums over all tiles of the
 // workgroup (one v_add per value, as an in-lane sum would cost) and the 32 lanes are added ONCE, when the workgroup ends;
 // colsum / fz_colsum therefore hold one partial row per WORKGROUP of the instance (WsArgs::wg_first), not per 64 rows.
+#ifndef WS_EXP
+#define WS_EXP 0   // timing experiments only (results are wrong with any bit set)
+#endif
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float ws_dpp(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xf, true));
@@ -608,7 +674,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
   }
   auto cs_read = [&](auto kqc) __attribute__((always_inline)) {
     constexpr int kq = decltype(kqc)::value & 7;
-    if constexpr (!PLAIN) ws_rd128<kq * 4096>(csq[kq & 1], cs_addr);
+    if constexpr (!PLAIN && !(WS_EXP & 2)) ws_rd128<kq * 4096>(csq[kq & 1], cs_addr);
   };
   v4f fcs = {0.f, 0.f, 0.f, 0.f};   // FUSE: running column sums of the formed A0 over the rows this thread stages
   v4f sh[4];                        // FUSE: row pieces in flight (fz_h)
@@ -628,17 +694,24 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
     v4f t;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
+#if WS_EXP & 16
+      float x = h[c];
+#else
       float x = dz0 * fw0[c];
       x = fmaf(dz1, fw1[c], x);
       x = h[c] > 0.f ? x : 0.01f * x;
+#endif
       t[c] = x;
+#if !(WS_EXP & 1)
       fcs[c] = fmaf(live, x, fcs[c]);   // live = 0 on the self-prefetch of a workgroup's last tile (counted once already)
+#endif
     }
     return t;
   };
   // (uniform bases once per tile, the quad's columns as instruction offsets: one scalar register pair per pointer)
   auto ref_load = [&](v4f &dst, gcf rbase, int kq) __attribute__((always_inline)) {
     if constexpr (PLAIN) return;
+    if (WS_EXP & 4) return;
     const int tn = (kq >> 2) & 1, q = kq & 3;
     dst = *(gcf4)(&ws_uni(rbase + 32 * tn + 8 * q)[vo_c]);
   };
@@ -648,15 +721,15 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const float v = pv[tn][4 * q + c];
-      if constexpr (PLAIN) {
+      if constexpr (PLAIN || (WS_EXP & 4)) {
         x[c] = v;
       } else {
         const float y = rq[kq % 4][c] > 0.f ? v : 0.01f * v;
         x[c] = y;
       }
     }
-    *(gf4)(&ws_uni(cbase + 32 * tn + 8 * q)[vo_c]) = x;
-    if constexpr (!PLAIN) {   // (requested a quad ahead: in order behind it, the LDS write below is seen by the next tile's read)
+    if (!(WS_EXP & 32)) *(gf4)(&ws_uni(cbase + 32 * tn + 8 * q)[vo_c]) = x;
+    if constexpr (!PLAIN && !(WS_EXP & 2)) {   // (requested a quad ahead: in order behind it, the LDS write below is seen by the next tile's read)
       csq[kq & 1] += x;
       *reinterpret_cast<v4f *>(csl + ((kq & 7) * 256 + tid) * 4) = csq[kq & 1];
     }
@@ -722,7 +795,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
           const float d0 = sdz.x, d1 = sdz.y;
           const v4f t = fuse_row(sh[u & 3], __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d0), u)),
                                  __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d1), u)), live);
-          if (keep_fz) (nout_w + (u - 4) * (LD / 4))[(unsigned)lane] = t;   // (workgroup-uniform: frozen instances have no weight gradients)
+          if (keep_fz && !(WS_EXP & 8)) (nout_w + (u - 4) * (LD / 4))[(unsigned)lane] = t;   // (workgroup-uniform: frozen instances have no weight gradients)
           *reinterpret_cast<v4f *>(lds + (IM ^ 1) * IMG + row * P + lane * 4) = t;
         }
         if constexpr (ureq >= 0) {   // (after the use of the register it refills)
@@ -1051,7 +1124,7 @@ template <int NSL, int NST, int HFQ>
 static hipError_t ws_launch(const WsArgs &a, hipStream_t s) {
   static bool attr[64];
   // two images + per-wave constants (bias, rider weights, 8 KiB of narrow weights per slot)
-  constexpr int lds_need = (2 * WS_BM * (WS_KMAIN + 8 * (NSL + NST) + 4) + 4 * 2 * 32 + 4 * 8 * 32 + (NSL + NST) * 2048) * 4;
+  constexpr int lds_need = (2 * WS_BM * (WS_KMAIN + 8 * (NSL + NST) + 4) + 4 * 2 * 32 + 4 * 8 * 32 + (NSL + NST) * 2048 + 2 * 2 * 4 * 32 * HFQ) * 4;
   constexpr int lds_stage = 4 * 32 * (WS_KMAIN + 4) * 4;   // the weight load's transposition area (4 waves x 32 rows)
   constexpr int lds_bytes = lds_need > lds_stage ? lds_need : lds_stage;
   return ws_launch_kernel(&k_wstat<NSL, NST, HFQ>, lds_bytes, attr, a, s);

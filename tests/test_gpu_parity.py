@@ -572,6 +572,12 @@ def test_update_matches_oracle_config2(dev, T, B, hid):
     ("ragged sizes on the tile kernels (FDQL_SMALL_GEMM=0; B=7, odd widths 18/33/21: unaligned rows, partial tiles, M < one tile)",
      dict(obs=3, act=2, C=2, Q=4, T=3, B=7, critic_hidden=(33, 18), pi_hidden=(21,), enc_hidden=(18,), joint_hidden=(33,),
           latent=21, enc_features=18, env={"FDQL_SMALL_GEMM": "0"})),
+    ("policy backward and the actor's last-layer gradient in one launch (k_policy_bwd_dpre): 8 actions (2A = 16, the widest head it "
+     "takes), 99 gradient rows (partial 64-row block)", dict(obs=17, act=8, C=3, Q=4, T=4, B=33)),
+    ("config 2 dims with the actor's last-layer gradient as a GEMM stage of its own (FDQL_NO_POLICY_DPRE_FUSE: the path the fused "
+     "launch replaces)", dict(obs=17, act=6, C=5, Q=2, T=4, B=64, env={"FDQL_NO_POLICY_DPRE_FUSE": "1"})),
+    ("config 2 dims on the weight-stationary kernel writing every head plane (FDQL_NO_HEAD_PRESUM: plane-sum launch + finish, the "
+     "path the in-kernel plane sum replaces)", dict(obs=17, act=6, C=5, Q=2, T=5, B=64, env={"FDQL_ROWGEMM": "all", "FDQL_NO_HEAD_PRESUM": "1"})),
     ("config 2 dims on the LDS-DMA GEMM, 128x128 tiles (dense shape 7: dual outputs + head fusion in that kernel)",
      dict(obs=17, act=6, C=5, Q=2, T=6, B=64, dense_shape=7)),
     ("ragged sizes on the LDS-DMA GEMM, 64x64 tiles (edge tiles and ragged chunks through its guarded path)",
@@ -1118,7 +1124,7 @@ def test_graph_replay_matches_eager_launches(dev, T, B, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("wstat", ["1", "0"])
+@pytest.mark.parametrize("wstat", ["1", "0", "presum"])
 @pytest.mark.parametrize("form", ["fwd", "fwd_hf", "fwd_minor_hf", "dgrad", "dgrad_fused", "dual_hf", "fwd_wide", "dual_wide", "dgrad_wide"])
 @pytest.mark.parametrize("M,ninst", [(64, 1), (192, 3), (1280, 15), (12544, 10)])
 def test_rowgemm_forms(dev, form, M, ninst, wstat, monkeypatch):
@@ -1129,6 +1135,12 @@ def test_rowgemm_forms(dev, form, M, ninst, wstat, monkeypatch):
     tiles than workgroups (the software-pipelined path) and the update's own size."""
     from fastdeepqlearning_amd import _native as nat
     monkeypatch.setenv("FDQL_ROWGEMM_FORMS", "7")
+    presum = wstat == "presum"   # the weight-stationary kernel summing a tile's head planes itself (WsArgs::hf_presum, the update's default)
+    if presum:
+        if form not in ("fwd_hf", "fwd_minor_hf", "dual_hf"):
+            pytest.skip("presum concerns the head-fusion forms")
+        monkeypatch.setenv("FDQL_TEST_HF_PRESUM", "1")
+        wstat = "1"
     monkeypatch.setenv("FDQL_WSTAT", wstat)
     if M > 2000 and wstat == "0":
         pytest.skip("the large case is the weight-stationary kernel's")
@@ -1199,9 +1211,15 @@ def test_rowgemm_forms(dev, form, M, ninst, wstat, monkeypatch):
             assert close(fcs, a0.view(ninst, M // 64, 64, 256).sum(2), 1e-4)
     if hfw is not None:
         w = hfw[:, :, :256].double().view(ninst, Q, 8, 32)
-        assert close(hfo, torch.einsum("impc,iqpc->ipmq", want.view(ninst, M, 8, 32), w), 1e-4)
-        if dual:
-            assert close(hfo2, torch.einsum("impc,iqpc->ipmq", want2.view(ninst, M, 8, 32), w), 1e-4)
+        if presum:   # plane 0 holds the sum over the eight column planes, the others were cleared by the hook
+            assert close(hfo[:, 0], torch.einsum("impc,iqpc->imq", want.view(ninst, M, 8, 32), w), 1e-4)
+            assert float(hfo[:, 1:].abs().max()) == 0.0
+            if dual:
+                assert close(hfo2[:, 0], torch.einsum("impc,iqpc->imq", want2.view(ninst, M, 8, 32), w), 1e-4)
+        else:
+            assert close(hfo, torch.einsum("impc,iqpc->ipmq", want.view(ninst, M, 8, 32), w), 1e-4)
+            if dual:
+                assert close(hfo2, torch.einsum("impc,iqpc->ipmq", want2.view(ninst, M, 8, 32), w), 1e-4)
     if wide and not ks:
         assert float(want.abs().max()) > 1.0   # (the wide narrow block contributes: 17 columns of unit-variance weights)
 

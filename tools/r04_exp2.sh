@@ -1,0 +1,8 @@
+#!/bin/bash
+# timing experiments on k_wstat_grad (libraries built with -DWS_EXP=n: results are wrong, only the stage times are read)
+mkdir -p gpurun_out/exp2
+python3 tools/profile_stages.py > gpurun_out/exp2/base.txt 2>&1
+for e in 1 2 4 8 16 32 63; do
+  FDQL_LIB_PATH=$PWD/fastdeepqlearning_amd/exp/libfdql_e$e.so timeout -k 10 120 python3 tools/profile_stages.py > gpurun_out/exp2/e$e.txt 2>&1
+done
+grep -H "dpre1\|dstate \|update-only" gpurun_out/exp2/*.txt
