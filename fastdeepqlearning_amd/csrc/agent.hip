@@ -695,6 +695,21 @@ struct Builder {
       }
     }
   }
+  // The column sums (bias gradients) and the tiny both-ways-narrow gradients of `skinny` that the streaming kernel takes join
+  // its launch when there is one: a launch less at the end of the step (FDQL_NO_COLSUM_STREAM: k_skinny_wgrad keeps them).
+  void colsums_into_stream(Stage &skinny, Stage &to) {
+    if (to.swg.empty() || getenv("FDQL_NO_COLSUM_STREAM")) return;
+    std::vector<SkinnyWgradProblem> first;   // (short waves: dispatched ahead of the streaming ones, they end under them)
+    for (size_t i = 0; i < skinny.swg.size();) {
+      if (stream_wgrad_takes(skinny.swg[i])) {
+        first.push_back(skinny.swg[i]);
+        skinny.swg.erase(skinny.swg.begin() + i);
+      } else {
+        ++i;
+      }
+    }
+    to.swg.insert(to.swg.begin(), first.begin(), first.end());
+  }
   // all weight / bias gradients of one MLP instance into the K-split slabs.  Every weight
   // gradient is a K-split GEMM (the narrow ones on the 128x32 / 32x128 tiles); bias gradients
   // come from the per-tile column sums the dgrad GEMMs leave behind (dy_cs / dpre_cs), or
@@ -1642,9 +1657,10 @@ int build_plan(fdql_agent *a) {
     Stage cnw;
     cnw.kind = ST_SKINNY_WGRAD; cnw.stream = true; cnw.name = "wgrad.critics.stream";
     b.take_stream_wgrads(cn, cnw, cws);
+    b.colsums_into_stream(cws, cnw);
     if (!cn.gemm.empty()) a->stages.push_back(cn);
     if (!cnw.swg.empty()) a->stages.push_back(cnw);
-    a->stages.push_back(cws);
+    if (!cws.swg.empty()) a->stages.push_back(cws);
     const float *slabs = a->buf("slabs");
     float *grads = a->grads;
     const int S = a->nsplit;
@@ -1880,9 +1896,10 @@ int build_plan(fdql_agent *a) {
     Stage nws;
     nws.kind = ST_SKINNY_WGRAD; nws.stream = true; nws.name = "wgrad.stream";
     b.take_stream_wgrads(tail, nws, ws);
+    b.colsums_into_stream(ws, nws);
     if (!tail.gemm.empty()) a->stages.push_back(tail);
     if (!nws.swg.empty()) a->stages.push_back(nws);
-    a->stages.push_back(ws);
+    if (!ws.swg.empty()) a->stages.push_back(ws);
     if (!conv_post.empty())
       b.func_stage("conv.wgrad_reduce", [=](hipStream_t s) {
         for (const auto &f : conv_post) { hipError_t e = f(s); if (e != hipSuccess) return e; }

@@ -329,10 +329,72 @@ __device__ __forceinline__ void stream_wgrad_tiny(const SkinnyWgradProblem &P, i
   }
 }
 
+// Column sums (dY == null: the bias gradients - sums of the per-tile partial rows the dgrad launches left, or of d z / d logits
+// over all rows) as problems of the same launch: they were a launch of their own behind this one (k_skinny_wgrad, 13 us at
+// config 2 for 4.6 MB).  256-wide X: a wave = 64 columns of one slab, sixteen rows in flight; K <= 16: a wave = one slab,
+// lanes take different rows, one butterfly at the end.
+__device__ __forceinline__ void stream_colsum_wide(const SkinnyWgradProblem &P, int split, int wave) {
+  typedef const __attribute__((address_space(1))) float *gcf;
+  typedef __attribute__((address_space(1))) float *gf;
+  const int lane = threadIdx.x, M = P.M;
+  const int per = (M + P.nsplit - 1) / P.nsplit;
+  const int m0 = split * per, m1 = min(M, m0 + per);
+  gcf X = (gcf)P.X + 64 * wave + lane;
+  float acc = 0.f;
+  for (int g = m0; g < m1; g += 16) {
+    float x[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) x[u] = X[(long long)min(g + u, m1 - 1) * 256];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc += g + u < m1 ? x[u] : 0.f;
+  }
+  ((gf)(P.dW + (long long)split * P.split_stride))[(long long)(64 * wave + lane) * P.sk] = acc;   // (a split without rows writes zero)
+}
+template <int KMAX>
+__device__ __forceinline__ void stream_colsum_narrow(const SkinnyWgradProblem &P, int split) {
+  typedef const __attribute__((address_space(1))) float *gcf;
+  typedef __attribute__((address_space(1))) float *gf;
+  const int lane = threadIdx.x, M = P.M, K = P.K, ldx = P.ldx;
+  const int per = (M + P.nsplit - 1) / P.nsplit;
+  const int m0 = split * per, m1 = min(M, m0 + per);
+  gcf X = (gcf)P.X;
+  float acc[KMAX];
+#pragma unroll
+  for (int c = 0; c < KMAX; ++c) acc[c] = 0.f;
+  for (int g = m0; g < m1; g += 4 * 64) {
+    float x[4][KMAX];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      gcf row = X + (long long)min(g + 64 * u + lane, m1 - 1) * ldx;
+#pragma unroll
+      for (int c = 0; c < KMAX; ++c) x[u][c] = row[min(c, K - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int c = 0; c < KMAX; ++c) acc[c] += g + 64 * u + lane < m1 ? x[u][c] : 0.f;
+  }
+  gf dst = (gf)(P.dW + (long long)split * P.split_stride);
+#pragma unroll
+  for (int c = 0; c < KMAX; ++c) {
+    float v = acc[c];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == c && c < K) dst[(long long)c * P.sk] = v;
+  }
+}
+
 __global__ __launch_bounds__(64) void k_stream_wgrad(const SkinnyWgradProblem *__restrict__ probs, int nprob) {
   const int bid = blockIdx.x;
   const int pi = find_problem<SkinnyWgradProblem, &SkinnyWgradProblem::block_start>(probs, nprob, bid, threadIdx.x & 63);
   const SkinnyWgradProblem &P = probs[pi];
+  if (!P.dY) {   // (workgroup-uniform) column sums
+    if (P.K <= 2) stream_colsum_narrow<2>(P, bid - P.block_start);
+    else if (P.K <= 8) stream_colsum_narrow<8>(P, bid - P.block_start);
+    else if (P.K <= 16) stream_colsum_narrow<16>(P, bid - P.block_start);
+    else stream_colsum_wide(P, (bid - P.block_start) >> 2, (bid - P.block_start) & 3);
+    return;
+  }
   if (P.K <= 32) { stream_wgrad_tiny(P, bid - P.block_start); return; }   // (workgroup-uniform)
   const int split = (bid - P.block_start) >> 2, wave = (bid - P.block_start) & 3;   // a workgroup is ONE wave: 64 columns of one slab
   const int ng = (P.Nout + 3) >> 2;   // workgroup-uniform: one of four loop bodies
@@ -353,7 +415,9 @@ int stream_wgrad_finalize(SkinnyWgradProblem *p, int n) {
 }
 
 bool stream_wgrad_takes(const SkinnyWgradProblem &p) {
-  if (!p.dY || !p.X || p.Nout < 1 || p.Nout > 32 || p.M < 1 || p.nsplit < 1) return false;
+  if (!p.X || p.M < 1 || p.nsplit < 1) return false;
+  if (!p.dY) return p.Nout == 1 && ((p.K == 256 && p.ldx == 256) || (p.K >= 1 && p.K <= 16));   // column sums
+  if (p.Nout < 1 || p.Nout > 32) return false;
   return (p.K == 256 && p.ldx == 256) || (p.K >= 1 && p.K <= 32);   // 256-wide X, or narrow both ways
 }
 
