@@ -627,7 +627,10 @@ struct Builder {
       return;
     }
     // narrow problems (other tile shapes = other launches) are pooled in one stage at the end
-    (gemm_shape_is_dense(gemm_pick_shape(p, gemm_dense_shape())) ? gs : narrow).gemm.push_back(p);
+    // (33..36 outputs over a 256-wide input - the 2 x 17 logits of config 4's actor head - pick a square tile shape, 20 TF for an
+    // HBM-bound product: they go with the narrow ones, where the streaming launch takes them)
+    const bool streams = nout > 32 && nout <= STREAM_WGRAD_MAX_OUT && width == 256 && ldx == 256;
+    (gemm_shape_is_dense(gemm_pick_shape(p, gemm_dense_shape())) && !streams ? gs : narrow).gemm.push_back(p);
   }
   // bias gradient = column sums of dOut over R rows, from per-64-row partials `cs` when the dgrad GEMM left them
   void wgrad_bias(int R, const float *dOut, int ldo, int nout, const float *cs, float *dst, Stage &ws, int cs_rows = 0) {
@@ -678,7 +681,9 @@ struct Builder {
       if (ok) {
         const GemmSeg &sg = p.seg[0];   // dW[nout = p.M][width = p.N] = dOut[R, nout]^T X[R, width]
         q.M = sg.K; q.K = 256; q.ldx = 256; q.dW = p.C; q.split_stride = p.split_stride; q.nsplit = p.ksplit;
-        if (all && p.N == 256 && sg.ldb == 256 && p.M <= 32) {   // few outputs over a 256-wide input
+        // (33..36 outputs - config 4's 2 x 17 logits - are two row tiles on the 32-row tile shape and a 20 TF launch on the square
+        // one: they stream whatever the slab length)
+        if ((all || p.M > 32) && p.N == 256 && sg.ldb == 256 && p.M <= STREAM_WGRAD_MAX_OUT) {   // few outputs over a 256-wide input
           q.Nout = p.M; q.dY = sg.A; q.lddy = sg.lda; q.X = sg.B; q.sq = p.ldc; q.sk = 1;
         } else if (p.M == 256 && sg.lda == 256 && p.N <= 32) {   // few input columns: dW^T[a][n] = X2[R, a]^T dOut[R, n]
           q.Nout = p.N; q.dY = sg.B; q.lddy = sg.ldb; q.X = sg.A; q.sq = 1; q.sk = p.ldc;

@@ -131,6 +131,7 @@ __device__ __forceinline__ int find_problem(const P *probs, int nprob, int bid, 
 // Column-sum / narrow reductions (kernels.hip): bias gradients
 // ---------------------------------------------------------------------------------------
 constexpr int SKINNY_MAX_OUT = 32;
+constexpr int STREAM_WGRAD_MAX_OUT = 36;   // k_stream_wgrad over a 256-wide X: up to nine groups of four outputs
 
 // dW(q, k) (slab s) = sum_{m in split s} dY[m, q] * X[m, k], written to dW[q*sq + k*sk].
 // dY == null: dY = 1, Nout = 1 (column sums of X: bias gradients).

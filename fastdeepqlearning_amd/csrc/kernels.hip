@@ -272,6 +272,7 @@ __device__ __forceinline__ void stream_wgrad_body(const SkinnyWgradProblem &P, i
 // slab, a row pair = one v_mfma_f32_32x32x2_f32 (A: lane (q, parity) = dY[m + parity][q], B: lane (k, parity) = X[m + parity][k]),
 // 32 pairs per request round.  (On the tile kernel these were a 0.16 ms launch for 42 MB at config 4: one memory round trip per
 // 16 rows; one column per thread in k_skinny_wgrad: 0.18 ms.)
+constexpr int STREAM_COLSUM_NARROW_MAX = 40;   // column sums with lanes over rows: up to this many columns
 constexpr int SW2_TP = 32;   // row pairs per request round
 __device__ __forceinline__ void stream_wgrad_tiny(const SkinnyWgradProblem &P, int split) {
   typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -333,12 +334,15 @@ __device__ __forceinline__ void stream_wgrad_tiny(const SkinnyWgradProblem &P, i
 // over all rows) as problems of the same launch: they were a launch of their own behind this one (k_skinny_wgrad, 13 us at
 // config 2 for 4.6 MB).  256-wide X: a wave = 64 columns of one slab, sixteen rows in flight; K <= 16: a wave = one slab,
 // lanes take different rows, one butterfly at the end.
-__device__ __forceinline__ void stream_colsum_wide(const SkinnyWgradProblem &P, int split, int wave) {
+__device__ __forceinline__ void stream_colsum_wide(const SkinnyWgradProblem &P, int grp, int wave) {
   typedef const __attribute__((address_space(1))) float *gcf;
   typedef __attribute__((address_space(1))) float *gf;
-  const int lane = threadIdx.x, M = P.M;
-  const int per = (M + P.nsplit - 1) / P.nsplit;
-  const int m0 = split * per, m1 = min(M, m0 + per);
+  // G = P.lddy row groups (stream_wgrad_finalize: about 64 rows each, at most one per slab - this launch's register count
+  // allows eight waves per CU, so a wave per slab and 64 columns of a 25-row table would spend a dispatch round on nothing):
+  // group g's sum goes to slab g, slabs g + G, g + 2 G, ... get its zeros
+  const int lane = threadIdx.x, M = P.M, G = P.lddy;
+  const int per = (M + G - 1) / G;
+  const int m0 = grp * per, m1 = min(M, m0 + per);
   gcf X = (gcf)P.X + 64 * wave + lane;
   float acc = 0.f;
   for (int g = m0; g < m1; g += 16) {
@@ -348,9 +352,12 @@ __device__ __forceinline__ void stream_colsum_wide(const SkinnyWgradProblem &P, 
 #pragma unroll
     for (int u = 0; u < 16; ++u) acc += g + u < m1 ? x[u] : 0.f;
   }
-  ((gf)(P.dW + (long long)split * P.split_stride))[(long long)(64 * wave + lane) * P.sk] = acc;   // (a split without rows writes zero)
+  for (int sl = grp; sl < P.nsplit; sl += G) {
+    ((gf)(P.dW + (long long)sl * P.split_stride))[(long long)(64 * wave + lane) * P.sk] = acc;
+    acc = 0.f;
+  }
 }
-template <int KMAX>
+template <int KMAX, int U = 4>   // U x 64 rows in flight
 __device__ __forceinline__ void stream_colsum_narrow(const SkinnyWgradProblem &P, int split) {
   typedef const __attribute__((address_space(1))) float *gcf;
   typedef __attribute__((address_space(1))) float *gf;
@@ -361,16 +368,16 @@ __device__ __forceinline__ void stream_colsum_narrow(const SkinnyWgradProblem &P
   float acc[KMAX];
 #pragma unroll
   for (int c = 0; c < KMAX; ++c) acc[c] = 0.f;
-  for (int g = m0; g < m1; g += 4 * 64) {
-    float x[4][KMAX];
+  for (int g = m0; g < m1; g += U * 64) {
+    float x[U][KMAX];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       gcf row = X + (long long)min(g + 64 * u + lane, m1 - 1) * ldx;
 #pragma unroll
       for (int c = 0; c < KMAX; ++c) x[u][c] = row[min(c, K - 1)];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int c = 0; c < KMAX; ++c) acc[c] += g + 64 * u + lane < m1 ? x[u][c] : 0.f;
   }
@@ -392,6 +399,7 @@ __global__ __launch_bounds__(64) void k_stream_wgrad(const SkinnyWgradProblem *_
     if (P.K <= 2) stream_colsum_narrow<2>(P, bid - P.block_start);
     else if (P.K <= 8) stream_colsum_narrow<8>(P, bid - P.block_start);
     else if (P.K <= 16) stream_colsum_narrow<16>(P, bid - P.block_start);
+    else if (P.K <= STREAM_COLSUM_NARROW_MAX) stream_colsum_narrow<STREAM_COLSUM_NARROW_MAX, 2>(P, bid - P.block_start);   // (25 atoms, 34 logits)
     else stream_colsum_wide(P, (bid - P.block_start) >> 2, (bid - P.block_start) & 3);
     return;
   }
@@ -401,14 +409,21 @@ __global__ __launch_bounds__(64) void k_stream_wgrad(const SkinnyWgradProblem *_
   if (ng <= 1) stream_wgrad_body<1>(P, split, wave);
   else if (ng <= 3) stream_wgrad_body<3>(P, split, wave);
   else if (ng <= 5) stream_wgrad_body<5>(P, split, wave);
-  else stream_wgrad_body<8>(P, split, wave);
+  else if (ng <= 8) stream_wgrad_body<8>(P, split, wave);
+  else stream_wgrad_body<9>(P, split, wave);   // (33..36 outputs: the 2 x 17 logits of config 4's actor head)
 }
 
 int stream_wgrad_finalize(SkinnyWgradProblem *p, int n) {
   int total = 0;
   for (int i = 0; i < n; ++i) {
-    p[i].col_blocks = p[i].K <= 32 ? 1 : 4;
+    p[i].col_blocks = (p[i].K <= 32 || (!p[i].dY && p[i].K <= STREAM_COLSUM_NARROW_MAX)) ? 1 : 4;
     p[i].block_start = total;
+    if (!p[i].dY && p[i].K > STREAM_COLSUM_NARROW_MAX) {   // column sums of a 256-wide table: row groups instead of slabs (stream_colsum_wide)
+      const int g = std::max(1, std::min(p[i].nsplit, (p[i].M + 63) / 64));
+      p[i].lddy = g;
+      total += 4 * g;
+      continue;
+    }
     total += p[i].col_blocks * p[i].nsplit;
   }
   return total;
@@ -416,9 +431,9 @@ int stream_wgrad_finalize(SkinnyWgradProblem *p, int n) {
 
 bool stream_wgrad_takes(const SkinnyWgradProblem &p) {
   if (!p.X || p.M < 1 || p.nsplit < 1) return false;
-  if (!p.dY) return p.Nout == 1 && ((p.K == 256 && p.ldx == 256) || (p.K >= 1 && p.K <= 16));   // column sums
-  if (p.Nout < 1 || p.Nout > 32) return false;
-  return (p.K == 256 && p.ldx == 256) || (p.K >= 1 && p.K <= 32);   // 256-wide X, or narrow both ways
+  if (!p.dY) return p.Nout == 1 && ((p.K == 256 && p.ldx == 256) || (p.K >= 1 && p.K <= STREAM_COLSUM_NARROW_MAX));   // column sums
+  if (p.Nout < 1 || p.Nout > STREAM_WGRAD_MAX_OUT) return false;
+  return (p.K == 256 && p.ldx == 256) || (p.K >= 1 && p.K <= 32 && p.Nout <= 32);   // 256-wide X, or narrow both ways
 }
 
 hipError_t stream_wgrad_launch(const SkinnyWgradProblem *dev, int n, int total_blocks, hipStream_t s) {

@@ -135,7 +135,7 @@ hipError_t act_fused_launch(const ActFusedArgs &a, hipStream_t s);
 hipError_t head_dgrad_launch(const HeadDgradProblem *dev, int n, int total_blocks, hipStream_t s);
 hipError_t skinny_wgrad_launch_host(const SkinnyWgradProblem *host, const SkinnyWgradProblem *dev, int n,
                                     int total_blocks, hipStream_t s);
-// Streaming form (kernels.hip, k_stream_wgrad): Nout <= 32 and X of exactly 256 columns (pitch 256: four single-wave
+// Streaming form (kernels.hip, k_stream_wgrad): Nout <= 36 (STREAM_WGRAD_MAX_OUT) and X of exactly 256 columns (pitch 256: four single-wave
 // workgroups per slab) or of <= 32 columns (one).
 bool stream_wgrad_takes(const SkinnyWgradProblem &p);
 int stream_wgrad_finalize(SkinnyWgradProblem *p, int n);
