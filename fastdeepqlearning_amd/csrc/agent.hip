@@ -1958,7 +1958,7 @@ hipError_t run_stage(fdql_agent *a, Stage &s, hipStream_t stream) {
       }
       return hipSuccess;
     case ST_SKINNY_WGRAD:
-      if (s.stream) return stream_wgrad_launch((const SkinnyWgradProblem *)s.dev, (int)s.swg.size(), s.blocks, stream);
+      if (s.stream) return stream_wgrad_launch(s.swg.data(), (const SkinnyWgradProblem *)s.dev, (int)s.swg.size(), s.blocks, stream);
       return skinny_wgrad_launch_host(s.swg.data(), (const SkinnyWgradProblem *)s.dev, (int)s.swg.size(), s.blocks, stream);
     case ST_FUNC: return s.fn(stream);
     case ST_HEAD_DGRAD: return head_dgrad_launch((const HeadDgradProblem *)s.dev, (int)s.hdg.size(), s.blocks, stream);

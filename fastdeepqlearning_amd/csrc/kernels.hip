@@ -273,7 +273,7 @@ __device__ __forceinline__ void stream_wgrad_body(const SkinnyWgradProblem &P, i
 // 32 pairs per request round.  (On the tile kernel these were a 0.16 ms launch for 42 MB at config 4: one memory round trip per
 // 16 rows; one column per thread in k_skinny_wgrad: 0.18 ms.)
 constexpr int STREAM_COLSUM_NARROW_MAX = 40;   // column sums with lanes over rows: up to this many columns
-constexpr int SW2_TP = 32;   // row pairs per request round
+constexpr int SW2_TP = 16;   // row pairs per request round
 __device__ __forceinline__ void stream_wgrad_tiny(const SkinnyWgradProblem &P, int split) {
   typedef float f32x16 __attribute__((ext_vector_type(16)));
   typedef const __attribute__((address_space(1))) float *gcf;
@@ -391,6 +391,11 @@ __device__ __forceinline__ void stream_colsum_narrow(const SkinnyWgradProblem &P
   }
 }
 
+// MAXNG: the widest problem's groups of four outputs (1, 3, 5, 8 or 9); TINY: the launch has both-ways-narrow problems.  The
+// register count of a launch is that of its widest path - 224 with everything in, two waves per SIMD; a launch whose problems
+// are all narrow (config 2: two or six outputs, at most twelve) gets the instantiation without the wide bodies: more single-wave
+// workgroups in flight for an HBM-latency-bound kernel.
+template <int MAXNG, bool TINY>
 __global__ __launch_bounds__(64) void k_stream_wgrad(const SkinnyWgradProblem *__restrict__ probs, int nprob) {
   const int bid = blockIdx.x;
   const int pi = find_problem<SkinnyWgradProblem, &SkinnyWgradProblem::block_start>(probs, nprob, bid, threadIdx.x & 63);
@@ -399,18 +404,21 @@ __global__ __launch_bounds__(64) void k_stream_wgrad(const SkinnyWgradProblem *_
     if (P.K <= 2) stream_colsum_narrow<2>(P, bid - P.block_start);
     else if (P.K <= 8) stream_colsum_narrow<8>(P, bid - P.block_start);
     else if (P.K <= 16) stream_colsum_narrow<16>(P, bid - P.block_start);
-    else if (P.K <= STREAM_COLSUM_NARROW_MAX) stream_colsum_narrow<STREAM_COLSUM_NARROW_MAX, 2>(P, bid - P.block_start);   // (25 atoms, 34 logits)
+    else if (P.K <= STREAM_COLSUM_NARROW_MAX) stream_colsum_narrow<STREAM_COLSUM_NARROW_MAX, 1>(P, bid - P.block_start);   // (25 atoms, 34 logits)
     else stream_colsum_wide(P, (bid - P.block_start) >> 2, (bid - P.block_start) & 3);
     return;
   }
-  if (P.K <= 32) { stream_wgrad_tiny(P, bid - P.block_start); return; }   // (workgroup-uniform)
+  if (P.K <= 32) {   // (workgroup-uniform)
+    if constexpr (TINY) stream_wgrad_tiny(P, bid - P.block_start);
+    return;
+  }
   const int split = (bid - P.block_start) >> 2, wave = (bid - P.block_start) & 3;   // a workgroup is ONE wave: 64 columns of one slab
-  const int ng = (P.Nout + 3) >> 2;   // workgroup-uniform: one of four loop bodies
+  const int ng = (P.Nout + 3) >> 2;   // workgroup-uniform: one of the loop bodies
   if (ng <= 1) stream_wgrad_body<1>(P, split, wave);
-  else if (ng <= 3) stream_wgrad_body<3>(P, split, wave);
-  else if (ng <= 5) stream_wgrad_body<5>(P, split, wave);
-  else if (ng <= 8) stream_wgrad_body<8>(P, split, wave);
-  else stream_wgrad_body<9>(P, split, wave);   // (33..36 outputs: the 2 x 17 logits of config 4's actor head)
+  else if (MAXNG >= 3 && ng <= 3) stream_wgrad_body<3>(P, split, wave);
+  else if (MAXNG >= 5 && ng <= 5) stream_wgrad_body<5>(P, split, wave);
+  else if (MAXNG >= 8 && ng <= 8) stream_wgrad_body<8>(P, split, wave);
+  else if (MAXNG >= 9) stream_wgrad_body<9>(P, split, wave);   // (33..36 outputs: the 2 x 17 logits of config 4's actor head)
 }
 
 int stream_wgrad_finalize(SkinnyWgradProblem *p, int n) {
@@ -436,9 +444,19 @@ bool stream_wgrad_takes(const SkinnyWgradProblem &p) {
   return (p.K == 256 && p.ldx == 256) || (p.K >= 1 && p.K <= 32 && p.Nout <= 32);   // 256-wide X, or narrow both ways
 }
 
-hipError_t stream_wgrad_launch(const SkinnyWgradProblem *dev, int n, int total_blocks, hipStream_t s) {
+hipError_t stream_wgrad_launch(const SkinnyWgradProblem *host, const SkinnyWgradProblem *dev, int n, int total_blocks, hipStream_t s) {
   if (total_blocks <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_stream_wgrad, dim3(total_blocks), dim3(64), 0, s, dev, n);
+  int ng = 1;
+  bool tiny = false;
+  for (int i = 0; i < n; ++i) {
+    if (!host[i].dY) continue;
+    if (host[i].K <= 32) tiny = true;
+    else ng = std::max(ng, (host[i].Nout + 3) >> 2);
+  }
+  const dim3 g(total_blocks), b(64);
+  if (ng <= 3 && !tiny) hipLaunchKernelGGL((k_stream_wgrad<3, false>), g, b, 0, s, dev, n);
+  else if (ng <= 5) hipLaunchKernelGGL((k_stream_wgrad<5, true>), g, b, 0, s, dev, n);
+  else hipLaunchKernelGGL((k_stream_wgrad<9, true>), g, b, 0, s, dev, n);
   return hipGetLastError();
 }
 

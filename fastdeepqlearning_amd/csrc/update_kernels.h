@@ -139,7 +139,7 @@ hipError_t skinny_wgrad_launch_host(const SkinnyWgradProblem *host, const Skinny
 // workgroups per slab) or of <= 32 columns (one).
 bool stream_wgrad_takes(const SkinnyWgradProblem &p);
 int stream_wgrad_finalize(SkinnyWgradProblem *p, int n);
-hipError_t stream_wgrad_launch(const SkinnyWgradProblem *dev, int n, int total_blocks, hipStream_t s);
+hipError_t stream_wgrad_launch(const SkinnyWgradProblem *host, const SkinnyWgradProblem *dev, int n, int total_blocks, hipStream_t s);
 hipError_t loss_launch(const LossArgs &a, hipStream_t s);
 // use_bootstrap_minibatch_nstep (soft_actor_critic.py:102-132, deepQlearning.py:226-228), SAC-min only:
 //   bound[b] = sum_t gamma^t r[t+1][b] + gamma^(T-1) td_target[T-2][b];
