@@ -2,6 +2,7 @@
 // loss with its analytic gradient, slab reduction, Adam + polyak.  gfx950, wave64.
 #include "common.h"
 #include "update_kernels.h"
+#include "dmath.h"
 #include <algorithm>
 #include <type_traits>
 
@@ -674,15 +675,15 @@ __global__ __launch_bounds__(256) void k_policy_fwd(PolicyFwdArgs a0, PolicyFwdA
     // transcendental functions through double, rounded once to f32: the log-prob below is
     // ill-conditioned near |a| -> 1 (d logp = 2a/(1-a^2+1e-4) da), so every ulp of exp/tanh/log
     // matters when comparing with the CPU path's (<= 1 ulp) vector math library.
-    const float sd = (float)exp((double)ls);
+    const float sd = (float)dm_exp((double)ls);
     const float eps = a.noise ? a.noise[(long long)m * A + j]
                               : device_noise(seed, (uint32_t)st->step, a.which, (uint32_t)(m * A + j), true);
     if (a.noise_out) a.noise_out[(long long)m * A + j] = eps;
     const float x = mean + eps * sd;
     const float d = x - mean;
-    lp = -(d * d) / (2.f * (sd * sd)) - (float)log((double)sd) - 0.91893853320467274178f;
-    const float act = (float)tanh((double)x);
-    lp -= (float)log((double)((1.f - act * act) + 1e-4f));
+    lp = -(d * d) / (2.f * (sd * sd)) - (float)dm_log((double)sd) - 0.91893853320467274178f;
+    const float act = (float)dm_tanh((double)x);
+    lp -= (float)dm_log((double)((1.f - act * act) + 1e-4f));
     a.action[(long long)m * A + j] = act;
     if (a.diff) a.diff[(long long)m * A + j] = act - a.sub[(long long)m * A + j];
   }
@@ -717,12 +718,16 @@ __global__ __launch_bounds__(256) void k_policy_bwd(const float *__restrict__ lo
   const float *lo = logits + (long long)m * 2 * A;
   const float lsr = lo[A + j];
   const float ls = fminf(fmaxf(lsr, -20.f), 2.f);
-  const float sd = (float)exp((double)ls);
+  const float sd = (float)dm_exp((double)ls);
   const float eps = noise[(long long)m * A + j];
   const float act = action[(long long)m * A + j];
   const float om = 1.f - act * act;
-  float g = 0.f;   // d loss / d pi_j = sum over the frozen critics' partials, fixed order
-  for (int c = 0; c < nparts; ++c) g += dpi_parts[((long long)c * M + m) * A + j];
+  float g = 0.f, gp[8];   // d loss / d pi_j = sum over the frozen critics' partials, fixed order (all requested before the first add)
+#pragma unroll
+  for (int c = 0; c < 8; ++c) gp[c] = dpi_parts[((long long)min(c, nparts - 1) * M + m) * A + j];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) g += c < nparts ? gp[c] : 0.f;
+  for (int c = 8; c < nparts; ++c) g += dpi_parts[((long long)c * M + m) * A + j];
   dpi_sum[(long long)m * A + j] = g;
   const float dx = g * om + glp * (2.f * act * om / (om + 1e-4f));
   const float dsd = dx * eps - glp / sd;
@@ -792,7 +797,7 @@ __global__ __launch_bounds__(1024) void k_policy_bwd_dpre(const float *__restric
       const float *lo = logits + (long long)m * 2 * A;
       const float lsr = lo[A + j];
       const float ls = fminf(fmaxf(lsr, -20.f), 2.f);
-      const float sd = (float)exp((double)ls);
+      const float sd = (float)dm_exp((double)ls);
       const float eps = noise[(long long)m * A + j];
       const float act = action[(long long)m * A + j];
       const float om = 1.f - act * act;
@@ -867,8 +872,8 @@ __device__ __forceinline__ float row_logsumexp(const LaneArr &x, int n) {
   float mx = -INFINITY;
   for (int j = 0; j < n; ++j) mx = fmaxf(mx, x[j]);
   float s = 0.f;
-  for (int j = 0; j < n; ++j) s += (float)exp((double)(x[j] - mx));
-  return mx + (float)log((double)s);
+  for (int j = 0; j < n; ++j) s += (float)dm_exp((double)(x[j] - mx));
+  return mx + (float)dm_log((double)s);
 }
 
 // forward pieces shared by fwd and bwd: norm = logits - lse, relaxed = softmax(norm + gumbel), hard index
@@ -879,14 +884,14 @@ __device__ __forceinline__ int gumbel_forward(const LaneArr &lo, const LaneArr &
   for (int j = 0; j < n; ++j) {
     norm[j] = lo[j] - lse;
     const float uc = fminf(fmaxf(u[j], tiny), 1.f - tiny);
-    const float g = -(float)log((double)(-(float)log((double)uc)));
+    const float g = -(float)dm_log((double)(-(float)dm_log((double)uc)));
     sc[j] = (norm[j] + g) / 1.0f;
   }
   const float lse2 = row_logsumexp(sc, n);
   int best = 0;
   float best_v = -INFINITY;
   for (int j = 0; j < n; ++j) {
-    const float r = (float)exp((double)(sc[j] - lse2));
+    const float r = (float)dm_exp((double)(sc[j] - lse2));
     relaxed[j] = r;
     if (j == 0 || r > best_v) { best_v = r; best = j; }   // first maximum, like torch.argmax
   }
@@ -958,13 +963,13 @@ __global__ __launch_bounds__(GUMBEL_THREADS) void k_policy_bwd_gumbel(const floa
     const float rj = relaxed[j];
     const float stv = (hard - rj) + rj;
     const float d_scores = rj * (gst[j] - dot_st);                                             // softmax backward
-    const float d_logsm = glp * stv - (float)exp((double)(norm[j] - lse3)) * sum_glogsm;       // log_softmax backward
+    const float d_logsm = glp * stv - (float)dm_exp((double)(norm[j] - lse3)) * sum_glogsm;       // log_softmax backward
     const float dn = d_scores + d_logsm;
     dnorm[j] = dn;
     sum_dnorm += dn;
   }
   for (int j = 0; j < n; ++j)
-    dlogits[(long long)m * n + j] = dnorm[j] - (float)exp((double)norm[j]) * sum_dnorm;        // norm = logits - lse
+    dlogits[(long long)m * n + j] = dnorm[j] - (float)dm_exp((double)norm[j]) * sum_dnorm;        // norm = logits - lse
 }
 
 // one-hot of the stored action index (deepQlearning.py:206-210)
@@ -2027,7 +2032,7 @@ __global__ void k_gru_cell_fwd(const float *__restrict__ gi, float *__restrict__
   }
   const float r = sigmoid_f(gi[g] + hr);
   const float z = sigmoid_f(gi[g + L] + hz);
-  const float n = (float)tanh((double)(gi[g + 2 * L] + r * hn));
+  const float n = (float)dm_tanh((double)(gi[g + 2 * L] + r * hn));
   const float hp = hprev[i];
   h[i] = (1.f - z) * n + z * hp;
   if (hprev_save) hprev_save[i] = hp;
@@ -2050,7 +2055,7 @@ __global__ void k_gru_cell_bwd(const float *__restrict__ dstate, const float *__
   const float hn = gh[g + 2 * L];
   const float r = sigmoid_f(gi[g] + gh[g]);
   const float z = sigmoid_f(gi[g + L] + gh[g + L]);
-  const float n = (float)tanh((double)(gi[g + 2 * L] + r * hn));
+  const float n = (float)dm_tanh((double)(gi[g + 2 * L] + r * hn));
   const float hp = hprev[i];
   const float dn_pre = (dh * (1.f - z)) * (1.f - n * n);
   const float dz_pre = (dh * (hp - n)) * (z * (1.f - z));
@@ -2282,16 +2287,16 @@ __device__ __forceinline__ void act_policy_row(const ActPolicyArgs &a, int m, co
   for (int j = 0; j < A; ++j) {
     const float mean = lo[j];
     const float ls = fminf(fmaxf(lo[A + j], -20.f), 2.f);
-    const float sd = (float)exp((double)ls);
+    const float sd = (float)dm_exp((double)ls);
     const float eps = a.noise ? a.noise[(long long)m * A + j]
                               : device_noise(a.seed, (uint32_t)a.counter, 7u, (uint32_t)(m * A + j), true);
     const float x = mean + eps * sd;
     const float d = x - mean;
-    float lp = -(d * d) / (2.f * (sd * sd)) - (float)log((double)sd) - 0.91893853320467274178f;
-    const float ex = (float)tanh((double)x);
-    lp -= (float)log((double)((1.f - ex * ex) + 1e-4f));
+    float lp = -(d * d) / (2.f * (sd * sd)) - (float)dm_log((double)sd) - 0.91893853320467274178f;
+    const float ex = (float)dm_tanh((double)x);
+    lp -= (float)dm_log((double)((1.f - ex * ex) + 1e-4f));
     logp += lp;
-    const float gr = (float)tanh((double)mean);
+    const float gr = (float)dm_tanh((double)mean);
     if (a.explore) a.explore[(long long)m * A + j] = ex;
     if (a.exploit) a.exploit[(long long)m * A + j] = gr;
     a.action[(long long)m * A + j] = use_exploit ? gr : ex;
@@ -2418,15 +2423,15 @@ __device__ __forceinline__ void act_gauss_elem(const ActPolicyArgs &a, int m, in
     const bool use_exploit = a.exploit_mask && a.exploit_mask[m] != 0;
     const float mean = lo[j];
     const float ls = fminf(fmaxf(lo[A + j], -20.f), 2.f);
-    const float sd = (float)exp((double)ls);
+    const float sd = (float)dm_exp((double)ls);
     const float eps = a.noise ? a.noise[(long long)m * A + j]
                               : device_noise(a.seed, (uint32_t)a.counter, 7u, (uint32_t)(m * A + j), true);
     const float x = mean + eps * sd;
     const float d = x - mean;
-    lp = -(d * d) / (2.f * (sd * sd)) - (float)log((double)sd) - 0.91893853320467274178f;
-    const float ex = (float)tanh((double)x);
-    lp -= (float)log((double)((1.f - ex * ex) + 1e-4f));
-    const float gr = (float)tanh((double)mean);
+    lp = -(d * d) / (2.f * (sd * sd)) - (float)dm_log((double)sd) - 0.91893853320467274178f;
+    const float ex = (float)dm_tanh((double)x);
+    lp -= (float)dm_log((double)((1.f - ex * ex) + 1e-4f));
+    const float gr = (float)dm_tanh((double)mean);
     if (a.explore) a.explore[(long long)m * A + j] = ex;
     if (a.exploit) a.exploit[(long long)m * A + j] = gr;
     a.action[(long long)m * A + j] = use_exploit ? gr : ex;
