@@ -75,6 +75,7 @@ struct MlpInst {
   float *out = nullptr;
   int ldout = 0;
   std::vector<float *> dpre;
+  std::vector<unsigned *> gm;    // per hidden layer: gate mask of h (GemmProblem::gm_*), [ceil(rows / 32)][4][64] dwords; empty: none
   std::vector<float *> dpre_cs;  // per hidden layer: [ceil(rows/64), hid] column sums of dpre (bias gradients)
   std::vector<int> dpre_cs_rows; // partial rows actually written there (0: one per 64 rows; the weight-stationary dgrad
                                  // launch writes one per workgroup of the instance, wstat.h)
@@ -144,6 +145,9 @@ struct Stage {
   // When every layer runs weight-stationary, the kernels sum a tile's planes themselves (WsArgs::hf_presum): stage 2 is switched
   // off and stage 3 adds one plane per layer as it reads them (hfin_presum instead of hfin_plain).
   int hf_role = 0;
+  // gate masks (GemmProblem::gm_*): 1 = a critics' forward layer whose weight-stationary launch writes them, 2 = a critics'
+  // backward launch that may gate by them - when EVERY stage of role 1 runs weight-stationary (else nobody writes or reads them)
+  int gm_role = 0;
   std::shared_ptr<HeadFinishArgs> hfin;
   HeadFinishArgs hfin_plain, hfin_presum;
   bool hfin_can_presum = false;
@@ -251,6 +255,7 @@ struct fdql_agent {
 
   DevState *st() const { return reinterpret_cast<DevState *>(ws + named.at("dev_state").first); }
   float *buf(const std::string &n) const { return reinterpret_cast<float *>(ws + named.at(n).first); }
+  bool has_buf(const std::string &n) const { return named.count(n) != 0; }
   float *alloc(const std::string &n, int64_t floats) {
     const int64_t bytes = (floats * 4 + 255) / 256 * 256;
     named[n] = {carve_top, floats};
@@ -434,6 +439,8 @@ void carve(fdql_agent *a) {
     mlp_bufs("crit_t" + s, a->critic[k], M, false, false);
     mlp_bufs("crit" + s, a->critic[k], M, true, false);
     mlp_bufs("crit_f" + s, a->critic[k], M, true, false);
+    for (size_t i = 0; i < a->critic[k].hid.size(); ++i)   // gate masks of the online and the frozen pass (wstat.hip; 32 bytes per row)
+      for (const char *pre : {"crit", "crit_f"}) a->alloc(pre + s + ".gm" + std::to_string(i), (int64_t)((M + 31) / 32) * 256);
   }
   {   // head fusion: per critic instance (3C of them) the partial head sums of every hidden layer, then their total
     int planes = 0;
@@ -551,6 +558,7 @@ struct Builder {
     }
     p.bias = m.Bv(i);
     p.epi = EPI_LRELU;
+    if ((size_t)i < m.gm.size()) p.gm_out = m.gm[i];
     return p;
   }
   // head: out = W_head cat(in, h_0..h_{n-1}) + b   (mlp.py:93-94); narrow heads get the 128x32 tile
@@ -589,6 +597,7 @@ struct Builder {
     p.ref = m.h[i];
     p.ldref = d.hid[i];
     p.colsum = m.dpre_cs[i];
+    if ((size_t)i < m.gm.size()) p.gm_ref = m.gm[i];
     return p;
   }
   // last hidden layer under a narrow head: the rank-dout outer product as a streaming kernel
@@ -944,6 +953,7 @@ MlpInst make_inst(fdql_agent *a, const MlpDesc &d, const std::string &p, const f
       m.dpre_cs.push_back(a->buf(p + ".cs" + std::to_string(i)));
       m.dpre_cs_rows.push_back(0);
     }
+    if (a->has_buf(p + ".gm" + std::to_string(i))) m.gm.push_back(reinterpret_cast<unsigned *>(a->buf(p + ".gm" + std::to_string(i))));
   }
   return m;
 }
@@ -1126,6 +1136,34 @@ int upload_tables(fdql_agent *a) {
           if (rl.ws) rl.wa.hf_presum = presum ? 1 : 0;
     if (fin) *fin->hfin = presum ? fin->hfin_presum : fin->hfin_plain;
     if (sum) sum->off = presum;
+  }
+  // gate masks: written by the critics' forward launches and read by their backward launches only when every one of those
+  // forward layers runs weight-stationary (the mask layout is that kernel's register layout); FDQL_NO_GATE_MASKS: never
+  {
+    int nfwd = 0;
+    bool all = getenv("FDQL_NO_GATE_MASKS") == nullptr;
+    for (Stage &s : a->stages) {
+      if (s.gm_role != 1) continue;
+      ++nfwd;
+      size_t n = 0;
+      bool ok = !s.rows.empty();
+      for (const RowsLaunch &rl : s.rows) { ok = ok && rl.ws; n += (size_t)rl.wa.ninst; }
+      all = all && ok && n == s.gemm.size();
+    }
+    const bool masks = nfwd > 0 && all;
+    for (Stage &s : a->stages) {
+      for (RowsLaunch &rl : s.rows) {
+        if (!rl.ws) continue;
+        if (rl.wa.grad == 0) {   // forward launches: nobody reads masks written outside the scheme
+          if (!masks || s.gm_role != 1)
+            for (int i = 0; i < rl.wa.ninst; ++i) rl.wa.inst[i].gm_out = rl.wa.inst[i].gm_out2 = nullptr;
+        } else if (s.gm_role == 2 && rl.wa.grad == 1) {   // gated dgrad forms: every instance must carry the masks it would read
+          bool have = masks;
+          for (int i = 0; i < rl.wa.ninst; ++i) have = have && rl.wa.inst[i].gm_ref && (!rl.wa.fz || rl.wa.inst[i].gm_fz);
+          rl.wa.use_masks = have ? 1 : 0;
+        }
+      }
+    }
   }
   return 0;
 }
@@ -1398,6 +1436,7 @@ int build_plan(fdql_agent *a) {
       Stage &gs = b.gemm_stage("critics.fwd0");
       gs.try_rows = true;
       gs.hf_role = fuse ? 1 : 0;
+      gs.gm_role = 1;
       for (int k = 0; k < C; ++k) {
         GemmProblem pt = b.fwd_layer(ct[k], 0);
         pt.emit_seg = pt.nseg - 1;   // no tail: rides in the same launch as the dual problems
@@ -1408,6 +1447,7 @@ int build_plan(fdql_agent *a) {
         p.emit_seg = p.nseg - 2;
         p.C2 = cf[k].h[0];
         p.ldc2 = a->critic[k].hid[0];
+        if (!cf[k].gm.empty()) p.gm_out2 = cf[k].gm[0];
         set_hf(p, co[k], 0, inst_id(k, 1), false);
         set_hf(p, cf[k], 0, inst_id(k, 2), true);
         gs.gemm.push_back(p);
@@ -1416,6 +1456,7 @@ int build_plan(fdql_agent *a) {
         Stage &ls = b.gemm_stage("critics.fwd" + std::to_string(i));
         ls.try_rows = true;
         ls.hf_role = fuse ? 1 : 0;
+        ls.gm_role = 1;
         for (int k = 0; k < C; ++k) {
           int which = 0;
           for (MlpInst *m : {&ct[k], &co[k], &cf[k]}) {
@@ -1588,6 +1629,7 @@ int build_plan(fdql_agent *a) {
         for (MlpInst *m : {&co[k], &cf[k]}) {
           GemmProblem p = b.bwd_dpre(*m, 0, a->buf(which == 0 ? "dz" : "dzf") + k * Q, Nq);
           p.fz_h = m->h[1];
+          if (m->gm.size() > 1) p.gm_fz = m->gm[1];
           p.fz_w = m->HW() + b.head_col_of_hidden(*m->d, 1);
           p.fz_ldw = m->d->head_ld();
           p.fz_out = m->dpre[1];
@@ -1601,6 +1643,7 @@ int build_plan(fdql_agent *a) {
       if (M % RG_BM == 0 && rows_launch_of(a, cand, rl)) {
         Stage &gs = b.gemm_stage("critics.dpre1+0");
         gs.try_rows = true;
+        gs.gm_role = 2;
         gs.gemm = cand;
         fused1 = true;
         if (rl.ws)   // the weight-stationary launch leaves one partial row of column sums per workgroup
@@ -1625,6 +1668,7 @@ int build_plan(fdql_agent *a) {
       }
       Stage &gs = b.gemm_stage("critics.dpre" + std::to_string(i));
       gs.try_rows = true;
+      gs.gm_role = 2;
       for (int k = 0; k < C; ++k) {
         gs.gemm.push_back(b.bwd_dpre(co[k], i, a->buf("dz") + k * Q, Nq));
         gs.gemm.push_back(b.bwd_dpre(cf[k], i, a->buf("dzf") + k * Q, Nq));

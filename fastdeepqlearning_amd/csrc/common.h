@@ -88,6 +88,13 @@ struct GemmProblem {
   int fz_ldw;
   int fz_discard;          // 1: nobody reads fz_out afterwards (frozen critics have no weight gradients): the weight-stationary kernel skips the store
   float *fz_out, *fz_colsum;
+  // Gate masks (weight-stationary kernels, wstat.hip, only; round 4): a forward layer leaves the SIGN of its activations -
+  // one bit per value, a dword per lane and 32-row tile in the kernel's own register layout - and the backward launches that gate
+  // with LeakyReLU'(h) read those 32 bytes per row instead of the 1 KiB row (EPI_LRELU_GRAD's ref; fz_h).  gm_out / gm_out2:
+  // written by a forward problem (second output of a dual one); gm_ref / gm_fz: stand in for ref / fz_h when the launch is told
+  // that the producing launches wrote them (WsArgs::use_masks, decided with the kernels).  [M / 32][4][64] dwords each; null: none.
+  unsigned *gm_out, *gm_out2;
+  const unsigned *gm_ref, *gm_fz;
   int tiles_m, tiles_n;    // filled by gemm_finalize
   int tile_start;          // first block id of this problem in its launch
   GemmSeg seg[GEMM_MAX_SEG];

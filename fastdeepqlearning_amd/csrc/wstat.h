@@ -13,7 +13,7 @@ constexpr int WS_N = 256;          // output columns (4 waves x 64)
 constexpr int WS_KMAIN = 256;      // K of the main segment
 constexpr int WS_MAX_MINOR = 2;    // narrow K-segments beside it (K <= 32 each: ceil(K / 8) MFMA steps of 8 k)
 constexpr int WS_MAX_SLOTS = 8;    // 8-k steps of all narrow segments together
-constexpr int WS_MAX_INST = 16;    // the table travels in the kernel arguments (scalar loads): 16 x 144 B + header < 4 KiB
+constexpr int WS_MAX_INST = 16;    // the table travels in the kernel arguments (scalar loads): 16 x 176 B + header < 4 KiB
 
 struct WsInst {
   const float *A[1 + WS_MAX_MINOR];   // activations of the segments, [0] = main; row-major, K contiguous
@@ -31,6 +31,8 @@ struct WsInst {
   // pitch 774; actor: d logits, 12 columns of a head of pitch 512) and in the row pitch of their layer-0 weights
   int k1, lda1, ldw0, ldw1;
   int fz_keep, pad;                   // fused form: 1 = store the formed A0 rows to fz_out (0: only the GEMM consumes them)
+  unsigned *gm_out, *gm_out2;         // forward: gate masks of the outputs (GemmProblem::gm_*), null: none
+  const unsigned *gm_ref, *gm_fz;     // dgrad forms with WsArgs::use_masks: the masks that stand in for ref / fz_h
 };
 
 struct WsArgs {
@@ -42,6 +44,7 @@ struct WsArgs {
   int lda[1 + WS_MAX_MINOR], ldw[1 + WS_MAX_MINOR];
   int dual;                  // 1: C = f(all segments but the last), C2 = f(all)
   int hf_q, hf_ldw;          // head fusion: outputs per row (2), 0 = off
+  int use_masks;             // dgrad forms: 1 = gate by WsInst::gm_ref / gm_fz (written by the forward launches) instead of ref / fz_h
   int hf_presum;             // head fusion: 1 = a tile's eight column planes are summed in the kernel, hf_out holds ONE plane [M][hf_q]
   int grad;                  // dgrad forms - weights K-strided (element (k, n) at W[k*ldw + n]): 1: x *= LeakyReLU'(ref), column sums;
                              // 2: plain (no gate, no sums: one network's share of an input gradient)

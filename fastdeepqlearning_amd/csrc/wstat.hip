@@ -136,6 +136,24 @@ __device__ __forceinline__ float ws_lrelu(float v) {   // max(v, 0.01 v); fmaxf 
   asm("v_max_f32 %0, %1, %2" : "=v"(o) : "v"(v), "v"(t));
   return o;
 }
+// gate masks: m = (m << 1) | (x > 0) - the first value packed ends up in bit 31 after 32 of them.  Integer form, no VCC
+// (a v_cmp / v_addc pair stalls on its carry every time: + 9 us per forward launch at config 2): x > 0  <=>  its bit pattern is
+// a positive integer  <=>  0 - bits is negative (+0 -> 0: not positive, as LeakyReLU'(0) = 0.01 wants; the one pattern that
+// goes wrong is -0, which max(v, 0.01 v) only returns for |v| below 1.4e-43).  Plain C++ on purpose (v_sub_u32 + v_alignbit_b32
+// from the compiler, the temporary in the value's own register when it can): as an asm statement with a temporary of its own
+// the pair got a register that an LDS read issued by an earlier asm statement - a prefetch nobody consumes on that path, so
+// dead for the allocator the moment it is issued - was still going to write (wrong forward outputs, found with tools/nan_probe.py).
+__device__ __forceinline__ void ws_mask_push(unsigned &m, float x) {
+  const unsigned t = 0u - __builtin_bit_cast(unsigned, x);
+  m = (m << 1) | (t >> 31);
+}
+// ... and back out: returns (bit 31 of m) ? v : 0.01 v, m <<= 1
+__device__ __forceinline__ float ws_mask_gate(unsigned &m, float v) {
+  const float t = 0.01f * v;
+  float y;
+  asm volatile("v_add_co_u32 %1, vcc, %1, %1\n\tv_cndmask_b32 %0, %2, %3, vcc" : "=v"(y), "+v"(m) : "v"(t), "v"(v) : "vcc");
+  return y;
+}
 __device__ __forceinline__ float ws_sum_halves(float x) {   // x[l] + x[l ^ 32] in every lane
   float a = x, b = x;
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
@@ -145,7 +163,8 @@ __device__ __forceinline__ float ws_sum_halves(float x) {   // x[l] + x[l ^ 32] 
 // NSL: narrow 8-k steps inside a tile's K loop (a narrow segment of K <= 32 columns takes ceil(K / 8) of them: the action
 // columns of critic layer 0 - 6 at config 2, 17 at config 4).  NST: steps of the LAST narrow segment of a two-output launch,
 // applied to the previous tile between its two outputs (0: one output).  HFQ: head-fusion outputs per row (0 = off).
-template <int NSL, int NST, int HFQ>
+// GM: the launch writes gate masks (GemmProblem::gm_out / gm_out2; instances without one only skip the store).
+template <int NSL, int NST, int HFQ, bool GM = false>
 __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
   static_assert(HFQ == 0 || HFQ == 2, "head-fusion riders: 2 outputs per row");
   constexpr bool DUAL = NST > 0;
@@ -168,12 +187,35 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
   if (j0 >= nblk) return;
   const WsInst &I = a.inst[inst];   // kernel-argument segment: scalar loads, each field read once
   const float *A0 = ws_uni(I.A[0]);
-  float *const C = ws_uni(I.C), *const C2 = ws_uni(I.C2);
+  // (GM: the output / narrow-input / head-sum pointers are not held in scalar registers over the tile loop but read from the
+  // kernel arguments where a tile needs them - ka_ptr below; the mask path's few extra scalars would not fit otherwise)
+  float *const C = GM ? nullptr : ws_uni(I.C), *const C2 = GM ? nullptr : ws_uni(I.C2);
   // DUAL launches may mix two-output instances with plain ones (critic layer 0: online + frozen pass / target pass): a plain
   // instance has no second output and no last narrow segment - those slots are staged from the first segment's memory and
   // never used
-  const bool has2 = DUAL && C2 != nullptr;
-  float *const hf_out = ws_uni(I.hf_out), *const hf_out2 = ws_uni(I.hf_out2);
+  const bool has2 = DUAL && ws_uni(I.C2) != nullptr;
+  // Pointers that are used once per tile are read from the kernel-argument segment where they are used, at an offset the
+  // optimiser cannot see through (so that the load is not hoisted out of the tile loop): the scalar registers are all taken.
+  auto ka_ptr = [&](int field_off) __attribute__((always_inline)) {
+    int off = (int)offsetof(WsArgs, inst) + field_off + inst * (int)sizeof(WsInst);
+    asm volatile("" : "+s"(off));
+    const char __attribute__((address_space(4))) *ka = (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+    void *p = *(void *const __attribute__((address_space(4))) *)(ka + off);
+    // the scalar load counts in lgkmcnt and returns out of order with LDS operations: it must not be outstanding when the tile
+    // loop's counted waits (ws_lgkm_wait) run - both statements are volatile, the load sits between them
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(p));
+    return p;
+  };
+  float *const hf_out_r = GM ? nullptr : ws_uni(I.hf_out), *const hf_out2_r = GM ? nullptr : ws_uni(I.hf_out2);
+  auto hf_ptr = [&](int second) __attribute__((always_inline)) {
+    if constexpr (GM) return (float *)ka_ptr((int)offsetof(WsInst, hf_out) + second * (int)sizeof(float *));
+    else return second ? hf_out2_r : hf_out_r;
+  };
+  auto c_ptr = [&](int second) __attribute__((always_inline)) {
+    if constexpr (GM) return (float *)ka_ptr((int)offsetof(WsInst, C) + second * (int)sizeof(float *));
+    else return second ? C2 : C;
+  };
+  constexpr bool masks = GM;
   // presum: the tile whose sums the last block left in hfx (-1: none yet); -2: the launch writes every plane (one scalar
   // register carries both: this kernel has none to spare)
   int pprv = (HFQ > 0 && a.hf_presum != 0) ? -1 : -2;
@@ -214,8 +256,23 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
   //   narrow-step weights: slot j covers k = k0_j + 4 lh + c of its segment (zero beyond its K)     [wave][slot][tn][lane][c]
   float *const cbias = lds + 2 * IMG, *const cwh = cbias + 4 * 2 * 32, *const cnw = cwh + 4 * 8 * 32;
   // slot j of the narrow steps: segment 0 (k = 8 j ..) inside the K loop, segment 1 (k = 8 (j - NSL) ..) in the tail
-  const float *Aseg[2] = {ws_uni(I.A[1]), ws_uni((DUAL && has2) ? I.A[2] : I.A[1])};
-  const int ldaseg[2] = {a.lda[1], a.lda[2]};
+  const float *Aseg_r[2] = {GM ? nullptr : ws_uni(I.A[1]), GM ? nullptr : ws_uni((DUAL && has2) ? I.A[2] : I.A[1])};
+  auto aseg = [&](int sg) __attribute__((always_inline)) {
+    if constexpr (GM) return (const float *)ka_ptr((int)offsetof(WsInst, A) + (int)sizeof(float *) * ((sg == 1 && DUAL && has2) ? 2 : 1));
+    else return Aseg_r[sg];
+  };
+  const int ldaseg_r[2] = {GM ? 0 : a.lda[1], GM ? 0 : a.lda[2]};
+  auto ldaseg = [&](int i) __attribute__((always_inline)) {
+    if constexpr (GM) {
+      int off = (int)offsetof(WsArgs, lda) + 4 * (1 + i);
+      asm volatile("" : "+s"(off));
+      int v = *(const int __attribute__((address_space(4))) *)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + off);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v));   // (as ka_ptr: not outstanding at a counted wait)
+      return v;
+    } else {
+      return ldaseg_r[i];
+    }
+  };
   bool m_ok[NS > 0 ? NS : 1];
   const int m_r = tid >> 3, m_c = tid & 7;   // narrow staging: thread -> (row tid / 8, column tid % 8) of every [32, 8] slot
   {
@@ -292,6 +349,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
     ws_rd128<(2 * j + 1) * 1024>(nw1[j & 1], nw_addr);
   };
   // finish + store one register quad of a finished set; the rider takes the finished values as its B operand
+  unsigned gmk = 0;   // gate mask of the output being finished: sign bits in the order the quads are finished
   auto quad = [&](f32x16 (&pv)[2], float *Cout, v4f (&hs)[2], int pblk, int kq) __attribute__((always_inline)) {
     const int tn = (kq >> 2) & 1, q = kq & 3;
     v4f x;
@@ -299,16 +357,29 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
     for (int c = 0; c < 4; ++c) x[c] = ws_lrelu(pv[tn][4 * q + c] + cb[kq & 1][c]);
     gf base = ws_uni((gf)Cout + (long long)pblk * WS_BM * LD + n0 + 32 * tn + 8 * q);
     *(gf4)(&base[vo_c]) = x;
+    if constexpr (masks) {   // sign(x) = sign of the pre-activation
+#pragma unroll
+      for (int c = 0; c < 4; ++c) ws_mask_push(gmk, x[c]);
+    }
     if constexpr (HFQ > 0) {
       if (q == 0) hs[tn] = v4f{0.f, 0.f, 0.f, 0.f};
       ws_rider(hs[tn], cw[kq & 1], x);
+    }
+  };
+  // a finished output's gate mask: one dword per lane, [tile][wave][lane]
+  // (the pointer is read from the kernel-argument segment where it is used, at an offset the optimiser cannot see through, so
+  // that the load is not hoisted out of the tile loop: this kernel has no scalar registers to keep two more pointers in)
+  auto mask_store = [&](int second, int pblk) __attribute__((always_inline)) {
+    if constexpr (masks) {
+      unsigned *const mout = (unsigned *)ka_ptr((int)offsetof(WsInst, gm_out) + second * (int)sizeof(unsigned *));
+      if (mout) ((__attribute__((address_space(1))) unsigned *)ws_uni(mout + ((long long)pblk * 4 + wave) * 64))[(unsigned)lane] = gmk;
     }
   };
   // the head partial sums of a finished tile: plane = wave * 2 + tn (its 32 columns), both lane halves summed.
   // WsArgs::hf_presum (round 4): the eight planes of a tile are summed HERE - each wave leaves its two column tiles' sum in LDS
   // (hfx[parity of the block][output][wave][32 rows x HFQ]), wave 0 adds the four waves in order one block later (behind that
   // block's barrier) and writes ONE plane: the plane-sum launch in front of the head's finish and 7/8 of its input go away.
-  auto hf_store = [&](v4f (&hs)[2], float *hout, int pblk, int par, int o) __attribute__((always_inline)) {
+  auto hf_store = [&](v4f (&hs)[2], int pblk, int par, int o) __attribute__((always_inline)) {
     if constexpr (HFQ > 0) {
       if (pprv != -2) {   // (uniform)
         ws_anchor(hs[0]); ws_anchor(hs[1]);
@@ -320,7 +391,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
       for (int tn = 0; tn < 2; ++tn) {
         ws_anchor(hs[tn]);
         const v2f y = {ws_sum_halves(hs[tn][0]), ws_sum_halves(hs[tn][1])};
-        gf base = ws_uni((gf)hout + ((long long)(wave * 2 + tn) * nblk + pblk) * (WS_BM * HFQ));
+        gf base = ws_uni((gf)hf_ptr(o) + ((long long)(wave * 2 + tn) * nblk + pblk) * (WS_BM * HFQ));
         *(gf2)(&base[(unsigned)(li * HFQ)]) = y;   // (both lane halves hold and write the same sums)
       }
     }
@@ -331,11 +402,11 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
       if (wave == 0 && pp >= 0) {   // (uniform; pp < 0: nothing pending, or not a presum launch)
         const float *src = hfx + (par * 2) * 4 * 32 * HFQ + lane;
         const float t = (src[0] + src[32 * HFQ]) + (src[2 * 32 * HFQ] + src[3 * 32 * HFQ]);
-        ((gf)ws_uni(hf_out + (long long)pp * WS_BM * HFQ))[(unsigned)lane] = t;
+        ((gf)ws_uni(hf_ptr(0) + (long long)pp * WS_BM * HFQ))[(unsigned)lane] = t;
         if (DUAL && has2) {
           const float *src2 = src + 4 * 32 * HFQ;
           const float t2 = (src2[0] + src2[32 * HFQ]) + (src2[2 * 32 * HFQ] + src2[3 * 32 * HFQ]);
-          ((gf)ws_uni(hf_out2 + (long long)pp * WS_BM * HFQ))[(unsigned)lane] = t2;
+          ((gf)ws_uni(hf_ptr(1) + (long long)pp * WS_BM * HFQ))[(unsigned)lane] = t2;
         }
       }
     }
@@ -364,6 +435,8 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
     const float *nsrc = ws_uni(A0 + (long long)nxt * WS_BM * lda0);
     v4f af[2];
     float em[8];   // presum: the four waves' sums of the tile before the previous one (first / second output), wave 0
+    float *Cb = nullptr, *C2b = nullptr;
+    if constexpr (HP) Cb = c_ptr(0);
     ws_rd128<IOFF>(af[0], abase);
     if constexpr (HP) read_consts(std::integral_constant<int, 0>{});
     sfor<0, NSTEP>([&](auto sc) __attribute__((always_inline)) {
@@ -390,7 +463,8 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
           if constexpr (kq + 1 < 8) read_consts(std::integral_constant<int, kq + 1>{});
         }
         if constexpr (s == 0) ws_anchor(pv[0], pv[1]);
-        if constexpr (s < 8) quad(pv, C, hacc, pblk, kq);
+        if constexpr (s < 8) quad(pv, Cb, hacc, pblk, kq);
+        if constexpr (s == 8) mask_store(0, pblk);
         // what the block before this one left in hfx[IM ^ 1]: wave 0 requests the four waves' sums at step 3 (uncounted asm
         // reads: in order behind them, step 4's counted wait covers their arrival) and adds / stores them at step 4
         if constexpr (HFQ > 0 && (s == 3 || s == 4)) {
@@ -404,22 +478,23 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
               }
             } else {
               asm volatile("" : "+v"(em[0]), "+v"(em[1]), "+v"(em[2]), "+v"(em[3]));
-              ((gf)ws_uni(hf_out + (long long)ppblk * WS_BM * HFQ))[(unsigned)lane] = (em[0] + em[1]) + (em[2] + em[3]);
+              ((gf)ws_uni(hf_ptr(0) + (long long)ppblk * WS_BM * HFQ))[(unsigned)lane] = (em[0] + em[1]) + (em[2] + em[3]);
               if (DUAL && has2) {
                 asm volatile("" : "+v"(em[4]), "+v"(em[5]), "+v"(em[6]), "+v"(em[7]));
-                ((gf)ws_uni(hf_out2 + (long long)ppblk * WS_BM * HFQ))[(unsigned)lane] = (em[4] + em[5]) + (em[6] + em[7]);
+                ((gf)ws_uni(hf_ptr(1) + (long long)ppblk * WS_BM * HFQ))[(unsigned)lane] = (em[4] + em[5]) + (em[6] + em[7]);
               }
             }
           }
         }
         if constexpr (!DUAL) {
-          if constexpr (s == 9) hf_store(hacc, hf_out, pblk, IM, 0);
+          if constexpr (s == 9) hf_store(hacc, pblk, IM, 0);
         } else {
-          if constexpr (s == 10) hf_store(hacc, hf_out, pblk, IM, 0);
+          if constexpr (s == 10) hf_store(hacc, pblk, IM, 0);
           if constexpr (s >= 7 && s <= 18) {
             if (has2) {   // (uniform: the instance's second output)
               if constexpr (s == 7) read_narrow(std::integral_constant<int, NSL>{}, std::integral_constant<int, IM ^ 1>{});
               if constexpr (s == 8) {
+                C2b = c_ptr(1);
                 tail_steps(pv, std::integral_constant<int, IM ^ 1>{});   // the previous tile becomes its second output
                 read_consts(std::integral_constant<int, 8>{});
               }
@@ -428,9 +503,10 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
                 if constexpr (HFQ > 0) asm volatile("" : "+v"(cw[kq & 1]));
                 if constexpr (kq + 1 < 16) read_consts(std::integral_constant<int, kq + 1>{});
                 if constexpr (s == 9) ws_anchor(pv[0], pv[1]);
-                quad(pv, C2, hacc2, pblk, kq);
+                quad(pv, C2b, hacc2, pblk, kq);
               }
-              if constexpr (s == 18) hf_store(hacc2, hf_out2, pblk, IM, 1);
+              if constexpr (s == 17) mask_store(1, pblk);
+              if constexpr (s == 18) hf_store(hacc2, pblk, IM, 1);
             }
           }
         }
@@ -438,8 +514,8 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
       if constexpr (s == 12) {
 #pragma unroll
         for (int u = 0; u < NS; ++u) {
-          const int sg = u < NSL ? 0 : 1, k0 = 8 * (u < NSL ? u : u - NSL), ld = ldaseg[(DUAL && !has2) ? 0 : sg];
-          stm[u] = ((gcf)(Aseg[sg] + (long long)nxt * WS_BM * ld))[m_r * ld + (m_ok[u] ? k0 + m_c : 0)];
+          const int sg = u < NSL ? 0 : 1, k0 = 8 * (u < NSL ? u : u - NSL), ld = ldaseg((DUAL && !has2) ? 0 : sg);
+          stm[u] = ((gcf)(aseg(sg) + (long long)nxt * WS_BM * ld))[m_r * ld + (m_ok[u] ? k0 + m_c : 0)];
         }
       }
       if constexpr (s >= 16 && s < 16 + WS_BM / 4) dma_row(nsrc, IM ^ 1, wave + 4 * (s - 16));
@@ -473,8 +549,8 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
     for (int u = 0; u < WS_BM / 4; ++u) dma_row(src, 0, wave + 4 * u);
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
-      const int sg = u < NSL ? 0 : 1, k0 = 8 * (u < NSL ? u : u - NSL), ld = ldaseg[(DUAL && !has2) ? 0 : sg];
-      const float x = ((gcf)(Aseg[sg] + (long long)blk * WS_BM * ld))[m_r * ld + (m_ok[u] ? k0 + m_c : 0)];
+      const int sg = u < NSL ? 0 : 1, k0 = 8 * (u < NSL ? u : u - NSL), ld = ldaseg((DUAL && !has2) ? 0 : sg);
+      const float x = ((gcf)(aseg(sg) + (long long)blk * WS_BM * ld))[m_r * ld + (m_ok[u] ? k0 + m_c : 0)];
       m_dst[8 * u] = m_ok[u] ? x : 0.f;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -507,8 +583,9 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
       read_consts(kc);
       ws_lgkm_wait<0>();
       asm volatile("" : "+v"(cb[decltype(kc)::value & 1]), "+v"(cw[decltype(kc)::value & 1]));
-      quad(pv, C, hacc, prv, decltype(kc)::value);
+      quad(pv, c_ptr(0), hacc, prv, decltype(kc)::value);
     });
+    mask_store(0, prv);
     if (DUAL && has2) {
       if constexpr (DUAL) {
         read_narrow(std::integral_constant<int, NSL>{}, imc);
@@ -521,16 +598,17 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
         read_consts(kc);
         ws_lgkm_wait<0>();
         asm volatile("" : "+v"(cb[decltype(kc)::value & 1]), "+v"(cw[decltype(kc)::value & 1]));
-        quad(pv, C2, hacc2, prv, decltype(kc)::value);
+        quad(pv, c_ptr(1), hacc2, prv, decltype(kc)::value);
       });
+      mask_store(1, prv);
     }
     asm volatile("s_nop 7" ::: "memory");   // rider results -> VALU readers
     constexpr int PL = decltype(imc)::value;   // the last block ran on image PL and left tile pprv's sums in hfx[PL]
     if constexpr (HFQ > 0) {
       if (pprv != -2) __syncthreads();   // wave 0 has taken what it had to take from hfx[PL ^ 1] (the last block's step 3)
     }
-    hf_store(hacc, hf_out, prv, PL ^ 1, 0);
-    if (DUAL && has2) hf_store(hacc2, hf_out2, prv, PL ^ 1, 1);
+    hf_store(hacc, prv, PL ^ 1, 0);
+    if (DUAL && has2) hf_store(hacc2, prv, PL ^ 1, 1);
     if constexpr (HFQ > 0) {
       if (pprv != -2) {
         __syncthreads();
@@ -574,8 +652,12 @@ __device__ __forceinline__ float ws_sum32(float x) {   // sum over the 32 lanes 
 // PLAIN: no gate and no column sums (C = A0 W0 + dY W1: one network's share of an input gradient that several networks add up
 // to, e.g. d state of the critics), K-strided weights of any row pitch.
 // NS: 8-k steps of the narrow segment dY (2 columns at config 2: one step; 25 at config 4: four).
-template <bool FUSE, bool PLAIN = false, int NS = 1>
+// MASK: the gates come from the forward launches' sign masks (GemmProblem::gm_*: a dword per lane and tile in this very register
+// layout, consumed from bit 31 down in the order the quads are finished; the fused loader takes its four columns' nibble of the
+// row's dword) instead of from the activations themselves: 32 bytes per row and gate instead of 1 KiB.
+template <bool FUSE, bool PLAIN = false, int NS = 1, bool MASK = false>
 __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
+  static_assert(!(MASK && PLAIN), "the plain form has no gate");
   static_assert(!(FUSE && PLAIN), "the fused head dgrad belongs to a gated layer");
   static_assert(!FUSE || NS == 1, "the fused head dgrad reads dY as two columns");
   extern __shared__ __attribute__((aligned(16))) float lds[];   // two images [32][P], column-sum accumulators, narrow weights
@@ -595,6 +677,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
   const float *A0 = ws_uni(FUSE ? I.fz_h : I.A[0]);
   const float *A1 = ws_uni(I.A[1]);
   const float *ref = PLAIN ? nullptr : ws_uni(I.ref);
+  const unsigned *const gm_ref = MASK ? ws_uni(I.gm_ref) : nullptr, *const gm_fz = (MASK && FUSE) ? ws_uni(I.gm_fz) : nullptr;
   float *const C = ws_uni(I.C), *const fz_out = ws_uni(I.fz_out);
   const bool keep_fz = I.fz_keep != 0;   // fused form: is the formed A0 (d pre-activation of the layer above) also stored?
   const int lda0 = FUSE ? LD : a.lda[0], lda1 = PLAIN ? ws_uni(I.lda1) : a.lda[1];
@@ -678,6 +761,11 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
   };
   v4f fcs = {0.f, 0.f, 0.f, 0.f};   // FUSE: running column sums of the formed A0 over the rows this thread stages
   v4f sh[4];                        // FUSE: row pieces in flight (fz_h)
+  unsigned shm[4] = {0, 0, 0, 0};   // FUSE + MASK: the rows' mask dwords in flight instead
+  unsigned gqn = 0;                 // MASK: gate mask of the tile being accumulated
+  // FUSE + MASK: this lane's dword of staged row 8 wave + 4 inside a tile's [4][64] mask block: its columns 4 lane .. 4 lane + 3
+  // belong to forward wave lane / 16, lane half lane % 2; the row is that wave's lane index
+  const unsigned fzm_lane = (unsigned)((lane >> 4) * 64 + 32 * (lane & 1) + 8 * wave + 4);
   v2f sdz = {0.f, 0.f};             // FUSE: dY of this wave's 8 rows of the tile in flight, row u in lane u
   float stm[NS];
   v4f nfr[2], nw0[2], nw1[2];       // operands of a narrow step (fragment, the slot's weights), requested a step ahead
@@ -708,9 +796,25 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
     }
     return t;
   };
+  // MASK: the row's dword of the layer's mask -> this lane's four gates (the nibble of its columns moved to the top bits)
+  const unsigned fz_lsh = 4u * ((unsigned)(lane & 15) >> 1);
+  auto fuse_row_m = [&](unsigned mrow, float dz0, float dz1, float live) __attribute__((always_inline)) {
+    v4f t;
+    unsigned m = mrow << fz_lsh;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float x = dz0 * fw0[c];
+      x = fmaf(dz1, fw1[c], x);
+      x = ws_mask_gate(m, x);
+      t[c] = x;
+      fcs[c] = fmaf(live, x, fcs[c]);
+    }
+    return t;
+  };
+  unsigned gq = 0;   // MASK: the gate mask of the tile being finished
   // (uniform bases once per tile, the quad's columns as instruction offsets: one scalar register pair per pointer)
   auto ref_load = [&](v4f &dst, gcf rbase, int kq) __attribute__((always_inline)) {
-    if constexpr (PLAIN) return;
+    if constexpr (PLAIN || MASK) return;
     if (WS_EXP & 4) return;
     const int tn = (kq >> 2) & 1, q = kq & 3;
     dst = *(gcf4)(&ws_uni(rbase + 32 * tn + 8 * q)[vo_c]);
@@ -723,6 +827,8 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
       const float v = pv[tn][4 * q + c];
       if constexpr (PLAIN || (WS_EXP & 4)) {
         x[c] = v;
+      } else if constexpr (MASK) {
+        x[c] = ws_mask_gate(gq, v);
       } else {
         const float y = rq[kq % 4][c] > 0.f ? v : 0.01f * v;
         x[c] = y;
@@ -735,11 +841,14 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
     }
   };
 
-  auto block = [&](auto has_prev, auto imgc, f32x16 (&ac)[2], f32x16 (&pv)[2], int nxt, int pblk, float live) __attribute__((always_inline)) {
+  auto block = [&](auto has_prev, auto imgc, f32x16 (&ac)[2], f32x16 (&pv)[2], int cur, int nxt, int pblk, float live) __attribute__((always_inline)) {
     constexpr bool HP = decltype(has_prev)::value;
     constexpr int IM = decltype(imgc)::value;
     constexpr int IOFF = IM * IMG * 4;
     asm volatile("s_barrier" ::: "memory");
+    if constexpr (MASK) gq = gqn;   // the previous tile's gates (requested while it was accumulated)
+    typedef const __attribute__((address_space(1))) unsigned *gcu;
+    gcu nmask_w = (MASK && FUSE) ? (gcu)ws_uni(gm_fz + (long long)nxt * (4 * 64)) : nullptr;
     const float *nsrc = ws_uni(A0 + (long long)nxt * WS_BM * lda0);
     const float *ndz = ws_uni(A1 + (long long)nxt * m_tile);
     // FUSE: this wave stages rows 8 wave .. 8 wave + 7 of the next tile: ONE base per pointer (row 8 wave + 4), the rows
@@ -793,13 +902,17 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
           const int row = 8 * wave + u;
           // (copies first: __builtin_bit_cast of a vector ELEMENT lvalue reads the vector's first element)
           const float d0 = sdz.x, d1 = sdz.y;
-          const v4f t = fuse_row(sh[u & 3], __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d0), u)),
-                                 __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d1), u)), live);
+          const float dzu0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d0), u));
+          const float dzu1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d1), u));
+          v4f t;
+          if constexpr (MASK) t = fuse_row_m(shm[u & 3], dzu0, dzu1, live);
+          else t = fuse_row(sh[u & 3], dzu0, dzu1, live);
           if (keep_fz && !(WS_EXP & 8)) (nout_w + (u - 4) * (LD / 4))[(unsigned)lane] = t;   // (workgroup-uniform: frozen instances have no weight gradients)
           *reinterpret_cast<v4f *>(lds + (IM ^ 1) * IMG + row * P + lane * 4) = t;
         }
         if constexpr (ureq >= 0) {   // (after the use of the register it refills)
-          sh[ureq & 3] = (nsrc_w + (ureq - 4) * (LD / 4))[(unsigned)lane];
+          if constexpr (MASK) shm[ureq & 3] = nmask_w[fzm_lane + (ureq - 4)];
+          else sh[ureq & 3] = (nsrc_w + (ureq - 4) * (LD / 4))[(unsigned)lane];
           if constexpr (ureq == 0) sdz = *(const __attribute__((address_space(1))) v2f *)(ndz + (8 * wave + (lane & 7)) * lda1);
         }
       } else {
@@ -808,6 +921,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
       if constexpr (s == 8) {
 #pragma unroll
         for (int j = 0; j < NS; ++j) stm[j] = ((gcf)ndz)[m_src[j]];
+        if constexpr (MASK) gqn = ((gcu)ws_uni(gm_ref + ((long long)cur * 4 + wave) * 64))[(unsigned)lane];   // this tile's gates, used a block later
       }
       if constexpr (s == 26) {
 #pragma unroll
@@ -846,9 +960,15 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int row = 8 * wave + u;
-        const v4f h = ((gcf4)(src + row * LD))[(unsigned)lane];
         const v2f dz = *(const __attribute__((address_space(1))) v2f *)(dzs + row * lda1);
-        const v4f t = fuse_row(h, dz.x, dz.y, 1.f);
+        v4f t;
+        if constexpr (MASK) {
+          const unsigned mrow = ((const __attribute__((address_space(1))) unsigned *)ws_uni(gm_fz + (long long)blk * (4 * 64)))[fzm_lane + (u - 4)];
+          t = fuse_row_m(mrow, dz.x, dz.y, 1.f);
+        } else {
+          const v4f h = ((gcf4)(src + row * LD))[(unsigned)lane];
+          t = fuse_row(h, dz.x, dz.y, 1.f);
+        }
         if (keep_fz) ((gf4)(out + row * LD))[(unsigned)lane] = t;
         *reinterpret_cast<v4f *>(lds + row * P + lane * 4) = t;
       }
@@ -864,17 +984,17 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   }
   int nxt = blk + stride < nblk ? blk + stride : blk;
-  block(F(), I0(), acc[0], acc[1], nxt, 0, nxt != blk ? 1.f : 0.f);
+  block(F(), I0(), acc[0], acc[1], blk, nxt, 0, nxt != blk ? 1.f : 0.f);
   int prv = blk, set = 1;
   blk += stride;
 #pragma unroll 1
   while (blk < nblk) {
     nxt = blk + stride < nblk ? blk + stride : blk;
-    block(T(), I1(), acc[1], acc[0], nxt, prv, nxt != blk ? 1.f : 0.f);
+    block(T(), I1(), acc[1], acc[0], blk, nxt, prv, nxt != blk ? 1.f : 0.f);
     prv = blk; blk += stride; set = 0;
     if (blk >= nblk) break;
     nxt = blk + stride < nblk ? blk + stride : blk;
-    block(T(), I0(), acc[0], acc[1], nxt, prv, nxt != blk ? 1.f : 0.f);
+    block(T(), I0(), acc[0], acc[1], blk, nxt, prv, nxt != blk ? 1.f : 0.f);
     prv = blk; blk += stride; set = 1;
   }
   auto flush = [&](f32x16 (&pv)[2]) __attribute__((always_inline)) {
@@ -882,6 +1002,7 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
     ws_anchor(pv[0], pv[1]);
     gf cprev = (gf)ws_uni(C + (long long)prv * WS_BM * LD + n0);
     gcf rprev = PLAIN ? nullptr : (gcf)ws_uni(ref + (long long)prv * WS_BM * LD + n0);
+    if constexpr (MASK) gq = gqn;
     sfor<0, 8>([&](auto kc) __attribute__((always_inline)) {
       constexpr int kq = decltype(kc)::value;
       ref_load(rq[kq % 4], rprev, kq);
@@ -1008,6 +1129,7 @@ bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
     I.hf_w = p.hf_w; I.hf_out = p.hf_out; I.hf_out2 = p.hf_out2;
     I.ref = p.ref; I.colsum = p.colsum;
     I.fz_h = p.fz_h; I.fz_w = p.fz_w; I.fz_out = p.fz_out; I.fz_colsum = p.fz_colsum; I.fz_keep = p.fz_discard ? 0 : 1;
+    I.gm_out = p.gm_out; I.gm_out2 = p.gm_out2; I.gm_ref = p.gm_ref; I.gm_fz = p.gm_fz;
     args.inst[i] = I;
     cost[i] = pd ? dual_cost : 11;   // a two-output instance finishes twice as many register quads per tile
     cost_sum += cost[i];
@@ -1120,21 +1242,27 @@ static hipError_t ws_launch_kernel(K kern, int lds_bytes, bool (&attr)[64], cons
   hipLaunchKernelGGL(kern, dim3(a.wg_first[a.ninst]), dim3(256), lds_bytes, s, a);
   return hipGetLastError();
 }
-template <int NSL, int NST, int HFQ>
-static hipError_t ws_launch(const WsArgs &a, hipStream_t s) {
+template <int NSL, int NST, int HFQ, bool GM>
+static hipError_t ws_launch_gm(const WsArgs &a, hipStream_t s) {
   static bool attr[64];
   // two images + per-wave constants (bias, rider weights, 8 KiB of narrow weights per slot)
   constexpr int lds_need = (2 * WS_BM * (WS_KMAIN + 8 * (NSL + NST) + 4) + 4 * 2 * 32 + 4 * 8 * 32 + (NSL + NST) * 2048 + 2 * 2 * 4 * 32 * HFQ) * 4;
   constexpr int lds_stage = 4 * 32 * (WS_KMAIN + 4) * 4;   // the weight load's transposition area (4 waves x 32 rows)
   constexpr int lds_bytes = lds_need > lds_stage ? lds_need : lds_stage;
-  return ws_launch_kernel(&k_wstat<NSL, NST, HFQ>, lds_bytes, attr, a, s);
+  return ws_launch_kernel(&k_wstat<NSL, NST, HFQ, GM>, lds_bytes, attr, a, s);
 }
-template <bool FUSE, bool PLAIN, int NS>
+template <int NSL, int NST, int HFQ>
+static hipError_t ws_launch(const WsArgs &a, hipStream_t s) {
+  bool gm = false;
+  for (int i = 0; i < a.ninst; ++i) gm = gm || a.inst[i].gm_out || a.inst[i].gm_out2;
+  return gm ? ws_launch_gm<NSL, NST, HFQ, true>(a, s) : ws_launch_gm<NSL, NST, HFQ, false>(a, s);
+}
+template <bool FUSE, bool PLAIN, int NS, bool MASK = false>
 static hipError_t ws_launch_grad(const WsArgs &a, hipStream_t s) {
   static bool attr[64];
   // images + column-sum accumulators + narrow weights
   constexpr int lds_bytes = 2 * WS_BM * (WS_KMAIN + 8 * NS + 4) * 4 + (PLAIN ? 0 : 32 * 256 * 4) + NS * 2048 * 4;
-  return ws_launch_kernel(&k_wstat_grad<FUSE, PLAIN, NS>, lds_bytes, attr, a, s);
+  return ws_launch_kernel(&k_wstat_grad<FUSE, PLAIN, NS, MASK>, lds_bytes, attr, a, s);
 }
 
 hipError_t wstat_launch(const WsArgs &a, hipStream_t s) {
@@ -1143,6 +1271,10 @@ hipError_t wstat_launch(const WsArgs &a, hipStream_t s) {
     return L == 5 ? ws_launch_grad<false, true, 5>(a, s)
                   : (L == 4 ? ws_launch_grad<false, true, 4>(a, s) : (L == 2 ? ws_launch_grad<false, true, 2>(a, s) : ws_launch_grad<false, true, 1>(a, s)));
   if (a.grad) {
+    if (a.use_masks) {   // (set by the plan when the forward launches wrote the masks: every instance carries gm_ref, and gm_fz if fused)
+      if (a.fz) return ws_launch_grad<true, false, 1, true>(a, s);
+      return L == 4 ? ws_launch_grad<false, false, 4, true>(a, s) : ws_launch_grad<false, false, 1, true>(a, s);
+    }
     if (a.fz) return ws_launch_grad<true, false, 1>(a, s);
     return L == 4 ? ws_launch_grad<false, false, 4>(a, s) : ws_launch_grad<false, false, 1>(a, s);
   }

@@ -2,7 +2,8 @@
 # timing experiments on k_wstat_grad (libraries built with -DWS_EXP=n: results are wrong, only the stage times are read)
 mkdir -p gpurun_out/exp2
 python3 tools/profile_stages.py > gpurun_out/exp2/base.txt 2>&1
-for e in 1 2 4 8 16 32 63; do
+for e in 64 68; do
   FDQL_LIB_PATH=$PWD/fastdeepqlearning_amd/exp/libfdql_e$e.so timeout -k 10 120 python3 tools/profile_stages.py > gpurun_out/exp2/e$e.txt 2>&1
 done
-grep -H "dpre1\|dstate \|update-only" gpurun_out/exp2/*.txt
+python3 tools/profile_stages.py > gpurun_out/exp2/base2.txt 2>&1
+grep -H "dpre1\|update-only" gpurun_out/exp2/base.txt gpurun_out/exp2/e64.txt gpurun_out/exp2/e68.txt gpurun_out/exp2/base2.txt
