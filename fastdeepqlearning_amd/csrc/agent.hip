@@ -148,6 +148,13 @@ struct Stage {
   // gate masks (GemmProblem::gm_*): 1 = a critics' forward layer whose weight-stationary launch writes them, 2 = a critics'
   // backward launch that may gate by them - when EVERY stage of role 1 runs weight-stationary (else nobody writes or reads them)
   int gm_role = 0;
+  // the one problem of this stage runs on the row-block dgrad kernel with its first segment formed as a sum of shares
+  // (RowDgradArgs::sum_*; build_plan has checked that the kernel takes it)
+  bool fold_sum = false;
+  const float *fold_parts = nullptr;
+  int fold_n = 0;
+  long long fold_stride = 0;
+  float *fold_out = nullptr, *fold_cs = nullptr;
   std::shared_ptr<HeadFinishArgs> hfin;
   HeadFinishArgs hfin_plain, hfin_presum;
   bool hfin_can_presum = false;
@@ -1023,10 +1030,18 @@ int upload_tables(fdql_agent *a) {
         RowsLaunch rl;
         if (taken[i] != 1 && s.gemm[i].M / RD_BM >= a->rowdgrad_min_blocks && s.gemm[i].M / RD_BM <= a->rowdgrad_max_blocks &&
             rowdgrad_from_problem(s.gemm[i], rl.rda)) {
+          if (s.fold_sum && !rowdgrad_fold_sum(rl.rda, s.fold_parts, s.fold_n, s.fold_stride, s.fold_out, s.fold_cs)) {
+            set_error("stage %s: the row-block dgrad kernel does not take the folded sum it was planned with", s.name.c_str());
+            return FDQL_EINVAL;
+          }
           rl.rd = true;
           s.rows.push_back(rl);
           taken[i] = 1;
         }
+      }
+      if (s.fold_sum && (s.rows.size() != 1 || !s.rows[0].rd)) {
+        set_error("stage %s was planned with a folded sum but does not run on the row-block dgrad kernel", s.name.c_str());
+        return FDQL_EINVAL;
       }
       // Small batches (temporal_len 2, a handful of env rows): a stage whose problems are too few tiles to fill the chip is as
       // long as one workgroup's serial K loop on the tile kernels; the small-batch kernel (smallgemm.hip) splits K over the 16
@@ -1780,7 +1795,21 @@ int build_plan(fdql_agent *a) {
     hosts.push_back(a->stages.size() - 1);
   }
   const size_t idx_dstate = a->stages.size() - 1;
-  if (a->dstate_split) {
+  // The sum of the shares inside the launch that consumes it first - the joiner's top hidden layer's dgrad on the row-block dgrad
+  // kernel (rowdgrad.h, RowDgradArgs::sum_*): each 64-row workgroup adds its rows of the C + 1 shares while it stages them, writes
+  // d state and its column sums; the summing launch (and one write + read of d state) goes away.  Asked here with the same
+  // deterministic questions upload_tables asks, because the answer changes the column sums' row count.
+  bool fold_dsum = false;
+  if (a->dstate_split && L % 4 == 0 && !gru && !a->joiner.hid.empty()) {
+    MlpInst jq = jo;
+    jq.rows = M;
+    GemmProblem p = b.bwd_dpre(jq, (int)a->joiner.hid.size() - 1, a->buf("dstate"), L);
+    RowDgradArgs tmp;
+    fold_dsum = M / RD_BM >= a->rowdgrad_min_blocks && M / RD_BM <= a->rowdgrad_max_blocks && (M >= a->rowdot_min_rows ? p.N > 16 : true) &&
+                rowdgrad_from_problem(p, tmp) &&
+                rowdgrad_fold_sum(tmp, a->buf("dstate.parts"), C + 1, (long long)M * L, a->buf("dstate"), a->buf("cs.dstate"));
+  }
+  if (a->dstate_split && !fold_dsum) {
     const float *parts = a->buf("dstate.parts");
     float *dsum = a->buf("dstate");
     const long long ML = (long long)M * L;
@@ -1792,15 +1821,20 @@ int build_plan(fdql_agent *a) {
       b.func_stage("dstate.sum", [=](hipStream_t s) { return reduce_partials_launch(parts, np, ML, dsum, s); });
     }
   }
-  // column sums of d state: per 64 rows from the one-problem GEMM, per 32 rows from the sum of shares, else straight from d state
+  // column sums of d state: per 64 rows from the one-problem GEMM or the folded sum, per 32 rows from the summing launch, else
+  // straight from d state
   const float *cs_dstate = (a->dstate_split && L % 4) ? nullptr : a->buf("cs.dstate");
-  const int cs_dstate_rows = a->dstate_split ? (M + 31) / 32 : 0;
+  const int cs_dstate_rows = a->dstate_split ? (fold_dsum ? (M + 63) / 64 : (M + 31) / 32) : 0;
   // ---- encoder backward over the M rows that carry gradient (next-only rows get none)
   MlpInst jb = jo, eb = eo;
   jb.rows = M; eb.rows = M;
   for (int i = (int)a->joiner.hid.size() - 1; i >= 0; --i) {
-    Stage &gs = b.gemm_stage("joiner.dpre" + std::to_string(i));
+    Stage &gs = b.gemm_stage((fold_dsum && i == (int)a->joiner.hid.size() - 1 ? "dstate.sum+joiner.dpre" : "joiner.dpre") + std::to_string(i));
     gs.gemm.push_back(b.bwd_dpre(jb, i, a->buf("dstate"), L));
+    if (fold_dsum && i == (int)a->joiner.hid.size() - 1) {
+      gs.fold_sum = true; gs.fold_parts = a->buf("dstate.parts"); gs.fold_n = C + 1; gs.fold_stride = (long long)M * L;
+      gs.fold_out = a->buf("dstate"); gs.fold_cs = a->buf("cs.dstate");
+    }
     hosts.push_back(a->stages.size() - 1);
   }
   if (gru) {

@@ -20,6 +20,14 @@ struct RowDgradArgs {
   const float *ref;                  // [M, 256] (gate)
   float *C;                          // [M, 256]
   float *colsum;                     // [M / 64, 256] or null
+  // Segment 0 as the SUM of nsum arrays of the same shape (the per-network shares of an input gradient, agent.hip "dstate"): the
+  // workgroup adds its 64 rows of every share in index order while it stages them, writes the sum to sum_out (= A[0]: the weight
+  // gradients read it) and the rows' column sums to sum_colsum [M / 64, 256] - the launch that summed the shares (and wrote and
+  // re-read the sum) goes away.  nsum == 0: A[0] is read as it is.
+  const float *sum_parts;
+  int nsum;
+  long long sum_stride;              // floats between consecutive shares
+  float *sum_out, *sum_colsum;
 };
 
 // Narrow-output dgrads of several networks in one launch (k_rowdot): out_p[M, A <= 16] = X_p[M, 256] W_p + D_p[M, Q <= 32] V_p with
@@ -41,6 +49,7 @@ inline double rowdot_flops(const RowDotArgs &a) { return 2.0 * a.M * (double)a.A
 
 // Does this problem have the kernel's form?  Fills args when it does.  FDQL_ROWDGRAD=0: never.
 bool rowdgrad_from_problem(const GemmProblem &p, RowDgradArgs &args);
+bool rowdgrad_fold_sum(RowDgradArgs &args, const float *parts, int nsum, long long stride, float *sum_out, float *sum_colsum);   // FDQL_NO_DSTATE_SUM_FOLD: never
 hipError_t rowdgrad_launch(const RowDgradArgs &args, hipStream_t stream);
 inline double rowdgrad_flops(const RowDgradArgs &a) { return 2.0 * a.M * (double)RD_N * RD_K * a.nseg; }
 

@@ -40,22 +40,52 @@ constexpr int IMG = RD_BM * P;
 
 __device__ __forceinline__ int rd_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-template <int NSEG, bool GATE>
+// SUM: segment 0's rows are the sum of a.nsum shares (RowDgradArgs::sum_*): staged through registers instead of by LDS-DMA
+template <int NSEG, bool GATE, bool SUM = false>
 __global__ __launch_bounds__(256, 1) void k_rowdgrad(const RowDgradArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];   // A images [NSEG][64][P]
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // A images [NSEG][64][P] (SUM: + [4][256] column sums of the sum)
   const int tid = threadIdx.x, lane = tid & 63, wave = rd_uni(tid >> 6);
   const int j = lane & 15, kq = lane >> 4;
   const int blk = blockIdx.x, r0 = blk * RD_BM, n0 = wave * 64;
 
   // ---- A tiles -> LDS (wave w: rows w, w + 4, ...: one 1 KiB row per instruction)
 #pragma unroll
-  for (int s = 0; s < NSEG; ++s) {
+  for (int s = SUM ? 1 : 0; s < NSEG; ++s) {
     const float *src = a.A[s] + (long long)r0 * RD_K;
 #pragma unroll
     for (int u = 0; u < RD_BM / 4; ++u) {
       const int row = wave + 4 * u;
       __builtin_amdgcn_global_load_lds((glb_vp)(src + row * RD_K + lane * 4), (lds_vp)(lds + s * IMG + row * P), 16, 0, 0);
     }
+  }
+  if constexpr (SUM) {   // the shares of a row added in index order (as k_sum_parts_colsum did)
+    const int nsum = rd_uni(a.nsum);
+    const long long ps = a.sum_stride;
+    gcf part = (gcf)a.sum_parts + (long long)r0 * RD_K + lane * 4;
+    v4f csum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int u0 = 0; u0 < RD_BM / 4; u0 += 8) {   // eight rows x nsum shares per request round
+      v4f v[8][8];
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        if (p < nsum) {   // (uniform)
+#pragma unroll
+          for (int uu = 0; uu < 8; ++uu) v[uu][p] = *(gcf4)(part + (long long)p * ps + (wave + 4 * (u0 + uu)) * RD_K);
+        }
+      }
+#pragma unroll
+      for (int uu = 0; uu < 8; ++uu) {
+        const int row = wave + 4 * (u0 + uu);
+        v4f t = v[uu][0];
+#pragma unroll
+        for (int p = 1; p < 8; ++p)
+          if (p < nsum) t += v[uu][p];   // (uniform)
+        *reinterpret_cast<v4f *>(lds + row * P + lane * 4) = t;
+        *(gf4)(a.sum_out + (long long)(r0 + row) * RD_K + lane * 4) = t;
+        csum += t;
+      }
+    }
+    *reinterpret_cast<v4f *>(lds + NSEG * IMG + wave * RD_K + lane * 4) = csum;
   }
 
   v4f acc[RD_RT][4];   // [16-row tile][c]: register r = row 16 rt + 4 kq + r, column n0 + 4 j + c
@@ -76,6 +106,10 @@ __global__ __launch_bounds__(256, 1) void k_rowdgrad(const RowDgradArgs a) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA pieces have landed (and the first weight fragments with them)
   __syncthreads();
+  if constexpr (SUM) {   // the block's column sums of the summed rows: the four waves' partial rows, in order
+    const float *cw = lds + NSEG * IMG;
+    a.sum_colsum[(long long)blk * RD_K + tid] = ((cw[tid] + cw[RD_K + tid]) + cw[2 * RD_K + tid]) + cw[3 * RD_K + tid];
+  }
 
   v4f rq[GATE ? 4 * RD_RT : 1];   // the gate's reference quads: requested under the last group's MFMAs
 #pragma unroll
@@ -279,6 +313,16 @@ bool rowdgrad_from_problem(const GemmProblem &p, RowDgradArgs &args) {
   return true;
 }
 
+// The launch that sums `nsum` shares [M, 256] (stride floats apart) into segment 0's array can be folded into this launch when
+// segment 0 is that array: at most 8 shares, 16-byte aligned.
+bool rowdgrad_fold_sum(RowDgradArgs &args, const float *parts, int nsum, long long stride, float *sum_out, float *sum_colsum) {
+  if (getenv("FDQL_NO_DSTATE_SUM_FOLD")) return false;
+  auto aligned = [](const void *q, uintptr_t n) { return (reinterpret_cast<uintptr_t>(q) & (n - 1)) == 0; };
+  if (nsum < 2 || nsum > 8 || args.A[0] != sum_out || !aligned(parts, 16) || (stride & 3) || !aligned(sum_out, 16) || !sum_colsum || args.nseg != 1) return false;
+  args.sum_parts = parts; args.nsum = nsum; args.sum_stride = stride; args.sum_out = sum_out; args.sum_colsum = sum_colsum;
+  return true;
+}
+
 hipError_t rowdgrad_launch(const RowDgradArgs &a, hipStream_t s) {
   static bool attr[64];
   static std::mutex mu;
@@ -289,16 +333,22 @@ hipError_t rowdgrad_launch(const RowDgradArgs &a, hipStream_t s) {
   {
     std::lock_guard<std::mutex> lk(mu);
     if (!attr[dev]) {   // the opt-in to > 64 KiB of dynamic LDS belongs to the (device, function) pair
-      const void *fns[4] = {reinterpret_cast<const void *>(&k_rowdgrad<1, false>), reinterpret_cast<const void *>(&k_rowdgrad<1, true>),
-                            reinterpret_cast<const void *>(&k_rowdgrad<2, false>), reinterpret_cast<const void *>(&k_rowdgrad<2, true>)};
-      for (int i = 0; i < 4 && e == hipSuccess; ++i)
-        e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (i < 2 ? 1 : 2) * IMG * 4);
+      const void *fns[6] = {reinterpret_cast<const void *>(&k_rowdgrad<1, false>), reinterpret_cast<const void *>(&k_rowdgrad<1, true>),
+                            reinterpret_cast<const void *>(&k_rowdgrad<2, false>), reinterpret_cast<const void *>(&k_rowdgrad<2, true>),
+                            reinterpret_cast<const void *>(&k_rowdgrad<1, false, true>), reinterpret_cast<const void *>(&k_rowdgrad<1, true, true>)};
+      for (int i = 0; i < 6 && e == hipSuccess; ++i)
+        e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, ((i & 3) < 2 ? 1 : 2) * IMG * 4 + (i >= 4 ? 4 * RD_K * 4 : 0));
       if (e != hipSuccess) return e;
       attr[dev] = true;
     }
   }
   const dim3 grid(a.M / RD_BM), block(256);
-  const size_t lds_bytes = (size_t)a.nseg * IMG * 4;
+  const size_t lds_bytes = (size_t)a.nseg * IMG * 4 + (a.nsum > 0 ? 4 * RD_K * 4 : 0);
+  if (a.nsum > 0 && a.nseg == 1) {
+    if (a.gate) hipLaunchKernelGGL((k_rowdgrad<1, true, true>), grid, block, lds_bytes, s, a);
+    else hipLaunchKernelGGL((k_rowdgrad<1, false, true>), grid, block, lds_bytes, s, a);
+    return hipGetLastError();
+  }
   if (a.nseg == 1 && !a.gate) hipLaunchKernelGGL((k_rowdgrad<1, false>), grid, block, lds_bytes, s, a);
   else if (a.nseg == 1) hipLaunchKernelGGL((k_rowdgrad<1, true>), grid, block, lds_bytes, s, a);
   else if (!a.gate) hipLaunchKernelGGL((k_rowdgrad<2, false>), grid, block, lds_bytes, s, a);

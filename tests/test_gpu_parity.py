@@ -581,6 +581,11 @@ def test_update_matches_oracle_config2(dev, T, B, hid):
     ("12 action columns, 8 quantiles per critic (column sums of d logits over 24 columns on the streaming launch's 40-column "
      "lanes-over-rows form, d z's 8 columns on the 8-column one, 256-wide partial rows in row groups), 99 rows",
      dict(obs=11, act=12, C=3, Q=8, T=4, B=33)),
+    ("config 2 dims at T=5, B=64 with the weight-stationary and the row-block dgrad kernels forced (FDQL_ROWGEMM=all, "
+     "FDQL_ROWDGRAD_MIN_BLOCKS=1): the sum of the d state shares inside the joiner's dgrad launch (RowDgradArgs::sum_*), column sums "
+     "per 64 rows", dict(obs=17, act=6, C=5, Q=2, T=5, B=64, env={"FDQL_ROWGEMM": "all", "FDQL_ROWDGRAD_MIN_BLOCKS": "1"})),
+    ("the same with the summing launch kept (FDQL_NO_DSTATE_SUM_FOLD)",
+     dict(obs=17, act=6, C=5, Q=2, T=5, B=64, env={"FDQL_ROWGEMM": "all", "FDQL_ROWDGRAD_MIN_BLOCKS": "1", "FDQL_NO_DSTATE_SUM_FOLD": "1"})),
     ("config 2 dims, weight-stationary launches forced, gates from the activations themselves (FDQL_NO_GATE_MASKS: the path the "
      "forward launches' sign masks replace)", dict(obs=17, act=6, C=5, Q=2, T=5, B=64, env={"FDQL_ROWGEMM": "all", "FDQL_NO_GATE_MASKS": "1"})),
     ("config 2 dims on the weight-stationary kernel writing every head plane (FDQL_NO_HEAD_PRESUM: plane-sum launch + finish, the "
