@@ -189,7 +189,9 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
   const float *A0 = ws_uni(I.A[0]);
   // (GM: the output / narrow-input / head-sum pointers are not held in scalar registers over the tile loop but read from the
   // kernel arguments where a tile needs them - ka_ptr below; the mask path's few extra scalars would not fit otherwise)
-  float *const C = GM ? nullptr : ws_uni(I.C), *const C2 = GM ? nullptr : ws_uni(I.C2);
+  // (only the two-output instantiations are short of scalar registers: the others keep every pointer in registers, masks or not)
+  constexpr bool KA = GM && DUAL;
+  float *const C = KA ? nullptr : ws_uni(I.C), *const C2 = KA ? nullptr : ws_uni(I.C2);
   // DUAL launches may mix two-output instances with plain ones (critic layer 0: online + frozen pass / target pass): a plain
   // instance has no second output and no last narrow segment - those slots are staged from the first segment's memory and
   // never used
@@ -206,13 +208,14 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(p));
     return p;
   };
-  float *const hf_out_r = GM ? nullptr : ws_uni(I.hf_out), *const hf_out2_r = GM ? nullptr : ws_uni(I.hf_out2);
+  float *const hf_out_r = KA ? nullptr : ws_uni(I.hf_out), *const hf_out2_r = KA ? nullptr : ws_uni(I.hf_out2);
+  unsigned *const gm_out_r = (GM && !KA) ? ws_uni(I.gm_out) : nullptr, *const gm_out2_r = (GM && !KA) ? ws_uni(I.gm_out2) : nullptr;
   auto hf_ptr = [&](int second) __attribute__((always_inline)) {
-    if constexpr (GM) return (float *)ka_ptr((int)offsetof(WsInst, hf_out) + second * (int)sizeof(float *));
+    if constexpr (KA) return (float *)ka_ptr((int)offsetof(WsInst, hf_out) + second * (int)sizeof(float *));
     else return second ? hf_out2_r : hf_out_r;
   };
   auto c_ptr = [&](int second) __attribute__((always_inline)) {
-    if constexpr (GM) return (float *)ka_ptr((int)offsetof(WsInst, C) + second * (int)sizeof(float *));
+    if constexpr (KA) return (float *)ka_ptr((int)offsetof(WsInst, C) + second * (int)sizeof(float *));
     else return second ? C2 : C;
   };
   constexpr bool masks = GM;
@@ -256,14 +259,14 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
   //   narrow-step weights: slot j covers k = k0_j + 4 lh + c of its segment (zero beyond its K)     [wave][slot][tn][lane][c]
   float *const cbias = lds + 2 * IMG, *const cwh = cbias + 4 * 2 * 32, *const cnw = cwh + 4 * 8 * 32;
   // slot j of the narrow steps: segment 0 (k = 8 j ..) inside the K loop, segment 1 (k = 8 (j - NSL) ..) in the tail
-  const float *Aseg_r[2] = {GM ? nullptr : ws_uni(I.A[1]), GM ? nullptr : ws_uni((DUAL && has2) ? I.A[2] : I.A[1])};
+  const float *Aseg_r[2] = {KA ? nullptr : ws_uni(I.A[1]), KA ? nullptr : ws_uni((DUAL && has2) ? I.A[2] : I.A[1])};
   auto aseg = [&](int sg) __attribute__((always_inline)) {
-    if constexpr (GM) return (const float *)ka_ptr((int)offsetof(WsInst, A) + (int)sizeof(float *) * ((sg == 1 && DUAL && has2) ? 2 : 1));
+    if constexpr (KA) return (const float *)ka_ptr((int)offsetof(WsInst, A) + (int)sizeof(float *) * ((sg == 1 && DUAL && has2) ? 2 : 1));
     else return Aseg_r[sg];
   };
-  const int ldaseg_r[2] = {GM ? 0 : a.lda[1], GM ? 0 : a.lda[2]};
+  const int ldaseg_r[2] = {KA ? 0 : a.lda[1], KA ? 0 : a.lda[2]};
   auto ldaseg = [&](int i) __attribute__((always_inline)) {
-    if constexpr (GM) {
+    if constexpr (KA) {
       int off = (int)offsetof(WsArgs, lda) + 4 * (1 + i);
       asm volatile("" : "+s"(off));
       int v = *(const int __attribute__((address_space(4))) *)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + off);
@@ -371,7 +374,9 @@ __global__ __launch_bounds__(256, 1) void k_wstat(const WsArgs a) {
   // that the load is not hoisted out of the tile loop: this kernel has no scalar registers to keep two more pointers in)
   auto mask_store = [&](int second, int pblk) __attribute__((always_inline)) {
     if constexpr (masks) {
-      unsigned *const mout = (unsigned *)ka_ptr((int)offsetof(WsInst, gm_out) + second * (int)sizeof(unsigned *));
+      unsigned *mout;
+      if constexpr (KA) mout = (unsigned *)ka_ptr((int)offsetof(WsInst, gm_out) + second * (int)sizeof(unsigned *));
+      else mout = second ? gm_out2_r : gm_out_r;
       if (mout) ((__attribute__((address_space(1))) unsigned *)ws_uni(mout + ((long long)pblk * 4 + wave) * 64))[(unsigned)lane] = gmk;
     }
   };
