@@ -245,7 +245,7 @@ def kernel_label(name):
     if name.startswith("chain"):
         return "k_chain (row-block MLP chain, fp32 v_mfma_f32_32x32x2_f32)"
     if name.startswith("wstat"):
-        return rocprof_tag(name) + " (weight-stationary persistent row-block GEMM, " + ("dgrad" if name.startswith("wstatg") else "forward") + \
+        return rocprof_tag(name) + "> (weight-stationary persistent row-block GEMM, " + ("dgrad" if name.startswith("wstatg") else "forward") + \
                " form, fp32 v_mfma_f32_32x32x2_f32)"
     if name.startswith("wgstat"):
         return "k_wgrad_stat (output-stationary weight-gradient blocks, fp32 v_mfma_f32_32x32x2_f32)"
@@ -270,10 +270,10 @@ def rocprof_tag(name):
         return "k_rowdgrad"
     if name.startswith("wstatg<"):       # "wstatg<fuse,plain,ns>:stage" -> k_wstat_grad<true, false, 1>
         f, pl, ns = name[7:name.index(">")].split(",")
-        return f"k_wstat_grad<{'true' if f == '1' else 'false'}, {'true' if pl == '1' else 'false'}, {ns}>"
+        return f"k_wstat_grad<{'true' if f == '1' else 'false'}, {'true' if pl == '1' else 'false'}, {ns}"   # (+ ", MASK>": prefix match)
     if name.startswith("wstat<"):        # "wstat<nsl,nst,hfq>:stage" -> k_wstat<0, 0, 2>
         n, t, q = name[6:name.index(">")].split(",")
-        return f"k_wstat<{n}, {t}, {q}>"
+        return f"k_wstat<{n}, {t}, {q}"   # (+ ", GM>" since round 4: the profile entries are matched by this prefix)
     if name.startswith("rows"):
         return "k_rowgemm"
     shape_id = {"128x128": 0, "128x32": 1, "32x128": 2, "64x128": 3, "64x64dual": 4, "64x64": 5, "64x64hf": 6}

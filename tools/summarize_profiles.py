@@ -57,7 +57,7 @@ except (OSError, KeyError, IndexError, ValueError):
 dom_tag = f"k_gemm_grouped<{shape_id[dom_shape]}," if dom_shape in shape_id else ("k_rowgemm" if dom_shape == "rows" else "k_chain")
 try:
     if "k_wstat" in kn:
-        dom_tag = kn.split(" (")[0]          # bench.py names the instantiation: "k_wstat<0, false, 2> (weight-stationary ..."
+        dom_tag = kn.split(" (")[0].rstrip(">")   # bench.py names the instantiation: "k_wstat<0, 0, 2> (weight-stationary ..."; rocprofv3's name has one more template argument
     elif "k_wgrad_stat" in kn:
         dom_tag = "k_wgrad_stat"
 except NameError:
