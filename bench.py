@@ -251,6 +251,8 @@ def kernel_label(name):
         return "k_wgrad_stat (output-stationary weight-gradient blocks, fp32 v_mfma_f32_32x32x2_f32)"
     if name.startswith("rowdot"):
         return "k_rowdot (narrow-output dgrads, fp32 v_mfma_f32_16x16x4_f32)"
+    if name.startswith("rowdchain"):
+        return "k_rowdgrad_chain (three row-block dgrads of the same rows, activations resident in LDS, fp32 v_mfma_f32_16x16x4_f32)"
     if name.startswith("rowd"):
         return "k_rowdgrad (row-block dgrad, K-strided weights, fp32 v_mfma_f32_16x16x4_f32)"
     if name.startswith("rows"):
@@ -266,6 +268,8 @@ def rocprof_tag(name):
         return "k_wgrad_stat"
     if name.startswith("rowdot<"):
         return "k_rowdot"
+    if name.startswith("rowdchain"):
+        return "k_rowdgrad_chain"
     if name.startswith("rowd<"):
         return "k_rowdgrad"
     if name.startswith("wstatg<"):       # "wstatg<fuse,plain,ns>:stage" -> k_wstat_grad<true, false, 1>

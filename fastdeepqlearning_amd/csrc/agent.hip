@@ -102,12 +102,15 @@ struct RowsLaunch {
   bool ws = false;
   bool rd = false;      // single-network dgrad on 64-row blocks (rowdgrad.h)
   bool dot = false;     // narrow-output dgrads of several networks (rowdgrad.h, k_rowdot)
+  bool chain3 = false;  // this launch and the two row-block dgrad launches behind it as one (rowdgrad.h, k_rowdgrad_chain)
+  RowChainArgs rch;
   RowGemmArgs rg;
   WsArgs wa;
   RowDgradArgs rda;
   RowDotArgs rdot;
   hipError_t launch(hipStream_t s) const {
     if (dot) return rowdot_launch(rdot, s);
+    if (chain3) return rowchain_launch(rch, s);
     return rd ? rowdgrad_launch(rda, s) : (ws ? wstat_launch(wa, s) : rowgemm_launch(rg, s));
   }
 };
@@ -150,6 +153,7 @@ struct Stage {
   int gm_role = 0;
   // the one problem of this stage runs on the row-block dgrad kernel with its first segment formed as a sum of shares
   // (RowDgradArgs::sum_*; build_plan has checked that the kernel takes it)
+  bool chained = false;   // switched off because the launch runs inside the chain launch of an earlier stage (RowsLaunch::chain3)
   bool fold_sum = false;
   const float *fold_parts = nullptr;
   int fold_n = 0;
@@ -1128,6 +1132,27 @@ int upload_tables(fdql_agent *a) {
     }
   }
   if (total) FDQL_HIP(hipMemcpy(a->tables_dev, host.data(), total, hipMemcpyHostToDevice));
+  // three dependent single-network dgrads in a row on the row-block dgrad kernel, the first with the folded sum of the d state
+  // shares (a config-2-shaped plan: joiner.dpre0, d enc, enc_obs.dpre0): one launch with the 64-row activations resident in LDS
+  for (Stage &s : a->stages)   // (decided anew with every table upload)
+    if (s.chained) { s.off = false; s.chained = false; }
+  for (size_t i = 0; i + 2 < a->stages.size(); ++i) {
+    Stage &s1 = a->stages[i], &s2 = a->stages[i + 1], &s3 = a->stages[i + 2];
+    auto lone_rd = [](const Stage &s) {
+      if (s.kind != ST_GEMM || s.gemm.size() != 1 || s.rows.size() != 1 || !s.rows[0].rd) return false;
+      for (const GemmSub &sub : s.sub) if (!sub.probs.empty()) return false;
+      return true;
+    };
+    if (!s1.fold_sum || !lone_rd(s1) || !lone_rd(s2) || !lone_rd(s3) || s1.phase != s2.phase || s1.phase != s3.phase) continue;
+    RowChainArgs c;
+    if (!rowchain_from_launches(s1.rows[0].rda, s2.rows[0].rda, s3.rows[0].rda, c)) continue;
+    s1.rows[0].chain3 = true;
+    s1.rows[0].rch = c;
+    s2.off = s3.off = true;
+    s2.chained = s3.chained = true;
+    s1.flops += s2.flops + s3.flops;   // (the launch does their work: fdql_agent_stats counts executed flops)
+    s1.bytes += s2.bytes + s3.bytes;
+  }
   // head-fusion planes: with every hidden layer of the critics on weight-stationary launches, those launches sum a tile's column
   // planes themselves, the plane-sum stage is switched off and the finish adds one plane per layer (Stage::hf_role)
   {
@@ -2433,6 +2458,10 @@ int32_t fdql_agent_profile_update(fdql_agent_t *a, const fdql_batch_t *batch, co
         flops = rowdot_flops(rl.rdot);
         bytes = 4.0 * rl.rdot.M * rl.rdot.nprob * (double)(RD_K + rl.rdot.Q + rl.rdot.A);
         snprintf(out[cnt].name, sizeof(out[cnt].name), "rowdot<%d>:%s", rl.rdot.A, st.name.c_str());
+      } else if (rl.rd && rl.chain3) {
+        flops = rowchain_flops(rl.rch);
+        bytes = 4.0 * rl.rch.M * (double)RD_N * (rl.rch.nsum + 4 + 2);
+        snprintf(out[cnt].name, sizeof(out[cnt].name), "rowdchain:%s+denc+enc_obs.dpre0", st.name.c_str());
       } else if (rl.rd) {
         flops = rowdgrad_flops(rl.rda);
         bytes = 4.0 * rl.rda.M * (double)RD_N * (rl.rda.nseg + 1 + (rl.rda.gate ? 1 : 0));

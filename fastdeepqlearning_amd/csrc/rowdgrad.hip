@@ -180,6 +180,139 @@ __global__ __launch_bounds__(256, 1) void k_rowdgrad(const RowDgradArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// k_rowdgrad_chain (rowdgrad.h, RowChainArgs): k_rowdgrad's K loop three times over the same 64 rows, the layers' inputs in two LDS
+// images: image 0 = x0 (the summed shares), image 1 = x1; x2 then replaces x0 in image 0.  The first weight fragments of the
+// next layer are requested before a layer's epilogue.
+__global__ __launch_bounds__(256, 1) void k_rowdgrad_chain(const RowChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // images [2][64][P], then [4][256] column sums of x0
+  const int tid = threadIdx.x, lane = tid & 63, wave = rd_uni(tid >> 6);
+  const int j = lane & 15, kq = lane >> 4;
+  const int blk = blockIdx.x, r0 = blk * RD_BM, n0 = wave * 64;
+  float *const img0 = lds, *const img1 = lds + IMG, *const csw = lds + 2 * IMG;
+
+  v4f acc[RD_RT][4];
+  v4f wv[2][8];
+  auto load_w = [&](gcf w, int ldw, int kb, v4f (&d)[8]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d[i] = *(gcf4)(w + (long long)(kb + 8 * kq + i) * ldw);
+  };
+  load_w((gcf)a.W1 + n0 + 4 * j, a.ldw1, 0, wv[0]);   // layer 1's first fragments: under the staging of the shares
+  {   // ---- x0 = sum of the shares (as k_rowdgrad<.., SUM>)
+    const int nsum = rd_uni(a.nsum);
+    const long long ps = a.sum_stride;
+    gcf part = (gcf)a.sum_parts + (long long)r0 * RD_K + lane * 4;
+    v4f csum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int u0 = 0; u0 < RD_BM / 4; u0 += 8) {
+      v4f v[8][8];
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        if (p < nsum) {   // (uniform)
+#pragma unroll
+          for (int uu = 0; uu < 8; ++uu) v[uu][p] = *(gcf4)(part + (long long)p * ps + (wave + 4 * (u0 + uu)) * RD_K);
+        }
+      }
+#pragma unroll
+      for (int uu = 0; uu < 8; ++uu) {
+        const int row = wave + 4 * (u0 + uu);
+        v4f t = v[uu][0];
+#pragma unroll
+        for (int p = 1; p < 8; ++p)
+          if (p < nsum) t += v[uu][p];
+        *reinterpret_cast<v4f *>(img0 + row * P + lane * 4) = t;
+        *(gf4)(a.x0 + (long long)(r0 + row) * RD_K + lane * 4) = t;
+        csum += t;
+      }
+    }
+    *reinterpret_cast<v4f *>(csw + wave * RD_K + lane * 4) = csum;
+  }
+  __syncthreads();
+  a.cs0[(long long)blk * RD_K + tid] = ((csw[tid] + csw[RD_K + tid]) + csw[2 * RD_K + tid]) + csw[3 * RD_K + tid];
+
+  // one 256-k segment: acc += image x W (K-strided weights streamed as in k_rowdgrad); the segment's first fragments are in
+  // wv[cur0]; `next`: the first fragments of what follows (next segment / next layer) are requested under the last group
+  auto segment = [&](const float *image, gcf w, int ldw, int cur0, gcf wnext, int ldwnext, bool has_next) __attribute__((always_inline)) {
+    const float *img = image + j * P + 8 * kq;
+#pragma unroll
+    for (int g = 0; g < RD_K / 32; ++g) {
+      const int cur = (cur0 + g) & 1;
+      if (g + 1 < RD_K / 32) load_w(w, ldw, 32 * (g + 1), wv[cur ^ 1]);
+      else if (has_next) load_w(wnext, ldwnext, 0, wv[cur ^ 1]);
+      asm volatile("" ::: "memory");
+      v4f xa[RD_RT], xb[RD_RT];
+#pragma unroll
+      for (int rt = 0; rt < RD_RT; ++rt) {
+        xa[rt] = *reinterpret_cast<const v4f *>(img + 16 * rt * P + 32 * g);
+        xb[rt] = *reinterpret_cast<const v4f *>(img + 16 * rt * P + 32 * g + 4);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int rt = 0; rt < RD_RT; ++rt) {
+          const float av = i < 4 ? xa[rt][i] : xb[rt][i - 4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wv[cur][i][c], acc[rt][c], 0, 0, 0);
+        }
+    }
+  };
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int rt = 0; rt < RD_RT; ++rt)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[rt][c] = v4f{0.f, 0.f, 0.f, 0.f};
+  };
+  // gate (ref != null), store, column sums, and the tile into an LDS image for the next layer (dst != null)
+  auto epilogue = [&](const float *ref, float *C, float *colsum, float *dst) __attribute__((always_inline)) {
+    v4f cs = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rt = 0; rt < RD_RT; ++rt) {
+      v4f h[4];
+      if (ref) {   // (uniform) the tile's four reference quads together
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = *(gcf4)((gcf)ref + (long long)(r0 + 16 * rt + 4 * kq + r) * RD_N + n0 + 4 * j);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v4f x = {acc[rt][0][r], acc[rt][1][r], acc[rt][2][r], acc[rt][3][r]};
+        if (ref) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) x[c] = h[r][c] > 0.f ? x[c] : 0.01f * x[c];
+        }
+        const int row = 16 * rt + 4 * kq + r;
+        *(gf4)(C + (long long)(r0 + row) * RD_N + n0 + 4 * j) = x;
+        if (dst) *reinterpret_cast<v4f *>(dst + row * P + n0 + 4 * j) = x;
+        cs += x;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v = cs[c];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      cs[c] = v;
+    }
+    if (kq == 0) *(gf4)(colsum + (long long)blk * RD_N + n0 + 4 * j) = cs;
+  };
+
+  // ---- layer 1: x1 = gate1(x0 W1) -> image 1                                   (wv[0] holds W1's first fragments)
+  zero_acc();
+  segment(img0, (gcf)a.W1 + n0 + 4 * j, a.ldw1, 0, (gcf)a.W2a + n0 + 4 * j, a.ldw2a, true);
+  epilogue(a.ref1, a.x1, a.cs1, img1);
+  __syncthreads();
+  // ---- layer 2: x2 = x0 W2a + x1 W2b -> image 0 (once every wave is done reading x0)   (8 groups per segment: wv[0] again)
+  zero_acc();
+  segment(img0, (gcf)a.W2a + n0 + 4 * j, a.ldw2a, 0, (gcf)a.W2b + n0 + 4 * j, a.ldw2b, true);
+  segment(img1, (gcf)a.W2b + n0 + 4 * j, a.ldw2b, 0, (gcf)a.W3 + n0 + 4 * j, a.ldw3, true);
+  __syncthreads();
+  epilogue(nullptr, a.x2, a.cs2, img0);
+  __syncthreads();
+  // ---- layer 3: x3 = gate3(x2 W3)
+  zero_acc();
+  segment(img0, (gcf)a.W3 + n0 + 4 * j, a.ldw3, 0, nullptr, 0, false);
+  epilogue(a.ref3, a.x3, a.cs3, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // k_rowdot (rowdgrad.h): wave = 16-row tiles of one problem, walked with a stride; v_mfma_f32_16x16x4_f32 with the rows as the
 // A operand (lane (row, kq): 16 bytes X[row][16 g + 4 kq ..]: sixteen requests = the tile's 16 KB in flight, two tiles deep)
 // and the network's few weight columns as the B operand, held in registers for the wave's life (lane (a, kq):
@@ -321,6 +454,41 @@ bool rowdgrad_fold_sum(RowDgradArgs &args, const float *parts, int nsum, long lo
   if (nsum < 2 || nsum > 8 || args.A[0] != sum_out || !aligned(parts, 16) || (stride & 3) || !aligned(sum_out, 16) || !sum_colsum || args.nseg != 1) return false;
   args.sum_parts = parts; args.nsum = nsum; args.sum_stride = stride; args.sum_out = sum_out; args.sum_colsum = sum_colsum;
   return true;
+}
+
+bool rowchain_from_launches(const RowDgradArgs &l1, const RowDgradArgs &l2, const RowDgradArgs &l3, RowChainArgs &c) {
+  if (getenv("FDQL_NO_ROWDGRAD_CHAIN")) return false;
+  if (l1.nsum < 2 || l1.nseg != 1 || !l1.gate || !l1.colsum || !l1.sum_colsum) return false;
+  if (l2.nsum || l2.nseg != 2 || l2.gate || !l2.colsum || l2.A[0] != l1.sum_out || l2.A[1] != l1.C) return false;
+  if (l3.nsum || l3.nseg != 1 || !l3.gate || !l3.colsum || l3.A[0] != l2.C) return false;
+  if (l1.M != l2.M || l1.M != l3.M) return false;
+  memset(&c, 0, sizeof(c));
+  c.M = l1.M;
+  c.sum_parts = l1.sum_parts; c.nsum = l1.nsum; c.sum_stride = l1.sum_stride; c.x0 = l1.sum_out; c.cs0 = l1.sum_colsum;
+  c.W1 = l1.W[0]; c.ldw1 = l1.ldw[0]; c.ref1 = l1.ref; c.x1 = l1.C; c.cs1 = l1.colsum;
+  c.W2a = l2.W[0]; c.ldw2a = l2.ldw[0]; c.W2b = l2.W[1]; c.ldw2b = l2.ldw[1]; c.x2 = l2.C; c.cs2 = l2.colsum;
+  c.W3 = l3.W[0]; c.ldw3 = l3.ldw[0]; c.ref3 = l3.ref; c.x3 = l3.C; c.cs3 = l3.colsum;
+  return true;
+}
+
+hipError_t rowchain_launch(const RowChainArgs &a, hipStream_t s) {
+  static bool attr[64];
+  static std::mutex mu;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  const size_t lds_bytes = (size_t)(2 * IMG + 4 * RD_K) * 4;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (!attr[dev]) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowdgrad_chain), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      if (e != hipSuccess) return e;
+      attr[dev] = true;
+    }
+  }
+  hipLaunchKernelGGL(k_rowdgrad_chain, dim3(a.M / RD_BM), dim3(256), lds_bytes, s, a);
+  return hipGetLastError();
 }
 
 hipError_t rowdgrad_launch(const RowDgradArgs &a, hipStream_t s) {

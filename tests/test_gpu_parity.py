@@ -584,6 +584,9 @@ def test_update_matches_oracle_config2(dev, T, B, hid):
     ("config 2 dims at T=5, B=64 with the weight-stationary and the row-block dgrad kernels forced (FDQL_ROWGEMM=all, "
      "FDQL_ROWDGRAD_MIN_BLOCKS=1): the sum of the d state shares inside the joiner's dgrad launch (RowDgradArgs::sum_*), column sums "
      "per 64 rows", dict(obs=17, act=6, C=5, Q=2, T=5, B=64, env={"FDQL_ROWGEMM": "all", "FDQL_ROWDGRAD_MIN_BLOCKS": "1"})),
+    ("the same with the three dgrad launches behind d state kept apart (FDQL_NO_ROWDGRAD_CHAIN: the sum folded into the first one "
+     "only; the default runs them as one k_rowdgrad_chain launch)",
+     dict(obs=17, act=6, C=5, Q=2, T=5, B=64, env={"FDQL_ROWGEMM": "all", "FDQL_ROWDGRAD_MIN_BLOCKS": "1", "FDQL_NO_ROWDGRAD_CHAIN": "1"})),
     ("the same with the summing launch kept (FDQL_NO_DSTATE_SUM_FOLD)",
      dict(obs=17, act=6, C=5, Q=2, T=5, B=64, env={"FDQL_ROWGEMM": "all", "FDQL_ROWDGRAD_MIN_BLOCKS": "1", "FDQL_NO_DSTATE_SUM_FOLD": "1"})),
     ("config 2 dims, weight-stationary launches forced, gates from the activations themselves (FDQL_NO_GATE_MASKS: the path the "
