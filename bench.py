@@ -692,7 +692,10 @@ def launch_ranks(n):
     reader.join(timeout=10)
     rc = rc or next((p.returncode for p in procs if p.returncode), 0)
     if chunks and chunks[0]:
-        sys.stdout.write(chunks[0])
+        # stdout carries the ONE JSON line; anything else a rank's libraries wrote there (gloo announces its peers on stdout) goes
+        # to stderr
+        for line in chunks[0].splitlines(keepends=True):
+            (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
         sys.stdout.flush()
     return rc
 
