@@ -153,6 +153,7 @@ struct Stage {
   int gm_role = 0;
   // the one problem of this stage runs on the row-block dgrad kernel with its first segment formed as a sum of shares
   // (RowDgradArgs::sum_*; build_plan has checked that the kernel takes it)
+  bool needs_masks = false;   // reads gate masks: the plan must have every critics' forward layer weight-stationary (checked in upload_tables)
   bool chained = false;   // switched off because the launch runs inside the chain launch of an earlier stage (RowsLaunch::chain3)
   bool fold_sum = false;
   const float *fold_parts = nullptr;
@@ -1191,6 +1192,11 @@ int upload_tables(fdql_agent *a) {
       all = all && ok && n == s.gemm.size();
     }
     const bool masks = nfwd > 0 && all;
+    for (const Stage &s : a->stages)
+      if (s.needs_masks && !masks) {
+        set_error("stage %s was planned on gate masks the forward launches of this plan do not write", s.name.c_str());
+        return FDQL_EINVAL;
+      }
     for (Stage &s : a->stages) {
       for (RowsLaunch &rl : s.rows) {
         if (!rl.ws) continue;
@@ -1695,7 +1701,38 @@ int build_plan(fdql_agent *a) {
     // workgroup) instead of the streaming kernel's row loop: 0.022 -> 0.011 ms at 256 rows
     const bool head_dgrad_as_gemm = a->small_max_tiles > 0 && gemm_dense_shape() == GEMM_64x64 && gemm_variant() == GEMM_DEFAULT_VARIANT &&
                                     (long long)2 * C * ((M + 63) / 64) * ((a->critic[0].hid.empty() ? 0 : a->critic[0].hid.back()) + 63) / 64 <= 4LL * a->small_max_tiles;
+    // Will the forward launches leave gate masks?  (the question upload_tables answers for good: every forward layer of the
+    // critics as one weight-stationary launch; a stage that relies on the answer is checked there - Stage::needs_masks)
+    bool masks_planned = getenv("FDQL_NO_GATE_MASKS") == nullptr;
+    for (const Stage &fs : a->stages) {
+      if (fs.gm_role != 1 || !masks_planned) continue;
+      RowsLaunch rl;
+      masks_planned = fs.gemm.size() > 1 && rows_launch_of(a, fs.gemm, rl) && rl.ws;
+    }
     for (int i = (int)nh - 1; i >= 0 && !fused1; --i) {
+      // the last hidden layer under a head of up to 32 outputs, gated by the masks (config 4: 25 quantiles; the rank-25 product was
+      // a tile launch at 25 TF that read h again): FDQL_NO_HEAD_DGRAD_MASKED keeps the GEMM stage
+      if (i == (int)nh - 1 && masks_planned && Q > HEAD_DGRAD_MAXQ && Q <= HDM_MAXQ && a->critic[0].hid[i] == 256 && M % 32 == 0 && 2 * C <= HDM_MAX_INST &&
+          !co[0].gm.empty() && getenv("FDQL_NO_HEAD_DGRAD_MASKED") == nullptr) {
+        HeadDgradMaskedArgs ha;
+        memset(&ha, 0, sizeof(ha));
+        ha.M = M; ha.Q = Q; ha.ninst = 2 * C; ha.lddy = Nq; ha.ldw = a->critic[0].head_ld();
+        for (int k = 0; k < C; ++k) {
+          int w = 0;
+          for (MlpInst *m : {&co[k], &cf[k]}) {
+            const int n = 2 * k + w;
+            ha.dY[n] = a->buf(w == 0 ? "dz" : "dzf") + k * Q;
+            ha.Wh[n] = m->HW() + b.head_col_of_hidden(*m->d, i);
+            ha.gm[n] = m->gm[i];
+            ha.dpre[n] = m->dpre[i];
+            ha.colsum[n] = m->dpre_cs[i];
+            ++w;
+          }
+        }
+        Stage &fs = b.func_stage("critics.dpre" + std::to_string(i) + "(masked)", [=](hipStream_t s) { return head_dgrad_masked_launch(ha, s); });
+        fs.needs_masks = true;
+        continue;
+      }
       if (Builder::narrow_head_last(a->critic[0], i) && !head_dgrad_as_gemm) {
         Stage st;
         st.kind = ST_HEAD_DGRAD; st.name = "critics.dpre" + std::to_string(i);

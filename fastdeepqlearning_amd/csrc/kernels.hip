@@ -853,6 +853,124 @@ __global__ __launch_bounds__(1024) void k_policy_bwd_dpre(const float *__restric
   }
 }
 
+// k_head_dgrad_masked (update_kernels.h, HeadDgradMaskedArgs): a 512-thread workgroup = 4 x 64 rows of one instance; the head's
+// Q x 256 weights through LDS into registers (a lane owns four columns), the 64 rows' dY in LDS (read as broadcasts), a wave
+// forms eight rows.  The gates of a row's four columns are a nibble of the row's mask dword in the forward wave that owned
+// the columns (the layout k_wstat_grad's fused loader reads, wstat.hip).
+constexpr int HDM_CHUNKS = 4;   // 64-row chunks per workgroup: the head's weights are staged once per 256 rows
+__global__ __launch_bounds__(512) void k_head_dgrad_masked(const HeadDgradMaskedArgs a) {
+  typedef float hv4 __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) float wl[HDM_MAXQ][256];
+  __shared__ __attribute__((aligned(16))) float dl[2][64][HDM_MAXQ];
+  __shared__ __attribute__((aligned(16))) float cs[8][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int inst = blockIdx.y, M = a.M, Q = a.Q;
+  const float *Wh = a.Wh[inst], *dY = a.dY[inst];
+  const unsigned *gm = a.gm[inst];
+  float *dpre = a.dpre[inst];
+  const unsigned mlane = (unsigned)((lane >> 4) * 64 + 32 * (lane & 1)), lsh = 4u * ((unsigned)(lane & 15) >> 1);
+  // (every staging round: all requests, then all LDS writes - a load -> store loop is one memory round trip per iteration)
+  auto stage_dy = [&](int buf, int r0) __attribute__((always_inline)) {
+    float v[64 * HDM_MAXQ / 512];
+#pragma unroll
+    for (int t = 0; t < 64 * HDM_MAXQ / 512; ++t) {
+      const int e = tid + 512 * t, r = e / HDM_MAXQ, q = e - r * HDM_MAXQ;
+      v[t] = dY[(long long)min(r0 + r, M - 1) * a.lddy + min(q, Q - 1)];
+    }
+#pragma unroll
+    for (int t = 0; t < 64 * HDM_MAXQ / 512; ++t) {
+      const int e = tid + 512 * t, r = e / HDM_MAXQ, q = e - r * HDM_MAXQ;
+      dl[buf][r][q] = (q < Q && r0 + r < M) ? v[t] : 0.f;
+    }
+  };
+  {
+    float v[HDM_MAXQ * 256 / 512];
+#pragma unroll
+    for (int t = 0; t < HDM_MAXQ * 256 / 512; ++t) {
+      const int e = tid + 512 * t, q = e >> 8, n = e & 255;
+      v[t] = Wh[(long long)min(q, Q - 1) * a.ldw + n];
+    }
+#pragma unroll
+    for (int t = 0; t < HDM_MAXQ * 256 / 512; ++t) {
+      const int e = tid + 512 * t, q = e >> 8, n = e & 255;
+      wl[q][n] = q < Q ? v[t] : 0.f;
+    }
+  }
+  const int rb = blockIdx.x * 64 * HDM_CHUNKS;
+  stage_dy(0, rb);
+  __syncthreads();
+#pragma unroll 1
+  for (int ch = 0; ch < HDM_CHUNKS; ++ch) {
+    const int r0 = rb + 64 * ch, buf = ch & 1;
+    if (r0 >= M) break;   // (uniform)
+    // the masks of this wave's eight rows (the only dependent-address loads) and the next chunk's dY: requested first
+    unsigned mk[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int m = min(r0 + 8 * wave + u, M - 1);
+      mk[u] = gm[(long long)(m >> 5) * 256 + mlane + (m & 31)];
+    }
+    if (ch + 1 < HDM_CHUNKS) stage_dy(buf ^ 1, r0 + 64);
+    // x[u] as two packed pairs: v_pk_fma_f32 forms two columns per instruction (the plain fp32 VALU rate bounds this kernel)
+    typedef float hv2 __attribute__((ext_vector_type(2)));
+    hv2 xa[8], xb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { xa[u] = hv2{0.f, 0.f}; xb[u] = hv2{0.f, 0.f}; }
+#pragma unroll
+    for (int q0 = 0; q0 < HDM_MAXQ; q0 += 4) {   // four head rows' weights in registers at a time; whole groups of 4 (q >= Q: 0 * 0 added)
+      if (q0 < Q) {   // (uniform)
+        hv4 wk[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wk[k] = *reinterpret_cast<const hv4 *>(&wl[q0 + k][lane * 4]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const hv4 d0 = *reinterpret_cast<const hv4 *>(&dl[buf][8 * wave + u][q0]);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const hv2 dv = {d0[k], d0[k]};
+            xa[u] = __builtin_elementwise_fma(dv, hv2{wk[k][0], wk[k][1]}, xa[u]);
+            xb[u] = __builtin_elementwise_fma(dv, hv2{wk[k][2], wk[k][3]}, xb[u]);
+          }
+        }
+      }
+    }
+    hv4 x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = hv4{xa[u][0], xa[u][1], xb[u][0], xb[u][1]};
+    hv4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int m = r0 + 8 * wave + u;
+      unsigned mm = mk[u] << lsh;
+      hv4 y;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        y[c] = (mm & 0x80000000u) ? x[u][c] : 0.01f * x[u][c];
+        mm <<= 1;
+      }
+      if (m < M) {
+        *reinterpret_cast<hv4 *>(dpre + (long long)m * 256 + lane * 4) = y;
+        sum += y;
+      }
+    }
+    *reinterpret_cast<hv4 *>(&cs[wave][lane * 4]) = sum;
+    __syncthreads();   // (also: the next chunk's dY has landed, everybody is done with this chunk's)
+    if (tid < 256) {
+      float t = 0.f;
+#pragma unroll
+      for (int v = 0; v < 8; ++v) t += cs[v][tid];
+      a.colsum[inst][(long long)(r0 >> 6) * 256 + tid] = t;
+    }
+    __syncthreads();   // (cs is rewritten by the next chunk)
+  }
+}
+hipError_t head_dgrad_masked_launch(const HeadDgradMaskedArgs &a, hipStream_t s) {
+  if (a.M <= 0 || a.ninst <= 0) return hipSuccess;
+  if (a.ninst > HDM_MAX_INST || a.Q < 1 || a.Q > HDM_MAXQ || (a.M & 31)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_head_dgrad_masked, dim3((unsigned)((a.M + 64 * HDM_CHUNKS - 1) / (64 * HDM_CHUNKS)), (unsigned)a.ninst), dim3(512), 0, s, a);
+  return hipGetLastError();
+}
+
 // ======================================================================================
 // Discrete actor: Gumbel-softmax straight-through sample and log-prob
 // (franQ/Agent/models/gumbel_mlp.py:7-54 on torch's ExpRelaxedCategorical.rsample, temperature 1)

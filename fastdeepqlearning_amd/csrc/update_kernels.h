@@ -267,6 +267,20 @@ hipError_t policy_bwd_launch(const float *logits, const float *noise, const floa
                              int nparts, float *dpi_sum, const float *w, const DevState *st, int M, int A,
                              float *dlogits, int discrete, hipStream_t s, const float *loss_partials = nullptr,
                              const LossFinishArgs *fin = nullptr);
+// The last hidden layer's pre-activation gradient under a head of up to 32 outputs, gated by the forward launches' sign masks
+// (GemmProblem::gm_*, wstat.hip) instead of the activations:  dpre[m][n] = mask(m, n) ? x : 0.01 x,  x = sum_q dY[m][q] Wh[q][n]
+// (fma chain over q), 256 columns, per-64-row column sums; `ninst` instances of M rows in one launch (config 4: the 25-quantile
+// critics' rank-25 product was a 0.25 ms tile launch that read h again; here 32 bytes of mask per row instead of 1 KiB).
+constexpr int HDM_MAX_INST = 16, HDM_MAXQ = 32;
+struct HeadDgradMaskedArgs {
+  int M, Q, ninst, lddy, ldw;
+  const float *dY[HDM_MAX_INST];      // [M, lddy]
+  const float *Wh[HDM_MAX_INST];      // head rows over this layer's columns: Wh[q * ldw + n]
+  const unsigned *gm[HDM_MAX_INST];   // [M / 32][4][64] sign masks of the layer's activations
+  float *dpre[HDM_MAX_INST];          // [M, 256]
+  float *colsum[HDM_MAX_INST];        // [M / 64, 256]
+};
+hipError_t head_dgrad_masked_launch(const HeadDgradMaskedArgs &a, hipStream_t s);
 // ... and the pre-activation gradient of the actor's last hidden layer (256 wide, continuous policy, 2A <= 16) in the same launch:
 // dpre = LeakyReLU'(h) * (d logits Wh), column sums per 64 rows
 bool policy_bwd_dpre_takes(int discrete, int A, int hidden);

@@ -581,6 +581,11 @@ def test_update_matches_oracle_config2(dev, T, B, hid):
     ("12 action columns, 8 quantiles per critic (column sums of d logits over 24 columns on the streaming launch's 40-column "
      "lanes-over-rows form, d z's 8 columns on the 8-column one, 256-wide partial rows in row groups), 99 rows",
      dict(obs=11, act=12, C=3, Q=8, T=4, B=33)),
+    ("config 4 dims (5x25 quantiles) with the weight-stationary launches forced at T=3, B=96 (FDQL_ROWGEMM=all): the last hidden "
+     "layer's rank-25 gradient gated by the forward launches' masks (k_head_dgrad_masked), the layer-0 dgrad on the masked "
+     "weight-stationary form with 4 narrow steps", dict(obs=376, act=17, C=5, Q=25, T=3, B=96, env={"FDQL_ROWGEMM": "all"})),
+    ("the same with the rank-25 gradient as a GEMM stage (FDQL_NO_HEAD_DGRAD_MASKED)",
+     dict(obs=376, act=17, C=5, Q=25, T=3, B=96, env={"FDQL_ROWGEMM": "all", "FDQL_NO_HEAD_DGRAD_MASKED": "1"})),
     ("config 2 dims at T=5, B=64 with the weight-stationary and the row-block dgrad kernels forced (FDQL_ROWGEMM=all, "
      "FDQL_ROWDGRAD_MIN_BLOCKS=1): the sum of the d state shares inside the joiner's dgrad launch (RowDgradArgs::sum_*), column sums "
      "per 64 rows", dict(obs=17, act=6, C=5, Q=2, T=5, B=64, env={"FDQL_ROWGEMM": "all", "FDQL_ROWDGRAD_MIN_BLOCKS": "1"})),

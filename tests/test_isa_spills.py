@@ -26,7 +26,7 @@ MAY_SPILL = {
 MUST_EXIST = {
     "wstat.hip": ["k_wstat"], "wgrad.hip": ["k_wgrad_stat"], "chain.hip": ["k_chainILi1E", "k_chainILi2E"], "rowdgrad.hip": ["k_rowdgrad", "k_rowdgrad_chain", "k_rowdot"],
     "gemm.hip": ["k_gemm_groupedILi5ELi16ELi1EE", "k_gemm_groupedILi1ELi16ELi1EE", "k_gemm_groupedILi2ELi16ELi1EE"],   # 64x64, 128x32, 32x128
-    "kernels.hip": ["6k_prepE", "12k_policy_fwdI", "12k_policy_bwdE", "17k_policy_bwd_dpreE", "19k_policy_fwd_gumbelE", "19k_policy_bwd_gumbelE", "6k_lossE",
+    "kernels.hip": ["6k_prepE", "12k_policy_fwdI", "12k_policy_bwdE", "17k_policy_bwd_dpreE", "19k_head_dgrad_maskedE", "19k_policy_fwd_gumbelE", "19k_policy_bwd_gumbelE", "6k_lossE",
                     "13k_loss_finishE", "13k_head_finishE", "18k_sum_parts_colsumE", "11k_summariesE", "14k_reduce_slabsE",
                     "17k_reduce_partialsE", "13k_adam_polyakE", "k_skinny_wgrad", "14k_stream_wgradI", "17k_boot_lowerboundE",
                     "12k_head_dgradE", "11k_act_layerE", "12k_act_policyI", "18k_act_policy_gaussI", "8k_onehotE", "k_im2col", "13k_col2im_maskE"],
