@@ -153,6 +153,7 @@ struct Stage {
   int gm_role = 0;
   // the one problem of this stage runs on the row-block dgrad kernel with its first segment formed as a sum of shares
   // (RowDgradArgs::sum_*; build_plan has checked that the kernel takes it)
+  int rd_max_blocks = 0;      // > 0: this stage's own limit for the row-block dgrad kernel (a member of a planned dgrad chain)
   bool needs_masks = false;   // reads gate masks: the plan must have every critics' forward layer weight-stationary (checked in upload_tables)
   bool chained = false;   // switched off because the launch runs inside the chain launch of an earlier stage (RowsLaunch::chain3)
   bool fold_sum = false;
@@ -1033,7 +1034,8 @@ int upload_tables(fdql_agent *a) {
       // single-network dgrads (256-wide K-strided segments, gate / column sums) with enough 64-row blocks to fill most of the chip
       for (size_t i = 0; i < s.gemm.size(); ++i) {
         RowsLaunch rl;
-        if (taken[i] != 1 && s.gemm[i].M / RD_BM >= a->rowdgrad_min_blocks && s.gemm[i].M / RD_BM <= a->rowdgrad_max_blocks &&
+        if (taken[i] != 1 && s.gemm[i].M / RD_BM >= a->rowdgrad_min_blocks &&
+            s.gemm[i].M / RD_BM <= (s.rd_max_blocks > 0 ? s.rd_max_blocks : a->rowdgrad_max_blocks) &&
             rowdgrad_from_problem(s.gemm[i], rl.rda)) {
           if (s.fold_sum && !rowdgrad_fold_sum(rl.rda, s.fold_parts, s.fold_n, s.fold_stride, s.fold_out, s.fold_cs)) {
             set_error("stage %s: the row-block dgrad kernel does not take the folded sum it was planned with", s.name.c_str());
@@ -1862,12 +1864,17 @@ int build_plan(fdql_agent *a) {
   // d state and its column sums; the summing launch (and one write + read of d state) goes away.  Asked here with the same
   // deterministic questions upload_tables asks, because the answer changes the column sums' row count.
   bool fold_dsum = false;
+  // ... and with one hidden layer in the joiner and in the encoder the three launches behind d state become one (k_rowdgrad_chain):
+  // its stages may have more blocks than one round of workgroups (784 at config 4, B = 1024: 0.379 ms against 0.397 for the summing
+  // launch + three tile launches; a lone row-block dgrad launch of that size loses against the tile kernel)
+  const bool chain_planned = a->joiner.hid.size() == 1 && a->enc_obs.hid.size() == 1 && c.enc_features == L && getenv("FDQL_NO_ROWDGRAD_CHAIN") == nullptr;
+  const int rd_max_blocks = chain_planned ? std::max(a->rowdgrad_max_blocks, 1024) : a->rowdgrad_max_blocks;
   if (a->dstate_split && L % 4 == 0 && !gru && !a->joiner.hid.empty()) {
     MlpInst jq = jo;
     jq.rows = M;
     GemmProblem p = b.bwd_dpre(jq, (int)a->joiner.hid.size() - 1, a->buf("dstate"), L);
     RowDgradArgs tmp;
-    fold_dsum = M / RD_BM >= a->rowdgrad_min_blocks && M / RD_BM <= a->rowdgrad_max_blocks && (M >= a->rowdot_min_rows ? p.N > 16 : true) &&
+    fold_dsum = M / RD_BM >= a->rowdgrad_min_blocks && M / RD_BM <= rd_max_blocks && (M >= a->rowdot_min_rows ? p.N > 16 : true) &&
                 rowdgrad_from_problem(p, tmp) &&
                 rowdgrad_fold_sum(tmp, a->buf("dstate.parts"), C + 1, (long long)M * L, a->buf("dstate"), a->buf("cs.dstate"));
   }
@@ -1896,6 +1903,7 @@ int build_plan(fdql_agent *a) {
     if (fold_dsum && i == (int)a->joiner.hid.size() - 1) {
       gs.fold_sum = true; gs.fold_parts = a->buf("dstate.parts"); gs.fold_n = C + 1; gs.fold_stride = (long long)M * L;
       gs.fold_out = a->buf("dstate"); gs.fold_cs = a->buf("cs.dstate");
+      gs.rd_max_blocks = rd_max_blocks;
     }
     hosts.push_back(a->stages.size() - 1);
   }
@@ -1949,12 +1957,14 @@ int build_plan(fdql_agent *a) {
     else b.input_grad_segs(jb, a->buf("dstate"), L, 0, p);
     p.colsum = a->buf("cs.denc");
     gs.gemm.push_back(p);
+    if (fold_dsum) gs.rd_max_blocks = rd_max_blocks;
     hosts.push_back(a->stages.size() - 1);
   }
   const size_t idx_denc = a->stages.size() - 1;
   for (int i = (int)a->enc_obs.hid.size() - 1; i >= 0; --i) {
     Stage &gs = b.gemm_stage("enc_obs.dpre" + std::to_string(i));
     gs.gemm.push_back(b.bwd_dpre(eb, i, a->buf("denc"), c.enc_features));
+    if (fold_dsum) gs.rd_max_blocks = rd_max_blocks;
     hosts.push_back(a->stages.size() - 1);
   }
   // ---- pixel encoder backward (M images): d features -> per layer [dW, db], d col -> col2im -> previous layer

@@ -857,7 +857,10 @@ __global__ __launch_bounds__(1024) void k_policy_bwd_dpre(const float *__restric
 // Q x 256 weights through LDS into registers (a lane owns four columns), the 64 rows' dY in LDS (read as broadcasts), a wave
 // forms eight rows.  The gates of a row's four columns are a nibble of the row's mask dword in the forward wave that owned
 // the columns (the layout k_wstat_grad's fused loader reads, wstat.hip).
-constexpr int HDM_CHUNKS = 4;   // 64-row chunks per workgroup: the head's weights are staged once per 256 rows
+#ifndef FDQL_HDM_CHUNKS
+#define FDQL_HDM_CHUNKS 4
+#endif
+constexpr int HDM_CHUNKS = FDQL_HDM_CHUNKS;   // 64-row chunks per workgroup: the head's weights are staged once per 256 rows
 __global__ __launch_bounds__(512) void k_head_dgrad_masked(const HeadDgradMaskedArgs a) {
   typedef float hv4 __attribute__((ext_vector_type(4)));
   __shared__ __attribute__((aligned(16))) float wl[HDM_MAXQ][256];
