@@ -17,12 +17,10 @@ N > 1 (one process per GPU - started by torch.distributed.run, or 
   final, its RCCL all-reduce starts on a side stream while FDQL_PHASE_GRAD_REST (encoder / joiner / actor gradients) runs, a
   second all-reduce takes the rest (the row weights already carry 1/(B_global), so the sums are the global-batch gradient),
   then FDQL_PHASE_APPLY: identical Adam on every rank.  No barrier inside a timed region.  Three workloads per line:
-  * `value` - the metric's literal reading, "gradient-steps/sec (1M buffer, batch=256) at 1/2/4/8": BASELINE config 2 with
-    B = 256 windows PER GPU on a 1M-slot ring shard per rank ("scaling": "weak"; the N = 1 point IS the single-GPU line).
-    `value` = minibatch gradient steps per second of the whole job = N x optimiser iterations/s (each iteration every rank
-    differentiates its own 256-window minibatch; the reference's trainer likewise counts one step per shard,
-    deepQlearning.py:106); `optimizer_iterations_per_s` and `transitions_per_s` are listed beside it.
-  * `config2_strong` - the same config with the GLOBAL batch fixed at 256 windows, split 256/N per GPU.
+  * `value` - the metric's literal reading, "gradient-steps/sec (1M buffer, batch=256) at 1/2/4/8": BASELINE config 2 with the
+    GLOBAL batch fixed at 256 windows, 256/N per GPU, a 1M-slot ring shard per rank ("scaling": "strong"; the N = 1 point IS
+    the single-GPU line).  `value` = optimiser iterations per second: one all-reduced Adam update is ONE gradient step.
+  * `config2_weak` - 256 windows PER GPU (global batch 256 N): `optimizer_iterations_per_s` and `minibatches_per_s` (= N x it).
   * `config4_strong` - SURVEY 8(d)'s multi-GPU workload: BASELINE config 4 (obs 376, act 17, TQC 5 x 25, 2M-slot ring shard
     per rank), GLOBAL batch 1024 windows split 1024/N, with `same_workload_1gpu` (rank 0 alone on the whole batch, measured
     in the same process) so that the strong-scaling speed-up is computable from the line itself.
@@ -432,6 +430,23 @@ def config4_per_rank(dev, full_ms):
     return out
 
 
+def config2_per_rank(dev, full_ms, T):
+    """What ONE rank of the N-GPU job computes per step at the metric's literal reading (config 2, GLOBAL batch 256 windows
+    split 256/N), measured on this one GPU without the collective: the compute-only bound on `value`'s strong-scaling curve.
+    `two_bucket` = the same batch on the data-parallel plan's launch list (FDQL_FORCE_BUCKETS: what a rank really runs)."""
+    w = WORKLOADS["config2"]
+    out = {"what": "config 2 per-rank batch on one GPU, no all-reduce: ms/step and the compute-only bound on the N-GPU speed-up "
+                   "(global batch 256 windows)", "B256_ms": round(full_ms, 4)}
+    for n in (2, 4, 8):
+        job = Job(w, dev, w["B"] // n, T, ring_slots=200_000)
+        med, rates, max_ms = job.timed_windows(200, 20)
+        out[f"N{n}_B{w['B'] // n}_ms"] = round(1e3 / med, 4)
+        out[f"N{n}_speedup_bound"] = round(full_ms / (1e3 / med), 2)
+        del job
+        torch.cuda.empty_cache()
+    return out
+
+
 def config3_her_ingest(dev, episodes=400):
     """Config 3's write path: episodes of 50 through fdql_ring_append_episode with the hindsight copy and the n-step
     return computed on the device (her.py:55-95, nstep_return.py:36-72); records/s including the host packing."""
@@ -495,14 +510,29 @@ def config3_her_vmap(dev, episodes=8000, K=32, steps=100):
                  "episode_done": i == ep_len - 1, "episode_step": i} for i in range(ep_len)]
 
     eps = [episode() for _ in range(200)]          # a pool of host episodes, appended round-robin (the relabel differs per append)
+    keys_ep = list(eps[0][0])
+    stacked = [{k: np.stack([np.asarray(r[k]) for r in ep]) for k in keys_ep} for ep in eps]   # what a vectorised actor holds
     for rec in eps[0]:
         wh.add(rec)
+    # three forms of the same write: per-record add() (the reference's only one), add_episode(list of records),
+    # add_episode(stacked columns: no per-record Python); the ring is filled by the last
+    n_a = max(episodes // 40, 20)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    n_rec = 0
-    for e in range(1, episodes):
+    for e in range(1, 1 + n_a):
         for rec in eps[e % len(eps)]:
             wh.add(rec)
+    torch.cuda.synchronize(dev)
+    ingest_per_record = n_a * ep_len / (time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    for e in range(n_a):
+        wh.add_episode(eps[e % len(eps)])
+    torch.cuda.synchronize(dev)
+    ingest_list = n_a * ep_len / (time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    n_rec = 0
+    for e in range(1 + 2 * n_a, episodes):
+        wh.add_episode(stacked[e % len(stacked)])
         n_rec += ep_len
     torch.cuda.synchronize(dev)
     ingest = n_rec / (time.perf_counter() - t0)
@@ -542,8 +572,11 @@ def config3_her_vmap(dev, episodes=8000, K=32, steps=100):
            "sampler_ms": round(ms, 4), "sampler_gbs": round(nbytes / (ms * 1e-3) / 1e9, 1), "sampler_algorithmic_bytes": nbytes,
            "sampler_note": "algorithmic bytes = 2 x T x B x the SELECTED row (one goal column of 33); latency-bound at 6 MB like config 2's gather",
            "her_vmap_ingest_records_per_s": round(ingest, 0),
-           "ingest_what": f"{episodes - 1} episodes of {ep_len} through HindsightVmapWrite -> NStepReturnVmap -> ring (per-record add() calls; "
-                          f"relabel + returns + append on the device once per episode)"}
+           "her_vmap_ingest_records_per_s_list_of_records": round(ingest_list, 0),
+           "her_vmap_ingest_records_per_s_per_record_add": round(ingest_per_record, 0),
+           "ingest_what": f"{n_rec // ep_len} episodes of {ep_len} through HindsightVmapWrite.add_episode(stacked columns) -> NStepReturnVmap -> ring "
+                          f"(one call per episode: one H2D copy, relabel + per-column returns + append on the device; no per-record Python); "
+                          f"beside it the same episodes as lists of records ({n_a} episodes) and through per-record add() ({n_a} episodes)"}
     del agent, read_heads, write_heads
     torch.cuda.empty_cache()
     return out
@@ -783,6 +816,10 @@ def bench_single(args, dev, T):
                 extras[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
             torch.cuda.empty_cache()
         try:
+            extras["config2_per_rank"] = config2_per_rank(dev, ms_per_step, T)
+        except Exception as e:   # noqa: BLE001
+            extras["config2_per_rank"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        try:
             if "ms_per_step" in extras.get("config4_1gpu_B1024", {}):
                 extras["config4_per_rank"] = config4_per_rank(dev, extras["config4_1gpu_B1024"]["ms_per_step"])
         except Exception as e:   # noqa: BLE001
@@ -867,7 +904,10 @@ class DPRun:
 
 
 def bench_distributed(args, dev, T, rank, world, backend, dist, nat):
-    """N > 1: config 2 weak scaling (`value`), config 2 strong scaling, config 4 strong scaling (module docstring)."""
+    """N > 1.  `value` = the metric's literal reading: BASELINE config 2 with the GLOBAL batch fixed at 256 windows, split
+    256/N per GPU - optimiser iterations (= gradient steps of the 256-window minibatch) per second, "scaling": "strong".
+    Beside it: config 2 weak (256 windows PER GPU; optimiser iterations/s and, separately, minibatches/s = N x that - a
+    gradient step is never counted N times) and config 4 strong (global batch 1024)."""
     w2, w4 = WORKLOADS["config2"], WORKLOADS["config4"]
     K, W = args.steps, args.warmup
     shrink = os.environ.get("FDQL_BENCH_RING")                           # rehearsal knob (ranks sharing one card)
@@ -875,9 +915,11 @@ def bench_distributed(args, dev, T, rank, world, backend, dist, nat):
     ring4 = int(shrink) if shrink else w4["ring"]
     extra = os.environ.get("FDQL_BENCH_SKIP_EXTRA") is None
 
-    # ---- headline: config 2, B = 256 windows per GPU, 1M-slot shard per rank
+    # ---- headline: config 2, GLOBAL batch 256 windows, 256/N per GPU, 1M-slot shard per rank
     B2 = args.batch or w2["B"]
-    run = DPRun(w2, dev, B2, T, rank, world, backend, dist, nat, ring_slots=ring2)
+    if B2 % world:
+        raise SystemExit(f"global batch {B2} windows does not split over {world} ranks")
+    run = DPRun(w2, dev, B2 // world, T, rank, world, backend, dist, nat, ring_slots=ring2)
     el = run.timed(K, W)
     it_s = K / el
     roofline, top = (roofline_of(run.job, committed_pmc=False) if rank == 0 else (None, None))
@@ -886,17 +928,19 @@ def bench_distributed(args, dev, T, rank, world, backend, dist, nat):
     del run
     torch.cuda.empty_cache()
 
-    strong2, strong4, single4 = None, None, None
+    weak2, strong4, single4 = None, None, None
     if extra:
-        # ---- config 2, global batch fixed at 256 windows
-        if B2 % world == 0:
-            r2 = DPRun(w2, dev, B2 // world, T, rank, world, backend, dist, nat, ring_slots=ring2)
-            e2 = r2.timed(max(K, 50), max(W, 5))
-            strong2 = {"workload": f"{w2['text']}, GLOBAL batch {B2} windows split {B2 // world} per GPU x T={T}", "scaling": "strong",
-                       "value": round(max(K, 50) / e2, 2), "unit": "steps/s", "ms_per_step": round(1e3 * e2 / max(K, 50), 4),
-                       "steps": max(K, 50)}
-            del r2
-            torch.cuda.empty_cache()
+        # ---- config 2, 256 windows PER GPU (global batch 256 N): one optimiser iteration consumes N minibatches
+        rw = DPRun(w2, dev, B2, T, rank, world, backend, dist, nat, ring_slots=ring2)
+        nw = max(K, 50)
+        ew = rw.timed(nw, max(W, 5))
+        weak2 = {"workload": f"{w2['text']} per rank, B={B2} windows PER GPU x T={T} (global batch {B2 * world})", "scaling": "weak",
+                 "optimizer_iterations_per_s": round(nw / ew, 2), "minibatches_per_s": round(world * nw / ew, 2),
+                 "transitions_per_s": round(nw / ew * B2 * world * T, 0), "ms_per_step": round(1e3 * ew / nw, 4), "steps": nw,
+                 "note": "one all-reduced Adam update = ONE gradient step whatever N is; minibatches_per_s = N x optimizer_iterations_per_s "
+                         "counts the 256-window minibatches differentiated per second"}
+        del rw
+        torch.cuda.empty_cache()
         # ---- config 4, global batch 1024 windows: rank 0 alone on the whole batch first, then the split
         B4 = w4["B"]
         if B4 % world == 0:
@@ -921,19 +965,19 @@ def bench_distributed(args, dev, T, rank, world, backend, dist, nat):
             del r4
             torch.cuda.empty_cache()
     return {
-        "metric": "gradient-steps/sec", "value": round(world * it_s, 2), "unit": "steps/s", "n_gpus": world,
+        "metric": "gradient-steps/sec", "value": round(it_s, 2), "unit": "steps/s", "n_gpus": world,
         "steps": K, "warmup": W, "ms_per_step": round(1e3 * el / max(K, 1), 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{w2['text']} per rank, B={B2} windows PER GPU x temporal_len T={T} (global batch {B2 * world}), "
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{w2['text']} per rank, GLOBAL batch {B2} windows split {B2 // world} per GPU x temporal_len T={T}, "
                                f"sample+loss+backward, all-reduce of the {arena_mb:.2f} MB gradient arena in two buckets "
                                f"({backend}; {bucket_frac:.0%} of it beside the actor / encoder backward), Adam+polyak on every rank",
-                   "windows_per_gpu": B2, "global_batch_windows": B2 * world, "temporal_len": T,
-                   "transitions_per_step": B2 * world * T, "ring": ring2, "parallelism": f"dp{world}",
+                   "windows_per_gpu": B2 // world, "global_batch_windows": B2, "temporal_len": T,
+                   "transitions_per_step": B2 * T, "ring": ring2, "parallelism": f"dp{world}",
                    "collective_ranks": dist.get_world_size(), "backend": backend},
-        "value_is": "256-window minibatch gradient steps per second over the whole job = n_gpus x optimizer_iterations_per_s "
-                    "(every iteration each GPU differentiates its own minibatch; the gradients are averaged by the all-reduce)",
-        "optimizer_iterations_per_s": round(it_s, 2), "transitions_per_s": round(it_s * B2 * world * T, 0),
-        "config2_strong": strong2, "config4_strong": strong4,
+        "value_is": "optimiser iterations per second = gradient steps of the 256-window global minibatch (the metric's 'batch=256'); "
+                    "the N = 1 point is the single-GPU BENCH line (same global batch)",
+        "optimizer_iterations_per_s": round(it_s, 2), "transitions_per_s": round(it_s * B2 * T, 0),
+        "config2_weak": weak2, "config4_strong": strong4,
         "roofline": roofline, "cpu_baseline": None, "kernel_ms_top": top, "csrc_sha": csrc_hash(),
     }
 

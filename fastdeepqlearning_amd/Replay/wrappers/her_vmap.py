@@ -39,6 +39,42 @@ class HindsightVmapWrite(ReplayMemoryWrapper):
             self._hindsight_flush()
             self._reset()
 
+    def add_episode(self, episode):
+        """A whole finished episode in ONE call (the reference only has the per-record ``add`` of
+        her_vmap.py:66-90, which this is equivalent to when the records end with ``episode_done``).  ``episode`` is either the
+        list of record dicts (oldest first) or ONE dict of stacked columns ``{key: array[n, ...]}`` - what a vectorised actor
+        holds anyway - in which case no per-record Python runs at all: the columns are packed with one numpy slice assignment
+        per key, copied to the device once, relabelled / scanned / appended there.  Returns the number of ring rows written
+        (n, or n + 1 with the one-shot ``_pop`` record of the n-step wrapper)."""
+        if self.buffer:
+            raise RuntimeError("add_episode() with records of an unfinished episode pending from add()")
+        if isinstance(episode, dict):
+            n = int(np.asarray(episode["episode_done"]).reshape(-1).shape[0])
+            done = np.asarray(episode["episode_done"]).reshape(-1)
+            if n == 0 or not bool(done[-1]) or bool(done[:-1].any()):
+                raise ValueError("add_episode(): exactly the last record of the episode must carry episode_done")
+            target = self._fused_target()
+            if target is not None:
+                cols = {k: self._as_col(v, n) for k, v in episode.items() if k not in self._ignored_keys}
+                first = {k: (episode[k][0] if np.ndim(episode[k]) > 0 else episode[k]) for k in cols}
+                return self._flush_columns(target[0], target[1], cols, first, n)
+            episode = [{k: (v[i] if np.ndim(v) > 0 else v) for k, v in episode.items()} for i in range(n)]   # host reward function
+        else:
+            episode = list(episode)
+            if not episode or not episode[-1]["episode_done"] or any(r["episode_done"] for r in episode[:-1]):
+                raise ValueError("add_episode(): exactly the last record of the episode must carry episode_done")
+        self.buffer = episode
+        try:
+            return self._hindsight_flush()
+        finally:
+            self._reset()
+
+    @staticmethod
+    def _as_col(v, n):
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        return np.asarray(v, np.float32).reshape(n, -1)
+
     def _draw_goal_indices(self, n):
         """her_vmap.py:75 draws indices into the NEWEST-first buffer; converted to oldest-first."""
         newest_first = np.random.randint(0, n, size=self.num_virtual_goals)
@@ -62,15 +98,19 @@ class HindsightVmapWrite(ReplayMemoryWrapper):
         """The relabel (fdql_episode_her_vmap), the per-column returns (fdql_episode_mc_return_vmap, incl. the one-shot _pop
         record of nstep_return_vmap.py:33-34, 50-57) and the packed rows stay on the device: one H2D copy of the episode's
         own columns, one append - no device -> host -> device round trip, no per-record add."""
-        lib = N.load()
-        n, K = len(self.buffer), self.num_virtual_goals
-        dev = self._device
+        n = len(self.buffer)
         col = lambda k: np.asarray([np.asarray(x[k].detach().cpu().numpy() if isinstance(x[k], torch.Tensor) else x[k],
                                                np.float32).reshape(-1) for x in self.buffer], np.float32)
-        ag, dg = col("achieved_goal"), col("desired_goal")
-        g = ag.shape[1]
         # the record the per-record path would hand down (key order = insertion order), virtual columns last
         rec0 = {k: v for k, v in self.buffer[0].items() if k not in self._ignored_keys}
+        return self._flush_columns(mem, nstep, {k: col(k) for k in rec0}, rec0, n)
+
+    def _flush_columns(self, mem, nstep, cols, rec0, n):
+        """``cols``: {key: float32 [n, dim]} of the episode's own keys; ``rec0``: its first record (the ring's template)."""
+        lib = N.load()
+        K = self.num_virtual_goals
+        dev = self._device
+        g = cols["achieved_goal"].shape[1]
         template = dict(rec0)
         template["virtual_goals"] = np.zeros((K + 1, g), np.float32)
         template["virtual_rewards"] = np.zeros(K + 1, np.float32)
@@ -82,7 +122,7 @@ class HindsightVmapWrite(ReplayMemoryWrapper):
         host = np.zeros((n, int(mem._offsets[-1])), np.float32)
         for k in mem._keys:
             if k in rec0:
-                host[:, off[k][0]:off[k][1]] = col(k)
+                host[:, off[k][0]:off[k][1]] = cols[k]
         rows = torch.from_numpy(host).to(dev)
         idx = torch.as_tensor(self._draw_goal_indices(n), dtype=torch.int32, device=dev)
         r, td = rows[:, off["reward"][0]].contiguous(), rows[:, off["task_done"][0]].contiguous()
@@ -114,6 +154,7 @@ class HindsightVmapWrite(ReplayMemoryWrapper):
             mem.add_rows(rows.contiguous())
         if hasattr(mem, "_len"):          # AsyncReplayMemory's own saturating counter (async_replay_memory.py:27-29)
             mem._len = min(mem._len + int(rows.shape[0]), mem._maxlen)
+        return int(rows.shape[0])
 
     def _hindsight_flush(self):
         target = self._fused_target()
@@ -145,6 +186,7 @@ class HindsightVmapWrite(ReplayMemoryWrapper):
             out["virtual_rewards"] = vr[i]
             out["virtual_dones"] = vd[i]
             self.replay_buffer.add(out)
+        return n
 
 
     def _host_relabel(self, ag, dg, reward, done, goal_idx):

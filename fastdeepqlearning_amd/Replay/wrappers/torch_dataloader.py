@@ -43,7 +43,10 @@ class TorchDataLoader(ReplayMemoryWrapper):
     def _issue_prefetch(self):
         """The next batch's gather on the side stream, behind everything the current stream holds so far (the update that
         last read the buffer being refilled) and beside whatever is enqueued after this call (the update of the batch
-        returned now)."""
+        returned now).  Writers that arrive on another stream afterwards (``add`` / ``add_rows`` scatters on the main
+        stream) are ordered behind this gather by the ring itself: every launch that writes slots waits for the events of
+        the reads issued on other streams (csrc/ring.hip ``begin_write`` / ``end_read``), so the gather never sees
+        half-written rows."""
         if self._side is None:
             self._side = torch.cuda.Stream(self.device)
             self._events = [torch.cuda.Event() for _ in range(6)]

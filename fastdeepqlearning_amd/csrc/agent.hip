@@ -154,7 +154,8 @@ struct Stage {
   // the one problem of this stage runs on the row-block dgrad kernel with its first segment formed as a sum of shares
   // (RowDgradArgs::sum_*; build_plan has checked that the kernel takes it)
   int rd_max_blocks = 0;      // > 0: this stage's own limit for the row-block dgrad kernel (a member of a planned dgrad chain)
-  bool needs_masks = false;   // reads gate masks: the plan must have every critics' forward layer weight-stationary (checked in upload_tables)
+  bool needs_masks = false;   // reads gate masks: runs only when every critics' forward layer of the plan is weight-stationary (upload_tables)
+  bool masks_fallback = false;   // ... and the GEMM stage that does the same work from h when they are not
   bool chained = false;   // switched off because the launch runs inside the chain launch of an earlier stage (RowsLaunch::chain3)
   bool fold_sum = false;
   const float *fold_parts = nullptr;
@@ -1153,7 +1154,9 @@ int upload_tables(fdql_agent *a) {
     s1.rows[0].rch = c;
     s2.off = s3.off = true;
     s2.chained = s3.chained = true;
-    s1.flops += s2.flops + s3.flops;   // (the launch does their work: fdql_agent_stats counts executed flops)
+    // the launch does their work (fdql_agent_stats counts executed flops); s1's own figures were recomputed from its
+    // problems at the top of this upload, so a second upload does not add them twice
+    s1.flops += s2.flops + s3.flops;
     s1.bytes += s2.bytes + s3.bytes;
   }
   // head-fusion planes: with every hidden layer of the critics on weight-stationary launches, those launches sum a tile's column
@@ -1194,11 +1197,10 @@ int upload_tables(fdql_agent *a) {
       all = all && ok && n == s.gemm.size();
     }
     const bool masks = nfwd > 0 && all;
-    for (const Stage &s : a->stages)
-      if (s.needs_masks && !masks) {
-        set_error("stage %s was planned on gate masks the forward launches of this plan do not write", s.name.c_str());
-        return FDQL_EINVAL;
-      }
+    for (Stage &s : a->stages) {   // a stage planned on the masks and its GEMM stand-in: exactly one of them runs
+      if (s.needs_masks) s.off = !masks;
+      if (s.masks_fallback) s.off = masks;
+    }
     for (Stage &s : a->stages) {
       for (RowsLaunch &rl : s.rows) {
         if (!rl.ws) continue;
@@ -1733,6 +1735,15 @@ int build_plan(fdql_agent *a) {
         }
         Stage &fs = b.func_stage("critics.dpre" + std::to_string(i) + "(masked)", [=](hipStream_t s) { return head_dgrad_masked_launch(ha, s); });
         fs.needs_masks = true;
+        // the same product as a GEMM stage gated by h itself (same outputs, same per-64-row column sums): switched on by
+        // upload_tables instead of the masked launch when the forward launches of the final plan turn out not to write masks
+        Stage &fb = b.gemm_stage("critics.dpre" + std::to_string(i) + "(unmasked)");
+        fb.masks_fallback = true;
+        fb.off = true;
+        for (int k = 0; k < C; ++k) {
+          fb.gemm.push_back(b.bwd_dpre(co[k], i, a->buf("dz") + k * Q, Nq));
+          fb.gemm.push_back(b.bwd_dpre(cf[k], i, a->buf("dzf") + k * Q, Nq));
+        }
         continue;
       }
       if (Builder::narrow_head_last(a->critic[0], i) && !head_dgrad_as_gemm) {
@@ -2414,8 +2425,11 @@ int fdql_agent_update(fdql_agent_t *a, const fdql_batch_t *batch, const float *n
     set_error("FDQL_PHASE_APPLY needs a finished gradient (FDQL_PHASE_GRAD, or FDQL_PHASE_GRAD_CRITICS + FDQL_PHASE_GRAD_REST) of the same step");
     return FDQL_ESTATE;
   }
-  a->step_state = phase == FDQL_PHASE_GRAD_CRITICS ? fdql_agent::STEP_CRITICS_DONE
+  // the state this call leaves behind when every stage has been launched; until then (and after a failed launch) there is
+  // no step an APPLY / GRAD_REST could continue
+  const fdql_agent::StepState done_state = phase == FDQL_PHASE_GRAD_CRITICS ? fdql_agent::STEP_CRITICS_DONE
                   : (phase == FDQL_PHASE_GRAD || phase == FDQL_PHASE_GRAD_REST) ? fdql_agent::STEP_GRAD_DONE : fdql_agent::STEP_NONE;
+  a->step_state = fdql_agent::STEP_NONE;
   hipStream_t s = (hipStream_t)stream;
   if (phase == FDQL_PHASE_ALL && a->use_graph) {
     fdql_agent::PlanGraph &g = a->graph;
@@ -2430,6 +2444,7 @@ int fdql_agent_update(fdql_agent_t *a, const fdql_batch_t *batch, const float *n
     if (g.exec) {
       FDQL_HIP(hipGraphLaunch(g.exec, s));
       ++a->graph_launches;
+      a->step_state = done_state;
       return 0;
     }
     ++g.eager_runs;
@@ -2439,6 +2454,7 @@ int fdql_agent_update(fdql_agent_t *a, const fdql_batch_t *batch, const float *n
     hipError_t e = run_stage(a, st, s);
     if (e != hipSuccess) { set_error("stage %s: %s", st.name.c_str(), hipGetErrorString(e)); return FDQL_EHIP; }
   }
+  a->step_state = done_state;
   return 0;
 }
 
@@ -2456,6 +2472,7 @@ int32_t fdql_agent_profile_update(fdql_agent_t *a, const fdql_batch_t *batch, co
   std::lock_guard<std::mutex> lk(a->mu);
   int rc = prepare_update(a, batch, noise_target, noise_actor, seed);
   if (rc) return rc;
+  a->step_state = fdql_agent::STEP_NONE;   // a whole update of its own: no split-phase step survives it
   hipStream_t s = (hipStream_t)stream;
   // one entry per kernel launch: GEMM stages launch one kernel per tile shape
   struct Part { Stage *st; int shape; };   // shape < -1: row-block group -(shape + 2)

@@ -42,11 +42,16 @@ FDQL_HD double dm_reduce_ln2(double x, int &n) {
   return __builtin_fma(t, -ln2_lo, __builtin_fma(t, -ln2_hi, x));
 }
 
-// |x| <= 700
+// Finite x: the argument is clamped to [-745.2, 709.8] (exp underflows to 0 / overflows to inf beyond it, and the reduction's
+// (int) conversion needs |n| small); exp(-inf) = 0, exp(inf) = inf through the clamp and ldexp; NaN in -> NaN out, as libm.
 FDQL_HD double dm_exp(double x) {
+  if (x != x) return x;
+  const double xc = x < -745.2 ? -745.2 : (x > 709.8 ? 709.8 : x);
   int n;
-  const double r = dm_reduce_ln2(x, n);
-  return __builtin_ldexp(1.0 + dm_expm1_small(r), n);
+  const double r = dm_reduce_ln2(xc, n);
+  // two-step scaling: 1 + p in [0.7, 1.5], n in [-1075, 1024] - one ldexp by n < -1022 or n = 1024 would lose the result
+  const int n1 = n / 2;
+  return __builtin_ldexp(__builtin_ldexp(1.0 + dm_expm1_small(r), n1), n - n1);
 }
 
 // x > 0, normal
@@ -72,6 +77,7 @@ FDQL_HD double dm_log(double x) {
 
 // tanh x = em / (em + 2), em = expm1(2 |x|)
 FDQL_HD double dm_tanh(double x) {
+  if (x != x) return x;   // NaN in -> NaN out (a diverged policy mean must not come back as a saturated action)
   const double ax = __builtin_fabs(x);
   const double u = 2.0 * (ax < 20.0 ? ax : 20.0);   // tanh(20) rounds to 1 in double
   int n;

@@ -756,9 +756,8 @@ __global__ __launch_bounds__(1024) void k_policy_bwd_dpre(const float *__restric
                                                           const float *__restrict__ action, const float *__restrict__ dpi_parts, int nparts,
                                                           float *__restrict__ dpi_sum, const float *__restrict__ w, const DevState *st, int M, int A,
                                                           float *__restrict__ dlogits, PolicyBwdDpreArgs d, LossFinishRider fin, int own_blocks) {
-  if ((int)blockIdx.x >= own_blocks) {   // (uniform; the finish is written for 256 threads)
-    if (threadIdx.x < 256)
-      loss_finish_block(fin.partials, fin.f.nblocks, fin.f.M, fin.f.Nq, fin.f.st, fin.f.scalars, fin.f.dlog_alpha, fin.f.lr, fin.f.b1, fin.f.b2);
+  if ((int)blockIdx.x >= own_blocks) {   // (uniform; every thread of the workgroup enters: the finish has workgroup barriers)
+    loss_finish_block(fin.partials, fin.f.nblocks, fin.f.M, fin.f.Nq, fin.f.st, fin.f.scalars, fin.f.dlog_alpha, fin.f.lr, fin.f.b1, fin.f.b2);
     return;
   }
   typedef float pv4 __attribute__((ext_vector_type(4)));
@@ -1445,17 +1444,21 @@ hipError_t loss_launch(const LossArgs &a, hipStream_t s) {
 __device__ __forceinline__ void loss_finish_block(const float *__restrict__ partials, int nblocks, int M, int Nq,
                                                   DevState *st, float *__restrict__ scalars,
                                                   float *__restrict__ dlog_alpha, double lr, double b1, double b2) {
+  // Called by EVERY thread of a workgroup of >= 256 threads (the barriers below are workgroup barriers); the first 256 do
+  // the work, in the same order whatever the workgroup's size.
   __shared__ float red[256][LOSS_NPART];
   if (threadIdx.x == 255) tick_adam(st, lr, b1, b2);
   const int tid = threadIdx.x;
-  float acc[LOSS_NPART];
+  if (tid < 256) {
+    float acc[LOSS_NPART];
 #pragma unroll
-  for (int k = 0; k < LOSS_NPART; ++k) acc[k] = 0.f;
-  for (int b = tid; b < nblocks; b += 256)
+    for (int k = 0; k < LOSS_NPART; ++k) acc[k] = 0.f;
+    for (int b = tid; b < nblocks; b += 256)
 #pragma unroll
-    for (int k = 0; k < LOSS_NPART; ++k) acc[k] += partials[(long long)b * LOSS_NPART + k];
+      for (int k = 0; k < LOSS_NPART; ++k) acc[k] += partials[(long long)b * LOSS_NPART + k];
 #pragma unroll
-  for (int k = 0; k < LOSS_NPART; ++k) red[tid][k] = acc[k];
+    for (int k = 0; k < LOSS_NPART; ++k) red[tid][k] = acc[k];
+  }
   __syncthreads();
   for (int off = 128; off >= 1; off >>= 1) {
     if (tid < off)

@@ -35,5 +35,14 @@ int main(int argc, char **argv) {
   sweep("tanh_small", [](double x) { return dm_tanh(x); }, [](double x) { return std::tanh(x); }, 1e-12, 0.5, n, true);
   sweep("tanh_neg_small", [](double x) { return dm_tanh(-x); }, [](double x) { return std::tanh(-x); }, 1e-12, 0.5, n, true);
   sweep("tanh_big", [](double x) { return dm_tanh(x); }, [](double x) { return std::tanh(x); }, 8.0, 60.0, n / 4, false);
+  // non-finite and out-of-range inputs follow libm: NaN in -> NaN out, exp(-inf) = 0, exp(+inf) = inf, tanh(+-inf) = +-1
+  const double inf = INFINITY, nan = NAN;
+  int bad = 0;
+  bad += !(dm_exp(nan) != dm_exp(nan));
+  bad += !(dm_tanh(nan) != dm_tanh(nan));
+  bad += !(dm_exp(-inf) == 0.0) + !(dm_exp(inf) == inf) + !(dm_exp(-1e4) == 0.0) + !(dm_exp(1e4) == inf);
+  bad += !(dm_tanh(inf) == 1.0) + !(dm_tanh(-inf) == -1.0) + !(dm_tanh(1e300) == 1.0);
+  bad += !((float)dm_exp(-744.0) == (float)std::exp(-744.0)) + !(dm_exp(709.0) == std::exp(709.0) || std::fabs(dm_exp(709.0) / std::exp(709.0) - 1.0) < 5e-15);
+  std::printf("nonfinite_failures %d\n", bad);
   return 0;
 }

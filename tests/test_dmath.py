@@ -13,6 +13,7 @@ def test_dmath_matches_libm(tmp_path):
     out = subprocess.run([exe, "600000"], check=True, capture_output=True, text=True).stdout
     rows = re.findall(r"^(\w+) max_rel_err (\S+) at \S+ float_mismatches (\d+) of (\d+)$", out, re.M)
     assert len(rows) == 10, out
+    assert re.search(r"^nonfinite_failures 0$", out, re.M), out   # NaN / +-inf / out-of-range arguments behave like libm
     for name, err, mism, n in rows:
         # a few double ulps; rounded to float (what every caller keeps) the results are libm's
         assert float(err) < 5e-15, (name, err)

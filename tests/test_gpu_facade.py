@@ -504,7 +504,7 @@ def _l2_callable(ag, dg, thr=0.25):
 
 
 @pytest.mark.parametrize("case", ["k4", "k32_pop"])
-@pytest.mark.parametrize("reward_kind", ["device", "device_per_record", "host_callable"])
+@pytest.mark.parametrize("reward_kind", ["device", "device_per_record", "host_callable", "episode_list", "episode_stacked", "episode_stacked_host_fn"])
 def test_her_vmap_stack_matches_reference(dev, case, reward_kind):
     """HindsightVmapWrite -> NStepReturnVmap -> HBM ring -> HindsightVmapRead against what the reference's own
     her_vmap.py / nstep_return_vmap.py emitted and sampled (tests/golden/her_vmap.npz): fdql_episode_her_vmap (or the
@@ -518,16 +518,38 @@ def test_her_vmap_stack_matches_reference(dev, case, reward_kind):
     inner = NStepReturnVmap(ring, int(g["n_step"]), float(g["gamma"]))
     # "device": the fused path (relabel, returns and packed rows stay on the device, one append per episode);
     # "device_per_record": the same kernels, records re-added one by one; "host_callable": an arbitrary Python reward function
-    fn = SparseL2Reward(float(g["thr"]), -1.0) if reward_kind.startswith("device") else _l2_callable
-    w = HindsightVmapWrite(inner, fn, num_virtual_goals=K, fused=reward_kind == "device")
-    if reward_kind == "device":
+    # "episode_list" / "episode_stacked": HindsightVmapWrite.add_episode() with the finished episode as a list of records / as ONE
+    # dict of stacked columns (no per-record Python); "episode_stacked_host_fn": stacked columns with a Python reward callable
+    host_fn = reward_kind in ("host_callable", "episode_stacked_host_fn")
+    fn = _l2_callable if host_fn else SparseL2Reward(float(g["thr"]), -1.0)
+    w = HindsightVmapWrite(inner, fn, num_virtual_goals=K, fused=reward_kind != "device_per_record")
+    if reward_kind in ("device", "episode_list", "episode_stacked"):
         assert w._fused_target() is not None
     inp = g["in"]
     np.random.seed(100 + K)                 # the generator's seed: her_vmap.py:75 draws from numpy's global state
-    for i in range(inp["reward"].shape[0]):
-        w.add({"obs_1d": inp["obs_1d"][i], "achieved_goal": inp["achieved_goal"][i], "desired_goal": inp["desired_goal"][i],
-               "action": inp["action"][i], "reward": float(inp["reward"][i, 0]), "task_done": bool(inp["task_done"][i, 0]),
-               "episode_done": bool(inp["episode_done"][i, 0]), "episode_step": int(inp["episode_step"][i, 0]), "info": {}})
+    recs = [{"obs_1d": inp["obs_1d"][i], "achieved_goal": inp["achieved_goal"][i], "desired_goal": inp["desired_goal"][i],
+             "action": inp["action"][i], "reward": float(inp["reward"][i, 0]), "task_done": bool(inp["task_done"][i, 0]),
+             "episode_done": bool(inp["episode_done"][i, 0]), "episode_step": int(inp["episode_step"][i, 0]), "info": {}}
+            for i in range(inp["reward"].shape[0])]
+    if reward_kind.startswith("episode"):
+        ends = [i for i, r in enumerate(recs) if r["episode_done"]]
+        assert ends and ends[-1] == len(recs) - 1
+        lo, written = 0, 0
+        for e in ends:
+            ep = recs[lo:e + 1]
+            if reward_kind == "episode_list":
+                written += w.add_episode(ep)
+            else:
+                keys = [k for k in ep[0] if k != "info"]
+                written += w.add_episode({k: np.stack([np.asarray(r[k]) for r in ep]) for k in keys})
+            lo = e + 1
+        with pytest.raises(ValueError):
+            w.add_episode(recs[:max(ends[0], 1)])          # no episode_done at the end
+        if reward_kind != "episode_stacked_host_fn":
+            assert written == int(g["ring_len"])           # (incl. the n-step wrapper's one-shot _pop record)
+    else:
+        for r in recs:
+            w.add(r)
     n = int(g["ring_len"])
     assert len(ring) == n
     got = ring[np.arange(n)]
