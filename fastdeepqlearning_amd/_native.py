@@ -133,6 +133,8 @@ SIGNATURES = {
                                  _i32, _vp]),
     "fdql_debug_rowgemm_life": (C.c_int, [_vp, _i32]),
     "fdql_debug_side_copy": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "fdql_test_conv": (C.c_int, [_i32, _vp, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32,
+                                 _i32, _vp]),
     "fdql_test_wgrad_stat": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _vp]),
     "fdql_test_wgrad_stat_riders": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _vp, _i32, _i32, _vp, _i32, _i32,
                                               _vp, _i32, _i32, _vp, _i32, _vp]),

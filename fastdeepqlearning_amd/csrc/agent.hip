@@ -24,6 +24,7 @@
 #include "wstat.h"
 #include "wgrad.h"
 #include "rowdgrad.h"
+#include "conv.h"
 #include "common.h"
 #include "update_kernels.h"
 
@@ -2951,6 +2952,42 @@ int fdql_test_gemm(const float *A, int32_t lda, int32_t a_kc, const float *B, in
 /* Test hook for the output-stationary weight-gradient kernel (wgrad.hip): nprob blocks dW[i] [256, ldw] (slab 0 at dW + i *
  * 256 * ldw, slabs slab_stride floats apart, nslab of them) = G[i]^T X[i] over M rows each (G, X: [nprob * M, 256]).  Every
  * slab of every block is written (partials or zeros): their sum is the gradient.  FDQL_EINVAL: the kernel does not take the form. */
+int fdql_test_conv(int32_t mode, const void *in, int32_t u8, const int64_t *starts, int64_t ring_len, int32_t B,
+                   const float *W, const float *bias, const float *dpre, const float *act_prev, float *out, float *scratch,
+                   int64_t scratch_floats, int64_t nimg, int32_t C, int32_t H, int32_t Wd, int32_t k, int32_t s, int32_t cout,
+                   void *stream) {
+  ConvGeom g;
+  g.C = C; g.H = H; g.W = Wd; g.k = k; g.s = s;
+  FDQL_REQUIRE(k > 0 && s > 0 && H >= k && Wd >= k && nimg > 0, "fdql_test_conv: bad geometry");
+  g.OH = (H - k) / s + 1; g.OW = (Wd - k) / s + 1;
+  ConvSrc src;
+  src.base = in; src.u8 = u8; src.starts = (const long long *)starts; src.ring_len = ring_len; src.B = B;
+  hipStream_t st = (hipStream_t)stream;
+  if (mode == 0) {
+    FDQL_REQUIRE(conv_fwd_takes(g, cout, u8 != 0), "fdql_test_conv: no forward kernel for this layer");
+    ConvFwdArgs a;
+    a.in = src; a.W = W; a.bias = bias; a.out = out; a.nimg = nimg; a.g = g; a.cout = cout;
+    FDQL_HIP(conv_fwd_launch(a, st));
+  } else if (mode == 1) {
+    FDQL_REQUIRE(!u8 && conv_dgrad_takes(g, cout), "fdql_test_conv: no data-gradient kernel for this layer");
+    ConvDgradArgs a;
+    a.dpre = dpre; a.W = W; a.act_prev = act_prev; a.dprev = out; a.nimg = nimg; a.g = g; a.cout = cout;
+    FDQL_HIP(conv_dgrad_launch(a, st));
+  } else if (mode == 2) {
+    const int nslab = conv_wgrad_slabs(g, cout, u8 != 0, nimg);
+    const long long n = (long long)cout * C * k * k + cout;
+    FDQL_REQUIRE(nslab > 0, "fdql_test_conv: no weight-gradient kernel for this layer");
+    FDQL_REQUIRE(scratch_floats >= nslab * n, "fdql_test_conv: scratch of %lld floats, %lld needed", (long long)scratch_floats, nslab * n);
+    ConvWgradArgs a;
+    a.in = src; a.dpre = dpre; a.wpart = scratch; a.nimg = nimg; a.g = g; a.cout = cout;
+    FDQL_HIP(conv_wgrad_launch(a, st));
+    FDQL_HIP(reduce_partials_launch(scratch, nslab, n, out, st));
+  } else {
+    FDQL_REQUIRE(false, "fdql_test_conv: unknown mode %d", (int)mode);
+  }
+  return 0;
+}
+
 int fdql_test_wgrad_stat(const float *G, const float *X, float *dW, int32_t M, int32_t nprob, int32_t ldw, int32_t nslab,
                          int64_t slab_stride, void *stream) {
   return fdql_test_wgrad_stat_riders(G, X, dW, M, nprob, ldw, nslab, slab_stride, nullptr, 0, 0, nullptr, 0, 1, nullptr, 0, 0, nullptr, 0, stream);

@@ -412,6 +412,20 @@ int fdql_test_wgrad_stat_riders(const float *G, const float *X, float *dW, int32
                                 int64_t slab_stride, const float *X2, int32_t nx2, int32_t ldx2, float *dW2, int32_t ldw2, int32_t x2_every,
                                 const float *G2, int32_t ng2, int32_t ldg2, float *dW3, int32_t ldw3, void *stream);
 
+/* Test hook for the implicit-GEMM convolutions of the pixel encoder (csrc/conv.hip; BASELINE config 5 - the reference's conv
+ * branch is dead code, franQ/Agent/components/encoder.py:16-23: the parity target is torch conv2d).  One layer on nimg images:
+ *   mode 0  forward        out[nimg, OH*OW, cout] = LeakyReLU(conv(in, W) + bias)                                  (NHWC)
+ *   mode 1  data gradient  out[nimg, H*W, C] = LeakyReLU'(act_prev) * conv^T(dpre, W); `in` unused
+ *   mode 2  weight grad.   out[cout*K + cout] = (dW, db) = sum over images and positions; scratch = partial slabs
+ * in: u8 != 0: uint8 NCHW frames - [nimg, C*H*W] back to back (starts == NULL) or a ring block [slots, C*H*W] read through
+ *     the window starts (image i = (t, b) = (i / B, i % B) is slot (starts[b] + t) % ring_len); W is [cout, K] with K = (c, ky, kx);
+ *     u8 == 0: float32 NHWC maps [nimg, H, W, C]; K = (ky, kx, c).
+ * FDQL_EINVAL when the layer geometry has no kernel instantiation.  Asynchronous on `stream`. */
+int fdql_test_conv(int32_t mode, const void *in, int32_t u8, const int64_t *starts, int64_t ring_len, int32_t B,
+                   const float *W, const float *bias, const float *dpre, const float *act_prev, float *out, float *scratch,
+                   int64_t scratch_floats, int64_t nimg, int32_t C, int32_t H, int32_t Wd, int32_t k, int32_t s, int32_t cout,
+                   void *stream);
+
 /* Diagnostic (tools/dp_overlap.py): a stand-in for the channel kernels of a collective - `workgroups` workgroups of 256
  * threads (each holding lds_bytes of LDS) copy n floats from src to dst `passes` times (the ring steps of an all-reduce
  * re-read their chunk) and then stay resident until hold_us microseconds have passed since they started (a collective's

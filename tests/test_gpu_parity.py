@@ -600,9 +600,6 @@ def test_update_matches_oracle_config2(dev, T, B, hid):
      "path the in-kernel plane sum replaces)", dict(obs=17, act=6, C=5, Q=2, T=5, B=64, env={"FDQL_ROWGEMM": "all", "FDQL_NO_HEAD_PRESUM": "1"})),
     ("config 2 dims at T=50, B=384: 18 816 gradient rows = 294 blocks of 64 - k_rowdgrad_chain (d state sum + joiner / d enc / "
      "encoder dgrads in one launch) with MORE blocks than one round of workgroups", dict(obs=17, act=6, C=5, Q=2, T=50, B=384)),
-    ("25-quantile heads at config 2's full row count (obs 17, act 6, 5x25, T=50, B=256: 12 544 rows = 49 per CU): k_head_dgrad_masked "
-     "with several 4 x 64-row groups per instance, k_loss_wave<2> on 12 544 waves, the masked weight-stationary dgrad at 5 narrow steps",
-     dict(obs=17, act=6, C=5, Q=25, T=50, B=256)),
     ("config 2 dims on the LDS-DMA GEMM, 128x128 tiles (dense shape 7: dual outputs + head fusion in that kernel)",
      dict(obs=17, act=6, C=5, Q=2, T=6, B=64, dense_shape=7)),
     ("ragged sizes on the LDS-DMA GEMM, 64x64 tiles (edge tiles and ragged chunks through its guarded path)",
@@ -1013,6 +1010,9 @@ def _gpu_branch_pattern(ag, spec, xp_cpu):
      dict(obs=17, act=6, C=5, Q=2, T=2, B=256)),
     ("config 2 dims at T=50, B=384 (18 816 gradient rows = 294 blocks of 64: k_rowdgrad_chain beyond one round of workgroups)",
      dict(obs=17, act=6, C=5, Q=2, T=50, B=384)),
+    ("25-quantile heads at config 2's full row count (obs 17, act 6, 5x25, T=50, B=256: 12 544 rows = 49 per CU): k_head_dgrad_masked "
+     "with several 4 x 64-row groups per instance, k_loss_wave<2> on 12 544 waves, the masked weight-stationary dgrad at 5 narrow steps",
+     dict(obs=17, act=6, C=5, Q=25, T=50, B=256)),
     ("config 4 dims (5x25 quantiles, 17 action columns) at T=6, B=64 with the stationary and streaming launches forced "
      "(FDQL_ROWGEMM=all FDQL_STREAM_WGRAD=2: 25 head rows and 17 input columns per streaming problem, no riders fit)",
      dict(obs=376, act=17, C=5, Q=25, T=6, B=64, env={"FDQL_ROWGEMM": "all", "FDQL_STREAM_WGRAD": "2", "FDQL_WGRAD_STAT_FACTOR": "1"})),

@@ -18,6 +18,7 @@ CASES = [("config 2 (obs 17, act 6)", [17, 6, 1, 1, 1, 1, 1, 1], 1_000_000, 50, 
 
 def main():
     dev = torch.device("cuda:0")
+    reps = int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 50
     for name, dims, maxlen, T, B in CASES:
         ring = NativeRing(maxlen, dims, dev)
         rowf = sum(dims)
@@ -31,7 +32,6 @@ def main():
         for i in range(5):
             ring.sample_windows(T, B, seed=1, counter=i, outs=outs)
         torch.cuda.synchronize()
-        reps = 50
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for i in range(reps):
@@ -40,8 +40,23 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
         nbytes = 2.0 * T * B * rowf * 4 + 8 * B
+        # the same bytes as ONE plain device-to-device copy (hipMemcpyAsync DtoD: reads n, writes n), timed the same way:
+        # what "the rate of a device copy" means on this box for this size
+        src = torch.empty(int(nbytes // 8), dtype=torch.float32, device=dev).normal_()
+        dst = torch.empty_like(src)
+        for _ in range(3):
+            dst.copy_(src)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        cms = e0.elapsed_time(e1) / reps
         print(f"{name:48s} {nbytes / 1e6:9.2f} MB/sample  {ms * 1e3:8.1f} us  {nbytes / ms / 1e6:8.1f} GB/s "
-              f"({nbytes / ms / 1e6 / 8000 * 100:.1f} % of 8 TB/s)", flush=True)
+              f"({nbytes / ms / 1e6 / 8000 * 100:.1f} % of 8 TB/s)   device copy of the same bytes: {cms * 1e3:8.1f} us "
+              f"{nbytes / cms / 1e6:8.1f} GB/s", flush=True)
+        del src, dst
         del ring, outs
         torch.cuda.empty_cache()
 
