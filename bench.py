@@ -229,7 +229,7 @@ def dominant(prof):
     the row-block chain kernel): name, ms/step, flops/step, launches/step, and the all-MFMA-kernel totals."""
     groups = {}
     for k, v in prof.items():
-        if k.startswith(("gemm", "chain", "rows", "rowd", "wstat", "wgstat")):
+        if k.startswith(("gemm", "chain", "rows", "rowd", "wstat", "wgstat", "conv:")):
             groups.setdefault(k.split(":")[0], []).append(v)
     name, rows = max(groups.items(), key=lambda kv: sum(r[0] for r in kv[1]))
     ms, fl, n = sum(r[0] for r in rows), sum(r[1] * r[3] for r in rows), sum(r[3] for r in rows)
@@ -240,6 +240,8 @@ def dominant(prof):
 
 
 def kernel_label(name):
+    if name.startswith("conv:"):
+        return "k_conv_* (implicit-GEMM convolution, image groups resident in LDS, fp32 v_mfma_f32_16x16x4_f32)"
     if name.startswith("chain"):
         return "k_chain (row-block MLP chain, fp32 v_mfma_f32_32x32x2_f32)"
     if name.startswith("wstat"):
@@ -260,6 +262,8 @@ def kernel_label(name):
 
 def rocprof_tag(name):
     """Substring of the rocprofv3 kernel name behind a profile entry (profiles/*: which kernel a PMC file is about)."""
+    if name.startswith("conv:"):
+        return "k_conv_"
     if name.startswith("chain"):
         return "k_chain"
     if name.startswith("wgstat"):
@@ -582,9 +586,11 @@ def config3_her_vmap(dev, episodes=8000, K=32, steps=100):
     return out
 
 
-def config5_secondary(dev, ring=200_000, B=512, T=50, steps=20):
+def config5_secondary(dev, ring=1_000_000, B=512, T=50, steps=20):
     """BASELINE config 5 (discrete SAC on 4x84x84 uint8 frame stacks, conv encoder of this build - no reference exists,
-    SURVEY 8d) at the full batch on a 200k-frame uint8 ring (5.6 GB; the step does not depend on the ring's length)."""
+    SURVEY 8d) at the full batch on the 1M-frame uint8 ring BASELINE states (28 GB of HBM).  Per step: windowed sample of the
+    scalar keys + the window slots, then the update - the first conv layer reads the uint8 frames of the sampled windows
+    straight from the ring (no float32 frame batch, no column matrices: csrc/conv.hip)."""
     from fastdeepqlearning_amd.core import NativeAgent, NativeRing, make_config
     IMG, ACT = (4, 84, 84), 6
     dims = [IMG[0] * IMG[1] * IMG[2], 1, 1, 1, 1, 1]
@@ -593,7 +599,7 @@ def config5_secondary(dev, ring=200_000, B=512, T=50, steps=20):
     g = torch.Generator(device=dev).manual_seed(0)
     done = 0
     while done < ring:
-        n = min(4096, ring - done)
+        n = min(8192, ring - done)
         rows = torch.empty(n, sum(dims), device=dev)
         rows[:, :dims[0]] = torch.randint(0, 256, (n, dims[0]), device=dev, generator=g).float()
         rows[:, dims[0]] = torch.randint(0, ACT, (n,), device=dev, generator=g).float()
@@ -602,22 +608,28 @@ def config5_secondary(dev, ring=200_000, B=512, T=50, steps=20):
         rows[:, dims[0] + 4] = ((torch.arange(n, device=dev) + done) % 1000).float()
         r.add_rows(rows)
         done += n
-    cfg = make_config(0, ACT, T, B, discrete=True, n_critics=5, n_quantiles=2, img=IMG, conv=((32, 8, 4), (64, 4, 2), (64, 3, 1)))
+    del rows
+    cfg = make_config(0, ACT, T, B, discrete=True, n_critics=5, n_quantiles=2, img=IMG, conv=((32, 8, 4), (64, 4, 2), (64, 3, 1)),
+                      obs_2d_u8=True)
     agent = NativeAgent(cfg, dev)
     agent.init_weights(0)
-    outs = [torch.empty((T, B) + (IMG if k == "obs_2d" else (1,)), device=dev) for k in keys]
-    xp = dict(zip(keys, outs))
-    flat = [o.view(T, B, -1) for o in outs]
+    in_place = agent.conv_reads_ring()
+    outs = [None if (k == "obs_2d" and in_place) else torch.empty((T, B, d), device=dev) for k, d in zip(keys, dims)]
+    starts = torch.empty(B, dtype=torch.int64, device=dev)
+    slots = torch.empty((T, B), dtype=torch.int32, device=dev)
+    xp = {k: o for k, o in zip(keys, outs) if o is not None}
+    xp["obs_2d"], xp["obs_2d_slots"] = r.key_block_u8(0), slots
 
     def step(i):
-        r.sample_windows(T, B, seed=7, counter=i, outs=flat)
+        r.sample_windows(T, B, seed=7, counter=i, outs=outs, select={0: None}, starts_out=starts)
+        r.window_slots(T, B, starts, out=slots)
         agent.update(xp, seed=7)
 
     for i in range(2):
         step(i)
     torch.cuda.synchronize(dev)
     dts = []
-    for wnd in range(3):                      # median of three windows (>= 2 s in all)
+    for wnd in range(3):                      # median of three windows
         t0 = time.perf_counter()
         for i in range(steps):
             step(10 + wnd * steps + i)
@@ -625,13 +637,18 @@ def config5_secondary(dev, ring=200_000, B=512, T=50, steps=20):
         dts.append((time.perf_counter() - t0) / steps)
     dt = sorted(dts)[1]
     fl = agent.stats()["gemm_flops"]
+    prof = agent.profile_update(xp, seed=7)
+    conv = [(n, ms, f) for n, ms, f, _ in prof if n.startswith("conv:")]
     out = {"workload": f"BASELINE config 5: discrete SAC (6 actions), 4x84x84 uint8 frame stacks, conv 32x8/4-64x4/2-64x3/1, "
-                       f"B={B} x T={T}, {ring}-frame uint8 ring (conv encoder: no reference exists, throughput only)",
+                       f"B={B} x T={T}, {ring}-frame uint8 ring, frames read from the ring in place by the first conv layer "
+                       f"(conv encoder: no reference exists, throughput only)",
            "value": round(1 / dt, 2), "unit": "steps/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
            "windows": [round(1 / d, 2) for d in dts],
            "frames_per_s": round(T * B / dt, 0), "all_mfma_kernels_tflops_over_step": round(fl / dt / 1e12, 1),
-           "workspace_GiB": round(agent.workspace.numel() / 2 ** 30, 1)}
-    del agent, r, outs, xp, flat
+           "workspace_GiB": round(agent.workspace.numel() / 2 ** 30, 1), "ring_GiB": round(ring * dims[0] / 2 ** 30, 1),
+           "plans_built": agent.stats()["plans_built"],
+           "conv_kernels": {n[5:]: {"ms": round(ms, 3), "tflops": round(f / ms / 1e9, 1) if ms else 0.0} for n, ms, f in conv}}
+    del agent, r, outs, xp
     torch.cuda.empty_cache()
     return out
 

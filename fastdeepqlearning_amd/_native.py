@@ -46,7 +46,8 @@ class AgentConfig(C.Structure):
         ("conv_out", C.c_int32 * MAX_CONV), ("conv_k", C.c_int32 * MAX_CONV), ("conv_s", C.c_int32 * MAX_CONV),
         ("joiner_gru", C.c_int32), ("gru_state_mode", C.c_int32),
         ("distributional", C.c_int32), ("use_lowerbound", C.c_int32), ("use_max_entropy", C.c_int32),
-        ("hard_updates", C.c_int32), ("keep_frozen_copy", C.c_int32), ("bootstrap_nstep", C.c_int32), ("burn_in_steps", C.c_int32),
+        ("hard_updates", C.c_int32), ("keep_frozen_copy", C.c_int32), ("bootstrap_nstep", C.c_int32), ("obs_2d_u8", C.c_int32),
+        ("burn_in_steps", C.c_int32),
         ("T", C.c_int32), ("B", C.c_int32), ("world_size", C.c_int32),
         ("gamma", C.c_double), ("tau", C.c_double), ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double),
         ("adam_eps", C.c_double), ("init_log_alpha", C.c_double), ("drop_frac", C.c_double),
@@ -55,7 +56,7 @@ class AgentConfig(C.Structure):
 
 class Batch(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("obs_1d", "achieved_goal", "desired_goal", "action", "reward", "mc_return",
-                                          "task_done", "episode_step", "obs_2d", "agent_state")]
+                                          "task_done", "episode_step", "obs_2d", "obs_2d_u8", "obs_2d_slots", "agent_state")]
 
 
 class AgentStats(C.Structure):
@@ -98,6 +99,9 @@ SIGNATURES = {
     "fdql_ring_top": (_i64, [_vp]),
     "fdql_ring_row_floats": (_i64, [_vp]),
     "fdql_ring_key_ptr": (C.c_int, [_vp, _i32, C.POINTER(_vp)]),
+    "fdql_ring_key_ptr_u8": (C.c_int, [_vp, _i32, C.POINTER(_vp)]),
+    "fdql_ring_window_slots": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
+    "fdql_ring_external_read": (C.c_int, [_vp, _i32, _vp]),
     "fdql_ring_sample_windows": (C.c_int, [_vp, _i32, _i32, _vp, _u64, _u64, C.POINTER(_vp), _vp, _vp]),
     "fdql_ring_sample_windows_sel": (C.c_int, [_vp, _i32, _i32, _vp, _u64, _u64, C.POINTER(_vp), C.POINTER(_i32),
                                                C.POINTER(_i32), _vp, _vp]),
@@ -114,6 +118,7 @@ SIGNATURES = {
     "fdql_agent_arena_floats": (_i64, [_vp, _i32]),
     "fdql_agent_tensor_info": (_i32, [_vp, _i32, C.c_char_p, _i32, C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i32)]),
     "fdql_agent_workspace_bytes": (_i64, [_vp]),
+    "fdql_agent_conv_reads_ring": (_i32, [_vp]),
     "fdql_agent_bind": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64]),
     "fdql_agent_update": (C.c_int, [_vp, C.POINTER(Batch), _vp, _vp, _u64, _i32, _vp]),
     "fdql_agent_grad_bucket": (C.c_int, [_vp, C.POINTER(_i64)]),
@@ -133,8 +138,7 @@ SIGNATURES = {
                                  _i32, _vp]),
     "fdql_debug_rowgemm_life": (C.c_int, [_vp, _i32]),
     "fdql_debug_side_copy": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
-    "fdql_test_conv": (C.c_int, [_i32, _vp, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32,
-                                 _i32, _vp]),
+    "fdql_test_conv": (C.c_int, [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "fdql_test_wgrad_stat": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _vp]),
     "fdql_test_wgrad_stat_riders": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _vp, _i32, _i32, _vp, _i32, _i32,
                                               _vp, _i32, _i32, _vp, _i32, _vp]),

@@ -13,6 +13,18 @@ import torch
 from . import _native as N
 
 
+def _device_view_u8(ptr, nbytes, device, owner):
+    """A torch uint8 tensor over device memory owned by `owner` (kept alive through the tensor's attribute)."""
+    class _Arr:      # __cuda_array_interface__: torch builds a non-owning view
+        pass
+    a = _Arr()
+    a.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 3, "strides": None}
+    with torch.cuda.device(device):
+        t = torch.as_tensor(a, device=device)
+    t._fdql_owner = owner
+    return t
+
+
 class NativeRing:
     """SoA replay ring in HBM (include/fdql.h `fdql_ring_*`;
     reference franQ/Replay/replay_memory.py:18-73)."""
@@ -93,12 +105,14 @@ class NativeRing:
         arr = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
         return outs, arr
 
-    def sample_windows(self, T, B, starts=None, seed=0, counter=0, outs=None, return_starts=False, select=None):
+    def sample_windows(self, T, B, starts=None, seed=0, counter=0, outs=None, return_starts=False, select=None, starts_out=None):
         """[T, B, dim_k] per key.  starts: optional int64 device tensor [B].
         select: optional {key_index: None (skip the key) | (offset, dim) (gather a sub-row)} — the read side
-        of HER-vmap; returns a list with None for skipped keys."""
+        of HER-vmap, and how a key that is read in place (window_slots) is left out; returns a list with None for skipped keys.
+        outs: optional persistent output tensors (with select: one per key, None for skipped keys); starts_out: optional
+        persistent int64 [B] tensor that receives the window starts (implies return_starts)."""
         if select is not None:
-            return self._sample_windows_sel(T, B, starts, seed, counter, select, return_starts)
+            return self._sample_windows_sel(T, B, starts, seed, counter, select, return_starts, outs, starts_out)
         if outs is None:
             outs, arr = self._outs((T, B))
         else:
@@ -107,14 +121,14 @@ class NativeRing:
         if starts is not None:
             starts = torch.as_tensor(starts, dtype=torch.int64, device=self.device).contiguous()
             sp = C.c_void_p(starts.data_ptr())
-        so = torch.empty(B, dtype=torch.int64, device=self.device) if return_starts else None
+        so = starts_out if starts_out is not None else (torch.empty(B, dtype=torch.int64, device=self.device) if return_starts else None)
         with torch.cuda.device(self.device):
             N.check(self.lib.fdql_ring_sample_windows(self.handle, T, B, sp, seed, counter, arr,
                                                       C.c_void_p(so.data_ptr()) if so is not None else None,
                                                       N.current_stream(self.device)))
-        return (outs, so) if return_starts else outs
+        return (outs, so) if (return_starts or starts_out is not None) else outs
 
-    def _sample_windows_sel(self, T, B, starts, seed, counter, select, return_starts):
+    def _sample_windows_sel(self, T, B, starts, seed, counter, select, return_starts, given=None, starts_out=None):
         nk = len(self.dims)
         outs, ptrs = [], (C.c_void_p * nk)()
         off, dim = (C.c_int32 * nk)(), (C.c_int32 * nk)()
@@ -130,19 +144,42 @@ class NativeRing:
             else:
                 off[k], dim[k] = int(sel[0]), int(sel[1])
                 d = int(sel[1])
-            t = torch.empty((T, B, d), dtype=torch.float32, device=self.device)
+            t = given[k] if given is not None and given[k] is not None else torch.empty((T, B, d), dtype=torch.float32, device=self.device)
+            assert t.numel() == T * B * d and t.dtype == torch.float32 and t.is_contiguous()
             outs.append(t)
             ptrs[k] = t.data_ptr()
         sp = None
         if starts is not None:
             starts = torch.as_tensor(starts, dtype=torch.int64, device=self.device).contiguous()
             sp = C.c_void_p(starts.data_ptr())
-        so = torch.empty(B, dtype=torch.int64, device=self.device) if return_starts else None
+        so = starts_out if starts_out is not None else (torch.empty(B, dtype=torch.int64, device=self.device) if return_starts else None)
         with torch.cuda.device(self.device):
             N.check(self.lib.fdql_ring_sample_windows_sel(self.handle, T, B, sp, seed, counter, ptrs, off, dim,
                                                           C.c_void_p(so.data_ptr()) if so is not None else None,
                                                           N.current_stream(self.device)))
-        return (outs, so) if return_starts else outs
+        return (outs, so) if (return_starts or starts_out is not None) else outs
+
+    def key_block_u8(self, key):
+        """Zero-copy uint8 view [maxlen, dims[key]] of a uint8 key's block in the ring (fdql_ring_key_ptr_u8): what a consumer that
+        reads the ring in place is handed (the pixel encoder's first layer, fdql_batch_t.obs_2d_u8 + obs_2d_slots)."""
+        p = C.c_void_p()
+        N.check(self.lib.fdql_ring_key_ptr_u8(self.handle, int(key), C.byref(p)))
+        return _device_view_u8(p.value, self.maxlen * self.dims[key], self.device, self).view(self.maxlen, self.dims[key])
+
+    def window_slots(self, T, B, starts, out=None):
+        """int32 [T, B] slot of every row of the windows that begin at `starts` (int64 device tensor [B]): (start[b] + t) % len."""
+        starts = torch.as_tensor(starts, dtype=torch.int64, device=self.device).contiguous()
+        if out is None:
+            out = torch.empty((T, B), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            N.check(self.lib.fdql_ring_window_slots(self.handle, T, B, C.c_void_p(starts.data_ptr()), C.c_void_p(out.data_ptr()),
+                                                    N.current_stream(self.device)))
+        return out
+
+    def external_read(self, begin):
+        """Bracket around a kernel that reads the ring's blocks in place on the current stream (fdql_ring_external_read)."""
+        with torch.cuda.device(self.device):
+            N.check(self.lib.fdql_ring_external_read(self.handle, 1 if begin else 0, N.current_stream(self.device)))
 
     def gather_rows(self, idx):
         """ring[k][idx] for explicit slot indices in [0, maxlen) (reference __getitem__, replay_memory.py:67-70)."""
@@ -171,7 +208,7 @@ def make_config(obs_dim, act_dim, T, B, goal_dim=0, discrete=False, n_critics=2,
                 distributional=True, use_lowerbound=True, use_max_entropy=True, hard_updates=False,
                 keep_frozen_copy=True, world_size=1, gamma=0.99, tau=5e-2, lr=3e-4, beta1=0.9, beta2=0.999,
                 adam_eps=1e-8, init_log_alpha=-2.0, drop_frac=0.2, bootstrap_nstep=False, burn_in_steps=0, joiner_gru=False,
-                gru_state_mode=0, img=(), conv=()):
+                gru_state_mode=0, img=(), conv=(), obs_2d_u8=False):
     c = N.AgentConfig()
     c.obs_dim, c.goal_dim, c.act_dim, c.discrete = obs_dim, goal_dim, act_dim, int(discrete)
     c.n_critics, c.n_quantiles, c.latent, c.enc_features = n_critics, n_quantiles, latent, enc_features
@@ -188,6 +225,7 @@ def make_config(obs_dim, act_dim, T, B, goal_dim=0, discrete=False, n_critics=2,
     c.hard_updates, c.keep_frozen_copy = int(hard_updates), int(keep_frozen_copy)
     c.bootstrap_nstep = int(bootstrap_nstep)
     c.burn_in_steps = int(burn_in_steps)
+    c.obs_2d_u8 = int(bool(obs_2d_u8) and bool(img))
     if img:      # pixel encoder (a design of this build: the reference has none)
         c.img_c, c.img_h, c.img_w = (int(v) for v in img)
         if not 1 <= len(conv) <= N.MAX_CONV:
@@ -261,16 +299,33 @@ class NativeAgent:
 
     # ------------------------------------------------------------------ update
     def _batch(self, xp):
+        """fdql_batch_t from a dict of device tensors.  Pixel agents created with ``obs_2d_u8``: ``xp["obs_2d"]`` is a uint8
+        tensor - the [T, B, c, h, w] frames, or (with ``xp["obs_2d_slots"]``, int32 [T, B]) the ring's own block of the key."""
         b = N.Batch()
         keep = []
         for k in BATCH_KEYS:
             t = xp.get(k)
-            if t is not None:
-                assert t.is_cuda and t.dtype == torch.float32, f"batch[{k}] must be a float32 device tensor"
-                t = t.contiguous()
+            if t is None:
+                continue
+            if k == "obs_2d" and t.dtype == torch.uint8:
+                assert t.is_cuda and t.is_contiguous(), "batch[obs_2d] (uint8) must be a contiguous device tensor"
                 keep.append(t)
-                setattr(b, k, t.data_ptr())
+                b.obs_2d_u8 = t.data_ptr()
+                sl = xp.get("obs_2d_slots")
+                if sl is not None:
+                    assert sl.is_cuda and sl.dtype == torch.int32 and sl.is_contiguous(), "batch[obs_2d_slots] must be an int32 device tensor"
+                    keep.append(sl)
+                    b.obs_2d_slots = sl.data_ptr()
+                continue
+            assert t.is_cuda and t.dtype == torch.float32, f"batch[{k}] must be a float32 device tensor"
+            t = t.contiguous()
+            keep.append(t)
+            setattr(b, k, t.data_ptr())
         return b, keep
+
+    def conv_reads_ring(self):
+        """True when the first conv layer may read the ring's uint8 block in place (batch key ``obs_2d_slots``)."""
+        return bool(self.lib.fdql_agent_conv_reads_ring(self.handle))
 
     def update(self, xp, noise_target=None, noise_actor=None, seed=0, phase=N.PHASE_ALL):
         """One train_step (deepQlearning.py:105-127) on the current torch stream; asynchronous."""

@@ -144,6 +144,7 @@ struct Stage {
   int phase = FDQL_PHASE_GRAD;
   int gpart = 1;  // FDQL_PHASE_GRAD stages of a bucketed plan: 0 = up to the critics' gradients (FDQL_PHASE_GRAD_CRITICS), 1 = the rest
   int when = 0;   // 0: whenever its phase runs; 1: only in a split (GRAD / APPLY) call; 2: only in a FDQL_PHASE_ALL call
+  bool mfma = false;  // ST_FUNC: an MFMA kernel of its own (the implicit-GEMM convolutions): its flops count as GEMM flops
   bool off = false;   // decided with the kernels (upload_tables): the stage has nothing left to do in this plan
   // head fusion (critics): 1 = a hidden layer's launch that leaves head partial sums, 2 = their plane sum, 3 = the head's finish.
   // When every layer runs weight-stationary, the kernels sum a tile's planes themselves (WsArgs::hf_presum): stage 2 is switched
@@ -186,7 +187,9 @@ struct fdql_agent {
   std::vector<MlpDesc> critic;
   int64_t log_alpha_off = 0;
   // pixel encoder (cfg.img_c > 0): geometry and arena offsets of each conv layer; conv_feat = flattened output width
-  struct ConvLayer { ConvGeom g; int cout; int64_t w_off, b_off; };
+  // fast_*: the layer's forward / data gradient / weight gradient run on the implicit-GEMM kernels (conv.h), decided at create
+  // from the geometry (the workspace has no column matrix for them); else im2col + grouped GEMM + col2im
+  struct ConvLayer { ConvGeom g; int cout; int64_t w_off, b_off; bool fast_fwd = false, fast_dgrad = false, fast_wgrad = false; };
   std::vector<ConvLayer> conv;
   int conv_feat = 0;
   int hf_planes = 0;   // partial-sum planes per critic instance (head fusion)
@@ -321,6 +324,12 @@ int layout(fdql_agent *a) {
       L.w_off = top; top += pad4((int64_t)L.cout * K);
       a->tensors.push_back({pre + ".bias", 0, top, L.cout, 0});
       L.b_off = top; top += pad4(L.cout);
+      const bool u8_in = i == 0 && c.obs_2d_u8;
+      if (i > 0 || u8_in) {   // (a float32 NCHW first layer has no implicit-GEMM kernel)
+        L.fast_fwd = conv_fwd_takes(L.g, L.cout, u8_in);
+        L.fast_wgrad = conv_wgrad_takes(L.g, L.cout, u8_in) && L.b_off == L.w_off + (int64_t)L.cout * K;
+        L.fast_dgrad = i > 0 && conv_dgrad_takes(L.g, L.cout);
+      }
       a->conv.push_back(L);
       ci = L.cout; h = L.g.OH; w = L.g.OW;
     }
@@ -411,14 +420,18 @@ void carve(fdql_agent *a) {
     const fdql_agent::ConvLayer &L = a->conv[i];
     const int64_t pos = (int64_t)L.g.OH * L.g.OW, K = (int64_t)L.g.C * L.g.k * L.g.k;
     const std::string p = "conv" + std::to_string(i);
-    a->alloc(p + ".col", N * pos * K);
+    if (!L.fast_fwd || !L.fast_wgrad) a->alloc(p + ".col", N * pos * K);   // (the implicit-GEMM kernels have no column matrix)
     a->alloc(p + ".out", N * pos * L.cout);
     a->alloc(p + ".dpre", M * pos * L.cout);
-    if (i > 0) a->alloc(p + ".dcol", M * pos * K);
-    // weight gradient: K-split of its own over the M*pos rows (far more rows than the slab count serves), then a
-    // reduction of the partials into slab 0; bias gradient: two-level column sum
-    a->alloc(p + ".wpart", (int64_t)conv_wsplit(M * pos) * L.cout * K);
-    a->alloc(p + ".bpart", (int64_t)(colsum_tall_blocks(M * pos) + colsum_tall_blocks(colsum_tall_blocks(M * pos))) * L.cout);
+    if (i > 0 && !L.fast_dgrad) a->alloc(p + ".dcol", M * pos * K);
+    if (L.fast_wgrad) {   // one (dW, db) partial per slab of the output-stationary launch, then one reduction into slab 0
+      a->alloc(p + ".wpart", (int64_t)conv_wgrad_slabs(L.g, L.cout, i == 0, M) * ((int64_t)L.cout * K + L.cout));
+    } else {
+      // weight gradient: K-split of its own over the M*pos rows (far more rows than the slab count serves), then a
+      // reduction of the partials into slab 0; bias gradient: two-level column sum
+      a->alloc(p + ".wpart", (int64_t)conv_wsplit(M * pos) * L.cout * K);
+      a->alloc(p + ".bpart", (int64_t)(colsum_tall_blocks(M * pos) + colsum_tall_blocks(colsum_tall_blocks(M * pos))) * L.cout);
+    }
   }
   mlp_bufs("enc_obs", a->enc_obs, N, true, true);
   if (c.joiner_gru) {
@@ -1319,7 +1332,20 @@ int build_plan(fdql_agent *a) {
     const int K = g.C * g.k * g.k;
     const long long rows = (long long)N * g.OH * g.OW;
     FDQL_REQUIRE(rows < (1LL << 31), "conv layer %d: %lld im2col rows exceed the GEMM's 32-bit row index", i, rows);
-    float *col = a->buf("conv" + std::to_string(i) + ".col"), *out = a->buf("conv" + std::to_string(i) + ".out");
+    float *out = a->buf("conv" + std::to_string(i) + ".out");
+    if (Lc.fast_fwd) {   // implicit GEMM (conv.hip): the image groups resident in LDS, no column matrix
+      ConvFwdArgs ca;
+      ca.in.base = i == 0 ? (const void *)x.obs_2d_u8 : (const void *)a->buf("conv" + std::to_string(i - 1) + ".out");
+      ca.in.u8 = i == 0; ca.in.slots = i == 0 ? x.obs_2d_slots : nullptr;
+      ca.W = params + Lc.w_off; ca.bias = params + Lc.b_off; ca.out = out; ca.nimg = N; ca.g = g; ca.cout = Lc.cout;
+      Stage &cs = b.func_stage("conv.fwd" + std::to_string(i), [=](hipStream_t s) { return conv_fwd_launch(ca, s); });
+      cs.mfma = true;
+      cs.flops = 2.0 * (double)rows * K * Lc.cout;
+      cs.bytes = (i == 0 ? 1.0 : 4.0) * (double)N * g.C * g.H * g.W + 4.0 * (double)rows * Lc.cout;
+      continue;
+    }
+    FDQL_REQUIRE(i > 0 || x.obs_2d, "conv layer 0 runs on the im2col path: it needs the float32 frames (batch.obs_2d)");
+    float *col = a->buf("conv" + std::to_string(i) + ".col");
     const float *in = i == 0 ? x.obs_2d : a->buf("conv" + std::to_string(i - 1) + ".out");
     const int nhwc = i > 0;
     const float scale = i == 0 ? 1.0f / 255.0f : 1.0f;
@@ -1996,6 +2022,17 @@ int build_plan(fdql_agent *a) {
       const ConvGeom g = Lc.g;
       const int K = g.C * g.k * g.k;
       const long long rows = (long long)M * g.OH * g.OW;
+      if (Lc.fast_dgrad) {   // gather-form implicit GEMM: no d col matrix, no col2im
+        ConvDgradArgs da;
+        da.dpre = a->buf("conv" + std::to_string(i) + ".dpre"); da.W = params + Lc.w_off;
+        da.act_prev = a->buf("conv" + std::to_string(i - 1) + ".out"); da.dprev = a->buf("conv" + std::to_string(i - 1) + ".dpre");
+        da.nimg = M; da.g = g; da.cout = Lc.cout;
+        Stage &ds = b.func_stage("conv.dgrad" + std::to_string(i), [=](hipStream_t s) { return conv_dgrad_launch(da, s); });
+        ds.mfma = true;
+        ds.flops = 2.0 * (double)rows * K * Lc.cout;
+        ds.bytes = 4.0 * ((double)rows * Lc.cout + 2.0 * (double)M * g.C * g.H * g.W);
+        continue;
+      }
       float *dcol = a->buf("conv" + std::to_string(i) + ".dcol");
       Stage &gs = b.gemm_stage("conv.dcol" + std::to_string(i));
       GemmProblem p = Builder::new_gemm((int)rows, K, dcol, K);
@@ -2037,6 +2074,23 @@ int build_plan(fdql_agent *a) {
       const int R = (int)((long long)M * Lc.g.OH * Lc.g.OW);
       float *slab = a->buf("slabs");
       const float *dpre = a->buf("conv" + std::to_string(i) + ".dpre");
+      if (Lc.fast_wgrad) {   // output-stationary implicit GEMM: (dW, db) partials per slab, one reduction into slab 0
+        ConvWgradArgs wa;
+        wa.in.base = i == 0 ? (const void *)x.obs_2d_u8 : (const void *)a->buf("conv" + std::to_string(i - 1) + ".out");
+        wa.in.u8 = i == 0; wa.in.slots = i == 0 ? x.obs_2d_slots : nullptr;
+        wa.dpre = dpre; wa.wpart = a->buf("conv" + std::to_string(i) + ".wpart"); wa.nimg = M; wa.g = Lc.g; wa.cout = Lc.cout;
+        const int nslab = conv_wgrad_slabs(Lc.g, Lc.cout, i == 0, M);
+        const long long nw = (long long)Lc.cout * K + Lc.cout;
+        FDQL_REQUIRE(nslab > 0 && a->named.at("conv" + std::to_string(i) + ".wpart").second >= nslab * nw, "conv layer %d: weight-gradient slabs", i);
+        Stage &wst = b.func_stage("conv.wgrad" + std::to_string(i), [=](hipStream_t s) { return conv_wgrad_launch(wa, s); });
+        wst.mfma = true;
+        wst.flops = 2.0 * (double)R * K * Lc.cout;
+        wst.bytes = (i == 0 ? 1.0 : 4.0) * (double)M * Lc.g.C * Lc.g.H * Lc.g.W + 4.0 * (double)R * Lc.cout;
+        const float *wpart = wa.wpart;
+        float *wdst = slab + Lc.w_off;   // (the bias follows its weights in the arena: checked in layout)
+        conv_post.push_back([=](hipStream_t s) { return reduce_partials_launch(wpart, nslab, nw, wdst, s); });
+        continue;
+      }
       float *wpart = a->buf("conv" + std::to_string(i) + ".wpart"), *bpart = a->buf("conv" + std::to_string(i) + ".bpart");
       const int S2 = conv_wsplit(R);
       {
@@ -2161,7 +2215,10 @@ int prepare_update(fdql_agent *a, const fdql_batch_t *batch, const float *noise_
   FDQL_REQUIRE(batch && batch->action && batch->reward && batch->task_done && batch->episode_step,
                "fdql_agent_update: batch needs action, reward, task_done, episode_step");
   FDQL_REQUIRE(!a->cfg.obs_dim || batch->obs_1d, "obs_dim > 0 needs obs_1d");
-  FDQL_REQUIRE(!a->cfg.img_c || batch->obs_2d, "img_c > 0 needs obs_2d");
+  FDQL_REQUIRE(!a->cfg.img_c || (a->cfg.obs_2d_u8 ? batch->obs_2d_u8 != nullptr : batch->obs_2d != nullptr),
+               "img_c > 0 needs the frames: batch.obs_2d (float32), or batch.obs_2d_u8 for an agent created with obs_2d_u8");
+  FDQL_REQUIRE(!batch->obs_2d_slots || (a->cfg.obs_2d_u8 && !a->conv.empty() && a->conv[0].fast_fwd && a->conv[0].fast_wgrad),
+               "batch.obs_2d_slots (frames read from the ring in place) needs fdql_agent_conv_reads_ring()");
   FDQL_REQUIRE(!a->cfg.goal_dim || (batch->achieved_goal && batch->desired_goal), "goal_dim > 0 needs achieved/desired goal");
   FDQL_REQUIRE(!a->cfg.use_lowerbound || batch->mc_return, "use_lowerbound needs mc_return");
   FDQL_REQUIRE(!(a->cfg.joiner_gru && a->cfg.gru_state_mode == 1) || batch->agent_state,
@@ -2288,6 +2345,12 @@ int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {
   int s = a->M / 384;
   a->nsplit = s < 1 ? 1 : (s > 32 ? 32 : s);
   layout(a);
+  if (c.obs_2d_u8 && (a->conv.empty() || !(a->conv[0].fast_fwd && a->conv[0].fast_wgrad))) {
+    delete a;
+    set_error("obs_2d_u8: the first conv layer must be one the implicit-GEMM kernels take (csrc/conv.hip: 32 x 8 / 4 on 4 x 84 x 84 "
+              "frame stacks); other stacks take float32 frames (batch.obs_2d)");
+    return FDQL_EINVAL;
+  }
   {
     // With the dense 256 x 256 blocks on the output-stationary kernel (wgrad.h: one slab per workgroup of a block, ncu /
     // blocks of them - 16 to 18 at config 2) and the narrow ones on single-wave streaming workgroups (k_stream_wgrad), slabs
@@ -2459,6 +2522,10 @@ int fdql_agent_update(fdql_agent_t *a, const fdql_batch_t *batch, const float *n
   return 0;
 }
 
+int32_t fdql_agent_conv_reads_ring(const fdql_agent_t *a) {
+  return a && a->cfg.obs_2d_u8 && !a->conv.empty() && a->conv[0].fast_fwd && a->conv[0].fast_wgrad ? 1 : 0;
+}
+
 int fdql_agent_grad_bucket(fdql_agent_t *a, int64_t *first_early_float) {
   FDQL_REQUIRE(a && first_early_float, "null argument");
   std::lock_guard<std::mutex> lk(a->mu);
@@ -2549,7 +2616,8 @@ int32_t fdql_agent_profile_update(fdql_agent_t *a, const fdql_batch_t *batch, co
       }
     } else {
       snprintf(out[cnt].name, sizeof(out[cnt].name), "%s%s",
-               st.kind == ST_SKINNY_WGRAD ? (st.stream ? "nwgrad:" : "colsum:") : (st.kind == ST_CHAIN ? "chain:" : (st.kind == ST_WGRAD_STAT ? "wgstat:" : "k:")),
+               st.kind == ST_SKINNY_WGRAD ? (st.stream ? "nwgrad:" : "colsum:")
+                                          : (st.kind == ST_CHAIN ? "chain:" : (st.kind == ST_WGRAD_STAT ? "wgstat:" : (st.mfma ? "conv:" : "k:"))),
                st.name.c_str());
     }
     out[cnt].ms = ms;
@@ -2870,7 +2938,7 @@ int fdql_agent_stats(const fdql_agent_t *a, fdql_agent_stats_t *out) {
       out->n_gemm_launches += (int)s.rows.size();
     }
     if (s.kind == ST_SKINNY_WGRAD) out->skinny_flops += s.flops;
-    if (s.kind == ST_CHAIN || s.kind == ST_WGRAD_STAT) { out->gemm_flops += s.flops; out->n_gemm_launches++; }
+    if (s.kind == ST_CHAIN || s.kind == ST_WGRAD_STAT || (s.kind == ST_FUNC && s.mfma)) { out->gemm_flops += s.flops; out->n_gemm_launches++; }
   }
   return 0;
 }
@@ -2952,7 +3020,7 @@ int fdql_test_gemm(const float *A, int32_t lda, int32_t a_kc, const float *B, in
 /* Test hook for the output-stationary weight-gradient kernel (wgrad.hip): nprob blocks dW[i] [256, ldw] (slab 0 at dW + i *
  * 256 * ldw, slabs slab_stride floats apart, nslab of them) = G[i]^T X[i] over M rows each (G, X: [nprob * M, 256]).  Every
  * slab of every block is written (partials or zeros): their sum is the gradient.  FDQL_EINVAL: the kernel does not take the form. */
-int fdql_test_conv(int32_t mode, const void *in, int32_t u8, const int64_t *starts, int64_t ring_len, int32_t B,
+int fdql_test_conv(int32_t mode, const void *in, int32_t u8, const int32_t *slots,
                    const float *W, const float *bias, const float *dpre, const float *act_prev, float *out, float *scratch,
                    int64_t scratch_floats, int64_t nimg, int32_t C, int32_t H, int32_t Wd, int32_t k, int32_t s, int32_t cout,
                    void *stream) {
@@ -2961,7 +3029,7 @@ int fdql_test_conv(int32_t mode, const void *in, int32_t u8, const int64_t *star
   FDQL_REQUIRE(k > 0 && s > 0 && H >= k && Wd >= k && nimg > 0, "fdql_test_conv: bad geometry");
   g.OH = (H - k) / s + 1; g.OW = (Wd - k) / s + 1;
   ConvSrc src;
-  src.base = in; src.u8 = u8; src.starts = (const long long *)starts; src.ring_len = ring_len; src.B = B;
+  src.base = in; src.u8 = u8; src.slots = slots;
   hipStream_t st = (hipStream_t)stream;
   if (mode == 0) {
     FDQL_REQUIRE(conv_fwd_takes(g, cout, u8 != 0), "fdql_test_conv: no forward kernel for this layer");

@@ -10,7 +10,7 @@
 //   data grad    dprev[img, y, x, :] = LeakyReLU'(act_prev) * sum over the taps covering (y, x)       a gather: no col2im
 //   weight grad  dW[co, k] = sum over (img, oy, ox) of dpre[.., co] * patch[.., k], db = column sums  partial slabs + reduction
 // The FIRST layer reads uint8 NCHW frames as the ring stores them - a [T, B, c, h, w] uint8 batch or the ring's own block through
-// the window starts (slot of image (t, b) = (starts[b] + t) % ring_len) - and widens them in registers (K ordered (c, ky, kx));
+// a slot index per image (fdql_ring_window_slots) - and widens them in registers (K ordered (c, ky, kx));
 // later layers read the previous layer's NHWC float32 output (K ordered (ky, kx, c)).  The weights [Cout, K] use the same order.
 #pragma once
 #include "common.h"
@@ -21,10 +21,8 @@ namespace fdql {
 struct ConvSrc {
   const void *base;          // float32 NHWC maps [nimg][H][W][C], or uint8 NCHW frames (u8 = 1)
   int u8;
-  const long long *starts;   // u8 only.  null: frames [nimg][C*H*W] back to back.  Else `base` is a ring block [slots][C*H*W] and
-  long long ring_len;        //   image i = (t, b) = (i / B, i % B) lives in slot (starts[b] + t) % ring_len
-  int B;
-};
+  const int *slots;          // u8 only.  null: frames [nimg][C*H*W] back to back.  Else `base` is a ring block [slots][C*H*W] and
+};                           //   image i lives in slot slots[i] (fdql_ring_window_slots: (start[b] + t) % len for i = t B + b)
 
 struct ConvFwdArgs {
   ConvSrc in;

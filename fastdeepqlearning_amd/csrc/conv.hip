@@ -35,9 +35,7 @@ __device__ __forceinline__ float lrelu(float v) { return fmaxf(v, 0.01f * v); }
 
 // first byte of image i of a source (uniform: i and the source are)
 __device__ __forceinline__ const char *image_ptr(const ConvSrc &s, long long i, long long imgbytes) {
-  if (!s.starts) return (const char *)s.base + i * imgbytes;
-  const long long t = i / s.B, b = i - t * s.B;
-  return (const char *)s.base + ((s.starts[b] + t) % s.ring_len) * imgbytes;
+  return (const char *)s.base + (s.slots ? (long long)s.slots[i] : i) * imgbytes;
 }
 
 // `bytes` (a multiple of 16) global -> LDS by LDS-DMA: 1 KiB per wave instruction, chunk c by wave (first + c) % NW.

@@ -345,6 +345,16 @@ __global__ void k_mc_return_vmap(const float *__restrict__ r, const float *__res
 
 using namespace fdql;
 
+// slot of row (t, b) of a windowed sample: (start[b] + t) % len (replay_memory.py:63-65), as int32 [T, B]
+__global__ void k_window_slots(const long long *__restrict__ starts, int T, int B, long long len, int *__restrict__ slots) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)T * B) return;
+  const long long t = i / B, b = i - t * B;
+  long long st = starts[b] % len;
+  if (st < 0) st += len;
+  slots[i] = (int)((st + t) % len);
+}
+
 struct fdql_ring {
   // Every entry point that takes a ring locks `mu`: the Runner's pattern is one writer thread per shard calling add()
   // while the trainer thread samples the same shard (franQ/Replay/async_replay_memory.py:55-70, runner.py:177-191);
@@ -801,6 +811,37 @@ int fdql_ring_key_ptr(fdql_ring_t *r, int32_t key, float **dev_ptr) {
   FDQL_REQUIRE(!r->u8[key], "key %d is stored as uint8", key);
   *dev_ptr = r->data[key];
   return 0;
+}
+
+int fdql_ring_key_ptr_u8(fdql_ring_t *r, int32_t key, uint8_t **dev_ptr) {
+  FDQL_REQUIRE(r && dev_ptr && key >= 0 && key < r->nkeys, "bad key");
+  FDQL_REQUIRE(r->u8[key], "key %d is stored as float32", key);
+  *dev_ptr = reinterpret_cast<uint8_t *>(r->data[key]);
+  return 0;
+}
+
+int fdql_ring_window_slots(fdql_ring_t *r, int32_t T, int32_t B, const int64_t *starts_dev, int32_t *slots_out_dev, void *stream) {
+  FDQL_REQUIRE(r && starts_dev && slots_out_dev && T >= 1 && B >= 1, "bad arguments");
+  Lock lk(r->mu);
+  FDQL_REQUIRE(r->len >= 1 && r->maxlen < (1LL << 31), "empty ring, or more slots than an int32 index holds");
+  hipStream_t s = (hipStream_t)stream;
+  const long long n = (long long)T * B;
+  hipLaunchKernelGGL(k_window_slots, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const long long *>(starts_dev), T, B,
+                     (long long)r->len, slots_out_dev);
+  FDQL_HIP(hipGetLastError());
+  return 0;
+}
+
+int fdql_ring_external_read(fdql_ring_t *r, int32_t begin, void *stream) {
+  FDQL_REQUIRE(r, "null ring");
+  Lock lk(r->mu);
+  hipStream_t s = (hipStream_t)stream;
+  if (begin) {
+    int rc = flush(r, s);   // staged add()s become visible to the reader, like a sample would make them
+    if (rc) return rc;
+    return begin_read(r, s);
+  }
+  return end_read(r, s);
 }
 
 int fdql_ring_sample_windows(fdql_ring_t *r, int32_t T, int32_t B, const int64_t *starts_dev, uint64_t seed,

@@ -93,6 +93,18 @@ int64_t fdql_ring_row_floats(const fdql_ring_t *ring);
 /* Device base pointer of key k ([maxlen, dims[k]] f32) — for tests and bulk fills. */
 int fdql_ring_key_ptr(fdql_ring_t *ring, int32_t key, float **dev_ptr);   /* float32 keys only */
 
+int fdql_ring_key_ptr_u8(fdql_ring_t *ring, int32_t key, uint8_t **dev_ptr); /* uint8 keys only: [maxlen, dims[k]] bytes */
+/* Reading a key's block IN PLACE instead of gathering it (the pixel encoder's first layer reads the uint8 frames of a window
+ * straight from the ring: fdql_batch_t.obs_2d_u8 / obs_2d_slots): slots_out_dev[t*B + b] = (starts_dev[b] + t) % len - the
+ * index matrix of replay_memory.py:63-65 as int32 [T, B] (device) - for the int64 [B] window starts a sample call returned
+ * (starts_out_dev) or the caller supplied. */
+int fdql_ring_window_slots(fdql_ring_t *ring, int32_t T, int32_t B, const int64_t *starts_dev, int32_t *slots_out_dev,
+                           void *stream);
+/* ... and the bracket around such a reader on `stream` (e.g. fdql_agent_update): begin != 0 flushes staged add()s and orders
+ * the reader behind writes issued on other streams; begin == 0, after the reader was enqueued, makes later writes on other
+ * streams wait for it - what a sample call does for its own gather (see "threads" above).  No-ops on one stream. */
+int fdql_ring_external_read(fdql_ring_t *ring, int32_t begin, void *stream);
+
 /* replay_memory.py:54-70 temporal_sample(): out[k] is [T, B, dims[k]] f32 (device, caller
  * owned), out[k][t,b,:] = ring[k][(start[b] + t) % len, :].
  *   starts_dev != NULL : int64 [B] window starts supplied by the caller (parity runs);
@@ -239,6 +251,8 @@ typedef struct {
   int32_t bootstrap_nstep;          /* conf.use_bootstrap_minibatch_nstep (soft_actor_critic.py:102-132,
                                        deepQlearning.py:226-228): window-long n-step lower bound on
                                        q(t=0); needs !distributional && use_lowerbound, as in the reference */
+  int32_t obs_2d_u8;                /* img_c > 0: the batch carries the frames as uint8 (fdql_batch_t.obs_2d_u8), as the ring stores
+                                       them (replay_memory.py:26-35 keeps the source dtype), not widened to float32               */
   int32_t burn_in_steps;            /* EncoderConf.use_burn_in: int(T * burn_in_portion) leading rows of
                                        is_contiguous are zeroed (deepQlearning.py:219-220); 0 = off        */
   /* batch geometry: this rank's [T, B, *] minibatch; loss is normalised by B*world_size    */
@@ -260,6 +274,9 @@ int64_t fdql_agent_arena_floats(const fdql_agent_t *agent, int32_t which);
 int32_t fdql_agent_tensor_info(const fdql_agent_t *agent, int32_t index, char *name, int32_t name_cap,
                                int32_t *arena, int64_t *offset_floats, int32_t *shape2);
 int64_t fdql_agent_workspace_bytes(const fdql_agent_t *agent);
+/* 1 when the pixel encoder's first layer runs on the implicit-GEMM kernel (csrc/conv.hip) and may therefore read the ring's
+ * uint8 block in place (fdql_batch_t.obs_2d_slots); 0: the batch must carry the frames themselves. */
+int32_t fdql_agent_conv_reads_ring(const fdql_agent_t *agent);
 
 /* Bind caller-owned device memory.  `frozen` may be NULL unless keep_frozen_copy.
  * grads/adam_m/adam_v/workspace are zeroed here (synchronises the device once).         */
@@ -272,7 +289,11 @@ int fdql_agent_bind(fdql_agent_t *agent, float *params, float *grads, float *ada
 typedef struct {
   const float *obs_1d, *achieved_goal, *desired_goal, *action;
   const float *reward, *mc_return, *task_done, *episode_step;
-  const float *obs_2d;        /* [T,B,img_c,img_h,img_w] pixel frames as float32 (0..255), iff img_c > 0                        */
+  const float *obs_2d;        /* [T,B,img_c,img_h,img_w] pixel frames as float32 (0..255), iff img_c > 0 && !cfg.obs_2d_u8      */
+  const uint8_t *obs_2d_u8;   /* cfg.obs_2d_u8: the frames as uint8, the ring's storage type: a [T,B,img_c,img_h,img_w] batch
+                                 (obs_2d_slots == NULL) or the ring's own block of the key (fdql_ring_key_ptr_u8) read in place  */
+  const int32_t *obs_2d_slots;/* ... through one slot index per row, int32 [T,B] (fdql_ring_window_slots); needs
+                                 fdql_agent_conv_reads_ring() != 0                                                               */
   const float *agent_state;   /* [T,B,latent]: hidden state the actor had at each step (runner.py:157); read iff
                                  joiner_gru && gru_state_mode == 1, row block t = 0 only (encoder.py:83-84)     */
 } fdql_batch_t;
@@ -417,11 +438,11 @@ int fdql_test_wgrad_stat_riders(const float *G, const float *X, float *dW, int32
  *   mode 0  forward        out[nimg, OH*OW, cout] = LeakyReLU(conv(in, W) + bias)                                  (NHWC)
  *   mode 1  data gradient  out[nimg, H*W, C] = LeakyReLU'(act_prev) * conv^T(dpre, W); `in` unused
  *   mode 2  weight grad.   out[cout*K + cout] = (dW, db) = sum over images and positions; scratch = partial slabs
- * in: u8 != 0: uint8 NCHW frames - [nimg, C*H*W] back to back (starts == NULL) or a ring block [slots, C*H*W] read through
- *     the window starts (image i = (t, b) = (i / B, i % B) is slot (starts[b] + t) % ring_len); W is [cout, K] with K = (c, ky, kx);
+ * in: u8 != 0: uint8 NCHW frames - [nimg, C*H*W] back to back (slots == NULL) or a ring block [*, C*H*W] read through one
+ *     int32 slot index per image (fdql_ring_window_slots); W is [cout, K] with K = (c, ky, kx);
  *     u8 == 0: float32 NHWC maps [nimg, H, W, C]; K = (ky, kx, c).
  * FDQL_EINVAL when the layer geometry has no kernel instantiation.  Asynchronous on `stream`. */
-int fdql_test_conv(int32_t mode, const void *in, int32_t u8, const int64_t *starts, int64_t ring_len, int32_t B,
+int fdql_test_conv(int32_t mode, const void *in, int32_t u8, const int32_t *slots,
                    const float *W, const float *bias, const float *dpre, const float *act_prev, float *out, float *scratch,
                    int64_t scratch_floats, int64_t nimg, int32_t C, int32_t H, int32_t Wd, int32_t k, int32_t s, int32_t cout,
                    void *stream);

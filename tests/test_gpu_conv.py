@@ -37,14 +37,14 @@ def _w_from_nchw(g, L):
     return g.reshape(co, -1) if L["u8"] else g.permute(0, 2, 3, 1).reshape(co, -1)
 
 
-def _call(mode, L, nimg, dev, inp=None, starts=None, ring_len=0, B=1, W=None, bias=None, dpre=None, act_prev=None, out=None):
+def _call(mode, L, nimg, dev, inp=None, slots=None, W=None, bias=None, dpre=None, act_prev=None, out=None):
     from fastdeepqlearning_amd import _native as nat
     lib = nat.load()
     K = L["C"] * L["k"] ** 2
     scratch = torch.empty(4096 * (L["co"] * K + L["co"]), device=dev) if mode == 2 else None
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
     with torch.cuda.device(dev):
-        nat.check(lib.fdql_test_conv(mode, p(inp), int(L["u8"]), p(starts), int(ring_len), int(B), p(W), p(bias), p(dpre), p(act_prev),
+        nat.check(lib.fdql_test_conv(mode, p(inp), int(L["u8"]), p(slots), p(W), p(bias), p(dpre), p(act_prev),
                                      p(out), p(scratch), scratch.numel() if scratch is not None else 0, int(nimg), L["C"], L["H"], L["W"],
                                      L["k"], L["s"], L["co"], nat.current_stream(dev)))
     torch.cuda.synchronize(dev)
@@ -82,8 +82,8 @@ def test_conv_forward(dev, name, L, nimg):
 
 
 def test_conv_forward_reads_the_ring_through_window_starts(dev):
-    """Layer 0 on the ring's own uint8 block: image (t, b) is slot (starts[b] + t) % ring_len (replay_memory.py:63-65), the
-    window of b = 1 wraps past the ring's end."""
+    """Layer 0 on the ring's own uint8 block through one slot index per image: image (t, b) is slot (starts[b] + t) % ring_len
+    (replay_memory.py:63-65; fdql_ring_window_slots computes them on the device), the window of b = 1 wraps past the ring's end."""
     L, T, B, slots = L0, 5, 3, 40
     g = torch.Generator().manual_seed(11)
     ring = torch.randint(0, 256, (slots, L["C"], L["H"], L["W"]), generator=g, dtype=torch.uint8)
@@ -93,7 +93,7 @@ def test_conv_forward_reads_the_ring_through_window_starts(dev):
     idx = (starts[None, :] + torch.arange(T)[:, None]) % ring_len          # [T, B]
     x = ring[idx.reshape(-1)]
     out = torch.full((T * B, 400, L["co"]), float("nan"), device=dev)
-    _call(0, L, T * B, dev, inp=ring.to(dev), starts=starts.to(dev), ring_len=ring_len, B=B, W=W.to(dev), bias=bias.to(dev), out=out)
+    _call(0, L, T * B, dev, inp=ring.to(dev), slots=idx.reshape(-1).to(torch.int32).to(dev), W=W.to(dev), bias=bias.to(dev), out=out)
     y = torch.nn.functional.conv2d(_x_nchw64(x, L), _w_nchw(W, L).double(), bias.double(), stride=L["s"])
     ref = torch.nn.functional.leaky_relu(y, 0.01).permute(0, 2, 3, 1).reshape(T * B, 400, L["co"])
     assert float((out.cpu().double() - ref).abs().max() / ref.abs().max()) < TOL
@@ -149,7 +149,7 @@ def test_conv_weight_gradient_through_window_starts(dev):
     K, nimg = L["C"] * 64, T * B
     dpre = torch.randn(nimg, 400, L["co"], generator=g)
     out = torch.full((L["co"] * K + L["co"],), float("nan"), device=dev)
-    _call(2, L, nimg, dev, inp=ring.to(dev), starts=starts.to(dev), ring_len=ring_len, B=B, dpre=dpre.to(dev), out=out)
+    _call(2, L, nimg, dev, inp=ring.to(dev), slots=idx.reshape(-1).to(torch.int32).to(dev), dpre=dpre.to(dev), out=out)
     w64 = torch.zeros(L["co"], L["C"], 8, 8, dtype=torch.float64, requires_grad=True)
     y = torch.nn.functional.conv2d(_x_nchw64(x, L), w64, stride=L["s"])
     (y * dpre.double().view(nimg, 20, 20, L["co"]).permute(0, 3, 1, 2)).sum().backward()
@@ -162,5 +162,5 @@ def test_conv_rejects_unknown_geometry(dev):
     from fastdeepqlearning_amd import _native as nat
     lib = nat.load()
     x = torch.zeros(2, 12, 12, 8, device=dev)
-    rc = lib.fdql_test_conv(0, C.c_void_p(x.data_ptr()), 0, None, 0, 1, None, None, None, None, None, None, 0, 2, 8, 12, 12, 3, 1, 16, None)
+    rc = lib.fdql_test_conv(0, C.c_void_p(x.data_ptr()), 0, None, None, None, None, None, None, None, 0, 2, 8, 12, 12, 3, 1, 16, None)
     assert rc == nat.FDQL_EINVAL if hasattr(nat, "FDQL_EINVAL") else rc != 0

@@ -488,6 +488,16 @@ def test_update_matches_oracle_config2(dev, T, B, hid):
           enc_features=32, enc_hidden=(48,), joint_hidden=(32,), pi_hidden=(32,), critic_hidden=(32, 32))),
     ("pixel encoder alone (obs_dim 0), Atari stack on 4x84x84, config-5 shapes at a small batch",
      dict(obs=0, act=6, discrete=True, C=2, Q=5, T=2, B=6, img=(4, 84, 84), conv=((32, 8, 4), (64, 4, 2), (64, 3, 1)))),
+    ("pixel encoder alone, Atari stack, the frames as a uint8 batch (agent created with obs_2d_u8): every conv layer on the "
+     "implicit-GEMM kernels (csrc/conv.hip) - forward from the bytes, gather-form data gradients, output-stationary weight gradients",
+     dict(obs=0, act=6, discrete=True, C=2, Q=5, T=2, B=6, img=(4, 84, 84), conv=((32, 8, 4), (64, 4, 2), (64, 3, 1)), frames="u8")),
+    ("the same with the first layer reading the ring's uint8 block in place through one slot index per row (batch.obs_2d_slots), "
+     "obs_1d beside the frames, T=3, B=7 (21 frame stacks: odd image groups in every conv launch)",
+     dict(obs=5, act=6, discrete=True, C=2, Q=5, T=3, B=7, img=(4, 84, 84), conv=((32, 8, 4), (64, 4, 2), (64, 3, 1)), frames="ring")),
+    ("Atari stack as float32 frames (first layer on im2col + GEMM, layers 1-2 on the implicit-GEMM kernels) with the implicit path "
+     "switched off altogether (FDQL_NO_IMPLICIT_CONV: the im2col / col2im path, the checker of the new one)",
+     dict(obs=0, act=6, discrete=True, C=2, Q=5, T=2, B=6, img=(4, 84, 84), conv=((32, 8, 4), (64, 4, 2), (64, 3, 1)),
+          env={"FDQL_NO_IMPLICIT_CONV": "1"})),
     ("config5 head (discrete SAC, 6 actions, Gumbel-softmax)", dict(obs=64, act=6, discrete=True, C=2, Q=5, T=4, B=128)),
     ("ragged sizes (B=7, odd widths 18/33/21: unaligned rows, partial tiles, M < one tile)",
      dict(obs=3, act=2, C=2, Q=3, T=3, B=7, critic_hidden=(33, 18), pi_hidden=(21,), enc_hidden=(18,), joint_hidden=(33,),
@@ -632,12 +642,15 @@ def test_update_matches_oracle_other_configs(dev, name, kw, monkeypatch):
 def _run_other_config(dev, name, kw):
     from oracle import update as oup
     T, B = kw.pop("T"), kw.pop("B")
+    frames = kw.pop("frames", None)   # "u8": uint8 frame batch; "ring": the ring's uint8 block read in place (obs_2d_slots)
     base = dict(latent=256, enc_features=256, enc_hidden=(256,), joint_hidden=(256,), pi_hidden=(256,), critic_hidden=(256, 256))
     base.update(kw)
     spec = oup.Spec(T=T, B=B, **base)
     params = oup.init_params(spec, seed=5)
     st = oup.new_state(spec, params)
-    ag = _agent_for(spec, dev)
+    ag = _agent_for(spec, dev, obs_2d_u8=frames is not None)
+    if frames is not None:
+        assert ag.conv_reads_ring()
     ag.load_tensors(params)
     g = torch.Generator().manual_seed(9)
     A = spec.act
@@ -665,7 +678,17 @@ def _run_other_config(dev, name, kw):
     if spec.bootstrap:   # the window-long bound must actually bind somewhere, or the case tests nothing
         assert int(((aux["bootstrap_lowerbound"] * aux["is_contiguous"].prod(0)) > 0).sum()) >= 8
     before = _snapshot(ag)
-    ag.update({k: v.to(dev) for k, v in xp.items()}, nt.to(dev), na.to(dev))
+    xd = {k: v.to(dev) for k, v in xp.items()}
+    if frames == "u8":
+        xd["obs_2d"] = xp["obs_2d"].to(torch.uint8).to(dev)
+    elif frames == "ring":   # a ring block of T B + 9 slots holding the batch's frames at scattered slots
+        nslot = T * B + 9
+        perm = torch.randperm(nslot, generator=g)[:T * B]
+        block = torch.randint(0, 256, (nslot,) + tuple(spec.img), generator=g, dtype=torch.uint8)
+        block[perm] = xp["obs_2d"].to(torch.uint8).reshape((T * B,) + tuple(spec.img))
+        xd["obs_2d"] = block.to(dev)
+        xd["obs_2d_slots"] = perm.to(torch.int32).view(T, B).to(dev)
+    ag.update(xd, nt.to(dev), na.to(dev))
     rep = Report("oracle:" + name)
     ref = {k: (v.detach().numpy() if isinstance(v, torch.Tensor) else v) for k, v in aux.items() if k != "grad"}
     ref["loss"], ref["grad"] = float(loss), aux["grad"]

@@ -17,6 +17,7 @@ ap.add_argument("--T", type=int, default=50)
 ap.add_argument("--B", type=int, default=512)
 ap.add_argument("--ring", type=int, default=200_000)
 ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--f32", action="store_true", help="float32 frame batch (the im2col first layer) instead of reading the uint8 ring in place")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 IMG, ACT = (4, 84, 84), 6
@@ -36,18 +37,31 @@ while done < a.ring:                      # synthetic fill, on the device
     rows[:, dims[0] + 4] = ((torch.arange(n, device=dev) + done) % 1000).float()
     ring.add_rows(rows)
     done += n
-cfg = make_config(0, ACT, a.T, a.B, discrete=True, n_critics=5, n_quantiles=2, img=IMG, conv=((32, 8, 4), (64, 4, 2), (64, 3, 1)))
+cfg = make_config(0, ACT, a.T, a.B, discrete=True, n_critics=5, n_quantiles=2, img=IMG, conv=((32, 8, 4), (64, 4, 2), (64, 3, 1)),
+                  obs_2d_u8=not a.f32)
 agent = NativeAgent(cfg, dev)
 agent.init_weights(0)
-print(f"ring {a.ring} frames of {dims[0]} B as uint8; workspace {agent.workspace.numel() / 2**30:.1f} GiB", flush=True)
-outs = [torch.empty((a.T, a.B) + (IMG if k == "obs_2d" else (1,)), device=dev) for k in keys]
-xp = dict(zip(keys, outs))
-flat = [o.view(a.T, a.B, -1) for o in outs]
+print(f"ring {a.ring} frames of {dims[0]} B as uint8; workspace {agent.workspace.numel() / 2**30:.1f} GiB; frames "
+      f"{'gathered and widened to a float32 batch (im2col path for layer 0)' if a.f32 else 'read from the ring in place'}", flush=True)
+if a.f32:
+    outs = [torch.empty((a.T, a.B) + (IMG if k == "obs_2d" else (1,)), device=dev) for k in keys]
+    xp = dict(zip(keys, outs))
+    flat = [o.view(a.T, a.B, -1) for o in outs]
 
+    def step(i):
+        ring.sample_windows(a.T, a.B, seed=7, counter=i, outs=flat)
+        agent.update(xp, seed=7)
+else:
+    outs = [None if k == "obs_2d" else torch.empty((a.T, a.B, d), device=dev) for k, d in zip(keys, dims)]
+    starts = torch.empty(a.B, dtype=torch.int64, device=dev)
+    slots = torch.empty((a.T, a.B), dtype=torch.int32, device=dev)
+    xp = {k: o for k, o in zip(keys, outs) if o is not None}
+    xp["obs_2d"], xp["obs_2d_slots"] = ring.key_block_u8(0), slots
 
-def step(i):
-    ring.sample_windows(a.T, a.B, seed=7, counter=i, outs=flat)
-    agent.update(xp, seed=7)
+    def step(i):
+        ring.sample_windows(a.T, a.B, seed=7, counter=i, outs=outs, select={0: None}, starts_out=starts)
+        ring.window_slots(a.T, a.B, starts, out=slots)
+        agent.update(xp, seed=7)
 
 
 for i in range(3):

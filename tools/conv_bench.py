@@ -49,7 +49,7 @@ for name, L in LAYERS:
     flops = 2.0 * N * pos * K * L["co"]
 
     def call(mode):
-        nat.check(lib.fdql_test_conv(mode, p(x), L["u8"], None, 0, 1, p(W), p(bias), p(dpre), p(x) if not L["u8"] else None,
+        nat.check(lib.fdql_test_conv(mode, p(x), L["u8"], None, p(W), p(bias), p(dpre), p(x) if not L["u8"] else None,
                                      p(out if mode == 0 else (dprev if mode == 1 else dw)), p(scratch), scratch.numel(), N, L["C"], L["H"],
                                      L["W"], L["k"], L["s"], L["co"], st))
 
