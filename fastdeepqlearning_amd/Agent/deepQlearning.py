@@ -33,12 +33,15 @@ def native_config_from_conf(conf):
     """Translate a franQ conf (conf.py:8-98, encoder.py:16-33) into the C-ABI config."""
     spaces = conf.obs_space.spaces
     ec = conf.encoder_conf
-    img, conv = (), ()
+    img, conv, u8_frames = (), (), False
     if "obs_2d" in spaces:
         # the reference's pixel encoder is dead code (encoder.py:16-23); this build's own conv stack takes its place:
         # EncoderConf.conv_layers = ((out_channels, kernel, stride), ...), default the 3-layer Atari stack
         img = tuple(int(v) for v in spaces["obs_2d"].shape)
         conv = tuple(getattr(ec, "conv_layers", ((32, 8, 4), (64, 4, 2), (64, 3, 1))))
+        # uint8 frames (the usual pixel space) stay uint8 from the ring to the first conv layer when that layer has an
+        # implicit-GEMM kernel (DeepQLearning.__init__ falls back to float32 frames when it has not)
+        u8_frames = np.dtype(getattr(spaces["obs_2d"], "dtype", np.float32)) == np.uint8 and not getattr(conf, "pixel_frames_float32", False)
     gru = getattr(getattr(ec, "joiner_mode", None), "name", "feedforward") == "gru"
     gru_mode = getattr(getattr(ec, "rnn_latent_state_training_mode", None), "name", "zero")
     obs = _space_dim(spaces["obs_1d"]) if "obs_1d" in spaces else 0
@@ -59,6 +62,7 @@ def native_config_from_conf(conf):
                        pi_hidden=tuple(conf.pi_hidden_dims), critic_hidden=tuple(conf.critic_hidden_dims),
                        distributional=bool(conf.use_distributional_sac), use_lowerbound=bool(conf.use_nStep_lowerbounds),
                        use_max_entropy=bool(conf.use_max_entropy_q), bootstrap_nstep=boot, joiner_gru=gru, gru_state_mode=gru_mode, img=img, conv=conv,
+                       obs_2d_u8=u8_frames,
                        burn_in_steps=int(conf.temporal_len * ec.burn_in_portion) if getattr(ec, "use_burn_in", False) else 0, hard_updates=bool(conf.use_hard_updates),
                        keep_frozen_copy=True, world_size=int(getattr(conf, "world_size", 1) or 1),
                        gamma=float(conf.gamma), tau=float(conf.tau), lr=float(conf.learning_rate),
@@ -75,7 +79,14 @@ class DeepQLearning:
         self.conf = conf
         self.param_queue = kwargs.get("param_queue", Queue(maxsize=1))
         self.device = torch.device(conf.training_device)
-        self.native = NativeAgent(native_config_from_conf(conf), self.device)
+        cfg = native_config_from_conf(conf)
+        try:
+            self.native = NativeAgent(cfg, self.device)
+        except Exception:
+            if not cfg.obs_2d_u8:
+                raise
+            cfg.obs_2d_u8 = 0   # this conv stack's first layer has no uint8 kernel: float32 frames through the gather, as before
+            self.native = NativeAgent(cfg, self.device)
         self.native.init_weights(seed=int(kwargs.get("seed", 0)))
         self.replays = []
         self._seed = int(kwargs.get("seed", 0))
@@ -101,6 +112,15 @@ class DeepQLearning:
 
     def _initialize_trainer_members(self, replays):
         self.replays = [TorchDataLoader(r, self.device, torch.float32) for r in replays]
+        if self.native.cfg.obs_2d_u8:
+            for loader in self.replays:
+                loader.keep_uint8.add("obs_2d")
+                if self.native.conv_reads_ring():   # ring shards hand out their uint8 block + row slots instead of a gathered batch
+                    shard = loader
+                    while hasattr(shard, "replay_buffer"):
+                        shard = shard.replay_buffer
+                    if hasattr(shard, "enable_in_place"):
+                        shard.enable_in_place(("obs_2d",))
 
     def _infinite_loop_for_async_training_process(self):
         """deepQlearning.py:83-94 (+ the crash report of :37-43: traceback, "[Trainer Crashed]" warning).  The failure
@@ -191,10 +211,15 @@ class DeepQLearning:
         for replay in self.replays:
             xp = replay.temporal_sample()
             self._last_xp = xp
+            in_place = "obs_2d_slots" in xp      # the update reads the ring's frames in place: ordered against writers on other streams
+            if in_place:
+                replay.external_read(True)
             if self._distributed():
                 self._distributed_step(xp, nt, na)
             else:
                 self.native.update(xp, nt, na, seed=self._seed, phase=N.PHASE_ALL)
+            if in_place:
+                replay.external_read(False)
             self._log_summaries()
             self.conf.train_step.value += 1
 

@@ -125,11 +125,65 @@ class ReplayMemory:
         outs = self._ring.sample_rows(self._batch_size, idx=idxes, seed=self._seed, counter=self._counter)
         return self._named(outs, (self._batch_size,))
 
+    # ---------------------------------------------------------------- keys read in place (uint8 pixel frames)
+    def enable_in_place(self, keys=("obs_2d",)):
+        """Asks temporal_sample() NOT to gather these keys: for a uint8 key ``k`` the batch then carries the ring's own block
+        (``xp[k]``: uint8 [maxlen, *shape], a zero-copy view) and ``xp[k + "_slots"]`` (int32 [T, B]: the slot of every row of
+        the sampled windows, (start[b] + t) % len as in replay_memory.py:63-65).  The native agent's first conv layer reads the
+        frames straight from there (fdql_batch_t.obs_2d_u8 / obs_2d_slots): no float32 frame batch is ever materialised.
+        Keys that turn out not to be stored as uint8 keep being gathered.  Not part of the reference's interface: switched on
+        by DeepQLearning.enable_training() for its own shards when the agent can use it."""
+        self._in_place = tuple(keys)
+        self._in_place_cache = None
+
+    def _in_place_active(self):
+        want = getattr(self, "_in_place", ())
+        if not want or self._ring is None:
+            return {}
+        if getattr(self, "_in_place_cache", None) is None:
+            self._in_place_cache = {k: self._keys.index(k) for k in want if k in self._keys and self._dtypes[self._keys.index(k)] == "u8"}
+            self._blocks = {k: self._ring.key_block_u8(j).view((self._maxlen,) + tuple(self._shapes[j])) for k, j in self._in_place_cache.items()}
+            self._slot_pool, self._start_pool = {}, {}
+        return self._in_place_cache
+
+    def external_read(self, begin):
+        """Bracket around a consumer that reads the ring's blocks in place on the current stream (see enable_in_place)."""
+        if self._ring is not None:
+            self._ring.external_read(begin)
+
+    def _temporal_sample_in_place(self, starts, active):
+        T, B = self._temporal_len, self._batch_size
+        slot = self._pool_i % self._pool_n if self._pool_n else None
+        outs = None
+        if self._pool_n:
+            if len(self._pool) < self._pool_n:
+                self._pool.append([torch.empty((T, B, d), dtype=torch.float32, device=self.device) for d in self._dims])
+            outs = [None if j in active.values() else o for j, o in enumerate(self._pool[self._pool_i % len(self._pool)])]
+        if slot is None or slot not in self._slot_pool:
+            so = torch.empty(B, dtype=torch.int64, device=self.device)
+            sl = torch.empty((T, B), dtype=torch.int32, device=self.device)
+            if slot is not None:
+                self._start_pool[slot], self._slot_pool[slot] = so, sl
+        else:
+            so, sl = self._start_pool[slot], self._slot_pool[slot]
+        outs, so = self._ring.sample_windows(T, B, starts=starts, seed=self._seed, counter=self._counter, outs=outs,
+                                             select={j: None for j in active.values()}, starts_out=so)
+        self._ring.window_slots(T, B, so, out=sl)
+        if self._pool_n:
+            self._pool_i = (self._pool_i + 1) % self._pool_n
+        res = {k: o.view((T, B) + s) for k, s, o in zip(self._keys, self._shapes, outs) if o is not None}
+        for k in active:
+            res[k], res[k + "_slots"] = self._blocks[k], sl
+        return res
+
     def temporal_sample(self, starts=None):
         """replay_memory.py:54-65: [T, B, *shape] per key; raises OversampleError when
         len < 2T or len < B."""
         self._check_init()
         self._counter += 1
+        active = self._in_place_active()
+        if active:
+            return self._temporal_sample_in_place(starts, active)
         outs = None
         if self._pool_n:
             if len(self._pool) < self._pool_n:

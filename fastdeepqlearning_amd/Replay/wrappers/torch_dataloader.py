@@ -34,6 +34,7 @@ class TorchDataLoader(ReplayMemoryWrapper):
         # in use, the one being prefetched and the previous one, which the update before may still be reading)
         self._prefetch = bool(prefetch) and os.environ.get("FDQL_NO_PREFETCH") is None and self.device.type == "cuda"
         self._pending, self._side, self._events, self._ev_i = None, None, None, 0
+        self.keep_uint8 = set()   # keys the consumer wants as uint8 device tensors instead of `precision` (set by the agent)
 
     def _can_prefetch(self):
         from ..replay_memory import ReplayMemory
@@ -72,6 +73,11 @@ class TorchDataLoader(ReplayMemoryWrapper):
         for key, value in batch.items():
             if isinstance(value, torch.Tensor) and value.device == self.device and value.dtype == self.precision:
                 out[key] = value
+            elif isinstance(value, torch.Tensor) and value.device == self.device and (
+                    (key.endswith("_slots") and value.dtype == torch.int32) or (value.dtype == torch.uint8 and key + "_slots" in batch)):
+                out[key] = value          # a key read in place (ReplayMemory.enable_in_place): the ring's uint8 block + row slots
+            elif key in self.keep_uint8:  # the agent takes these frames as bytes (fdql_batch_t.obs_2d_u8)
+                out[key] = torch.as_tensor(value).to(device=self.device, dtype=torch.uint8).contiguous()
             else:
                 out[key] = torch.as_tensor(value).to(device=self.device, dtype=self.precision)
         return out

@@ -315,11 +315,15 @@ struct DgCfg {
   static constexpr int HY = GE::OH - 1 + TA, HX = GE::OW - 1 + TA, CPOS = HY * HX;   // class grid (H = S HY exactly)
   static constexpr int ROWS = G * CPOS, NTILE = (ROWS + 15) / 16;
   static constexpr int KP = TA * TA * GE::CO;
-  static constexpr int NCH = GE::C / 16, NCOMBO = GE::S * GE::S * NCH, NCW = NCOMBO / NW;   // combinations per wave (same class)
+  // combinations per wave (same class): as many as keep the stationary weights within ~150 registers; waves beyond the
+  // combination groups split the row tiles (row groups)
+  static constexpr int NCH = GE::C / 16, NCOMBO = GE::S * GE::S * NCH;
+  static constexpr int NCW = (NCOMBO >= NW) ? NCOMBO / NW : 1;
+  static constexpr int NCGRP = NCOMBO / NCW, NRG = NW / NCGRP;
   static constexpr int BUF = G * PIMG;
   static constexpr int LDS_FLOATS = 2 * BUF + 2 * NTILE * 16;
   static_assert(GE::KS % GE::S == 0 && GE::C % 16 == 0 && GE::CO % 16 == 0, "uniform tap sets, 16-channel groups");
-  static_assert(NCOMBO % NW == 0 && NCH % NCW == 0, "a wave's combinations share one class");
+  static_assert(NCOMBO % NCW == 0 && NW % NCGRP == 0 && NCH % NCW == 0, "a wave's combinations share one class");
   static_assert(GE::H == GE::S * HY && GE::W == GE::S * HX, "class grids tile the map");
   static_assert(LDS_FLOATS * 4 <= LDS_LIMIT, "padded image group does not fit the LDS");
 };
@@ -336,7 +340,8 @@ __global__ __launch_bounds__(NW * 64, 1) void k_conv_dgrad(const ConvDgradArgs a
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NT = NW * 64, KP = CF::KP, NJ4 = KP / 16, NCW = CF::NCW, TA = CF::TA;
   const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6), l16 = lane & 15, q = lane >> 4;
-  const int combo0 = wave * NCW, cls = combo0 / CF::NCH, chg0 = combo0 % CF::NCH, py = cls / GE::S, px = cls % GE::S;
+  const int rg = wave / CF::NCGRP;
+  const int combo0 = (wave % CF::NCGRP) * NCW, cls = combo0 / CF::NCH, chg0 = combo0 % CF::NCH, py = cls / GE::S, px = cls % GE::S;
   int *rowoff = reinterpret_cast<int *>(lds + 2 * CF::BUF), *outoff = rowoff + CF::NTILE * 16;
   lds_zero<NT>(lds, 2 * CF::BUF, tid);
   for (int r = tid; r < CF::NTILE * 16; r += NT) {
@@ -448,8 +453,8 @@ __global__ __launch_bounds__(NW * 64, 1) void k_conv_dgrad(const ConvDgradArgs a
         }
       }
     };
-    for (int t0 = 0; t0 < CF::NTILE; t0 += 2) {
-      if (t0 + 1 < CF::NTILE) tiles(std::true_type{}, t0, t0 + 1);   // (uniform)
+    for (int t0 = rg; t0 < CF::NTILE; t0 += 2 * CF::NRG) {
+      if (t0 + CF::NRG < CF::NTILE) tiles(std::true_type{}, t0, t0 + CF::NRG);   // (uniform)
       else tiles(std::false_type{}, t0, t0);
     }
   }
@@ -769,7 +774,25 @@ hipError_t launch_persistent(KernelT kernel, const ArgsT &a, long long units, in
 
 // images per group (forward / data gradient / weight gradient): rows per group close to a multiple of 16 (4), double-buffered in 160 KB
 constexpr int G_F0 = 2, G_F1 = 1, G_F2 = 3, G_D1 = 2, G_D2 = 2, G_W1 = 1, G_W2 = 2;
-constexpr int NW_F = 4, NW_D = 4, NW_W0 = 8;
+#ifndef CONV_NW_F0
+#define CONV_NW_F0 4
+#endif
+#ifndef CONV_NW_F1
+#define CONV_NW_F1 4
+#endif
+#ifndef CONV_NW_F2
+#define CONV_NW_F2 4
+#endif
+#ifndef CONV_NW_D1
+#define CONV_NW_D1 4
+#endif
+#ifndef CONV_NW_D2
+#define CONV_NW_D2 4
+#endif
+#ifndef CONV_NW_W0
+#define CONV_NW_W0 8
+#endif
+constexpr int NW_F0 = CONV_NW_F0, NW_F1 = CONV_NW_F1, NW_F2 = CONV_NW_F2, NW_D1 = CONV_NW_D1, NW_D2 = CONV_NW_D2, NW_W0 = CONV_NW_W0;
 using W1Cfg = WgCfg<L1, G_W1, 1, 2>;   // 4 kernel rows x 2 row groups = 8 waves
 using W2Cfg = WgCfg<L2, G_W2, 2, 2>;   // 3 kernel rows x 2 channel halves x 2 row groups = 12 waves
 
@@ -795,19 +818,19 @@ int conv_wgrad_slabs(const ConvGeom &g, int cout, bool u8, long long nimg) {
 
 hipError_t conv_fwd_launch(const ConvFwdArgs &a, hipStream_t s) {
   if (a.in.u8 && geo_is<L0>(a.g, a.cout))
-    return launch_persistent(k_conv_fwd_u8<L0, G_F0, NW_F>, a, (a.nimg + G_F0 - 1) / G_F0, NW_F * 64, Fwd8Cfg<L0, G_F0, NW_F>::LDS_BYTES, s);
+    return launch_persistent(k_conv_fwd_u8<L0, G_F0, NW_F0>, a, (a.nimg + G_F0 - 1) / G_F0, NW_F0 * 64, Fwd8Cfg<L0, G_F0, NW_F0>::LDS_BYTES, s);
   if (!a.in.u8 && geo_is<L1>(a.g, a.cout))
-    return launch_persistent(k_conv_fwd<L1, G_F1, NW_F>, a, (a.nimg + G_F1 - 1) / G_F1, NW_F * 64, FwdCfg<L1, G_F1, NW_F>::LDS_FLOATS * 4, s);
+    return launch_persistent(k_conv_fwd<L1, G_F1, NW_F1>, a, (a.nimg + G_F1 - 1) / G_F1, NW_F1 * 64, FwdCfg<L1, G_F1, NW_F1>::LDS_FLOATS * 4, s);
   if (!a.in.u8 && geo_is<L2>(a.g, a.cout))
-    return launch_persistent(k_conv_fwd<L2, G_F2, NW_F>, a, (a.nimg + G_F2 - 1) / G_F2, NW_F * 64, FwdCfg<L2, G_F2, NW_F>::LDS_FLOATS * 4, s);
+    return launch_persistent(k_conv_fwd<L2, G_F2, NW_F2>, a, (a.nimg + G_F2 - 1) / G_F2, NW_F2 * 64, FwdCfg<L2, G_F2, NW_F2>::LDS_FLOATS * 4, s);
   return hipErrorInvalidValue;
 }
 
 hipError_t conv_dgrad_launch(const ConvDgradArgs &a, hipStream_t s) {
   if (geo_is<L1>(a.g, a.cout))
-    return launch_persistent(k_conv_dgrad<L1, G_D1, NW_D>, a, (a.nimg + G_D1 - 1) / G_D1, NW_D * 64, DgCfg<L1, G_D1, NW_D>::LDS_FLOATS * 4, s);
+    return launch_persistent(k_conv_dgrad<L1, G_D1, NW_D1>, a, (a.nimg + G_D1 - 1) / G_D1, NW_D1 * 64, DgCfg<L1, G_D1, NW_D1>::LDS_FLOATS * 4, s);
   if (geo_is<L2>(a.g, a.cout))
-    return launch_persistent(k_conv_dgrad<L2, G_D2, NW_D>, a, (a.nimg + G_D2 - 1) / G_D2, NW_D * 64, DgCfg<L2, G_D2, NW_D>::LDS_FLOATS * 4, s);
+    return launch_persistent(k_conv_dgrad<L2, G_D2, NW_D2>, a, (a.nimg + G_D2 - 1) / G_D2, NW_D2 * 64, DgCfg<L2, G_D2, NW_D2>::LDS_FLOATS * 4, s);
   return hipErrorInvalidValue;
 }
 

@@ -802,3 +802,62 @@ def test_pixel_agent_life_cycle(dev):
     assert np.isfinite(sc["loss"]) and sc["step"] == 2
     assert not torch.equal(before["encoder.visible_layer_encoders.obs_2d.conv.0.weight"],
                            agent.state_dict()["encoder.visible_layer_encoders.obs_2d.conv.0.weight"])
+
+
+def test_pixel_agent_reads_uint8_frames_from_the_ring_in_place(dev):
+    """BASELINE config 5's frame stacks through the facade: a uint8 obs_2d space makes the agent take the frames as bytes
+    (cfg.obs_2d_u8), enable_training() switches its shards to in-place reads - temporal_sample() hands out the ring's uint8
+    block and an int32 slot per row instead of a gathered float32 batch - and the gradient equals the one an agent on float32
+    frames (first layer on im2col + GEMM) forms from the same windows."""
+    from fastdeepqlearning_amd import Agent, Replay
+    from fastdeepqlearning_amd import _native as N
+
+    class _U8Space(_Space):
+        dtype = np.uint8
+
+    def build(float_frames):
+        conf = _conf(dev, T=3, B=4)
+        conf.num_instances = 1
+        conf.obs_space = _Space(spaces={"obs_2d": _U8Space(shape=(4, 84, 84))})
+        conf.action_space = _Space(n=6)
+        conf.discrete = True
+        conf.encoder_conf.conv_layers = ((32, 8, 4), (64, 4, 2), (64, 3, 1))
+        conf.pixel_frames_float32 = float_frames
+        return conf
+
+    conf = build(False)
+    read_heads, write_heads = Replay.make(conf)
+    agent = Agent.make(conf)
+    assert agent.native.cfg.obs_2d_u8 == 1 and agent.native.conv_reads_ring()
+    rng = np.random.RandomState(4)
+    for i in range(40):
+        write_heads[0].add({"obs_2d": rng.randint(0, 256, (4, 84, 84)).astype(np.uint8), "action": np.asarray([int(rng.randint(6))]),
+                            "reward": float(rng.standard_normal()), "task_done": False, "episode_done": i == 39, "episode_step": i, "idx": 0})
+    agent.enable_training(read_heads)
+    loader = agent.replays[0]
+    xp = loader.temporal_sample()
+    ring = read_heads[0]
+    assert xp["obs_2d"].dtype == torch.uint8 and tuple(xp["obs_2d"].shape) == (ring._maxlen, 4, 84, 84)
+    assert xp["obs_2d_slots"].dtype == torch.int32 and tuple(xp["obs_2d_slots"].shape) == (3, 4)
+    slots = xp["obs_2d_slots"].long()
+    assert int(slots.max()) < len(ring) and torch.equal(slots[1:], slots[:-1] + 1)      # consecutive slots of a window (no wrap at this fill)
+    M, A = 2 * 4, 6
+    g = torch.Generator().manual_seed(1)
+    nt, na = torch.rand(2, 4, A, generator=g).to(dev), torch.rand(2, 4, A, generator=g).to(dev)
+    agent.native.update(xp, nt, na, phase=N.PHASE_GRAD)
+    # the same windows as a gathered float32 batch, on an agent whose first layer takes float32 frames
+    ref = Agent.make(build(True))
+    assert ref.native.cfg.obs_2d_u8 == 0
+    ref.load_state_dict(agent.state_dict())
+    xp2 = {k: v for k, v in xp.items() if not k.startswith("obs_2d")}
+    xp2["obs_2d"] = xp["obs_2d"][slots.reshape(-1)].float().view(3, 4, 4, 84, 84)
+    ref.native.update(xp2, nt, na, phase=N.PHASE_GRAD)
+    torch.cuda.synchronize(dev)
+    for name, gv in agent.native.grad_views.items():
+        r = ref.native.grad_views[name]
+        scale = float(r.abs().max()) + 1e-30
+        assert float((gv - r).abs().max()) / scale < 1e-4, name
+    for _ in range(2):
+        agent.train_step()
+    sc = agent.native.scalars()
+    assert np.isfinite(sc["loss"]) and agent.native.stats()["plans_built"] <= 4
