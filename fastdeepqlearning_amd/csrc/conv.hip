@@ -335,7 +335,9 @@ __host__ __device__ constexpr int koff_dg(int j4) {
 }
 
 template <typename GE, int G, int NW>
-__global__ __launch_bounds__(NW * 64, 1) void k_conv_dgrad(const ConvDgradArgs a) {
+__global__ __launch_bounds__(NW * 64, 1) void k_conv_dgrad(const ConvDgradArgs a, const float *__restrict__ act_prev, float *__restrict__ dprev) {
+  // (act_prev / dprev = a.act_prev / a.dprev as restrict kernel parameters: without the promise that they are distinct a gate
+  // request placed behind a store waits for that store to complete - s_waitcnt vmcnt(0) after every tile pair)
   using CF = DgCfg<GE, G, NW>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NT = NW * 64, KP = CF::KP, NJ4 = KP / 16, NCW = CF::NCW, TA = CF::TA;
@@ -403,8 +405,8 @@ __global__ __launch_bounds__(NW * 64, 1) void k_conv_dgrad(const ConvDgradArgs a
       v4f gate0[NCW], gate1[NCW];   // the gate references, requested before the K loop
 #pragma unroll
       for (int i = 0; i < NCW; ++i) {
-        gate0[i] = ok0 ? *reinterpret_cast<const v4f *>(a.act_prev + g0 + 16 * i) : v4f{0.f, 0.f, 0.f, 0.f};
-        if constexpr (TWO) gate1[i] = ok1 ? *reinterpret_cast<const v4f *>(a.act_prev + g1 + 16 * i) : v4f{0.f, 0.f, 0.f, 0.f};
+        gate0[i] = ok0 ? *reinterpret_cast<const v4f *>(act_prev + g0 + 16 * i) : v4f{0.f, 0.f, 0.f, 0.f};
+        if constexpr (TWO) gate1[i] = ok1 ? *reinterpret_cast<const v4f *>(act_prev + g1 + 16 * i) : v4f{0.f, 0.f, 0.f, 0.f};
       }
       v4f acc0[NCW], acc1[NCW];
 #pragma unroll
@@ -435,21 +437,23 @@ __global__ __launch_bounds__(NW * 64, 1) void k_conv_dgrad(const ConvDgradArgs a
           }
         x0 = n0; x1 = n1;
       }
+      // every gated value is formed BEFORE the first store: with loads and stores both outstanding hipcc waits vmcnt(0) for
+      // any load result, i.e. for the stores issued so far to complete
+      v4f y0[NCW], y1[NCW];
+#pragma unroll
+      for (int i = 0; i < NCW; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          y0[i][c] = gate0[i][c] > 0.f ? acc0[i][c] : 0.01f * acc0[i][c];
+          y1[i][c] = TWO ? (gate1[i][c] > 0.f ? acc1[i][c] : 0.01f * acc1[i][c]) : 0.f;
+        }
+#pragma unroll
+      for (int i = 0; i < NCW; ++i) asm volatile("" : "+v"(y0[i]), "+v"(y1[i]));   // (materialised here: not sunk into the store branches)
 #pragma unroll
       for (int i = 0; i < NCW; ++i) {
-        if (ok0) {
-          v4f y;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) y[c] = gate0[i][c] > 0.f ? acc0[i][c] : 0.01f * acc0[i][c];
-          *reinterpret_cast<v4f *>(a.dprev + g0 + 16 * i) = y;
-        }
+        if (ok0) *reinterpret_cast<v4f *>(dprev + g0 + 16 * i) = y0[i];
         if constexpr (TWO) {
-          if (ok1) {
-            v4f y;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) y[c] = gate1[i][c] > 0.f ? acc1[i][c] : 0.01f * acc1[i][c];
-            *reinterpret_cast<v4f *>(a.dprev + g1 + 16 * i) = y;
-          }
+          if (ok1) *reinterpret_cast<v4f *>(dprev + g1 + 16 * i) = y1[i];
         }
       }
     };
@@ -762,13 +766,13 @@ int num_cus() {
   return ncu;
 }
 
-template <typename KernelT, typename ArgsT>
-hipError_t launch_persistent(KernelT kernel, const ArgsT &a, long long units, int threads, int lds_bytes, hipStream_t s) {
+template <typename KernelT, typename... ArgsT>
+hipError_t launch_persistent(KernelT kernel, long long units, int threads, int lds_bytes, hipStream_t s, ArgsT... args) {
   if (units <= 0) return hipSuccess;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) return e;
   const int blocks = (int)std::min<long long>(units, cu_budget(num_cus()));
-  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds_bytes, s, a);
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds_bytes, s, args...);
   return hipGetLastError();
 }
 
@@ -778,16 +782,16 @@ constexpr int G_F0 = 2, G_F1 = 1, G_F2 = 3, G_D1 = 2, G_D2 = 2, G_W1 = 1, G_W2 =
 #define CONV_NW_F0 4
 #endif
 #ifndef CONV_NW_F1
-#define CONV_NW_F1 4
+#define CONV_NW_F1 8
 #endif
 #ifndef CONV_NW_F2
-#define CONV_NW_F2 4
+#define CONV_NW_F2 8
 #endif
 #ifndef CONV_NW_D1
-#define CONV_NW_D1 4
+#define CONV_NW_D1 8
 #endif
 #ifndef CONV_NW_D2
-#define CONV_NW_D2 4
+#define CONV_NW_D2 8
 #endif
 #ifndef CONV_NW_W0
 #define CONV_NW_W0 8
@@ -818,29 +822,29 @@ int conv_wgrad_slabs(const ConvGeom &g, int cout, bool u8, long long nimg) {
 
 hipError_t conv_fwd_launch(const ConvFwdArgs &a, hipStream_t s) {
   if (a.in.u8 && geo_is<L0>(a.g, a.cout))
-    return launch_persistent(k_conv_fwd_u8<L0, G_F0, NW_F0>, a, (a.nimg + G_F0 - 1) / G_F0, NW_F0 * 64, Fwd8Cfg<L0, G_F0, NW_F0>::LDS_BYTES, s);
+    return launch_persistent(k_conv_fwd_u8<L0, G_F0, NW_F0>, (a.nimg + G_F0 - 1) / G_F0, NW_F0 * 64, Fwd8Cfg<L0, G_F0, NW_F0>::LDS_BYTES, s, a);
   if (!a.in.u8 && geo_is<L1>(a.g, a.cout))
-    return launch_persistent(k_conv_fwd<L1, G_F1, NW_F1>, a, (a.nimg + G_F1 - 1) / G_F1, NW_F1 * 64, FwdCfg<L1, G_F1, NW_F1>::LDS_FLOATS * 4, s);
+    return launch_persistent(k_conv_fwd<L1, G_F1, NW_F1>, (a.nimg + G_F1 - 1) / G_F1, NW_F1 * 64, FwdCfg<L1, G_F1, NW_F1>::LDS_FLOATS * 4, s, a);
   if (!a.in.u8 && geo_is<L2>(a.g, a.cout))
-    return launch_persistent(k_conv_fwd<L2, G_F2, NW_F2>, a, (a.nimg + G_F2 - 1) / G_F2, NW_F2 * 64, FwdCfg<L2, G_F2, NW_F2>::LDS_FLOATS * 4, s);
+    return launch_persistent(k_conv_fwd<L2, G_F2, NW_F2>, (a.nimg + G_F2 - 1) / G_F2, NW_F2 * 64, FwdCfg<L2, G_F2, NW_F2>::LDS_FLOATS * 4, s, a);
   return hipErrorInvalidValue;
 }
 
 hipError_t conv_dgrad_launch(const ConvDgradArgs &a, hipStream_t s) {
   if (geo_is<L1>(a.g, a.cout))
-    return launch_persistent(k_conv_dgrad<L1, G_D1, NW_D1>, a, (a.nimg + G_D1 - 1) / G_D1, NW_D1 * 64, DgCfg<L1, G_D1, NW_D1>::LDS_FLOATS * 4, s);
+    return launch_persistent(k_conv_dgrad<L1, G_D1, NW_D1>, (a.nimg + G_D1 - 1) / G_D1, NW_D1 * 64, DgCfg<L1, G_D1, NW_D1>::LDS_FLOATS * 4, s, a, a.act_prev, a.dprev);
   if (geo_is<L2>(a.g, a.cout))
-    return launch_persistent(k_conv_dgrad<L2, G_D2, NW_D2>, a, (a.nimg + G_D2 - 1) / G_D2, NW_D2 * 64, DgCfg<L2, G_D2, NW_D2>::LDS_FLOATS * 4, s);
+    return launch_persistent(k_conv_dgrad<L2, G_D2, NW_D2>, (a.nimg + G_D2 - 1) / G_D2, NW_D2 * 64, DgCfg<L2, G_D2, NW_D2>::LDS_FLOATS * 4, s, a, a.act_prev, a.dprev);
   return hipErrorInvalidValue;
 }
 
 hipError_t conv_wgrad_launch(const ConvWgradArgs &a, hipStream_t s) {
   if (a.in.u8 && geo_is<L0>(a.g, a.cout))
-    return launch_persistent(k_conv_wgrad_u8<L0, NW_W0>, a, a.nimg, NW_W0 * 64, Wg8Cfg<L0, NW_W0>::LDS_BYTES, s);
+    return launch_persistent(k_conv_wgrad_u8<L0, NW_W0>, a.nimg, NW_W0 * 64, Wg8Cfg<L0, NW_W0>::LDS_BYTES, s, a);
   if (!a.in.u8 && geo_is<L1>(a.g, a.cout))
-    return launch_persistent(k_conv_wgrad<W1Cfg>, a, (a.nimg + G_W1 - 1) / G_W1, W1Cfg::NT, W1Cfg::LDS_FLOATS * 4, s);
+    return launch_persistent(k_conv_wgrad<W1Cfg>, (a.nimg + G_W1 - 1) / G_W1, W1Cfg::NT, W1Cfg::LDS_FLOATS * 4, s, a);
   if (!a.in.u8 && geo_is<L2>(a.g, a.cout))
-    return launch_persistent(k_conv_wgrad<W2Cfg>, a, (a.nimg + G_W2 - 1) / G_W2, W2Cfg::NT, W2Cfg::LDS_FLOATS * 4, s);
+    return launch_persistent(k_conv_wgrad<W2Cfg>, (a.nimg + G_W2 - 1) / G_W2, W2Cfg::NT, W2Cfg::LDS_FLOATS * 4, s, a);
   return hipErrorInvalidValue;
 }
 

@@ -18,7 +18,6 @@ constexpr int RING_MAX_KEYS = 16;
 constexpr int GATHER_THREADS = 256;
 constexpr int STAGE_WINDOWS = 8;         // windows per block in the LDS-staged path
 constexpr int STAGE_LDS_FLOATS = 8192;   // 32 KiB of staging per block
-constexpr int GATHER_WIDE_MAXIT = 2;     // wide-row window path: rows of up to 2 x 64 float4 = 512 floats (config 4: 376)
 
 struct GatherKey {
   const float *src;  // [maxlen, pitch] (+ column offset already applied)
@@ -131,48 +130,11 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather_windows(GatherArgs a)
       float *dp = dst0 + r;
       for (int t = 0; t < nt; ++t) dp[t * tstride] = sp[t * dim];
     }
-  } else if (K.staged == 2) {
-    // wide float32 rows of a WINDOWED sample: a block = (window b, chunk of tchunk time steps).  The window start is drawn once
-    // per block; a wave takes rows t0 + wave, + 4, ... FOUR at a time - every 16-byte request of the four rows is issued
-    // before the first store (a row at a time left a wave with one or two requests in flight: 3.9 TB/s at config 4 where
-    // a device copy of the same bytes runs at 7).  The source rows of a window are one contiguous run.
-    const int b = local % B, tc = local / B;
-    const int t0 = tc * K.tchunk, nt = min(K.tchunk, T - t0);
-    const long long st = window_start(a, b);
-    if (a.starts_out && ki == 0 && tc == 0 && tid == 0) a.starts_out[b] = st;
-    const int d4 = dim >> 2, nit = (d4 + 63) >> 6;
-    const long long p4 = K.pitch >> 2;
-    const float4 *src4 = reinterpret_cast<const float4 *>(K.src);
-    float4 *dst4 = reinterpret_cast<float4 *>(K.dst);
-    constexpr int NWV = GATHER_THREADS / 64, UR = 4;
-    for (int tb = wave; tb < nt; tb += NWV * UR) {
-      float4 v[UR][GATHER_WIDE_MAXIT];
-#pragma unroll
-      for (int u = 0; u < UR; ++u) {
-        const int t = tb + u * NWV;
-        long long srow = st + t0 + (t < nt ? t : tb);
-        if (srow >= len) srow %= len;
-        const float4 *sp = src4 + srow * p4;
-#pragma unroll
-        for (int i = 0; i < GATHER_WIDE_MAXIT; ++i) {
-          const int e = lane + 64 * i;
-          if (i < nit && e < d4) v[u][i] = sp[e];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < UR; ++u) {
-        const int t = tb + u * NWV;
-        if (t >= nt) continue;
-        float4 *dp = dst4 + ((long long)(t0 + t) * B + b) * d4;
-#pragma unroll
-        for (int i = 0; i < GATHER_WIDE_MAXIT; ++i) {
-          const int e = lane + 64 * i;
-          if (i < nit && e < d4) dp[e] = v[u][i];
-        }
-      }
-    }
   } else {
-    // wide rows: one (t, b) row per wave iteration, lanes stride over the row
+    // wide rows: one (t, b) row per wave iteration, lanes stride over the row.  (Round 5 tried blocks of (window, 32 time steps)
+    // with four rows per wave in flight - contiguous 48 KB reads, rows scattered B x dim apart on the write side: 66 us against
+    // 41 us for this form at config 4, B = 1024 (profiles/r05_sampler_pmc.txt); consecutive (t, b) rows on consecutive waves
+    // keep the WRITE side contiguous, which is what matters.)
     const int rows = T * B;
     const int waves_total = K.blocks_b * (GATHER_THREADS / 64);
     for (int row = local * (GATHER_THREADS / 64) + wave; row < rows; row += waves_total) {
@@ -565,13 +527,6 @@ int gather(fdql_ring *r, int T, int B, long long modulus, const long long *start
       int tc = STAGE_LDS_FLOATS / (STAGE_WINDOWS * g.dim);
       g.tchunk = std::max(1, std::min(T, tc));
       g.blocks_b = (B + STAGE_WINDOWS - 1) / STAGE_WINDOWS;
-      g.blocks_t = (T + g.tchunk - 1) / g.tchunk;
-      total += g.blocks_b * g.blocks_t;
-    } else if (!g.u8 && T > 1 && (g.dim & 3) == 0 && (g.pitch & 3) == 0 && g.dim <= 256 * GATHER_WIDE_MAXIT &&
-               (reinterpret_cast<uintptr_t>(g.src) & 15) == 0 && (reinterpret_cast<uintptr_t>(g.dst) & 15) == 0) {
-      g.staged = 2;   // wide float32 rows of windows: blocks of (window, time chunk), four rows per wave in flight
-      g.tchunk = std::min(T, 32);
-      g.blocks_b = B;
       g.blocks_t = (T + g.tchunk - 1) / g.tchunk;
       total += g.blocks_b * g.blocks_t;
     } else {
