@@ -132,11 +132,9 @@ SIGNATURES = {
                                  _vp]),
     "fdql_agent_stats": (C.c_int, [_vp, C.POINTER(AgentStats)]),
     "fdql_agent_profile_update": (_i32, [_vp, C.POINTER(Batch), _vp, _vp, _u64, C.POINTER(KernelTime), _i32, _vp]),
-    "fdql_debug_set_gemm_variant": (C.c_int, [_i32]),
     "fdql_debug_set_gemm_dense_shape": (C.c_int, [_i32]),
     "fdql_test_gemm": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32,
                                  _i32, _vp]),
-    "fdql_debug_rowgemm_life": (C.c_int, [_vp, _i32]),
     "fdql_debug_side_copy": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "fdql_test_conv": (C.c_int, [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "fdql_test_wgrad_stat": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _vp]),

@@ -67,7 +67,7 @@ int chain_finalize(ChainProblem *probs, int nprob, int bm);
 hipError_t chain_launch(const ChainProblem *probs_dev, int nprob, const ChainOp *ops_dev, int total_blocks, int lds_floats, int bm,
                         hipStream_t stream);
 double chain_op_flops(const ChainOp &op, int rows);
-int chain_read_stamps(unsigned long long *out, int cap);   // diagnostic (FDQL_CHAIN_STAMPS): s_memtime per operation of the last launch
+int chain_read_stamps(unsigned long long *out, int cap);   // diagnostic (chain_enable_stamps): s_memtime per operation of the last launch
 void chain_enable_stamps(int on);
 
 }  // namespace fdql

@@ -54,7 +54,7 @@ __device__ __forceinline__ const float *ch_uni(const float *p) {
   return reinterpret_cast<const float *>(((uintptr_t)hi << 32) | lo);
 }
 
-// Diagnostic stamps (FDQL_CHAIN_STAMPS=1 -> chain_read_stamps): the workgroup in the middle of a launch records
+// Diagnostic stamps (fdql_debug_chain_stamps(NULL, 1) -> chain_read_stamps): the workgroup in the middle of a launch records
 // s_memtime at its entry, after the program fetch and after every operation.
 __device__ unsigned long long g_ch_stamps[8 * CH_MAX_OPS + 4];
 __device__ int g_ch_stamps_on = 0;
@@ -674,7 +674,6 @@ hipError_t chain_launch(const ChainProblem *probs_dev, int nprob, const ChainOp 
       if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<1>), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_FLOATS * 4);
       if (e != hipSuccess) return e;
-      if (getenv("FDQL_CHAIN_STAMPS")) chain_enable_stamps(1);
       attr_set[dev] = true;
     }
   }

@@ -29,14 +29,45 @@ void set_error(const char *fmt, ...);
     }                                \
   } while (0)
 
-// Compute units the persistent one-workgroup-per-CU launches (wstat / wgrad / rowgemm) may occupy: all of them, minus
-// FDQL_CU_RESERVE (tuning hook, read when a plan is built).  A data-parallel job can leave a few CUs to the collective's
-// channel kernels, which cannot share a CU with a workgroup that holds ~158 KB of LDS (tools/dp_overlap.py measures both ways).
-inline int cu_budget(int ncu) {
-  const char *e = getenv("FDQL_CU_RESERVE");
-  const int r = e ? atoi(e) : 0;
-  return (r > 0 && r < ncu - 16) ? ncu - r : ncu;
-}
+// Compute units the persistent one-workgroup-per-CU launches (wstat / wgrad / conv) may occupy: all of them.  (Round 4 measured
+// leaving 16 / 32 CUs to a collective's channel kernels - FDQL_CU_RESERVE, profiles/r04_dp_overlap.txt: a net loss; the knob is gone.)
+inline int cu_budget(int ncu) { return ncu; }
+
+// ---------------------------------------------------------------------------------------
+// Plan switches: every environment variable the library reads, in ONE place (agent.hip, plan_switches_refresh).  Read when an
+// agent is created (and by the test hooks); each alternative they select is a parity case of tests/ - the second implementation
+// a kernel family is checked against.  Defaults = what bench.py measures.
+// ---------------------------------------------------------------------------------------
+struct PlanSwitches {
+  int chain = 1;                  // FDQL_CHAIN: 0 never / 1 encoder -> joiner -> actors as one k_chain launch when the batch fills the chip /
+                                  //   2 ("enc") that chain whatever the size / 3 ("all") the critics as chain programs too
+  long long rows_min_tiles = 256; // FDQL_ROWGEMM: "0" no row-block / stationary launches (1 << 60), "all" every eligible group whatever its
+  bool rows_all = false;          //   size (1; also drops the size thresholds of k_wgrad_stat and k_rowdgrad), a number = the threshold
+  bool rowdgrad = true;           // FDQL_ROWDGRAD=0: single-network dgrads on the tile kernel
+  bool rowdgrad_chain = true;     // FDQL_NO_ROWDGRAD_CHAIN: the three dgrads behind d state as launches of their own
+  bool wgrad_stat = true;         // FDQL_WGRAD_STAT=0: dense weight gradients ride in the dgrad launches (tile kernel K-split)
+  bool wgrad_riders = true;       // FDQL_WGRAD_RIDERS=0: head / action-column gradients on their own launches
+  int stream_wgrad = 1;           // FDQL_STREAM_WGRAD: 0 narrow gradients on the tile kernels / 1 streaming launch where slabs are short / 2 always
+  bool small_gemm = true;         // FDQL_SMALL_GEMM=0: small stages on the tile kernels
+  bool colsum_stream = true;      // FDQL_NO_COLSUM_STREAM: column sums in k_skinny_wgrad's launch
+  bool gate_masks = true;         // FDQL_NO_GATE_MASKS
+  bool head_dgrad_masked = true;  // FDQL_NO_HEAD_DGRAD_MASKED
+  bool head_fuse = true;          // FDQL_NO_HEAD_FUSE
+  bool head_presum = true;        // FDQL_NO_HEAD_PRESUM
+  bool dual = true;               // FDQL_NO_DUAL
+  bool fuse_dpre1 = true;         // FDQL_NO_FUSE_DPRE1
+  bool policy_dpre_fuse = true;   // FDQL_NO_POLICY_DPRE_FUSE
+  bool small_folds = true;        // FDQL_NO_SMALL_FOLDS: prep and the loss finish as launches of their own
+  bool loss_wave = true;          // FDQL_LOSS_WAVE=0: thread-per-atom TQC loss
+  bool gru_scan = true;           // FDQL_GRU_SCAN=0: step-by-step GRU launches
+  bool act_fuse = true;           // FDQL_ACT_NO_FUSE: act() one launch per layer
+  bool implicit_conv = true;      // FDQL_NO_IMPLICIT_CONV: conv layers on im2col + GEMM + col2im
+  bool graph = false;             // FDQL_GRAPH=1: hipGraph replay of a plan
+  bool no_buckets = false, force_buckets = false;   // FDQL_NO_BUCKETS / FDQL_FORCE_BUCKETS (data-parallel plans)
+  int plan_cache = -1;            // FDQL_PLAN_CACHE: finished plans kept (-1: default)
+};
+const PlanSwitches &plan_switches();   // as of the last refresh
+void plan_switches_refresh();          // re-reads the environment (fdql_agent_create, the fdql_test_* hooks)
 
 // ---------------------------------------------------------------------------------------
 // Grouped, K-segmented fp32 MFMA GEMM (gemm.hip)
@@ -55,8 +86,7 @@ struct GemmSeg {
 
 enum GemmEpilogue { EPI_NONE = 0, EPI_LRELU = 1, EPI_LRELU_GRAD = 2, EPI_ADD_REF = 3 /* x += ref[row][col] */ };
 enum GemmShape { GEMM_128x128 = 0, GEMM_128x32 = 1, GEMM_32x128 = 2, GEMM_64x128 = 3, GEMM_64x128_DUAL = 4, GEMM_64x64 = 5, GEMM_64x64_HF = 6,
-                 GEMM_DMA_128x128 = 7, GEMM_DMA_128x64 = 8, GEMM_DMA_64x64 = 9 /* LDS-DMA staged dense shapes */,
-                 GEMM_SMALL = 10 /* smallgemm.hip: 64x32 tiles, K split over the 16 waves of a workgroup (small batches) */, GEMM_NSHAPES = 11 };
+                 GEMM_SMALL = 7 /* smallgemm.hip: 64x32 tiles, K split over the 16 waves of a workgroup (small batches) */, GEMM_NSHAPES = 8 };
 
 struct GemmProblem {
   int M, N;
@@ -80,7 +110,7 @@ struct GemmProblem {
   const float *hf_w;
   int hf_ldw, hf_q;
   float *hf_out, *hf_out2;
-  // Fused head dgrad (row-block kernel, rowgemm.hip, only): the 256-wide segment's A operand is not read from memory
+  // Fused head dgrad (weight-stationary row-block kernel, wstat.hip, only): the 256-wide segment's A operand is not read from memory
   // but formed while the tile is staged,  A[m][k] = LeakyReLU'(fz_h[m][k]) * sum_q dY[m][q] * fz_w[q*fz_ldw + k]  with dY
   // the problem's narrow segment (that is k_head_dgrad's formula: the gradient of the last hidden layer under a narrow
   // head), written to fz_out [M, 256] for the weight gradients, its per-64-row column sums to fz_colsum.
@@ -113,9 +143,6 @@ hipError_t gemm_launch(const GemmProblem *probs_dev, int nprob, int total_blocks
 // Small-batch kernel (smallgemm.hip): does it take the problem's form (no K-split slabs, no second output / head fusion)?
 bool gemm_small_takes(const GemmProblem &p);
 hipError_t gemm_small_launch(const GemmProblem *probs_dev, int nprob, int total_blocks, hipStream_t stream);
-constexpr int GEMM_DEFAULT_VARIANT = 1;
-int gemm_variant();
-void gemm_set_variant(int v);
 
 // Which problem of a launch group a workgroup belongs to (problems sorted by their first block id): ONE vector load round -
 // lane i looks at problem i, ballot, highest set bit - instead of a chain of up to nprob dependent loads; with a handful

@@ -803,11 +803,11 @@ using W2Cfg = WgCfg<L2, G_W2, 2, 2>;   // 3 kernel rows x 2 channel halves x 2 r
 }  // namespace
 
 bool conv_fwd_takes(const ConvGeom &g, int cout, bool u8) {
-  if (getenv("FDQL_NO_IMPLICIT_CONV")) return false;
+  if (!plan_switches().implicit_conv) return false;
   return u8 ? geo_is<L0>(g, cout) : (geo_is<L1>(g, cout) || geo_is<L2>(g, cout));
 }
 bool conv_dgrad_takes(const ConvGeom &g, int cout) {
-  if (getenv("FDQL_NO_IMPLICIT_CONV")) return false;
+  if (!plan_switches().implicit_conv) return false;
   return geo_is<L1>(g, cout) || geo_is<L2>(g, cout);
 }
 bool conv_wgrad_takes(const ConvGeom &g, int cout, bool u8) { return conv_fwd_takes(g, cout, u8); }

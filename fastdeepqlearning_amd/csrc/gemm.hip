@@ -17,7 +17,8 @@
 // LDS buffer after them (one barrier per chunk); a chunk's MFMA k-steps run at raised wave priority.
 //
 // Two kernels live here: k_gemm_grouped (register-staged, described above: the default for every shape) and, further
-// down, k_gemm_dma (operands by LDS-DMA into a ring of chunk images; dense shapes 7/8/9, selectable, see its header).
+// down.  (Round 2's LDS-DMA build of the dense shapes, k_gemm_dma, lost against this kernel on every stage of the update for three
+// rounds and was removed in round 5: profiles/r02_* keep its measurements.)
 #include "common.h"
 
 #include <cstdarg>
@@ -238,22 +239,6 @@ __device__ __forceinline__ void store_chunk_kc(float *__restrict__ lds, int tid,
   }
 }
 
-// K-contiguous operand kept K-contiguous in LDS (variant 5): [row][16 k] with the four 16-byte slots of a row permuted
-// by (row >> 2) & 3, ONE ds_write_b128 per thread instead of a transposing set of ds_write_b32; the fragment reads are
-// then two conflict-free ds_read_b128 per operand and chunk instead of eight ds_read_b32 (every LDS instruction costs
-// MFMA issue time: profiles/r02_rowgemm_notes.txt).
-template <int R, int NV, int BKT>
-__device__ __forceinline__ void store_chunk_kc128(float *__restrict__ lds, int tid, const float (&v)[4 * NV]) {
-  static_assert(BKT == 16, "four float4 slots per row");
-#pragma unroll
-  for (int h = 0; h < NV; ++h) {
-    const int slot = tid + GEMM_THREADS * h;
-    const int kq = slot & 3, r = slot >> 2;
-    if (r < R)
-      *reinterpret_cast<float4 *>(&lds[r * 16 + ((kq ^ ((r >> 2) & 3)) << 2)]) = make_float4(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
-  }
-}
-
 template <int R, int NV, int BKT>
 __device__ __forceinline__ void store_chunk_ks(float *__restrict__ lds, int tid, const float (&v)[4 * NV]) {
   constexpr int PITCH = R + 4, RQ = R / 4;
@@ -353,7 +338,7 @@ __device__ __forceinline__ void hf_partial(const f32x16 &acc, float bv, int epi,
   }
 }
 
-template <int SHAPE, int BK, int PIPE>
+template <int SHAPE, int BK>
 __global__ __launch_bounds__(GEMM_THREADS, TileCfg<SHAPE>::MINB) void k_gemm_grouped(const GemmProblem *__restrict__ probs, int nprob) {
   using Cfg = TileCfg<SHAPE>;
   constexpr int BM = Cfg::WM * Cfg::TM * 32, BN = Cfg::WN * Cfg::TN * 32;
@@ -439,11 +424,10 @@ __global__ __launch_bounds__(GEMM_THREADS, TileCfg<SHAPE>::MINB) void k_gemm_gro
     vob = operand_lane_off<BN, BK>(sldb, sbkc, tid);
   };
   float va[4 * NVA], vb[4 * NVB];
-  constexpr bool F128 = PIPE == 2;
   auto stage = [&](int buf, int akc, int bkc) {
-    if (akc) { if constexpr (F128) store_chunk_kc128<BM, NVA, BK>(lds[buf], tid, va); else store_chunk_kc<BM, NVA, BK>(lds[buf], tid, va); }
+    if (akc) store_chunk_kc<BM, NVA, BK>(lds[buf], tid, va);
     else store_chunk_ks<BM, NVA, BK>(lds[buf], tid, va);
-    if (bkc) { if constexpr (F128) store_chunk_kc128<BN, NVB, BK>(lds[buf] + BK * PA, tid, vb); else store_chunk_kc<BN, NVB, BK>(lds[buf] + BK * PA, tid, vb); }
+    if (bkc) store_chunk_kc<BN, NVB, BK>(lds[buf] + BK * PA, tid, vb);
     else store_chunk_ks<BN, NVB, BK>(lds[buf] + BK * PA, tid, vb);
   };
   if (have) {
@@ -457,84 +441,6 @@ __global__ __launch_bounds__(GEMM_THREADS, TileCfg<SHAPE>::MINB) void k_gemm_gro
   int c_akc = sakc, c_bkc = sbkc;   // operand forms of the chunk staged in lds[cur] (F128 picks its fragment reads by them)
   // MFMAs of the chunk staged in lds[cur] (k, ke: its position in the current segment)
   auto run_chunk = [&]() {
-    if constexpr (F128) {
-      // k-pairing of an MFMA step: lanes lh = 0 supply k = kk, lanes lh = 1 k = 8 + kk (kk = 0..7; both operands agree).
-      // K-contiguous operand: the lane's 8 k's are two float4 slots of its row; K-strided operand: [k][row] as before.
-      const int ksteps = min(8, ke - k);
-      v4f fa[TM][2], fb[TN][2];
-      float sa[TM][8], sb[TN][8];
-      if (c_akc) {
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-          const int row = wm * (TM * 32) + tm * 32 + li, sw = (row >> 2) & 3;
-          const unsigned base = lds_addr(lds[cur] + row * 16);
-          frag_read_b128<0>(fa[tm][0], base + ((unsigned)((2 * lh) ^ sw) << 4));
-          frag_read_b128<0>(fa[tm][1], base + ((unsigned)((2 * lh + 1) ^ sw) << 4));
-        }
-      } else {
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-          const unsigned base = lds_addr(lds[cur] + wm * (TM * 32) + tm * 32 + li + lh * 8 * PA);
-#pragma unroll
-          for (int kk = 0; kk < 8; ++kk) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=&v"(sa[tm][kk]) : "v"(base), "n"(kk * PA * 4));
-        }
-      }
-      if (c_bkc) {
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-          const int row = wn * (TN * 32) + tn * 32 + li, sw = (row >> 2) & 3;
-          const unsigned base = lds_addr(lds[cur] + BK * PA + row * 16);
-          frag_read_b128<0>(fb[tn][0], base + ((unsigned)((2 * lh) ^ sw) << 4));
-          frag_read_b128<0>(fb[tn][1], base + ((unsigned)((2 * lh + 1) ^ sw) << 4));
-        }
-      } else {
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-          const unsigned base = lds_addr(lds[cur] + BK * PA + wn * (TN * 32) + tn * 32 + li + lh * 8 * PB);
-#pragma unroll
-          for (int kk = 0; kk < 8; ++kk) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=&v"(sb[tn][kk]) : "v"(base), "n"(kk * PB * 4));
-        }
-      }
-      lds_wait<0>();
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
-        if (c_akc) {
-          asm volatile("" : "+v"(fa[tm][0]), "+v"(fa[tm][1]));
-#pragma unroll
-          for (int kk = 0; kk < 8; ++kk) sa[tm][kk] = fa[tm][kk >> 2][kk & 3];
-        } else {
-#pragma unroll
-          for (int kk = 0; kk < 8; ++kk) asm volatile("" : "+v"(sa[tm][kk]));
-        }
-      }
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        if (c_bkc) {
-          asm volatile("" : "+v"(fb[tn][0]), "+v"(fb[tn][1]));
-#pragma unroll
-          for (int kk = 0; kk < 8; ++kk) sb[tn][kk] = fb[tn][kk >> 2][kk & 3];
-        } else {
-#pragma unroll
-          for (int kk = 0; kk < 8; ++kk) asm volatile("" : "+v"(sb[tn][kk]));
-        }
-      }
-#if FDQL_MFMA_PRIO
-      __builtin_amdgcn_s_setprio(FDQL_MFMA_PRIO);
-#endif
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        if (kk >= ksteps) break;   // wave-uniform
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[tm][kk], sb[tn][kk], acc[tm][tn], 0, 0, 0);
-      }
-#if FDQL_MFMA_PRIO
-      __builtin_amdgcn_s_setprio(0);
-#endif
-      return;
-    }
     // Fragment reads are written as inline `ds_read_b32` with EARLY-CLOBBER destinations and explicit
     // lgkmcnt waits.  Reason (observed twice on gfx950, reproducible, LDS contents verified by a dump):
     // when hipcc allocates a fragment's destination VGPR on top of that read's own address VGPR
@@ -562,7 +468,7 @@ __global__ __launch_bounds__(GEMM_THREADS, TileCfg<SHAPE>::MINB) void k_gemm_gro
       }
       float(&ac)[TM] = a[kk & 1];
       float(&bc)[TN] = b[kk & 1];
-      if (PIPE && kk + 1 < NS) {
+      if (kk + 1 < NS) {
         // next k-step's fragments are requested before this step's MFMAs issue; LDS returns in order,
         // so "at most TM+TN reads outstanding" means this step's fragments have landed
         frag_read_dyn<TM, PA>(a[(kk + 1) & 1], la, kk + 1);
@@ -578,10 +484,6 @@ __global__ __launch_bounds__(GEMM_THREADS, TileCfg<SHAPE>::MINB) void k_gemm_gro
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[tm], bc[tn], acc[tm][tn], 0, 0, 0);
-      if (!PIPE && kk + 1 < NS) {
-        frag_read_dyn<TM, PA>(a[(kk + 1) & 1], la, kk + 1);
-        frag_read_dyn<TN, PB>(b[(kk + 1) & 1], lb, kk + 1);
-      }
     }
     // the two base registers stay reserved until every read of the chunk has returned, so no
     // fragment destination is ever allocated on top of an address still in use by an in-flight read
@@ -716,436 +618,8 @@ __global__ __launch_bounds__(GEMM_THREADS, TileCfg<SHAPE>::MINB) void k_gemm_gro
   }
 }
 
-// =================================================================================================
-// Dense shapes: operands staged by LDS-DMA (global_load_lds_dwordx4) into a ring of NBUF chunk images
-// =================================================================================================
-// Why (measured on MI355X, 192000 x 256 x 256, random operands; tools/proto): the register-staged kernel above keeps ONE
-// 16-deep chunk of loads in flight per wave and reaches 72 TF; the same tile fed by a 3-chunks-ahead LDS-DMA ring 98 TF,
-// and - with the staging registers gone - 128x128 tiles 115 TF.  What the old kernel was short of was memory-level
-// parallelism per workgroup, not occupancy.
-//
-// Chunk image of an operand with R tile rows (R = 64 or 128), 16 k's, written in 1-KiB pieces (one wave-instruction:
-// LDS address = wave-uniform base + lane * 16 B, so the image is lane-linear and any swizzle goes on the SOURCE address):
-//   K-contiguous operand (kc): [R rows][4 float4 slots]; slot s of row r holds k-group s ^ ((r >> 2) & 3).  A piece is 16
-//     rows; fragments are ds_read_b128 (conflict-free with that key): lane half lh takes k-group 2j + lh for j = 0, 1, and
-//     component c of it feeds MFMA k-step 4j + c - both operands pair the same k's, and the order inside one fp32 sum
-//     changes only from k-ascending to a fixed permutation of it (same 1e-5 budget).
-//   K-strided operand (ks):    [16 k][R rows]; a piece is 256 / R k-rows; fragments are ds_read_b32 at the k's above.
-// A chunk that is not an interior full chunk (edge tiles, a segment's ragged tail, the 6 action columns ...) is fetched
-// with guarded loads and written to the same image by ds_write_b128: same consumer, exact zeros in the padding.
-//
-// Ring protocol per chunk c (D = NBUF - 1 chunks requested ahead): counted s_waitcnt vmcnt -> own DMA of chunk c retired;
-// lgkmcnt(0) -> own ds_writes retired; s_barrier -> everyone's are, and everyone has finished reading chunk c - 1;
-// request chunk c + D into the image chunk c - 1 used; read fragments of chunk c; MFMA.  The vmcnt count is exact:
-// PER DMA instructions per wave for every DMA chunk requested after c (tracked in a bit history), 0 for guarded ones.
-typedef __attribute__((address_space(3))) void *lds_vp;
-typedef const __attribute__((address_space(1))) void *glb_vp;
-
-template <int SHAPE> struct DmaCfg;
-#ifndef FDQL_DMA_NBUF_128
-#define FDQL_DMA_NBUF_128 3   // 48 KB -> 3 workgroups per CU: 88.9 TF vs 81.4 with 4 images (2 per CU) at 192000x256x256
-#endif
-template <> struct DmaCfg<GEMM_DMA_128x128> { static constexpr int TM = 2, TN = 2, NBUF = FDQL_DMA_NBUF_128, MINB = FDQL_DMA_NBUF_128 == 3 ? 3 : 2; };
-template <> struct DmaCfg<GEMM_DMA_128x64> { static constexpr int TM = 2, TN = 1, NBUF = 4, MINB = 3; };
-template <> struct DmaCfg<GEMM_DMA_64x64> { static constexpr int TM = 1, TN = 1, NBUF = 5, MINB = 4; };
-
-template <int OFF>
-__device__ __forceinline__ void lds_read_b128(v4f &d, unsigned addr) {
-  static_assert(OFF >= 0 && OFF < 65536, "ds_read_b128 offset field is 16 bits");
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(d) : "v"(addr), "n"(OFF));
-}
-template <int N>
-__device__ __forceinline__ void vm_wait() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// fragments of read group J (k-groups 2J, 2J+1) for T 32-row MFMA tiles of one operand
-template <int T, int R, int J>
-__device__ __forceinline__ void dma_frag_kc(v4f (&f)[T], unsigned a0, unsigned a1) {
-  const unsigned a = J ? a1 : a0;
-  lds_read_b128<0>(f[0], a);
-  if constexpr (T > 1) lds_read_b128<2048>(f[1], a);   // 32 rows x 64 B
-}
-template <int T, int R, int J>
-__device__ __forceinline__ void dma_frag_ks(v4f (&f)[T], unsigned a) {
-#pragma unroll
-  for (int t = 0; t < T; ++t) {
-    float x, y, z, w;
-    if (t == 0) {
-      lds_read_b32<((8 * J + 0) * R) * 4>(x, a); lds_read_b32<((8 * J + 1) * R) * 4>(y, a);
-      lds_read_b32<((8 * J + 2) * R) * 4>(z, a); lds_read_b32<((8 * J + 3) * R) * 4>(w, a);
-    } else {
-      lds_read_b32<((8 * J + 0) * R + 32) * 4>(x, a); lds_read_b32<((8 * J + 1) * R + 32) * 4>(y, a);
-      lds_read_b32<((8 * J + 2) * R + 32) * 4>(z, a); lds_read_b32<((8 * J + 3) * R + 32) * 4>(w, a);
-    }
-    asm volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(w));   // keep the four destinations distinct until packed
-    f[t] = v4f{x, y, z, w};
-  }
-}
-
-template <int SHAPE>
-__global__ __launch_bounds__(GEMM_THREADS, DmaCfg<SHAPE>::MINB) void k_gemm_dma(const GemmProblem *__restrict__ probs, int nprob) {
-  using Cfg = DmaCfg<SHAPE>;
-  constexpr int TM = Cfg::TM, TN = Cfg::TN, NBUF = Cfg::NBUF, D = NBUF - 1, PER = TM + TN;
-  constexpr int BM = 64 * TM, BN = 64 * TN, BK = 16, OPA = BM * BK, OPB = BN * BK;
-  static_assert(TM <= 2 && TN <= 2 && D >= 2 && D <= 4, "tile / ring limits of this kernel");
-  __shared__ __attribute__((aligned(16))) float lds[NBUF][OPA + OPB];
-
-  const int tid = threadIdx.x;
-  const int bid = blockIdx.x;
-  const int pi = find_problem<GemmProblem, &GemmProblem::tile_start>(probs, nprob, bid, tid & 63);   // one load round
-  const GemmProblem &P = probs[pi];
-
-  const int M = uni(P.M), N = uni(P.N), nseg = uni(P.nseg), ksplit = uni(P.ksplit);
-  const int tiles_n = uni(P.tiles_n);
-  // segment 0's descriptor rides in the same round as the header (the ring starts there unless it is empty)
-  const float *s0A = uni(P.seg[0].A), *s0B = uni(P.seg[0].B);
-  const int s0lda = uni(P.seg[0].lda), s0ldb = uni(P.seg[0].ldb), s0akc = uni(P.seg[0].a_kc), s0bkc = uni(P.seg[0].b_kc);
-  const int emit_seg = uni(P.emit_seg);
-  const int local = bid - uni(P.tile_start);
-  const int tiles_mn = uni(P.tiles_m) * tiles_n;
-  const int split = local / tiles_mn;
-  const int rem = local - split * tiles_mn;
-  int tile_m, tile_n;   // XCD-local order: see k_gemm_grouped
-  {
-    const int tiles_m = uni(P.tiles_m), full = (tiles_m >> 3) << 3;
-    if (rem < full * tiles_n) {
-      const int grp = rem / (8 * tiles_n), r = rem - grp * 8 * tiles_n;
-      tile_n = r >> 3;
-      tile_m = grp * 8 + (r & 7);
-    } else {
-      const int r = rem - full * tiles_n;
-      tile_m = full + r / tiles_n;
-      tile_n = r - (r / tiles_n) * tiles_n;
-    }
-  }
-  const int r0 = tile_m * BM, c0 = tile_n * BN;
-  const int K0 = uni(P.seg[0].K);
-  int kb0 = 0, ke0 = K0;
-  if (ksplit > 1) {
-    const int per = ((K0 + ksplit - 1) / ksplit + BK - 1) / BK * BK;
-    kb0 = split * per;
-    ke0 = min(K0, kb0 + per);
-  }
-
-  const int lane = tid & 63, wave = uni(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int li = lane & 31, lh = lane >> 5;
-  const bool interior = (r0 + BM <= M) && (c0 + BN <= N);
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int a = 0; a < TM; ++a)
-#pragma unroll
-    for (int b = 0; b < TN; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  // ---- producer side: where this lane's 16 bytes of a piece come from (tile-local), per layout
-  const int kc_row = 16 * wave + (lane >> 2);                      // piece i adds 64 rows
-  const int kc_k = 4 * ((lane & 3) ^ ((lane >> 4) & 3));           // swizzled k-group of the lane's slot
-  constexpr int RPA = 256 / BM, RPB = 256 / BN;                    // k-rows per piece of a ks image
-  const int ksa_k = RPA * wave + lane / (BM / 4), ksa_r = (lane % (BM / 4)) * 4;   // piece i adds 4 * RPA k-rows
-  const int ksb_k = RPB * wave + lane / (BN / 4), ksb_r = (lane % (BN / 4)) * 4;
-  // descriptor of the segment being requested; pA / pB walk along k (scalar pointers to the tile's first element of the
-  // next chunk to request), so a request costs two 64-bit scalar adds instead of the address arithmetic from scratch
-  int sakc = 1, sbkc = 1;
-  gcf pA = nullptr, pB = nullptr;
-  long long incA = 0, incB = 0, stA = 0, stB = 0;   // elements per chunk step / per piece step
-  unsigned voa = 0, vob = 0;
-  auto fetch_issue = [&](int idx, int k) __attribute__((always_inline)) {
-    const float *sA = s0A, *sB = s0B;
-    int slda = s0lda, sldb = s0ldb;
-    sakc = s0akc; sbkc = s0bkc;
-    if (idx != 0) {
-      const GemmSeg &S = P.seg[idx];
-      sA = uni(S.A); sB = uni(S.B); slda = uni(S.lda); sldb = uni(S.ldb); sakc = uni(S.a_kc); sbkc = uni(S.b_kc);
-    }
-    voa = sakc ? (unsigned)(kc_row * slda + kc_k) : (unsigned)(ksa_k * slda + ksa_r);
-    vob = sbkc ? (unsigned)(kc_row * sldb + kc_k) : (unsigned)(ksb_k * sldb + ksb_r);
-    pA = (gcf)(sakc ? sA + (long long)r0 * slda + k : sA + (long long)k * slda + r0);
-    pB = (gcf)(sbkc ? sB + (long long)c0 * sldb + k : sB + (long long)k * sldb + c0);
-    incA = sakc ? BK : (long long)BK * slda;
-    incB = sbkc ? BK : (long long)BK * sldb;
-    stA = (long long)(sakc ? 64 : 4 * RPA) * slda;
-    stB = (long long)(sbkc ? 64 : 4 * RPB) * sldb;
-  };
-  unsigned hist = 0;   // bit i: the (i+1)-th most recently requested chunk went by DMA
-  auto issue = [&](int buf, int kl) __attribute__((always_inline)) {   // kl: k's left in the segment
-    float *img = lds[buf];
-    gcf baseA = pA, baseB = pB;
-    pA += incA; pB += incB;
-    if (interior && kl >= BK) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        __builtin_amdgcn_global_load_lds((glb_vp)(baseA + i * stA + voa), (lds_vp)(img + (wave + 4 * i) * 256), 16, 0, 0);
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-        __builtin_amdgcn_global_load_lds((glb_vp)(baseB + i * stB + vob), (lds_vp)(img + OPA + (wave + 4 * i) * 256), 16, 0, 0);
-      hist = (hist << 1) | 1u;
-      return;
-    }
-    // guarded path: same lane -> (source, image position) map, zeros outside the operand
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      gcf p = baseA + i * stA + voa;
-      v4f v;
-      if (sakc) {
-        const bool rok = r0 + kc_row + 64 * i < M;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (rok && kc_k + j < kl) ? p[j] : 0.f;
-      } else {
-        const bool kok = ksa_k + 4 * RPA * i < kl;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (kok && r0 + ksa_r + j < M) ? p[j] : 0.f;
-      }
-      *reinterpret_cast<v4f *>(img + (wave + 4 * i) * 256 + lane * 4) = v;
-    }
-#pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      gcf p = baseB + i * stB + vob;
-      v4f v;
-      if (sbkc) {
-        const bool rok = c0 + kc_row + 64 * i < N;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (rok && kc_k + j < kl) ? p[j] : 0.f;
-      } else {
-        const bool kok = ksb_k + 4 * RPB * i < kl;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (kok && c0 + ksb_r + j < N) ? p[j] : 0.f;
-      }
-      *reinterpret_cast<v4f *>(img + OPA + (wave + 4 * i) * 256 + lane * 4) = v;
-    }
-    hist <<= 1;
-  };
-
-  // ---- consumer side: byte offsets of this lane's fragments inside a chunk image
-  const int ra = wm * 32 * TM + li, rb = wn * 32 * TN + li;
-  const unsigned fa_kc0 = (unsigned)(ra * 4 + (lh ^ ((ra >> 2) & 3))) * 16, fa_kc1 = (unsigned)(ra * 4 + ((2 + lh) ^ ((ra >> 2) & 3))) * 16;
-  const unsigned fb_kc0 = (unsigned)(rb * 4 + (lh ^ ((rb >> 2) & 3))) * 16 + OPA * 4, fb_kc1 = (unsigned)(rb * 4 + ((2 + lh) ^ ((rb >> 2) & 3))) * 16 + OPA * 4;
-  const unsigned fa_ks = (unsigned)(4 * lh * BM + ra) * 4, fb_ks = (unsigned)(4 * lh * BN + rb) * 4 + OPA * 4;
-  auto mfma_group = [&](v4f (&a)[TM], v4f (&b)[TN]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int t = 0; t < TM; ++t) asm volatile("" : "+v"(a[t]));   // orders the MFMAs behind the lgkmcnt wait
-#pragma unroll
-    for (int t = 0; t < TN; ++t) asm volatile("" : "+v"(b[t]));
-#if FDQL_MFMA_PRIO
-    __builtin_amdgcn_s_setprio(FDQL_MFMA_PRIO);
-#endif
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][c], b[tn][c], acc[tm][tn], 0, 0, 0);
-#if FDQL_MFMA_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
-  };
-  v4f fa[TM], fb[TN], ga[TM], gb[TN];   // fragments of the chunk being multiplied (read groups 0 and 1)
-  auto read_frags = [&](int buf, int akc, int bkc) __attribute__((always_inline)) {
-    const unsigned lb = lds_addr(lds[buf]);
-    const unsigned a0 = lb + fa_kc0, a1 = lb + fa_kc1, as = lb + fa_ks;
-    const unsigned b0 = lb + fb_kc0, b1 = lb + fb_kc1, bs = lb + fb_ks;
-    if (akc) { dma_frag_kc<TM, BM, 0>(fa, a0, a1); dma_frag_kc<TM, BM, 1>(ga, a0, a1); }
-    else { dma_frag_ks<TM, BM, 0>(fa, as); dma_frag_ks<TM, BM, 1>(ga, as); }
-    if (bkc) { dma_frag_kc<TN, BN, 0>(fb, b0, b1); dma_frag_kc<TN, BN, 1>(gb, b0, b1); }
-    else { dma_frag_ks<TN, BN, 0>(fb, bs); dma_frag_ks<TN, BN, 1>(gb, bs); }
-    asm volatile("" ::"v"(a0), "v"(a1), "v"(as), "v"(b0), "v"(b1), "v"(bs));   // addresses outlive the reads
-  };
-
-  // ---- the ring over the chunks of segments [seg_lo, seg_hi).  One loop does the D lead-in requests and the steady
-  // state (time step t requests chunk t and consumes chunk t - D), so the request / consume code exists once.
-  // Chunk order: phase 0 visits the ragged tails (K % 16 k's at the end of a segment, or all of a narrow one), phase 1
-  // the full chunks.  The guarded loads of a ragged chunk make hipcc wait vmcnt(0); first in line that drains nothing,
-  // in the middle of the stream it would stall the tile for a full memory round trip.  (K order inside the fp32 sum is a
-  // fixed permutation either way.)
-  struct Cur { int ph, s, k, ke; bool valid; };
-  auto step = [&](Cur &c, int seg_lo, int seg_hi) __attribute__((always_inline)) {   // to the next chunk of the sequence
-    if (c.ph == 1 && c.k + 2 * BK <= c.ke) { c.k += BK; return; }
-    for (;;) {
-      ++c.s;
-      if (c.s >= seg_hi) {
-        if (c.ph == 1) { c.valid = false; return; }
-        c.ph = 1; c.s = seg_lo - 1;
-        continue;
-      }
-      const int lo = c.s == 0 ? kb0 : 0, hi = c.s == 0 ? ke0 : uni(P.seg[c.s].K);
-      const int len = hi - lo;
-      if (len <= 0) continue;
-      const int full = len & ~(BK - 1);
-      if (c.ph == 0) {
-        if (len != full) { c.k = lo + full; c.ke = hi; return; }
-      } else if (full > 0) {
-        c.k = lo; c.ke = lo + full; return;
-      }
-    }
-  };
-  auto run = [&](int seg_lo, int seg_hi) __attribute__((always_inline)) {
-    if (ksplit > 1 && seg_lo > 0) return;
-    Cur ic{0, seg_lo - 1, 0, 0, true};
-    step(ic, seg_lo, seg_hi);
-    if (!ic.valid) return;
-    Cur cc = ic;
-    int cakc = cc.s == 0 ? s0akc : uni(P.seg[cc.s].a_kc), cbkc = cc.s == 0 ? s0bkc : uni(P.seg[cc.s].b_kc);
-    fetch_issue(ic.s, ic.k);
-    lds_wait<0>();
-    __builtin_amdgcn_s_barrier();   // nobody still reads an image of the previous pass
-    asm volatile("" ::: "memory");
-    hist = 0;
-    int ibuf = 0, cbuf = 0;
-#pragma unroll 1
-    for (int t = 0; cc.valid; ++t) {
-      if (t >= D) {
-        const int ahead = __builtin_popcount(hist & ((1u << (D - 1)) - 1u));   // DMA chunks requested after the one due now
-        switch (ahead) {
-          case 0: vm_wait<0>(); break;
-          case 1: vm_wait<PER>(); break;
-          case 2: vm_wait<2 * PER>(); break;
-          default: vm_wait<3 * PER>(); break;
-        }
-        lds_wait<0>();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        read_frags(cbuf, cakc, cbkc);   // in flight while the next request's addresses are formed
-      }
-      if (ic.valid) {
-        issue(ibuf, ic.ke - ic.k);
-        ibuf = ibuf + 1 == NBUF ? 0 : ibuf + 1;
-        const int was = ic.s, wask = ic.k;
-        step(ic, seg_lo, seg_hi);
-        if (ic.valid && (ic.s != was || ic.k != wask + BK)) fetch_issue(ic.s, ic.k);
-      } else {
-        hist <<= 1;
-      }
-      if (t >= D) {
-        lds_wait<0>();
-        mfma_group(fa, fb);
-        mfma_group(ga, gb);   // a chunk with fewer than 9 k's multiplies staged zeros here
-        cbuf = cbuf + 1 == NBUF ? 0 : cbuf + 1;
-        const int was = cc.s;
-        step(cc, seg_lo, seg_hi);
-        if (cc.valid && cc.s != was) { cakc = cc.s == 0 ? s0akc : uni(P.seg[cc.s].a_kc); cbkc = cc.s == 0 ? s0bkc : uni(P.seg[cc.s].b_kc); }
-      }
-    }
-  };
-
-  const int nseg_main = emit_seg >= 0 ? emit_seg + 1 : nseg;
-
-  // epilogue: D[i][j] of a 32x32 tile sits at col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  const int epi = P.epi;
-  gcf bias = (gcf)P.bias;
-  gcf ref = (gcf)P.ref;
-  const int ldref = P.ldref;
-  float csum[TN];
-#pragma unroll
-  for (int tn = 0; tn < TN; ++tn) csum[tn] = 0.f;
-  auto store_tile = [&](gf C, int ldc, bool second) __attribute__((always_inline)) {
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        const int col = c0 + (wn * TN + tn) * 32 + li;
-        if (col >= N) continue;
-        const float bv = bias ? bias[col] : 0.f;
-        // the 16 reference values of the tile first, then the stores: C and ref may alias as far as hipcc knows, so a
-        // load placed after a store waits for it - one exposed memory round trip per element
-        float rv[16];
-        if (epi == EPI_LRELU_GRAD || epi == EPI_ADD_REF) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = r0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            rv[r] = row < M ? ref[(long long)row * ldref + col] : 0.f;
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = r0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (row >= M) continue;
-          float x = acc[tm][tn][r];
-          x += bv;
-          if (epi == EPI_LRELU) x = x > 0.f ? x : 0.01f * x;
-          else if (epi == EPI_LRELU_GRAD) x = rv[r] > 0.f ? x : 0.01f * x;
-          else if (epi == EPI_ADD_REF) x += rv[r];
-          C[(long long)row * ldc + col] = x;
-          if (!second) csum[tn] += x;
-        }
-      }
-    }
-    gcf hw = (gcf)P.hf_w;
-    if (hw) {   // head fusion: see hf_partial; one plane per 32 output columns
-      const int Q = P.hf_q, ldw = P.hf_ldw, nplanes = ((N + 63) / 64) * 2;
-      gf out = (gf)(second ? P.hf_out2 : P.hf_out);
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-          const int col = c0 + (wn * TN + tn) * 32 + li;
-          const int plane = (c0 + (wn * TN + tn) * 32) / 32;
-          if (plane >= nplanes) continue;   // wave-uniform
-          const bool cok = col < N;
-          const float bv = (bias && cok) ? bias[col] : 0.f;
-          float wq[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) wq[q] = (q < Q && cok) ? hw[(long long)q * ldw + col] : 0.f;
-          const int rbase = r0 + (wm * TM + tm) * 32 + 4 * lh;
-          if (Q == 2) hf_partial<2>(acc[tm][tn], bv, epi, wq, cok, lane, M, rbase, out, plane);
-          else if (Q == 1) hf_partial<1>(acc[tm][tn], bv, epi, wq, cok, lane, M, rbase, out, plane);
-          else if (Q == 4) hf_partial<4>(acc[tm][tn], bv, epi, wq, cok, lane, M, rbase, out, plane);
-          else hf_partial<8>(acc[tm][tn], bv, epi, wq, cok, lane, M, rbase, out, plane);
-        }
-      }
-    }
-  };
-  // pass 0: segments [0, nseg_main) -> C.  Dual problems take a second pass: the tail segments are added on top of the
-  // stored sum and the tile is stored again into C2 (the loop keeps ring and epilogue code to one copy).
-#ifndef FDQL_DMA_PASS_LOOP
-#define FDQL_DMA_PASS_LOOP 0
-#endif
-#if FDQL_DMA_PASS_LOOP
-  const int npass = nseg > nseg_main ? 2 : 1;
-#pragma unroll 1
-  for (int pass = 0; pass < npass; ++pass) {
-    asm volatile("" ::: "memory");   // keeps the epilogue's loads (bias, head weights) from being hoisted above the ring
-    run(pass ? nseg_main : 0, pass ? nseg : nseg_main);
-    asm volatile("" ::: "memory");
-    store_tile(pass ? (gf)P.C2 : (gf)(P.C + (long long)split * P.split_stride), pass ? P.ldc2 : P.ldc, pass != 0);
-  }
-#else
-  run(0, nseg_main);
-  store_tile((gf)(P.C + (long long)split * P.split_stride), P.ldc, false);
-  if (nseg > nseg_main) {
-    run(nseg_main, nseg);
-    store_tile((gf)P.C2, P.ldc2, true);
-  }
-#endif
-  if (P.colsum) {
-    constexpr int RW = TM * 32;
-    constexpr int WPG = RW >= 64 ? 1 : 64 / RW;
-    constexpr int GROUPS = (BM + 63) / 64;
-    __syncthreads();
-    float *red = lds[0];  // [2 wave rows][2 lane halves][BN]
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) red[(wm * 2 + lh) * BN + (wn * TN + tn) * 32 + li] = csum[tn];
-    __syncthreads();
-    for (int e = tid; e < GROUPS * BN; e += GEMM_THREADS) {
-      const int g = e / BN, c = e - g * BN;
-      if (c0 + c < N && r0 + g * 64 < M) {
-        float t = 0.f;
-#pragma unroll
-        for (int j = 0; j < WPG * 2; ++j) t += red[(g * WPG * 2 + j) * BN + c];
-        ((gf)P.colsum)[(long long)(r0 / 64 + g) * N + c0 + c] = t;
-      }
-    }
-  }
-}
-
 static void shape_dims(int shape, int &bm, int &bn) {
   if (shape == GEMM_SMALL) { bm = 64; bn = 32; return; }
-  if (shape == GEMM_DMA_128x128) { bm = 128; bn = 128; return; }
-  if (shape == GEMM_DMA_128x64) { bm = 128; bn = 64; return; }
-  if (shape == GEMM_DMA_64x64) { bm = 64; bn = 64; return; }
   bm = shape == GEMM_32x128 ? 32 : ((shape == GEMM_64x128 || shape == GEMM_64x128_DUAL || shape == GEMM_64x64 || shape == GEMM_64x64_HF) ? 64 : 128);
   bn = shape == GEMM_128x32 ? 32 : ((shape == GEMM_64x64 || shape == GEMM_64x64_HF) ? 64 : (shape == GEMM_64x128_DUAL ? 64 * FDQL_DUAL_TN : 128));
 }
@@ -1170,36 +644,23 @@ int gemm_finalize(GemmProblem *probs, int nprob, int shape) {
 // more, smaller workgroups (5 per CU at 92 VGPRs / 25.6 KB LDS) hide the per-chunk load latency
 // better than the bigger tile's higher MFMA:LDS ratio helps.  `prefer_128` keeps the big tile
 // selectable for experiments (FDQL_GEMM_DENSE_SHAPE).
-static int g_dense_shape = -1;
+static int g_dense_shape = GEMM_64x64;
 void gemm_set_dense_shape(int shape) { g_dense_shape = shape; }
-int gemm_dense_shape() {
-  if (g_dense_shape < 0) {
-    const char *e = getenv("FDQL_GEMM_DENSE_SHAPE");   // tuning hook: 0 = 128x128, 3 = 64x128, 5 = 64x64 (default)
-    const int v = e ? atoi(e) : (int)GEMM_64x64;
-    g_dense_shape = gemm_shape_is_dense(v) ? v : (int)GEMM_64x64;
-  }
-  return g_dense_shape;
-}
-
-static bool shape_is_dma(int shape) { return shape == GEMM_DMA_128x128 || shape == GEMM_DMA_128x64 || shape == GEMM_DMA_64x64; }
+int gemm_dense_shape() { return g_dense_shape; }   // (test / tuning hook: fdql_debug_set_gemm_dense_shape)
 
 int gemm_pick_shape(const GemmProblem &p, int dense_shape) {
   if (dense_shape == GEMM_SMALL) {   // test hook: the small-batch kernel wherever it has the form, else the default shapes
     if (gemm_small_takes(p)) return GEMM_SMALL;
     dense_shape = GEMM_64x64;
   }
-  if (shape_is_dma(dense_shape)) {   // dual outputs and the head-fusion epilogue are run-time features of that kernel
-    if (p.emit_seg >= 0 || p.hf_w) return dense_shape;
-  } else {
-    if (p.emit_seg >= 0) return GEMM_64x128_DUAL;
-    if (p.hf_w) return GEMM_64x64_HF;
-  }
+  if (p.emit_seg >= 0) return GEMM_64x128_DUAL;
+  if (p.hf_w) return GEMM_64x64_HF;
   if (p.N <= 32) return GEMM_128x32;
   if (p.M <= 32 && !p.colsum) return GEMM_32x128;
   return dense_shape;
 }
 
-bool gemm_shape_is_dense(int shape) { return shape == GEMM_128x128 || shape == GEMM_64x128 || shape == GEMM_64x64 || shape_is_dma(shape); }
+bool gemm_shape_is_dense(int shape) { return shape == GEMM_128x128 || shape == GEMM_64x128 || shape == GEMM_64x64; }
 
 double gemm_flops(const GemmProblem &p) {
   double k = 0;
@@ -1213,58 +674,30 @@ double gemm_bytes(const GemmProblem &p) {
   return b + 4.0 * p.M * (double)p.N * p.ksplit;
 }
 
+// K-chunk 32 for a SMALL launch of the 64x64 shapes (at most two workgroups per CU: the launch is as long as one workgroup's K
+// loop, and half the chunks and barriers shorten that - temporal_len 2 0.380 -> 0.353 ms, one rank's share of config 4 at 128
+// windows 1.068 -> 1.058 ms); K-chunk 16 for big launches (81 instead of 63 VGPR cost them two waves per SIMD: config 4 at
+// B = 1024 6.09 -> 6.26 ms with 32 everywhere) and for the narrow shapes (116 VGPR at 32).  (The other builds of the main loop -
+// K-chunk 8, b128 fragments, no fragment prefetch - lost every measurement of rounds 2-4 and are gone.)
 template <int SHAPE>
-static void launch_shape(const GemmProblem *probs_dev, int nprob, int total_blocks, int variant, hipStream_t stream) {
+static void launch_shape(const GemmProblem *probs_dev, int nprob, int total_blocks, hipStream_t stream) {
   const dim3 g(total_blocks), b(GEMM_THREADS);
-  switch (variant) {
-    case 1:   // default: K-chunk 32 for a SMALL launch of the 64x64 shapes (at most two workgroups per CU: the launch is as long as
-              // one workgroup's K loop, and half the chunks and barriers shorten that - temporal_len 2 0.380 -> 0.353 ms, one rank's
-              // share of config 4 at 128 windows 1.068 -> 1.058 ms); K-chunk 16 for big launches (81 instead of 63 VGPR cost them two
-              // waves per SIMD: config 4 at B = 1024 6.09 -> 6.26 ms with 32 everywhere) and for the narrow shapes (116 VGPR at 32)
-      if constexpr (SHAPE == GEMM_64x64 || SHAPE == GEMM_64x64_HF) {
-        if (total_blocks <= 512) { hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 32, 1>), g, b, 0, stream, probs_dev, nprob); break; }
-      }
-      hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 16, 1>), g, b, 0, stream, probs_dev, nprob);
-      break;
-    case 6: hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 16, 1>), g, b, 0, stream, probs_dev, nprob); break;   // K-chunk 16 everywhere (round 2's default)
-    case 4: hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 8, 1>), g, b, 0, stream, probs_dev, nprob); break;
-    case 5:   // b128 fragments of K-contiguous operands: the 64x64 shapes only (the others spill at their register caps)
-      if constexpr (SHAPE == GEMM_64x64 || SHAPE == GEMM_64x64_HF) hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 16, 2>), g, b, 0, stream, probs_dev, nprob);
-      else hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 16, 1>), g, b, 0, stream, probs_dev, nprob);
-      break;
-    default: hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 16, 0>), g, b, 0, stream, probs_dev, nprob); break;
+  if constexpr (SHAPE == GEMM_64x64 || SHAPE == GEMM_64x64_HF) {
+    if (total_blocks <= 512) { hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 32>), g, b, 0, stream, probs_dev, nprob); return; }
   }
+  hipLaunchKernelGGL((k_gemm_grouped<SHAPE, 16>), g, b, 0, stream, probs_dev, nprob);
 }
-
-// variant: K-chunk / fragment-pipelining build of the kernel (FDQL_GEMM_VARIANT overrides, for experiments)
-static int g_variant = -1;
-int gemm_variant() {
-  if (g_variant < 0) {
-    const char *e = getenv("FDQL_GEMM_VARIANT");
-    g_variant = e ? atoi(e) : GEMM_DEFAULT_VARIANT;
-  }
-  return g_variant;
-}
-void gemm_set_variant(int v) { g_variant = v; }
 
 hipError_t gemm_launch(const GemmProblem *probs_dev, int nprob, int total_blocks, int shape, hipStream_t stream) {
   if (total_blocks <= 0) return hipSuccess;
   if (shape == GEMM_SMALL) return gemm_small_launch(probs_dev, nprob, total_blocks, stream);
-  if (shape_is_dma(shape)) {
-    const dim3 g(total_blocks), b(GEMM_THREADS);
-    if (shape == GEMM_DMA_128x128) hipLaunchKernelGGL((k_gemm_dma<GEMM_DMA_128x128>), g, b, 0, stream, probs_dev, nprob);
-    else if (shape == GEMM_DMA_128x64) hipLaunchKernelGGL((k_gemm_dma<GEMM_DMA_128x64>), g, b, 0, stream, probs_dev, nprob);
-    else hipLaunchKernelGGL((k_gemm_dma<GEMM_DMA_64x64>), g, b, 0, stream, probs_dev, nprob);
-    return hipGetLastError();
-  }
-  const int v = gemm_variant();
-  if (shape == GEMM_128x128) launch_shape<GEMM_128x128>(probs_dev, nprob, total_blocks, v, stream);
-  else if (shape == GEMM_128x32) launch_shape<GEMM_128x32>(probs_dev, nprob, total_blocks, v, stream);
-  else if (shape == GEMM_64x128) launch_shape<GEMM_64x128>(probs_dev, nprob, total_blocks, v, stream);
-  else if (shape == GEMM_64x128_DUAL) launch_shape<GEMM_64x128_DUAL>(probs_dev, nprob, total_blocks, v, stream);
-  else if (shape == GEMM_64x64) launch_shape<GEMM_64x64>(probs_dev, nprob, total_blocks, v, stream);
-  else if (shape == GEMM_64x64_HF) launch_shape<GEMM_64x64_HF>(probs_dev, nprob, total_blocks, v, stream);
-  else launch_shape<GEMM_32x128>(probs_dev, nprob, total_blocks, v, stream);
+  if (shape == GEMM_128x128) launch_shape<GEMM_128x128>(probs_dev, nprob, total_blocks, stream);
+  else if (shape == GEMM_128x32) launch_shape<GEMM_128x32>(probs_dev, nprob, total_blocks, stream);
+  else if (shape == GEMM_64x128) launch_shape<GEMM_64x128>(probs_dev, nprob, total_blocks, stream);
+  else if (shape == GEMM_64x128_DUAL) launch_shape<GEMM_64x128_DUAL>(probs_dev, nprob, total_blocks, stream);
+  else if (shape == GEMM_64x64) launch_shape<GEMM_64x64>(probs_dev, nprob, total_blocks, stream);
+  else if (shape == GEMM_64x64_HF) launch_shape<GEMM_64x64_HF>(probs_dev, nprob, total_blocks, stream);
+  else launch_shape<GEMM_32x128>(probs_dev, nprob, total_blocks, stream);
   return hipGetLastError();
 }
 

@@ -289,13 +289,9 @@ hipError_t gs_launch(K kern, const GruScanArgs &a, int R, int lds_floats, hipStr
 }  // namespace
 
 bool gru_scan_takes(int B, int L) {
-  const char *e = getenv("FDQL_GRU_SCAN");
-  return !(e && e[0] == '0') && L % 64 == 0 && L >= 64 && L <= 256 && B >= 1;
+  return plan_switches().gru_scan && L % 64 == 0 && L >= 64 && L <= 256 && B >= 1;
 }
-static int gru_scan_rt() {   // rows per workgroup / 4 (tuning hook FDQL_GRU_SCAN_RT = 1 | 2)
-  const char *e = getenv("FDQL_GRU_SCAN_RT");
-  return e && e[0] == '2' ? 2 : 1;
-}
+static int gru_scan_rt() { return 1; }   // rows per workgroup / 4 (2: measured slower, profiles/r04_gru_scan.txt)
 hipError_t gru_scan_fwd_launch(const GruScanArgs &a, hipStream_t s) {
   const int waves = a.L / 64, rt = gru_scan_rt();
   const int lds = 2 * 4 * rt * (a.L + 4);

@@ -1422,8 +1422,7 @@ __global__ __launch_bounds__(256) void k_loss_wave(LossArgs a) {
 
 // wave-per-row form: TQC with 32 < Nq <= 128 (LossArgs::G == 64 then: four rows per workgroup); FDQL_LOSS_WAVE=0: never
 bool loss_wave_form(int distributional, int Nq) {
-  const char *e = getenv("FDQL_LOSS_WAVE");
-  return distributional && Nq > 32 && Nq <= 128 && !(e && e[0] == '0');
+  return distributional && Nq > 32 && Nq <= 128 && plan_switches().loss_wave;
 }
 
 hipError_t loss_launch(const LossArgs &a, hipStream_t s) {
@@ -2370,13 +2369,13 @@ __global__ __launch_bounds__(256) void k_act_layer(ActLayerArgs a) {
 // (row m; `lrow`: its logits, in global memory or LDS)
 // `vals`: 5 x GUMBEL_MAXN floats of this thread, element (k, j) at vals[(k * GUMBEL_MAXN + j) * stride] (discrete actor only)
 // MODE: 1 discrete only, 0 continuous only (k_act_policy: one instantiation each keeps the argument block's live ranges
-// inside the SGPR file), -1 either (k_act_fused)
+// inside the SGPR file)
 template <int MODE>
 __device__ __forceinline__ void act_policy_row(const ActPolicyArgs &a, int m, const float *lrow, float *vals, int stride) {
 #pragma clang fp contract(off)
   const bool use_exploit = a.exploit_mask && a.exploit_mask[m] != 0;
   const int A = a.A;
-  if (MODE == 1 || (MODE < 0 && a.discrete)) {
+  if (MODE == 1) {
     auto arr = [&](int k) { return LaneArr{vals + k * GUMBEL_MAXN * stride, stride}; };
     const LaneArr lo = arr(0), u = arr(1), norm = arr(2), relaxed = arr(3), sc = arr(4);
     int greedy = 0;
@@ -2434,99 +2433,6 @@ __global__ __launch_bounds__(64) void k_act_policy(ActPolicyArgs a) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= a.rows) return;
   act_policy_row<MODE>(a, m, a.logits + (long long)m * a.ld, lane_vals + (MODE ? threadIdx.x : 0), 64);
-}
-
-// --------------------------------------------------------------------------------------
-// act() in one launch (update_kernels.h, ActFusedArgs): seven dependent launches of 5-6 us each were the whole latency of a
-// 1-row act(); a grid-wide barrier between layers costs as much as a launch (measured), so ONE workgroup does all
-// of it: 16 waves, wave w owns the output tiles n = 16 w, 16 (w + 16), ... of a layer as v_mfma_f32_16x16x4_f32 with the
-// weights as the A operand (lane (i, kq): 16 bytes W[n0 + i][16 g + 4 kq ..] - whole 64-byte runs of a weight row per four
-// lanes, every request of a layer in flight before the first MFMA) and the <= 8 rows' activations as the B operand from
-// LDS; D[n][row] goes back to LDS as the next layer's input.  Bound by what one CU can pull from L2 (256 KB per layer).
-// --------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_act_fused(const ActFusedArgs a) {
-  typedef float v4f __attribute__((ext_vector_type(4)));
-  typedef const __attribute__((address_space(1))) float *gcf;
-  typedef const __attribute__((address_space(1))) v4f *gcf4;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 15, kq = lane >> 4;
-  const int rows = a.rows;
-  // inputs: global rows -> feature rows (rows past the batch as zeros)
-  for (int s = 0; s < a.nin; ++s) {
-    const ActFusedInput in = a.in[s];
-    for (int e = tid; e < ACTF_ROWS * in.width; e += 1024) {
-      const int r = e / in.width, k = e - r * in.width;
-      lds[in.x_off + r * in.x_pitch + k] = r < rows ? in.ptr[(long long)r * in.ld + k] : 0.f;
-    }
-  }
-  __syncthreads();
-  for (int l = 0; l < a.nlayers; ++l) {
-    const ActFusedLayer &L = a.L[l];
-    const int N = L.N, ldw = L.ldw, nseg = L.nseg, xp = L.x_pitch;
-    gcf W = (gcf)L.W;
-    for (int n0 = 16 * wave; n0 < N; n0 += 256) {
-      const int n = min(n0 + li, N - 1);   // (rows of a partial tile repeat row N - 1; never stored)
-      float bv[4];                         // requested with the weights, not after the MFMAs (one round trip less per layer)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bv[r] = ((gcf)L.bias)[min(n0 + 4 * kq + r, N - 1)];
-      v4f acc[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) acc[c] = v4f{0.f, 0.f, 0.f, 0.f};
-      for (int s = 0; s < nseg; ++s) {
-        const ActFusedSeg sg = L.seg[s];
-        gcf wrow = W + (long long)n * ldw + sg.wcol + 4 * kq;
-        const float *xrow = lds + sg.x_off + (li & 7) * xp + 4 * kq;   // B operand: lane (j = li, kq) = x[row li][..]; rows 8..15 mirror 0..7 (never stored)
-        const int G = sg.width >> 4;
-        for (int g0 = 0; g0 < G; g0 += 16) {   // up to 16 groups (256 k) of requests in flight
-          v4f wv[16];
-#pragma unroll
-          for (int u = 0; u < 16; ++u)
-            if (g0 + u < G) wv[u] = *(gcf4)(wrow + 16 * (g0 + u));
-#pragma unroll
-          for (int u = 0; u < 16; ++u) {
-            if (g0 + u < G) {
-              const v4f xv = *reinterpret_cast<const v4f *>(xrow + 16 * (g0 + u));
-#pragma unroll
-              for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][c], xv[c], acc[c], 0, 0, 0);
-            }
-          }
-        }
-        const int kt = 16 * G + 4 * kq;   // the segment's tail (< 16 columns): guarded single elements
-        if (16 * G < sg.width) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const bool ok = kt + c < sg.width;
-            const float wv = ok ? wrow[16 * G + c] : 0.f;
-            const float xv = ok ? xrow[16 * G + c] : 0.f;
-            acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xv, acc[c], 0, 0, 0);
-          }
-        }
-      }
-      // D[i][j]: lane (j = li, kq) holds outputs n0 + 4 kq + reg of row li
-      const v4f sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-      if (li < ACTF_ROWS) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int nn = n0 + 4 * kq + r;
-          if (nn < N) {
-            float y = sum[r] + bv[r];
-            if (L.leaky) y = y > 0.f ? y : 0.01f * y;
-            lds[L.out_off + li * L.out_pitch + nn] = li < rows ? y : 0.f;
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-  __shared__ float lane_vals[5 * GUMBEL_MAXN * ACTF_ROWS];
-  if (tid < rows) act_policy_row<-1>(a.pol, tid, lds + a.logits_off + tid * a.logits_pitch, lane_vals + tid, ACTF_ROWS);
-}
-
-hipError_t act_fused_launch(const ActFusedArgs &a, hipStream_t s) {
-  if (a.rows <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_act_fused, dim3(1), dim3(1024), ACTF_LDS_FLOATS * 4, s, a);
-  return hipGetLastError();
 }
 
 hipError_t act_layer_launch(const ActLayerArgs &a, hipStream_t s) {

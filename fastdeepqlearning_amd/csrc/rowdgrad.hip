@@ -388,8 +388,7 @@ __global__ __launch_bounds__(256) void k_rowdot(const RowDotArgs a) {
 }  // namespace
 
 bool rowdot_from_problems(const GemmProblem *probs, int nprob, RowDotArgs &args) {
-  const char *env = getenv("FDQL_ROWDGRAD");
-  if (env && env[0] == '0') return false;
+  if (!plan_switches().rowdgrad) return false;
   if (nprob < 1 || nprob > RDOT_MAX_PROB) return false;
   memset(&args, 0, sizeof(args));
   auto aligned = [](const void *q, uintptr_t n) { return (reinterpret_cast<uintptr_t>(q) & (n - 1)) == 0; };
@@ -427,8 +426,7 @@ hipError_t rowdot_launch(const RowDotArgs &a, hipStream_t s) {
 }
 
 bool rowdgrad_from_problem(const GemmProblem &p, RowDgradArgs &args) {
-  const char *env = getenv("FDQL_ROWDGRAD");   // "0": never (tuning / test hook; read per plan build)
-  if (env && env[0] == '0') return false;
+  if (!plan_switches().rowdgrad) return false;   // FDQL_ROWDGRAD=0
   if (p.M < RD_BM || p.M % RD_BM || p.N != RD_N || p.nseg < 1 || p.nseg > RD_MAX_SEG || p.ksplit != 1 || p.bias || p.C2 || p.hf_w || p.fz_h ||
       p.ldc != RD_N || (p.epi != EPI_NONE && p.epi != EPI_LRELU_GRAD))
     return false;
@@ -449,7 +447,6 @@ bool rowdgrad_from_problem(const GemmProblem &p, RowDgradArgs &args) {
 // The launch that sums `nsum` shares [M, 256] (stride floats apart) into segment 0's array can be folded into this launch when
 // segment 0 is that array: at most 8 shares, 16-byte aligned.
 bool rowdgrad_fold_sum(RowDgradArgs &args, const float *parts, int nsum, long long stride, float *sum_out, float *sum_colsum) {
-  if (getenv("FDQL_NO_DSTATE_SUM_FOLD")) return false;
   auto aligned = [](const void *q, uintptr_t n) { return (reinterpret_cast<uintptr_t>(q) & (n - 1)) == 0; };
   if (nsum < 2 || nsum > 8 || args.A[0] != sum_out || !aligned(parts, 16) || (stride & 3) || !aligned(sum_out, 16) || !sum_colsum || args.nseg != 1) return false;
   args.sum_parts = parts; args.nsum = nsum; args.sum_stride = stride; args.sum_out = sum_out; args.sum_colsum = sum_colsum;
@@ -457,7 +454,7 @@ bool rowdgrad_fold_sum(RowDgradArgs &args, const float *parts, int nsum, long lo
 }
 
 bool rowchain_from_launches(const RowDgradArgs &l1, const RowDgradArgs &l2, const RowDgradArgs &l3, RowChainArgs &c) {
-  if (getenv("FDQL_NO_ROWDGRAD_CHAIN")) return false;
+  if (!plan_switches().rowdgrad_chain) return false;   // FDQL_NO_ROWDGRAD_CHAIN
   if (l1.nsum < 2 || l1.nseg != 1 || !l1.gate || !l1.colsum || !l1.sum_colsum) return false;
   if (l2.nsum || l2.nseg != 2 || l2.gate || !l2.colsum || l2.A[0] != l1.sum_out || l2.A[1] != l1.C) return false;
   if (l3.nsum || l3.nseg != 1 || !l3.gate || !l3.colsum || l3.A[0] != l2.C) return false;

@@ -109,29 +109,6 @@ hipError_t act_policy_launch(const ActPolicyArgs &a, hipStream_t s);
 bool act_head_policy_takes(const ActLayerArgs &l, const ActPolicyArgs &p);
 hipError_t act_head_policy_launch(const ActLayerArgs &l, const ActPolicyArgs &p, hipStream_t s);
 
-// act() in ONE launch for a handful of rows (kernels.hip, k_act_fused): a single 1024-thread workgroup walks the Linear
-// layers of encoder -> joiner -> actor with the activations of its <= 8 rows in LDS and ends with the policy head.  A
-// layer's input is up to ACTF_MAX_SEG column ranges of the LDS feature rows (the skip head's cat as K-segments).
-constexpr int ACTF_MAX_LAYERS = 12, ACTF_MAX_SEG = 6, ACTF_MAX_IN = 4, ACTF_ROWS = 8;
-constexpr int ACTF_LDS_FLOATS = 15360;   // 60 KiB of feature rows
-struct ActFusedSeg { int x_off, wcol, width; };   // LDS float offset of x[0][0] of the segment, its first weight column
-struct ActFusedLayer {
-  ActFusedSeg seg[ACTF_MAX_SEG];
-  int nseg, x_pitch;        // row pitch (floats) of the feature rows the segments live in
-  const float *W;           // [N, ldw] row-major
-  const float *bias;
-  int ldw, N, leaky;
-  int out_off, out_pitch;   // LDS destination of the layer's output
-};
-struct ActFusedInput { const float *ptr; int ld, width, x_off, x_pitch; };   // global rows -> LDS feature rows (layer 0's input)
-struct ActFusedArgs {
-  int nlayers, nin, rows, logits_off, logits_pitch;
-  ActFusedInput in[ACTF_MAX_IN];
-  ActFusedLayer L[ACTF_MAX_LAYERS];
-  ActPolicyArgs pol;        // pol.logits is ignored: the logits are read from LDS
-};
-hipError_t act_fused_launch(const ActFusedArgs &a, hipStream_t s);
-
 hipError_t head_dgrad_launch(const HeadDgradProblem *dev, int n, int total_blocks, hipStream_t s);
 hipError_t skinny_wgrad_launch_host(const SkinnyWgradProblem *host, const SkinnyWgradProblem *dev, int n,
                                     int total_blocks, hipStream_t s);

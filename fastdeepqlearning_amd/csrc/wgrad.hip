@@ -335,8 +335,7 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_stat(const WgArgs a) {
 }  // namespace
 
 bool wgrad_stat_takes(const GemmProblem &p) {
-  const char *env = getenv("FDQL_WGRAD_STAT");   // "0": never (tuning / test hook; read per plan build)
-  if (env && env[0] == '0') return false;
+  if (!plan_switches().wgrad_stat) return false;   // FDQL_WGRAD_STAT=0
   if (p.M != WG_N || p.N != WG_N || p.nseg != 1 || p.ksplit < 1 || p.bias || p.epi != EPI_NONE || p.colsum || p.C2 || p.hf_w || p.fz_h) return false;
   const GemmSeg &s = p.seg[0];
   if (s.a_kc || s.b_kc || s.lda != WG_N || s.ldb != WG_N || s.K % WG_BM || s.K < WG_BM) return false;
@@ -404,8 +403,7 @@ bool wgrad_stat_balance(WgArgs &args) {
 }
 
 bool wgrad_stat_add_rider(WgArgs &args, int inst, const GemmProblem &p) {
-  const char *env = getenv("FDQL_WGRAD_RIDERS");   // "0": never (tuning / test hook; read per plan build)
-  if (env && env[0] == '0') return false;
+  if (!plan_switches().wgrad_riders) return false;   // FDQL_WGRAD_RIDERS=0
   if (inst < 0 || inst >= args.ninst) return false;
   WgInst &I = args.inst[inst];
   if (p.nseg != 1 || p.ksplit != args.nslab || p.split_stride != args.slab_stride || p.bias || p.epi != EPI_NONE || p.colsum || p.C2 ||

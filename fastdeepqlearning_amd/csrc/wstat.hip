@@ -1042,8 +1042,6 @@ __global__ __launch_bounds__(256, 1) void k_wstat_grad(const WsArgs a) {
 
 bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
   if (nprob < 1 || nprob > WS_MAX_INST) return false;
-  const char *env = getenv("FDQL_WSTAT");   // "0": never; "fwd": forward forms only (tuning / test hook; read per plan build)
-  if (env && env[0] == '0') return false;
   memset(&args, 0, sizeof(args));
   auto aligned = [](const void *p, uintptr_t n) { return (reinterpret_cast<uintptr_t>(p) & (n - 1)) == 0; };
   auto main_of = [](const GemmProblem &p) {
@@ -1076,7 +1074,6 @@ bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
   const bool grad = !p0.seg[main0].b_kc;
   const bool plain = grad && p0.epi == EPI_NONE;
   if (grad ? (p0.epi != EPI_LRELU_GRAD && !plain) : p0.epi != EPI_LRELU) return false;
-  if (grad && env && !strcmp(env, "fwd")) return false;
   const int nminor = p0.nseg - 1;
   if (nminor > WS_MAX_MINOR) return false;
   const bool fz = p0.fz_h != nullptr;
@@ -1097,8 +1094,7 @@ bool wstat_from_problems(const GemmProblem *probs, int nprob, WsArgs &args) {
   args.nminor = nminor; args.dual = dual; args.grad = grad ? (plain ? 2 : 1) : 0; args.fz = fz; args.fz_ldw = p0.fz_ldw;
   args.hf_q = p0.hf_w ? p0.hf_q : 0; args.hf_ldw = p0.hf_ldw;
   int cost[WS_MAX_INST], cost_sum = 0;
-  int dual_cost = 12;
-  if (const char *dc = getenv("FDQL_WSTAT_DUAL_COST")) dual_cost = atoi(dc) > 0 ? atoi(dc) : 12;   // tuning hook
+  const int dual_cost = 12;
   for (int i = 0; i < nprob; ++i) {
     const GemmProblem &p = probs[i];
     const bool pd = is_dual(p);

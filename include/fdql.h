@@ -399,20 +399,19 @@ int fdql_test_gemm(const float *A, int32_t lda, int32_t a_kc, const float *B, in
  * h_out: NULL or nh device pointers [rows, h_i].  Synchronises `stream`. */
 int fdql_test_chain_mlp(const float *x, int32_t rows, int32_t din, const int32_t *hid, int32_t nh, int32_t dout,
                         const float *weights, float *const *h_out, float *out, void *stream);
-/* Diagnostic: with FDQL_CHAIN_STAMPS=1 in the environment the middle workgroup of every chain launch records the
- * shader clock at its entry, after its program fetch and after each operation; returns the count copied. */
+/* Diagnostic: fdql_debug_chain_stamps(NULL, 1) switches the recording on (NULL, 0: off): the middle workgroup of every chain
+ * launch then records the shader clock at its entry, after its program fetch and after each operation; with a buffer: returns
+ * the count copied. */
 int fdql_debug_chain_stamps(uint64_t *out, int32_t cap);
 
-/* Diagnostic: (shader cycles, 100 MHz wall ticks) of every workgroup's life in the last row-block launch, interleaved;
- * cycles / ticks / 10 = shader clock in GHz under that launch's load.  Returns the count of values copied. */
-int fdql_debug_rowgemm_life(uint64_t *out, int32_t cap);
-/* Test hook: one launch of the persistent row-block kernel (csrc/rowgemm.hip) over `ninst` instances of a Linear layer
+/* Test hook: one launch of the weight-stationary row-block kernel (csrc/wstat.hip) over `ninst` instances of a Linear layer
  * with 256 inputs (+ up to two narrow input blocks of k1, k2 <= 8 columns) and 256 outputs; instance i owns rows
  * [i*M, (i+1)*M) of every array.  ks: weights stored [k][n] (dgrad) else [n][k]; grad: LeakyReLU' gate from `ref` and
  * column sums instead of bias + LeakyReLU; dual: C = f(all but the last narrow block), C2 = f(all); hf_*: head fusion
  * (GemmProblem::hf_* in csrc/common.h); fz_h != null: the head dgrad of the layer above fused into the loader - A0's rows
  * are then OUTPUT, LeakyReLU'(fz_h) * (A1 . fz_w[i]) with A1 = dY (k1 = 2), their per-64-row column sums in fz_colsum.
- * Asynchronous on `stream`.  FDQL_EINVAL: the kernel does not take the form. */
+ * planes: head-sum planes per instance in hf_out; NEGATIVE: the kernel adds a tile's planes itself (the update's default) and
+ * plane 0 holds the total.  Asynchronous on `stream`.  FDQL_EINVAL: the kernel does not take the form. */
 int fdql_test_rowgemm(const float *A0, const float *A1, int32_t k1, const float *A2, int32_t k2, const float *W0, int32_t ldw0,
                       const float *W1, const float *W2, const float *bias, float *C, float *C2, const float *ref, float *colsum,
                       const float *hf_w, int32_t hf_ldw, int32_t hf_q, float *hf_out, float *hf_out2, int32_t M, int32_t ninst,
@@ -457,13 +456,9 @@ int fdql_test_conv(int32_t mode, const void *in, int32_t u8, const int32_t *slot
 int fdql_debug_side_copy(const float *src, float *dst, int64_t n, int32_t workgroups, int32_t passes, int32_t hold_us,
                          int32_t lds_bytes, void *stream);
 
-/* Tuning hook: build of the GEMM main loop: 1 (default) = next-step fragment prefetch, K-chunk 32 for small launches (<= 512 workgroups) of the
- * 64x64 tile shapes and 16 otherwise, 6 = K-chunk 16 for every shape, 0 = K-chunk 16 without the prefetch, 4 = K-chunk 8, 5 = b128 fragments; 2 and 3
- * alias 0.  Affects speed only. */
-int fdql_debug_set_gemm_variant(int32_t variant);
-/* Tuning / test hook: tile shape of the dense problems: 5 = 64x64 (default), 3 = 64x128, 0 = 128x128, 7 / 8 / 9 = the LDS-DMA
- * builds, 10 = the small-batch kernel (csrc/smallgemm.hip) on every problem that has its form, whatever the size.
- * Applies to plans built afterwards and to fdql_test_gemm. */
+/* Tuning / test hook: tile shape of the dense problems: 5 = 64x64 (default), 3 = 64x128, 0 = 128x128, 7 = the small-batch
+ * kernel (csrc/smallgemm.hip) on every problem that has its form, whatever the size.  Applies to plans built afterwards
+ * and to fdql_test_gemm. */
 int fdql_debug_set_gemm_dense_shape(int32_t shape);
 
 #ifdef __cplusplus

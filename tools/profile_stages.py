@@ -43,12 +43,3 @@ t0 = time.perf_counter()
 for _ in range(50): ag.update(xp, seed=1)
 torch.cuda.synchronize()
 print(f"update-only wall: {(time.perf_counter()-t0)/50*1e3:.4f} ms/step")
-import ctypes, numpy as np
-from fastdeepqlearning_amd import _native as _nat
-buf = (ctypes.c_uint64 * 2048)()
-n = _nat.load().fdql_debug_rowgemm_life(buf, 2048)
-v = np.array(buf[:n], dtype=np.float64).reshape(-1, 2)
-v = v[v[:, 1] > 0]
-if len(v):
-    print(f"row-block kernel, last launch: {len(v)} workgroups, life {v[:,1].mean()/100:.1f} us mean / {v[:,1].max()/100:.1f} us max, "
-          f"shader clock {v[:,0].sum()/v[:,1].sum()/10:.3f} GHz")

@@ -27,11 +27,12 @@ def per_kernel(rows, counter):
     return acc
 
 
-DENSE = ("k_gemm", "k_chain", "k_rowgemm", "k_rowdgrad", "k_wstat", "k_wgrad_stat")   # the MFMA kernels
+DENSE = ("k_gemm", "k_chain", "k_rowdgrad", "k_wstat", "k_wgrad_stat", "k_conv")   # the MFMA kernels
 fetch = per_kernel(counter_rows("pmc_fetch"), "FETCH_SIZE")
 write = per_kernel(counter_rows("pmc_write"), "WRITE_SIZE")
+WORKLOAD = sys.argv[2] if len(sys.argv) > 2 else "tools/profile_stages.py (config 2, T=50, B=256)"
 lines = ["# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, --kernel-trace only) over",
-         "# tools/profile_stages.py (config 2, T=50, B=256); mean per dispatch.  HBM_read = 2 x FETCH_SIZE KiB (gfx950",
+         f"# {WORKLOAD}; mean per dispatch.  HBM_read = 2 x FETCH_SIZE KiB (gfx950",
          "# reports half of wide coalesced reads, MI355X_MICROARCH.md; check: k_reduce_slabs must read 32 slabs x 4.07 MB",
          "# = 130 MB).  HBM_write = WRITE_SIZE KiB.  Values are L2<->fabric traffic (Infinity-Cache hits included)."]
 tot = collections.defaultdict(lambda: [0.0, 0.0, 0])
