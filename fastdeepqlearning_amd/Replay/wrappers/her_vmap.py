@@ -106,55 +106,40 @@ class HindsightVmapWrite(ReplayMemoryWrapper):
         return self._flush_columns(mem, nstep, {k: col(k) for k in rec0}, rec0, n)
 
     def _flush_columns(self, mem, nstep, cols, rec0, n):
-        """``cols``: {key: float32 [n, dim]} of the episode's own keys; ``rec0``: its first record (the ring's template)."""
-        lib = N.load()
+        """``cols``: {key: float32 [n, dim]} of the episode's own keys; ``rec0``: its first record (the ring's template).
+        ONE native call per episode (fdql_ring_append_episode_vmap): the packed rows and the K goal indices go to the device in
+        one copy; relabel, per-column returns, the _pop record and the scatter into the ring run there."""
         K = self.num_virtual_goals
-        dev = self._device
         g = cols["achieved_goal"].shape[1]
-        template = dict(rec0)
-        template["virtual_goals"] = np.zeros((K + 1, g), np.float32)
-        template["virtual_rewards"] = np.zeros(K + 1, np.float32)
-        template["virtual_dones"] = np.zeros(K + 1, np.float32)
-        if nstep is not None:
-            template[nstep.return_name] = np.zeros(K + 1, np.float32)
-        mem._ensure_ring(template)
-        off = {k: (int(mem._offsets[j]), int(mem._offsets[j + 1])) for j, k in enumerate(mem._keys)}
-        host = np.zeros((n, int(mem._offsets[-1])), np.float32)
-        for k in mem._keys:
-            if k in rec0:
-                host[:, off[k][0]:off[k][1]] = cols[k]
-        rows = torch.from_numpy(host).to(dev)
-        idx = torch.as_tensor(self._draw_goal_indices(n), dtype=torch.int32, device=dev)
-        r, td = rows[:, off["reward"][0]].contiguous(), rows[:, off["task_done"][0]].contiguous()
-        agd = rows[:, off["achieved_goal"][0]:off["achieved_goal"][1]].contiguous()
-        dgd = rows[:, off["desired_goal"][0]:off["desired_goal"][1]].contiguous()
-        vg = torch.empty(n, (K + 1) * g, device=dev)
-        vr, vd = torch.empty(n, K + 1, device=dev), torch.empty(n, K + 1, device=dev)
-        fn = self.compute_reward.native()
-        with torch.cuda.device(dev):
-            st = N.current_stream(dev)
-            N.check(lib.fdql_episode_her_vmap(N.ptr(r), N.ptr(td), N.ptr(agd), N.ptr(dgd), C.c_void_p(idx.data_ptr()), n, g, K,
-                                              C.byref(fn), N.ptr(vg), N.ptr(vr), N.ptr(vd), st))
-            rows[:, off["virtual_goals"][0]:off["virtual_goals"][1]] = vg
-            rows[:, off["virtual_rewards"][0]:off["virtual_rewards"][1]] = vr
-            rows[:, off["virtual_dones"][0]:off["virtual_dones"][1]] = vd
+        if mem._ring is None:
+            template = dict(rec0)
+            template["virtual_goals"] = np.zeros((K + 1, g), np.float32)
+            template["virtual_rewards"] = np.zeros(K + 1, np.float32)
+            template["virtual_dones"] = np.zeros(K + 1, np.float32)
             if nstep is not None:
-                lo, hi = off[nstep.return_name]
-                ret = torch.empty(n, K + 1, device=dev)
-                N.check(lib.fdql_episode_mc_return_vmap(N.ptr(vr), N.ptr(vd), N.ptr(ret), n, K + 1, float(nstep.discount), st))
-                rows[:, lo:hi] = ret
-                if n > nstep.n_step:      # _pop fired once, when the buffer held n_step records: record 0 with THAT return
-                    ns = int(nstep.n_step)
-                    part = torch.empty(ns, K + 1, device=dev)
-                    N.check(lib.fdql_episode_mc_return_vmap(N.ptr(vr[:ns].contiguous()), N.ptr(vd[:ns].contiguous()), N.ptr(part), ns,
-                                                            K + 1, float(nstep.discount), st))
-                    pop = rows[:1].clone()
-                    pop[0, lo:hi] = part[0]
-                    rows = torch.cat([pop, rows], 0)
-            mem.add_rows(rows.contiguous())
+                template[nstep.return_name] = np.zeros(K + 1, np.float32)
+            mem._ensure_ring(template)
+        spec = getattr(self, "_vmap_spec", None)
+        if spec is None or spec[0] is not mem or spec[1] != K:
+            key = lambda name: mem._keys.index(name)
+            sp = N.EpisodeVmapSpec()
+            sp.reward_key, sp.task_done_key = key("reward"), key("task_done")
+            sp.achieved_key, sp.desired_key = key("achieved_goal"), key("desired_goal")
+            sp.vgoals_key, sp.vrewards_key, sp.vdones_key = key("virtual_goals"), key("virtual_rewards"), key("virtual_dones")
+            sp.vreturn_key = key(nstep.return_name) if nstep is not None else -1
+            sp.K, sp.n_step, sp.gamma = K, int(nstep.n_step) if nstep is not None else 0, float(nstep.discount) if nstep is not None else 0.0
+            sp.reward_fn = self.compute_reward.native()
+            offs = [(int(mem._offsets[j]), int(mem._offsets[j + 1])) for j in range(len(mem._keys))]
+            spec = self._vmap_spec = (mem, K, sp, {k: offs[j] for j, k in enumerate(mem._keys)}, int(mem._offsets[-1]))
+        _, _, sp, off, width = spec
+        host = np.zeros((n, width), np.float32)
+        for k, v in cols.items():
+            if k in off:
+                host[:, off[k][0]:off[k][1]] = v
+        written = mem._ring.append_episode_vmap(host, self._draw_goal_indices(n), sp)
         if hasattr(mem, "_len"):          # AsyncReplayMemory's own saturating counter (async_replay_memory.py:27-29)
-            mem._len = min(mem._len + int(rows.shape[0]), mem._maxlen)
-        return int(rows.shape[0])
+            mem._len = min(mem._len + written, mem._maxlen)
+        return written
 
     def _hindsight_flush(self):
         target = self._fused_target()

@@ -80,6 +80,12 @@ class EpisodeSpec(C.Structure):
                 ("reward_fn", RewardFn)]
 
 
+class EpisodeVmapSpec(C.Structure):
+    _fields_ = [("reward_key", C.c_int32), ("task_done_key", C.c_int32), ("achieved_key", C.c_int32), ("desired_key", C.c_int32),
+                ("vgoals_key", C.c_int32), ("vrewards_key", C.c_int32), ("vdones_key", C.c_int32), ("vreturn_key", C.c_int32),
+                ("K", C.c_int32), ("n_step", C.c_int32), ("gamma", C.c_float), ("reward_fn", RewardFn)]
+
+
 # Every symbol include/fdql.h declares, with its ctypes signature (restype, argtypes).
 _vp, _i32, _i64, _u64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
 SIGNATURES = {
@@ -93,6 +99,7 @@ SIGNATURES = {
     "fdql_ring_add_device": (C.c_int, [_vp, _vp, _i64, _vp]),
     "fdql_ring_flush": (C.c_int, [_vp, _vp]),
     "fdql_ring_append_episode": (C.c_int, [_vp, _vp, _i64, C.POINTER(EpisodeSpec), C.POINTER(_i64), _vp]),
+    "fdql_ring_append_episode_vmap": (C.c_int, [_vp, _vp, _i64, _vp, C.POINTER(EpisodeVmapSpec), C.POINTER(_i64), _vp]),
     "fdql_ring_snapshot": (C.c_int, [_vp, _vp, _i64, _vp]),
     "fdql_ring_restore": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp]),
     "fdql_ring_len": (_i64, [_vp]),

@@ -81,6 +81,17 @@ class NativeRing:
                                                       C.byref(spec), C.byref(out), N.current_stream(self.device)))
         return int(out.value)
 
+    def append_episode_vmap(self, rows, goal_idx, spec):
+        """One finished episode of the "vmap" hindsight stack (packed float32 host rows [n, row_floats], K goal indices) ->
+        ring: relabel, per-column returns, _pop record and scatter on the device (fdql_ring_append_episode_vmap)."""
+        rows = np.ascontiguousarray(rows, dtype=np.float32).reshape(-1, self.row_floats)
+        goal_idx = np.ascontiguousarray(goal_idx, dtype=np.int32)
+        out = C.c_int64(0)
+        N.check(self.lib.fdql_ring_append_episode_vmap(self.handle, rows.ctypes.data_as(C.c_void_p), rows.shape[0],
+                                                       goal_idx.ctypes.data_as(C.c_void_p), C.byref(spec), C.byref(out),
+                                                       N.current_stream(self.device)))
+        return int(out.value)
+
     def flush(self):
         N.check(self.lib.fdql_ring_flush(self.handle, N.current_stream(self.device)))
 

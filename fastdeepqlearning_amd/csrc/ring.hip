@@ -307,41 +307,46 @@ __global__ void k_episode_expand(ExpandArgs a) {
 }
 
 // her_vmap.py:30-45: one thread per (step, virtual goal column); the last column is the real one
+// (ld*: floats between consecutive records of each array: gd / K1 * gd / K1 for packed arrays, the ring's row width when the
+// arrays are columns of packed rows - fdql_ring_append_episode_vmap relabels the staged rows in place)
 __global__ void k_her_vmap(const float *reward, const float *task_done, const float *ag, const float *dg,
                            const int *goal_idx, int n, int gd, int K, fdql_reward_fn_t fn, float *vgoals,
-                           float *vrew, float *vdone) {
+                           float *vrew, float *vdone, long long ld_s, long long ld_g, long long ld_vg, long long ld_v) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const int K1 = K + 1;
   if (e >= n * K1) return;
   const int i = e / K1, k = e - i * K1;
-  const float *ag_i = ag + (long long)i * gd;
-  const float *goal = k < K ? ag + (long long)goal_idx[k] * gd : dg + (long long)i * gd;
-  float *vg = vgoals + ((long long)i * K1 + k) * gd;
+  const float *ag_i = ag + (long long)i * ld_g;
+  const float *goal = k < K ? ag + (long long)goal_idx[k] * ld_g : dg + (long long)i * ld_g;
+  float *vg = vgoals + (long long)i * ld_vg + (long long)k * gd;
   for (int j = 0; j < gd; ++j) vg[j] = goal[j];
+  const long long o = (long long)i * ld_v + k;
+  const float rew = reward[(long long)i * ld_s], td = task_done[(long long)i * ld_s];
   if (k == K) {
-    vrew[e] = reward[i];
-    vdone[e] = task_done[i] != 0.f ? 1.f : 0.f;
+    vrew[o] = rew;
+    vdone[o] = td != 0.f ? 1.f : 0.f;
     return;
   }
-  const float dr = reward_fn(fn, ag_i, dg + (long long)i * gd, gd);
+  const float dr = reward_fn(fn, ag_i, dg + (long long)i * ld_g, gd);
   const float vr = reward_fn(fn, ag_i, goal, gd);
-  vrew[e] = (reward[i] - dr) + vr;
-  const bool agnostic_done = (task_done[i] != 0.f) && !(dr == 0.f);
-  vdone[e] = (agnostic_done || vr == 0.f) ? 1.f : 0.f;
+  vrew[o] = (rew - dr) + vr;
+  const bool agnostic_done = (td != 0.f) && !(dr == 0.f);
+  vdone[o] = (agnostic_done || vr == 0.f) ? 1.f : 0.f;
 }
-
-// nstep_return_vmap.py:71-74, one thread per column, float32 with the product rounded before the add
 __global__ void k_mc_return_vmap(const float *__restrict__ r, const float *__restrict__ d, float *__restrict__ ret,
-                                 int n, int cols, float gamma) {
+                                 int n, int cols, float gamma, long long ld, float *__restrict__ first_out) {
 #pragma clang fp contract(off)
+  // ld: floats between consecutive records (cols for packed arrays); ret == null: only the scan's value at record 0 is kept,
+  // in first_out[c] (the one-shot _pop record of nstep_return_vmap.py:33-34, 50-57)
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= cols) return;
   float acc = 0.f;
   for (int i = n - 1; i >= 0; --i) {
-    const float prod = (acc * gamma) * (d[(long long)i * cols + c] != 0.f ? 1.f : 0.f);
-    acc = (i == n - 1) ? r[(long long)i * cols + c] : r[(long long)i * cols + c] + prod;
-    ret[(long long)i * cols + c] = acc;
+    const float prod = (acc * gamma) * (d[(long long)i * ld + c] != 0.f ? 1.f : 0.f);
+    acc = (i == n - 1) ? r[(long long)i * ld + c] : r[(long long)i * ld + c] + prod;
+    if (ret) ret[(long long)i * ld + c] = acc;
   }
+  if (first_out) first_out[c] = acc;
 }
 
 }  // namespace fdql
@@ -916,7 +921,7 @@ int fdql_episode_her_vmap(const float *reward, const float *task_done, const flo
   const int total = n * (K + 1);
   hipLaunchKernelGGL(k_her_vmap, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, reward, task_done,
                      achieved_goal, desired_goal, goal_idx, n, goal_dim, K, *fn, virtual_goals, virtual_rewards,
-                     virtual_dones);
+                     virtual_dones, 1LL, (long long)goal_dim, (long long)(K + 1) * goal_dim, (long long)(K + 1));
   FDQL_HIP(hipGetLastError());
   return 0;
 }
@@ -926,8 +931,90 @@ int fdql_episode_mc_return_vmap(const float *rewards, const float *dones, float 
   FDQL_REQUIRE(rewards && dones && ret && n >= 0 && cols > 0, "bad arguments");
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_mc_return_vmap, dim3((cols + 63) / 64), dim3(64), 0, (hipStream_t)stream, rewards, dones, ret, n,
-                     cols, gamma);
+                     cols, gamma, (long long)cols, (float *)nullptr);
   FDQL_HIP(hipGetLastError());
+  return 0;
+}
+
+int fdql_ring_append_episode_vmap(fdql_ring_t *r, const float *host_rows, int64_t n, const int32_t *goal_idx_host,
+                                  const fdql_episode_vmap_spec_t *sp, int64_t *appended, void *stream) {
+  FDQL_REQUIRE(r && host_rows && goal_idx_host && sp && n >= 0, "bad arguments");
+  if (appended) *appended = 0;
+  if (n == 0) return 0;
+  Lock lk(r->mu);
+  const int K = sp->K, K1 = K + 1;
+  auto f32key = [&](int k) { return k >= 0 && k < r->nkeys && !r->u8[k]; };
+  FDQL_REQUIRE(K >= 1 && sp->reward_fn.kind == 0, "append_episode_vmap: K >= 1 and a known reward function");
+  FDQL_REQUIRE(f32key(sp->reward_key) && f32key(sp->task_done_key) && r->dims[sp->reward_key] == 1 && r->dims[sp->task_done_key] == 1,
+               "append_episode_vmap: reward / task_done must be float32 keys of width 1");
+  FDQL_REQUIRE(f32key(sp->achieved_key) && f32key(sp->desired_key) && r->dims[sp->achieved_key] == r->dims[sp->desired_key],
+               "append_episode_vmap: achieved_goal / desired_goal keys must exist with equal width");
+  const int gd = r->dims[sp->achieved_key];
+  FDQL_REQUIRE(f32key(sp->vgoals_key) && r->dims[sp->vgoals_key] == K1 * gd && f32key(sp->vrewards_key) && r->dims[sp->vrewards_key] == K1 &&
+                   f32key(sp->vdones_key) && r->dims[sp->vdones_key] == K1,
+               "append_episode_vmap: virtual_goals / virtual_rewards / virtual_dones keys of widths (K+1)*g, K+1, K+1");
+  FDQL_REQUIRE(sp->vreturn_key < 0 || (f32key(sp->vreturn_key) && r->dims[sp->vreturn_key] == K1 && sp->n_step >= 1),
+               "append_episode_vmap: the return key must have width K+1 and n_step >= 1");
+  for (int k = 0; k < K; ++k) FDQL_REQUIRE(goal_idx_host[k] >= 0 && goal_idx_host[k] < n, "append_episode_vmap: goal index %d outside the episode", (int)goal_idx_host[k]);
+  const int pop = (sp->vreturn_key >= 0 && n > sp->n_step) ? 1 : 0;   // NStepReturnVmap._pop fires once (quirk q3)
+  const int64_t n_out = n + pop;
+  FDQL_REQUIRE(n_out <= r->maxlen, "append_episode_vmap: %lld rows do not fit a ring of %lld slots", (long long)n_out, (long long)r->maxlen);
+  hipStream_t s = (hipStream_t)stream;
+  int rc = flush(r, s);
+  if (rc) return rc;
+  const int F = r->rowfloats;
+  if (r->ep_inflight) { FDQL_HIP(hipEventSynchronize(r->ep_done)); r->ep_inflight = false; }
+  if (!r->ep_done) FDQL_HIP(hipEventCreateWithFlags(&r->ep_done, hipEventDisableTiming));
+  // staging: the rows and, behind them, the K goal indices (one pinned buffer, one H2D copy)
+  const int64_t need_rows = n + (K + F - 1) / F;
+  if (need_rows > r->ep_in_cap) {
+    const int64_t cap = std::max<int64_t>(need_rows, 2 * r->ep_in_cap);
+    if (r->ep_pinned) FDQL_HIP(hipHostFree(r->ep_pinned));
+    if (r->ep_in) FDQL_HIP(hipFree(r->ep_in));
+    r->ep_pinned = nullptr; r->ep_in = nullptr; r->ep_in_cap = 0;
+    FDQL_HIP(hipHostMalloc(&r->ep_pinned, cap * F * sizeof(float)));
+    FDQL_HIP(hipMalloc(&r->ep_in, cap * F * sizeof(float)));
+    r->ep_in_cap = cap;
+  }
+  if (n_out > r->ep_out_cap) {
+    const int64_t cap = std::max<int64_t>(n_out, 2 * r->ep_out_cap);
+    if (r->ep_out) FDQL_HIP(hipFree(r->ep_out));
+    r->ep_out = nullptr; r->ep_out_cap = 0;
+    FDQL_HIP(hipMalloc(&r->ep_out, cap * F * sizeof(float)));
+    r->ep_out_cap = cap;
+  }
+  memcpy(r->ep_pinned, host_rows, n * F * sizeof(float));
+  memcpy(r->ep_pinned + n * F, goal_idx_host, K * sizeof(int32_t));
+  FDQL_HIP(hipMemcpyAsync(r->ep_in, r->ep_pinned, (n * F + K) * sizeof(float), hipMemcpyHostToDevice, s));
+  // the records go to ep_out behind the _pop record's slot; the virtual columns are formed in place
+  float *rec0 = r->ep_out + (int64_t)pop * F;
+  FDQL_HIP(hipMemcpyAsync(rec0, r->ep_in, n * F * sizeof(float), hipMemcpyDeviceToDevice, s));
+  const int *gidx = reinterpret_cast<const int *>(r->ep_in + n * F);
+  {
+    const int total = (int)n * K1;
+    hipLaunchKernelGGL(k_her_vmap, dim3((total + 255) / 256), dim3(256), 0, s, r->ep_in + r->offs[sp->reward_key],
+                       r->ep_in + r->offs[sp->task_done_key], r->ep_in + r->offs[sp->achieved_key], r->ep_in + r->offs[sp->desired_key],
+                       gidx, (int)n, gd, K, sp->reward_fn, rec0 + r->offs[sp->vgoals_key], rec0 + r->offs[sp->vrewards_key],
+                       rec0 + r->offs[sp->vdones_key], (long long)F, (long long)F, (long long)F, (long long)F);
+    FDQL_HIP(hipGetLastError());
+  }
+  if (sp->vreturn_key >= 0) {   // nstep_return_vmap.py:61-74 per column (q10), and _pop's scan of the first n_step records
+    hipLaunchKernelGGL(k_mc_return_vmap, dim3((K1 + 63) / 64), dim3(64), 0, s, rec0 + r->offs[sp->vrewards_key],
+                       rec0 + r->offs[sp->vdones_key], rec0 + r->offs[sp->vreturn_key], (int)n, K1, sp->gamma, (long long)F, (float *)nullptr);
+    if (pop) {
+      FDQL_HIP(hipMemcpyAsync(r->ep_out, rec0, F * sizeof(float), hipMemcpyDeviceToDevice, s));   // record 0 again ...
+      hipLaunchKernelGGL(k_mc_return_vmap, dim3((K1 + 63) / 64), dim3(64), 0, s, rec0 + r->offs[sp->vrewards_key],
+                         rec0 + r->offs[sp->vdones_key], (float *)nullptr, sp->n_step, K1, sp->gamma, (long long)F,
+                         r->ep_out + r->offs[sp->vreturn_key]);                                 // ... with the n_step-record return
+    }
+    FDQL_HIP(hipGetLastError());
+  }
+  rc = scatter(r, r->ep_out, n_out, r->top, s);
+  if (rc) return rc;
+  advance(r, n_out);
+  FDQL_HIP(hipEventRecord(r->ep_done, s));
+  r->ep_inflight = true;
+  if (appended) *appended = n_out;
   return 0;
 }
 

@@ -207,6 +207,23 @@ int fdql_episode_her_vmap(const float *reward, const float *task_done, const flo
 int fdql_episode_mc_return_vmap(const float *rewards, const float *dones, float *ret, int32_t n, int32_t cols,
                                 float gamma, void *stream);
 
+/* A finished episode of the "vmap" hindsight stack (franQ/Replay/wrappers/her_vmap.py:66-90 over nstep_return_vmap.py:26-74) in
+ * ONE call: the packed host rows [n, row_floats] (oldest first; the virtual columns' contents are ignored) are staged through
+ * pinned memory with the K goal indices (her_vmap.py:75 draws them on the host: numpy's global generator), copied to the device
+ * once, relabelled IN PLACE there (fdql_episode_her_vmap's arithmetic on the rows' own columns), given their per-column returns
+ * (vreturn_key >= 0; with the one-shot _pop record of quirk q3 in front when n > n_step) and scattered into the ring - what
+ * HindsightVmapWrite -> NStepReturnVmap -> ReplayMemory.add would have written record by record.  *appended = n (+ 1). */
+typedef struct {
+  int32_t reward_key, task_done_key, achieved_key, desired_key;   /* keys of the episode's own columns            */
+  int32_t vgoals_key, vrewards_key, vdones_key;                   /* [(K+1)*g], [K+1], [K+1]: written here        */
+  int32_t vreturn_key;                                            /* [K+1] or -1 (no n-step wrapper underneath)   */
+  int32_t K, n_step;
+  float gamma;
+  fdql_reward_fn_t reward_fn;
+} fdql_episode_vmap_spec_t;
+int fdql_ring_append_episode_vmap(fdql_ring_t *ring, const float *host_rows, int64_t n, const int32_t *goal_idx_host,
+                                  const fdql_episode_vmap_spec_t *spec, int64_t *appended, void *stream);
+
 /* ------------------------------------------------------------------------------------ */
 /* Agent update: one SAC/TQC gradient step                                               */
 /* replaces franQ/Agent/deepQlearning.py:105-127 (train_step), :198-258 (get_losses),    */

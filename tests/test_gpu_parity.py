@@ -20,6 +20,7 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-5
 GTOL = 5e-5
+_THREE_WAY_CACHE = {}   # test_gradient_parity_three_way_fp64: the CPU evaluations of a spec, shared by the cases that differ in switches only
 
 
 def rel_err(a, b):
@@ -961,9 +962,6 @@ def _gpu_branch_pattern(ag, spec, xp_cpu):
      "(FDQL_ROWGEMM=all FDQL_STREAM_WGRAD=2: 25 head rows and 17 input columns per streaming problem, no riders fit)",
      dict(obs=376, act=17, C=5, Q=25, T=6, B=64, env={"FDQL_ROWGEMM": "all", "FDQL_STREAM_WGRAD": "2"})),
 ])
-_THREE_WAY_CACHE = {}
-
-
 def test_gradient_parity_three_way_fp64(dev, name, kw, monkeypatch):
     """north_star: gradients within 1e-5 rel fp32 of the reference CPU path.  Two fp32 evaluations of this loss cannot
     agree to 1e-5 element by element: LeakyReLU and relu(mc - q) make the gradient discontinuous in the activations, and
