@@ -1864,6 +1864,37 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const float *__restrict
   if (pl == 0 && e < n) dst[e] = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
 }
 
+// Many partials (the conv weight gradients' slab per workgroup: 256 of them): 32 quads x 8 part lanes per block, eight 16-byte
+// loads in flight per lane (the narrow form above keeps two 4-byte loads in flight: 0.19 ms for the 79 MB of config 5's three
+// layers, latency-bound at 0.4 TB/s).  Fixed order: a lane adds its parts in ascending order, LDS folds the lanes in order.
+typedef float rp_v4f __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_reduce_partials_wide(const float *__restrict__ part, int nparts, long long n, float *__restrict__ dst) {
+  __shared__ rp_v4f red[8][32];
+  const int ql = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const long long qd = (long long)blockIdx.x * 32 + ql, nq = n >> 2;
+  rp_v4f s = {0.f, 0.f, 0.f, 0.f};
+  if (qd < nq) {
+    const rp_v4f *src = reinterpret_cast<const rp_v4f *>(part) + qd;
+    int p = pl;
+    for (; p + 56 < nparts; p += 64) {
+      rp_v4f v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(long long)(p + 8 * u) * nq];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; p < nparts; p += 8) s += src[(long long)p * nq];
+  }
+  red[pl][ql] = s;
+  __syncthreads();
+  if (pl == 0 && qd < nq) {
+    rp_v4f t = red[0][ql];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += red[k][ql];
+    reinterpret_cast<rp_v4f *>(dst)[qd] = t;
+  }
+}
+
 // see update_kernels.h: the critics' head finish.  grid (ceil(M / 16), groups), one wave = 16 rows per workgroup.
 // v_mfma_f32_16x16x4_f32: lane l holds A[row l & 15][k = 4 (l >> 4) + c] and B[k][column l & 15] for step c of a 16-k
 // block; D: column l & 15, rows 4 (l >> 4) + reg.
@@ -2116,6 +2147,10 @@ hipError_t sum_parts_colsum_launch(const float *part, int nparts, int rows, int 
   return hipGetLastError();
 }
 hipError_t reduce_partials_launch(const float *part, int nparts, long long n, float *dst, hipStream_t s) {
+  if (nparts >= 32 && (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(part) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) {
+    hipLaunchKernelGGL(k_reduce_partials_wide, dim3((unsigned)((n / 4 + 31) / 32)), dim3(256), 0, s, part, nparts, n, dst);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, part, nparts, n, dst);
   return hipGetLastError();
 }
