@@ -583,13 +583,16 @@ int build_plan(fdql_agent *a) {
   const bool chain_on = chain_mode != 0;
   std::vector<int> bms;
   {
-    if (chain_all || N >= (long long)chain_min_blocks * CH_BM) bms.push_back(CH_BM);
     // 32-row blocks only while they are one round of workgroups (one per CU): measured at config 4, 128 windows per GPU
     // (200 blocks) 1.172 -> 1.154 ms per step against the six per-layer launches; at 256 windows (400 blocks, 1.6 rounds) the
-    // chain is the slower one (1.902 -> 1.987 ms)
+    // chain is the slower one (1.902 -> 1.987 ms).  While they ARE one round they come first: a block's time is the weights it
+    // streams plus its MFMAs, 200 blocks of 32 rows finish in 0.10 ms where 100 blocks of 64 take 0.146 (config 2, 128 windows).
     int ncu = 256, dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    if (chain_all || (N >= (long long)chain_min_blocks * 32 && (N + 31) / 32 <= ncu)) bms.push_back(32);
+    const bool one_round32 = N >= (long long)chain_min_blocks * 32 && (N + 31) / 32 <= ncu;
+    if (one_round32 && !chain_all) bms.push_back(32);
+    if (chain_all || N >= (long long)chain_min_blocks * CH_BM) bms.push_back(CH_BM);
+    if (chain_all) bms.push_back(32);
   }
   bool enc_chained = false;
   for (size_t t = 0; t < bms.size() && !enc_chained && (chain_all || chain_on) && !gru; ++t) {
