@@ -920,6 +920,33 @@ class DPRun:
         return float(t.item())
 
 
+def dp_run_best(w, dev, B_local, T, rank, world, backend, dist, nat, ring_slots=None, calib_steps=30):
+    """The launch list a rank runs is a plan decision like the others, taken by measurement where it cannot be known ahead: the
+    two-bucket plan (critics' gradients all-reduced beside the actor / encoder backward; three launches more, the dense weight
+    gradients in two launches) against the one-bucket plan (the single-GPU launch list, one all-reduce behind the last
+    gradient).  Which wins depends on the collective's latency on the node at hand and on the rank's batch (a rank's share of
+    a strong-scaled step is launch-bound).  Both are timed for `calib_steps` steps (MAX over ranks: every rank sees the same
+    two numbers), the faster one runs the timed region.  FDQL_NO_BUCKETS / FDQL_FORCE_BUCKETS set by the caller: no choice."""
+    if os.environ.get("FDQL_NO_BUCKETS") or os.environ.get("FDQL_FORCE_BUCKETS"):
+        run = DPRun(w, dev, B_local, T, rank, world, backend, dist, nat, ring_slots=ring_slots)
+        return run, {"chosen": "one_bucket" if run.bucket >= run.job.agent.grads.numel() else "two_bucket", "calibration": None}
+    runs, ms = {}, {}
+    for mode in ("two_bucket", "one_bucket"):
+        if mode == "one_bucket":
+            os.environ["FDQL_NO_BUCKETS"] = "1"          # read once, when the agent is created
+        try:
+            runs[mode] = DPRun(w, dev, B_local, T, rank, world, backend, dist, nat, ring_slots=ring_slots)
+        finally:
+            os.environ.pop("FDQL_NO_BUCKETS", None)
+        ms[mode] = round(1e3 * runs[mode].timed(calib_steps, 10) / calib_steps, 4)
+    best = min(ms, key=ms.get)
+    for mode in list(runs):
+        if mode != best:
+            del runs[mode]
+    torch.cuda.empty_cache()
+    return runs[best], {"chosen": best, "calibration": {"steps": calib_steps, "ms_per_step": ms}}
+
+
 def bench_distributed(args, dev, T, rank, world, backend, dist, nat):
     """N > 1.  `value` = the metric's literal reading: BASELINE config 2 with the GLOBAL batch fixed at 256 windows, split
     256/N per GPU - optimiser iterations (= gradient steps of the 256-window minibatch) per second, "scaling": "strong".
@@ -936,7 +963,7 @@ def bench_distributed(args, dev, T, rank, world, backend, dist, nat):
     B2 = args.batch or w2["B"]
     if B2 % world:
         raise SystemExit(f"global batch {B2} windows does not split over {world} ranks")
-    run = DPRun(w2, dev, B2 // world, T, rank, world, backend, dist, nat, ring_slots=ring2)
+    run, plan2 = dp_run_best(w2, dev, B2 // world, T, rank, world, backend, dist, nat, ring_slots=ring2)
     el = run.timed(K, W)
     it_s = K / el
     roofline, top = (roofline_of(run.job, committed_pmc=False) if rank == 0 else (None, None))
@@ -948,12 +975,12 @@ def bench_distributed(args, dev, T, rank, world, backend, dist, nat):
     weak2, strong4, single4 = None, None, None
     if extra:
         # ---- config 2, 256 windows PER GPU (global batch 256 N): one optimiser iteration consumes N minibatches
-        rw = DPRun(w2, dev, B2, T, rank, world, backend, dist, nat, ring_slots=ring2)
+        rw, planw = dp_run_best(w2, dev, B2, T, rank, world, backend, dist, nat, ring_slots=ring2)
         nw = max(K, 50)
         ew = rw.timed(nw, max(W, 5))
         weak2 = {"workload": f"{w2['text']} per rank, B={B2} windows PER GPU x T={T} (global batch {B2 * world})", "scaling": "weak",
                  "optimizer_iterations_per_s": round(nw / ew, 2), "minibatches_per_s": round(world * nw / ew, 2),
-                 "transitions_per_s": round(nw / ew * B2 * world * T, 0), "ms_per_step": round(1e3 * ew / nw, 4), "steps": nw,
+                 "transitions_per_s": round(nw / ew * B2 * world * T, 0), "ms_per_step": round(1e3 * ew / nw, 4), "steps": nw, "dp_plan": planw,
                  "note": "one all-reduced Adam update = ONE gradient step whatever N is; minibatches_per_s = N x optimizer_iterations_per_s "
                          "counts the 256-window minibatches differentiated per second"}
         del rw
@@ -970,13 +997,13 @@ def bench_distributed(args, dev, T, rank, world, backend, dist, nat):
                 del j1
                 torch.cuda.empty_cache()
             dist.barrier()
-            r4 = DPRun(w4, dev, B4 // world, T, rank, world, backend, dist, nat, ring_slots=ring4)
+            r4, plan4 = dp_run_best(w4, dev, B4 // world, T, rank, world, backend, dist, nat, ring_slots=ring4, calib_steps=20)
             n4 = max(K, 30)
             e4 = r4.timed(n4, max(W, 5))
             strong4 = {"workload": f"{w4['text']} per rank, GLOBAL batch {B4} windows split {B4 // world} per GPU x T={T}",
                        "scaling": "strong", "value": round(n4 / e4, 2), "unit": "steps/s", "ms_per_step": round(1e3 * e4 / n4, 4),
                        "steps": n4, "transitions_per_s": round(n4 / e4 * B4 * T, 0),
-                       "grad_arena_MB": round(r4.job.agent.grads.numel() * 4 / 1e6, 2), "same_workload_1gpu": single4}
+                       "grad_arena_MB": round(r4.job.agent.grads.numel() * 4 / 1e6, 2), "same_workload_1gpu": single4, "dp_plan": plan4}
             if single4:
                 strong4["speedup_vs_1gpu"] = round(strong4["value"] / single4["value"], 3)
             del r4
@@ -986,15 +1013,16 @@ def bench_distributed(args, dev, T, rank, world, backend, dist, nat):
         "steps": K, "warmup": W, "ms_per_step": round(1e3 * el / max(K, 1), 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{w2['text']} per rank, GLOBAL batch {B2} windows split {B2 // world} per GPU x temporal_len T={T}, "
-                               f"sample+loss+backward, all-reduce of the {arena_mb:.2f} MB gradient arena in two buckets "
-                               f"({backend}; {bucket_frac:.0%} of it beside the actor / encoder backward), Adam+polyak on every rank",
+                               f"sample+loss+backward, all-reduce of the {arena_mb:.2f} MB gradient arena "
+                               + (f"in two buckets ({backend}; {bucket_frac:.0%} of it beside the actor / encoder backward)" if bucket_frac > 0
+                                  else f"in one bucket behind the last gradient ({backend})") + ", Adam+polyak on every rank",
                    "windows_per_gpu": B2 // world, "global_batch_windows": B2, "temporal_len": T,
                    "transitions_per_step": B2 * T, "ring": ring2, "parallelism": f"dp{world}",
                    "collective_ranks": dist.get_world_size(), "backend": backend},
         "value_is": "optimiser iterations per second = gradient steps of the 256-window global minibatch (the metric's 'batch=256'); "
                     "the N = 1 point is the single-GPU BENCH line (same global batch)",
         "optimizer_iterations_per_s": round(it_s, 2), "transitions_per_s": round(it_s * B2 * T, 0),
-        "config2_weak": weak2, "config4_strong": strong4,
+        "dp_plan": plan2, "config2_weak": weak2, "config4_strong": strong4,
         "roofline": roofline, "cpu_baseline": None, "kernel_ms_top": top, "csrc_sha": csrc_hash(),
     }
 

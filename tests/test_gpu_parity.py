@@ -596,6 +596,10 @@ def test_update_matches_oracle_config2(dev, T, B, hid):
     ("config 2 dims at T=50, B=32: one rank's share of the 256-window global batch at N = 8 (1 568 gradient rows: d state as per-network "
      "problems + a summing pass, the tile / small-batch kernels for the single networks, weight-stationary critics layer 1)",
      dict(obs=17, act=6, C=5, Q=2, T=50, B=32)),
+    ("config 2 dims at T=50, B=128: one rank's share at N = 2 (6 272 gradient rows: encoder -> joiner -> actors as 200 chain blocks of "
+     "32 rows, k_chain<1>, the output-stationary weight-gradient launch at 11 tiles per workgroup)", dict(obs=17, act=6, C=5, Q=2, T=50, B=128)),
+    ("config 2 dims at T=50, B=64: one rank's share at N = 4 (3 136 gradient rows: 100 chain blocks of 32 rows, the dense weight "
+     "gradients as K-split problems riding in the dgrad launches)", dict(obs=17, act=6, C=5, Q=2, T=50, B=64)),
     ("config 2 dims at T=50, B=384: 18 816 gradient rows = 294 blocks of 64 - k_rowdgrad_chain (d state sum + joiner / d enc / "
      "encoder dgrads in one launch) with MORE blocks than one round of workgroups", dict(obs=17, act=6, C=5, Q=2, T=50, B=384)),
 ])
