@@ -1,13 +1,16 @@
 #!/bin/bash
 # Regenerates the evidence under profiles/ on a GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh'
+#   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh a'     (the headline: bench line, kernel stats, PMC passes)
+#   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh b'     (the other workloads, config 5, the N > 1 rehearsal)
 # Writes into gpurun_out/profiles_new/ (merged back by gpurun); copy what should be judged into profiles/ (round prefix).
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+PART=${1:-ab}
 OUT=$R/gpurun_out/profiles_new
-rm -rf $OUT
 mkdir -p $OUT $OUT/c5
 cd /tmp && export TMPDIR=/tmp
+if [[ $PART == *a* ]]; then
+rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_insts
 # 1. bench line (N=1) and its rocprofv3 kernel stats (same command)
 python3 $R/bench.py --steps 20 --warmup 5 > $OUT/bench_n1.json 2> $OUT/bench_n1.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-extras > $OUT/bench_under_rocprof.json 2> $OUT/stats.err || exit 1
@@ -21,6 +24,10 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_C
 # 5. instruction mix of every dense kernel (what the fp32 MFMA stream is shared with): counts in their own pass
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU --output-format csv -d $OUT/pmc_insts -- python3 $R/tools/profile_stages.py --reps 1 > $OUT/pmc_insts.log 2>&1 || exit 1
 python3 $R/tools/summarize_profiles.py $OUT || exit 1
+echo "part a collected"
+fi
+if [[ $PART == *b* ]]; then
+rm -rf $OUT/c5; mkdir -p $OUT/c5
 # 6. the other workloads' per-stage times, the small-batch step, act() latency, the GRU joiner step
 python3 $R/tools/profile_stages.py --obs 376 --act 17 --Q 25 --B 1024 --reps 3 > $OUT/stage_times_config4_B1024.txt 2>&1 || exit 1
 python3 $R/tools/profile_stages.py --obs 376 --act 17 --Q 25 --B 128 --reps 5 > $OUT/stage_times_config4_B128_per_rank.txt 2>&1 || exit 1
@@ -39,4 +46,5 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS
 python3 $R/tools/summarize_profiles.py $OUT/c5 "tools/config5_bench.py (BASELINE config 5, T=50, B=512, frames read from the uint8 ring in place)" || exit 1
 # 8. the N > 1 code path from the plain command line (ranks share this box's one GPU: gloo rehearsal, not a scaling figure)
 FDQL_BENCH_BACKEND=gloo FDQL_BENCH_RING=200000 python3 $R/bench.py --gpus 2 --steps 20 --warmup 5 > $OUT/bench_2rank_gloo_plain_launch.json 2> $OUT/bench_2rank.err || exit 1
-echo collected
+echo "part b collected"
+fi
