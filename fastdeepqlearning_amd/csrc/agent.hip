@@ -266,14 +266,13 @@ int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {
     int dev = 0;
     if (plan_switches().wgrad_stat && plan_switches().stream_wgrad != 0 && nblk > 0 && nblk <= WG_MAX_INST && a->M % WG_BM == 0 &&
         a->M / a->nsplit <= STREAM_WGRAD_MAX_SLAB_ROWS &&   // (long slabs keep the tile kernels' narrow launches, which want the splits)
-        (long long)nblk * (a->M / WG_BM) >= a->wgrad_stat_factor * a->rows_min_tiles && hipGetDevice(&dev) == hipSuccess &&
-        hipGetDeviceProperties(&pr, dev) == hipSuccess) {
+        hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) {
       // a data-parallel (two-bucket) plan launches the critics' blocks and the rest separately (at most one workgroup per slab
       // and block): sized to the larger launch, the critics' (config 2: 10 blocks -> 28 slabs; the 5-block launch of the
       // rest then runs 140 workgroups instead of 100)
       const int per_launch = a->bucketed() && nblk_critics > 0 ? std::max(nblk_critics, nblk - nblk_critics) : nblk;
       const int want = std::max(8, pr.multiProcessorCount / per_launch + 3);
-      if (want < a->nsplit) a->nsplit = want;
+      if (want < a->nsplit && a->wgrad_stat_pays(per_launch)) a->nsplit = want;
     }
   }
   {

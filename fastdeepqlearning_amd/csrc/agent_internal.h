@@ -243,9 +243,12 @@ struct fdql_agent {
   int rowdot_min_rows = 4096;       // rows from which a stage of narrow-output dgrads runs on k_rowdot
   int rowdgrad_max_blocks = 256;    // ... and may have: one round of workgroups (config 4 at B = 1024, 784 blocks = 3.06 rounds: the tile
                                     // kernel's 3136 tiles are the better fit there: 0.138 against 0.153 ms for d enc)
-  int wgrad_stat_factor = 8;        // x rows_min_tiles 32-row tiles for the output-stationary weight-gradient launch: 8 per workgroup (a
-                                    //   workgroup writes a 256 KB partial whatever its rows: config 2 at 64 windows, 5.8 tiles each, 0.541 ms with
-                                    //   the launch and 0.502 with the gradients riding in the dgrad launches; at 128 windows 0.722 against 0.753)
+  int wgrad_stat_factor = 6;        // x rows_min_tiles 32-row tiles for the output-stationary weight-gradient launch (1 with FDQL_ROWGEMM=all):
+                                    //   1536 = 8 tiles for each of 192 workgroups.  A workgroup writes a 256 KB partial whatever its rows -
+                                    //   config 2 at 64 windows (1470 tiles: 120 workgroups of 12) 0.541 ms with the launch, 0.502 with the
+                                    //   gradients riding in the dgrad launches; at 128 windows (2940 tiles) 0.722 against 0.753; the 5-block
+                                    //   launch of the two-bucket plan at 256 windows (1960 tiles) 1.241 against 1.257
+  bool wgrad_stat_pays(long long nblk) const { return nblk * (M / 32) >= wgrad_stat_factor * rows_min_tiles; }
   int small_max_tiles = 128;        // a GEMM stage of at most this many 64x64 tiles runs on the small-batch kernel (smallgemm.hip); 0: never
   // d state = sum over the online critics and the actor: one problem accumulating every network's K-segments, or - few rows
   // (a handful of workgroups would walk all segments serially), or many rows with critics the weight-stationary kernel

@@ -44,8 +44,7 @@ struct Builder {
     for (auto &pc : wg_cand) probs.push_back(pc.first);
     Stage wst;
     wst.kind = ST_WGRAD_STAT; wst.name = name;
-    const long long tiles = (long long)probs.size() * (probs[0].seg[0].K / WG_BM);
-    if (tiles >= a->wgrad_stat_factor * a->rows_min_tiles && wgrad_stat_from_problems(probs.data(), (int)probs.size(), a->nsplit, a->n_train, wst.wga)) {
+    if (a->wgrad_stat_pays((long long)probs.size()) && wgrad_stat_from_problems(probs.data(), (int)probs.size(), a->nsplit, a->n_train, wst.wga)) {
       // the few-column / few-row gradients that share an operand with one of the blocks (a critic's action columns, its
       // skip head's rows over the state and over h0) ride with it instead of re-reading the operand in the tail launches
       for (size_t i = 0; i < fallback.gemm.size();) {
