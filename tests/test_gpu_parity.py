@@ -936,6 +936,50 @@ def _gpu_branch_pattern(ag, spec, xp_cpu):
     return pat
 
 
+def _f64_eval(dev, spec, params, xp, nt, na, alpha, force=None):
+    """The fp64 arbiter of the three-way test: oracle.update.grads_in in float64.  dev = a GPU: the SAME Python code evaluated
+    by torch on the device (torch's own float64 kernels and rocBLAS dgemm - nothing of this library); the evaluation is 2-10 s
+    of CPU time otherwise, two per case, which was most of the suite's wall clock.  The float32 evaluations - the reference
+    CPU path - always run on the CPU, and so does the arbiter of the default full-size case (dev = None);
+    test_fp64_arbiter_on_the_device_agrees_with_the_cpu pins the two float64 evaluations to each other.
+    FDQL_TEST_FP64_CPU=1: the CPU everywhere."""
+    from oracle import update as oup
+    if dev is None or os.environ.get("FDQL_TEST_FP64_CPU"):
+        return oup.grads_in(torch.float64, spec, params, xp, nt, na, alpha, force=force)
+    to = lambda d: {k: v.to(dev) for k, v in d.items()}
+    with torch.device(dev):   # the oracle's factory calls (arange, eye, zeros) follow its inputs to the device
+        loss, g, dq, rec, _ = oup.grads_in(torch.float64, spec, to(params), to(xp), nt.to(dev), na.to(dev), alpha,
+                                           force=None if force is None else to(force))
+    return loss.cpu(), {k: v.cpu() for k, v in g.items()}, dq.cpu(), {k: v.cpu() for k, v in rec.items()}, None
+
+
+@pytest.mark.gpu
+def test_fp64_arbiter_on_the_device_agrees_with_the_cpu(dev):
+    """Both float64 evaluations of the oracle - torch on the CPU and torch on the GPU - on one batch, unforced and with a
+    branch pattern imposed: gradients equal to 1e-11, pre-activations to 1e-12 (max-norm relative)."""
+    from oracle import update as oup
+    spec = oup.Spec(obs=17, act=6, C=5, Q=2, T=8, B=96)
+    params = oup.init_params(spec, seed=3)
+    st = oup.new_state(spec, params)
+    g = torch.Generator().manual_seed(1)
+    T, B = spec.T, spec.B
+    xp = {"obs_1d": torch.randn(T, B, spec.obs, generator=g), "action": torch.rand(T, B, spec.act, generator=g) * 2 - 1,
+          "reward": torch.randn(T, B, 1, generator=g), "mc_return": torch.randn(T, B, 1, generator=g) * 2,
+          "task_done": (torch.rand(T, B, 1, generator=g) < 0.05).float(),
+          "episode_step": (torch.arange(T).view(T, 1, 1) + torch.randint(0, 900, (1, B, 1), generator=g)).float()}
+    nt, na = torch.randn(T - 1, B, spec.act, generator=g), torch.randn(T - 1, B, spec.act, generator=g)
+    _, gc, dqc, recc, _ = oup.grads_in(torch.float64, spec, params, xp, nt, na, st.alpha)
+    _, gd, dqd, recd, _ = _f64_eval(dev, spec, params, xp, nt, na, st.alpha)
+    assert set(gc) == set(gd) and set(recc) == set(recd)
+    rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-300))
+    assert max(rel(gd[n], gc[n]) for n in gc) < 1e-11 and rel(dqd, dqc) < 1e-11
+    assert max(rel(recd[k].double(), recc[k].double()) for k in recc) < 1e-12
+    pat = {k: (v > 0) ^ (torch.rand(v.shape, generator=g) < 1e-3) for k, v in recc.items()}   # a pattern with flips imposed
+    _, gcf, dqcf, _, _ = oup.grads_in(torch.float64, spec, params, xp, nt, na, st.alpha, force=pat)
+    _, gdf, dqdf, _, _ = _f64_eval(dev, spec, params, xp, nt, na, st.alpha, force=pat)
+    assert max(rel(gdf[n], gcf[n]) for n in gcf) < 1e-11 and rel(dqdf, dqcf) < 1e-11
+
+
 @pytest.mark.parametrize("name,kw", [
     ("config 2 full size (T=50, B=256)", dict(obs=17, act=6, C=5, Q=2, T=50, B=256)),
     ("config 4 dims (obs 376, act 17, 5x25 quantiles, T=3, B=96)", dict(obs=376, act=17, C=5, Q=25, T=3, B=96)),
@@ -1006,14 +1050,16 @@ def test_gradient_parity_three_way_fp64(dev, name, kw, monkeypatch):
     g_gpu["d loss / d q_pred"] = ag.debug("dz", (T - 1, B, spec.Nq)).cpu().double()
     # the unforced CPU evaluations depend on the spec alone (fixed seeds): shared by the cases that differ only in plan switches
     ckey = repr(sorted(kw.items()))
+    # the arbiter of the default full-size case is evaluated on the CPU, the others' by torch on the GPU (_f64_eval)
+    dev64 = None if name == "config 2 full size (T=50, B=256)" else dev
     if ckey not in _THREE_WAY_CACHE:
         _, g32, dq32, rec32, _ = oup.grads_in(torch.float32, spec, params, xp, nt, na, st.alpha)
-        _, g64, dq64, rec64, _ = oup.grads_in(torch.float64, spec, params, xp, nt, na, st.alpha)
+        _, g64, dq64, rec64, _ = _f64_eval(dev64, spec, params, xp, nt, na, st.alpha)
         while len(_THREE_WAY_CACHE) >= 3:   # (three specs at most: a full-size case holds ~1 GB of pre-activations)
             _THREE_WAY_CACHE.pop(next(iter(_THREE_WAY_CACHE)))
         _THREE_WAY_CACHE[ckey] = (g32, dq32, rec32, g64, dq64, rec64)
     g32, dq32, rec32, g64, dq64, rec64 = (dict(v) if isinstance(v, dict) else v for v in _THREE_WAY_CACHE[ckey])
-    _, g64f, dq64f, _, _ = oup.grads_in(torch.float64, spec, params, xp, nt, na, st.alpha, force=pat)
+    _, g64f, dq64f, _, _ = _f64_eval(dev64, spec, params, xp, nt, na, st.alpha, force=pat)
     _, g32f, dq32f, _, _ = oup.grads_in(torch.float32, spec, params, xp, nt, na, st.alpha, force=pat)
     for d, dq in ((g32, dq32), (g64, dq64), (g64f, dq64f), (g32f, dq32f)):
         d["d loss / d q_pred"] = dq
