@@ -240,7 +240,7 @@ struct fdql_agent {
                                     // 64-row tile per CU (a weight-stationary workgroup with 2 + 2 32-row tiles still beats the tile
                                     // kernels: config 4 at 128 windows per GPU)
   int rowdgrad_min_blocks = 128;    // 64-row blocks a single-network dgrad needs for the row-block dgrad kernel (FDQL_ROWDGRAD_MIN_BLOCKS)
-  int rowdot_min_rows = 4096;       // rows from which a stage of narrow-output dgrads runs on k_rowdot
+  int rowdot_min_rows = 2048;       // rows from which a stage of narrow-output dgrads runs on k_rowdot (config 2: 3136 rows 18.4 against 23.4 us on 128x32 tiles; 1568 rows 18.2 against 16.4 on the small-batch kernel)
   int rowdgrad_max_blocks = 256;    // ... and may have: one round of workgroups (config 4 at B = 1024, 784 blocks = 3.06 rounds: the tile
                                     // kernel's 3136 tiles are the better fit there: 0.138 against 0.153 ms for d enc)
   int wgrad_stat_factor = 6;        // x rows_min_tiles 32-row tiles for the output-stationary weight-gradient launch (1 with FDQL_ROWGEMM=all):
