@@ -17,6 +17,7 @@ ap.add_argument("--T", type=int, default=50)
 ap.add_argument("--B", type=int, default=512)
 ap.add_argument("--ring", type=int, default=200_000)
 ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--dense-shape", type=int, default=-1, help="tile shape of the dense GEMM launches (test hook fdql_debug_set_gemm_dense_shape: 0 = 128x128, 3 = 64x128, 5 = 64x64, the default)")
 ap.add_argument("--f32", action="store_true", help="float32 frame batch (the im2col first layer) instead of reading the uint8 ring in place")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -39,6 +40,9 @@ while done < a.ring:                      # synthetic fill, on the device
     done += n
 cfg = make_config(0, ACT, a.T, a.B, discrete=True, n_critics=5, n_quantiles=2, img=IMG, conv=((32, 8, 4), (64, 4, 2), (64, 3, 1)),
                   obs_2d_u8=not a.f32)
+if a.dense_shape >= 0:
+    from fastdeepqlearning_amd import _native as nat
+    nat.check(nat.load().fdql_debug_set_gemm_dense_shape(a.dense_shape))
 agent = NativeAgent(cfg, dev)
 agent.init_weights(0)
 print(f"ring {a.ring} frames of {dims[0]} B as uint8; workspace {agent.workspace.numel() / 2**30:.1f} GiB; frames "
