@@ -225,3 +225,47 @@ def test_data_parallel_gradient_identity_gloo():
     [p.join(120) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     assert ret["err"] < 1e-5, ret["err"]
+
+
+def test_bench_picks_the_faster_data_parallel_launch_list(monkeypatch):
+    """bench.py::dp_run_best (N > 1): both launch lists are built - the one-bucket one under FDQL_NO_BUCKETS, which must not
+    leak into the environment - each is timed, the faster one is returned; a switch set by the caller takes the choice away."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    built = []
+
+    class FakeAgent:
+        def __init__(self, no_buckets):
+            self.grads = torch.zeros(100)
+            self._b = 100 if no_buckets else 34
+
+    class FakeJob:
+        def __init__(self, no_buckets):
+            self.agent = FakeAgent(no_buckets)
+
+    class FakeRun:
+        ms = {False: 1.30, True: 1.10}   # two-bucket, one-bucket
+
+        def __init__(self, *a, **k):
+            self.nb = os.environ.get("FDQL_NO_BUCKETS") is not None
+            self.job = FakeJob(self.nb)
+            self.bucket = self.job.agent._b
+            built.append(self.nb)
+
+        def timed(self, steps, warmup):
+            return self.ms[self.nb] * 1e-3 * steps
+
+    monkeypatch.setattr(bench, "DPRun", FakeRun)
+    monkeypatch.delenv("FDQL_NO_BUCKETS", raising=False)
+    monkeypatch.delenv("FDQL_FORCE_BUCKETS", raising=False)
+    run, plan = bench.dp_run_best({}, "cpu", 32, 50, 0, 2, "gloo", None, None)
+    assert built == [False, True] and "FDQL_NO_BUCKETS" not in os.environ
+    assert plan["chosen"] == "one_bucket" and run.nb and plan["calibration"]["ms_per_step"] == {"two_bucket": 1.3, "one_bucket": 1.1}
+    FakeRun.ms = {False: 0.90, True: 1.10}
+    run, plan = bench.dp_run_best({}, "cpu", 32, 50, 0, 2, "gloo", None, None)
+    assert plan["chosen"] == "two_bucket" and not run.nb
+    monkeypatch.setenv("FDQL_NO_BUCKETS", "1")   # the caller decided: one run, no calibration
+    del built[:]
+    run, plan = bench.dp_run_best({}, "cpu", 32, 50, 0, 2, "gloo", None, None)
+    assert built == [True] and plan == {"chosen": "one_bucket", "calibration": None} and os.environ.get("FDQL_NO_BUCKETS") == "1"
