@@ -53,6 +53,8 @@ HBM_PEAK_GBS = 8000.0
 
 # name -> workload.  dims/keys: ring layout; rowbytes follow from it.
 WORKLOADS = {
+    "config1": dict(obs=3, act=1, goal=0, C=2, Q=1, distributional=False, ring=50_000, B=256, T=50, ep_len=200,
+                    text="BASELINE config 1: Pendulum dims (obs=3 act=1), SAC-min 2 critics, MLP(256,256), 50k-transition HBM ring"),
     "config2": dict(obs=17, act=6, goal=0, C=5, Q=2, ring=1_000_000, B=256, T=50, ep_len=1000,
                     text="BASELINE config 2: TQC 5x2 quantile critics, obs=17 act=6, MLP(256), 1M-transition HBM ring"),
     "config3": dict(obs=28, act=6, goal=10, C=5, Q=2, ring=1_000_000, B=256, T=50, ep_len=50,
@@ -114,12 +116,13 @@ class Job:
         slots = ring_slots or w["ring"]
         cfg = make_config(w["obs"], w["act"], T, B, goal_dim=w["goal"], n_critics=w["C"], n_quantiles=w["Q"], latent=HID,
                           enc_features=HID, enc_hidden=(HID,), joint_hidden=(HID,), pi_hidden=(HID,), critic_hidden=(HID, HID),
-                          world_size=world, keep_frozen_copy=True)
+                          distributional=w.get("distributional", True), world_size=world, keep_frozen_copy=True)
         self.agent = NativeAgent(cfg, dev)
         self.agent.init_weights(seed=0)                        # same weights on every rank
         # the ring is filled last: the step that follows finds the device as a running job would (busy, not idling
         # behind host-side set-up)
         self.ring = NativeRing(slots, self.dims, dev)
+        fill_chunk = min(fill_chunk, max(slots // 2, 1))       # (one add stays well inside the ring)
         for c0 in range(0, slots + 1000, fill_chunk):          # wraps once: len = slots - 1 (quirk q1)
             n = min(fill_chunk, slots + 1000 - c0)
             self.ring.add_rows(synth_rows(w, n, 1000 * rank + c0 // fill_chunk, dev))
@@ -187,8 +190,10 @@ class Job:
         for i in range(steps):
             self.step(first + warmup + i)
             evs[i + 1].record()
+        self.last_host_issue_ms = 1e3 * (time.perf_counter() - t0) / max(steps, 1)   # the loop without the synchronize
         torch.cuda.synchronize(self.dev)
         el = time.perf_counter() - t0
+        self.last_device_ms = evs[0].elapsed_time(evs[steps]) / max(steps, 1)
         return el, max(evs[i].elapsed_time(evs[i + 1]) for i in range(steps)) if steps else 0.0
 
     def timed_windows(self, steps, warmup, windows=3):
@@ -212,6 +217,45 @@ class Job:
             first += steps
         rates.sort()
         return rates[len(rates) // 2], rates, max_ms
+
+    def timed_split(self, steps, warmup, windows=3):
+        """timed_windows() that also says WHERE the time goes: per window the wall time of the step loop WITHOUT the trailing
+        synchronize (`host_issue_ms` per step: how long the host needs to enqueue one step - an upper bound, the runtime may
+        block the host when its queue is full) and the device's own first-to-last time (`device_ms` per step, HIP events on the
+        launch stream around the window).  A launch-bound step (17-23 dependent kernels) that is slow on one box shows here
+        whether the host or the chip was slow.  Returns the median window's figures + every window's rate + max_step_ms."""
+        for i in range(warmup):
+            self.step(i)
+        torch.cuda.synchronize(self.dev)
+        rows, max_ms, first = [], 0.0, warmup
+        for _ in range(windows):
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+            t0 = time.perf_counter()
+            evs[0].record()
+            for i in range(steps):
+                self.step(first + i)
+                evs[i + 1].record()
+            t_issue = time.perf_counter() - t0
+            torch.cuda.synchronize(self.dev)
+            t_all = time.perf_counter() - t0
+            rows.append((steps / t_all, 1e3 * t_issue / steps, evs[0].elapsed_time(evs[steps]) / steps))
+            max_ms = max(max_ms, max(evs[i].elapsed_time(evs[i + 1]) for i in range(steps)))
+            first += steps
+        med = sorted(rows)[len(rows) // 2]
+        return {"rate": med[0], "host_issue_ms": round(med[1], 4), "device_ms": round(med[2], 4),
+                "windows": [round(r[0], 2) for r in rows], "max_step_ms": round(max_ms, 4)}
+
+    def calibrate_launch_mode(self, max_rows=6272, steps=30):
+        """Eager launches or hipGraph replay for this plan, by measurement on this host (plans with <= max_rows TD rows: the
+        launch-bound regime); bigger plans stay eager (kernel-bound: replay measured 0.5-1.5 % slower)."""
+        if (self.T - 1) * self.B > max_rows or self.prefetch:
+            return {"chosen": "eager", "calibration": None}
+        self._ci = getattr(self, "_ci", 900_000)
+
+        def one():
+            self.step(self._ci)
+            self._ci += 1
+        return self.agent.calibrate_launch_mode(one, steps=steps)
 
     def kernel_profile(self, reps=3):
         """name -> (ms, flops, bytes, launches) per step, HIP events on the launch stream."""
@@ -340,7 +384,7 @@ def sampler_roofline(job, reps=50):
             "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes": nbytes}
 
 
-def cpu_baseline(w, T, B, seconds_budget=25.0):
+def cpu_baseline(w, T, B, seconds_budget=25.0, max_steps=200, thread_sets=None):
     """The CPU oracle (oracle/: numpy ring + eager-torch update, a port of the reference path) timed on this host:
     sample + update, steady state, bounded sample of the same workload."""
     from oracle import update as oup
@@ -348,10 +392,11 @@ def cpu_baseline(w, T, B, seconds_budget=25.0):
     keys, dims = layout(w)
     threads = torch.get_num_threads()
     spec = oup.Spec(obs=w["obs"], act=w["act"], C=w["C"], Q=w["Q"], latent=HID, enc_features=HID, enc_hidden=(HID,),
-                    joint_hidden=(HID,), pi_hidden=(HID,), critic_hidden=(HID, HID), T=T, B=B)
+                    joint_hidden=(HID,), pi_hidden=(HID,), critic_hidden=(HID, HID), distributional=w.get("distributional", True),
+                    T=T, B=B)
     st = oup.new_state(spec, oup.init_params(spec, seed=0))
     ring = RingOracle(w["ring"], B, T)
-    rows = synth_rows(w, 200_000, 0, "cpu").numpy()          # a 200k-row slice of the ring is enough for timing
+    rows = synth_rows(w, min(200_000, w["ring"] - 1), 0, "cpu").numpy()   # a <= 200k-row slice of the ring is enough for timing
     off = np.cumsum([0] + dims)
     ring.memory = {k: np.zeros((w["ring"], d), np.float32) for k, d in zip(keys, dims)}
     for j, k in enumerate(keys):
@@ -378,14 +423,15 @@ def cpu_baseline(w, T, B, seconds_budget=25.0):
             one()
             n += 1
             el = time.perf_counter() - t0
-            if el > budget or n >= 200:
+            if el > budget or n >= max_steps:
                 break
         return n / el, n, el
 
     # eager torch-CPU on small GEMMs does not scale to a whole socket: time all cores and 16 threads, report the faster
-    results = [(timed(threads, seconds_budget / 2), threads)]
-    if threads > 16:
-        results.append((timed(16, seconds_budget / 2), 16))
+    # (the secondaries' short baselines run the 16-thread setting only: the faster one at config 2 on every box so far)
+    sets = thread_sets or ([threads, 16] if threads > 16 else [threads])
+    sets = sorted({min(t, threads) for t in sets}, reverse=True)
+    results = [(timed(t, seconds_budget / len(sets)), t) for t in sets]
     torch.set_num_threads(threads)
     t0 = time.perf_counter()
     for _ in range(20):
@@ -403,18 +449,77 @@ def secondary(name, dev, steps=200, warmup=10, **kw):
     """steps/s of another BASELINE config on this one GPU + its dominant kernel's fraction (never `value`): the median of
     three windows of `steps` steps each, every window's figure and the longest single step listed beside it."""
     w = WORKLOADS[name]
+    cpu_budget, cpu_steps = kw.pop("cpu_budget", 4.0), kw.pop("cpu_steps", 50)
     job = Job(w, dev, kw.pop("B", w["B"]), kw.pop("T", w["T"]), **kw)
+    mode = job.calibrate_launch_mode()
     plans0 = job.agent.stats()["plans_built"]
-    med, rates, max_ms = job.timed_windows(steps, warmup)
+    sp = job.timed_split(steps, warmup)
+    med = sp["rate"]
     r, _ = roofline_of(job, committed_pmc=False)
+    smp = sampler_roofline(job, 20)
     out = {"workload": w["text"] + f", B={job.B} x T={job.T}", "value": round(med, 2), "unit": "steps/s",
-           "ms_per_step": round(1e3 / med, 4), "steps": steps, "windows": [round(x, 2) for x in rates],
-           "max_step_ms": round(max_ms, 4), "plans_built_in_windows": job.agent.stats()["plans_built"] - plans0,
+           "ms_per_step": round(1e3 / med, 4), "steps": steps, "windows": sp["windows"],
+           "max_step_ms": sp["max_step_ms"], "host_issue_ms": sp["host_issue_ms"], "device_ms": sp["device_ms"],
+           "launch_mode": mode, "plans_built_in_windows": job.agent.stats()["plans_built"] - plans0,
            "dominant_kernel": r["kernel"], "dominant_kernel_tflops": r["achieved"], "dominant_kernel_frac": r["frac"],
            "all_mfma_kernels_tflops": r["all_mfma_kernels"]["achieved"],
-           "sampler_gbs": sampler_roofline(job, 20)["achieved"]}
+           "sampler_gbs": smp["achieved"], "sampler_roofline": smp}
+    B, T = job.B, job.T
     del job
     torch.cuda.empty_cache()
+    if cpu_budget:
+        try:
+            out["cpu_baseline"] = cpu_baseline(w, T, B, seconds_budget=cpu_budget, max_steps=cpu_steps, thread_sets=[16])
+        except Exception as e:   # noqa: BLE001
+            out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    return out
+
+
+def temporal_len_2(w, dev, B, steps=300):
+    """The plain 1-step-minibatch reading of batch=256 (temporal_len 2): 23 dependent launches of ~11 us.  Median of three
+    windows, the longest single step, host issue time against device time, and the launch mode chosen by calibration."""
+    job = Job(w, dev, B, 2, ring_slots=min(200_000, w["ring"]))
+    mode = job.calibrate_launch_mode()
+    sp = job.timed_split(steps, 30)
+    out = {"temporal_len": 2, "value": round(sp["rate"], 1), "unit": "steps/s", "ms_per_step": round(1e3 / sp["rate"], 4),
+           "steps": steps, "windows": sp["windows"], "max_step_ms": sp["max_step_ms"], "host_issue_ms": sp["host_issue_ms"],
+           "device_ms": sp["device_ms"], "launch_mode": mode, "launches_per_step": job.agent.stats()["n_launches"] + 1,
+           "transitions_per_step": 2 * B,
+           "note": "the plain 1-step-minibatch reading of batch=256: launch/latency-bound, 2.6 GFLOP per step; host_issue_ms = wall time "
+                   "of the step loop without the trailing synchronize, device_ms = HIP events first to last"}
+    del job
+    torch.cuda.empty_cache()
+    try:
+        cb = cpu_baseline(w, 2, B, seconds_budget=3.0, max_steps=100, thread_sets=[16])
+        out["cpu_baseline"] = cb
+    except Exception as e:   # noqa: BLE001
+        out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    return out
+
+
+def config1_pendulum(dev):
+    """BASELINE config 1 (the reference's own CPU-runnable case: franQ/Agent/components/soft_actor_critic.py:63-134 on
+    experiments/train/pendulum.py's dims): SAC-min, 2 critics, 50k ring, B=256; T=50 (reference default) and T=2."""
+    w = WORKLOADS["config1"]
+    out = secondary("config1", dev, steps=200, warmup=10, cpu_budget=3.0)
+    out["temporal_len_2"] = temporal_len_2(w, dev, w["B"], steps=200)
+    return out
+
+
+def config4_secondary(dev):
+    """Config 4 at the full batch on one GPU; its gather is the one bandwidth-bound sampler launch of the BASELINE configs, so
+    it carries a sampler_roofline with the PMC traffic of the committed rocprofv3 passes (quoted only on the same csrc revision);
+    the CPU baseline is a few oracle steps (one step is ~1.5 s of CPU work)."""
+    out = secondary("config4", dev, steps=100, warmup=5, cpu_budget=5.0, cpu_steps=3)
+    tj = os.path.join(ROOT, "profiles", "r06_sampler_traffic.json")
+    smp = out.get("sampler_roofline")
+    if smp and os.path.exists(tj):
+        tr = json.load(open(tj))
+        if tr.get("csrc_sha") == csrc_hash() and "config4" in tr:
+            smp["traffic"] = tr["config4"]["hbm_bytes_per_launch"]
+            smp["traffic_source"] = "profiles/r06_sampler_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        else:
+            smp["stale_profile"] = True
     return out
 
 
@@ -426,9 +531,12 @@ def config4_per_rank(dev, full_ms):
            "B1024_ms": round(full_ms, 4)}
     for n in (2, 4, 8):
         job = Job(w, dev, w["B"] // n, w["T"], ring_slots=200_000)
-        med, rates, max_ms = job.timed_windows(100, 10)
-        out[f"N{n}_B{w['B'] // n}_ms"] = round(1e3 / med, 4)
-        out[f"N{n}_speedup_bound"] = round(full_ms / (1e3 / med), 2)
+        mode = job.calibrate_launch_mode()
+        sp = job.timed_split(100, 10)
+        out[f"N{n}_B{w['B'] // n}_ms"] = round(1e3 / sp["rate"], 4)
+        out[f"N{n}_speedup_bound"] = round(full_ms / (1e3 / sp["rate"]), 2)
+        out[f"N{n}_detail"] = {"windows_steps_per_s": sp["windows"], "max_step_ms": sp["max_step_ms"], "host_issue_ms": sp["host_issue_ms"],
+                               "device_ms": sp["device_ms"], "launch_mode": mode}
         del job
         torch.cuda.empty_cache()
     return out
@@ -443,9 +551,12 @@ def config2_per_rank(dev, full_ms, T):
                    "(global batch 256 windows)", "B256_ms": round(full_ms, 4)}
     for n in (2, 4, 8):
         job = Job(w, dev, w["B"] // n, T, ring_slots=200_000)
-        med, rates, max_ms = job.timed_windows(200, 20)
-        out[f"N{n}_B{w['B'] // n}_ms"] = round(1e3 / med, 4)
-        out[f"N{n}_speedup_bound"] = round(full_ms / (1e3 / med), 2)
+        mode = job.calibrate_launch_mode()
+        sp = job.timed_split(200, 20)
+        out[f"N{n}_B{w['B'] // n}_ms"] = round(1e3 / sp["rate"], 4)
+        out[f"N{n}_speedup_bound"] = round(full_ms / (1e3 / sp["rate"]), 2)
+        out[f"N{n}_detail"] = {"windows_steps_per_s": sp["windows"], "max_step_ms": sp["max_step_ms"], "host_issue_ms": sp["host_issue_ms"],
+                               "device_ms": sp["device_ms"], "launch_mode": mode}
         del job
         torch.cuda.empty_cache()
     return out
@@ -809,23 +920,20 @@ def bench_single(args, dev, T):
     el_sus = job.timed(n_sus, 0, first=100_000)
     el, max_step_ms = job.timed_with_events(args.steps, args.warmup)
     ms_per_step = 1e3 * el / max(args.steps, 1)
+    host_issue_ms, device_ms = job.last_host_issue_ms, job.last_device_ms
     # two more windows of the same length right behind it: one stalled step in a short window shows up here
     more = [job.timed_with_events(args.steps, 0, first=300_000 + 1000 * k) for k in range(2)]
     roofline, top = roofline_of(job)
     sampler = sampler_roofline(job)
     extras, t2, facade = None, None, None
     if not args.no_extras:
-        t2job = Job(w, dev, B, 2, ring_slots=200_000)
-        e2 = t2job.timed(300, 30)
-        t2 = {"temporal_len": 2, "value": round(300 / e2, 1), "unit": "steps/s", "ms_per_step": round(1e3 * e2 / 300, 4),
-              "transitions_per_step": 2 * B, "note": "the plain 1-step-minibatch reading of batch=256: launch/latency-bound, 2.6 GFLOP per step"}
-        del t2job
-        torch.cuda.empty_cache()
+        t2 = temporal_len_2(w, dev, B)
         facade = facade_path(dev)
         extras = {}
-        for name, fn in (("config3_her", lambda: dict(secondary("config3", dev), her_ingest_records_per_s=config3_her_ingest(dev))),
+        for name, fn in (("config1_pendulum", lambda: config1_pendulum(dev)),
+                         ("config3_her", lambda: dict(secondary("config3", dev), her_ingest_records_per_s=config3_her_ingest(dev))),
                          ("config3_her_vmap", lambda: config3_her_vmap(dev)),
-                         ("config4_1gpu_B1024", lambda: secondary("config4", dev, steps=100, warmup=5)),
+                         ("config4_1gpu_B1024", lambda: config4_secondary(dev)),
                          ("config5_B512", lambda: config5_secondary(dev))):
             try:
                 extras[name] = fn()
@@ -851,7 +959,7 @@ def bench_single(args, dev, T):
                    "global_batch_windows": B, "temporal_len": T, "transitions_per_step": B * T, "ring": w["ring"],
                    "parallelism": "dp1"},
         "roofline": roofline, "cpu_baseline": cpu,
-        "max_step_ms": round(max_step_ms, 4),
+        "max_step_ms": round(max_step_ms, 4), "host_issue_ms": round(host_issue_ms, 4), "device_ms": round(device_ms, 4),
         "windows_after": [{"value": round(args.steps / e, 2), "max_step_ms": round(m, 4)} for e, m in more],
         "sustained": {"value": round(n_sus / el_sus, 2), "unit": "steps/s", "steps": n_sus, "seconds": round(el_sus, 2)},
         "sampler_roofline": sampler, "kernel_ms_top": top, "also_temporal_len_2": t2, "facade_path": facade,
@@ -1023,7 +1131,11 @@ def bench_distributed(args, dev, T, rank, world, backend, dist, nat):
                     "the N = 1 point is the single-GPU BENCH line (same global batch)",
         "optimizer_iterations_per_s": round(it_s, 2), "transitions_per_s": round(it_s * B2 * T, 0),
         "dp_plan": plan2, "config2_weak": weak2, "config4_strong": strong4,
-        "roofline": roofline, "cpu_baseline": None, "kernel_ms_top": top, "csrc_sha": csrc_hash(),
+        "roofline": roofline,
+        "cpu_baseline": {"value": None, "unit": "steps/s", "cores": None, "kind": "port", "sample": "not timed at N > 1",
+                         "see": "the N = 1 line of the same bench.py (BENCH_rNN.json): the CPU oracle is timed on rank 0 at N = 1 only, as the "
+                                "measurement contract asks; it does not depend on N"},
+        "kernel_ms_top": top, "csrc_sha": csrc_hash(),
     }
 
 

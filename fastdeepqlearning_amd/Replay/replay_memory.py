@@ -37,6 +37,7 @@ class ReplayMemory:
         self.device = torch.device(device if device is not None else "cuda:0")
         self._seed, self._counter = int(seed), 0
         self._ring = None
+        self._in_place, self._in_place_cache, self._blocks, self._slot_pool, self._start_pool = (), None, {}, {}, {}
         self._keys, self._shapes, self._dims, self._dtypes = [], [], [], []
 
     # ---------------------------------------------------------------- write
@@ -54,7 +55,15 @@ class ReplayMemory:
             # replay_memory.py:26-35 keeps the source dtype: uint8 frames stay one byte per element in HBM
             self._dtypes.append("u8" if a.dtype == np.uint8 and a.ndim > 0 else "f32")
         self._offsets = np.cumsum([0] + self._dims)
+        self._new_ring()
+
+    def _new_ring(self):
+        """(Re)creates the HBM ring for the current key layout.  Everything that points INTO a ring - the uint8 blocks handed
+        out for in-place reads, their slot / start buffers, the persistent sample buffers sized for the old layout - is dropped
+        with the old one: a batch sampled after a restore must never carry views of the ring it replaced."""
         self._ring = NativeRing(self._maxlen, self._dims, self.device, dtypes=self._dtypes)
+        self._in_place_cache, self._blocks, self._slot_pool, self._start_pool = None, {}, {}, {}
+        self._pool, self._pool_i = [], 0
 
     def _pack(self, experience_dict, out):
         for j, k in enumerate(self._keys):
@@ -157,7 +166,9 @@ class ReplayMemory:
         outs = None
         if self._pool_n:
             if len(self._pool) < self._pool_n:
-                self._pool.append([torch.empty((T, B, d), dtype=torch.float32, device=self.device) for d in self._dims])
+                # (no float32 buffer for a key read in place: 2.9 GB per pool entry at config 5)
+                self._pool.append([None if j in active.values() else torch.empty((T, B, d), dtype=torch.float32, device=self.device)
+                                   for j, d in enumerate(self._dims)])
             outs = [None if j in active.values() else o for j, o in enumerate(self._pool[self._pool_i % len(self._pool)])]
         if slot is None or slot not in self._slot_pool:
             so = torch.empty(B, dtype=torch.int64, device=self.device)
@@ -257,7 +268,7 @@ class ReplayMemory:
         self._dims = [int(np.prod(s)) if s else 1 for s in self._shapes]
         self._offsets = np.cumsum([0] + self._dims)
         self._dtypes = list(sd.get("dtypes") or ["f32"] * len(self._keys))
-        self._ring = NativeRing(self._maxlen, self._dims, self.device, dtypes=self._dtypes)
+        self._new_ring()
         self._ring.restore(sd["rows"], sd["top"], sd["len"])
 
     def save(self, path):

@@ -39,7 +39,9 @@ class TorchDataLoader(ReplayMemoryWrapper):
     def _can_prefetch(self):
         from ..replay_memory import ReplayMemory
         rb = self.replay_buffer
-        return self._prefetch and isinstance(rb, ReplayMemory) and rb._pool_n >= 3 and rb.device == self.device
+        # a shard whose frames are read IN PLACE is never prefetched: such a batch is not a snapshot (the update reads the
+        # ring's own slots when it runs), so a batch drawn one step ahead could see frames a writer replaced in between
+        return self._prefetch and isinstance(rb, ReplayMemory) and rb._pool_n >= 3 and rb.device == self.device and not rb._in_place
 
     def _issue_prefetch(self):
         """The next batch's gather on the side stream, behind everything the current stream holds so far (the update that
@@ -71,13 +73,13 @@ class TorchDataLoader(ReplayMemoryWrapper):
     def _on_device(self, batch):
         out = {}
         for key, value in batch.items():
-            if isinstance(value, torch.Tensor) and value.device == self.device and value.dtype == self.precision:
-                out[key] = value
-            elif isinstance(value, torch.Tensor) and value.device == self.device and (
+            if isinstance(value, torch.Tensor) and value.device == self.device and (
                     (key.endswith("_slots") and value.dtype == torch.int32) or (value.dtype == torch.uint8 and key + "_slots" in batch)):
                 out[key] = value          # a key read in place (ReplayMemory.enable_in_place): the ring's uint8 block + row slots
-            elif key in self.keep_uint8:  # the agent takes these frames as bytes (fdql_batch_t.obs_2d_u8)
+            elif key in self.keep_uint8:  # the agent takes these frames as bytes (fdql_batch_t.obs_2d_u8), whatever the shard stored
                 out[key] = torch.as_tensor(value).to(device=self.device, dtype=torch.uint8).contiguous()
+            elif isinstance(value, torch.Tensor) and value.device == self.device and value.dtype == self.precision:
+                out[key] = value
             else:
                 out[key] = torch.as_tensor(value).to(device=self.device, dtype=self.precision)
         return out
@@ -102,4 +104,4 @@ class TorchDataLoader(ReplayMemoryWrapper):
             self._pending = None
             torch.cuda.current_stream(self.device).wait_event(done)
         self._issue_prefetch()
-        return batch
+        return self._on_device(batch)      # (a pass-through for the ring's float32 device tensors; applies keep_uint8)

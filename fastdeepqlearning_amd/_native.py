@@ -129,6 +129,7 @@ SIGNATURES = {
     "fdql_agent_bind": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64]),
     "fdql_agent_update": (C.c_int, [_vp, C.POINTER(Batch), _vp, _vp, _u64, _i32, _vp]),
     "fdql_agent_grad_bucket": (C.c_int, [_vp, C.POINTER(_i64)]),
+    "fdql_agent_set_launch_mode": (C.c_int, [_vp, _i32]),
     "fdql_agent_scalars": (C.c_int, [_vp, C.POINTER(_f32), _vp]),
     "fdql_agent_summaries": (C.c_int, [_vp, C.POINTER(_f32), _i32, _i32, _vp]),
     "fdql_agent_set_alpha": (C.c_int, [_vp, _f32, _vp]),

@@ -349,6 +349,35 @@ class NativeAgent:
             N.check(self.lib.fdql_agent_update(self.handle, C.byref(b), N.ptr(noise_target), N.ptr(noise_actor), seed,
                                                phase, N.current_stream(self.device)))
 
+    def set_launch_mode(self, graph):
+        """PHASE_ALL as one hipGraphLaunch per step (True) or one launch per stage (False); fdql_agent_set_launch_mode."""
+        N.check(self.lib.fdql_agent_set_launch_mode(self.handle, 1 if graph else 0))
+        self.launch_mode = "graph" if graph else "eager"
+
+    def calibrate_launch_mode(self, step, steps=30, warmup=9, rounds=2):
+        """Times `step()` (a callable that issues one whole train step, sampler included, on the current stream) with the
+        launch list issued eagerly and replayed as a hipGraph, `rounds` x `steps` steps each in alternation, and keeps the
+        faster.  The answer depends on the host as much as on the plan (a launch-bound step of 17-23 dependent kernels is
+        host-issue-bound on a slow or busy host and device-latency-bound on a fast one), so it is measured where the job runs,
+        like the data-parallel launch list (bench.py::dp_run_best).  Returns {"chosen", "ms_per_step": {"eager", "graph"}}."""
+        import time
+        ms = {"eager": [], "graph": []}
+        for _ in range(rounds):
+            for mode in ("eager", "graph"):
+                self.set_launch_mode(mode == "graph")
+                for _ in range(warmup):          # (a plan's graph is captured on its second run in graph mode)
+                    step()
+                torch.cuda.synchronize(self.device)
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    step()
+                torch.cuda.synchronize(self.device)
+                ms[mode].append(1e3 * (time.perf_counter() - t0) / steps)
+        best = {m: min(v) for m, v in ms.items()}
+        chosen = "graph" if best["graph"] < 0.98 * best["eager"] else "eager"      # a tie stays eager
+        self.set_launch_mode(chosen == "graph")
+        return {"chosen": chosen, "steps": steps, "rounds": rounds, "ms_per_step": {m: round(v, 4) for m, v in best.items()}}
+
     def grad_bucket(self):
         """First float of the gradient arena's EARLY bucket: grads[b:] (critics + log_alpha) is final after
         PHASE_GRAD_CRITICS, grads[:b] after PHASE_GRAD_REST; b == grads.numel() when the agent is not data-parallel."""

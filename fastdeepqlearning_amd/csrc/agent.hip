@@ -413,6 +413,13 @@ int32_t fdql_agent_conv_reads_ring(const fdql_agent_t *a) {
   return a && a->cfg.obs_2d_u8 && !a->conv.empty() && a->conv[0].fast_fwd && a->conv[0].fast_wgrad ? 1 : 0;
 }
 
+int fdql_agent_set_launch_mode(fdql_agent_t *a, int32_t graph) {
+  FDQL_REQUIRE(a && (graph == 0 || graph == 1), "fdql_agent_set_launch_mode: graph must be 0 or 1");
+  std::lock_guard<std::mutex> lk(a->mu);
+  a->use_graph = graph != 0;   // captured graphs are kept: switching back and forth costs nothing
+  return 0;
+}
+
 int fdql_agent_grad_bucket(fdql_agent_t *a, int64_t *first_early_float) {
   FDQL_REQUIRE(a && first_early_float, "null argument");
   std::lock_guard<std::mutex> lk(a->mu);

@@ -378,6 +378,7 @@ struct fdql_ring {
   int u8[RING_MAX_KEYS] = {};
   // bookkeeping (replay_memory.py:45-46)
   int64_t top = 0, len = 0;
+  int64_t sample_len = 0;   // the length the last window gather reduced its starts by (fdql_ring_window_slots uses the same one)
   // staging of add(): two pinned / device buffer pairs, so that filling one never waits for the H2D copy of the other
   float *pinned[2] = {nullptr, nullptr};
   float *dev_stage[2] = {nullptr, nullptr};
@@ -799,6 +800,7 @@ int fdql_ring_restore(fdql_ring_t *r, const float *host_rows, int64_t n_slots, i
   }
   r->top = top;
   r->len = len;
+  r->sample_len = 0;
   return 0;
 }
 
@@ -834,8 +836,11 @@ int fdql_ring_window_slots(fdql_ring_t *r, int32_t T, int32_t B, const int64_t *
   FDQL_REQUIRE(r->len >= 1 && r->maxlen < (1LL << 31), "empty ring, or more slots than an int32 index holds");
   hipStream_t s = (hipStream_t)stream;
   const long long n = (long long)T * B;
+  // the window gather that drew `starts` wrapped its rows at the length it saw (replay_memory.py:63-65): a writer that
+  // flushed between the two calls must not make the slots wrap somewhere else
+  const long long len = r->sample_len > 0 ? r->sample_len : r->len;
   hipLaunchKernelGGL(k_window_slots, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const long long *>(starts_dev), T, B,
-                     (long long)r->len, slots_out_dev);
+                     len, slots_out_dev);
   FDQL_HIP(hipGetLastError());
   return 0;
 }
@@ -870,6 +875,7 @@ int fdql_ring_sample_windows_sel(fdql_ring_t *r, int32_t T, int32_t B, const int
   int rc = flush(r, s);
   if (rc) return rc;
   // starts drawn inside the gather (one launch); caller-supplied starts are reduced mod len there
+  r->sample_len = r->len;
   return gather(r, T, B, r->len, reinterpret_cast<const long long *>(starts_dev), (long long)(r->len - T), seed, counter,
                 reinterpret_cast<long long *>(starts_out_dev), out, sel_off, sel_dim, s);
 }

@@ -335,6 +335,13 @@ int fdql_agent_update(fdql_agent_t *agent, const fdql_batch_t *batch, const floa
 
 int fdql_agent_grad_bucket(fdql_agent_t *agent, int64_t *first_early_float);
 
+/* How FDQL_PHASE_ALL is issued (franQ/Agent/deepQlearning.py:105-127 is one Python-level step; here it is a fixed launch list):
+ * graph = 0: one hipLaunchKernel per stage (default; FDQL_GRAPH=1 in the environment at create time makes 1 the default),
+ * graph = 1: the launch list of each plan replayed as ONE hipGraphLaunch (captured on the plan's second run; bit-identical
+ * results).  Which is faster depends on the step (17-23 dependent launches of 8-40 us: host issue time matters) and on the
+ * host: callers decide by timing both (bench.py / NativeAgent.calibrate_launch_mode).  Split-phase calls are always eager. */
+int fdql_agent_set_launch_mode(fdql_agent_t *agent, int32_t graph);
+
 /* Scalars of the last update (device -> host copy; synchronises `stream`):
  * [0] loss (deepQlearning.py:249)  [1] mean q_loss  [2] mean pi_loss  [3] mean alpha_loss
  * [4] q_pred mean  [5] mc-constraint violation rate  [6] alpha used  [7] optimiser step   */

@@ -861,3 +861,35 @@ def test_pixel_agent_reads_uint8_frames_from_the_ring_in_place(dev):
         agent.train_step()
     sc = agent.native.scalars()
     assert np.isfinite(sc["loss"]) and agent.native.stats()["plans_built"] <= 4
+
+
+def test_in_place_batches_follow_a_restored_ring(dev):
+    """load_state_dict() builds a new HBM ring; the uint8 block, the slot / start buffers and the persistent
+    sample buffers handed out before must go with the old one.  Sample in place, restore a checkpoint whose frames differ,
+    sample again: the batch's block is the restored ring's (its frames at the sampled slots are the checkpoint's)."""
+    from fastdeepqlearning_amd.Replay import ReplayMemory
+    T, B, n, shape = 3, 4, 40, (2, 6, 6)
+
+    def fill(shard, offset):
+        for i in range(n):
+            shard.add({"obs_2d": np.full(shape, (i + offset) % 256, np.uint8), "action": np.asarray([float(i)], np.float32),
+                       "reward": 0.0, "task_done": False, "episode_done": False, "episode_step": i})
+
+    a = ReplayMemory(64, B, T, device=dev, sample_buffers=3)
+    fill(a, 100)
+    sd = a.state_dict()
+    b = ReplayMemory(64, B, T, device=dev, sample_buffers=3)
+    fill(b, 0)
+    b.enable_in_place(("obs_2d",))
+    xp0 = b.temporal_sample()
+    old_block = xp0["obs_2d"]
+    s0 = xp0["obs_2d_slots"].long()
+    assert torch.equal(old_block[s0.reshape(-1)][:, 0, 0, 0].float().view(T, B), xp0["action"].view(T, B))
+    b.load_state_dict(sd)
+    xp1 = b.temporal_sample()
+    assert xp1["obs_2d"].data_ptr() != old_block.data_ptr(), "the batch still carries the replaced ring's block"
+    s1 = xp1["obs_2d_slots"].long()
+    frames = xp1["obs_2d"][s1.reshape(-1)][:, 0, 0, 0].float().view(T, B)
+    assert torch.equal(frames, (xp1["action"].view(T, B) + 100) % 256), "frames do not belong to the sampled records"
+    # no float32 buffer exists for the key read in place
+    assert all(entry[b._keys.index("obs_2d")] is None for entry in b._pool)

@@ -2,6 +2,7 @@
 # Regenerates the evidence under profiles/ on a GPU box (run through gpurun from the repo root):
 #   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh a'     (the headline: bench line, kernel stats, PMC passes)
 #   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh b'     (the other workloads, config 5, the N > 1 rehearsal)
+#   gpurun --timeout 900  -- 'bash tools/collect_profiles.sh s'     (the sampler: HBM GB/s + PMC traffic of k_gather_windows)
 # Writes into gpurun_out/profiles_new/ (merged back by gpurun); copy what should be judged into profiles/ (round prefix).
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -47,4 +48,17 @@ python3 $R/tools/summarize_profiles.py $OUT/c5 "tools/config5_bench.py (BASELINE
 # 8. the N > 1 code path from the plain command line (ranks share this box's one GPU: gloo rehearsal, not a scaling figure)
 FDQL_BENCH_BACKEND=gloo FDQL_BENCH_RING=200000 python3 $R/bench.py --gpus 2 --steps 20 --warmup 5 > $OUT/bench_2rank_gloo_plain_launch.json 2> $OUT/bench_2rank.err || exit 1
 echo "part b collected"
+fi
+if [[ $PART == *s* ]]; then
+# 9. north_star: "evidenced by rocprof HBM GB/s on the sampler".  Three rocprofv3 passes over tools/sampler_bench.py (config 2 / 3 /
+#    4 / 5 row sizes): FETCH_SIZE, WRITE_SIZE (their own passes: TCC counter slots) and a kernel trace for the durations
+S=$OUT/sampler
+rm -rf $S; mkdir -p $S
+python3 $R/tools/sampler_bench.py > $S/sampler_hbm.txt 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $S/pmc_fetch -- python3 $R/tools/sampler_bench.py --reps 5 > $S/pmc_fetch.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $S/pmc_write -- python3 $R/tools/sampler_bench.py --reps 5 > $S/pmc_write.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --output-format csv -d $S/trace -- python3 $R/tools/sampler_bench.py --reps 5 > $S/trace.log 2>&1 || exit 1
+python3 $R/tools/sampler_pmc.py $S > $S/sampler_pmc.txt 2>&1 || exit 1
+cat $S/sampler_hbm.txt >> $S/sampler_pmc.txt
+echo "part s collected"
 fi

@@ -106,16 +106,14 @@ def standalone_copy_ms(job, W, P, lo, hi, hold_us=0, lds=0):
 
 def table(args):
     """Per workload: compute only; then the stand-in in its two characters - bandwidth-bound (copy passes, no hold) and
-    latency-bound (one pass, then resident for hold_us: what a ring all-reduce over xGMI mostly is) - beside / serial.
-    FDQL_CU_RESERVE (set by the caller) leaves CUs free of persistent workgroups."""
+    latency-bound (one pass, then resident for hold_us: what a ring all-reduce over xGMI mostly is) - beside / serial."""
     import json
     import torch
-    reserve = os.environ.get("FDQL_CU_RESERVE", "0")
     for name, B in (("config2", 256), ("config4", 128), ("config4", 512)):
         job = make_job(name, B, 2)
         n, b = job.agent.grads.numel(), job.agent.grad_bucket()
         base = Stepper(job, 0, 1, "none").timed(args.steps)
-        line = {"workload": f"{name} B={B}/GPU", "cu_reserve": int(reserve), "arena_MB": round(4 * n / 1e6, 2),
+        line = {"workload": f"{name} B={B}/GPU", "arena_MB": round(4 * n / 1e6, 2),
                 "early_bucket_MB": round(4 * (n - b) / 1e6, 2), "none_ms": round(base, 4)}
         for tag, W, P, hold, lds in (("copy6_W32", 32, 6, 0, 0), ("hold100us_W16", 16, 1, 100, 0), ("hold100us_W32", 32, 1, 100, 0),
                                      ("hold100us_W32_lds16k", 32, 1, 100, 16384), ("hold200us_W32", 32, 1, 200, 0), ("hold100us_W8", 8, 1, 100, 0)):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condenses the rocprofv3 passes of tools/r05_sampler_pmc.sh: per k_gather_windows launch shape (grid size) the bytes the
+"""Condenses the rocprofv3 passes of `tools/collect_profiles.sh s`: per k_gather_windows launch shape (grid size) the bytes the
 L2 exchanged with the fabric (FETCH_SIZE x 2: gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md "HBM";
 WRITE_SIZE as is), the kernel-trace duration and the resulting GB/s, beside the algorithmic bytes of tools/sampler_bench.py."""
 import collections
