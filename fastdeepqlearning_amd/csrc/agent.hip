@@ -506,7 +506,7 @@ int32_t fdql_agent_profile_update(fdql_agent_t *a, const fdql_batch_t *batch, co
     } else {
       snprintf(out[cnt].name, sizeof(out[cnt].name), "%s%s",
                st.kind == ST_SKINNY_WGRAD ? (st.stream ? "nwgrad:" : "colsum:")
-                                          : (st.kind == ST_CHAIN ? "chain:" : (st.kind == ST_WGRAD_STAT ? "wgstat:" : (st.mfma ? "conv:" : "k:"))),
+                                          : (st.kind == ST_CHAIN ? "chain:" : (st.kind == ST_WGRAD_STAT ? "wgstat:" : (st.prof ? st.prof : (st.mfma ? "conv:" : "k:")))),
                st.name.c_str());
     }
     out[cnt].ms = ms;

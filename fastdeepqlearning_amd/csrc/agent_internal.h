@@ -23,6 +23,7 @@
 #include "wstat.h"
 #include "wgrad.h"
 #include "rowdgrad.h"
+#include "fwdchain.h"
 #include "conv.h"
 #include "common.h"
 #include "update_kernels.h"
@@ -136,7 +137,8 @@ struct Stage {
   int phase = FDQL_PHASE_GRAD;
   int gpart = 1;  // FDQL_PHASE_GRAD stages of a bucketed plan: 0 = up to the critics' gradients (FDQL_PHASE_GRAD_CRITICS), 1 = the rest
   int when = 0;   // 0: whenever its phase runs; 1: only in a split (GRAD / APPLY) call; 2: only in a FDQL_PHASE_ALL call
-  bool mfma = false;  // ST_FUNC: an MFMA kernel of its own (the implicit-GEMM convolutions): its flops count as GEMM flops
+  bool mfma = false;  // ST_FUNC: an MFMA kernel of its own (the implicit-GEMM convolutions, the small-block forward chain): its flops count as GEMM flops
+  const char *prof = nullptr;   // ST_FUNC: prefix of the stage's name in fdql_agent_profile_update (default "k:" / "conv:")
   bool off = false;   // decided with the kernels (upload_tables): the stage has nothing left to do in this plan
   // head fusion (critics): 1 = a hidden layer's launch that leaves head partial sums, 2 = their plane sum, 3 = the head's finish.
   // When every layer runs weight-stationary, the kernels sum a tile's planes themselves (WsArgs::hf_presum): stage 2 is switched
@@ -148,6 +150,7 @@ struct Stage {
   // the one problem of this stage runs on the row-block dgrad kernel with its first segment formed as a sum of shares
   // (RowDgradArgs::sum_*; build_plan has checked that the kernel takes it)
   int rd_max_blocks = 0;      // > 0: this stage's own limit for the row-block dgrad kernel (a member of a planned dgrad chain)
+  int rd_chain_bm = 0;        // 32 / 16: planned as a member of a chain launch on blocks of that many rows (k_rowdgrad_chain<2> / <1>)
   bool needs_masks = false;   // reads gate masks: runs only when every critics' forward layer of the plan is weight-stationary (upload_tables)
   bool masks_fallback = false;   // ... and the GEMM stage that does the same work from h when they are not
   bool chained = false;   // switched off because the launch runs inside the chain launch of an earlier stage (RowsLaunch::chain3)

@@ -111,7 +111,7 @@ void carve(fdql_agent *a) {
       a->alloc(p + ".h" + std::to_string(i), rows * d.hid[i]);
       if (bwd) {
         a->alloc(p + ".dpre" + std::to_string(i), M * d.hid[i]);
-        a->alloc(p + ".cs" + std::to_string(i), ((M + 63) / 64) * d.hid[i]);
+        a->alloc(p + ".cs" + std::to_string(i), ((M + 15) / 16) * d.hid[i]);   // per 64 rows (tile kernels) ... per 16 rows (k_rowdgrad_chain<1>)
       }
     }
     if (out) a->alloc(p + ".out", rows * d.dout);
@@ -193,8 +193,8 @@ void carve(fdql_agent *a) {
   a->alloc("dstate", M * c.latent);
   if (a->dstate_split) a->alloc("dstate.parts", (int64_t)(c.n_critics + 1) * M * c.latent);
   a->alloc("denc", M * c.enc_features);
-  a->alloc("cs.dstate", ((M + 31) / 32) * c.latent);   // per 64 rows (one-problem d state) or per 32 rows (sum of shares)
-  a->alloc("cs.denc", ((M + 63) / 64) * c.enc_features);
+  a->alloc("cs.dstate", ((M + 15) / 16) * c.latent);   // per 64 rows (one-problem d state), per 32 rows (sum of shares), per block of the chain launch
+  a->alloc("cs.denc", ((M + 15) / 16) * c.enc_features);
   a->alloc("dpi_part", (int64_t)c.n_critics * M * c.act_dim);
   a->alloc("loss_partials", (int64_t)loss_blocks((int)M, 256) * LOSS_NPART + (int64_t)M * LOSS_NPART + LOSS_NPART);
   a->alloc("slabs", (int64_t)a->nsplit * a->n_train);
@@ -258,9 +258,10 @@ int upload_tables(fdql_agent *a) {
       // single-network dgrads (256-wide K-strided segments, gate / column sums) with enough 64-row blocks to fill most of the chip
       for (size_t i = 0; i < s.gemm.size(); ++i) {
         RowsLaunch rl;
-        if (taken[i] != 1 && s.gemm[i].M / RD_BM >= a->rowdgrad_min_blocks &&
-            s.gemm[i].M / RD_BM <= (s.rd_max_blocks > 0 ? s.rd_max_blocks : a->rowdgrad_max_blocks) &&
-            rowdgrad_from_problem(s.gemm[i], rl.rda)) {
+        const bool small_chain = s.rd_chain_bm > 0 && s.rd_chain_bm < RD_BM;   // a member of a planned chain launch on 32- / 16-row blocks
+        if (taken[i] != 1 && (small_chain || (s.gemm[i].M / RD_BM >= a->rowdgrad_min_blocks &&
+                                              s.gemm[i].M / RD_BM <= (s.rd_max_blocks > 0 ? s.rd_max_blocks : a->rowdgrad_max_blocks))) &&
+            rowdgrad_from_problem(s.gemm[i], rl.rda, small_chain ? s.rd_chain_bm : RD_BM)) {
           if (s.fold_sum && !rowdgrad_fold_sum(rl.rda, s.fold_parts, s.fold_n, s.fold_stride, s.fold_out, s.fold_cs)) {
             set_error("stage %s: the row-block dgrad kernel does not take the folded sum it was planned with", s.name.c_str());
             return FDQL_EINVAL;
@@ -371,8 +372,9 @@ int upload_tables(fdql_agent *a) {
       return true;
     };
     if (!s1.fold_sum || !lone_rd(s1) || !lone_rd(s2) || !lone_rd(s3) || s1.phase != s2.phase || s1.phase != s3.phase) continue;
+    if (s1.rd_chain_bm != s2.rd_chain_bm || s1.rd_chain_bm != s3.rd_chain_bm) continue;
     RowChainArgs c;
-    if (!rowchain_from_launches(s1.rows[0].rda, s2.rows[0].rda, s3.rows[0].rda, c)) continue;
+    if (!rowchain_from_launches(s1.rows[0].rda, s2.rows[0].rda, s3.rows[0].rda, c, s1.rd_chain_bm > 0 ? s1.rd_chain_bm : RD_BM)) continue;
     s1.rows[0].chain3 = true;
     s1.rows[0].rch = c;
     s2.off = s3.off = true;
@@ -382,6 +384,12 @@ int upload_tables(fdql_agent *a) {
     s1.flops += s2.flops + s3.flops;
     s1.bytes += s2.bytes + s3.bytes;
   }
+  // a stage planned on 32- / 16-row blocks exists only inside a chain launch (the lone kernel is the 64-row one)
+  for (const Stage &s : a->stages)
+    if (s.rd_chain_bm > 0 && s.rd_chain_bm < RD_BM && !s.chained && !(s.rows.size() == 1 && s.rows[0].chain3)) {
+      set_error("stage %s was planned as a member of a %d-row dgrad chain that did not form", s.name.c_str(), s.rd_chain_bm);
+      return FDQL_EINVAL;
+    }
   // head-fusion planes: with every hidden layer of the critics on weight-stationary launches, those launches sum a tile's column
   // planes themselves, the plane-sum stage is switched off and the finish adds one plane per layer (Stage::hf_role)
   {
@@ -595,6 +603,33 @@ int build_plan(fdql_agent *a) {
     if (chain_all) bms.push_back(32);
   }
   bool enc_chained = false;
+  // Round 6: the same four networks on 16- / 32-row blocks, two workgroups per CU, weights eight groups ahead (fwdchain.hip) when
+  // they have the reference's default shape (one hidden layer of 256 everywhere) - k_chain's blocks are latency-bound below a
+  // dispatch round of them
+  if (chain_mode == 1 && !gru && nconv == 0 && a->enc_obs.hid.size() == 1 && a->joiner.hid.size() == 1 && a->actor.hid.size() == 1 &&
+      a->enc_obs.hid[0] == F3_W && a->joiner.hid[0] == F3_W && a->actor.hid[0] == F3_W && c.enc_features == F3_W && L == F3_W &&
+      (int)eo.in.size() <= F3_MAX_IN) {
+    Fwd3Args fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.N = N; fa.M = M; fa.B = B;
+    fa.nin = (int)eo.in.size();
+    for (int i = 0; i < fa.nin; ++i) { fa.in[i] = eo.in[i].ptr; fa.in_ld[i] = eo.in[i].ld; fa.in_w[i] = eo.in[i].width; fa.K0 += eo.in[i].width; }
+    auto mlp_of = [](const MlpInst &m) { return Fwd3Mlp{m.W(0), m.Bv(0), m.HW(), m.HB()}; };
+    fa.enc = mlp_of(eo); fa.joi = mlp_of(jo); fa.act = mlp_of(ao); fa.act_t = mlp_of(at);
+    fa.P = a->actor.dout;
+    fa.enc_h = eo.h[0]; fa.enc_out = eo.out; fa.joi_h = jo.h[0]; fa.state = state; fa.act_h = ao.h[0]; fa.act_out = ao.out; fa.act_t_out = at.out;
+    int bm = 0;
+    if (const char *e = getenv("FDQL_EXP_FWD3")) bm = atoi(e);   // EXPERIMENT (round 6 sweep): removed once the rule is measured
+    fa.bm = bm;
+    if (bm > 0 && fwd3_takes(fa)) {
+      Stage &fs = b.func_stage("enc_joiner_actors", [=](hipStream_t s) { return fwd3_launch(fa, s); });
+      fs.mfma = true;
+      fs.prof = bm == 16 ? "fwd3<16>:" : "fwd3<32>:";
+      fs.flops = fwd3_flops(fa);
+      fs.bytes = 4.0 * ((double)N * (fa.K0 + 4 * F3_W) + (double)M * (F3_W + 2 * fa.P));
+      enc_chained = true;
+    }
+  }
   for (size_t t = 0; t < bms.size() && !enc_chained && (chain_all || chain_on) && !gru; ++t) {
     Stage cs;
     cs.kind = ST_CHAIN; cs.name = "enc_joiner_actors"; cs.chain_bm = bms[t];
@@ -1113,6 +1148,10 @@ int build_plan(fdql_agent *a) {
   // launch + three tile launches; a lone row-block dgrad launch of that size loses against the tile kernel)
   const bool chain_planned = a->joiner.hid.size() == 1 && a->enc_obs.hid.size() == 1 && c.enc_features == L && plan_switches().rowdgrad_chain;
   const int rd_max_blocks = chain_planned ? std::max(a->rowdgrad_max_blocks, 1024) : a->rowdgrad_max_blocks;
+  // Round 6: the same launch on 32- or 16-row blocks (k_rowdgrad_chain<2> / <1>) where 64-row blocks are a fraction of a dispatch
+  // round - one rank's share of a data-parallel batch (config 2 at 128 / 64 / 32 windows: 98 / 49 / 24.5 blocks of 64) and
+  // temporal_len 2 - instead of the summing launch + three tile / small-batch launches.  chain_bm: 0 = the 64-row rules above.
+  int chain_bm = 0;
   if (a->dstate_split && L % 4 == 0 && !gru && !a->joiner.hid.empty()) {
     MlpInst jq = jo;
     jq.rows = M;
@@ -1121,6 +1160,33 @@ int build_plan(fdql_agent *a) {
     fold_dsum = M / RD_BM >= a->rowdgrad_min_blocks && M / RD_BM <= rd_max_blocks && (M >= a->rowdot_min_rows ? p.N > 16 : true) &&
                 rowdgrad_from_problem(p, tmp) &&
                 rowdgrad_fold_sum(tmp, a->buf("dstate.parts"), C + 1, (long long)M * L, a->buf("dstate"), a->buf("cs.dstate"));
+    // Rows per workgroup of the chain launch (measured, profiles/r06_rowdgrad_chain_blocks.txt): 64 while the blocks are 0.5 .. 1
+    // dispatch rounds; 32 beyond one round (config 4 at B = 1024, 784 blocks of 64: 0.377 -> 0.308 ms) and at 6 272 rows; 16 at
+    // 3 136 / 1 568 rows; below 1 024 rows (temporal_len 2) the small-batch kernel's launches carry the weight gradients as
+    // riders and stay
+    int want = RD_BM;
+    if (M / RD_BM < a->rowdgrad_min_blocks) want = M < 1024 ? 0 : ((M % 16 == 0 && M / 16 <= 256) ? 16 : (M % 32 == 0 ? 32 : (M % 16 == 0 ? 16 : 0)));
+    else if (M / RD_BM > 256 && M % 32 == 0) want = 32;
+    const char *exp_bm = getenv("FDQL_EXP_CHAIN_BM");   // EXPERIMENT (round 6 sweep): removed once the rule is measured
+    if (exp_bm) want = atoi(exp_bm);
+    if (chain_planned && plan_switches().rowdgrad && want > 0 && want < RD_BM) {
+      const int bm = want;
+      // the other two members, asked like the first (upload_tables builds the same three launches)
+      MlpInst eq = eo;
+      eq.rows = M;
+      GemmProblem p2 = Builder::new_gemm(M, c.enc_features, a->buf("denc"), c.enc_features);
+      b.input_grad_segs(jq, a->buf("dstate"), L, 0, p2);
+      p2.colsum = a->buf("cs.denc");
+      GemmProblem p3 = b.bwd_dpre(eq, (int)a->enc_obs.hid.size() - 1, a->buf("denc"), c.enc_features);
+      RowDgradArgs t1, t2, t3;
+      RowChainArgs tc;
+      if (bm > 0 && bm < RD_BM && rowdgrad_from_problem(p, t1, bm) && rowdgrad_from_problem(p2, t2, bm) && rowdgrad_from_problem(p3, t3, bm) &&
+          rowdgrad_fold_sum(t1, a->buf("dstate.parts"), C + 1, (long long)M * L, a->buf("dstate"), a->buf("cs.dstate")) &&
+          rowchain_from_launches(t1, t2, t3, tc, bm)) {
+        chain_bm = bm;
+        fold_dsum = true;
+      }
+    }
   }
   if (a->dstate_split && !fold_dsum) {
     const float *parts = a->buf("dstate.parts");
@@ -1137,10 +1203,14 @@ int build_plan(fdql_agent *a) {
   // column sums of d state: per 64 rows from the one-problem GEMM or the folded sum, per 32 rows from the summing launch, else
   // straight from d state
   const float *cs_dstate = (a->dstate_split && L % 4) ? nullptr : a->buf("cs.dstate");
-  const int cs_dstate_rows = a->dstate_split ? (fold_dsum ? (M + 63) / 64 : (M + 31) / 32) : 0;
+  const int cs_dstate_rows = a->dstate_split ? (chain_bm ? M / chain_bm : (fold_dsum ? (M + 63) / 64 : (M + 31) / 32)) : 0;
   // ---- encoder backward over the M rows that carry gradient (next-only rows get none)
   MlpInst jb = jo, eb = eo;
   jb.rows = M; eb.rows = M;
+  if (chain_bm) {   // the chain launch leaves one row of column sums per block
+    jb.dpre_cs_rows[a->joiner.hid.size() - 1] = M / chain_bm;
+    eb.dpre_cs_rows[a->enc_obs.hid.size() - 1] = M / chain_bm;
+  }
   for (int i = (int)a->joiner.hid.size() - 1; i >= 0; --i) {
     Stage &gs = b.gemm_stage((fold_dsum && i == (int)a->joiner.hid.size() - 1 ? "dstate.sum+joiner.dpre" : "joiner.dpre") + std::to_string(i));
     gs.gemm.push_back(b.bwd_dpre(jb, i, a->buf("dstate"), L));
@@ -1148,8 +1218,9 @@ int build_plan(fdql_agent *a) {
       gs.fold_sum = true; gs.fold_parts = a->buf("dstate.parts"); gs.fold_n = C + 1; gs.fold_stride = (long long)M * L;
       gs.fold_out = a->buf("dstate"); gs.fold_cs = a->buf("cs.dstate");
       gs.rd_max_blocks = rd_max_blocks;
+      gs.rd_chain_bm = chain_bm;
     }
-    hosts.push_back(a->stages.size() - 1);
+    if (!chain_bm) hosts.push_back(a->stages.size() - 1);   // (a member of the small-block chain carries no riders: it must stay a lone problem)
   }
   if (gru) {
     // back-propagation through time over the T-1 rows that carry gradient (h_{T-1} only feeds no_grad targets):
@@ -1202,14 +1273,16 @@ int build_plan(fdql_agent *a) {
     p.colsum = a->buf("cs.denc");
     gs.gemm.push_back(p);
     if (fold_dsum) gs.rd_max_blocks = rd_max_blocks;
-    hosts.push_back(a->stages.size() - 1);
+    gs.rd_chain_bm = chain_bm;
+    if (!chain_bm) hosts.push_back(a->stages.size() - 1);
   }
   const size_t idx_denc = a->stages.size() - 1;
   for (int i = (int)a->enc_obs.hid.size() - 1; i >= 0; --i) {
     Stage &gs = b.gemm_stage("enc_obs.dpre" + std::to_string(i));
     gs.gemm.push_back(b.bwd_dpre(eb, i, a->buf("denc"), c.enc_features));
     if (fold_dsum) gs.rd_max_blocks = rd_max_blocks;
-    hosts.push_back(a->stages.size() - 1);
+    gs.rd_chain_bm = chain_bm;
+    if (!chain_bm) hosts.push_back(a->stages.size() - 1);
   }
   // ---- pixel encoder backward (M images): d features -> per layer [dW, db], d col -> col2im -> previous layer
   if (nconv) {
@@ -1263,7 +1336,7 @@ int build_plan(fdql_agent *a) {
     b.wgrads(ao, a->buf("dlogits"), a->actor.dout, nullptr, a->stages[idx_dstate], tail, ws);
     // joiner: needs d state and its dpre -> the d enc launch; encoder MLP: needs d enc and its dpre -> the tail
     if (!gru) {
-      b.wgrads(jb, a->buf("dstate"), L, cs_dstate, a->stages[idx_denc], tail, ws, cs_dstate_rows);
+      b.wgrads(jb, a->buf("dstate"), L, cs_dstate, chain_bm ? tail : a->stages[idx_denc], tail, ws, cs_dstate_rows);
     } else {   // GRU weights: dW_hh = d gh^T h_prev, dW_ih = d gi^T e, biases = column sums (all over the M rows)
       const int L3 = 3 * L, F = c.enc_features;
       float *slab = a->buf("slabs");
@@ -1273,7 +1346,7 @@ int build_plan(fdql_agent *a) {
       b.wgrad_bias(M, a->buf("gru.dgh"), L3, L3, nullptr, slab + a->gru_bhh, ws);
       b.wgrad_bias(M, a->buf("gru.dgi"), L3, L3, nullptr, slab + a->gru_bih, ws);
     }
-    b.wgrads(eb, a->buf("denc"), c.enc_features, a->buf("cs.denc"), tail, tail, ws);
+    b.wgrads(eb, a->buf("denc"), c.enc_features, a->buf("cs.denc"), tail, tail, ws, chain_bm ? M / chain_bm : 0);
     for (int i = 0; i < nconv; ++i) {   // conv weights: dW = d pre^T col over the M*OH*OW rows, bias = column sums
       const fdql_agent::ConvLayer &Lc = a->conv[i];
       const int K = Lc.g.C * Lc.g.k * Lc.g.k;

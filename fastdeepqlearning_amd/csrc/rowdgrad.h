@@ -48,20 +48,20 @@ hipError_t rowdot_launch(const RowDotArgs &args, hipStream_t stream);
 inline double rowdot_flops(const RowDotArgs &a) { return 2.0 * a.M * (double)a.A * (RD_K + a.Q) * a.nprob; }
 
 // Does this problem have the kernel's form?  Fills args when it does.  FDQL_ROWDGRAD=0: never.
-bool rowdgrad_from_problem(const GemmProblem &p, RowDgradArgs &args);
-// Three dependent single-network dgrads of the same 64-row blocks in ONE launch (k_rowdgrad_chain): the summed input gradient
+bool rowdgrad_from_problem(const GemmProblem &p, RowDgradArgs &args, int bm = RD_BM);   // bm < 64: only as a member of a chain launch
+// Three dependent single-network dgrads of the same row blocks (64, 32 or 16 rows) in ONE launch (k_rowdgrad_chain<RT>): the summed input gradient
 // x0 (RowDgradArgs::sum_*), then  x1 = gate1(x0 W1),  x2 = x0 W2a + x1 W2b,  x3 = gate3(x2 W3)  with x0, x1, x2 resident in LDS
 // between the layers - the joiner's hidden-layer dgrad, d enc and the encoder's hidden-layer dgrad of a config-2-shaped plan
-// (one hidden layer each).  Every xi is also written to memory (the weight gradients read them) with its per-64-row column sums.
+// (one hidden layer each).  Every xi is also written to memory (the weight gradients read them) with its per-block column sums.
 struct RowChainArgs {
-  int M;
+  int M, bm;   // bm: rows per workgroup, 64 (round 4), 32 or 16 (round 6: small batches); every column-sum array has M / bm rows
   const float *sum_parts; int nsum; long long sum_stride; float *x0, *cs0;
   const float *W1; int ldw1; const float *ref1; float *x1, *cs1;
   const float *W2a, *W2b; int ldw2a, ldw2b; float *x2, *cs2;
   const float *W3; int ldw3; const float *ref3; float *x3, *cs3;
 };
 // Do three consecutive launches (the first with a folded sum) form such a chain?  Fills args when they do.  FDQL_NO_ROWDGRAD_CHAIN: never.
-bool rowchain_from_launches(const RowDgradArgs &l1, const RowDgradArgs &l2, const RowDgradArgs &l3, RowChainArgs &args);
+bool rowchain_from_launches(const RowDgradArgs &l1, const RowDgradArgs &l2, const RowDgradArgs &l3, RowChainArgs &args, int bm = RD_BM);
 hipError_t rowchain_launch(const RowChainArgs &args, hipStream_t stream);
 inline double rowchain_flops(const RowChainArgs &a) { return 2.0 * a.M * (double)RD_N * RD_K * 4; }
 bool rowdgrad_fold_sum(RowDgradArgs &args, const float *parts, int nsum, long long stride, float *sum_out, float *sum_colsum);   // FDQL_NO_DSTATE_SUM_FOLD: never

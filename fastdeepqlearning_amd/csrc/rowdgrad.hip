@@ -180,17 +180,22 @@ __global__ __launch_bounds__(256, 1) void k_rowdgrad(const RowDgradArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// k_rowdgrad_chain (rowdgrad.h, RowChainArgs): k_rowdgrad's K loop three times over the same 64 rows, the layers' inputs in two LDS
-// images: image 0 = x0 (the summed shares), image 1 = x1; x2 then replaces x0 in image 0.  The first weight fragments of the
-// next layer are requested before a layer's epilogue.
-__global__ __launch_bounds__(256, 1) void k_rowdgrad_chain(const RowChainArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];   // images [2][64][P], then [4][256] column sums of x0
+// k_rowdgrad_chain<RT> (rowdgrad.h, RowChainArgs): k_rowdgrad's K loop three times over the same 16 RT rows, the layers' inputs in
+// two LDS images: image 0 = x0 (the summed shares), image 1 = x1; x2 then replaces x0 in image 0.  The first weight fragments of
+// the next layer are requested before a layer's epilogue.  RT = 4 (64-row blocks) is the form of round 4; RT = 2 / 1 (round 6)
+// are one rank's share of a data-parallel batch and temporal_len 2: the same four weight matrices streamed per workgroup for
+// fewer rows, so twice / four times the workgroups fill the chip where 64-row blocks are a fraction of a dispatch round, and two
+// workgroups share a CU (the images are 33 / 66 KB) so that one's weight requests fly under the other's MFMAs.
+template <int RT>
+__global__ __launch_bounds__(256, RT <= 2 ? 2 : 1) void k_rowdgrad_chain(const RowChainArgs a) {
+  constexpr int BM = 16 * RT, IMGB = BM * P, RW = BM / 4, RB = RT <= 2 ? 4 : 8;   // rows per wave / per request round of the sum (RB x 8 quads in flight: 128 registers under the two-workgroup budget)
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // images [2][BM][P], then [4][256] column sums of x0
   const int tid = threadIdx.x, lane = tid & 63, wave = rd_uni(tid >> 6);
   const int j = lane & 15, kq = lane >> 4;
-  const int blk = blockIdx.x, r0 = blk * RD_BM, n0 = wave * 64;
-  float *const img0 = lds, *const img1 = lds + IMG, *const csw = lds + 2 * IMG;
+  const int blk = blockIdx.x, r0 = blk * BM, n0 = wave * 64;
+  float *const img0 = lds, *const img1 = lds + IMGB, *const csw = lds + 2 * IMGB;
 
-  v4f acc[RD_RT][4];
+  v4f acc[RT][4];
   v4f wv[2][8];
   auto load_w = [&](gcf w, int ldw, int kb, v4f (&d)[8]) __attribute__((always_inline)) {
 #pragma unroll
@@ -203,17 +208,17 @@ __global__ __launch_bounds__(256, 1) void k_rowdgrad_chain(const RowChainArgs a)
     gcf part = (gcf)a.sum_parts + (long long)r0 * RD_K + lane * 4;
     v4f csum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-    for (int u0 = 0; u0 < RD_BM / 4; u0 += 8) {
-      v4f v[8][8];
+    for (int u0 = 0; u0 < RW; u0 += RB) {
+      v4f v[RB][8];
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
         if (p < nsum) {   // (uniform)
 #pragma unroll
-          for (int uu = 0; uu < 8; ++uu) v[uu][p] = *(gcf4)(part + (long long)p * ps + (wave + 4 * (u0 + uu)) * RD_K);
+          for (int uu = 0; uu < RB; ++uu) v[uu][p] = *(gcf4)(part + (long long)p * ps + (wave + 4 * (u0 + uu)) * RD_K);
         }
       }
 #pragma unroll
-      for (int uu = 0; uu < 8; ++uu) {
+      for (int uu = 0; uu < RB; ++uu) {
         const int row = wave + 4 * (u0 + uu);
         v4f t = v[uu][0];
 #pragma unroll
@@ -239,16 +244,16 @@ __global__ __launch_bounds__(256, 1) void k_rowdgrad_chain(const RowChainArgs a)
       if (g + 1 < RD_K / 32) load_w(w, ldw, 32 * (g + 1), wv[cur ^ 1]);
       else if (has_next) load_w(wnext, ldwnext, 0, wv[cur ^ 1]);
       asm volatile("" ::: "memory");
-      v4f xa[RD_RT], xb[RD_RT];
+      v4f xa[RT], xb[RT];
 #pragma unroll
-      for (int rt = 0; rt < RD_RT; ++rt) {
+      for (int rt = 0; rt < RT; ++rt) {
         xa[rt] = *reinterpret_cast<const v4f *>(img + 16 * rt * P + 32 * g);
         xb[rt] = *reinterpret_cast<const v4f *>(img + 16 * rt * P + 32 * g + 4);
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int rt = 0; rt < RD_RT; ++rt) {
+        for (int rt = 0; rt < RT; ++rt) {
           const float av = i < 4 ? xa[rt][i] : xb[rt][i - 4];
 #pragma unroll
           for (int c = 0; c < 4; ++c) acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wv[cur][i][c], acc[rt][c], 0, 0, 0);
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(256, 1) void k_rowdgrad_chain(const RowChainArgs a)
   };
   auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int rt = 0; rt < RD_RT; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[rt][c] = v4f{0.f, 0.f, 0.f, 0.f};
   };
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(256, 1) void k_rowdgrad_chain(const RowChainArgs a)
   auto epilogue = [&](const float *ref, float *C, float *colsum, float *dst) __attribute__((always_inline)) {
     v4f cs = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int rt = 0; rt < RD_RT; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
       v4f h[4];
       if (ref) {   // (uniform) the tile's four reference quads together
 #pragma unroll
@@ -425,9 +430,9 @@ hipError_t rowdot_launch(const RowDotArgs &a, hipStream_t s) {
   return hipGetLastError();
 }
 
-bool rowdgrad_from_problem(const GemmProblem &p, RowDgradArgs &args) {
+bool rowdgrad_from_problem(const GemmProblem &p, RowDgradArgs &args, int bm) {
   if (!plan_switches().rowdgrad) return false;   // FDQL_ROWDGRAD=0
-  if (p.M < RD_BM || p.M % RD_BM || p.N != RD_N || p.nseg < 1 || p.nseg > RD_MAX_SEG || p.ksplit != 1 || p.bias || p.C2 || p.hf_w || p.fz_h ||
+  if ((bm != 16 && bm != 32 && bm != RD_BM) || p.M < bm || p.M % bm || p.N != RD_N || p.nseg < 1 || p.nseg > RD_MAX_SEG || p.ksplit != 1 || p.bias || p.C2 || p.hf_w || p.fz_h ||
       p.ldc != RD_N || (p.epi != EPI_NONE && p.epi != EPI_LRELU_GRAD))
     return false;
   auto aligned = [](const void *q, uintptr_t n) { return (reinterpret_cast<uintptr_t>(q) & (n - 1)) == 0; };
@@ -453,14 +458,15 @@ bool rowdgrad_fold_sum(RowDgradArgs &args, const float *parts, int nsum, long lo
   return true;
 }
 
-bool rowchain_from_launches(const RowDgradArgs &l1, const RowDgradArgs &l2, const RowDgradArgs &l3, RowChainArgs &c) {
+bool rowchain_from_launches(const RowDgradArgs &l1, const RowDgradArgs &l2, const RowDgradArgs &l3, RowChainArgs &c, int bm) {
   if (!plan_switches().rowdgrad_chain) return false;   // FDQL_NO_ROWDGRAD_CHAIN
+  if ((bm != 16 && bm != 32 && bm != RD_BM) || l1.M % bm) return false;
   if (l1.nsum < 2 || l1.nseg != 1 || !l1.gate || !l1.colsum || !l1.sum_colsum) return false;
   if (l2.nsum || l2.nseg != 2 || l2.gate || !l2.colsum || l2.A[0] != l1.sum_out || l2.A[1] != l1.C) return false;
   if (l3.nsum || l3.nseg != 1 || !l3.gate || !l3.colsum || l3.A[0] != l2.C) return false;
   if (l1.M != l2.M || l1.M != l3.M) return false;
   memset(&c, 0, sizeof(c));
-  c.M = l1.M;
+  c.M = l1.M; c.bm = bm;
   c.sum_parts = l1.sum_parts; c.nsum = l1.nsum; c.sum_stride = l1.sum_stride; c.x0 = l1.sum_out; c.cs0 = l1.sum_colsum;
   c.W1 = l1.W[0]; c.ldw1 = l1.ldw[0]; c.ref1 = l1.ref; c.x1 = l1.C; c.cs1 = l1.colsum;
   c.W2a = l2.W[0]; c.ldw2a = l2.ldw[0]; c.W2b = l2.W[1]; c.ldw2b = l2.ldw[1]; c.x2 = l2.C; c.cs2 = l2.colsum;
@@ -475,16 +481,23 @@ hipError_t rowchain_launch(const RowChainArgs &a, hipStream_t s) {
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
   if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-  const size_t lds_bytes = (size_t)(2 * IMG + 4 * RD_K) * 4;
+  const int bm = a.bm ? a.bm : RD_BM;
+  if ((bm != 16 && bm != 32 && bm != 64) || a.M % bm) return hipErrorInvalidValue;   // (a grid that does not cover M exactly must never start)
+  auto lds_of = [](int rows) { return (size_t)(2 * rows * P + 4 * RD_K) * 4; };
   {
     std::lock_guard<std::mutex> lk(mu);
     if (!attr[dev]) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowdgrad_chain), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowdgrad_chain<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(64));
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowdgrad_chain<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(32));
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowdgrad_chain<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(16));
       if (e != hipSuccess) return e;
       attr[dev] = true;
     }
   }
-  hipLaunchKernelGGL(k_rowdgrad_chain, dim3(a.M / RD_BM), dim3(256), lds_bytes, s, a);
+  const dim3 grid(a.M / bm), block(256);
+  if (bm == 64) hipLaunchKernelGGL(k_rowdgrad_chain<4>, grid, block, lds_of(64), s, a);
+  else if (bm == 32) hipLaunchKernelGGL(k_rowdgrad_chain<2>, grid, block, lds_of(32), s, a);
+  else hipLaunchKernelGGL(k_rowdgrad_chain<1>, grid, block, lds_of(16), s, a);
   return hipGetLastError();
 }
 
@@ -507,6 +520,7 @@ hipError_t rowdgrad_launch(const RowDgradArgs &a, hipStream_t s) {
       attr[dev] = true;
     }
   }
+  if (a.M % RD_BM) return hipErrorInvalidValue;   // (smaller blocks exist only inside the chain launch)
   const dim3 grid(a.M / RD_BM), block(256);
   const size_t lds_bytes = (size_t)a.nseg * IMG * 4 + (a.nsum > 0 ? 4 * RD_K * 4 : 0);
   if (a.nsum > 0 && a.nseg == 1) {
