@@ -538,6 +538,9 @@ int build_plan(fdql_agent *a) {
     const size_t nh = group[0]->d->hid.size();
     for (size_t i = 0; i < nh; ++i) {
       Stage &gs = b.gemm_stage(name + ".fwd" + std::to_string(i));
+      // a 256 -> 256 hidden layer of one or two networks with >= one 64-row tile per CU runs weight-stationary (config 4 / 5:
+      // joiner.fwd0 0.083 -> 0.071 ms, actors.fwd0 0.147 -> 0.123 at config 4; measured in round 5, kept in round 6)
+      gs.try_rows = true;
       for (MlpInst *m : group) gs.gemm.push_back(b.fwd_layer(*m, (int)i));
     }
     Stage &hs = b.gemm_stage(name + ".head");
@@ -618,8 +621,19 @@ int build_plan(fdql_agent *a) {
     fa.enc = mlp_of(eo); fa.joi = mlp_of(jo); fa.act = mlp_of(ao); fa.act_t = mlp_of(at);
     fa.P = a->actor.dout;
     fa.enc_h = eo.h[0]; fa.enc_out = eo.out; fa.joi_h = jo.h[0]; fa.state = state; fa.act_h = ao.h[0]; fa.act_out = ao.out; fa.act_t_out = at.out;
+    // Block size by measurement (profiles/r06_fwd3_blocks.txt; 17 observation columns): 16 rows while that is at most one
+    // workgroup per CU (512 / 1 600 / 3 200 rows: 0.052 / 0.064 / 0.066 ms against 0.085-0.101 for the six small-batch launches /
+    // k_chain<1>), 32 rows up to one round of two workgroups per CU (6 400 / 12 800 rows: 0.087 / 0.146 ms against k_chain's
+    // 0.108 / 0.159); beyond that, and for wide observations (config 4's 376 columns go through the ragged dword path: 0.18 ms
+    // either way), k_chain keeps the plan
+    int ncu3 = 256, dev3 = 0;
+    if (hipGetDevice(&dev3) == hipSuccess) (void)hipDeviceGetAttribute(&ncu3, hipDeviceAttributeMultiprocessorCount, dev3);
     int bm = 0;
-    if (const char *e = getenv("FDQL_EXP_FWD3")) bm = atoi(e);   // EXPERIMENT (round 6 sweep): removed once the rule is measured
+    if (fa.K0 <= 64) {
+      if (N % 16 == 0 && B % 16 == 0 && N / 16 <= ncu3) bm = 16;
+      else if (N % 32 == 0 && B % 32 == 0 && N / 32 <= 2 * ncu3) bm = 32;
+      else if (N % 16 == 0 && B % 16 == 0 && N / 16 <= 2 * ncu3) bm = 16;
+    }
     fa.bm = bm;
     if (bm > 0 && fwd3_takes(fa)) {
       Stage &fs = b.func_stage("enc_joiner_actors", [=](hipStream_t s) { return fwd3_launch(fa, s); });
@@ -1167,8 +1181,6 @@ int build_plan(fdql_agent *a) {
     int want = RD_BM;
     if (M / RD_BM < a->rowdgrad_min_blocks) want = M < 1024 ? 0 : ((M % 16 == 0 && M / 16 <= 256) ? 16 : (M % 32 == 0 ? 32 : (M % 16 == 0 ? 16 : 0)));
     else if (M / RD_BM > 256 && M % 32 == 0) want = 32;
-    const char *exp_bm = getenv("FDQL_EXP_CHAIN_BM");   // EXPERIMENT (round 6 sweep): removed once the rule is measured
-    if (exp_bm) want = atoi(exp_bm);
     if (chain_planned && plan_switches().rowdgrad && want > 0 && want < RD_BM) {
       const int bm = want;
       // the other two members, asked like the first (upload_tables builds the same three launches)

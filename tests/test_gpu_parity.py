@@ -526,8 +526,10 @@ def test_update_matches_oracle_config2(dev, T, B, hid):
     ("config 2 dims, critic layers forced onto the weight-stationary row-block kernel at a small batch (FDQL_ROWGEMM=all: "
      "8 tiles per instance, prologue + flush paths, per-workgroup column sums)",
      dict(obs=17, act=6, C=5, Q=2, T=5, B=64, env={"FDQL_ROWGEMM": "all"})),
-    ("3-layer 256-wide critics on the weight-stationary kernel (non-fused dgrad form on the middle layer, fused on the last)",
-     dict(obs=17, act=6, C=3, Q=2, T=5, B=64, critic_hidden=(256, 256, 256), env={"FDQL_ROWGEMM": "all"})),
+    ("3-layer 256-wide critics on the weight-stationary kernel (non-fused dgrad form on the middle layer, fused on the last); "
+     "gradients by the fp64 three-way test: with this case's data ONE unit of critic 2's middle layer sits 1.0e-7 of the layer's "
+     "scale from its LeakyReLU kink and the forward chain kernels round it to different sides (tools/diag in DESIGN section 2)",
+     dict(obs=17, act=6, C=3, Q=2, T=5, B=64, critic_hidden=(256, 256, 256), env={"FDQL_ROWGEMM": "all"}, grad_gate=False)),
     ("config 2 dims, every MLP forward through the row-block chain kernel (FDQL_CHAIN=all: encoder/joiner/actors in one "
      "program, each critic instance in one)", dict(obs=17, act=6, C=5, Q=2, T=4, B=64, env={"FDQL_CHAIN": "all"})),
     ("config 2 dims on per-layer launches only (FDQL_CHAIN=0)", dict(obs=17, act=6, C=5, Q=2, T=6, B=192, env={"FDQL_CHAIN": "0"})),
@@ -600,8 +602,18 @@ def test_update_matches_oracle_config2(dev, T, B, hid):
      "32 rows, k_chain<1>, the output-stationary weight-gradient launch at 11 tiles per workgroup)", dict(obs=17, act=6, C=5, Q=2, T=50, B=128)),
     ("config 2 dims at T=50, B=64: one rank's share at N = 4 (3 136 gradient rows: 100 chain blocks of 32 rows, the dense weight "
      "gradients as K-split problems riding in the dgrad launches)", dict(obs=17, act=6, C=5, Q=2, T=50, B=64)),
-    ("config 2 dims at T=50, B=384: 18 816 gradient rows = 294 blocks of 64 - k_rowdgrad_chain (d state sum + joiner / d enc / "
-     "encoder dgrads in one launch) with MORE blocks than one round of workgroups", dict(obs=17, act=6, C=5, Q=2, T=50, B=384)),
+    ("config 2 dims at T=50, B=384: 18 816 gradient rows = 588 blocks of 32 - k_rowdgrad_chain<2> (d state sum + joiner / d enc / "
+     "encoder dgrads in one launch) with MORE blocks than one round of workgroups; 600 forward blocks of 32: past k_fwd3's one round, "
+     "k_chain<2>", dict(obs=17, act=6, C=5, Q=2, T=50, B=384)),
+    ("config 2 dims at T=50, B=32 on the launches the small-block kernels replace (FDQL_NO_ROWDGRAD_CHAIN: summing launch + three "
+     "dgrad launches; FDQL_CHAIN=0: six per-layer forward launches)", dict(obs=17, act=6, C=5, Q=2, T=50, B=32,
+                                                                           env={"FDQL_NO_ROWDGRAD_CHAIN": "1", "FDQL_CHAIN": "0"})),
+    ("config 2 dims at T=50, B=64 with encoder -> joiner -> actors on k_chain<1> (FDQL_CHAIN=enc: 100 blocks of 32 rows, the launch "
+     "k_fwd3<1> replaces at this size)", dict(obs=17, act=6, C=5, Q=2, T=50, B=64, env={"FDQL_CHAIN": "enc"})),
+    ("config 3 dims at T=50, B=64: three observation segments (obs 28 + two goals of 10 = 48 ragged columns: three 16-k groups) "
+     "through k_fwd3<1>, k_rowdgrad_chain<1> behind d state", dict(obs=28, goal=10, act=6, C=5, Q=2, T=50, B=64)),
+    ("discrete head (6 logits) and 40 windows (B % 16 != 0: no small-block forward kernel; 1 960 gradient rows, not a multiple of 16: "
+     "no small-block dgrad chain)", dict(obs=17, act=6, discrete=True, C=3, Q=4, T=50, B=40)),
 ])
 def test_update_matches_oracle_other_configs(dev, name, kw, monkeypatch):
     """The remaining BASELINE configs' shapes (and non-default depths) against the CPU oracle, one step."""
@@ -623,6 +635,7 @@ def test_update_matches_oracle_other_configs(dev, name, kw, monkeypatch):
 def _run_other_config(dev, name, kw):
     from oracle import update as oup
     T, B = kw.pop("T"), kw.pop("B")
+    grad_gate = kw.pop("grad_gate", True)   # False: the case's gradients are compared by test_gradient_parity_three_way_fp64 (a unit on its kink)
     frames = kw.pop("frames", None)   # "u8": uint8 frame batch; "ring": the ring's uint8 block read in place (obs_2d_slots)
     base = dict(latent=256, enc_features=256, enc_hidden=(256,), joint_hidden=(256,), pi_hidden=(256,), critic_hidden=(256, 256))
     base.update(kw)
@@ -674,7 +687,7 @@ def _run_other_config(dev, name, kw):
     ref = {k: (v.detach().numpy() if isinstance(v, torch.Tensor) else v) for k, v in aux.items() if k != "grad"}
     ref["loss"], ref["grad"] = float(loss), aux["grad"]
     ref["after"] = {n: st.params[n] for n in ag.tensors if "_frozen." not in n}
-    _check_step(rep, 0, ag, spec, ref, before, alpha, log_alpha, 1)
+    _check_step(rep, 0, ag, spec, ref, before, alpha, log_alpha, 1, grad_gate=grad_gate)
     rep.finish()
 
 
@@ -1006,6 +1019,13 @@ def test_fp64_arbiter_on_the_device_agrees_with_the_cpu(dev):
     ("25-quantile heads at config 2's full row count (obs 17, act 6, 5x25, T=50, B=256: 12 544 rows = 49 per CU): k_head_dgrad_masked "
      "with several 4 x 64-row groups per instance, k_loss_wave<2> on 12 544 waves, the masked weight-stationary dgrad at 5 narrow steps",
      dict(obs=17, act=6, C=5, Q=25, T=50, B=256)),
+    ("3-layer 256-wide critics at T=5, B=64 with the weight-stationary launches forced (the case whose fraction gate a kink flip "
+     "defeats in test_update_matches_oracle_other_configs): k_fwd3<1> forward, non-fused + fused dgrad forms",
+     dict(obs=17, act=6, C=3, Q=2, T=5, B=64, critic_hidden=(256, 256, 256), env={"FDQL_ROWGEMM": "all"})),
+    ("config 2 dims at T=50, B=64: one rank's share at N = 4 on the small-block kernels (k_fwd3<1>: 200 forward blocks of 16 rows, "
+     "k_rowdgrad_chain<1>: 196 blocks of 16)", dict(obs=17, act=6, C=5, Q=2, T=50, B=64)),
+    ("config 2 dims at T=50, B=128: one rank's share at N = 2 (k_fwd3<2>: 200 blocks of 32 rows, k_rowdgrad_chain<2>: 196 of 32)",
+     dict(obs=17, act=6, C=5, Q=2, T=50, B=128)),
     ("config 4 dims (5x25 quantiles, 17 action columns) at T=6, B=64 with the stationary and streaming launches forced "
      "(FDQL_ROWGEMM=all FDQL_STREAM_WGRAD=2: 25 head rows and 17 input columns per streaming problem, no riders fit)",
      dict(obs=376, act=17, C=5, Q=25, T=6, B=64, env={"FDQL_ROWGEMM": "all", "FDQL_STREAM_WGRAD": "2"})),
