@@ -621,19 +621,19 @@ int build_plan(fdql_agent *a) {
     fa.enc = mlp_of(eo); fa.joi = mlp_of(jo); fa.act = mlp_of(ao); fa.act_t = mlp_of(at);
     fa.P = a->actor.dout;
     fa.enc_h = eo.h[0]; fa.enc_out = eo.out; fa.joi_h = jo.h[0]; fa.state = state; fa.act_h = ao.h[0]; fa.act_out = ao.out; fa.act_t_out = at.out;
-    // Block size by measurement (profiles/r06_fwd3_blocks.txt; 17 observation columns): 16 rows while that is at most one
-    // workgroup per CU (512 / 1 600 / 3 200 rows: 0.052 / 0.064 / 0.066 ms against 0.085-0.101 for the six small-batch launches /
-    // k_chain<1>), 32 rows up to one round of two workgroups per CU (6 400 / 12 800 rows: 0.087 / 0.146 ms against k_chain's
-    // 0.108 / 0.159); beyond that, and for wide observations (config 4's 376 columns go through the ragged dword path: 0.18 ms
-    // either way), k_chain keeps the plan
+    // Block size by measurement (profiles/r06_fwd3_blocks.txt): 16 rows while that is at most one workgroup per CU (17 observation
+    // columns, 512 / 1 600 / 3 200 rows: 0.052 / 0.064 / 0.066 ms against 0.085-0.101 for the six small-batch launches / k_chain<1>),
+    // 32 rows up to one round of two workgroups per CU (6 400 / 12 800 rows: 0.087 / 0.146 ms against k_chain's 0.108 / 0.159;
+    // config 4's 376 columns at 6 400 / 12 800 rows: 0.122 / 0.244 against 0.183 / 0.290); beyond one round the per-layer launches /
+    // k_chain keep the plan (config 4 at 51 200 rows: 0.84 against 0.75 ms).  Wide observations need the 16-byte request form
+    // (fwdchain.hip VOBS: row pitch a multiple of four floats, whole ring rounds)
     int ncu3 = 256, dev3 = 0;
     if (hipGetDevice(&dev3) == hipSuccess) (void)hipDeviceGetAttribute(&ncu3, hipDeviceAttributeMultiprocessorCount, dev3);
+    auto obs_ok = [&](int bmx) { return fa.K0 <= 64 || (fa.K0 % 4 == 0 && ((fa.K0 + 15) / 16) % (bmx == 16 ? 8 : 4) == 0); };
     int bm = 0;
-    if (fa.K0 <= 64) {
-      if (N % 16 == 0 && B % 16 == 0 && N / 16 <= ncu3) bm = 16;
-      else if (N % 32 == 0 && B % 32 == 0 && N / 32 <= 2 * ncu3) bm = 32;
-      else if (N % 16 == 0 && B % 16 == 0 && N / 16 <= 2 * ncu3) bm = 16;
-    }
+    if (N % 16 == 0 && B % 16 == 0 && N / 16 <= ncu3 && obs_ok(16)) bm = 16;
+    else if (N % 32 == 0 && B % 32 == 0 && N / 32 <= 2 * ncu3 && obs_ok(32)) bm = 32;
+    else if (N % 16 == 0 && B % 16 == 0 && N / 16 <= 2 * ncu3 && obs_ok(16)) bm = 16;
     fa.bm = bm;
     if (bm > 0 && fwd3_takes(fa)) {
       Stage &fs = b.func_stage("enc_joiner_actors", [=](hipStream_t s) { return fwd3_launch(fa, s); });

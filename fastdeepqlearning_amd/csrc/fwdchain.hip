@@ -32,7 +32,9 @@ constexpr int NDEPTH = 4;      // ... of the narrow head's (one request per grou
 
 __device__ __forceinline__ int f3_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-template <int RT>
+// VOBS: the observation segment through the 16-byte request ring as well (wide observations whose weight rows are multiples of
+// four floats - config 4: 376 columns = 24 groups; the dword path below is one request round per 16-k group, 0.05 ms of them)
+template <int RT, bool VOBS>
 __global__ __launch_bounds__(256, 2) void k_fwd3(const Fwd3Args a) {
   constexpr int BM = 16 * RT;
   // 16-k weight groups in flight per wave (16 % DEPTH == 0: a segment's groups keep their ring slots): a group is 16 RT MFMAs
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd3(const Fwd3Args a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = f3_uni(tid >> 6);
   const int j = lane & 15, kq = lane >> 4;
   const int r0 = blockIdx.x * BM, n0 = wave * 64;
-  const int K0 = a.K0, G0 = (K0 + 15) >> 4, PX = 16 * G0 + 4;
+  const int K0 = a.K0, G0 = (K0 + 15) >> 4, PX = 16 * G0 + 4;   // (VOBS: G0 % DEPTH == 0, checked by the launcher)
   float *const I0 = lds, *const I1 = lds + BM * FP, *const X0 = lds + 2 * BM * FP;
   const bool has_act = r0 < a.M, has_tgt = r0 >= a.B;   // (uniform: a block never straddles a time step, B % BM == 0)
 
@@ -111,6 +113,30 @@ __global__ __launch_bounds__(256, 2) void k_fwd3(const Fwd3Args a) {
       for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[rt][s], w[4 * ct + s], acc[rt][ct], 0, 0, 0);
+  };
+  // VOBS: the same segment as G0 (a multiple of DEPTH) ring groups; columns >= K0 of X0 are zero, so what the last group reads
+  // past a weight row's end does not count
+  auto wide_obs = [&](const WSeg &w, const WSeg &wn) __attribute__((always_inline)) {
+    const float *xp = X0 + j * PX + 4 * kq;
+#pragma unroll 1
+    for (int gb = 0; gb < G0; gb += DEPTH) {
+#pragma unroll
+      for (int q = 0; q < DEPTH; ++q) {
+        const int g = gb + q;
+        v4f x[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) x[rt] = *reinterpret_cast<const v4f *>(xp + 16 * rt * PX + 16 * g);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[rt][s], ring[q][ct][s], acc[rt][ct], 0, 0, 0);
+        if (g + DEPTH < G0) req(w, g + DEPTH, ring[q]);
+        else req(wn, g + DEPTH - G0, ring[q]);
+        asm volatile("" ::: "memory");
+      }
+    }
   };
   auto ragged = [&](gcf W, int ldw, float (&w0)[16]) __attribute__((always_inline)) {
     float w1[16];
@@ -190,14 +216,15 @@ __global__ __launch_bounds__(256, 2) void k_fwd3(const Fwd3Args a) {
     }
   };
 
-  // ---- requests that depend on nothing: the first ragged group of layer 1, the ring for the encoder head's hidden part
+  // ---- requests that depend on nothing: the first observation group(s) of layer 1, the ring for the first wide segment
   float wg[16];
-  rag_load((gcf)a.enc.W0, K0, 0, wg);
   const int ld_eh = K0 + F3_W;
   const WSeg w_eh = wseg(a.enc.Wh, ld_eh, K0), w_j0 = wseg(a.joi.W0, F3_W, 0), w_jh0 = wseg(a.joi.Wh, 2 * F3_W, 0),
              w_jh1 = wseg(a.joi.Wh, 2 * F3_W, F3_W), w_a0 = wseg(a.act.W0, F3_W, 0), w_t0 = wseg(a.act_t.W0, F3_W, 0), w_none = {nullptr, 0, 0};
+  const WSeg w_x0 = wseg(a.enc.W0, K0, 0), w_xh = wseg(a.enc.Wh, ld_eh, 0);
+  if constexpr (!VOBS) rag_load((gcf)a.enc.W0, K0, 0, wg);
 #pragma unroll
-  for (int q = 0; q < DEPTH; ++q) req(w_eh, q, ring[q]);
+  for (int q = 0; q < DEPTH; ++q) req(VOBS ? w_x0 : w_eh, q, ring[q]);
   asm volatile("" ::: "memory");
   // ---- observation rows -> X0 (zero-padded to 16 G0 columns)
   {
@@ -221,12 +248,17 @@ __global__ __launch_bounds__(256, 2) void k_fwd3(const Fwd3Args a) {
 
   // ---- encoder, hidden layer: h_e = LeakyReLU(W0 x + b0) -> I0
   zero_acc();
-  ragged((gcf)a.enc.W0, K0, wg);
-  rag_load((gcf)a.enc.Wh, ld_eh, 0, wg);   // the head's observation part: first group under the epilogue
+  if constexpr (VOBS) {
+    wide_obs(w_x0, w_xh);
+  } else {
+    ragged((gcf)a.enc.W0, K0, wg);
+    rag_load((gcf)a.enc.Wh, ld_eh, 0, wg);   // the head's observation part: first group under the epilogue
+  }
   to_image(a.enc.b0, true, I0);
   // ---- encoder head: e = Wh cat(x, h_e) + bh -> I1 (its observation part needs no barrier)
   zero_acc();
-  ragged((gcf)a.enc.Wh, ld_eh, wg);
+  if constexpr (VOBS) wide_obs(w_xh, w_eh);
+  else ragged((gcf)a.enc.Wh, ld_eh, wg);
   __syncthreads();
   store_image(I0, a.enc_h, 0, a.N, 0);
   wide(I0, w_eh, w_j0, true);
@@ -298,15 +330,24 @@ hipError_t fwd3_launch(const Fwd3Args &a, hipStream_t s) {
   {
     std::lock_guard<std::mutex> lk(mu);
     if (!attr[dev]) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd3<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(16, F3_MAX_K0));
-      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd3<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(32, F3_MAX_K0));
+      const void *fns[4] = {reinterpret_cast<const void *>(&k_fwd3<1, false>), reinterpret_cast<const void *>(&k_fwd3<1, true>),
+                            reinterpret_cast<const void *>(&k_fwd3<2, false>), reinterpret_cast<const void *>(&k_fwd3<2, true>)};
+      for (int i = 0; i < 4 && e == hipSuccess; ++i)
+        e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(i < 2 ? 16 : 32, F3_MAX_K0));
       if (e != hipSuccess) return e;
       attr[dev] = true;
     }
   }
   const dim3 grid(a.N / a.bm), block(256);
-  if (a.bm == 16) hipLaunchKernelGGL(k_fwd3<1>, grid, block, lds_of(16, a.K0), s, a);
-  else hipLaunchKernelGGL(k_fwd3<2>, grid, block, lds_of(32, a.K0), s, a);
+  const int depth = a.bm == 16 ? 8 : 4, g0 = (a.K0 + 15) / 16;
+  const bool vobs = a.K0 >= 128 && a.K0 % 4 == 0 && g0 % depth == 0;   // (row pitches K0 and K0 + 256 are then multiples of four floats)
+  if (a.bm == 16) {
+    if (vobs) hipLaunchKernelGGL((k_fwd3<1, true>), grid, block, lds_of(16, a.K0), s, a);
+    else hipLaunchKernelGGL((k_fwd3<1, false>), grid, block, lds_of(16, a.K0), s, a);
+  } else {
+    if (vobs) hipLaunchKernelGGL((k_fwd3<2, true>), grid, block, lds_of(32, a.K0), s, a);
+    else hipLaunchKernelGGL((k_fwd3<2, false>), grid, block, lds_of(32, a.K0), s, a);
+  }
   return hipGetLastError();
 }
 
