@@ -345,7 +345,7 @@ def roofline_of(job, committed_pmc=True):
         return r, top
     # PMC figures (HBM traffic, MFMA pipe utilisation, clock) cannot be measured from inside this process: they come from
     # the committed rocprofv3 --pmc passes of the SAME workload, and only if those were collected on THIS csrc revision
-    tj = os.path.join(ROOT, "profiles", "r05_dominant_kernel_traffic.json")
+    tj = os.path.join(ROOT, "profiles", "r06_dominant_kernel_traffic.json")
     if os.path.exists(tj):
         tr = json.load(open(tj))
         ent = None
@@ -359,7 +359,7 @@ def roofline_of(job, committed_pmc=True):
             tr = ent
             r["traffic"] = tr["hbm_bytes_per_launch"]
             r["traffic_unit"] = "bytes/launch (L2<->fabric read+write, PMC FETCH_SIZE x2 + WRITE_SIZE)"
-            r["traffic_source"] = "profiles/r05_hbm_traffic_pmc.txt (" + tr["source"] + ")"
+            r["traffic_source"] = "profiles/r06_hbm_traffic_pmc.txt (" + tr["source"] + ")"
             r["algorithmic_bytes_per_launch"] = by / max(n, 1)
             for k in ("mfma_pipe_busy_frac", "shader_clock_ghz_under_load"):
                 if k in tr:

@@ -45,7 +45,15 @@ __global__ __launch_bounds__(256, 2) void k_fwd3(const Fwd3Args a) {
   const int j = lane & 15, kq = lane >> 4;
   const int r0 = blockIdx.x * BM, n0 = wave * 64;
   const int K0 = a.K0, G0 = (K0 + 15) >> 4, PX = 16 * G0 + 4;   // (VOBS: G0 % DEPTH == 0, checked by the launcher)
-  float *const I0 = lds, *const I1 = lds + BM * FP, *const X0 = lds + 2 * BM * FP;
+  // RT = 1 runs one workgroup per CU (the plan picks 16-row blocks only up to one per CU): every activation keeps an LDS image
+  // of its own and goes to memory at the END of the kernel - a store in the middle makes the next use of a requested weight
+  // wait for vmcnt(0), i.e. for the store's round trip (loads and stores retire out of order with each other), five times per
+  // block with nothing to cover it.  RT = 2 (two workgroups per CU, 79 KB each) ping-pongs two images and stores as it goes.
+  constexpr bool DEFER = RT == 1;
+  constexpr int NIMG = DEFER ? 6 : 2;
+  float *const I_eh = lds, *const I_e = lds + BM * FP, *const I_jh = DEFER ? lds + 2 * BM * FP : I_eh, *const I_s = DEFER ? lds + 3 * BM * FP : I_e,
+               *const I_ah = DEFER ? lds + 4 * BM * FP : I_eh, *const I_th = DEFER ? lds + 5 * BM * FP : I_eh;
+  float *const HS = lds + NIMG * BM * FP, *const X0 = HS + 4 * BM * 16;   // HS: the narrow head's four partial tiles
   const bool has_act = r0 < a.M, has_tgt = r0 >= a.B;   // (uniform: a block never straddles a time step, B % BM == 0)
 
   v4f ring[DEPTH][4];
@@ -153,10 +161,15 @@ __global__ __launch_bounds__(256, 2) void k_fwd3(const Fwd3Args a) {
     }
   };
   // bias (+ LeakyReLU) and the tile into an LDS image: lane (j, kq) holds rows 16 rt + 4 kq + r of column n0 + 16 ct + j
-  auto to_image = [&](const float *bias, bool lrelu, float *IM) __attribute__((always_inline)) {
+  float bq[4];   // the layer's bias, requested before its K loop
+  auto bias_req = [&](const float *bias) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) bq[ct] = ((gcf)bias)[n0 + 16 * ct + j];
+  };
+  auto to_image = [&](bool lrelu, float *IM) __attribute__((always_inline)) {
     float b[4];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) b[ct] = ((gcf)bias)[n0 + 16 * ct + j];
+    for (int ct = 0; ct < 4; ++ct) b[ct] = bq[ct];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -177,9 +190,54 @@ __global__ __launch_bounds__(256, 2) void k_fwd3(const Fwd3Args a) {
       if (gr >= lo && gr < hi) *(gf4)(out + (long long)(gr - shift) * F3_W + lane * 4) = *reinterpret_cast<const v4f *>(IM + row * FP + lane * 4);
     }
   };
-  // narrow head over cat(S = I1, H = I0): wave w owns output columns 16 w .. 16 w + 15 (waves past the head's width idle)
-  auto narrow = [&](const Fwd3Mlp &m, float *out, int shift) __attribute__((always_inline)) {
+  // narrow head over cat(S = IS, H = IH).  P <= 16 (one column tile): the K range is dealt to the four waves - wave w takes the
+  // 128 k's [128 w, 128 w + 128) (waves 0, 1 read S, waves 2, 3 read H), its eight 16-byte requests are issued by narrow_req()
+  // before the hidden layer's epilogue, the four partial tiles meet in LDS and are added in wave order.  Wider heads (config 4: 34
+  // outputs): wave w owns column tile w over the whole K range (waves past the head's width idle).
+  v4f hw[8];
+  auto narrow_req = [&](const Fwd3Mlp &m) __attribute__((always_inline)) {
+    if (a.P > 16) return;
+    gcf w = (gcf)m.Wh + (long long)(j < a.P ? j : a.P - 1) * (2 * F3_W) + 128 * wave + 4 * kq;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) hw[q] = *(gcf4)(w + 16 * q);
+  };
+  auto narrow = [&](const Fwd3Mlp &m, const float *IS, const float *IH, float *out, int shift) __attribute__((always_inline)) {
     const int P = a.P;
+    if (P <= 16) {
+      const float *xp = (wave < 2 ? IS : IH) + j * FP + 128 * (wave & 1) + 4 * kq;
+      v4f hs[4][RT];
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) hs[s][rt] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        v4f x[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) x[rt] = *reinterpret_cast<const v4f *>(xp + 16 * rt * FP + 16 * g);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) hs[s][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[rt][s], hw[g][s], hs[s][rt], 0, 0, 0);
+      }
+      float *sc = HS + wave * (BM * 16);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const v4f t = (hs[0][rt] + hs[1][rt]) + (hs[2][rt] + hs[3][rt]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sc[(16 * rt + 4 * kq + r) * 16 + j] = t[r];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < RT; ++u) {
+        const int idx = tid + 256 * u, row = idx >> 4, col = idx & 15;
+        if (col < P) {
+          const float v = ((HS[idx] + HS[BM * 16 + idx]) + HS[2 * BM * 16 + idx]) + HS[3 * BM * 16 + idx];
+          ((gf)out)[(long long)(r0 + row - shift) * P + col] = v + ((gcf)m.bh)[col];
+        }
+      }
+      return;
+    }
     if (16 * wave >= P) return;
     const int n = 16 * wave + j;
     const bool ok = n < P;
@@ -194,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd3(const Fwd3Args a) {
       for (int rt = 0; rt < RT; ++rt) hs[s][rt] = v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int g = 0; g < 32; ++g) {
-      const float *xp = (g < 16 ? I1 : I0) + j * FP + 16 * (g & 15) + 4 * kq;
+      const float *xp = (g < 16 ? IS : IH) + j * FP + 16 * (g & 15) + 4 * kq;
       v4f x[RT];
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) x[rt] = *reinterpret_cast<const v4f *>(xp + 16 * rt * FP);
@@ -223,6 +281,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd3(const Fwd3Args a) {
              w_jh1 = wseg(a.joi.Wh, 2 * F3_W, F3_W), w_a0 = wseg(a.act.W0, F3_W, 0), w_t0 = wseg(a.act_t.W0, F3_W, 0), w_none = {nullptr, 0, 0};
   const WSeg w_x0 = wseg(a.enc.W0, K0, 0), w_xh = wseg(a.enc.Wh, ld_eh, 0);
   if constexpr (!VOBS) rag_load((gcf)a.enc.W0, K0, 0, wg);
+  bias_req(a.enc.b0);
 #pragma unroll
   for (int q = 0; q < DEPTH; ++q) req(VOBS ? w_x0 : w_eh, q, ring[q]);
   asm volatile("" ::: "memory");
@@ -246,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd3(const Fwd3Args a) {
   }
   __syncthreads();
 
-  // ---- encoder, hidden layer: h_e = LeakyReLU(W0 x + b0) -> I0
+  // ---- encoder, hidden layer: h_e = LeakyReLU(W0 x + b0)
   zero_acc();
   if constexpr (VOBS) {
     wide_obs(w_x0, w_xh);
@@ -254,48 +313,62 @@ __global__ __launch_bounds__(256, 2) void k_fwd3(const Fwd3Args a) {
     ragged((gcf)a.enc.W0, K0, wg);
     rag_load((gcf)a.enc.Wh, ld_eh, 0, wg);   // the head's observation part: first group under the epilogue
   }
-  to_image(a.enc.b0, true, I0);
-  // ---- encoder head: e = Wh cat(x, h_e) + bh -> I1 (its observation part needs no barrier)
+  to_image(true, I_eh);
+  bias_req(a.enc.bh);
+  // ---- encoder head: e = Wh cat(x, h_e) + bh (its observation part needs no barrier)
   zero_acc();
   if constexpr (VOBS) wide_obs(w_xh, w_eh);
   else ragged((gcf)a.enc.Wh, ld_eh, wg);
   __syncthreads();
-  store_image(I0, a.enc_h, 0, a.N, 0);
-  wide(I0, w_eh, w_j0, true);
-  to_image(a.enc.bh, false, I1);
+  if constexpr (!DEFER) store_image(I_eh, a.enc_h, 0, a.N, 0);
+  wide(I_eh, w_eh, w_j0, true);
+  to_image(false, I_e);
+  bias_req(a.joi.b0);
   __syncthreads();
-  store_image(I1, a.enc_out, 0, a.N, 0);
-  // ---- joiner, hidden layer: h_j = LeakyReLU(W0 e + b0) -> I0
+  if constexpr (!DEFER) store_image(I_e, a.enc_out, 0, a.N, 0);
+  // ---- joiner, hidden layer: h_j = LeakyReLU(W0 e + b0)
   zero_acc();
-  wide(I1, w_j0, w_jh0, true);
-  to_image(a.joi.b0, true, I0);
+  wide(I_e, w_j0, w_jh0, true);
+  to_image(true, I_jh);
+  bias_req(a.joi.bh);
   __syncthreads();
-  store_image(I0, a.joi_h, 0, a.N, 0);
-  // ---- joiner head: state = Wh cat(e, h_j) + bh -> I1 (over e, once every wave has read it)
+  if constexpr (!DEFER) store_image(I_jh, a.joi_h, 0, a.N, 0);
+  // ---- joiner head: state = Wh cat(e, h_j) + bh (two images: over e, once every wave has read it)
   zero_acc();
-  wide(I1, w_jh0, w_jh1, true);
-  wide(I0, w_jh1, has_act ? w_a0 : w_t0, true);
+  wide(I_e, w_jh0, w_jh1, true);
+  wide(I_jh, w_jh1, has_act ? w_a0 : w_t0, true);
+  if constexpr (!DEFER) __syncthreads();
+  to_image(false, I_s);
   __syncthreads();
-  to_image(a.joi.bh, false, I1);
-  __syncthreads();
-  store_image(I1, a.state, 0, a.N, 0);
-  // ---- online actor on rows [0, M): h_a -> I0, logits = Wh cat(state, h_a) + bh
+  if constexpr (!DEFER) store_image(I_s, a.state, 0, a.N, 0);
+  // ---- online actor on rows [0, M): h_a, logits = Wh cat(state, h_a) + bh
   if (has_act) {
+    bias_req(a.act.b0);
     zero_acc();
-    wide(I1, w_a0, w_t0, has_tgt);
-    to_image(a.act.b0, true, I0);
+    wide(I_s, w_a0, w_t0, has_tgt);
+    narrow_req(a.act);
+    to_image(true, I_ah);
     __syncthreads();
-    store_image(I0, a.act_h, 0, a.M, 0);
-    narrow(a.act, a.act_out, 0);
+    if constexpr (!DEFER) store_image(I_ah, a.act_h, 0, a.M, 0);
+    narrow(a.act, I_s, I_ah, a.act_out, 0);
   }
   // ---- target actor on rows [B, N), stored at row - B
   if (has_tgt) {
+    bias_req(a.act_t.b0);
     zero_acc();
-    wide(I1, w_t0, w_none, false);
-    if (has_act) __syncthreads();   // the online head's waves are done with h_a
-    to_image(a.act_t.b0, true, I0);
+    wide(I_s, w_t0, w_none, false);
+    narrow_req(a.act_t);
+    if (!DEFER && has_act) __syncthreads();   // two images: the online head's waves are done with h_a
+    to_image(true, I_th);
     __syncthreads();
-    narrow(a.act_t, a.act_t_out, a.B);
+    narrow(a.act_t, I_s, I_th, a.act_t_out, a.B);
+  }
+  if constexpr (DEFER) {
+    store_image(I_eh, a.enc_h, 0, a.N, 0);
+    store_image(I_e, a.enc_out, 0, a.N, 0);
+    store_image(I_jh, a.joi_h, 0, a.N, 0);
+    store_image(I_s, a.state, 0, a.N, 0);
+    if (has_act) store_image(I_ah, a.act_h, 0, a.M, 0);
   }
 }
 
@@ -326,7 +399,7 @@ hipError_t fwd3_launch(const Fwd3Args &a, hipStream_t s) {
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
   if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-  auto lds_of = [&](int bm, int k0) { return (size_t)(2 * bm * FP + bm * (((k0 + 15) & ~15) + 4)) * 4; };
+  auto lds_of = [&](int bm, int k0) { return (size_t)((bm == 16 ? 6 : 2) * bm * FP + 4 * bm * 16 + bm * (((k0 + 15) & ~15) + 4)) * 4; };
   {
     std::lock_guard<std::mutex> lk(mu);
     if (!attr[dev]) {

@@ -1,3 +1,3 @@
-mkdir -p gpurun_out/r06g
-python -m pytest tests -x -q -m gpu > gpurun_out/r06g/gputest.log 2>&1; echo "pytest rc $?" >> gpurun_out/r06g/gputest.log; tail -3 gpurun_out/r06g/gputest.log
-python bench.py --steps 20 --warmup 5 > gpurun_out/r06g/bench.json 2> gpurun_out/r06g/bench.err; echo bench rc $?
+mkdir -p gpurun_out/r06j
+python -m pytest tests -x -q -m gpu > gpurun_out/r06j/gputest.log 2>&1; echo "pytest rc $?" >> gpurun_out/r06j/gputest.log; tail -3 gpurun_out/r06j/gputest.log
+for cfg in "--B 256" "--B 128" "--B 64" "--B 32" "--T 2 --B 256" "--obs 376 --act 17 --Q 25 --B 32 --reps 5" "--obs 376 --act 17 --Q 25 --B 128 --reps 5"; do echo "== $cfg"; python tools/profile_stages.py $cfg 2>&1 | grep -E "fwd3|wall"; done > gpurun_out/r06j/fwd3.txt 2>&1

@@ -40,6 +40,7 @@ def durations(rows, want):
     return acc
 
 
+shapes = []
 for kern in ("k_gather_windows", "k_conv"):
     fetch = per_grid(newest("pmc_fetch", "*_counter_collection.csv"), "FETCH_SIZE", kern)
     write = per_grid(newest("pmc_write", "*_counter_collection.csv"), "WRITE_SIZE", kern)
@@ -53,3 +54,23 @@ for kern in ("k_gather_windows", "k_conv"):
         wr = write[g][0] / write[g][1] * 1024 / 1e6 if g in write else float("nan")
         us = dur[g][0] / dur[g][1] if g in dur else float("nan")
         print(f"{g:10d} {n:8d} {rd:26.2f} {wr:10.2f} {us:9.1f} {(rd + wr) / us * 1e3 if us == us else float('nan'):17.1f}")
+        if kern == "k_gather_windows" and wr == wr:
+            shapes.append((rd, wr, us, g))
+
+# config 4 at B = 1024 (50 x 1024 rows of 399 floats = 81.72 MB each way): the launch shape whose written bytes are closest,
+# for bench.py's sampler_roofline.traffic (quoted only on the csrc revision it was measured on)
+if shapes:
+    import hashlib
+    import json
+    want = 50 * 1024 * 399 * 4 / 1e6
+    rd, wr, us, g = min(shapes, key=lambda t: abs(t[1] - want))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    d = os.path.join(root, "fastdeepqlearning_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    json.dump({"csrc_sha": h.hexdigest()[:16],
+               "config4": {"grid": g, "hbm_read_MB_per_launch": rd, "hbm_write_MB_per_launch": wr, "hbm_bytes_per_launch": (rd + wr) * 1e6,
+                           "kernel_trace_us": us, "algorithmic_MB_each_way": want}},
+              open(os.path.join(out, "sampler_traffic.json"), "w"))
