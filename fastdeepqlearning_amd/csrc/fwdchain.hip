@@ -34,16 +34,22 @@ __device__ __forceinline__ int f3_uni(int v) { return __builtin_amdgcn_readfirst
 
 // VOBS: the observation segment through the 16-byte request ring as well (wide observations whose weight rows are multiples of
 // four floats - config 4: 376 columns = 24 groups; the dword path below is one request round per 16-k group, 0.05 ms of them)
+// RT = 1 runs EIGHT waves per workgroup (32 output columns each, two waves per SIMD): a 16-byte weight request of 16 rows costs
+// its wave ~100 cycles of issue (profiles/r06_fwd3_cycle_stamps.txt), one per four MFMAs at 16 rows - with a second wave on the SIMD
+// that time is the other wave's MFMAs.  RT = 2 gets the same from its two workgroups per CU.
 template <int RT, bool VOBS>
-__global__ __launch_bounds__(256, 2) void k_fwd3(const Fwd3Args a) {
+__global__ __launch_bounds__(RT == 1 ? 512 : 256, RT == 1 ? 1 : 2) void k_fwd3(const Fwd3Args a) {
   constexpr int BM = 16 * RT;
+  constexpr int NW = RT == 1 ? 8 : 4;      // waves per workgroup
+  constexpr int CT = 16 / NW;              // 16-column tiles per wave
+  constexpr int NT = 64 * NW;              // threads
   // 16-k weight groups in flight per wave (16 % DEPTH == 0: a segment's groups keep their ring slots): a group is 16 RT MFMAs
   // = 0.21 RT us of matrix-pipe time against ~1 us of request latency
   constexpr int DEPTH = RT == 1 ? 8 : 4;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = f3_uni(tid >> 6);
   const int j = lane & 15, kq = lane >> 4;
-  const int r0 = blockIdx.x * BM, n0 = wave * 64;
+  const int r0 = blockIdx.x * BM, n0 = wave * (16 * CT);
   const int K0 = a.K0, G0 = (K0 + 15) >> 4, PX = 16 * G0 + 4;   // (VOBS: G0 % DEPTH == 0, checked by the launcher)
   // RT = 1 runs one workgroup per CU (the plan picks 16-row blocks only up to one per CU): every activation keeps an LDS image
   // of its own and goes to memory at the END of the kernel - a store in the middle makes the next use of a requested weight
@@ -53,24 +59,24 @@ __global__ __launch_bounds__(256, 2) void k_fwd3(const Fwd3Args a) {
   constexpr int NIMG = DEFER ? 6 : 2;
   float *const I_eh = lds, *const I_e = lds + BM * FP, *const I_jh = DEFER ? lds + 2 * BM * FP : I_eh, *const I_s = DEFER ? lds + 3 * BM * FP : I_e,
                *const I_ah = DEFER ? lds + 4 * BM * FP : I_eh, *const I_th = DEFER ? lds + 5 * BM * FP : I_eh;
-  float *const HS = lds + NIMG * BM * FP, *const X0 = HS + 4 * BM * 16;   // HS: the narrow head's four partial tiles
+  float *const HS = lds + NIMG * BM * FP, *const X0 = HS + NW * BM * 16;   // HS: the narrow head's partial tiles, one per wave
   const bool has_act = r0 < a.M, has_tgt = r0 >= a.B;   // (uniform: a block never straddles a time step, B % BM == 0)
 
-  v4f ring[DEPTH][4];
-  v4f acc[RT][4];
+  v4f ring[DEPTH][CT];
+  v4f acc[RT][CT];
   // a wide segment's requests: uniform base (W + koff, column tile ct, group g: scalar arithmetic) + the lane's offset
   // (row n0 + j of pitch ldw, column 4 kq): one 32-bit register per pitch instead of a 64-bit pointer per segment
   struct WSeg { const float *W; int ldw, off; };
   auto wseg = [&](const float *W, int ldw, int koff) __attribute__((always_inline)) { return WSeg{W + koff, ldw, (n0 + j) * ldw + 4 * kq}; };
-  auto req = [&](const WSeg &w, int g, v4f (&d)[4]) __attribute__((always_inline)) {
+  auto req = [&](const WSeg &w, int g, v4f (&d)[CT]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) d[ct] = *(gcf4)((gcf)(w.W + (16 * ct * w.ldw + 16 * g)) + w.off);
+    for (int ct = 0; ct < CT; ++ct) d[ct] = *(gcf4)((gcf)(w.W + (16 * ct * w.ldw + 16 * g)) + w.off);
   };
   auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = v4f{0.f, 0.f, 0.f, 0.f};
+      for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = v4f{0.f, 0.f, 0.f, 0.f};
   };
   // one 256-k segment: acc += image x W^T.  On entry the ring holds the segment's groups 0 .. DEPTH - 1; a group's slot is
   // refilled with group g + DEPTH of this segment or group g + DEPTH - 16 of the next one (wn) right behind its MFMAs.
@@ -88,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd3(const Fwd3Args a) {
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+        for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
             acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[rt][s], ring[g % DEPTH][ct][s], acc[rt][ct], 0, 0, 0);
@@ -102,23 +108,23 @@ __global__ __launch_bounds__(256, 2) void k_fwd3(const Fwd3Args a) {
   };
   // the ragged observation segment (K0 columns, zero-padded image X0, any row pitch / alignment of W): dword requests, one
   // 16-k group ahead; wg holds group 0 on entry
-  auto rag_load = [&](gcf W, int ldw, int g, float (&w)[16]) __attribute__((always_inline)) {
+  auto rag_load = [&](gcf W, int ldw, int g, float (&w)[4 * CT]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+    for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int k = 16 * g + 4 * kq + s;
         w[4 * ct + s] = k < K0 ? W[(long long)(n0 + 16 * ct + j) * ldw + k] : 0.f;
       }
   };
-  auto rag_mma = [&](int g, const float (&w)[16]) __attribute__((always_inline)) {
+  auto rag_mma = [&](int g, const float (&w)[4 * CT]) __attribute__((always_inline)) {
     v4f x[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) x[rt] = *reinterpret_cast<const v4f *>(X0 + (16 * rt + j) * PX + 16 * g + 4 * kq);
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
+      for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[rt][s], w[4 * ct + s], acc[rt][ct], 0, 0, 0);
   };
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd3(const Fwd3Args a) {
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-          for (int ct = 0; ct < 4; ++ct)
+          for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[rt][s], ring[q][ct][s], acc[rt][ct], 0, 0, 0);
         if (g + DEPTH < G0) req(w, g + DEPTH, ring[q]);
@@ -146,8 +152,8 @@ __global__ __launch_bounds__(256, 2) void k_fwd3(const Fwd3Args a) {
       }
     }
   };
-  auto ragged = [&](gcf W, int ldw, float (&w0)[16]) __attribute__((always_inline)) {
-    float w1[16];
+  auto ragged = [&](gcf W, int ldw, float (&w0)[4 * CT]) __attribute__((always_inline)) {
+    float w1[4 * CT];
 #pragma unroll 1
     for (int g = 0; g < G0; g += 2) {
       if (g + 1 < G0) rag_load(W, ldw, g + 1, w1);
@@ -161,19 +167,19 @@ __global__ __launch_bounds__(256, 2) void k_fwd3(const Fwd3Args a) {
     }
   };
   // bias (+ LeakyReLU) and the tile into an LDS image: lane (j, kq) holds rows 16 rt + 4 kq + r of column n0 + 16 ct + j
-  float bq[4];   // the layer's bias, requested before its K loop
+  float bq[CT];   // the layer's bias, requested before its K loop
   auto bias_req = [&](const float *bias) __attribute__((always_inline)) {
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) bq[ct] = ((gcf)bias)[n0 + 16 * ct + j];
+    for (int ct = 0; ct < CT; ++ct) bq[ct] = ((gcf)bias)[n0 + 16 * ct + j];
   };
   auto to_image = [&](bool lrelu, float *IM) __attribute__((always_inline)) {
-    float b[4];
+    float b[CT];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) b[ct] = bq[ct];
+    for (int ct = 0; ct < CT; ++ct) b[ct] = bq[ct];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
+      for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = acc[rt][ct][r] + b[ct];
@@ -181,12 +187,12 @@ __global__ __launch_bounds__(256, 2) void k_fwd3(const Fwd3Args a) {
           IM[(16 * rt + 4 * kq + r) * FP + n0 + 16 * ct + j] = v;
         }
   };
-  // a finished image -> memory, whole rows (wave w: rows w, w + 4, ...); rows [lo, hi) of the batch only, stored at row - shift
+  // a finished image -> memory, whole rows (wave w: rows w, w + NW, ...); rows [lo, hi) of the batch only, stored at row - shift
   auto store_image = [&](const float *IM, float *out, int lo, int hi, int shift) __attribute__((always_inline)) {
     if (!out) return;
 #pragma unroll
-    for (int u = 0; u < BM / 4; ++u) {
-      const int row = wave + 4 * u, gr = r0 + row;
+    for (int u = 0; u < BM / NW; ++u) {
+      const int row = wave + NW * u, gr = r0 + row;
       if (gr >= lo && gr < hi) *(gf4)(out + (long long)(gr - shift) * F3_W + lane * 4) = *reinterpret_cast<const v4f *>(IM + row * FP + lane * 4);
     }
   };
@@ -194,24 +200,25 @@ __global__ __launch_bounds__(256, 2) void k_fwd3(const Fwd3Args a) {
   // 128 k's [128 w, 128 w + 128) (waves 0, 1 read S, waves 2, 3 read H), its eight 16-byte requests are issued by narrow_req()
   // before the hidden layer's epilogue, the four partial tiles meet in LDS and are added in wave order.  Wider heads (config 4: 34
   // outputs): wave w owns column tile w over the whole K range (waves past the head's width idle).
-  v4f hw[8];
+  constexpr int KW = 512 / NW, NG = KW / 16;   // the wave's share of the head's 512 k's, in 16-k groups
+  v4f hw[NG];
   auto narrow_req = [&](const Fwd3Mlp &m) __attribute__((always_inline)) {
     if (a.P > 16) return;
-    gcf w = (gcf)m.Wh + (long long)(j < a.P ? j : a.P - 1) * (2 * F3_W) + 128 * wave + 4 * kq;
+    gcf w = (gcf)m.Wh + (long long)(j < a.P ? j : a.P - 1) * (2 * F3_W) + KW * wave + 4 * kq;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) hw[q] = *(gcf4)(w + 16 * q);
+    for (int q = 0; q < NG; ++q) hw[q] = *(gcf4)(w + 16 * q);
   };
   auto narrow = [&](const Fwd3Mlp &m, const float *IS, const float *IH, float *out, int shift) __attribute__((always_inline)) {
     const int P = a.P;
     if (P <= 16) {
-      const float *xp = (wave < 2 ? IS : IH) + j * FP + 128 * (wave & 1) + 4 * kq;
+      const float *xp = (wave < NW / 2 ? IS : IH) + j * FP + KW * (wave & (NW / 2 - 1)) + 4 * kq;
       v4f hs[4][RT];
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) hs[s][rt] = v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int g = 0; g < 8; ++g) {
+      for (int g = 0; g < NG; ++g) {
         v4f x[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) x[rt] = *reinterpret_cast<const v4f *>(xp + 16 * rt * FP + 16 * g);
@@ -228,11 +235,12 @@ __global__ __launch_bounds__(256, 2) void k_fwd3(const Fwd3Args a) {
         for (int r = 0; r < 4; ++r) sc[(16 * rt + 4 * kq + r) * 16 + j] = t[r];
       }
       __syncthreads();
-#pragma unroll
-      for (int u = 0; u < RT; ++u) {
-        const int idx = tid + 256 * u, row = idx >> 4, col = idx & 15;
+      for (int idx = tid; idx < BM * 16; idx += NT) {
+        const int row = idx >> 4, col = idx & 15;
         if (col < P) {
-          const float v = ((HS[idx] + HS[BM * 16 + idx]) + HS[2 * BM * 16 + idx]) + HS[3 * BM * 16 + idx];
+          float v = HS[idx];
+#pragma unroll
+          for (int w8 = 1; w8 < NW; ++w8) v += HS[w8 * BM * 16 + idx];   // (wave order)
           ((gf)out)[(long long)(r0 + row - shift) * P + col] = v + ((gcf)m.bh)[col];
         }
       }
@@ -275,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd3(const Fwd3Args a) {
   };
 
   // ---- requests that depend on nothing: the first observation group(s) of layer 1, the ring for the first wide segment
-  float wg[16];
+  float wg[4 * CT];
   const int ld_eh = K0 + F3_W;
   const WSeg w_eh = wseg(a.enc.Wh, ld_eh, K0), w_j0 = wseg(a.joi.W0, F3_W, 0), w_jh0 = wseg(a.joi.Wh, 2 * F3_W, 0),
              w_jh1 = wseg(a.joi.Wh, 2 * F3_W, F3_W), w_a0 = wseg(a.act.W0, F3_W, 0), w_t0 = wseg(a.act_t.W0, F3_W, 0), w_none = {nullptr, 0, 0};
@@ -288,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd3(const Fwd3Args a) {
   // ---- observation rows -> X0 (zero-padded to 16 G0 columns)
   {
     const int KP = 16 * G0;
-    for (int idx = tid; idx < BM * KP; idx += 256) {
+    for (int idx = tid; idx < BM * KP; idx += NT) {
       const int row = idx / KP, col = idx - row * KP;
       float v = 0.f;
       int c0 = 0;
@@ -399,7 +407,7 @@ hipError_t fwd3_launch(const Fwd3Args &a, hipStream_t s) {
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
   if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-  auto lds_of = [&](int bm, int k0) { return (size_t)((bm == 16 ? 6 : 2) * bm * FP + 4 * bm * 16 + bm * (((k0 + 15) & ~15) + 4)) * 4; };
+  auto lds_of = [&](int bm, int k0) { return (size_t)((bm == 16 ? 6 : 2) * bm * FP + (bm == 16 ? 8 : 4) * bm * 16 + bm * (((k0 + 15) & ~15) + 4)) * 4; };
   {
     std::lock_guard<std::mutex> lk(mu);
     if (!attr[dev]) {
@@ -411,7 +419,7 @@ hipError_t fwd3_launch(const Fwd3Args &a, hipStream_t s) {
       attr[dev] = true;
     }
   }
-  const dim3 grid(a.N / a.bm), block(256);
+  const dim3 grid(a.N / a.bm), block(a.bm == 16 ? 512 : 256);
   const int depth = a.bm == 16 ? 8 : 4, g0 = (a.K0 + 15) / 16;
   const bool vobs = a.K0 >= 128 && a.K0 % 4 == 0 && g0 % depth == 0;   // (row pitches K0 and K0 + 256 are then multiples of four floats)
   if (a.bm == 16) {
