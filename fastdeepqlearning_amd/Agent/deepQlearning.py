@@ -96,6 +96,17 @@ class DeepQLearning:
         self._trainer = None
         self._stop_training = False
         self.trainer_error = None
+        # How a step's launch list is issued (fdql_agent_set_launch_mode): conf.launch_mode = "eager" (default) | "graph" | "auto".
+        # "auto": plans of at most 6 272 gradient rows (temporal_len 2, one rank's share of a data-parallel batch: 17-23 dependent
+        # launches of 5-40 us) are timed both ways on this host once 20 steps have run - 2 x 2 x 39 ORDINARY training steps inside
+        # that train_step() call, which is why it is opt-in - and the faster way is kept; larger plans are kernel-bound and stay
+        # eager.  The bucketed data-parallel step is always eager.  bench.py calibrates every launch-bound workload the same way.
+        self.launch_mode_choice = None
+        mode = self.conf.get("launch_mode", "eager")
+        rows = (int(conf.temporal_len) - 1) * int(conf.batch_size)
+        self._calibrate_at = 20 if (mode == "auto" and rows <= 6272 and not self._distributed()) else None
+        if mode == "graph":
+            self.native.set_launch_mode(True)
         if kwargs.get("train_process", False):   # reference signature: run the trainer loop in place
             self._initialize_trainer_members(kwargs["replays"])
             self._infinite_loop_for_async_training_process()
@@ -208,6 +219,9 @@ class DeepQLearning:
         noise: optional (noise_target, noise_actor) device tensors replayed by the policy kernels instead of the
         device's Philox draws (parity runs; the reference draws from torch's global generator)."""
         nt, na = noise if noise is not None else (None, None)
+        if self._calibrate_at is not None and noise is None and self.iteration >= self._calibrate_at:
+            self._calibrate_at = None       # (the calibration's own steps come back through here)
+            self.launch_mode_choice = self.native.calibrate_launch_mode(self.train_step)
         for replay in self.replays:
             xp = replay.temporal_sample()
             self._last_xp = xp

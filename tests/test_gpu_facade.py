@@ -893,3 +893,36 @@ def test_in_place_batches_follow_a_restored_ring(dev):
     assert torch.equal(frames, (xp1["action"].view(T, B) + 100) % 256), "frames do not belong to the sampled records"
     # no float32 buffer exists for the key read in place
     assert all(entry[b._keys.index("obs_2d")] is None for entry in b._pool)
+
+
+def test_launch_mode_auto_calibrates_and_keeps_training(dev):
+    """conf.launch_mode = "auto" (round 6): a launch-bound plan (temporal_len 2) is timed eagerly and as a hipGraph replay after
+    20 steps - ordinary training steps, counted like any other - and the faster way stays; the weights keep moving and the
+    loss stays finite whichever was chosen (replay is bit-identical to the eager list: test_graph_replay_matches_eager_launches)."""
+    from fastdeepqlearning_amd import Agent, Replay
+    conf = _conf(dev, T=2, B=64)
+    conf.num_instances = 1
+    conf.launch_mode = "auto"
+    read_heads, write_heads = Replay.make(conf)
+    rng = np.random.RandomState(0)
+    for i in range(400):
+        write_heads[0].add({"obs_1d": rng.standard_normal(5).astype(np.float32),
+                            "action": rng.uniform(-1, 1, 3).astype(np.float32), "reward": float(rng.standard_normal()),
+                            "task_done": False, "episode_done": i % 50 == 49, "episode_step": i % 50, "idx": 0})
+    agent = Agent.make(conf)
+    agent.enable_training(read_heads)
+    for _ in range(19):
+        agent.train_step()
+    assert agent.launch_mode_choice is None and agent.iteration == 19
+    w0 = agent.state_dict()["actor_critic.actor.head.weight"].clone()
+    agent.train_step()          # step 20 -> still plain
+    agent.train_step()          # iteration 20 reached: calibrates (2 rounds x 2 modes x (9 + 30) steps), then steps once more
+    ch = agent.launch_mode_choice
+    assert ch is not None and ch["chosen"] in ("eager", "graph") and agent.native.launch_mode == ch["chosen"]
+    assert agent.iteration == 21 + 2 * 2 * 39
+    for _ in range(5):
+        agent.train_step()
+    sc = agent.native.scalars()
+    assert np.isfinite(sc["loss"]) and not torch.equal(w0, agent.state_dict()["actor_critic.actor.head.weight"])
+    if ch["chosen"] == "graph":
+        assert agent.native.stats()["graph_launches"] > 0
