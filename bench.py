@@ -273,7 +273,7 @@ def dominant(prof):
     the row-block chain kernel): name, ms/step, flops/step, launches/step, and the all-MFMA-kernel totals."""
     groups = {}
     for k, v in prof.items():
-        if k.startswith(("gemm", "chain", "rows", "rowd", "wstat", "wgstat", "conv:")):
+        if k.startswith(("gemm", "chain", "fwd3", "rows", "rowd", "wstat", "wgstat", "conv:")):
             groups.setdefault(k.split(":")[0], []).append(v)
     name, rows = max(groups.items(), key=lambda kv: sum(r[0] for r in kv[1]))
     ms, fl, n = sum(r[0] for r in rows), sum(r[1] * r[3] for r in rows), sum(r[3] for r in rows)
@@ -288,6 +288,8 @@ def kernel_label(name):
         return "k_conv_* (implicit-GEMM convolution, image groups resident in LDS, fp32 v_mfma_f32_16x16x4_f32)"
     if name.startswith("chain"):
         return "k_chain (row-block MLP chain, fp32 v_mfma_f32_32x32x2_f32)"
+    if name.startswith("fwd3"):
+        return "k_fwd3 (small-block forward chain: encoder -> joiner -> actors on 16- / 32-row blocks, fp32 v_mfma_f32_16x16x4_f32)"
     if name.startswith("wstat"):
         return rocprof_tag(name) + "> (weight-stationary persistent row-block GEMM, " + ("dgrad" if name.startswith("wstatg") else "forward") + \
                " form, fp32 v_mfma_f32_32x32x2_f32)"
@@ -310,6 +312,8 @@ def rocprof_tag(name):
         return "k_conv_"
     if name.startswith("chain"):
         return "k_chain"
+    if name.startswith("fwd3"):
+        return "k_fwd3"
     if name.startswith("wgstat"):
         return "k_wgrad_stat"
     if name.startswith("rowdot<"):

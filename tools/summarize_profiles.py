@@ -27,7 +27,7 @@ def per_kernel(rows, counter):
     return acc
 
 
-DENSE = ("k_gemm", "k_chain", "k_rowdgrad", "k_wstat", "k_wgrad_stat", "k_conv")   # the MFMA kernels
+DENSE = ("k_gemm", "k_chain", "k_fwd3", "k_rowdgrad", "k_wstat", "k_wgrad_stat", "k_conv")   # the MFMA kernels
 fetch = per_kernel(counter_rows("pmc_fetch"), "FETCH_SIZE")
 write = per_kernel(counter_rows("pmc_write"), "WRITE_SIZE")
 WORKLOAD = sys.argv[2] if len(sys.argv) > 2 else "tools/profile_stages.py (config 2, T=50, B=256)"
