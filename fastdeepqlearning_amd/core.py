@@ -25,6 +25,24 @@ def _device_view_u8(ptr, nbytes, device, owner):
     return t
 
 
+class _NoGuard:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def _on_device(device):
+    """`with torch.cuda.device(device)` only when another device is current: the guard costs the per-step host path ~10 us,
+    a launch-bound step (17-23 kernels of 5-40 us) has 100-120 us of host time per step to spend."""
+    idx = device.index if device.index is not None else 0
+    return _NO_GUARD if torch.cuda.current_device() == idx else torch.cuda.device(device)
+
+
 class NativeRing:
     """SoA replay ring in HBM (include/fdql.h `fdql_ring_*`;
     reference franQ/Replay/replay_memory.py:18-73)."""
@@ -43,6 +61,7 @@ class NativeRing:
         with torch.cuda.device(self.device):
             N.check(self.lib.fdql_ring_create_typed(C.byref(self.handle), self.maxlen, len(self.dims), arr, types))
         self.row_floats = sum(self.dims)
+        self._arr_cache = {}
 
     def __del__(self):
         h, self.handle = getattr(self, "handle", None), None
@@ -126,14 +145,19 @@ class NativeRing:
             return self._sample_windows_sel(T, B, starts, seed, counter, select, return_starts, outs, starts_out)
         if outs is None:
             outs, arr = self._outs((T, B))
-        else:
-            arr = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
+        else:   # persistent output sets (a trainer's rotating pool): the pointer array of a set is built once
+            key = tuple(o.data_ptr() for o in outs)
+            arr = self._arr_cache.get(key)
+            if arr is None:
+                if len(self._arr_cache) >= 16:
+                    self._arr_cache.clear()
+                arr = self._arr_cache[key] = (C.c_void_p * len(outs))(*key)
         sp = None
         if starts is not None:
             starts = torch.as_tensor(starts, dtype=torch.int64, device=self.device).contiguous()
             sp = C.c_void_p(starts.data_ptr())
         so = starts_out if starts_out is not None else (torch.empty(B, dtype=torch.int64, device=self.device) if return_starts else None)
-        with torch.cuda.device(self.device):
+        with _on_device(self.device):
             N.check(self.lib.fdql_ring_sample_windows(self.handle, T, B, sp, seed, counter, arr,
                                                       C.c_void_p(so.data_ptr()) if so is not None else None,
                                                       N.current_stream(self.device)))
@@ -254,6 +278,7 @@ def make_config(obs_dim, act_dim, T, B, goal_dim=0, discrete=False, n_critics=2,
 
 BATCH_KEYS = ("obs_1d", "achieved_goal", "desired_goal", "action", "reward", "mc_return", "task_done", "episode_step",
               "obs_2d", "agent_state")
+_BATCH_CACHE_KEYS = BATCH_KEYS + ("obs_2d_slots",)
 
 
 class NativeAgent:
@@ -299,6 +324,7 @@ class NativeAgent:
                 self.v_views[key] = self.adam_v[off.value: off.value + cnt].view(shp)
         self.trainable = list(self.grad_views.keys())
         self._keep = None
+        self._batch_cache = {}
 
     def __del__(self):
         h, self.handle = getattr(self, "handle", None), None
@@ -340,12 +366,25 @@ class NativeAgent:
 
     def update(self, xp, noise_target=None, noise_actor=None, seed=0, phase=N.PHASE_ALL):
         """One train_step (deepQlearning.py:105-127) on the current torch stream; asynchronous."""
-        b, keep = self._batch(xp) if xp is not None else (N.Batch(), [])
+        if xp is None:
+            b, keep = N.Batch(), []
+        else:
+            # the fdql_batch_t of a recurring batch (a rotating pool of sample buffers) is built once: keyed by the device
+            # pointers themselves, so a dead tensor's recycled id can never alias a cached entry
+            vals = [xp.get(k) for k in _BATCH_CACHE_KEYS]
+            key = tuple(0 if t is None else (t.data_ptr(), t.dtype) for t in vals)
+            b, keep = self._batch_cache.get(key), vals
+            if b is None:
+                b, keep = self._batch(xp)      # (checks device / dtype; copies a non-contiguous tensor - such a batch is not cached)
+                if all(t is None or t.is_contiguous() for t in vals):
+                    if len(self._batch_cache) >= 16:
+                        self._batch_cache.clear()
+                    self._batch_cache[key], keep = b, vals
         for t in (noise_target, noise_actor):
             if t is not None:
                 keep.append(t)
         self._keep = keep  # keep the tensors alive until the next call
-        with torch.cuda.device(self.device):
+        with _on_device(self.device):
             N.check(self.lib.fdql_agent_update(self.handle, C.byref(b), N.ptr(noise_target), N.ptr(noise_actor), seed,
                                                phase, N.current_stream(self.device)))
 
