@@ -222,7 +222,9 @@ int fdql_agent_create(fdql_agent_t **out, const fdql_agent_config_t *cfg) {
     a->force_buckets = w.force_buckets;   // test hook: the two-bucket plan at world_size 1
     if (w.plan_cache >= 0) a->plan_cache_max = (size_t)w.plan_cache;
     a->rows_min_tiles = w.rows_min_tiles;
-    if (w.rows_all) { a->wgrad_stat_factor = 1; a->rowdgrad_min_blocks = 1; }   // "all": every persistent kernel whatever the size (tests)
+    if (w.rows_all) { a->wgrad_stat_min_tiles = 1; a->rowdgrad_min_blocks = 1; }   // "all": every persistent kernel whatever the size (tests)
+    else if (w.rows_min_tiles >= (1LL << 40)) a->wgrad_stat_min_tiles = 1LL << 60;                                                  // FDQL_ROWGEMM=0: tile kernels only
+    else if (w.rows_min_tiles != PlanSwitches().rows_min_tiles) a->wgrad_stat_min_tiles = 6 * w.rows_min_tiles;                       // FDQL_ROWGEMM=n
     if (!w.small_gemm) a->small_max_tiles = 0;
   }
   a->T = c.T; a->B = c.B; a->N = c.T * c.B; a->M = (c.T - 1) * c.B; a->A = c.act_dim; a->L = c.latent;

@@ -239,19 +239,22 @@ struct fdql_agent {
   std::vector<CachedPlan> plan_cache;   // most recently stashed last; a hit moves a plan out (it becomes current): the front is the least recently used
   size_t plan_cache_max = PLAN_CACHE_DEFAULT;
   long long plans_built = 0;
-  long long rows_min_tiles = 256;   // FDQL_ROWGEMM: "0" never, "all" always, a number = the threshold; default: groups with at least one
-                                    // 64-row tile per CU (a weight-stationary workgroup with 2 + 2 32-row tiles still beats the tile
-                                    // kernels: config 4 at 128 windows per GPU)
+  long long rows_min_tiles = 224;   // FDQL_ROWGEMM: "0" never, "all" always, a number = the threshold; default: groups of about one 64-row
+                                    // tile per CU (a weight-stationary workgroup with 2 + 2 32-row tiles still beats the tile kernels:
+                                    // config 4 at 128 windows per GPU; round 6: 256 -> 224 - config 2 at 32 windows, 10
+                                    // layer-0 problems x 24 tiles = 240: critics.fwd0 0.0447 -> 0.0373 ms, critics.dpre0 0.0392 -> 0.0323,
+                                    // step 0.346 -> 0.329 ms)
   int rowdgrad_min_blocks = 128;    // 64-row blocks a single-network dgrad needs for the row-block dgrad kernel (FDQL_ROWDGRAD_MIN_BLOCKS)
   int rowdot_min_rows = 2048;       // rows from which a stage of narrow-output dgrads runs on k_rowdot (config 2: 3136 rows 18.4 against 23.4 us on 128x32 tiles; 1568 rows 18.2 against 16.4 on the small-batch kernel)
   int rowdgrad_max_blocks = 256;    // ... and may have: one round of workgroups (config 4 at B = 1024, 784 blocks = 3.06 rounds: the tile
                                     // kernel's 3136 tiles are the better fit there: 0.138 against 0.153 ms for d enc)
-  int wgrad_stat_factor = 6;        // x rows_min_tiles 32-row tiles for the output-stationary weight-gradient launch (1 with FDQL_ROWGEMM=all):
-                                    //   1536 = 8 tiles for each of 192 workgroups.  A workgroup writes a 256 KB partial whatever its rows -
-                                    //   config 2 at 64 windows (1470 tiles: 120 workgroups of 12) 0.541 ms with the launch, 0.502 with the
-                                    //   gradients riding in the dgrad launches; at 128 windows (2940 tiles) 0.722 against 0.753; the 5-block
-                                    //   launch of the two-bucket plan at 256 windows (1960 tiles) 1.241 against 1.257
-  bool wgrad_stat_pays(long long nblk) const { return nblk * (M / 32) >= wgrad_stat_factor * rows_min_tiles; }
+  long long wgrad_stat_min_tiles = 1536;   // 32-row tiles (blocks x M / 32) from which the dense weight gradients run as one output-stationary
+                                    //   launch (1 with FDQL_ROWGEMM=all, 6 x n with FDQL_ROWGEMM=n): 1536 = 8 tiles for each of 192 workgroups.
+                                    //   A workgroup writes a 256 KB partial whatever its rows - config 2 at 64 windows (1470 tiles: 120
+                                    //   workgroups of 12) 0.541 ms with the launch, 0.502 with the gradients riding in the dgrad launches; at
+                                    //   128 windows (2940 tiles) 0.722 against 0.753; the 5-block launch of the two-bucket plan at 256
+                                    //   windows (1960 tiles) 1.241 against 1.257
+  bool wgrad_stat_pays(long long nblk) const { return nblk * (M / 32) >= wgrad_stat_min_tiles; }
   int small_max_tiles = 128;        // a GEMM stage of at most this many 64x64 tiles runs on the small-batch kernel (smallgemm.hip); 0: never
   // d state = sum over the online critics and the actor: one problem accumulating every network's K-segments, or - few rows
   // (a handful of workgroups would walk all segments serially), or many rows with critics the weight-stationary kernel

@@ -41,7 +41,7 @@ inline int cu_budget(int ncu) { return ncu; }
 struct PlanSwitches {
   int chain = 1;                  // FDQL_CHAIN: 0 never / 1 encoder -> joiner -> actors as one k_chain launch when the batch fills the chip /
                                   //   2 ("enc") that chain whatever the size / 3 ("all") the critics as chain programs too
-  long long rows_min_tiles = 256; // FDQL_ROWGEMM: "0" no row-block / stationary launches (1 << 60), "all" every eligible group whatever its
+  long long rows_min_tiles = 224; // FDQL_ROWGEMM: "0" no row-block / stationary launches (1 << 60), "all" every eligible group whatever its
   bool rows_all = false;          //   size (1; also drops the size thresholds of k_wgrad_stat and k_rowdgrad), a number = the threshold
   bool rowdgrad = true;           // FDQL_ROWDGRAD=0: single-network dgrads on the tile kernel
   bool rowdgrad_chain = true;     // FDQL_NO_ROWDGRAD_CHAIN: the three dgrads behind d state as launches of their own
