@@ -972,7 +972,7 @@ int build_plan(fdql_agent *a) {
         }
       }
       RowsLaunch rl;
-      if (M % ROWS_BM == 0 && rows_launch_of(a, cand, rl)) {
+      if (M % WS_BM == 0 && rows_launch_of(a, cand, rl)) {   // (32-row tiles: 1 568 rows - config 2 at 32 windows - are 49 of them)
         Stage &gs = b.gemm_stage("critics.dpre1+0");
         gs.try_rows = true;
         gs.gm_role = 2;
