@@ -437,7 +437,7 @@ def test_update_matches_oracle_config2(dev, T, B, hid):
     ag.load_tensors(params)
     rep = Report(f"oracle:config2 T={T} B={B}")
     g = torch.Generator().manual_seed(1)
-    for step in range(2):
+    for step in range(2 if T * B < 10000 else 1):   # (full size: one step - the second costs 8 s of CPU oracle and exercises the same launches)
         xp = {"obs_1d": torch.randn(T, B, 17, generator=g), "action": torch.rand(T, B, 6, generator=g) * 2 - 1,
               "reward": torch.randn(T, B, 1, generator=g), "mc_return": torch.randn(T, B, 1, generator=g) * 2,
               "task_done": (torch.rand(T, B, 1, generator=g) < 0.05).float(),
