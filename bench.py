@@ -255,7 +255,11 @@ class Job:
         def one():
             self.step(self._ci)
             self._ci += 1
-        return self.agent.calibrate_launch_mode(one, steps=steps)
+        try:
+            return self.agent.calibrate_launch_mode(one, steps=steps)
+        except Exception as e:   # noqa: BLE001 - a failed capture must never take a figure of the line down: eager launches always work
+            self.agent.set_launch_mode(False)
+            return {"chosen": "eager", "calibration": None, "error": f"{type(e).__name__}: {e}"[:200]}
 
     def kernel_profile(self, reps=3):
         """name -> (ms, flops, bytes, launches) per step, HIP events on the launch stream."""
@@ -931,7 +935,10 @@ def bench_single(args, dev, T):
     sampler = sampler_roofline(job)
     extras, t2, facade = None, None, None
     if not args.no_extras:
-        t2 = temporal_len_2(w, dev, B)
+        try:
+            t2 = temporal_len_2(w, dev, B)
+        except Exception as e:   # noqa: BLE001 - a secondary figure must never take the headline line down
+            t2 = {"error": f"{type(e).__name__}: {e}"[:300]}
         facade = facade_path(dev)
         extras = {}
         for name, fn in (("config1_pendulum", lambda: config1_pendulum(dev)),
