@@ -1356,3 +1356,39 @@ def test_wgrad_stat_riders(dev, M, nprob, nx2, x2_every, ng2, nslab):
         assert bool((head == untouched).all())
     assert bool((tot[n_dense + n_head:] == untouched).all())
     # (a slab the kernel left alone inside a block or a rider would put 7.0 into the sums checked above)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw,want,absent", [
+    (dict(obs=17, act=6, T=50, B=32), ["fwd3<16>:", "rowdchain:", "wstat<1,1,2>:critics.fwd0", "wstatg<1,0,1>:critics.dpre1+0"], ["chain:", "k:dstate.sum"]),
+    (dict(obs=17, act=6, T=50, B=64), ["fwd3<16>:", "rowdchain:"], ["chain:", "k:dstate.sum"]),
+    (dict(obs=17, act=6, T=50, B=128), ["fwd3<32>:", "rowdchain:", "wgstat:"], ["chain:", "k:dstate.sum"]),
+    (dict(obs=17, act=6, T=50, B=256), ["fwd3<32>:", "rowdchain:", "wgstat:"], ["chain:"]),
+    (dict(obs=17, act=6, T=2, B=256), ["fwd3<16>:", "k:dstate.sum"], ["rowdchain:", "gemmsmall:enc_obs.fwd0"]),
+    (dict(obs=17, act=6, T=50, B=384), ["chain:enc_joiner_actors", "rowdchain:"], ["fwd3"]),
+    (dict(obs=376, act=17, Q=25, T=50, B=32), ["fwd3<16>:", "rowdchain:"], ["chain:"]),
+    (dict(obs=28, goal=10, act=6, T=50, B=128), ["fwd3<32>:", "rowdchain:"], ["chain:"]),
+])
+def test_default_plans_run_the_small_block_kernels(dev, kw, want, absent):
+    """Which kernels a default plan launches is a measured decision; a rule edited by accident would not fail
+    any parity test - the launches it falls back to are parity-green too - it would only be slower.  The launch names of
+    fdql_agent_profile_update pin the round-6 choices: k_fwd3 on 16- / 32-row blocks up to one dispatch round, the dgrad chain on
+    small blocks from 1 024 rows, the critics' layer 0 weight-stationary from 224 tiles."""
+    from fastdeepqlearning_amd.core import NativeAgent, make_config
+    kw = dict(kw)
+    T, B, obs, act, goal, Q = kw["T"], kw["B"], kw["obs"], kw["act"], kw.get("goal", 0), kw.get("Q", 2)
+    ag = NativeAgent(make_config(obs, act, T, B, goal_dim=goal, n_critics=5, n_quantiles=Q), dev)
+    ag.init_weights(0)
+    g = torch.Generator(device=dev).manual_seed(0)
+    xp = {"obs_1d": torch.randn(T, B, obs, device=dev, generator=g), "action": torch.rand(T, B, act, device=dev, generator=g) * 2 - 1,
+          "reward": torch.randn(T, B, 1, device=dev, generator=g), "mc_return": torch.randn(T, B, 1, device=dev, generator=g),
+          "task_done": torch.zeros(T, B, 1, device=dev), "episode_step": torch.arange(T, device=dev, dtype=torch.float32).view(T, 1, 1).expand(T, B, 1).contiguous()}
+    if goal:
+        xp["achieved_goal"] = torch.randn(T, B, goal, device=dev, generator=g)
+        xp["desired_goal"] = torch.randn(T, B, goal, device=dev, generator=g)
+    names = [r[0] for r in ag.profile_update(xp, seed=1)]
+    for w in want:
+        assert any(n.startswith(w) for n in names), (w, names)
+    for w in absent:
+        assert not any(n.startswith(w) for n in names), (w, names)
+    assert np.isfinite(ag.scalars()["loss"])
